@@ -1,0 +1,93 @@
+// Shared declarations for the icsg3d_amd HIP library (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+namespace ics {
+
+// ---------------------------------------------------------------- error plumbing
+void set_error(const std::string& msg);
+#define ICS_HIP(expr)                                                                     \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess) {                                                               \
+      ::ics::set_error(std::string(#expr) + " -> " + hipGetErrorString(_e) + " @" +       \
+                       __FILE__ + ":" + std::to_string(__LINE__));                        \
+      return -1;                                                                          \
+    }                                                                                     \
+  } while (0)
+#define ICS_CHECK(cond, msg)                                                              \
+  do {                                                                                    \
+    if (!(cond)) {                                                                        \
+      ::ics::set_error(std::string(msg) + " (" #cond ") @" + __FILE__ + ":" +             \
+                       std::to_string(__LINE__));                                         \
+      return -1;                                                                          \
+    }                                                                                     \
+  } while (0)
+#define ICS_TRY(expr)                                                                     \
+  do {                                                                                    \
+    if ((expr) != 0) return -1;                                                           \
+  } while (0)
+
+// ---------------------------------------------------------------- activations
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2 };
+constexpr float kLeaky = 0.3f;     // keras LeakyReLU default alpha (vae/lattice_vae.py:175)
+constexpr float kBnEps = 1e-3f;    // keras BatchNormalization default epsilon
+constexpr float kKEps = 1e-7f;     // keras.backend.epsilon()
+constexpr float kPoolTieTol = 1e-5f;
+
+__device__ __forceinline__ float act_fwd(float v, int act) {
+  if (act == ACT_RELU) return fmaxf(v, 0.f);
+  if (act == ACT_LRELU) return v > 0.f ? v : kLeaky * v;
+  return v;
+}
+// derivative given the activation OUTPUT (or input: same sign for these monotone acts)
+__device__ __forceinline__ float act_grad(float v, int act) {
+  if (act == ACT_RELU) return v > 0.f ? 1.f : 0.f;
+  if (act == ACT_LRELU) return v > 0.f ? 1.f : kLeaky;
+  return 1.f;
+}
+
+// ---------------------------------------------------------------- A-operand sources of a conv
+// One input source of a convolution's (virtual) input tensor.  The virtual input is the channel
+// concatenation of up to two sources, each optionally (a) BatchNorm-applied on the fly
+// (v*scale[c]+shift[c], then `act`), (b) nearest-upsampled by 2, (c) a per-sample broadcast vector
+// (the K.tile'd condition of vae/lattice_vae.py:167-169).  Zero "same" padding applies AFTER that.
+struct ConvSrc {
+  const float* p;       // NDHWC tensor at the source's own resolution (or [B][bc_n] if bcast)
+  const float* scale;   // per-channel affine or nullptr
+  const float* shift;
+  int C;                // channels this source contributes
+  int up;               // 1: source is at S/2 and is nearest-upsampled
+  int act;              // activation after the affine
+  int bcast;            // >0: broadcast mode, value = p[b*bcast + (c % bcast)]
+};
+
+struct ConvGeom {
+  int B, S, lgS;        // batch, cubic spatial extent (power of two) and its log2
+  int Cin, Cout;        // logical channel counts of this GEMM (Cin = sum of source C)
+  int taps;             // 27 (3x3x3 same) or 1 (1x1x1)
+  int Kpad, Npad;       // padded GEMM K (= taps*Cin rounded up to 32) and N (Cout rounded up to 32)
+};
+
+// ---------------------------------------------------------------- kernel launchers (conv_igemm.hip)
+// out[m*ldo + n] = pre_act( sum_k A[m][k] * W[k][n] + bias[n] ),  m over B*S^3 voxels.
+// stat_partial: optional [gridM][3][Npad] (count, mean, M2) of the stored values per block column.
+int launch_conv_fwd(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int nsrc,
+                    const float* wpacked, const float* bias, float* out, int ldo, int pre_act,
+                    float* stat_partial, int* stat_rows_per_block);
+// partial[split][k][n] = sum_{m in split} A[m][k] * dy[m*ldy + n];  then reduced into dw[k*ldw+n].
+int launch_conv_wgrad(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int nsrc,
+                      const float* dy, int ldy, float* dw, int ldw, float* workspace,
+                      size_t workspace_floats);
+size_t conv_wgrad_workspace_floats(const ConvGeom& g, const ConvSrc* src, int nsrc);
+int conv_fwd_rows_per_block(const ConvGeom& g);
+// weight packing: Keras [taps][Cin][Cout] -> [Kpad/4][Npad][4]
+int launch_pack_fwd(hipStream_t st, const float* w, int K, int N, float* dst, int Kpad, int Npad,
+                    int k_off, int n_off, int zero_first);
+int launch_pack_bwd(hipStream_t st, const float* w, int taps, int Cin, int Cout, float* dst,
+                    int Kpad, int Npad, int cout_total, int co_off, int zero_first);
+
+}  // namespace ics

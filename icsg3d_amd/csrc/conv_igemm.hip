@@ -1,0 +1,725 @@
+// Conv3D forward / backward-data / backward-weight as implicit GEMMs on the exact-fp32 MFMA
+// (v_mfma_f32_32x32x2_f32: bit-identical to an fmaf chain, issued at the fp32 vector peak; see
+// /opt/skills/guides/cdna_hip_programming.md §3).  Replaces keras.layers.Conv3D as used at
+// /root/reference/unet/unet.py:276-352 and /root/reference/vae/lattice_vae.py:173,178,213,219.
+//
+// GEMM view (NDHWC):  out[m][n] = sum_k A[m][k] * W[k][n],  m = voxel (b,z,y,x), k = (tap,ci), n = co.
+// A is never materialised: the tile loader gathers the tap-shifted voxel rows, applies the
+// producer's BatchNorm affine + activation, nearest-upsampling and channel concat on the fly, and
+// writes zeros for the "same" padding.  Tiles are register-staged (global -> VGPR -> LDS) with two
+// LDS buffers; fragments are read with ds_read_b128 using a fixed k-permutation inside each 8-deep
+// k group (lane half h supplies k = 4h..4h+3), which only reorders the fp32 summation.
+#include "common.h"
+
+namespace ics {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));   // first-class vector: stays in VGPRs
+
+constexpr int kLDA = 36;   // A-tile row stride in floats: 32 + 4 pad -> conflict-free ds_read_b128
+
+__device__ __forceinline__ int xcd_swizzle(int bid, int nblk) {
+  // blocks are dispatched round-robin over the 8 XCDs; give each XCD a contiguous range of tiles
+  // so neighbouring M-tiles (shared halo) and the N-tiles of one M-tile hit the same L2.
+  const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+struct RowPos {
+  int b, z, y, x;
+};
+__device__ __forceinline__ RowPos decode_row(int m, int S, int lg) {
+  RowPos r;
+  r.x = m & (S - 1);
+  r.y = (m >> lg) & (S - 1);
+  r.z = (m >> (2 * lg)) & (S - 1);
+  r.b = m >> (3 * lg);
+  return r;
+}
+
+// element offset of voxel (b,z,y,x) (already shifted, in bounds) inside source s
+__device__ __forceinline__ size_t src_voxel(const ConvSrc& s, int b, int z, int y, int x, int S) {
+  if (s.up) {
+    const int Sh = S >> 1;
+    return ((((size_t)b * Sh + (z >> 1)) * Sh + (y >> 1)) * Sh + (x >> 1)) * (size_t)s.C;
+  }
+  return ((((size_t)b * S + z) * S + y) * S + x) * (size_t)s.C;
+}
+
+__device__ __forceinline__ float4 affine_act4(float4 v, float4 sc, float4 sh, int act) {
+  v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
+  v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+  v.x = act_fwd(v.x, act); v.y = act_fwd(v.y, act); v.z = act_fwd(v.z, act); v.w = act_fwd(v.w, act);
+  return v;
+}
+
+// field-wise select (a reference to `cond ? s0 : s1` would force both kernel-arg structs to scratch)
+__device__ __forceinline__ ConvSrc pick_src(const ConvSrc& s0, const ConvSrc& s1, bool first) {
+  ConvSrc s;
+  s.p = first ? s0.p : s1.p;
+  s.scale = first ? s0.scale : s1.scale;
+  s.shift = first ? s0.shift : s1.shift;
+  s.C = first ? s0.C : s1.C;
+  s.up = first ? s0.up : s1.up;
+  s.act = first ? s0.act : s1.act;
+  s.bcast = first ? s0.bcast : s1.bcast;
+  return s;
+}
+
+// scalar gather of one element of the virtual input (used by the thin-channel paths)
+__device__ __forceinline__ float gather_scalar(const ConvSrc& s0, const ConvSrc& s1, int ci, int b,
+                                               int z, int y, int x, int S) {
+  const bool first = ci < s0.C;
+  const ConvSrc s = pick_src(s0, s1, first);
+  const int cl = first ? ci : ci - s0.C;
+  float v;
+  if (s.bcast > 0) {
+    v = s.p[(size_t)b * s.bcast + (cl % s.bcast)];
+  } else {
+    v = s.p[src_voxel(s, b, z, y, x, S) + cl];
+  }
+  if (s.scale) v = act_fwd(fmaf(v, s.scale[cl], s.shift[cl]), s.act);
+  return v;
+}
+
+// =====================================================================================
+// Forward / backward-data kernel
+// =====================================================================================
+template <int WM, int WN, int TM, int TN, bool VEC>
+__global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, ConvSrc s1,
+                                                        const float* __restrict__ wp,
+                                                        const float* __restrict__ bias,
+                                                        float* __restrict__ out, int ldo, int pre_act,
+                                                        float* __restrict__ stat_partial, int gridM,
+                                                        int gridN) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr int A_FLOATS = BM * kLDA, B_FLOATS = 32 * BN;
+  constexpr int RA = BM / 32;    // VEC: float4 A loads per thread per chunk
+  constexpr int RS = BM / 8;     // SCALAR: scalar A loads per thread per chunk
+  constexpr int NB = BN / 32;    // float4 B loads per thread per chunk
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                      // [2][BM][36]
+  float* Bs = smem + 2 * A_FLOATS;       // [2][8][BN][4]
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int sw = xcd_swizzle(blockIdx.x, gridM * gridN);
+  const int mb = sw / gridN, nb = sw % gridN;
+  const int S = g.S, lg = g.lgS;
+  const int M = g.B << (3 * lg);
+  const int n0 = nb * BN;
+  const int nchunks = g.Kpad >> 5;
+  const int cpt = VEC ? (g.Cin >> 5) : 1;   // 32-channel chunks per tap (VEC only)
+
+  // ---- per-thread row bookkeeping
+  const int mrow_base = mb * BM + (VEC ? (t >> 3) : (t >> 5));   // + 32*r (VEC) / 8*r (SCALAR)
+
+  v4f ra4[RA];
+  float ras[RS];
+  v4f rb[NB];
+
+  auto load_chunk = [&](int c) {
+    // ---- B tile: packed weights [Kpad/4][Npad][4]
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+      const int idx = t + 256 * r;
+      const int kq = idx / BN, n = idx % BN;
+      rb[r] = *reinterpret_cast<const v4f*>(wp + ((size_t)(c * 8 + kq) * g.Npad + n0 + n) * 4);
+    }
+    // ---- A tile
+    if (VEC) {
+      const int tap = c / cpt, ci0 = (c - tap * cpt) << 5;
+      int dz = 0, dy = 0, dx = 0;
+      if (g.taps == 27) { dz = tap / 9 - 1; dy = (tap / 3) % 3 - 1; dx = tap % 3 - 1; }
+      const bool first = ci0 < s0.C;
+      const ConvSrc s = pick_src(s0, s1, first);
+      const int cl = (first ? ci0 : ci0 - s0.C) + (t & 7) * 4;
+      float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool aff = s.scale != nullptr;
+      if (aff) {
+        sc = *reinterpret_cast<const float4*>(s.scale + cl);
+        sh = *reinterpret_cast<const float4*>(s.shift + cl);
+      }
+#pragma unroll
+      for (int r = 0; r < RA; ++r) {
+        const int m = mrow_base + 32 * r;
+        const RowPos rp = decode_row(m, S, lg);
+        const int zz = rp.z + dz, yy = rp.y + dy, xx = rp.x + dx;
+        const bool inb = m < M && (unsigned)zz < (unsigned)S && (unsigned)yy < (unsigned)S &&
+                         (unsigned)xx < (unsigned)S;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (inb) {
+          v = *reinterpret_cast<const float4*>(s.p + src_voxel(s, rp.b, zz, yy, xx, S) + cl);
+          if (aff) v = affine_act4(v, sc, sh, s.act);
+        }
+        ra4[r] = v4f{v.x, v.y, v.z, v.w};
+      }
+    } else {
+      const int kf = (c << 5) + (t & 31);
+      const int tap = kf / g.Cin, ci = kf - tap * g.Cin;
+      const bool kvalid = tap < g.taps;
+      int dz = 0, dy = 0, dx = 0;
+      if (g.taps == 27) { dz = tap / 9 - 1; dy = (tap / 3) % 3 - 1; dx = tap % 3 - 1; }
+#pragma unroll
+      for (int r = 0; r < RS; ++r) {
+        const int m = mrow_base + 8 * r;
+        const RowPos rp = decode_row(m, S, lg);
+        const int zz = rp.z + dz, yy = rp.y + dy, xx = rp.x + dx;
+        const bool inb = kvalid && m < M && (unsigned)zz < (unsigned)S &&
+                         (unsigned)yy < (unsigned)S && (unsigned)xx < (unsigned)S;
+        ras[r] = inb ? gather_scalar(s0, s1, ci, rp.b, zz, yy, xx, S) : 0.f;
+      }
+    }
+  };
+
+  auto store_chunk = [&](int buf) {
+    float* A = As + buf * A_FLOATS;
+    float* Bw = Bs + buf * B_FLOATS;
+#pragma unroll
+    for (int r = 0; r < NB; ++r) *reinterpret_cast<v4f*>(Bw + (t + 256 * r) * 4) = rb[r];
+    if (VEC) {
+#pragma unroll
+      for (int r = 0; r < RA; ++r)
+        *reinterpret_cast<v4f*>(A + ((t >> 3) + 32 * r) * kLDA + (t & 7) * 4) = ra4[r];
+    } else {
+#pragma unroll
+      for (int r = 0; r < RS; ++r) A[((t >> 5) + 8 * r) * kLDA + (t & 31)] = ras[r];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+
+  auto compute = [&](int buf) {
+    const float* A = As + buf * A_FLOATS + (wm * TM * 32 + li) * kLDA + lh * 4;
+    const float* Bw = Bs + buf * B_FLOATS + (lh * BN + wn * TN * 32 + li) * 4;
+#pragma unroll
+    for (int g8 = 0; g8 < 4; ++g8) {
+      float4 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4*>(A + i * 32 * kLDA + g8 * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const float4*>(Bw + (g8 * 2 * BN + j * 32) * 4);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+  };
+  for (int c = 0; c + 1 < nchunks; ++c) {
+    load_chunk(c + 1);
+    compute(c & 1);
+    store_chunk((c + 1) & 1);
+    __syncthreads();
+  }
+  compute((nchunks - 1) & 1);
+  __syncthreads();
+
+  // ---- epilogue: bias + activation, store, per-block BatchNorm partial statistics
+  const int mrow0 = mb * BM + wm * TM * 32 + 4 * lh;
+  float colsum[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * TN * 32 + j * 32 + li;
+    const bool nvalid = n < g.Cout;
+    const float bv = (bias != nullptr && nvalid) ? bias[n] : 0.f;
+    float cs = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
+        float v = act_fwd(acc[i][j][r] + bv, pre_act);
+        const bool ok = m < M;
+        if (!ok) v = 0.f;
+        acc[i][j][r] = v;
+        cs += v;
+        if (ok && nvalid) out[(size_t)m * ldo + n] = v;
+      }
+    colsum[j] = cs;
+  }
+  if (stat_partial == nullptr) return;
+
+  // block-level (count, mean, M2) per column, two-pass inside the block -> exact Chan merge later
+  float* red = smem;              // [WM][BN]
+  float* bmean = smem + WM * BN;  // [BN]
+  const int nvalid_rows = min(BM, M - mb * BM);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    float cs = colsum[j];
+    cs += __shfl_xor(cs, 32);
+    if (lh == 0) red[wm * BN + wn * TN * 32 + j * 32 + li] = cs;
+  }
+  __syncthreads();
+  if (t < BN) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < WM; ++w) s += red[w * BN + t];
+    bmean[t] = s / (float)nvalid_rows;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const float mu = bmean[wn * TN * 32 + j * 32 + li];
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
+        const float d = acc[i][j][r] - mu;
+        q += (m < M) ? d * d : 0.f;
+      }
+    q += __shfl_xor(q, 32);
+    colsum[j] = q;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+    if (lh == 0) red[wm * BN + wn * TN * 32 + j * 32 + li] = colsum[j];
+  __syncthreads();
+  if (t < BN) {
+    float q = 0.f;
+#pragma unroll
+    for (int w = 0; w < WM; ++w) q += red[w * BN + t];
+    float* sp = stat_partial + (size_t)mb * 3 * g.Npad + n0 + t;
+    sp[0] = (float)nvalid_rows;
+    sp[g.Npad] = bmean[t];
+    sp[2 * g.Npad] = q;
+  }
+}
+
+template <int WM, int WN, int TM, int TN, bool VEC>
+static int launch_fwd_cfg(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, const ConvSrc& s1,
+                          const float* wp, const float* bias, float* out, int ldo, int pre_act,
+                          float* stat_partial, int* rows_per_block) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  const int M = g.B << (3 * g.lgS);
+  const int gridM = (M + BM - 1) / BM, gridN = g.Npad / BN;
+  const size_t lds = (size_t)2 * (BM * kLDA + 32 * BN) * sizeof(float);
+  auto kern = conv_fwd_kernel<WM, WN, TM, TN, VEC>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    ICS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  if (rows_per_block) *rows_per_block = BM;
+  hipLaunchKernelGGL(kern, dim3(gridM * gridN), dim3(256), lds, st, g, s0, s1, wp, bias, out, ldo,
+                     pre_act, stat_partial, gridM, gridN);
+  ICS_HIP(hipGetLastError());
+  return 0;
+}
+
+// tile choice for a geometry. Available layouts (4 waves): BM=128 x BN in {128,96,64,32}; 64x64.
+static void pick_fwd_tile(const ConvGeom& g, int* bm, int* bn) {
+  const int M = g.B << (3 * g.lgS);
+  int BN = (g.Npad % 128 == 0) ? 128 : (g.Npad % 96 == 0) ? 96 : (g.Npad % 64 == 0) ? 64 : 32;
+  int BM = 128;
+  // keep >= ~1.5 blocks per CU in flight on the low-resolution layers
+  if (g.Npad % 64 == 0 && (long)((M + 127) / 128) * (g.Npad / BN) < 384) {
+    BM = 64;
+    BN = 64;
+  }
+  *bm = BM;
+  *bn = BN;
+}
+
+int conv_fwd_rows_per_block(const ConvGeom& g) {
+  int bm, bn;
+  pick_fwd_tile(g, &bm, &bn);
+  return bm;
+}
+
+int launch_conv_fwd(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int nsrc,
+                    const float* wp, const float* bias, float* out, int ldo, int pre_act,
+                    float* stat_partial, int* rows_per_block) {
+  ConvSrc s0 = src[0], s1 = src[nsrc > 1 ? 1 : 0];
+  if (nsrc == 1) s1.C = 0;
+  bool vec = (g.Cin % 32 == 0) && (s0.C % 32 == 0) && s0.bcast == 0 && s1.bcast == 0;
+  int bm, bn;
+  pick_fwd_tile(g, &bm, &bn);
+#define ICS_FWD(WM, WN, TM, TN)                                                                  \
+  return vec ? launch_fwd_cfg<WM, WN, TM, TN, true>(st, g, s0, s1, wp, bias, out, ldo, pre_act,  \
+                                                    stat_partial, rows_per_block)                \
+             : launch_fwd_cfg<WM, WN, TM, TN, false>(st, g, s0, s1, wp, bias, out, ldo, pre_act, \
+                                                     stat_partial, rows_per_block)
+  if (bm == 64) { ICS_FWD(2, 2, 1, 1); }
+  if (bn == 128) { ICS_FWD(2, 2, 2, 2); }
+  if (bn == 96) { ICS_FWD(4, 1, 1, 3); }
+  if (bn == 64) { ICS_FWD(2, 2, 2, 1); }
+  ICS_FWD(4, 1, 1, 1);
+#undef ICS_FWD
+}
+
+// =====================================================================================
+// Backward-weight kernel: ws[split][k][n] = sum_{m in split} A[m][k] * dy[m][n]
+// =====================================================================================
+template <int WM, int WN, int TM, int TN, bool VEC>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvGeom g, ConvSrc s0, ConvSrc s1,
+                                                          const float* __restrict__ dy, int ldy,
+                                                          int n_load, int dy_vec,
+                                                          float* __restrict__ ws, int ktiles,
+                                                          int ntiles, int rows_per_split) {
+  constexpr int KT = WM * TM * 32, NT = WN * TN * 32;
+  constexpr int A_FLOATS = 32 * KT, D_FLOATS = 32 * NT;
+  constexpr int AF4 = KT / 4, ATOT = 32 * AF4, APASS = (ATOT + 255) / 256;   // 256 % AF4 == 0
+  constexpr int DF4 = NT / 4, DTOT = 32 * DF4, DPASS = (DTOT + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                    // [2][32][KT]
+  float* Ds = smem + 2 * A_FLOATS;     // [2][32][NT]
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int S = g.S, lg = g.lgS;
+  const int M = g.B << (3 * lg);
+  const int K = g.taps * g.Cin;
+
+  int bid = blockIdx.x;
+  const int nt_i = bid % ntiles; bid /= ntiles;
+  const int kt_i = bid % ktiles; bid /= ktiles;
+  const int split = bid;
+  const int n0 = nt_i * NT;
+  const int m_begin = split * rows_per_split;
+  const int m_end = min(M, m_begin + rows_per_split);
+  const int nchunks = (m_end - m_begin + 31) >> 5;
+
+  // VEC: the k tile lies in one tap and one source
+  int dz = 0, dyy = 0, dx = 0, ci0 = 0, k0;
+  if (VEC) {
+    const int tpt = g.Cin / KT;   // k tiles per tap
+    const int tap = kt_i / tpt;
+    ci0 = (kt_i - tap * tpt) * KT;
+    k0 = tap * g.Cin + ci0;
+    if (g.taps == 27) { dz = tap / 9 - 1; dyy = (tap / 3) % 3 - 1; dx = tap % 3 - 1; }
+  } else {
+    k0 = kt_i * KT;   // KT == 32, flattened (tap, ci)
+  }
+  // SCALAR: this thread's fixed k
+  int s_tap = 0, s_ci = 0; bool s_kvalid = false; int sdz = 0, sdy = 0, sdx = 0;
+  if (!VEC) {
+    const int kf = k0 + (t & 31);
+    s_tap = kf / g.Cin; s_ci = kf - s_tap * g.Cin; s_kvalid = kf < K;
+    if (g.taps == 27) { sdz = s_tap / 9 - 1; sdy = (s_tap / 3) % 3 - 1; sdx = s_tap % 3 - 1; }
+  }
+  const bool first = ci0 < s0.C;
+  const ConvSrc sv = pick_src(s0, s1, first);
+  const int cl0 = first ? ci0 : ci0 - s0.C;
+  const bool aff = VEC && sv.scale != nullptr;
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (aff && (t % AF4) * 4 < KT) {
+    sc = *reinterpret_cast<const float4*>(sv.scale + cl0 + (t % AF4) * 4);
+    sh = *reinterpret_cast<const float4*>(sv.shift + cl0 + (t % AF4) * 4);
+  }
+
+  v4f ra[VEC ? APASS : 1];
+  float ras[4];
+  v4f rd[DPASS];
+
+  auto load_chunk = [&](int c) {
+    const int mbase = m_begin + (c << 5);
+    if (VEC) {
+#pragma unroll
+      for (int p = 0; p < APASS; ++p) {
+        const int idx = t + 256 * p;
+        const int row = idx / AF4;
+        const int m = mbase + row;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < ATOT && m < m_end) {
+          const RowPos r = decode_row(m, S, lg);
+          const int zz = r.z + dz, yy = r.y + dyy, xx = r.x + dx;
+          if ((unsigned)zz < (unsigned)S && (unsigned)yy < (unsigned)S && (unsigned)xx < (unsigned)S) {
+            v = *reinterpret_cast<const float4*>(sv.p + src_voxel(sv, r.b, zz, yy, xx, S) + cl0 +
+                                                 (t % AF4) * 4);
+            if (aff) v = affine_act4(v, sc, sh, sv.act);
+          }
+        }
+        ra[p] = v4f{v.x, v.y, v.z, v.w};
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int m = mbase + (t >> 5) + 8 * p;
+        float v = 0.f;
+        if (s_kvalid && m < m_end) {
+          const RowPos r = decode_row(m, S, lg);
+          const int zz = r.z + sdz, yy = r.y + sdy, xx = r.x + sdx;
+          if ((unsigned)zz < (unsigned)S && (unsigned)yy < (unsigned)S && (unsigned)xx < (unsigned)S)
+            v = gather_scalar(s0, s1, s_ci, r.b, zz, yy, xx, S);
+        }
+        ras[p] = v;
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < DPASS; ++p) {
+      const int idx = t + 256 * p;
+      const int row = idx / DF4;
+      const int m = mbase + row;
+      const int n = n0 + (idx % DF4) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < DTOT && m < m_end) {
+        const float* q = dy + (size_t)m * ldy + n;
+        if (dy_vec) {
+          if (n < n_load) v = *reinterpret_cast<const float4*>(q);
+        } else {
+          if (n + 0 < n_load) v.x = q[0];
+          if (n + 1 < n_load) v.y = q[1];
+          if (n + 2 < n_load) v.z = q[2];
+          if (n + 3 < n_load) v.w = q[3];
+        }
+      }
+      rd[p] = v4f{v.x, v.y, v.z, v.w};
+    }
+  };
+  auto store_chunk = [&](int buf) {
+    float* A = As + buf * A_FLOATS;
+    float* D = Ds + buf * D_FLOATS;
+    if (VEC) {
+#pragma unroll
+      for (int p = 0; p < APASS; ++p) {
+        const int idx = t + 256 * p;
+        if (idx < ATOT) *reinterpret_cast<v4f*>(A + (idx / AF4) * KT + (idx % AF4) * 4) = ra[p];
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) A[((t >> 5) + 8 * p) * KT + (t & 31)] = ras[p];
+    }
+#pragma unroll
+    for (int p = 0; p < DPASS; ++p) {
+      const int idx = t + 256 * p;
+      if (idx < DTOT) *reinterpret_cast<v4f*>(D + (idx / DF4) * NT + (idx % DF4) * 4) = rd[p];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (nchunks > 0) {
+    load_chunk(0);
+    store_chunk(0);
+  }
+  __syncthreads();
+  auto compute = [&](int buf) {
+    const float* A = As + buf * A_FLOATS + lh * KT + wm * TM * 32 + li;
+    const float* D = Ds + buf * D_FLOATS + lh * NT + wn * TN * 32 + li;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = A[s * 2 * KT + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = D[s * 2 * NT + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  };
+  for (int c = 0; c + 1 < nchunks; ++c) {
+    load_chunk(c + 1);
+    compute(c & 1);
+    store_chunk((c + 1) & 1);
+    __syncthreads();
+  }
+  if (nchunks > 0) compute((nchunks - 1) & 1);
+
+  float* wsp = ws + (size_t)split * K * g.Cout;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * TN * 32 + j * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int k = k0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (k < K && n < g.Cout) wsp[(size_t)k * g.Cout + n] = acc[i][j][r];
+      }
+    }
+}
+
+__global__ void reduce_splits_kernel(const float* __restrict__ ws, int nsplit, size_t n_elems,
+                                     int N, float* __restrict__ dw, int ldw) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_elems) return;
+  float s = 0.f;
+  for (int p = 0; p < nsplit; ++p) s += ws[(size_t)p * n_elems + i];   // fixed order: deterministic
+  const size_t k = i / N, n = i - k * N;
+  dw[k * ldw + n] = s;
+}
+
+struct WgradPlan {
+  int kt, nt, ktiles, ntiles, ksplit, rows_per_split;
+  bool vec;
+};
+
+static WgradPlan plan_wgrad(const ConvGeom& g, const ConvSrc& s0, int nsrc, const ConvSrc& s1) {
+  WgradPlan p;
+  const int M = g.B << (3 * g.lgS);
+  p.vec = (g.Cin % 32 == 0) && (s0.C % 32 == 0) && s0.bcast == 0 && (nsrc < 2 || s1.bcast == 0);
+  if (p.vec) {
+    auto divides = [&](int kt) { return s0.C % kt == 0 && g.Cin % kt == 0; };
+    p.kt = divides(128) ? 128 : divides(64) ? 64 : 32;
+    p.ktiles = g.taps * (g.Cin / p.kt);
+  } else {
+    p.kt = 32;
+    p.ktiles = g.Kpad / 32;
+  }
+  // available (kt, nt) layouts: 128x{128,96,64,32}, 64x{128,64}, 32x128; nt need not divide Npad
+  const int n32 = g.Npad;
+  if (p.kt == 128) p.nt = (n32 % 128 == 0) ? 128 : (n32 == 96) ? 96 : (n32 >= 128) ? 128 : (n32 == 64) ? 64 : 32;
+  else if (p.kt == 64) p.nt = (n32 <= 64) ? 64 : 128;
+  else p.nt = 128;
+  p.ntiles = (g.Npad + p.nt - 1) / p.nt;
+  const long base = (long)p.ktiles * p.ntiles;
+  long want = (1536 + base - 1) / base;
+  long maxsplit = M / 256 > 0 ? M / 256 : 1;
+  if (want > maxsplit) want = maxsplit;
+  if (want < 1) want = 1;
+  if (want > 64) want = 64;
+  int rows = (int)(((M + want - 1) / want + 31) / 32 * 32);
+  p.rows_per_split = rows;
+  p.ksplit = (M + rows - 1) / rows;
+  return p;
+}
+
+size_t conv_wgrad_workspace_floats(const ConvGeom& g, const ConvSrc* src, int nsrc) {
+  ConvSrc s0 = src[0], s1 = src[nsrc > 1 ? 1 : 0];
+  WgradPlan p = plan_wgrad(g, s0, nsrc, s1);
+  return (size_t)p.ksplit * g.taps * g.Cin * g.Cout;
+}
+
+template <int WM, int WN, int TM, int TN, bool VEC>
+static int launch_wgrad_cfg(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, const ConvSrc& s1,
+                            const float* dy, int ldy, int n_load, int dy_vec, float* ws,
+                            const WgradPlan& p) {
+  constexpr int KT = WM * TM * 32, NT = WN * TN * 32;
+  const size_t lds = (size_t)2 * 32 * (KT + NT) * sizeof(float);
+  auto kern = conv_wgrad_kernel<WM, WN, TM, TN, VEC>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    ICS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.ktiles * p.ntiles * p.ksplit), dim3(256), lds, st, g, s0, s1, dy,
+                     ldy, n_load, dy_vec, ws, p.ktiles, p.ntiles, p.rows_per_split);
+  ICS_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_conv_wgrad(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int nsrc,
+                      const float* dy, int ldy, float* dw, int ldw, float* workspace,
+                      size_t workspace_floats) {
+  ConvSrc s0 = src[0], s1 = src[nsrc > 1 ? 1 : 0];
+  if (nsrc == 1) s1.C = 0;
+  const WgradPlan p = plan_wgrad(g, s0, nsrc, s1);
+  const size_t n_elems = (size_t)g.taps * g.Cin * g.Cout;
+  ICS_CHECK((size_t)p.ksplit * n_elems <= workspace_floats, "wgrad workspace too small");
+  // dy columns that may be loaded: the whole row span of dy that is addressable from this column
+  // offset (callers pass dy already offset); vector loads need 16-byte alignment of every row.
+  const int n_load4 = (g.Cout + 3) / 4 * 4;
+  const int dy_vec = (ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(dy) & 15) == 0) &&
+                     (n_load4 <= ldy);
+  const int n_load = dy_vec ? n_load4 : g.Cout;
+#define ICS_WG(WM, WN, TM, TN)                                                                     \
+  do {                                                                                             \
+    if (p.vec) ICS_TRY((launch_wgrad_cfg<WM, WN, TM, TN, true>(st, g, s0, s1, dy, ldy, n_load,     \
+                                                                dy_vec, workspace, p)));            \
+    else ICS_TRY((launch_wgrad_cfg<WM, WN, TM, TN, false>(st, g, s0, s1, dy, ldy, n_load, dy_vec,  \
+                                                           workspace, p)));                         \
+  } while (0)
+  if (p.kt == 128) {
+    if (p.nt == 128) ICS_WG(2, 2, 2, 2);
+    else if (p.nt == 96) ICS_WG(4, 1, 1, 3);
+    else if (p.nt == 64) ICS_WG(4, 1, 1, 2);
+    else ICS_WG(4, 1, 1, 1);
+  } else if (p.kt == 64) {
+    if (p.nt == 128) ICS_WG(2, 2, 1, 2);
+    else ICS_WG(2, 2, 1, 1);
+  } else {
+    ICS_WG(1, 4, 1, 1);
+  }
+#undef ICS_WG
+  const int thr = 256;
+  hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((n_elems + thr - 1) / thr)), dim3(thr), 0,
+                     st, workspace, p.ksplit, n_elems, g.Cout, dw, ldw);
+  ICS_HIP(hipGetLastError());
+  return 0;
+}
+
+// =====================================================================================
+// Weight packing
+// =====================================================================================
+// dst[(kq*Npad + n)*4 + t] = w[(k_src)*N + n_src] with k = kq*4+t; region outside is zero-filled
+// only when zero_first (the head packs two weight tensors into one buffer).
+__global__ void pack_fwd_kernel(const float* __restrict__ w, int K, int N, float* __restrict__ dst,
+                                int Kpad, int Npad, int k_off, int n_off, int zero_first) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)Kpad * Npad;
+  if (i >= total) return;
+  const int tq = i & 3;
+  const size_t rest = i >> 2;
+  const int n = rest % Npad;
+  const int k = (int)(rest / Npad) * 4 + tq;
+  const int ks = k - k_off, ns = n - n_off;
+  if (ks >= 0 && ks < K && ns >= 0 && ns < N) dst[i] = w[(size_t)ks * N + ns];
+  else if (zero_first) dst[i] = 0.f;
+}
+
+// backward-data weights: k' = t'*cout_total + co_off + co, n' = ci, value = w[26-t'][ci][co]
+__global__ void pack_bwd_kernel(const float* __restrict__ w, int taps, int Cin, int Cout,
+                                float* __restrict__ dst, int Kpad, int Npad, int cout_total,
+                                int co_off, int zero_first) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)Kpad * Npad;
+  if (i >= total) return;
+  const int tq = i & 3;
+  const size_t rest = i >> 2;
+  const int n = rest % Npad;
+  const int k = (int)(rest / Npad) * 4 + tq;
+  const int tp = k / cout_total, co = k - tp * cout_total - co_off;
+  if (tp < taps && co >= 0 && co < Cout && n < Cin)
+    dst[i] = w[((size_t)(taps - 1 - tp) * Cin + n) * Cout + co];
+  else if (zero_first) dst[i] = 0.f;
+}
+
+int launch_pack_fwd(hipStream_t st, const float* w, int K, int N, float* dst, int Kpad, int Npad,
+                    int k_off, int n_off, int zero_first) {
+  const size_t total = (size_t)Kpad * Npad;
+  hipLaunchKernelGGL(pack_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, K, N,
+                     dst, Kpad, Npad, k_off, n_off, zero_first);
+  ICS_HIP(hipGetLastError());
+  return 0;
+}
+int launch_pack_bwd(hipStream_t st, const float* w, int taps, int Cin, int Cout, float* dst,
+                    int Kpad, int Npad, int cout_total, int co_off, int zero_first) {
+  const size_t total = (size_t)Kpad * Npad;
+  hipLaunchKernelGGL(pack_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, taps,
+                     Cin, Cout, dst, Kpad, Npad, cout_total, co_off, zero_first);
+  ICS_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace ics

@@ -1,0 +1,69 @@
+// Declarations for elementwise.hip (BatchNorm / pool / heads / losses / Adam launchers).
+#pragma once
+#include "common.h"
+
+namespace ics {
+
+struct BnParams {
+  const float* gamma;
+  const float* beta;
+  float* moving_mean;
+  float* moving_var;
+  float* mean;    // batch (or moving, in eval) mean
+  float* rstd;    // 1/sqrt(var+eps)
+  float* scale;   // gamma*rstd
+  float* shift;   // beta - mean*scale
+};
+
+enum GradSrcKind : int { GS_NONE = 0, GS_DIRECT = 1, GS_UP = 2, GS_POOL = 3 };
+
+// Where the gradient w.r.t. a layer's OUTPUT o comes from: the dA buffer of a consumer conv.
+struct GradSrc {
+  const float* p;                 // consumer's input-gradient buffer [rows][ld]
+  int ld, off;                    // leading dimension and first channel of this layer inside it
+  int kind;                       // GS_DIRECT same resolution; GS_UP consumer at 2S (sum 8 children);
+                                  // GS_POOL consumer at S/2 behind MaxPool3D
+  const float* pooled;            // GS_POOL: pooled forward values [rows/8][C]
+  const unsigned char* pool_idx;  // GS_POOL: argmax index (first max) [rows/8][C]
+};
+
+// Everything needed to push a gradient back through  o = post_act(BN(s)), s = pre_act(conv + b).
+struct LayerBwd {
+  const float* s;                 // stored pre-BN activations [M][C]
+  const float* scale; const float* shift; const float* mean; const float* rstd;
+  const float* dtap;              // optional extra gradient w.r.t. s (perceptual taps)
+  GradSrc g0, g1;
+  int B, S, lgS, C;
+  int has_bn, pre_act, post_act;
+  int pool_ties_all;              // 1: TF-CPU MaxPool3DGrad tie rule, 0: first max only
+};
+
+int launch_bn_finalize(hipStream_t st, const float* partial, int nblk, int Npad, const BnParams& bn,
+                       int C, int update_moving, int unbias);
+int launch_bn_eval_prepare(hipStream_t st, const BnParams& bn, int C);
+int launch_pool_fwd(hipStream_t st, const float* s, const float* scale, const float* shift, int act,
+                    int B, int S, int C, float* out, unsigned char* idx);
+int launch_layer_bwd(hipStream_t st, const LayerBwd& L, float* dy, float* ws_partial, float* c1c2,
+                     float* dgamma, float* dbeta, float* dbias);
+size_t layer_bwd_workspace_floats(const LayerBwd& L);
+int launch_head(hipStream_t st, float* z, int ldz, int ncls, const unsigned char* labels, size_t M,
+                int mode, int want_grad, float wsoft, double* partial, int partial_blocks,
+                float* metrics);
+int launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v, size_t n, float lr_t,
+                float gscale);
+int launch_bn_apply(hipStream_t st, const float* s, const float* scale, const float* shift, int act,
+                    size_t n, int C, float* out);
+int launch_sqdiff(hipStream_t st, const float* a, const float* b, int B, size_t per_sample,
+                  int blocks_per_sample, double* partial, float* grad, float coef, int accumulate);
+int launch_sampling(hipStream_t st, const float* mulv, int ld, int latent, const float* eps,
+                    const float* cond, int ncond, int B, float* z, float* zc);
+int launch_vae_loss(hipStream_t st, const float* mulv, int ld, int latent, int B, const double* mse_partial,
+                    int n_mse, double n_elems, const double* pm_partial, const int* pm_counts,
+                    const float* pm_w, float alpha, float beta, float* metrics);
+int launch_vae_dz(hipStream_t st, const float* mulv, int ld, int latent, int B, const float* eps,
+                  const float* dzc, int ldzc, float beta, float* dmulv);
+int launch_relu_bwd(hipStream_t st, const float* a, float* g, size_t n);
+int launch_colsum_small(hipStream_t st, const float* a, int rows, int cols, int ld, float* out);
+int launch_axpy(hipStream_t st, float* y, const float* x, size_t n, float a);
+
+}  // namespace ics

@@ -1,0 +1,673 @@
+// HBM-bound kernels around the convolutions: BatchNorm statistics merge / backward, MaxPool3D,
+// fused softmax+sigmoid heads with the U-Net losses and metrics, DFC-VAE loss terms, Adam.
+// Semantics follow /root/reference/unet/unet.py:159-221,276-352 and
+// /root/reference/vae/lattice_vae.py:53-66,232-270 plus the Keras op semantics of SURVEY.md App. B.
+// All reductions are block partials + fixed-order merges (no float atomics): run-to-run bit-stable.
+#include "common.h"
+#include "elementwise.h"
+
+namespace ics {
+
+// ------------------------------------------------------------------------------------------
+// block reduction helpers (256 threads)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+// sum over the whole 256-thread block; result valid in every thread
+__device__ __forceinline__ double block_sum_d(double v, double* sh /*[4]*/) {
+  v = wave_sum_d(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// ------------------------------------------------------------------------------------------
+// BatchNorm forward statistics: merge per-block (count, mean, M2) -> mean/var -> scale/shift,
+// moving-average update.  One block per channel, fp64 merge (Chan et al.).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int nblk,
+                                                           int Npad, BnParams bn, int update_moving,
+                                                           float momentum, int unbias) {
+  __shared__ double sh[4];
+  const int c = blockIdx.x;
+  double n = 0.0, s = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += 256) {
+    const float* p = partial + (size_t)b * 3 * Npad + c;
+    n += (double)p[0];
+    s += (double)p[0] * (double)p[Npad];
+  }
+  n = block_sum_d(n, sh);
+  s = block_sum_d(s, sh);
+  const double mean = s / n;
+  double m2 = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += 256) {
+    const float* p = partial + (size_t)b * 3 * Npad + c;
+    const double d = (double)p[Npad] - mean;
+    m2 += (double)p[2 * Npad] + (double)p[0] * d * d;
+  }
+  m2 = block_sum_d(m2, sh);
+  if (threadIdx.x == 0) {
+    const double var = m2 / n;   // biased, as tf.nn.moments
+    const float rstd = (float)(1.0 / sqrt(var + (double)kBnEps));
+    const float sc = bn.gamma[c] * rstd;
+    bn.mean[c] = (float)mean;
+    bn.rstd[c] = rstd;
+    bn.scale[c] = sc;
+    bn.shift[c] = bn.beta[c] - (float)mean * sc;
+    if (update_moving) {
+      // keras 2.3.1 BatchNormalization.call: variance fed to the moving average is rescaled by
+      // n/(n-(1+eps)); plain EMA with momentum 0.99
+      const double v = unbias ? var * (n / (n - (1.0 + (double)kBnEps))) : var;
+      bn.moving_mean[c] = bn.moving_mean[c] * momentum + (float)mean * (1.f - momentum);
+      bn.moving_var[c] = bn.moving_var[c] * momentum + (float)v * (1.f - momentum);
+    }
+  }
+}
+
+__global__ void bn_eval_prepare_kernel(BnParams bn, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float rstd = 1.f / sqrtf(bn.moving_var[c] + kBnEps);
+  const float sc = bn.gamma[c] * rstd;
+  bn.mean[c] = bn.moving_mean[c];
+  bn.rstd[c] = rstd;
+  bn.scale[c] = sc;
+  bn.shift[c] = bn.beta[c] - bn.moving_mean[c] * sc;
+}
+
+int launch_bn_finalize(hipStream_t st, const float* partial, int nblk, int Npad, const BnParams& bn,
+                       int C, int update_moving, int unbias) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, st, partial, nblk, Npad, bn,
+                     update_moving, 0.99f, unbias);
+  ICS_HIP(hipGetLastError());
+  return 0;
+}
+int launch_bn_eval_prepare(hipStream_t st, const BnParams& bn, int C) {
+  hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3((C + 255) / 256), dim3(256), 0, st, bn, C);
+  ICS_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// MaxPool3D(2) over o = act(s*scale+shift)   (pooling follows BN: unet.py:282, lattice_vae.py:176)
+// ------------------------------------------------------------------------------------------
+__global__ void pool_fwd_kernel(const float* __restrict__ s, const float* __restrict__ scale,
+                                const float* __restrict__ shift, int act, int B, int S, int C,
+                                float* __restrict__ out, unsigned char* __restrict__ idx) {
+  const int Sh = S >> 1;
+  const size_t total = (size_t)B * Sh * Sh * Sh * C;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = i % C;
+  size_t v = i / C;
+  const int x = v % Sh; v /= Sh;
+  const int y = v % Sh; v /= Sh;
+  const int z = v % Sh;
+  const int b = v / Sh;
+  const float sc = scale ? scale[c] : 1.f, sh = scale ? shift[c] : 0.f;
+  float best = -INFINITY;
+  int bi = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int zz = 2 * z + (k >> 2), yy = 2 * y + ((k >> 1) & 1), xx = 2 * x + (k & 1);
+    const float o = act_fwd(fmaf(s[((((size_t)b * S + zz) * S + yy) * S + xx) * C + c], sc, sh), act);
+    if (o > best) { best = o; bi = k; }   // first maximum in (dz,dy,dx) scan order
+  }
+  out[i] = best;
+  idx[i] = (unsigned char)bi;
+}
+
+int launch_pool_fwd(hipStream_t st, const float* s, const float* scale, const float* shift, int act,
+                    int B, int S, int C, float* out, unsigned char* idx) {
+  const size_t total = (size_t)B * (S / 2) * (S / 2) * (S / 2) * C;
+  hipLaunchKernelGGL(pool_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, s, scale,
+                     shift, act, B, S, C, out, idx);
+  ICS_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Backward through  o = post_act(BN(s)),  s = pre_act(conv):  gather dO from the consumers,
+// reduce (sum d, sum d*xhat), then dy = pre_act'(s) * [ scale*(d - c1 - xhat*c2) + dtap ].
+// ------------------------------------------------------------------------------------------
+struct ElemCtx {
+  int b, z, y, x, c;
+};
+
+__device__ __forceinline__ float gather_do(const GradSrc& g, const LayerBwd& L, size_t row,
+                                           const ElemCtx& e, float o) {
+  if (g.kind == GS_DIRECT) return g.p[row * g.ld + g.off + e.c];
+  if (g.kind == GS_UP) {
+    // consumer ran at 2S on the nearest-upsampled tensor: sum the 8 children (UpSampling3D bwd)
+    const int S2 = L.S * 2;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int zz = 2 * e.z + (k >> 2), yy = 2 * e.y + ((k >> 1) & 1), xx = 2 * e.x + (k & 1);
+      acc += g.p[((((size_t)e.b * S2 + zz) * S2 + yy) * S2 + xx) * g.ld + g.off + e.c];
+    }
+    return acc;
+  }
+  if (g.kind == GS_POOL) {
+    const int Sh = L.S >> 1;
+    const size_t prow = (((size_t)e.b * Sh + (e.z >> 1)) * Sh + (e.y >> 1)) * Sh + (e.x >> 1);
+    const float up = g.p[prow * g.ld + g.off + e.c];
+    if (L.pool_ties_all) {
+      // TF CPU MaxPool3DGrad: every window element within 1e-5 of the max receives the gradient
+      const float ymax = g.pooled[prow * L.C + e.c];
+      return fabsf(o - ymax) < kPoolTieTol ? up : 0.f;
+    }
+    const int k = ((e.z & 1) << 2) | ((e.y & 1) << 1) | (e.x & 1);
+    return g.pool_idx[prow * L.C + e.c] == k ? up : 0.f;
+  }
+  return 0.f;
+}
+
+// d = dO * post_act'(bn_out);  also returns xhat
+__device__ __forceinline__ float elem_d(const LayerBwd& L, size_t row, const ElemCtx& e, float sv,
+                                        float* xhat) {
+  float bnout = sv, xh = 0.f;
+  if (L.has_bn) {
+    bnout = fmaf(sv, L.scale[e.c], L.shift[e.c]);
+    xh = (sv - L.mean[e.c]) * L.rstd[e.c];
+  }
+  const float o = act_fwd(bnout, L.post_act);
+  float d = gather_do(L.g0, L, row, e, o);
+  if (L.g1.kind != GS_NONE) d += gather_do(L.g1, L, row, e, o);
+  d *= act_grad(bnout, L.post_act);
+  *xhat = xh;
+  return d;
+}
+
+__device__ __forceinline__ ElemCtx decode_elem(size_t row, int c, int S, int lg) {
+  ElemCtx e;
+  e.c = c;
+  e.x = row & (S - 1);
+  e.y = (row >> lg) & (S - 1);
+  e.z = (row >> (2 * lg)) & (S - 1);
+  e.b = row >> (3 * lg);
+  return e;
+}
+
+// Thread layout for [M][C] tensors with power-of-two C: CB = min(C,256) channels across threads,
+// RPP = 256/CB rows per pass; channel groups of 256 looped when C > 256.
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(LayerBwd L, int rows_per_block,
+                                                             float* __restrict__ partial) {
+  __shared__ float sh1[256], sh2[256];
+  const int C = L.C, CB = C < 256 ? C : 256, RPP = 256 / CB;
+  const int t = threadIdx.x, tc = t % CB, tr = t / CB;
+  const size_t M = (size_t)L.B << (3 * L.lgS);
+  const size_t r0 = (size_t)blockIdx.x * rows_per_block;
+  const size_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+  for (int cg = 0; cg < C; cg += 256) {
+    const int c = cg + tc;
+    float a1 = 0.f, a2 = 0.f;
+    for (size_t row = r0 + tr; row < r1; row += RPP) {
+      const ElemCtx e = decode_elem(row, c, L.S, L.lgS);
+      float xh;
+      const float d = elem_d(L, row, e, L.s[row * C + c], &xh);
+      a1 += d;
+      a2 += d * xh;
+    }
+    sh1[t] = a1; sh2[t] = a2;
+    __syncthreads();
+    if (t < CB) {
+      float s1 = 0.f, s2 = 0.f;
+      for (int r = 0; r < RPP; ++r) { s1 += sh1[r * CB + t]; s2 += sh2[r * CB + t]; }
+      partial[((size_t)blockIdx.x * 2 + 0) * C + cg + t] = s1;
+      partial[((size_t)blockIdx.x * 2 + 1) * C + cg + t] = s2;
+    }
+    __syncthreads();
+  }
+}
+
+// merges the block partials: c1 = sum d / n, c2 = sum d*xhat / n ; writes dgamma/dbeta if asked
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial,
+                                                               int nblk, int C, double n,
+                                                               float* __restrict__ c1,
+                                                               float* __restrict__ c2,
+                                                               float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta) {
+  __shared__ double sh[4];
+  const int c = blockIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += 256) {
+    s1 += (double)partial[((size_t)b * 2 + 0) * C + c];
+    s2 += (double)partial[((size_t)b * 2 + 1) * C + c];
+  }
+  s1 = block_sum_d(s1, sh);
+  s2 = block_sum_d(s2, sh);
+  if (threadIdx.x == 0) {
+    c1[c] = (float)(s1 / n);
+    c2[c] = (float)(s2 / n);
+    if (dgamma) { dgamma[c] = (float)s2; dbeta[c] = (float)s1; }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(LayerBwd L, int rows_per_block,
+                                                            const float* __restrict__ c1,
+                                                            const float* __restrict__ c2,
+                                                            float* __restrict__ dy,
+                                                            float* __restrict__ db_partial) {
+  __shared__ float sh1[256];
+  const int C = L.C, CB = C < 256 ? C : 256, RPP = 256 / CB;
+  const int t = threadIdx.x, tc = t % CB, tr = t / CB;
+  const size_t M = (size_t)L.B << (3 * L.lgS);
+  const size_t r0 = (size_t)blockIdx.x * rows_per_block;
+  const size_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+  for (int cg = 0; cg < C; cg += 256) {
+    const int c = cg + tc;
+    const float k1 = L.has_bn ? c1[c] : 0.f, k2 = L.has_bn ? c2[c] : 0.f;
+    const float sg = L.has_bn ? L.scale[c] : 1.f;
+    float acc = 0.f;
+    for (size_t row = r0 + tr; row < r1; row += RPP) {
+      const ElemCtx e = decode_elem(row, c, L.S, L.lgS);
+      const float sv = L.s[row * C + c];
+      float xh;
+      const float d = elem_d(L, row, e, sv, &xh);
+      float ds = L.has_bn ? sg * (d - k1 - xh * k2) : d;
+      if (L.dtap) ds += L.dtap[row * C + c];
+      const float g = ds * act_grad(sv, L.pre_act);
+      dy[row * C + c] = g;
+      acc += g;
+    }
+    if (db_partial) {
+      sh1[t] = acc;
+      __syncthreads();
+      if (t < CB) {
+        float s = 0.f;
+        for (int r = 0; r < RPP; ++r) s += sh1[r * CB + t];
+        db_partial[(size_t)blockIdx.x * C + cg + t] = s;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partial,
+                                                               int nblk, int C, float* __restrict__ out) {
+  __shared__ double sh[4];
+  const int c = blockIdx.x;
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += 256) s += (double)partial[(size_t)b * C + c];
+  s = block_sum_d(s, sh);
+  if (threadIdx.x == 0) out[c] = (float)s;
+}
+
+int bn_bwd_num_blocks(const LayerBwd& L, int* rows_per_block) {
+  const size_t M = (size_t)L.B << (3 * L.lgS);
+  // aim for ~2048 blocks, at least 64 rows each
+  size_t rpb = (M + 2047) / 2048;
+  if (rpb < 64) rpb = 64;
+  const int CB = L.C < 256 ? L.C : 256, RPP = 256 / CB;
+  rpb = (rpb + RPP - 1) / RPP * RPP;
+  *rows_per_block = (int)rpb;
+  return (int)((M + rpb - 1) / rpb);
+}
+
+int launch_layer_bwd(hipStream_t st, const LayerBwd& L, float* dy, float* ws_partial, float* c1c2,
+                     float* dgamma, float* dbeta, float* dbias) {
+  int rpb;
+  const int nblk = bn_bwd_num_blocks(L, &rpb);
+  const double n = (double)((size_t)L.B << (3 * L.lgS));
+  float* c1 = c1c2;
+  float* c2 = c1c2 + L.C;
+  if (L.has_bn) {
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, st, L, rpb, ws_partial);
+    ICS_HIP(hipGetLastError());
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(L.C), dim3(256), 0, st, ws_partial, nblk, L.C, n, c1,
+                       c2, dgamma, dbeta);
+    ICS_HIP(hipGetLastError());
+  }
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk), dim3(256), 0, st, L, rpb, c1, c2, dy,
+                     dbias ? ws_partial : nullptr);
+  ICS_HIP(hipGetLastError());
+  if (dbias) {
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(L.C), dim3(256), 0, st, ws_partial, nblk, L.C, dbias);
+    ICS_HIP(hipGetLastError());
+  }
+  return 0;
+}
+size_t layer_bwd_workspace_floats(const LayerBwd& L) {
+  int rpb;
+  const int nblk = bn_bwd_num_blocks(L, &rpb);
+  return (size_t)nblk * 2 * L.C;
+}
+
+// ------------------------------------------------------------------------------------------
+// U-Net heads: z[M][ldz] holds 95 softmax logits + 1 sigmoid logit per voxel (one 1x1x1 GEMM).
+// One wave per voxel row; lane l owns columns l and l+64.
+//   mode 0 (predict): overwrite z with probabilities.
+//   mode 1 (train/test): accumulate losses + metrics; if want_grad overwrite z with dLoss/dz.
+// weighted_categorical_crossentropy (unet.py:196-221) with scalar weight, keras binary_crossentropy,
+// f1_m / wr_m (unet.py:159-193).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_kernel(float* __restrict__ z, int ldz, int ncls,
+                                                   const unsigned char* __restrict__ labels, size_t M,
+                                                   int rows_per_block, int mode, int want_grad,
+                                                   float wsoft, float inv_bv, double* __restrict__ partial) {
+  __shared__ double shd[4][6];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t r0 = (size_t)blockIdx.x * rows_per_block;
+  const size_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+  double a_ls = 0, a_lg = 0, a_tp = 0, a_pred = 0, a_tpw = 0, a_posw = 0;
+  for (size_t row = r0 + wave; row < r1; row += 4) {
+    float* zr = z + row * ldz;
+    const int c0 = lane, c1 = lane + 64;
+    const float z0 = c0 < ncls ? zr[c0] : -INFINITY;
+    const float z1 = c1 < ncls ? zr[c1] : -INFINITY;
+    const float zsig = zr[ncls];   // uniform broadcast load
+    const float mx = wave_max_f(fmaxf(z0, z1));
+    const float e0 = c0 < ncls ? expf(z0 - mx) : 0.f;
+    const float e1 = c1 < ncls ? expf(z1 - mx) : 0.f;
+    const float sum = wave_sum_f(e0 + e1);
+    const float p0 = e0 / sum, p1 = e1 / sum;
+    const float ps = 1.f / (1.f + expf(-zsig));
+    if (mode == 0) {
+      if (c0 < ncls) zr[c0] = p0;
+      if (c1 < ncls) zr[c1] = p1;
+      if (lane == 0) zr[ncls] = ps;
+      continue;
+    }
+    const int lab = labels[row];
+    // renormalise (p /= sum p), clip, -w*log  (only the true class contributes)
+    const float psum = wave_sum_f(p0 + p1);
+    const float pt_raw = (lab < 64) ? __shfl(p0, lab) : __shfl(p1, lab - 64);
+    const float qt = pt_raw / psum;
+    const bool inside = qt >= kKEps && qt <= 1.f - kKEps;
+    const float qc = fminf(fmaxf(qt, kKEps), 1.f - kKEps);
+    const float tsig = lab != 0 ? 1.f : 0.f;
+    const bool inside_s = ps >= kKEps && ps <= 1.f - kKEps;
+    const float pc = fminf(fmaxf(ps, kKEps), 1.f - kKEps);
+    // predicted positives: round(clip(p,0,1)) == 1  <=>  p > 0.5 (round-half-even: 0.5 -> 0)
+    const unsigned long long b0 = __ballot(c0 < ncls && p0 > 0.5f);
+    const unsigned long long b1 = __ballot(c1 < ncls && p1 > 0.5f);
+    if (lane == 0) {
+      a_ls += (double)(-wsoft * logf(qc));
+      a_lg += (double)(-(tsig * logf(pc) + (1.f - tsig) * logf(1.f - pc)));
+      const bool hit = pt_raw > 0.5f;
+      a_tp += hit ? 1.0 : 0.0;
+      a_pred += (double)(__popcll(b0) + __popcll(b1));
+      if (lab != 0) { a_posw += 1.0; a_tpw += hit ? 1.0 : 0.0; }
+    }
+    if (want_grad) {
+      // d lsoft/dz = w*(p - y)/(B*V) when the true-class probability is not clipped, else 0
+      const float gs = inside ? wsoft * inv_bv : 0.f;
+      if (c0 < ncls) zr[c0] = gs * (p0 - (c0 == lab ? 1.f : 0.f));
+      if (c1 < ncls) zr[c1] = gs * (p1 - (c1 == lab ? 1.f : 0.f));
+      if (lane == 0) zr[ncls] = inside_s ? (ps - tsig) * inv_bv : 0.f;
+    }
+  }
+  if (mode == 0) return;
+  if (lane == 0) {
+    shd[wave][0] = a_ls; shd[wave][1] = a_lg; shd[wave][2] = a_tp;
+    shd[wave][3] = a_pred; shd[wave][4] = a_tpw; shd[wave][5] = a_posw;
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int k = threadIdx.x;
+    partial[(size_t)blockIdx.x * 6 + k] = shd[0][k] + shd[1][k] + shd[2][k] + shd[3][k];
+  }
+}
+
+// metrics[5] = [Loss, lsoft, lsig, f1, wr]
+__global__ __launch_bounds__(256) void head_finalize_kernel(const double* __restrict__ partial, int nblk,
+                                                            double M, float* __restrict__ metrics) {
+  __shared__ double sh[4];
+  double acc[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 256) s += partial[(size_t)b * 6 + k];
+    acc[k] = block_sum_d(s, sh);
+  }
+  if (threadIdx.x == 0) {
+    const double eps = 1e-7;
+    const double lsoft = acc[0] / M, lsig = acc[1] / M;
+    const double tp = acc[2], predicted = acc[3], possible = M;
+    const double precision = tp / (predicted + eps), recall = tp / (possible + eps);
+    const double f1 = 2.0 * ((precision * recall) / (precision + recall + eps));
+    const double wr = acc[4] / (acc[5] + eps);
+    metrics[0] = (float)(lsoft + lsig);
+    metrics[1] = (float)lsoft;
+    metrics[2] = (float)lsig;
+    metrics[3] = (float)f1;
+    metrics[4] = (float)wr;
+  }
+}
+
+int launch_head(hipStream_t st, float* z, int ldz, int ncls, const unsigned char* labels, size_t M,
+                int mode, int want_grad, float wsoft, double* partial, int partial_blocks,
+                float* metrics) {
+  ICS_CHECK(ncls <= 128, "head kernel supports at most 128 classes");
+  int rpb = (int)((M + partial_blocks - 1) / partial_blocks);
+  rpb = (rpb + 3) / 4 * 4;
+  const int nblk = (int)((M + rpb - 1) / rpb);
+  hipLaunchKernelGGL(head_kernel, dim3(nblk), dim3(256), 0, st, z, ldz, ncls, labels, M, rpb, mode,
+                     want_grad, wsoft, (float)(1.0 / (double)M), partial);
+  ICS_HIP(hipGetLastError());
+  if (mode != 0) {
+    hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(256), 0, st, partial, nblk, (double)M, metrics);
+    ICS_HIP(hipGetLastError());
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Adam (keras 2.3.1): m,v update, p -= lr_t * m / (sqrt(v) + 1e-7)
+// ------------------------------------------------------------------------------------------
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, size_t n, float lr_t, float b1, float b2, float eps,
+                            float gscale) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i] * gscale;
+  const float mi = b1 * m[i] + (1.f - b1) * gi;
+  const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  p[i] = p[i] - lr_t * mi / (sqrtf(vi) + eps);
+}
+int launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v, size_t n, float lr_t,
+                float gscale) {
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, g, m, v, n,
+                     lr_t, 0.9f, 0.999f, 1e-7f, gscale);
+  ICS_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// DFC-VAE pieces (vae/lattice_vae.py:53-66, 232-270)
+// ------------------------------------------------------------------------------------------
+// o = act(s*scale+shift) materialised (decoder output / any tensor that must leave the device)
+__global__ void bn_apply_kernel(const float* __restrict__ s, const float* __restrict__ scale,
+                                const float* __restrict__ shift, int act, size_t n, int C,
+                                float* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int c = i % C;
+  out[i] = act_fwd(scale ? fmaf(s[i], scale[c], shift[c]) : s[i], act);
+}
+int launch_bn_apply(hipStream_t st, const float* s, const float* scale, const float* shift, int act,
+                    size_t n, int C, float* out) {
+  hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s, scale, shift,
+                     act, n, C, out);
+  ICS_HIP(hipGetLastError());
+  return 0;
+}
+
+// sum over elements of (a-b)^2 per sample -> partial[b][blk]; optional grad: dst = coef*(b - a)
+// (coef carries the 2/N and loss weights; sign chosen for d/d b of (a-b)^2 = 2 (b-a)).
+__global__ __launch_bounds__(256) void sqdiff_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                      size_t per_sample, int blocks_per_sample,
+                                                      double* __restrict__ partial, float* __restrict__ grad,
+                                                      float coef, int accumulate) {
+  __shared__ double sh[4];
+  const int smp = blockIdx.x / blocks_per_sample, blk = blockIdx.x % blocks_per_sample;
+  const size_t chunk = (per_sample + blocks_per_sample - 1) / blocks_per_sample;
+  const size_t i0 = (size_t)blk * chunk, i1 = i0 + chunk < per_sample ? i0 + chunk : per_sample;
+  const size_t base = (size_t)smp * per_sample;
+  double acc = 0.0;
+  for (size_t i = i0 + threadIdx.x; i < i1; i += 256) {
+    const float d = b[base + i] - a[base + i];
+    acc += (double)d * (double)d;
+    if (grad) {
+      const float gv = coef * d;
+      grad[base + i] = accumulate ? grad[base + i] + gv : gv;
+    }
+  }
+  acc = block_sum_d(acc, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+int launch_sqdiff(hipStream_t st, const float* a, const float* b, int B, size_t per_sample,
+                  int blocks_per_sample, double* partial, float* grad, float coef, int accumulate) {
+  hipLaunchKernelGGL(sqdiff_kernel, dim3(B * blocks_per_sample), dim3(256), 0, st, a, b, per_sample,
+                     blocks_per_sample, partial, grad, coef, accumulate);
+  ICS_HIP(hipGetLastError());
+  return 0;
+}
+
+// z = mu + exp(0.5*logvar)*eps ; zc = [z | cond]
+__global__ void sampling_kernel(const float* __restrict__ mulv, int ld, int latent,
+                                const float* __restrict__ eps, const float* __restrict__ cond, int ncond,
+                                int B, float* __restrict__ z, float* __restrict__ zc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int W = latent + ncond;
+  if (i >= B * W) return;
+  const int b = i / W, j = i % W;
+  if (j < latent) {
+    const float mu = mulv[b * ld + j], lv = mulv[b * ld + latent + j];
+    const float zz = mu + expf(0.5f * lv) * eps[b * latent + j];
+    z[b * latent + j] = zz;
+    zc[i] = zz;
+  } else {
+    zc[i] = cond[b * ncond + (j - latent)];
+  }
+}
+int launch_sampling(hipStream_t st, const float* mulv, int ld, int latent, const float* eps,
+                    const float* cond, int ncond, int B, float* z, float* zc) {
+  const int n = B * (latent + ncond);
+  hipLaunchKernelGGL(sampling_kernel, dim3((n + 255) / 256), dim3(256), 0, st, mulv, ld, latent, eps, cond,
+                     ncond, B, z, zc);
+  ICS_HIP(hipGetLastError());
+  return 0;
+}
+
+// VAE loss assembly + gradient w.r.t. (mu, logvar) given dL/dz.
+//   kld_b = -0.5*sum_j(1 + lv - mu^2 - exp(lv));  Loss = mse + alpha*mean_b(pm_b) + beta*mean_b(kld_b)
+// metrics[4] = [Loss, PM, MSE, KLD]; dmulv[b][0:latent] = dz + beta*mu/B ;
+// dmulv[b][latent:] = dz*eps*0.5*exp(0.5 lv) + beta*(-0.5)*(1-exp(lv))/B
+__global__ __launch_bounds__(256) void vae_loss_kernel(const float* __restrict__ mulv, int ld, int latent,
+                                                       int B, const double* __restrict__ mse_partial,
+                                                       int n_mse, double n_elems,
+                                                       const double* __restrict__ pm_partial,
+                                                       const int* __restrict__ pm_counts /*[4][2]: nblk/sample, per-sample elems*/,
+                                                       const float* __restrict__ pm_w, float alpha,
+                                                       float beta, float* __restrict__ metrics) {
+  __shared__ double sh[4];
+  double kl = 0.0;
+  for (int i = threadIdx.x; i < B * latent; i += 256) {
+    const int b = i / latent, j = i % latent;
+    const double mu = mulv[b * ld + j], lv = mulv[b * ld + latent + j];
+    kl += -0.5 * (1.0 + lv - mu * mu - exp(lv));
+  }
+  kl = block_sum_d(kl, sh);
+  double mse = 0.0;
+  for (int i = threadIdx.x; i < n_mse; i += 256) mse += mse_partial[i];
+  mse = block_sum_d(mse, sh) / n_elems;
+  double pm = 0.0;
+  size_t off = 0;
+  for (int l = 0; l < 4; ++l) {
+    const int nb = pm_counts[2 * l] * B;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nb; i += 256) s += pm_partial[off + i];
+    s = block_sum_d(s, sh);
+    pm += (double)pm_w[l] * s / (double)pm_counts[2 * l + 1];
+    off += nb;
+  }
+  if (threadIdx.x == 0) {
+    const double pm_mean = pm / B, kl_mean = kl / B;
+    metrics[0] = (float)(mse + alpha * pm_mean + beta * kl_mean);
+    metrics[1] = (float)pm_mean;
+    metrics[2] = (float)mse;
+    metrics[3] = (float)kl_mean;
+  }
+}
+__global__ void vae_dz_kernel(const float* __restrict__ mulv, int ld, int latent, int B,
+                              const float* __restrict__ eps, const float* __restrict__ dzc, int ldzc,
+                              float beta, float* __restrict__ dmulv) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * latent) return;
+  const int b = i / latent, j = i % latent;
+  const float mu = mulv[b * ld + j], lv = mulv[b * ld + latent + j];
+  const float dz = dzc[b * ldzc + j];
+  dmulv[b * ld + j] = dz + beta * mu / (float)B;
+  dmulv[b * ld + latent + j] =
+      dz * eps[b * latent + j] * 0.5f * expf(0.5f * lv) + beta * (-0.5f) * (1.f - expf(lv)) / (float)B;
+}
+int launch_vae_loss(hipStream_t st, const float* mulv, int ld, int latent, int B, const double* mse_partial,
+                    int n_mse, double n_elems, const double* pm_partial, const int* pm_counts,
+                    const float* pm_w, float alpha, float beta, float* metrics) {
+  hipLaunchKernelGGL(vae_loss_kernel, dim3(1), dim3(256), 0, st, mulv, ld, latent, B, mse_partial, n_mse,
+                     n_elems, pm_partial, pm_counts, pm_w, alpha, beta, metrics);
+  ICS_HIP(hipGetLastError());
+  return 0;
+}
+int launch_vae_dz(hipStream_t st, const float* mulv, int ld, int latent, int B, const float* eps,
+                  const float* dzc, int ldzc, float beta, float* dmulv) {
+  const int n = B * latent;
+  hipLaunchKernelGGL(vae_dz_kernel, dim3((n + 255) / 256), dim3(256), 0, st, mulv, ld, latent, B, eps, dzc,
+                     ldzc, beta, dmulv);
+  ICS_HIP(hipGetLastError());
+  return 0;
+}
+
+// relu backward for the Dense(256, relu): g *= (a > 0), where a is the stored relu OUTPUT
+__global__ void relu_bwd_kernel(const float* __restrict__ a, float* __restrict__ g, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && !(a[i] > 0.f)) g[i] = 0.f;
+}
+int launch_relu_bwd(hipStream_t st, const float* a, float* g, size_t n) {
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, g, n);
+  ICS_HIP(hipGetLastError());
+  return 0;
+}
+// column sums of a small [rows][cols] matrix (dense-layer bias gradients)
+__global__ void colsum_small_kernel(const float* __restrict__ a, int rows, int cols, int ld,
+                                    float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int r = 0; r < rows; ++r) s += a[(size_t)r * ld + c];
+  out[c] = s;
+}
+int launch_colsum_small(hipStream_t st, const float* a, int rows, int cols, int ld, float* out) {
+  hipLaunchKernelGGL(colsum_small_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, a, rows, cols, ld, out);
+  ICS_HIP(hipGetLastError());
+  return 0;
+}
+__global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, size_t n, float a) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] += a * x[i];
+}
+int launch_axpy(hipStream_t st, float* y, const float* x, size_t n, float a) {
+  hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, y, x, n, a);
+  ICS_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace ics

@@ -1,0 +1,1295 @@
+// Host-side engine: wires the HIP kernels into the two reference graphs
+//   AtomUnet.unet_3d_multiclass      /root/reference/unet/unet.py:272-355
+//   LatticeDFCVAE encoder/decoder    /root/reference/vae/lattice_vae.py:160-230
+// and their training steps (unet.py:252-259,370 ; lattice_vae.py:232-270,296), and exports the
+// C ABI declared in include/icsg3d.h.  One engine = one HIP stream on one device; everything a
+// step needs lives in HBM for the life of the handle (activations for B=32, d=32 are ~7 GB of 288).
+#include "common.h"
+#include "elementwise.h"
+#include "../../include/icsg3d.h"
+
+#include <rccl/rccl.h>
+
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <vector>
+
+namespace ics {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+
+static int ilog2(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// ------------------------------------------------------------------------------------------
+struct Tensor {
+  std::string name;
+  std::vector<int64_t> dims;
+  size_t count = 0;
+  bool trainable = false;
+  size_t off = 0;        // offset into the flat parameter buffer when trainable
+  float* ptr = nullptr;  // device pointer (state tensors own theirs; trainable: P + off)
+};
+
+struct Profiler {
+  struct Row { std::string label; int64_t launches = 0; double ms = 0, flop = 0, bytes = 0; };
+  struct Pending { int row; hipEvent_t a, b; };
+  bool on = false;
+  std::vector<Row> rows;
+  std::map<std::string, int> index;
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> pool;
+  hipEvent_t get() {
+    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    hipEvent_t e; (void)hipEventCreate(&e); return e;
+  }
+  void begin(hipStream_t st, const std::string& label, double flop, double bytes) {
+    if (!on) return;
+    auto it = index.find(label);
+    int r;
+    if (it == index.end()) { r = (int)rows.size(); rows.push_back(Row{label}); index[label] = r; }
+    else r = it->second;
+    rows[r].launches += 1; rows[r].flop += flop; rows[r].bytes += bytes;
+    Pending p{r, get(), get()};
+    (void)hipEventRecord(p.a, st);
+    pending.push_back(p);
+  }
+  void end(hipStream_t st) {
+    if (!on) return;
+    (void)hipEventRecord(pending.back().b, st);
+  }
+  void resolve() {   // call after a stream sync
+    for (auto& p : pending) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) rows[p.row].ms += ms;
+      pool.push_back(p.a); pool.push_back(p.b);
+    }
+    pending.clear();
+  }
+  void reset() { resolve(); rows.clear(); index.clear(); }
+};
+
+struct ConvLayer {
+  std::string name;
+  int Cin = 0, Cout = 0, taps = 27, S = 1;
+  int pre_act = ACT_NONE, has_bn = 0, post_act = ACT_NONE;
+  int Kpad = 0, Npad = 0, Kpad_b = 0, Npad_b = 0;
+  int t_w = -1, t_b = -1, t_gamma = -1, t_beta = -1;   // tensor indices
+  // BatchNorm state
+  float *mm = nullptr, *mv = nullptr, *mean = nullptr, *rstd = nullptr, *scale = nullptr, *shift = nullptr;
+  float *wp = nullptr, *wf = nullptr;   // packed forward / backward-data weights
+  float* s = nullptr;                   // stored output [M][Cout]
+  float* dy = nullptr;                  // grad w.r.t. conv output [M][Cout]
+  float* dA = nullptr;                  // grad w.r.t. virtual input [M][Cin]
+  float* c1c2 = nullptr;
+  float* pooled = nullptr;              // MaxPool3D(o) if a pool follows
+  unsigned char* pool_idx = nullptr;
+  ConvSrc src[2];
+  int nsrc = 1;
+};
+
+struct Net {
+  int kind = 0;   // 0 U-Net, 1 VAE
+  int device = 0;
+  hipStream_t st = nullptr;
+  int maxB = 0, d = 0, C = 0;
+  std::vector<void*> allocs;
+  std::vector<Tensor> tensors;
+  std::map<std::string, int> tindex;
+  size_t nparams = 0;
+  float *P = nullptr, *G = nullptr, *Mo = nullptr, *Vo = nullptr;
+  int adam_t = 0;
+  float lr = 1e-6f;
+  bool packed_valid = false;
+  int pool_ties_all = 1, bn_unbias = 1;
+  Profiler prof;
+  std::vector<std::unique_ptr<ConvLayer>> layers;
+  // shared workspaces
+  float* ws_stat = nullptr;  size_t ws_stat_n = 0;
+  float* ws_bwd = nullptr;   size_t ws_bwd_n = 0;
+  float* ws_wgrad = nullptr; size_t ws_wgrad_n = 0;
+  double* ws_dbl = nullptr;  size_t ws_dbl_n = 0;
+  float* d_metrics = nullptr;
+  // data parallel
+  ncclComm_t comm = nullptr;
+  int rank = 0, nranks = 1;
+  double* d_red = nullptr;
+
+  // U-Net specifics
+  int ncls = 95;
+  float loss_weight = 95.f;
+  float* x_in = nullptr;              // [maxB][d^3][C]
+  unsigned char* labels = nullptr;    // [maxB][d^3]
+  ConvLayer* head = nullptr;
+  float* head_bias_grad = nullptr;
+  float* tap_copy[4] = {nullptr, nullptr, nullptr, nullptr};   // perceptual taps of the x pass
+  float* dtap[4] = {nullptr, nullptr, nullptr, nullptr};
+  int resident_batch = 0;
+
+  // VAE specifics
+  Net* pm = nullptr;
+  int ncond = 10, latent = 256, filters[4] = {16, 32, 64, 128};
+  float alpha = 0.5f, beta = 3e-4f, pm_w[4] = {1, 1, 1, 1};
+  float *cond_in = nullptr, *eps_in = nullptr, *z_buf = nullptr, *zc = nullptr, *recon = nullptr,
+        *drecon = nullptr, *dmulv = nullptr, *d_pm_w = nullptr;
+  int* d_pm_counts = nullptr;
+  ConvLayer *enc_dense = nullptr, *zmulv = nullptr, *dec_dense = nullptr;
+
+  ~Net() {
+    if (comm) ncclCommDestroy(comm);
+    for (void* p : allocs) (void)hipFree(p);
+    if (st) (void)hipStreamDestroy(st);
+  }
+  template <typename T>
+  int alloc(T** out, size_t n) {
+    void* p = nullptr;
+    ICS_HIP(hipMalloc(&p, n * sizeof(T) + 256));
+    ICS_HIP(hipMemsetAsync(p, 0, n * sizeof(T) + 256, st));
+    allocs.push_back(p);
+    *out = reinterpret_cast<T*>(p);
+    return 0;
+  }
+  int add_tensor(const std::string& name, std::vector<int64_t> dims, bool trainable) {
+    Tensor t;
+    t.name = name; t.dims = dims; t.trainable = trainable;
+    t.count = 1;
+    for (auto v : dims) t.count *= (size_t)v;
+    if (trainable) { t.off = nparams; nparams += t.count; }
+    tensors.push_back(t);
+    tindex[name] = (int)tensors.size() - 1;
+    return (int)tensors.size() - 1;
+  }
+  float* tp(int ti) const { return P + tensors[ti].off; }
+  float* tg(int ti) const { return G + tensors[ti].off; }
+  size_t rows(const ConvLayer& L, int B) const { return (size_t)B * L.S * L.S * L.S; }
+};
+
+// ------------------------------------------------------------------------------------------
+// layer construction
+// ------------------------------------------------------------------------------------------
+static ConvLayer* add_conv(Net& n, const std::string& name, int Cin, int Cout, int taps, int S, int pre_act,
+                           int has_bn, int post_act, bool dense, bool register_params = true) {
+  auto L = std::make_unique<ConvLayer>();
+  L->name = name; L->Cin = Cin; L->Cout = Cout; L->taps = taps; L->S = S;
+  L->pre_act = pre_act; L->has_bn = has_bn; L->post_act = post_act;
+  L->Kpad = round_up(taps * Cin, 32); L->Npad = round_up(Cout, 32);
+  L->Kpad_b = round_up(taps * Cout, 32); L->Npad_b = round_up(Cin, 32);
+  if (register_params) {
+    if (dense) L->t_w = n.add_tensor(name + "/kernel", {Cin, Cout}, true);
+    else L->t_w = n.add_tensor(name + "/kernel", {taps == 27 ? 3 : 1, taps == 27 ? 3 : 1, taps == 27 ? 3 : 1, Cin, Cout}, true);
+    L->t_b = n.add_tensor(name + "/bias", {Cout}, true);
+    if (has_bn) {
+      L->t_gamma = n.add_tensor(name + "/gamma", {Cout}, true);
+      L->t_beta = n.add_tensor(name + "/beta", {Cout}, true);
+    }
+  }
+  n.layers.push_back(std::move(L));
+  return n.layers.back().get();
+}
+
+static int alloc_layer(Net& n, ConvLayer& L, bool need_bwd, bool pooled) {
+  const size_t M = n.rows(L, n.maxB);
+  ICS_TRY(n.alloc(&L.wp, (size_t)L.Kpad * L.Npad));
+  ICS_TRY(n.alloc(&L.s, M * L.Cout));
+  if (need_bwd) {
+    ICS_TRY(n.alloc(&L.wf, (size_t)L.Kpad_b * L.Npad_b));
+    ICS_TRY(n.alloc(&L.dy, M * L.Cout));
+    ICS_TRY(n.alloc(&L.dA, M * L.Cin));
+    ICS_TRY(n.alloc(&L.c1c2, (size_t)2 * L.Cout));
+  }
+  if (L.has_bn) {
+    ICS_TRY(n.alloc(&L.mm, (size_t)L.Cout)); ICS_TRY(n.alloc(&L.mv, (size_t)L.Cout));
+    ICS_TRY(n.alloc(&L.mean, (size_t)L.Cout)); ICS_TRY(n.alloc(&L.rstd, (size_t)L.Cout));
+    ICS_TRY(n.alloc(&L.scale, (size_t)L.Cout)); ICS_TRY(n.alloc(&L.shift, (size_t)L.Cout));
+    int ti = n.add_tensor(L.name + "/moving_mean", {L.Cout}, false);
+    n.tensors[ti].ptr = L.mm;
+    ti = n.add_tensor(L.name + "/moving_var", {L.Cout}, false);
+    n.tensors[ti].ptr = L.mv;
+  }
+  if (pooled) {
+    ICS_TRY(n.alloc(&L.pooled, M / 8 * L.Cout));
+    ICS_TRY(n.alloc(&L.pool_idx, M / 8 * L.Cout));
+  }
+  return 0;
+}
+
+static ConvSrc src_plain(const float* p, int C) { return ConvSrc{p, nullptr, nullptr, C, 0, ACT_NONE, 0}; }
+static ConvSrc src_layer(const ConvLayer& L, int up) {
+  if (L.has_bn) return ConvSrc{L.s, L.scale, L.shift, L.Cout, up, L.post_act, 0};
+  return ConvSrc{L.s, nullptr, nullptr, L.Cout, up, ACT_NONE, 0};
+}
+
+static ConvGeom geom_fwd(const ConvLayer& L, int B) {
+  return ConvGeom{B, L.S, ilog2(L.S), L.Cin, L.Cout, L.taps, L.Kpad, L.Npad};
+}
+static ConvGeom geom_bwd(const ConvLayer& L, int B) {
+  return ConvGeom{B, L.S, ilog2(L.S), L.Cout, L.Cin, L.taps, L.Kpad_b, L.Npad_b};
+}
+
+// workspace sizing over all layers (max batch)
+static int alloc_workspaces(Net& n, bool need_bwd) {
+  size_t stat = 0, bwd = 0, wg = 0;
+  for (auto& Lp : n.layers) {
+    ConvLayer& L = *Lp;
+    const size_t M = n.rows(L, n.maxB);
+    const ConvGeom g = geom_fwd(L, n.maxB);
+    const int rpb = conv_fwd_rows_per_block(g);
+    stat = std::max(stat, (M + rpb - 1) / rpb * 3 * (size_t)L.Npad);
+    if (need_bwd) {
+      LayerBwd lb{};
+      lb.B = n.maxB; lb.S = L.S; lb.lgS = ilog2(L.S); lb.C = L.Cout;
+      // Cout may be a non power of two only for the head, which never goes through layer_bwd
+      if ((L.Cout & (L.Cout - 1)) == 0) bwd = std::max(bwd, layer_bwd_workspace_floats(lb));
+      wg = std::max(wg, conv_wgrad_workspace_floats(g, L.src, L.nsrc));
+    }
+  }
+  n.ws_stat_n = stat; n.ws_bwd_n = std::max(bwd, (size_t)4096 * 128); n.ws_wgrad_n = wg;
+  ICS_TRY(n.alloc(&n.ws_stat, stat + 16));
+  if (need_bwd) {
+    ICS_TRY(n.alloc(&n.ws_bwd, n.ws_bwd_n + 16));
+    ICS_TRY(n.alloc(&n.ws_wgrad, wg + 16));
+  }
+  n.ws_dbl_n = 1 << 16;
+  ICS_TRY(n.alloc(&n.ws_dbl, n.ws_dbl_n));
+  ICS_TRY(n.alloc(&n.d_metrics, (size_t)16));
+  ICS_TRY(n.alloc(&n.d_red, (size_t)2));
+  return 0;
+}
+
+static int alloc_params(Net& n) {
+  ICS_TRY(n.alloc(&n.P, n.nparams)); ICS_TRY(n.alloc(&n.G, n.nparams));
+  ICS_TRY(n.alloc(&n.Mo, n.nparams)); ICS_TRY(n.alloc(&n.Vo, n.nparams));
+  for (auto& t : n.tensors)
+    if (t.trainable) t.ptr = n.P + t.off;
+  return 0;
+}
+
+// BN defaults: gamma 1, moving_var 1 (keras initialisers); everything else zero
+__global__ void fill_kernel(float* p, size_t n, float v) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+static int fill(Net& n, float* p, size_t cnt, float v) {
+  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, n.st, p, cnt, v);
+  ICS_HIP(hipGetLastError());
+  return 0;
+}
+static int init_bn_defaults(Net& n) {
+  for (auto& Lp : n.layers)
+    if (Lp->has_bn) {
+      ICS_TRY(fill(n, n.tp(Lp->t_gamma), Lp->Cout, 1.f));
+      ICS_TRY(fill(n, Lp->mv, Lp->Cout, 1.f));
+    }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// weight packing (after every parameter change)
+// ------------------------------------------------------------------------------------------
+static int pack_layer(Net& n, ConvLayer& L, bool need_bwd) {
+  ICS_TRY(launch_pack_fwd(n.st, n.tp(L.t_w), L.taps * L.Cin, L.Cout, L.wp, L.Kpad, L.Npad, 0, 0, 1));
+  if (need_bwd && L.wf)
+    ICS_TRY(launch_pack_bwd(n.st, n.tp(L.t_w), L.taps, L.Cin, L.Cout, L.wf, L.Kpad_b, L.Npad_b, L.Cout, 0, 1));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// generic layer forward / backward
+// ------------------------------------------------------------------------------------------
+static int conv_forward(Net& n, ConvLayer& L, int B, bool training, bool update_moving, const float* bias) {
+  const ConvGeom g = geom_fwd(L, B);
+  const size_t M = n.rows(L, B);
+  const bool stats = L.has_bn && training;
+  int rpb = 128;
+  n.prof.begin(n.st, "conv_fwd:" + L.name, 2.0 * M * L.taps * L.Cin * L.Cout,
+               4.0 * (M * L.Cin + M * L.Cout + (double)L.taps * L.Cin * L.Cout));
+  ICS_TRY(launch_conv_fwd(n.st, g, L.src, L.nsrc, L.wp, bias, L.s, L.Cout, L.pre_act,
+                          stats ? n.ws_stat : nullptr, &rpb));
+  n.prof.end(n.st);
+  if (L.has_bn) {
+    BnParams bn{n.tp(L.t_gamma), n.tp(L.t_beta), L.mm, L.mv, L.mean, L.rstd, L.scale, L.shift};
+    if (training) {
+      const int nblk = (int)((M + rpb - 1) / rpb);
+      ICS_TRY(launch_bn_finalize(n.st, n.ws_stat, nblk, L.Npad, bn, L.Cout, update_moving ? 1 : 0, n.bn_unbias));
+    } else {
+      ICS_TRY(launch_bn_eval_prepare(n.st, bn, L.Cout));
+    }
+  }
+  if (L.pooled) {
+    n.prof.begin(n.st, "pool_fwd", 0, 4.0 * M * L.Cout * 1.125);
+    ICS_TRY(launch_pool_fwd(n.st, L.s, L.has_bn ? L.scale : nullptr, L.shift, L.has_bn ? L.post_act : ACT_NONE,
+                            B, L.S, L.Cout, L.pooled, L.pool_idx));
+    n.prof.end(n.st);
+  }
+  return 0;
+}
+
+static GradSrc gs_none() { return GradSrc{nullptr, 0, 0, GS_NONE, nullptr, nullptr}; }
+static GradSrc gs_direct(const float* p, int ld, int off) { return GradSrc{p, ld, off, GS_DIRECT, nullptr, nullptr}; }
+static GradSrc gs_up(const float* p, int ld, int off) { return GradSrc{p, ld, off, GS_UP, nullptr, nullptr}; }
+static GradSrc gs_pool(const float* p, int ld, const ConvLayer& producer) {
+  return GradSrc{p, ld, 0, GS_POOL, producer.pooled, producer.pool_idx};
+}
+
+// weight / input gradients given L.dy
+static int conv_grads_from_dy(Net& n, ConvLayer& L, int B, bool need_dA, bool param_grads) {
+  const ConvGeom g = geom_fwd(L, B);
+  const size_t M = n.rows(L, B);
+  if (param_grads) {
+    n.prof.begin(n.st, "conv_wgrad:" + L.name, 2.0 * M * L.taps * L.Cin * L.Cout,
+                 4.0 * (M * L.Cin + M * L.Cout + (double)L.taps * L.Cin * L.Cout));
+    ICS_TRY(launch_conv_wgrad(n.st, g, L.src, L.nsrc, L.dy, L.Cout, n.tg(L.t_w), L.Cout, n.ws_wgrad, n.ws_wgrad_n));
+    n.prof.end(n.st);
+  }
+  if (need_dA) {
+    const ConvGeom gb = geom_bwd(L, B);
+    ConvSrc sdy = src_plain(L.dy, L.Cout);
+    n.prof.begin(n.st, "conv_dgrad:" + L.name, 2.0 * M * L.taps * L.Cin * L.Cout,
+                 4.0 * (M * L.Cin + M * L.Cout + (double)L.taps * L.Cin * L.Cout));
+    ICS_TRY(launch_conv_fwd(n.st, gb, &sdy, 1, L.wf, nullptr, L.dA, L.Cin, ACT_NONE, nullptr, nullptr));
+    n.prof.end(n.st);
+  }
+  return 0;
+}
+
+static int conv_backward(Net& n, ConvLayer& L, int B, GradSrc g0, GradSrc g1, const float* dtap, bool need_dA,
+                         bool param_grads) {
+  LayerBwd lb{};
+  lb.s = L.s; lb.scale = L.scale; lb.shift = L.shift; lb.mean = L.mean; lb.rstd = L.rstd;
+  lb.dtap = dtap; lb.g0 = g0; lb.g1 = g1;
+  lb.B = B; lb.S = L.S; lb.lgS = ilog2(L.S); lb.C = L.Cout;
+  lb.has_bn = L.has_bn; lb.pre_act = L.pre_act; lb.post_act = L.post_act;
+  lb.pool_ties_all = n.pool_ties_all;
+  const size_t M = n.rows(L, B);
+  n.prof.begin(n.st, "bn_act_bwd", 0, 4.0 * M * L.Cout * (L.has_bn ? 5.0 : 3.0));
+  ICS_TRY(launch_layer_bwd(n.st, lb, L.dy, n.ws_bwd, L.c1c2,
+                           (param_grads && L.has_bn) ? n.tg(L.t_gamma) : nullptr,
+                           (param_grads && L.has_bn) ? n.tg(L.t_beta) : nullptr,
+                           param_grads ? n.tg(L.t_b) : nullptr));
+  n.prof.end(n.st);
+  return conv_grads_from_dy(n, L, B, need_dA, param_grads);
+}
+
+static int adam_step(Net& n) {
+  float gscale = 1.f;
+  if (n.comm) {
+    n.prof.begin(n.st, "rccl_allreduce_grads", 0, 4.0 * n.nparams);
+    ncclResult_t r = ncclAllReduce(n.G, n.G, n.nparams, ncclFloat, ncclSum, n.comm, n.st);
+    n.prof.end(n.st);
+    ICS_CHECK(r == ncclSuccess, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+    gscale = 1.f / (float)n.nranks;
+  }
+  n.adam_t += 1;
+  const double b1 = 0.9, b2 = 0.999;
+  const double lr_t = (double)n.lr * std::sqrt(1.0 - std::pow(b2, n.adam_t)) / (1.0 - std::pow(b1, n.adam_t));
+  n.prof.begin(n.st, "adam", 0, 4.0 * 7 * n.nparams);
+  ICS_TRY(launch_adam(n.st, n.P, n.G, n.Mo, n.Vo, n.nparams, (float)lr_t, gscale));
+  n.prof.end(n.st);
+  n.packed_valid = false;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// U-Net
+// ------------------------------------------------------------------------------------------
+struct UnetRefs {
+  ConvLayer *c1, *c2, *c3, *c4, *c5, *c6, *c9, *c10, *c13, *c14, *c15, *c16, *c17, *c18;
+};
+static UnetRefs unet_refs(Net& n) {
+  UnetRefs r;
+  ConvLayer** f[] = {&r.c1, &r.c2, &r.c3, &r.c4, &r.c5, &r.c6, &r.c9, &r.c10, &r.c13, &r.c14, &r.c15, &r.c16, &r.c17, &r.c18};
+  for (int i = 0; i < 14; ++i) *f[i] = n.layers[i].get();
+  return r;
+}
+
+static int unet_build(Net& n, const ics_unet_config& cfg) {
+  n.kind = 0; n.maxB = cfg.max_batch; n.d = cfg.d; n.C = cfg.in_channels; n.ncls = cfg.num_classes;
+  n.lr = cfg.lr; n.loss_weight = cfg.loss_weight > 0 ? cfg.loss_weight : (float)cfg.num_classes;
+  n.pool_ties_all = cfg.pool_ties_all; n.bn_unbias = cfg.bn_unbias;
+  const int d = cfg.d;
+  struct Spec { const char* name; int cin, cout, S; bool pooled; };
+  const Spec specs[14] = {
+      {"c1", cfg.in_channels, 32, d, false}, {"c2", 32, 64, d, true},
+      {"c3", 64, 64, d / 2, false},          {"c4", 64, 128, d / 2, true},
+      {"c5", 128, 128, d / 4, false},        {"c6", 128, 256, d / 4, true},
+      {"c9", 256, 512, d / 8, false},        {"c10", 512, 512, d / 8, false},
+      {"c13", 768, 512, d / 4, false},       {"c14", 512, 256, d / 4, false},
+      {"c15", 384, 256, d / 2, false},       {"c16", 256, 128, d / 2, false},
+      {"c17", 192, 128, d, false},           {"c18", 128, 128, d, false}};
+  for (auto& s : specs) add_conv(n, s.name, s.cin, s.cout, 27, s.S, ACT_RELU, 1, ACT_NONE, false);
+  // heads: one 1x1x1 GEMM with N = num_classes + 1; params keep the reference's two layers
+  n.head = add_conv(n, "head", 128, cfg.num_classes + 1, 1, d, ACT_NONE, 0, ACT_NONE, false, false);
+  const int t_sw = n.add_tensor("soft/kernel", {1, 1, 1, 128, cfg.num_classes}, true);
+  const int t_gw = n.add_tensor("sig/kernel", {1, 1, 1, 128, 1}, true);
+  const int t_sb = n.add_tensor("soft/bias", {cfg.num_classes}, true);   // soft/bias | sig/bias contiguous
+  n.add_tensor("sig/bias", {1}, true);
+  n.head->t_w = t_sw; n.head->t_b = t_sb; n.head->t_gamma = t_gw;   // t_gamma slot reused: sig kernel index
+  ICS_TRY(alloc_params(n));
+  const size_t M = (size_t)n.maxB * d * d * d;
+  ICS_TRY(n.alloc(&n.x_in, M * n.C));
+  ICS_TRY(n.alloc(&n.labels, M));
+  for (int i = 0; i < 14; ++i) ICS_TRY(alloc_layer(n, *n.layers[i], true, specs[i].pooled));
+  ICS_TRY(alloc_layer(n, *n.head, true, false));
+  ICS_TRY(n.alloc(&n.head_bias_grad, (size_t)256));
+  UnetRefs r = unet_refs(n);
+  r.c1->src[0] = src_plain(n.x_in, n.C);
+  r.c2->src[0] = src_layer(*r.c1, 0);
+  r.c3->src[0] = src_plain(r.c2->pooled, 64);
+  r.c4->src[0] = src_layer(*r.c3, 0);
+  r.c5->src[0] = src_plain(r.c4->pooled, 128);
+  r.c6->src[0] = src_layer(*r.c5, 0);
+  r.c9->src[0] = src_plain(r.c6->pooled, 256);
+  r.c10->src[0] = src_layer(*r.c9, 0);
+  r.c13->src[0] = src_layer(*r.c6, 0); r.c13->src[1] = src_layer(*r.c10, 1); r.c13->nsrc = 2;   // [skip | up]
+  r.c14->src[0] = src_layer(*r.c13, 0);
+  r.c15->src[0] = src_layer(*r.c4, 0); r.c15->src[1] = src_layer(*r.c14, 1); r.c15->nsrc = 2;
+  r.c16->src[0] = src_layer(*r.c15, 0);
+  r.c17->src[0] = src_layer(*r.c2, 0); r.c17->src[1] = src_layer(*r.c16, 1); r.c17->nsrc = 2;
+  r.c18->src[0] = src_layer(*r.c17, 0);
+  n.head->src[0] = src_layer(*r.c18, 0);
+  ICS_TRY(alloc_workspaces(n, true));
+  ICS_TRY(init_bn_defaults(n));
+  return 0;
+}
+
+static int unet_pack(Net& n) {
+  if (n.packed_valid) return 0;
+  for (int i = 0; i < 14; ++i) ICS_TRY(pack_layer(n, *n.layers[i], true));
+  ConvLayer& H = *n.head;
+  const int ncls = n.ncls;
+  const float* wsoft = n.tp(H.t_w);
+  const float* wsig = n.tp(H.t_gamma);
+  ICS_TRY(launch_pack_fwd(n.st, wsoft, 128, ncls, H.wp, H.Kpad, H.Npad, 0, 0, 1));
+  ICS_TRY(launch_pack_fwd(n.st, wsig, 128, 1, H.wp, H.Kpad, H.Npad, 0, ncls, 0));
+  ICS_TRY(launch_pack_bwd(n.st, wsoft, 1, 128, ncls, H.wf, H.Kpad_b, H.Npad_b, ncls + 1, 0, 1));
+  ICS_TRY(launch_pack_bwd(n.st, wsig, 1, 128, 1, H.wf, H.Kpad_b, H.Npad_b, ncls + 1, ncls, 0));
+  n.packed_valid = true;
+  return 0;
+}
+
+// trunk forward; upto_c10 for the perceptual sub-model (lattice_vae.py:257-270)
+static int unet_forward_trunk(Net& n, int B, bool training, bool update_moving, bool upto_c10, const float* input) {
+  ICS_TRY(unet_pack(n));
+  UnetRefs r = unet_refs(n);
+  r.c1->src[0].p = input;
+  const int last = upto_c10 ? 8 : 14;
+  for (int i = 0; i < last; ++i) {
+    ConvLayer& L = *n.layers[i];
+    ICS_TRY(conv_forward(n, L, B, training, update_moving, n.tp(L.t_b)));
+  }
+  return 0;
+}
+
+static int unet_head_forward(Net& n, int B) {
+  ConvLayer& H = *n.head;
+  return conv_forward(n, H, B, false, false, n.tp(H.t_b));
+}
+
+static int unet_loss(Net& n, int B, int mode, int want_grad) {
+  const size_t M = n.rows(*n.head, B);
+  n.prof.begin(n.st, "head_softmax_loss", 0, 4.0 * M * (n.ncls + 1) * 2);
+  ICS_TRY(launch_head(n.st, n.head->s, n.ncls + 1, n.ncls, n.labels, M, mode, want_grad, n.loss_weight,
+                      n.ws_dbl, 2048, n.d_metrics));
+  n.prof.end(n.st);
+  return 0;
+}
+
+// small generic column-sum (head bias gradient): rows blocked, 32 columns x 8 rows per pass
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ a, size_t M, int C, int ld,
+                                                              int rows_per_block, float* __restrict__ partial) {
+  __shared__ float sh[256];
+  const int tc = threadIdx.x & 31, tr = threadIdx.x >> 5;
+  const size_t r0 = (size_t)blockIdx.x * rows_per_block;
+  const size_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+  for (int cg = 0; cg < C; cg += 32) {
+    const int c = cg + tc;
+    float acc = 0.f;
+    if (c < C)
+      for (size_t row = r0 + tr; row < r1; row += 8) acc += a[row * ld + c];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < 32 && c < C) {
+      float s = 0.f;
+      for (int r = 0; r < 8; ++r) s += sh[r * 32 + threadIdx.x];
+      partial[(size_t)blockIdx.x * C + c] = s;
+    }
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(256) void colsum_merge_kernel(const float* __restrict__ partial, int nblk, int C,
+                                                            float* __restrict__ out) {
+  __shared__ double shd[256];
+  const int c = blockIdx.x;
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += 256) s += (double)partial[(size_t)b * C + c];
+  shd[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) shd[threadIdx.x] += shd[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[c] = (float)shd[0];
+}
+static int colsum(Net& n, const float* a, size_t M, int C, int ld, float* out) {
+  int nblk = (int)std::min<size_t>(1024, (M + 63) / 64);
+  if ((size_t)nblk * C > n.ws_bwd_n) nblk = (int)(n.ws_bwd_n / C);
+  const int rpb = (int)((M + nblk - 1) / nblk);
+  nblk = (int)((M + rpb - 1) / rpb);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, n.st, a, M, C, ld, rpb, n.ws_bwd);
+  ICS_HIP(hipGetLastError());
+  hipLaunchKernelGGL(colsum_merge_kernel, dim3(C), dim3(256), 0, n.st, n.ws_bwd, nblk, C, out);
+  ICS_HIP(hipGetLastError());
+  return 0;
+}
+
+static int unet_backward(Net& n, int B) {
+  UnetRefs r = unet_refs(n);
+  ConvLayer& H = *n.head;
+  const size_t M = n.rows(H, B);
+  const int nc1 = n.ncls + 1;
+  // head: dz is in H.s (written by the loss kernel)
+  const ConvGeom gh = geom_fwd(H, B);
+  {
+    ConvGeom gs = gh; gs.Cout = n.ncls; gs.Npad = round_up(n.ncls, 32);
+    n.prof.begin(n.st, "conv_wgrad:head", 2.0 * M * 128 * nc1, 4.0 * M * (128 + nc1));
+    ICS_TRY(launch_conv_wgrad(n.st, gs, H.src, 1, H.s, nc1, n.tg(H.t_w), n.ncls, n.ws_wgrad, n.ws_wgrad_n));
+    ConvGeom gg = gh; gg.Cout = 1; gg.Npad = 32;
+    ICS_TRY(launch_conv_wgrad(n.st, gg, H.src, 1, H.s + n.ncls, nc1, n.tg(H.t_gamma), 1, n.ws_wgrad, n.ws_wgrad_n));
+    n.prof.end(n.st);
+    ICS_TRY(colsum(n, H.s, M, nc1, nc1, n.tg(H.t_b)));   // soft/bias | sig/bias are contiguous
+    const ConvGeom gb = geom_bwd(H, B);
+    ConvSrc sdz = src_plain(H.s, nc1);
+    n.prof.begin(n.st, "conv_dgrad:head", 2.0 * M * 128 * nc1, 4.0 * M * (128 + nc1));
+    ICS_TRY(launch_conv_fwd(n.st, gb, &sdz, 1, H.wf, nullptr, H.dA, 128, ACT_NONE, nullptr, nullptr));
+    n.prof.end(n.st);
+  }
+  auto bw = [&](ConvLayer* L, GradSrc g0, GradSrc g1, bool need_dA) {
+    return conv_backward(n, *L, B, g0, g1, nullptr, need_dA, true);
+  };
+  ICS_TRY(bw(r.c18, gs_direct(H.dA, 128, 0), gs_none(), true));
+  ICS_TRY(bw(r.c17, gs_direct(r.c18->dA, 128, 0), gs_none(), true));
+  ICS_TRY(bw(r.c16, gs_up(r.c17->dA, 192, 64), gs_none(), true));
+  ICS_TRY(bw(r.c15, gs_direct(r.c16->dA, 256, 0), gs_none(), true));
+  ICS_TRY(bw(r.c14, gs_up(r.c15->dA, 384, 128), gs_none(), true));
+  ICS_TRY(bw(r.c13, gs_direct(r.c14->dA, 512, 0), gs_none(), true));
+  ICS_TRY(bw(r.c10, gs_up(r.c13->dA, 768, 256), gs_none(), true));
+  ICS_TRY(bw(r.c9, gs_direct(r.c10->dA, 512, 0), gs_none(), true));
+  ICS_TRY(bw(r.c6, gs_pool(r.c9->dA, 256, *r.c6), gs_direct(r.c13->dA, 768, 0), true));
+  ICS_TRY(bw(r.c5, gs_direct(r.c6->dA, 128, 0), gs_none(), true));
+  ICS_TRY(bw(r.c4, gs_pool(r.c5->dA, 128, *r.c4), gs_direct(r.c15->dA, 384, 0), true));
+  ICS_TRY(bw(r.c3, gs_direct(r.c4->dA, 64, 0), gs_none(), true));
+  ICS_TRY(bw(r.c2, gs_pool(r.c3->dA, 64, *r.c2), gs_direct(r.c17->dA, 192, 0), true));
+  ICS_TRY(bw(r.c1, gs_direct(r.c2->dA, 32, 0), gs_none(), false));
+  return 0;
+}
+
+// perceptual sub-model backward: gradients w.r.t. the input given dtap (weights frozen)
+static int unet_pm_backward(Net& n, int B) {
+  UnetRefs r = unet_refs(n);
+  auto bw = [&](ConvLayer* L, GradSrc g0, const float* dtap, bool need_dA) {
+    return conv_backward(n, *L, B, g0, gs_none(), dtap, need_dA, false);
+  };
+  ICS_TRY(bw(r.c10, gs_none(), n.dtap[3], true));
+  ICS_TRY(bw(r.c9, gs_direct(r.c10->dA, 512, 0), nullptr, true));
+  ICS_TRY(bw(r.c6, gs_pool(r.c9->dA, 256, *r.c6), n.dtap[2], true));
+  ICS_TRY(bw(r.c5, gs_direct(r.c6->dA, 128, 0), nullptr, true));
+  ICS_TRY(bw(r.c4, gs_pool(r.c5->dA, 128, *r.c4), n.dtap[1], true));
+  ICS_TRY(bw(r.c3, gs_direct(r.c4->dA, 64, 0), nullptr, true));
+  ICS_TRY(bw(r.c2, gs_pool(r.c3->dA, 64, *r.c2), n.dtap[0], true));
+  ICS_TRY(bw(r.c1, gs_direct(r.c2->dA, 32, 0), nullptr, true));
+  return 0;
+}
+
+static int unet_train_resident(Net& n, int B, float* metrics) {
+  ICS_TRY(unet_forward_trunk(n, B, true, true, false, n.x_in));
+  ICS_TRY(unet_head_forward(n, B));
+  ICS_TRY(unet_loss(n, B, 1, 1));
+  ICS_TRY(unet_backward(n, B));
+  ICS_TRY(adam_step(n));
+  if (metrics) {
+    ICS_HIP(hipMemcpyAsync(metrics, n.d_metrics, 5 * sizeof(float), hipMemcpyDeviceToHost, n.st));
+    ICS_HIP(hipStreamSynchronize(n.st));
+    n.prof.resolve();
+  }
+  return 0;
+}
+
+static int unet_upload(Net& n, const float* x, const unsigned char* labels, int B) {
+  ICS_CHECK(B >= 1 && B <= n.maxB, "batch exceeds max_batch");
+  const size_t M = (size_t)B * n.d * n.d * n.d;
+  ICS_HIP(hipMemcpyAsync(n.x_in, x, M * n.C * sizeof(float), hipMemcpyHostToDevice, n.st));
+  if (labels) ICS_HIP(hipMemcpyAsync(n.labels, labels, M, hipMemcpyHostToDevice, n.st));
+  n.resident_batch = B;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// VAE
+// ------------------------------------------------------------------------------------------
+struct VaeRefs {
+  ConvLayer *e[4], *e4, *encd, *zml, *decd, *dl[4], *dout;
+};
+static VaeRefs vae_refs(Net& n) {
+  VaeRefs r;
+  int i = 0;
+  for (int k = 0; k < 4; ++k) r.e[k] = n.layers[i++].get();
+  r.e4 = n.layers[i++].get(); r.encd = n.layers[i++].get(); r.zml = n.layers[i++].get();
+  r.decd = n.layers[i++].get();
+  for (int k = 0; k < 4; ++k) r.dl[k] = n.layers[i++].get();
+  r.dout = n.layers[i++].get();
+  return r;
+}
+
+static int vae_build(Net& n, const ics_vae_config& cfg, Net* pm) {
+  n.kind = 1; n.maxB = cfg.max_batch; n.d = cfg.d; n.C = cfg.in_channels; n.pm = pm;
+  n.ncond = cfg.cond_shape; n.latent = cfg.latent_dim; n.lr = cfg.lr; n.alpha = cfg.alpha; n.beta = cfg.beta;
+  n.bn_unbias = cfg.bn_unbias; n.pool_ties_all = pm ? pm->pool_ties_all : 1;
+  for (int i = 0; i < 4; ++i) { n.filters[i] = cfg.filters[i]; n.pm_w[i] = cfg.pm_layer_weights[i]; }
+  const int d = cfg.d, C = cfg.in_channels, lat = cfg.latent_dim;
+  ICS_CHECK(d >= 16 && (d & (d - 1)) == 0, "d must be a power of two >= 16");
+  int cin = C + C * cfg.cond_shape;   // K.tile quirk: cond channels = C*cond_shape
+  int S = d;
+  for (int i = 0; i < 4; ++i) {
+    add_conv(n, "e" + std::to_string(i), cin, cfg.filters[i], 27, S, ACT_NONE, 1, ACT_LRELU, false);
+    cin = cfg.filters[i]; S /= 2;
+  }
+  add_conv(n, "e4", cin, 4, 27, S, ACT_LRELU, 0, ACT_NONE, false);        // S = d/16
+  const int flat = S * S * S * 4;
+  add_conv(n, "enc_dense", flat, lat, 1, 1, ACT_RELU, 0, ACT_NONE, true);
+  // z_mean | z_log_var as one GEMM with N = 2*latent; parameters stay two reference layers
+  ConvLayer* zml = add_conv(n, "zmulv", lat, 2 * lat, 1, 1, ACT_NONE, 0, ACT_NONE, true, false);
+  const int t_zm = n.add_tensor("z_mean/kernel", {lat, lat}, true);
+  const int t_zl = n.add_tensor("z_log_var/kernel", {lat, lat}, true);
+  const int t_zb = n.add_tensor("z_mean/bias", {lat}, true);   // z_mean/bias | z_log_var/bias contiguous
+  n.add_tensor("z_log_var/bias", {lat}, true);
+  zml->t_w = t_zm; zml->t_gamma = t_zl; zml->t_b = t_zb;
+  const int seedS = d / 8, seed = seedS * seedS * seedS * 4;
+  add_conv(n, "dec_dense", lat + cfg.cond_shape, seed, 1, 1, ACT_NONE, 0, ACT_NONE, true);
+  cin = 4; S = seedS;
+  for (int i = 0; i < 4; ++i) {
+    add_conv(n, "d" + std::to_string(i), cin, cfg.filters[3 - i], 27, S, ACT_NONE, 1, ACT_LRELU, false);
+    cin = cfg.filters[3 - i];
+    if (i < 3) S *= 2;
+  }
+  add_conv(n, "dout", cin, C, 27, S, ACT_NONE, 1, ACT_RELU, false);
+  ICS_TRY(alloc_params(n));
+  const size_t M = (size_t)n.maxB * d * d * d;
+  ICS_TRY(n.alloc(&n.x_in, M * C));
+  ICS_TRY(n.alloc(&n.cond_in, (size_t)n.maxB * cfg.cond_shape));
+  ICS_TRY(n.alloc(&n.eps_in, (size_t)n.maxB * lat));
+  ICS_TRY(n.alloc(&n.z_buf, (size_t)n.maxB * lat));
+  ICS_TRY(n.alloc(&n.zc, (size_t)n.maxB * (lat + cfg.cond_shape)));
+  ICS_TRY(n.alloc(&n.recon, M * C));
+  ICS_TRY(n.alloc(&n.drecon, M * C));
+  ICS_TRY(n.alloc(&n.dmulv, (size_t)n.maxB * 2 * lat));
+  ICS_TRY(n.alloc(&n.d_pm_w, (size_t)4));
+  ICS_TRY(n.alloc(&n.d_pm_counts, (size_t)8));
+  VaeRefs r = vae_refs(n);
+  for (int i = 0; i < 4; ++i) ICS_TRY(alloc_layer(n, *r.e[i], true, true));
+  ICS_TRY(alloc_layer(n, *r.e4, true, false));
+  ICS_TRY(alloc_layer(n, *r.encd, true, false));
+  ICS_TRY(alloc_layer(n, *r.zml, true, false));
+  ICS_TRY(alloc_layer(n, *r.decd, true, false));
+  for (int i = 0; i < 4; ++i) ICS_TRY(alloc_layer(n, *r.dl[i], true, false));
+  ICS_TRY(alloc_layer(n, *r.dout, true, false));
+  // sources
+  r.e[0]->src[0] = src_plain(n.x_in, C);
+  r.e[0]->src[1] = ConvSrc{n.cond_in, nullptr, nullptr, C * cfg.cond_shape, 0, ACT_NONE, cfg.cond_shape};
+  r.e[0]->nsrc = 2;
+  for (int i = 1; i < 4; ++i) r.e[i]->src[0] = src_plain(r.e[i - 1]->pooled, r.e[i - 1]->Cout);
+  r.e4->src[0] = src_plain(r.e[3]->pooled, r.e[3]->Cout);
+  r.encd->src[0] = src_plain(r.e4->s, flat);
+  r.zml->src[0] = src_plain(r.encd->s, lat);
+  r.decd->src[0] = src_plain(n.zc, lat + cfg.cond_shape);
+  r.dl[0]->src[0] = src_plain(r.decd->s, 4);
+  for (int i = 1; i < 4; ++i) r.dl[i]->src[0] = src_layer(*r.dl[i - 1], 1);   // UpSampling3D after d0..d2
+  r.dout->src[0] = src_layer(*r.dl[3], 0);
+  ICS_TRY(alloc_workspaces(n, true));
+  ICS_TRY(init_bn_defaults(n));
+  if (pm) {
+    // perceptual tap copies / gradients live with the U-Net (sized for ITS max batch)
+    UnetRefs u = unet_refs(*pm);
+    ConvLayer* taps[4] = {u.c2, u.c4, u.c6, u.c10};
+    ICS_CHECK(pm->maxB >= n.maxB && pm->d == d && pm->C == C, "perceptual U-Net shape mismatch");
+    int counts[8];
+    for (int l = 0; l < 4; ++l) {
+      const size_t cnt = pm->rows(*taps[l], pm->maxB) * taps[l]->Cout;
+      if (!pm->tap_copy[l]) { ICS_TRY(pm->alloc(&pm->tap_copy[l], cnt)); ICS_TRY(pm->alloc(&pm->dtap[l], cnt)); }
+      counts[2 * l] = 8;   // blocks per sample
+      counts[2 * l + 1] = taps[l]->S * taps[l]->S * taps[l]->S * taps[l]->Cout;
+    }
+    ICS_HIP(hipMemcpyAsync(n.d_pm_counts, counts, sizeof(counts), hipMemcpyHostToDevice, n.st));
+    ICS_HIP(hipMemcpyAsync(n.d_pm_w, n.pm_w, 4 * sizeof(float), hipMemcpyHostToDevice, n.st));
+    ICS_HIP(hipStreamSynchronize(n.st));
+    ICS_HIP(hipStreamSynchronize(pm->st));
+  }
+  return 0;
+}
+
+static int vae_pack(Net& n) {
+  if (n.packed_valid) return 0;
+  VaeRefs r = vae_refs(n);
+  for (auto& Lp : n.layers) {
+    ConvLayer& L = *Lp;
+    if (&L == r.zml) continue;
+    ICS_TRY(pack_layer(n, L, true));
+  }
+  ConvLayer& Z = *r.zml;
+  const int lat = n.latent;
+  ICS_TRY(launch_pack_fwd(n.st, n.tp(Z.t_w), lat, lat, Z.wp, Z.Kpad, Z.Npad, 0, 0, 1));
+  ICS_TRY(launch_pack_fwd(n.st, n.tp(Z.t_gamma), lat, lat, Z.wp, Z.Kpad, Z.Npad, 0, lat, 0));
+  ICS_TRY(launch_pack_bwd(n.st, n.tp(Z.t_w), 1, lat, lat, Z.wf, Z.Kpad_b, Z.Npad_b, 2 * lat, 0, 1));
+  ICS_TRY(launch_pack_bwd(n.st, n.tp(Z.t_gamma), 1, lat, lat, Z.wf, Z.Kpad_b, Z.Npad_b, 2 * lat, lat, 0));
+  n.packed_valid = true;
+  return 0;
+}
+
+static int vae_encode_fwd(Net& n, int B, bool training) {
+  ICS_TRY(vae_pack(n));
+  VaeRefs r = vae_refs(n);
+  for (int i = 0; i < 4; ++i) ICS_TRY(conv_forward(n, *r.e[i], B, training, training, n.tp(r.e[i]->t_b)));
+  ICS_TRY(conv_forward(n, *r.e4, B, training, training, n.tp(r.e4->t_b)));
+  ICS_TRY(conv_forward(n, *r.encd, B, training, training, n.tp(r.encd->t_b)));
+  ICS_TRY(conv_forward(n, *r.zml, B, training, training, n.tp(r.zml->t_b)));
+  ICS_TRY(launch_sampling(n.st, r.zml->s, 2 * n.latent, n.latent, n.eps_in, n.cond_in, n.ncond, B, n.z_buf, n.zc));
+  return 0;
+}
+
+static int vae_decode_fwd(Net& n, int B, bool training) {
+  ICS_TRY(vae_pack(n));
+  VaeRefs r = vae_refs(n);
+  ICS_TRY(conv_forward(n, *r.decd, B, training, training, n.tp(r.decd->t_b)));
+  for (int i = 0; i < 4; ++i) ICS_TRY(conv_forward(n, *r.dl[i], B, training, training, n.tp(r.dl[i]->t_b)));
+  ICS_TRY(conv_forward(n, *r.dout, B, training, training, n.tp(r.dout->t_b)));
+  const size_t cnt = n.rows(*r.dout, B) * n.C;
+  ICS_TRY(launch_bn_apply(n.st, r.dout->s, r.dout->scale, r.dout->shift, ACT_RELU, cnt, n.C, n.recon));
+  return 0;
+}
+
+// both engines share one stream in a VAE step: the U-Net is driven on the VAE's stream
+static int vae_step(Net& n, int B, bool training, float* metrics) {
+  ICS_CHECK(n.pm != nullptr, "VAE engine has no perceptual U-Net");
+  Net& u = *n.pm;
+  hipStream_t saved = u.st;
+  u.st = n.st;
+  Profiler* uprof_on = nullptr; (void)uprof_on;
+  const bool uprof = u.prof.on; u.prof.on = false;
+  int rc = 0;
+  do {
+    VaeRefs r = vae_refs(n);
+    UnetRefs ur = unet_refs(u);
+    ConvLayer* taps[4] = {ur.c2, ur.c4, ur.c6, ur.c10};
+    if ((rc = vae_encode_fwd(n, B, training))) break;
+    if ((rc = vae_decode_fwd(n, B, training))) break;
+    const size_t M = (size_t)B * n.d * n.d * n.d;
+    // perceptual pass on y_true, taps copied aside; then on y_pred (state kept for backward)
+    if ((rc = unet_forward_trunk(u, B, training, false, true, n.x_in))) break;
+    for (int l = 0; l < 4; ++l) {
+      const size_t cnt = u.rows(*taps[l], B) * taps[l]->Cout;
+      if (hipMemcpyAsync(u.tap_copy[l], taps[l]->s, cnt * sizeof(float), hipMemcpyDeviceToDevice, n.st) != hipSuccess) {
+        set_error("tap copy failed"); rc = -1; break;
+      }
+    }
+    if (rc) break;
+    if ((rc = unet_forward_trunk(u, B, training, false, true, n.recon))) break;
+    // loss terms (+ gradients when training)
+    double* mse_part = n.ws_dbl;
+    const int mse_bps = 16;
+    size_t off = (size_t)B * mse_bps;
+    if ((rc = launch_sqdiff(n.st, n.x_in, n.recon, B, M / B * n.C, mse_bps, mse_part, training ? n.drecon : nullptr,
+                            (float)(2.0 / ((double)M * n.C)), 0))) break;
+    double* pm_part = n.ws_dbl + off;
+    size_t poff = 0;
+    for (int l = 0; l < 4; ++l) {
+      const size_t per = (size_t)taps[l]->S * taps[l]->S * taps[l]->S * taps[l]->Cout;
+      const float coef = (float)(2.0 * n.alpha * n.pm_w[l] / ((double)per * B));
+      if ((rc = launch_sqdiff(n.st, u.tap_copy[l], taps[l]->s, B, per, 8, pm_part + poff,
+                              training ? u.dtap[l] : nullptr, coef, 0))) break;
+      poff += (size_t)B * 8;
+    }
+    if (rc) break;
+    if ((rc = launch_vae_loss(n.st, r.zml->s, 2 * n.latent, n.latent, B, mse_part, B * mse_bps, (double)M * n.C,
+                              pm_part, n.d_pm_counts, n.d_pm_w, n.alpha, n.beta, n.d_metrics))) break;
+    if (training) {
+      if ((rc = unet_pm_backward(u, B))) break;
+      if ((rc = launch_axpy(n.st, n.drecon, ur.c1->dA, M * n.C, 1.f))) break;
+      // decoder
+      if ((rc = conv_backward(n, *r.dout, B, gs_direct(n.drecon, n.C, 0), gs_none(), nullptr, true, true))) break;
+      if ((rc = conv_backward(n, *r.dl[3], B, gs_direct(r.dout->dA, r.dout->Cin, 0), gs_none(), nullptr, true, true))) break;
+      for (int i = 2; i >= 0; --i)
+        if ((rc = conv_backward(n, *r.dl[i], B, gs_up(r.dl[i + 1]->dA, r.dl[i + 1]->Cin, 0), gs_none(), nullptr, true, true))) break;
+      if (rc) break;
+      if ((rc = conv_backward(n, *r.decd, B, gs_direct(r.dl[0]->dA, r.decd->Cout, 0), gs_none(), nullptr, true, true))) break;
+      // sampling + KL
+      if ((rc = launch_vae_dz(n.st, r.zml->s, 2 * n.latent, n.latent, B, n.eps_in, r.decd->dA, r.decd->Cin, n.beta, n.dmulv))) break;
+      // zmulv given dy = dmulv
+      ConvLayer& Z = *r.zml;
+      const int lat = n.latent;
+      {
+        ConvGeom g1 = geom_fwd(Z, B); g1.Cout = lat; g1.Npad = round_up(lat, 32);
+        if ((rc = launch_conv_wgrad(n.st, g1, Z.src, 1, n.dmulv, 2 * lat, n.tg(Z.t_w), lat, n.ws_wgrad, n.ws_wgrad_n))) break;
+        if ((rc = launch_conv_wgrad(n.st, g1, Z.src, 1, n.dmulv + lat, 2 * lat, n.tg(Z.t_gamma), lat, n.ws_wgrad, n.ws_wgrad_n))) break;
+        if ((rc = launch_colsum_small(n.st, n.dmulv, B, 2 * lat, 2 * lat, n.tg(Z.t_b)))) break;
+        const ConvGeom gb = geom_bwd(Z, B);
+        ConvSrc sd = src_plain(n.dmulv, 2 * lat);
+        if ((rc = launch_conv_fwd(n.st, gb, &sd, 1, Z.wf, nullptr, Z.dA, lat, ACT_NONE, nullptr, nullptr))) break;
+      }
+      if ((rc = conv_backward(n, *r.encd, B, gs_direct(Z.dA, lat, 0), gs_none(), nullptr, true, true))) break;
+      if ((rc = conv_backward(n, *r.e4, B, gs_direct(r.encd->dA, 4, 0), gs_none(), nullptr, true, true))) break;
+      for (int i = 3; i >= 0; --i) {
+        ConvLayer* cons = (i == 3) ? r.e4 : r.e[i + 1];
+        if ((rc = conv_backward(n, *r.e[i], B, gs_pool(cons->dA, cons->Cin, *r.e[i]), gs_none(), nullptr, i > 0, true))) break;
+      }
+      if (rc) break;
+      if ((rc = adam_step(n))) break;
+    }
+    if (metrics) {
+      if (hipMemcpyAsync(metrics, n.d_metrics, 4 * sizeof(float), hipMemcpyDeviceToHost, n.st) != hipSuccess ||
+          hipStreamSynchronize(n.st) != hipSuccess) { set_error("metrics copy failed"); rc = -1; break; }
+      n.prof.resolve();
+    }
+  } while (0);
+  u.st = saved;
+  u.prof.on = uprof;
+  return rc;
+}
+
+static int vae_upload(Net& n, const float* x, const float* cond, const float* eps, int B) {
+  ICS_CHECK(B >= 1 && B <= n.maxB, "batch exceeds max_batch");
+  const size_t M = (size_t)B * n.d * n.d * n.d;
+  if (x) ICS_HIP(hipMemcpyAsync(n.x_in, x, M * n.C * sizeof(float), hipMemcpyHostToDevice, n.st));
+  if (cond) ICS_HIP(hipMemcpyAsync(n.cond_in, cond, (size_t)B * n.ncond * sizeof(float), hipMemcpyHostToDevice, n.st));
+  if (eps) ICS_HIP(hipMemcpyAsync(n.eps_in, eps, (size_t)B * n.latent * sizeof(float), hipMemcpyHostToDevice, n.st));
+  n.resident_batch = B;
+  return 0;
+}
+
+// compact columns [col0, col0+ncols) of a [M][ld] matrix into a dense [M][ncols] buffer
+__global__ void gather_cols_kernel(const float* __restrict__ src, int ld, int col0, int ncols, size_t M,
+                                   float* __restrict__ dst) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * (size_t)ncols) return;
+  const size_t row = i / ncols;
+  const int c = (int)(i - row * ncols);
+  dst[i] = src[row * ld + col0 + c];
+}
+
+// argmax species + thresholded mask from head probabilities (generate.py:221-225)
+__global__ void labels_kernel(const float* __restrict__ p, int ld, int ncls, size_t M, float thresh,
+                              unsigned char* __restrict__ species, unsigned char* __restrict__ mask) {
+  const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= M) return;
+  const float* pr = p + row * ld;
+  int best = 0;
+  float bv = pr[0];
+  for (int c = 1; c < ncls; ++c)
+    if (pr[c] > bv) { bv = pr[c]; best = c; }   // np.argmax: first maximum
+  species[row] = (unsigned char)best;
+  mask[row] = pr[ncls] >= thresh ? 1 : 0;
+}
+
+}  // namespace ics
+
+// ==========================================================================================
+// C ABI
+// ==========================================================================================
+using namespace ics;
+
+struct ics_net {
+  Net n;
+};
+
+extern "C" {
+
+const char* ics_last_error(void) { return g_err.c_str(); }
+const char* ics_version(void) { return "icsg3d_amd 0.1 (gfx950, fp32 MFMA implicit-GEMM)"; }
+
+int ics_device_count(int* count) {
+  ICS_HIP(hipGetDeviceCount(count));
+  return 0;
+}
+int ics_set_device(int device) {
+  ICS_HIP(hipSetDevice(device));
+  return 0;
+}
+int ics_device_info(char* name, int* cus, size_t* hbm) {
+  int dev = 0;
+  ICS_HIP(hipGetDevice(&dev));
+  hipDeviceProp_t p;
+  ICS_HIP(hipGetDeviceProperties(&p, dev));
+  if (name) { std::strncpy(name, p.name, 255); name[255] = 0; }
+  if (cus) *cus = p.multiProcessorCount;
+  if (hbm) *hbm = p.totalGlobalMem;
+  return 0;
+}
+
+static int net_common_init(Net& n) {
+  ICS_HIP(hipGetDevice(&n.device));
+  ICS_HIP(hipStreamCreateWithFlags(&n.st, hipStreamNonBlocking));
+  return 0;
+}
+
+int ics_unet_create(const ics_unet_config* cfg, ics_net** out) {
+  ICS_CHECK(cfg && out, "null argument");
+  ICS_CHECK(cfg->d >= 8 && (cfg->d & (cfg->d - 1)) == 0, "d must be a power of two >= 8");
+  ICS_CHECK(cfg->in_channels >= 1 && cfg->max_batch >= 1 && cfg->num_classes >= 2 && cfg->num_classes <= 127,
+            "bad U-Net config");
+  auto h = std::make_unique<ics_net>();
+  ICS_TRY(net_common_init(h->n));
+  ICS_TRY(unet_build(h->n, *cfg));
+  ICS_HIP(hipStreamSynchronize(h->n.st));
+  *out = h.release();
+  return 0;
+}
+
+int ics_vae_create(const ics_vae_config* cfg, ics_net* pm, ics_net** out) {
+  ICS_CHECK(cfg && out, "null argument");
+  ICS_CHECK(pm == nullptr || pm->n.kind == 0, "perceptual model must be a U-Net engine");
+  auto h = std::make_unique<ics_net>();
+  ICS_TRY(net_common_init(h->n));
+  ICS_TRY(vae_build(h->n, *cfg, pm ? &pm->n : nullptr));
+  ICS_HIP(hipStreamSynchronize(h->n.st));
+  *out = h.release();
+  return 0;
+}
+
+int ics_net_destroy(ics_net* net) {
+  if (!net) return 0;
+  (void)hipStreamSynchronize(net->n.st);
+  delete net;
+  return 0;
+}
+int ics_net_sync(ics_net* net) {
+  ICS_CHECK(net, "null handle");
+  ICS_HIP(hipStreamSynchronize(net->n.st));
+  net->n.prof.resolve();
+  return 0;
+}
+
+int ics_net_num_tensors(ics_net* net, int* count) {
+  ICS_CHECK(net && count, "null argument");
+  *count = (int)net->n.tensors.size();
+  return 0;
+}
+int ics_net_tensor_info(ics_net* net, int index, const char** name, int* ndim, int64_t dims[5], int* trainable) {
+  ICS_CHECK(net && index >= 0 && index < (int)net->n.tensors.size(), "tensor index out of range");
+  const Tensor& t = net->n.tensors[index];
+  if (name) *name = t.name.c_str();
+  if (ndim) *ndim = (int)t.dims.size();
+  if (dims) for (size_t i = 0; i < t.dims.size() && i < 5; ++i) dims[i] = t.dims[i];
+  if (trainable) *trainable = t.trainable ? 1 : 0;
+  return 0;
+}
+static int find_tensor(ics_net* net, const char* name, Tensor** t) {
+  ICS_CHECK(net && name, "null argument");
+  auto it = net->n.tindex.find(name);
+  ICS_CHECK(it != net->n.tindex.end(), std::string("unknown tensor: ") + name);
+  *t = &net->n.tensors[it->second];
+  return 0;
+}
+int ics_net_set_tensor(ics_net* net, const char* name, const float* host, size_t count) {
+  Tensor* t;
+  ICS_TRY(find_tensor(net, name, &t));
+  ICS_CHECK(count == t->count, std::string("size mismatch for tensor ") + name);
+  ICS_HIP(hipMemcpyAsync(t->ptr, host, count * sizeof(float), hipMemcpyHostToDevice, net->n.st));
+  ICS_HIP(hipStreamSynchronize(net->n.st));
+  net->n.packed_valid = false;
+  return 0;
+}
+int ics_net_get_tensor(ics_net* net, const char* name, float* host, size_t count) {
+  Tensor* t;
+  ICS_TRY(find_tensor(net, name, &t));
+  ICS_CHECK(count == t->count, std::string("size mismatch for tensor ") + name);
+  ICS_HIP(hipMemcpyAsync(host, t->ptr, count * sizeof(float), hipMemcpyDeviceToHost, net->n.st));
+  ICS_HIP(hipStreamSynchronize(net->n.st));
+  return 0;
+}
+int ics_net_get_grad(ics_net* net, const char* name, float* host, size_t count) {
+  Tensor* t;
+  ICS_TRY(find_tensor(net, name, &t));
+  ICS_CHECK(t->trainable, "tensor is not trainable");
+  ICS_CHECK(count == t->count, std::string("size mismatch for tensor ") + name);
+  ICS_HIP(hipMemcpyAsync(host, net->n.G + t->off, count * sizeof(float), hipMemcpyDeviceToHost, net->n.st));
+  ICS_HIP(hipStreamSynchronize(net->n.st));
+  return 0;
+}
+int ics_net_set_lr(ics_net* net, float lr) {
+  ICS_CHECK(net, "null handle");
+  net->n.lr = lr;
+  return 0;
+}
+int ics_net_reset_optimizer(ics_net* net) {
+  ICS_CHECK(net, "null handle");
+  Net& n = net->n;
+  n.adam_t = 0;
+  ICS_HIP(hipMemsetAsync(n.Mo, 0, n.nparams * sizeof(float), n.st));
+  ICS_HIP(hipMemsetAsync(n.Vo, 0, n.nparams * sizeof(float), n.st));
+  ICS_HIP(hipStreamSynchronize(n.st));
+  return 0;
+}
+
+int ics_net_profile_enable(ics_net* net, int on) {
+  ICS_CHECK(net, "null handle");
+  ICS_HIP(hipStreamSynchronize(net->n.st));
+  net->n.prof.reset();
+  net->n.prof.on = on != 0;
+  return 0;
+}
+int ics_net_profile_count(ics_net* net, int* rows) {
+  ICS_CHECK(net && rows, "null argument");
+  ICS_HIP(hipStreamSynchronize(net->n.st));
+  net->n.prof.resolve();
+  *rows = (int)net->n.prof.rows.size();
+  return 0;
+}
+int ics_net_profile_row(ics_net* net, int row, const char** label, int64_t* launches, double* ms, double* flop,
+                        double* bytes) {
+  ICS_CHECK(net && row >= 0 && row < (int)net->n.prof.rows.size(), "profile row out of range");
+  const auto& r = net->n.prof.rows[row];
+  if (label) *label = r.label.c_str();
+  if (launches) *launches = r.launches;
+  if (ms) *ms = r.ms;
+  if (flop) *flop = r.flop;
+  if (bytes) *bytes = r.bytes;
+  return 0;
+}
+
+// ---------------------------------------------------------------- U-Net entry points
+static int require_kind(ics_net* net, int kind) {
+  ICS_CHECK(net, "null handle");
+  ICS_CHECK(net->n.kind == kind, kind == 0 ? "handle is not a U-Net engine" : "handle is not a VAE engine");
+  ICS_HIP(hipSetDevice(net->n.device));
+  return 0;
+}
+
+int ics_unet_predict(ics_net* net, const float* x, int batch, float* soft, float* sig) {
+  ICS_TRY(require_kind(net, 0));
+  Net& n = net->n;
+  ICS_TRY(unet_upload(n, x, nullptr, batch));
+  ICS_TRY(unet_forward_trunk(n, batch, false, false, false, n.x_in));
+  ICS_TRY(unet_head_forward(n, batch));
+  ICS_TRY(unet_loss(n, batch, 0, 0));
+  const size_t M = n.rows(*n.head, batch);
+  const int ld = n.ncls + 1;
+  float* stage = n.head->dy;   // [M][ncls+1] scratch: soft packed first, sig after it
+  if (soft) {
+    const size_t cnt = M * (size_t)n.ncls;
+    hipLaunchKernelGGL(gather_cols_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, n.st, n.head->s, ld, 0,
+                       n.ncls, M, stage);
+    ICS_HIP(hipGetLastError());
+    ICS_HIP(hipMemcpyAsync(soft, stage, cnt * sizeof(float), hipMemcpyDeviceToHost, n.st));
+  }
+  if (sig) {
+    hipLaunchKernelGGL(gather_cols_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, n.st, n.head->s, ld, n.ncls,
+                       1, M, stage + M * (size_t)n.ncls);
+    ICS_HIP(hipGetLastError());
+    ICS_HIP(hipMemcpyAsync(sig, stage + M * (size_t)n.ncls, M * sizeof(float), hipMemcpyDeviceToHost, n.st));
+  }
+  ICS_HIP(hipStreamSynchronize(n.st));
+  n.prof.resolve();
+  return 0;
+}
+
+int ics_unet_predict_labels(ics_net* net, const float* x, int batch, float thresh, uint8_t* species, uint8_t* mask) {
+  ICS_TRY(require_kind(net, 0));
+  Net& n = net->n;
+  ICS_TRY(unet_upload(n, x, nullptr, batch));
+  ICS_TRY(unet_forward_trunk(n, batch, false, false, false, n.x_in));
+  ICS_TRY(unet_head_forward(n, batch));
+  ICS_TRY(unet_loss(n, batch, 0, 0));
+  const size_t M = n.rows(*n.head, batch);
+  unsigned char* d_species = reinterpret_cast<unsigned char*>(n.head->dy);   // [M][ncls+1] float scratch
+  unsigned char* d_mask = d_species + M;
+  hipLaunchKernelGGL(labels_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, n.st, n.head->s, n.ncls + 1,
+                     n.ncls, M, thresh, d_species, d_mask);
+  ICS_HIP(hipGetLastError());
+  if (species) ICS_HIP(hipMemcpyAsync(species, d_species, M, hipMemcpyDeviceToHost, n.st));
+  if (mask) ICS_HIP(hipMemcpyAsync(mask, d_mask, M, hipMemcpyDeviceToHost, n.st));
+  ICS_HIP(hipStreamSynchronize(n.st));
+  return 0;
+}
+
+int ics_unet_upload_batch(ics_net* net, const float* x, const uint8_t* labels, int batch) {
+  ICS_TRY(require_kind(net, 0));
+  ICS_TRY(unet_upload(net->n, x, labels, batch));
+  ICS_HIP(hipStreamSynchronize(net->n.st));
+  return 0;
+}
+int ics_unet_train_step_resident(ics_net* net, float* metrics) {
+  ICS_TRY(require_kind(net, 0));
+  ICS_CHECK(net->n.resident_batch > 0, "no resident batch: call ics_unet_upload_batch first");
+  return unet_train_resident(net->n, net->n.resident_batch, metrics);
+}
+int ics_unet_train_step(ics_net* net, const float* x, const uint8_t* labels, int batch, float metrics[5]) {
+  ICS_TRY(require_kind(net, 0));
+  ICS_CHECK(x && labels && metrics, "null argument");
+  ICS_TRY(unet_upload(net->n, x, labels, batch));
+  return unet_train_resident(net->n, batch, metrics);
+}
+int ics_unet_test_step(ics_net* net, const float* x, const uint8_t* labels, int batch, float metrics[5]) {
+  ICS_TRY(require_kind(net, 0));
+  ICS_CHECK(x && labels && metrics, "null argument");
+  Net& n = net->n;
+  ICS_TRY(unet_upload(n, x, labels, batch));
+  ICS_TRY(unet_forward_trunk(n, batch, false, false, false, n.x_in));
+  ICS_TRY(unet_head_forward(n, batch));
+  ICS_TRY(unet_loss(n, batch, 1, 0));
+  ICS_HIP(hipMemcpyAsync(metrics, n.d_metrics, 5 * sizeof(float), hipMemcpyDeviceToHost, n.st));
+  ICS_HIP(hipStreamSynchronize(n.st));
+  return 0;
+}
+
+// ---------------------------------------------------------------- VAE entry points
+int ics_vae_encode(ics_net* net, const float* x, const float* cond, const float* eps, int batch, float* z_mean,
+                   float* z_log_var, float* z) {
+  ICS_TRY(require_kind(net, 1));
+  Net& n = net->n;
+  ICS_CHECK(x && cond && eps, "null argument");
+  ICS_TRY(vae_upload(n, x, cond, eps, batch));
+  ICS_TRY(vae_encode_fwd(n, batch, false));
+  VaeRefs r = vae_refs(n);
+  const size_t lat = n.latent;
+  if (z_mean) ICS_HIP(hipMemcpy2DAsync(z_mean, lat * 4, r.zml->s, 2 * lat * 4, lat * 4, batch, hipMemcpyDeviceToHost, n.st));
+  if (z_log_var) ICS_HIP(hipMemcpy2DAsync(z_log_var, lat * 4, r.zml->s + lat, 2 * lat * 4, lat * 4, batch, hipMemcpyDeviceToHost, n.st));
+  if (z) ICS_HIP(hipMemcpyAsync(z, n.z_buf, batch * lat * 4, hipMemcpyDeviceToHost, n.st));
+  ICS_HIP(hipStreamSynchronize(n.st));
+  return 0;
+}
+int ics_vae_decode(ics_net* net, const float* z, const float* cond, int batch, float* recon) {
+  ICS_TRY(require_kind(net, 1));
+  Net& n = net->n;
+  ICS_CHECK(z && cond && recon, "null argument");
+  ICS_CHECK(batch >= 1 && batch <= n.maxB, "batch exceeds max_batch");
+  // zc = [z | cond] assembled on the host side of the ABI: two strided uploads
+  const size_t lat = n.latent, W = lat + n.ncond;
+  ICS_HIP(hipMemcpy2DAsync(n.zc, W * 4, z, lat * 4, lat * 4, batch, hipMemcpyHostToDevice, n.st));
+  ICS_HIP(hipMemcpy2DAsync(n.zc + lat, W * 4, cond, n.ncond * 4, n.ncond * 4, batch, hipMemcpyHostToDevice, n.st));
+  ICS_TRY(vae_decode_fwd(n, batch, false));
+  const size_t cnt = (size_t)batch * n.d * n.d * n.d * n.C;
+  ICS_HIP(hipMemcpyAsync(recon, n.recon, cnt * 4, hipMemcpyDeviceToHost, n.st));
+  ICS_HIP(hipStreamSynchronize(n.st));
+  return 0;
+}
+int ics_vae_upload_batch(ics_net* net, const float* x, const float* cond, const float* eps, int batch) {
+  ICS_TRY(require_kind(net, 1));
+  ICS_TRY(vae_upload(net->n, x, cond, eps, batch));
+  ICS_HIP(hipStreamSynchronize(net->n.st));
+  return 0;
+}
+int ics_vae_train_step_resident(ics_net* net, float* metrics) {
+  ICS_TRY(require_kind(net, 1));
+  ICS_CHECK(net->n.resident_batch > 0, "no resident batch: call ics_vae_upload_batch first");
+  return vae_step(net->n, net->n.resident_batch, true, metrics);
+}
+int ics_vae_train_step(ics_net* net, const float* x, const float* cond, const float* eps, int batch, float metrics[4]) {
+  ICS_TRY(require_kind(net, 1));
+  ICS_CHECK(x && cond && eps && metrics, "null argument");
+  ICS_TRY(vae_upload(net->n, x, cond, eps, batch));
+  return vae_step(net->n, batch, true, metrics);
+}
+int ics_vae_test_step(ics_net* net, const float* x, const float* cond, const float* eps, int batch, float metrics[4]) {
+  ICS_TRY(require_kind(net, 1));
+  ICS_CHECK(x && cond && eps && metrics, "null argument");
+  ICS_TRY(vae_upload(net->n, x, cond, eps, batch));
+  return vae_step(net->n, batch, false, metrics);
+}
+
+// ---------------------------------------------------------------- data parallel
+int ics_comm_unique_id(char uid[128]) {
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+  ncclUniqueId id;
+  ncclResult_t r = ncclGetUniqueId(&id);
+  ICS_CHECK(r == ncclSuccess, std::string("ncclGetUniqueId: ") + ncclGetErrorString(r));
+  std::memcpy(uid, &id, 128);
+  return 0;
+}
+int ics_net_comm_init(ics_net* net, int rank, int nranks, const char uid[128]) {
+  ICS_CHECK(net && uid && nranks >= 1 && rank >= 0 && rank < nranks, "bad comm arguments");
+  Net& n = net->n;
+  ICS_HIP(hipSetDevice(n.device));
+  ncclUniqueId id;
+  std::memcpy(&id, uid, 128);
+  ncclResult_t r = ncclCommInitRank(&n.comm, nranks, id, rank);
+  ICS_CHECK(r == ncclSuccess, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+  n.rank = rank; n.nranks = nranks;
+  return 0;
+}
+int ics_net_comm_allreduce_max(ics_net* net, double* value) {
+  ICS_CHECK(net && value, "null argument");
+  Net& n = net->n;
+  if (!n.comm) { ICS_HIP(hipStreamSynchronize(n.st)); return 0; }
+  ICS_HIP(hipMemcpyAsync(n.d_red, value, sizeof(double), hipMemcpyHostToDevice, n.st));
+  ncclResult_t r = ncclAllReduce(n.d_red, n.d_red, 1, ncclDouble, ncclMax, n.comm, n.st);
+  ICS_CHECK(r == ncclSuccess, std::string("ncclAllReduce(max): ") + ncclGetErrorString(r));
+  ICS_HIP(hipMemcpyAsync(value, n.d_red, sizeof(double), hipMemcpyDeviceToHost, n.st));
+  ICS_HIP(hipStreamSynchronize(n.st));
+  return 0;
+}
+
+// ---------------------------------------------------------------- single-op entry points
+static int op_prepare(Net& n) { return net_common_init(n); }
+
+int ics_op_conv3d_forward(const float* x, const float* w, const float* bias, int B, int S, int Cin, int Cout,
+                          int taps, int pre_act, float* y) {
+  ICS_CHECK(x && w && y && (taps == 27 || taps == 1) && S >= 1 && (S & (S - 1)) == 0, "bad conv arguments");
+  Net n;
+  ICS_TRY(op_prepare(n));
+  const size_t M = (size_t)B * S * S * S;
+  const int Kpad = round_up(taps * Cin, 32), Npad = round_up(Cout, 32);
+  float *dx, *dw, *db, *dwp, *dyv;
+  ICS_TRY(n.alloc(&dx, M * Cin)); ICS_TRY(n.alloc(&dw, (size_t)taps * Cin * Cout)); ICS_TRY(n.alloc(&db, (size_t)Cout));
+  ICS_TRY(n.alloc(&dwp, (size_t)Kpad * Npad)); ICS_TRY(n.alloc(&dyv, M * Cout));
+  ICS_HIP(hipMemcpyAsync(dx, x, M * Cin * 4, hipMemcpyHostToDevice, n.st));
+  ICS_HIP(hipMemcpyAsync(dw, w, (size_t)taps * Cin * Cout * 4, hipMemcpyHostToDevice, n.st));
+  if (bias) ICS_HIP(hipMemcpyAsync(db, bias, (size_t)Cout * 4, hipMemcpyHostToDevice, n.st));
+  ICS_TRY(launch_pack_fwd(n.st, dw, taps * Cin, Cout, dwp, Kpad, Npad, 0, 0, 1));
+  ConvGeom g{B, S, ilog2(S), Cin, Cout, taps, Kpad, Npad};
+  ConvSrc s = src_plain(dx, Cin);
+  ICS_TRY(launch_conv_fwd(n.st, g, &s, 1, dwp, bias ? db : nullptr, dyv, Cout, pre_act, nullptr, nullptr));
+  ICS_HIP(hipMemcpyAsync(y, dyv, M * Cout * 4, hipMemcpyDeviceToHost, n.st));
+  ICS_HIP(hipStreamSynchronize(n.st));
+  return 0;
+}
+
+int ics_op_conv3d_backward(const float* x, const float* w, const float* dy, int B, int S, int Cin, int Cout,
+                           int taps, float* dxo, float* dwo) {
+  ICS_CHECK(x && w && dy && (taps == 27 || taps == 1) && S >= 1 && (S & (S - 1)) == 0, "bad conv arguments");
+  Net n;
+  ICS_TRY(op_prepare(n));
+  const size_t M = (size_t)B * S * S * S;
+  const int Kpad_b = round_up(taps * Cout, 32), Npad_b = round_up(Cin, 32);
+  const int Kpad = round_up(taps * Cin, 32), Npad = round_up(Cout, 32);
+  float *dx, *dw, *ddy, *dwf, *dgx, *dgw, *ws;
+  ICS_TRY(n.alloc(&dx, M * Cin)); ICS_TRY(n.alloc(&dw, (size_t)taps * Cin * Cout)); ICS_TRY(n.alloc(&ddy, M * Cout));
+  ICS_TRY(n.alloc(&dwf, (size_t)Kpad_b * Npad_b)); ICS_TRY(n.alloc(&dgx, M * Cin));
+  ICS_TRY(n.alloc(&dgw, (size_t)taps * Cin * Cout));
+  ICS_HIP(hipMemcpyAsync(dx, x, M * Cin * 4, hipMemcpyHostToDevice, n.st));
+  ICS_HIP(hipMemcpyAsync(dw, w, (size_t)taps * Cin * Cout * 4, hipMemcpyHostToDevice, n.st));
+  ICS_HIP(hipMemcpyAsync(ddy, dy, M * Cout * 4, hipMemcpyHostToDevice, n.st));
+  ConvGeom g{B, S, ilog2(S), Cin, Cout, taps, Kpad, Npad};
+  ConvSrc s = src_plain(dx, Cin);
+  const size_t wsn = conv_wgrad_workspace_floats(g, &s, 1);
+  ICS_TRY(n.alloc(&ws, wsn + 16));
+  if (dwo) {
+    ICS_TRY(launch_conv_wgrad(n.st, g, &s, 1, ddy, Cout, dgw, Cout, ws, wsn));
+    ICS_HIP(hipMemcpyAsync(dwo, dgw, (size_t)taps * Cin * Cout * 4, hipMemcpyDeviceToHost, n.st));
+  }
+  if (dxo) {
+    ICS_TRY(launch_pack_bwd(n.st, dw, taps, Cin, Cout, dwf, Kpad_b, Npad_b, Cout, 0, 1));
+    ConvGeom gb{B, S, ilog2(S), Cout, Cin, taps, Kpad_b, Npad_b};
+    ConvSrc sd = src_plain(ddy, Cout);
+    ICS_TRY(launch_conv_fwd(n.st, gb, &sd, 1, dwf, nullptr, dgx, Cin, ACT_NONE, nullptr, nullptr));
+    ICS_HIP(hipMemcpyAsync(dxo, dgx, M * Cin * 4, hipMemcpyDeviceToHost, n.st));
+  }
+  ICS_HIP(hipStreamSynchronize(n.st));
+  return 0;
+}
+
+}  // extern "C"

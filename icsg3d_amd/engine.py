@@ -1,0 +1,286 @@
+"""Thin Python handles over the C ABI (include/icsg3d.h): numpy in / numpy out.
+
+These are what the reference-shaped classes (icsg3d_amd/unet/unet.py, icsg3d_amd/vae/lattice_vae.py)
+call where the reference calls Keras.  All compute happens in libicsg3d_hip.so on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class _Net:
+    """Common handle plumbing: named tensors, gradients, profiling, data-parallel comm."""
+
+    def __init__(self):
+        self._h = L._H(None)
+        self._lib = L.load()
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.ics_net_destroy(self._h)
+            self._h = L._H(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- tensors
+    def tensor_infos(self):
+        n = C.c_int(0)
+        L.check(self._lib.ics_net_num_tensors(self._h, C.byref(n)))
+        out = []
+        for i in range(n.value):
+            name = C.c_char_p()
+            nd = C.c_int(0)
+            dims = (C.c_int64 * 5)()
+            tr = C.c_int(0)
+            L.check(self._lib.ics_net_tensor_info(self._h, i, C.byref(name), C.byref(nd), dims, C.byref(tr)))
+            out.append((name.value.decode(), tuple(int(dims[k]) for k in range(nd.value)), bool(tr.value)))
+        return out
+
+    def get_tensor(self, name, shape=None):
+        if shape is None:
+            shape = dict((n, s) for n, s, _ in self.tensor_infos())[name]
+        a = np.empty(shape, np.float32)
+        L.check(self._lib.ics_net_get_tensor(self._h, name.encode(), L.fptr(a), a.size))
+        return a
+
+    def set_tensor(self, name, value):
+        a = _f32(value)
+        L.check(self._lib.ics_net_set_tensor(self._h, name.encode(), L.fptr(a), a.size))
+
+    def get_grad(self, name, shape):
+        a = np.empty(shape, np.float32)
+        L.check(self._lib.ics_net_get_grad(self._h, name.encode(), L.fptr(a), a.size))
+        return a
+
+    def get_weights(self):
+        return {n: self.get_tensor(n, s) for n, s, _ in self.tensor_infos()}
+
+    def set_weights(self, weights):
+        known = dict((n, s) for n, s, _ in self.tensor_infos())
+        for k, v in weights.items():
+            if k not in known:
+                raise KeyError("unknown tensor %r" % k)
+            if tuple(np.shape(v)) != known[k]:
+                raise ValueError("shape mismatch for %s: %s vs %s" % (k, np.shape(v), known[k]))
+            self.set_tensor(k, v)
+
+    def set_lr(self, lr):
+        L.check(self._lib.ics_net_set_lr(self._h, float(lr)))
+
+    def reset_optimizer(self):
+        L.check(self._lib.ics_net_reset_optimizer(self._h))
+
+    def sync(self):
+        L.check(self._lib.ics_net_sync(self._h))
+
+    # ---- profiling (HIP events on the engine's stream)
+    def profile_enable(self, on=True):
+        L.check(self._lib.ics_net_profile_enable(self._h, 1 if on else 0))
+
+    def profile_rows(self):
+        n = C.c_int(0)
+        L.check(self._lib.ics_net_profile_count(self._h, C.byref(n)))
+        rows = []
+        for i in range(n.value):
+            label = C.c_char_p()
+            cnt = C.c_int64(0)
+            ms, fl, by = C.c_double(0), C.c_double(0), C.c_double(0)
+            L.check(self._lib.ics_net_profile_row(self._h, i, C.byref(label), C.byref(cnt), C.byref(ms),
+                                                  C.byref(fl), C.byref(by)))
+            rows.append({"label": label.value.decode(), "launches": cnt.value, "ms": ms.value,
+                         "flop": fl.value, "bytes": by.value})
+        return rows
+
+    # ---- data parallel
+    def comm_init(self, rank, nranks, uid):
+        L.check(self._lib.ics_net_comm_init(self._h, int(rank), int(nranks), uid))
+
+    def allreduce_max(self, value):
+        v = C.c_double(float(value))
+        L.check(self._lib.ics_net_comm_allreduce_max(self._h, C.byref(v)))
+        return v.value
+
+
+def comm_unique_id():
+    buf = C.create_string_buffer(128)
+    L.check(L.load().ics_comm_unique_id(buf))
+    return buf.raw
+
+
+class UnetEngine(_Net):
+    def __init__(self, in_channels=1, num_classes=95, d=32, max_batch=32, lr=1e-6, loss_weight=0.0,
+                 pool_ties="tf_cpu", bn_unbias=True, device=None):
+        super().__init__()
+        if device is not None:
+            L.check(self._lib.ics_set_device(int(device)))
+        self.in_channels, self.num_classes, self.d, self.max_batch = in_channels, num_classes, d, max_batch
+        cfg = L.UnetConfig(in_channels, num_classes, d, max_batch, lr, loss_weight,
+                           1 if pool_ties == "tf_cpu" else 0, 1 if bn_unbias else 0)
+        L.check(self._lib.ics_unet_create(C.byref(cfg), C.byref(self._h)))
+
+    def _check_x(self, x):
+        x = _f32(x)
+        d = self.d
+        if x.ndim != 5 or x.shape[1:] != (d, d, d, self.in_channels):
+            raise ValueError("expected (B,%d,%d,%d,%d), got %s" % (d, d, d, self.in_channels, x.shape))
+        return x
+
+    def predict(self, x):
+        x = self._check_x(x)
+        B, d = x.shape[0], self.d
+        soft = np.empty((B, d, d, d, self.num_classes), np.float32)
+        sig = np.empty((B, d, d, d, 1), np.float32)
+        for i in range(0, B, self.max_batch):
+            xs = x[i:i + self.max_batch]
+            L.check(self._lib.ics_unet_predict(self._h, L.fptr(xs), xs.shape[0], L.fptr(soft[i:i + self.max_batch]),
+                                               L.fptr(sig[i:i + self.max_batch])))
+        return soft, sig
+
+    def predict_labels(self, x, thresh=0.8):
+        x = self._check_x(x)
+        B, d = x.shape[0], self.d
+        sp = np.empty((B, d, d, d), np.uint8)
+        mk = np.empty((B, d, d, d), np.uint8)
+        for i in range(0, B, self.max_batch):
+            xs = x[i:i + self.max_batch]
+            L.check(self._lib.ics_unet_predict_labels(self._h, L.fptr(xs), xs.shape[0], float(thresh),
+                                                      L.u8ptr(sp[i:i + self.max_batch]), L.u8ptr(mk[i:i + self.max_batch])))
+        return sp, mk
+
+    def _labels(self, labels, B):
+        lab = np.ascontiguousarray(labels, dtype=np.uint8)
+        if lab.shape != (B, self.d, self.d, self.d):
+            raise ValueError("labels must be (B,d,d,d) uint8 class ids, got %s" % (lab.shape,))
+        return lab
+
+    def train_step(self, x, labels):
+        x = self._check_x(x)
+        lab = self._labels(labels, x.shape[0])
+        m = np.zeros(5, np.float32)
+        L.check(self._lib.ics_unet_train_step(self._h, L.fptr(x), L.u8ptr(lab), x.shape[0], L.fptr(m)))
+        return m
+
+    def test_step(self, x, labels):
+        x = self._check_x(x)
+        lab = self._labels(labels, x.shape[0])
+        m = np.zeros(5, np.float32)
+        L.check(self._lib.ics_unet_test_step(self._h, L.fptr(x), L.u8ptr(lab), x.shape[0], L.fptr(m)))
+        return m
+
+    def upload_batch(self, x, labels):
+        x = self._check_x(x)
+        lab = self._labels(labels, x.shape[0])
+        L.check(self._lib.ics_unet_upload_batch(self._h, L.fptr(x), L.u8ptr(lab), x.shape[0]))
+
+    def train_step_resident(self, want_metrics=False):
+        if want_metrics:
+            m = np.zeros(5, np.float32)
+            L.check(self._lib.ics_unet_train_step_resident(self._h, L.fptr(m)))
+            return m
+        L.check(self._lib.ics_unet_train_step_resident(self._h, None))
+        return None
+
+
+class VaeEngine(_Net):
+    def __init__(self, unet: UnetEngine, in_channels=1, cond_shape=10, latent_dim=256,
+                 filters=(16, 32, 64, 128), d=32, max_batch=32, lr=5e-4, alpha=0.5, beta=3e-4,
+                 pm_layer_weights=(1.0, 1.0, 1.0, 1.0), bn_unbias=True):
+        super().__init__()
+        self.unet = unet   # keep the perceptual engine alive
+        self.in_channels, self.cond_shape, self.latent_dim, self.d, self.max_batch = (
+            in_channels, cond_shape, latent_dim, d, max_batch)
+        cfg = L.VaeConfig(in_channels, cond_shape, latent_dim, (C.c_int * 4)(*filters), d, max_batch, lr,
+                          alpha, beta, (C.c_float * 4)(*pm_layer_weights), 1 if bn_unbias else 0)
+        L.check(self._lib.ics_vae_create(C.byref(cfg), unet._h if unet is not None else None, C.byref(self._h)))
+
+    def _args(self, x, cond, eps):
+        x, cond = _f32(x), _f32(cond)
+        B = x.shape[0]
+        d = self.d
+        if x.shape != (B, d, d, d, self.in_channels):
+            raise ValueError("bad input shape %s" % (x.shape,))
+        if cond.shape != (B, self.cond_shape):
+            raise ValueError("bad cond shape %s" % (cond.shape,))
+        eps = _f32(eps)
+        if eps.shape != (B, self.latent_dim):
+            raise ValueError("bad eps shape %s" % (eps.shape,))
+        return x, cond, eps, B
+
+    def encode(self, x, cond, eps):
+        x, cond, eps, B = self._args(x, cond, eps)
+        zm = np.empty((B, self.latent_dim), np.float32)
+        zlv = np.empty_like(zm)
+        z = np.empty_like(zm)
+        for i in range(0, B, self.max_batch):
+            s = slice(i, i + self.max_batch)
+            L.check(self._lib.ics_vae_encode(self._h, L.fptr(x[s]), L.fptr(cond[s]), L.fptr(eps[s]), x[s].shape[0],
+                                             L.fptr(zm[s]), L.fptr(zlv[s]), L.fptr(z[s])))
+        return zm, zlv, z
+
+    def decode(self, z, cond):
+        z, cond = _f32(z), _f32(cond)
+        B, d = z.shape[0], self.d
+        out = np.empty((B, d, d, d, self.in_channels), np.float32)
+        for i in range(0, B, self.max_batch):
+            s = slice(i, i + self.max_batch)
+            L.check(self._lib.ics_vae_decode(self._h, L.fptr(z[s]), L.fptr(cond[s]), z[s].shape[0], L.fptr(out[s])))
+        return out
+
+    def train_step(self, x, cond, eps):
+        x, cond, eps, B = self._args(x, cond, eps)
+        m = np.zeros(4, np.float32)
+        L.check(self._lib.ics_vae_train_step(self._h, L.fptr(x), L.fptr(cond), L.fptr(eps), B, L.fptr(m)))
+        return m
+
+    def test_step(self, x, cond, eps):
+        x, cond, eps, B = self._args(x, cond, eps)
+        m = np.zeros(4, np.float32)
+        L.check(self._lib.ics_vae_test_step(self._h, L.fptr(x), L.fptr(cond), L.fptr(eps), B, L.fptr(m)))
+        return m
+
+    def upload_batch(self, x, cond, eps):
+        x, cond, eps, B = self._args(x, cond, eps)
+        L.check(self._lib.ics_vae_upload_batch(self._h, L.fptr(x), L.fptr(cond), L.fptr(eps), B))
+
+    def train_step_resident(self, want_metrics=False):
+        if want_metrics:
+            m = np.zeros(4, np.float32)
+            L.check(self._lib.ics_vae_train_step_resident(self._h, L.fptr(m)))
+            return m
+        L.check(self._lib.ics_vae_train_step_resident(self._h, None))
+        return None
+
+
+def conv3d_forward(x, w, bias=None, pre_act=0):
+    """Single-op entry (kernel parity tests): x (B,S,S,S,Cin), w (k,k,k,Cin,Cout)."""
+    lib = L.load()
+    x, w = _f32(x), _f32(w)
+    B, S, Cin = x.shape[0], x.shape[1], x.shape[4]
+    taps, Cout = w.shape[0] ** 3, w.shape[4]
+    y = np.empty((B, S, S, S, Cout), np.float32)
+    b = _f32(bias) if bias is not None else None
+    L.check(lib.ics_op_conv3d_forward(L.fptr(x), L.fptr(w), L.fptr(b), B, S, Cin, Cout, taps, pre_act, L.fptr(y)))
+    return y
+
+
+def conv3d_backward(x, w, dy):
+    lib = L.load()
+    x, w, dy = _f32(x), _f32(w), _f32(dy)
+    B, S, Cin = x.shape[0], x.shape[1], x.shape[4]
+    taps, Cout = w.shape[0] ** 3, w.shape[4]
+    dx = np.empty_like(x)
+    dw = np.empty_like(w)
+    L.check(lib.ics_op_conv3d_backward(L.fptr(x), L.fptr(w), L.fptr(dy), B, S, Cin, Cout, taps, L.fptr(dx), L.fptr(dw)))
+    return dx, dw

@@ -1,0 +1,150 @@
+/*
+ * icsg3d.h -- C ABI of libicsg3d_hip.so, the MI355X (gfx950) engine for the ICSG3D hot path.
+ *
+ * The reference (by256/icsg3d) has no FFI: its boundary is the Python class surface of
+ * unet/unet.py (AtomUnet) and vae/lattice_vae.py (LatticeDFCVAE) over Keras.  This header is what
+ * those classes bind instead of Keras; each entry point cites the reference call it stands in for
+ * (paths relative to the reference root).  icsg3d_amd/_lib.py is the ctypes binding;
+ * INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions: every function returns 0 on success, non-zero on failure with the message in
+ * ics_last_error() (thread-local).  Host tensors are caller-owned, dense, row-major, channels-last
+ * (B,D,H,W,C) float32 unless stated; the library copies them.  All device memory is owned by the
+ * handle and released by *_destroy.  A handle is bound to the HIP device current at creation and is
+ * not thread-safe (the reference drives training from one thread: unet/unet.py:370).
+ */
+#ifndef ICSG3D_H
+#define ICSG3D_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------- library / device */
+const char* ics_last_error(void);
+const char* ics_version(void);
+int ics_device_count(int* count);
+int ics_set_device(int device);
+/* HIP device properties the benchmark reports (name is a 256-byte buffer). */
+int ics_device_info(char* name, int* compute_units, size_t* hbm_bytes);
+
+typedef struct ics_net ics_net; /* opaque: a U-Net or a DFC-VAE engine */
+
+/* ---------------------------------------------------------------- AtomUnet
+ * AtomUnet.__init__ / unet_3d_multiclass            (unet/unet.py:235-355)
+ * loss = weighted_categorical_crossentropy(num_classes) + binary_crossentropy, Adam(lr)
+ *                                                   (unet/unet.py:245-259) */
+typedef struct ics_unet_config {
+  int in_channels;   /* C of input_shape=(d,d,d,C): 1 or 4          (unet/unet.py:240) */
+  int num_classes;   /* 95                                          (unet/unet.py:237) */
+  int d;             /* grid edge, power of two >= 8 (32; 64 is a build extension) */
+  int max_batch;     /* largest batch a single call may carry                             */
+  float lr;          /* Adam learning rate                          (unet/unet.py:241,245) */
+  float loss_weight; /* scalar class weight; <=0 selects float(num_classes)  */
+  int pool_ties_all; /* 1: TF-CPU MaxPool3DGrad tie rule (default), 0: first max only     */
+  int bn_unbias;     /* 1: Keras moving-variance n/(n-(1+eps)) rescale (default)          */
+} ics_unet_config;
+
+int ics_unet_create(const ics_unet_config* cfg, ics_net** out);
+
+/* model.predict(X) -> [soft (B,d,d,d,num_classes), sig (B,d,d,d,1)]   (unet/unet.py:98,383-385;
+ * callers generate.py:220, eval.py:166).  Eval-mode BatchNorm. */
+int ics_unet_predict(ics_net* net, const float* x, int batch, float* soft, float* sig);
+/* Fused inference tail (generate.py:220-225): argmax species + (sig >= thresh) mask, uint8. */
+int ics_unet_predict_labels(ics_net* net, const float* x, int batch, float thresh,
+                            uint8_t* species, uint8_t* mask);
+/* model.train_on_batch / the per-batch step inside fit_generator (unet/unet.py:370): forward in
+ * training mode, loss, backward, BN moving-stat update, Adam.  labels are uint8 class ids
+ * (B,d,d,d) -- the one-hot of unet/data.py:89 is never built; the sigmoid target is labels != 0
+ * (unet/data.py:87).  metrics = [Loss, lsoft, lsig, f1, wr] (unet/unet.py:250). */
+int ics_unet_train_step(ics_net* net, const float* x, const uint8_t* labels, int batch,
+                        float metrics[5]);
+/* model.test_on_batch / validation pass: eval-mode BN, same metrics, no update. */
+int ics_unet_test_step(ics_net* net, const float* x, const uint8_t* labels, int batch,
+                       float metrics[5]);
+
+/* Benchmark path: batch resident in HBM, steps enqueued back-to-back on the engine's stream. */
+int ics_unet_upload_batch(ics_net* net, const float* x, const uint8_t* labels, int batch);
+int ics_unet_train_step_resident(ics_net* net, float metrics_or_null[5]);
+
+/* ---------------------------------------------------------------- LatticeDFCVAE
+ * LatticeDFCVAE.__init__/_set_model/build_encoder/build_decoder (vae/lattice_vae.py:89-230);
+ * loss = mse + alpha*perceptual + beta*kld (vae/lattice_vae.py:232-270). The perceptual U-Net is
+ * an ics_net created by ics_unet_create whose weights stay frozen (vae/lattice_vae.py:120). */
+typedef struct ics_vae_config {
+  int in_channels;  /* C                                           (vae/lattice_vae.py:91)  */
+  int cond_shape;   /* 10                                          (vae/lattice_vae.py:102) */
+  int latent_dim;   /* 256                                         (vae/lattice_vae.py:95)  */
+  int filters[4];   /* 16,32,64,128                                (vae/lattice_vae.py:94)  */
+  int d;            /* 32 (decoder seed (d/8)^3*4, encoder flatten (d/16)^3*4)              */
+  int max_batch;
+  float lr;         /* Adam(5e-4)                                  (vae/lattice_vae.py:98)  */
+  float alpha;      /* 0.5  */
+  float beta;       /* 3e-4 */
+  float pm_layer_weights[4]; /* 1,1,1,1 for re_lu_2/4/6/8          (vae/lattice_vae.py:100-101) */
+  int bn_unbias;
+} ics_vae_config;
+
+int ics_vae_create(const ics_vae_config* cfg, ics_net* perceptual_unet, ics_net** out);
+
+/* encoder.predict([M, cond]) -> (z_mean, z_log_var, z)  (generate.py:196, interpolate.py:50-59);
+ * eps is the N(0,1) draw of sampling() (vae/lattice_vae.py:53-66), injected by the caller. */
+int ics_vae_encode(ics_net* net, const float* x, const float* cond, const float* eps, int batch,
+                   float* z_mean, float* z_log_var, float* z);
+/* decoder.predict([z, cond]) -> (B,d,d,d,C)             (generate.py:208, lattice_vae.py:351) */
+int ics_vae_decode(ics_net* net, const float* z, const float* cond, int batch, float* recon);
+/* model.train_on_batch([M,cond], M) (vae/lattice_vae.py:296) -> [Loss, PM, MSE, KLD]; the
+ * perceptual U-Net runs BatchNorm on batch statistics, frozen. */
+int ics_vae_train_step(ics_net* net, const float* x, const float* cond, const float* eps, int batch,
+                       float metrics[4]);
+/* model.test_on_batch (vae/lattice_vae.py:307): learning phase 0 everywhere. */
+int ics_vae_test_step(ics_net* net, const float* x, const float* cond, const float* eps, int batch,
+                      float metrics[4]);
+int ics_vae_upload_batch(ics_net* net, const float* x, const float* cond, const float* eps, int batch);
+int ics_vae_train_step_resident(ics_net* net, float metrics_or_null[4]);
+
+/* ---------------------------------------------------------------- common to both engines */
+int ics_net_destroy(ics_net* net);
+int ics_net_sync(ics_net* net);
+/* model.save_weights / load_weights / get_weights (unet/unet.py:261-264,378; lattice_vae.py:149,339):
+ * named tensors in Keras layouts (conv kernel (3,3,3,Cin,Cout), dense (in,out)); BatchNorm moving
+ * statistics are the non-trainable entries. */
+int ics_net_num_tensors(ics_net* net, int* count);
+int ics_net_tensor_info(ics_net* net, int index, const char** name, int* ndim, int64_t dims[5],
+                        int* trainable);
+int ics_net_set_tensor(ics_net* net, const char* name, const float* host, size_t count);
+int ics_net_get_tensor(ics_net* net, const char* name, float* host, size_t count);
+/* gradient of the last train step w.r.t. a trainable tensor (parity tests) */
+int ics_net_get_grad(ics_net* net, const char* name, float* host, size_t count);
+int ics_net_set_lr(ics_net* net, float lr);
+/* optimizer step counter (Adam t) and reset of its moments */
+int ics_net_reset_optimizer(ics_net* net);
+
+/* Per-kernel timing with HIP events on the engine's stream (bench.py roofline): enable, run steps,
+ * then read back rows {label, launches, total_ms, total_flop, total_bytes}. */
+int ics_net_profile_enable(ics_net* net, int on);
+int ics_net_profile_count(ics_net* net, int* rows);
+int ics_net_profile_row(ics_net* net, int row, const char** label, int64_t* launches, double* total_ms,
+                        double* total_flop, double* total_bytes);
+
+/* ---------------------------------------------------------------- data parallel (new)
+ * One process per GPU; gradients are summed with one RCCL all-reduce on the flat fp32 gradient
+ * buffer and scaled by 1/nranks before Adam.  uid is an ncclUniqueId (128 bytes) from rank 0. */
+int ics_comm_unique_id(char uid[128]);
+int ics_net_comm_init(ics_net* net, int rank, int nranks, const char uid[128]);
+int ics_net_comm_allreduce_max(ics_net* net, double* value); /* barrier + max over ranks */
+
+/* ---------------------------------------------------------------- single-op entry points
+ * (kernel parity tests against oracle/; host buffers, NDHWC) */
+int ics_op_conv3d_forward(const float* x, const float* w, const float* bias, int B, int S, int Cin,
+                          int Cout, int taps, int pre_act, float* y);
+int ics_op_conv3d_backward(const float* x, const float* w, const float* dy, int B, int S, int Cin,
+                           int Cout, int taps, float* dx, float* dw);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICSG3D_H */
