@@ -67,6 +67,8 @@ SIGNATURES = {
     "ics_net_set_tensor": (C.c_int, [_H, C.c_char_p, _F, C.c_size_t]),
     "ics_net_get_tensor": (C.c_int, [_H, C.c_char_p, _F, C.c_size_t]),
     "ics_net_get_grad": (C.c_int, [_H, C.c_char_p, _F, C.c_size_t]),
+    "ics_net_get_activation": (C.c_int, [_H, C.c_char_p, _F, C.c_size_t]),
+    "ics_net_get_bn_affine": (C.c_int, [_H, C.c_char_p, _F, _F, C.c_size_t]),
     "ics_net_set_lr": (C.c_int, [_H, C.c_float]),
     "ics_net_reset_optimizer": (C.c_int, [_H]),
     "ics_net_profile_enable": (C.c_int, [_H, C.c_int]),

@@ -597,7 +597,7 @@ static WgradPlan plan_wgrad(const ConvGeom& g, const ConvSrc& s0, int nsrc, cons
   long maxsplit = M / 256 > 0 ? M / 256 : 1;
   if (want > maxsplit) want = maxsplit;
   if (want < 1) want = 1;
-  if (want > 64) want = 64;
+  if (want > 512) want = 512;
   int rows = (int)(((M + want - 1) / want + 31) / 32 * 32);
   p.rows_per_split = rows;
   p.ksplit = (M + rows - 1) / rows;

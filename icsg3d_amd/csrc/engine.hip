@@ -132,6 +132,7 @@ struct Net {
   float* tap_copy[4] = {nullptr, nullptr, nullptr, nullptr};   // perceptual taps of the x pass
   float* dtap[4] = {nullptr, nullptr, nullptr, nullptr};
   int resident_batch = 0;
+  int last_batch = 0;                 // batch of the most recent forward (activation export)
 
   // VAE specifics
   Net* pm = nullptr;
@@ -304,6 +305,7 @@ static int pack_layer(Net& n, ConvLayer& L, bool need_bwd) {
 // generic layer forward / backward
 // ------------------------------------------------------------------------------------------
 static int conv_forward(Net& n, ConvLayer& L, int B, bool training, bool update_moving, const float* bias) {
+  n.last_batch = B;
   const ConvGeom g = geom_fwd(L, B);
   const size_t M = n.rows(L, B);
   const bool stats = L.has_bn && training;
@@ -1019,6 +1021,35 @@ int ics_net_get_grad(ics_net* net, const char* name, float* host, size_t count) 
   ICS_HIP(hipMemcpyAsync(host, net->n.G + t->off, count * sizeof(float), hipMemcpyDeviceToHost, net->n.st));
   ICS_HIP(hipStreamSynchronize(net->n.st));
   return 0;
+}
+int ics_net_get_activation(ics_net* net, const char* layer, float* host, size_t count) {
+  ICS_CHECK(net && layer && host, "null argument");
+  Net& n = net->n;
+  for (auto& Lp : n.layers) {
+    if (Lp->name != layer) continue;
+    const size_t cnt = n.rows(*Lp, n.last_batch) * Lp->Cout;
+    ICS_CHECK(cnt == count, std::string("size mismatch for activation ") + layer);
+    ICS_HIP(hipMemcpyAsync(host, Lp->s, cnt * sizeof(float), hipMemcpyDeviceToHost, n.st));
+    ICS_HIP(hipStreamSynchronize(n.st));
+    return 0;
+  }
+  set_error(std::string("unknown layer: ") + layer);
+  return -1;
+}
+int ics_net_get_bn_affine(ics_net* net, const char* layer, float* scale, float* shift, size_t count) {
+  ICS_CHECK(net && layer && scale && shift, "null argument");
+  Net& n = net->n;
+  for (auto& Lp : n.layers) {
+    if (Lp->name != layer) continue;
+    ICS_CHECK(Lp->has_bn, "layer has no BatchNorm");
+    ICS_CHECK(count == (size_t)Lp->Cout, std::string("size mismatch for layer ") + layer);
+    ICS_HIP(hipMemcpyAsync(scale, Lp->scale, count * sizeof(float), hipMemcpyDeviceToHost, n.st));
+    ICS_HIP(hipMemcpyAsync(shift, Lp->shift, count * sizeof(float), hipMemcpyDeviceToHost, n.st));
+    ICS_HIP(hipStreamSynchronize(n.st));
+    return 0;
+  }
+  set_error(std::string("unknown layer: ") + layer);
+  return -1;
 }
 int ics_net_set_lr(ics_net* net, float lr) {
   ICS_CHECK(net, "null handle");

@@ -64,6 +64,17 @@ class _Net:
         L.check(self._lib.ics_net_get_grad(self._h, name.encode(), L.fptr(a), a.size))
         return a
 
+    def get_activation(self, layer, shape):
+        a = np.empty(shape, np.float32)
+        L.check(self._lib.ics_net_get_activation(self._h, layer.encode(), L.fptr(a), a.size))
+        return a
+
+    def get_bn_affine(self, layer, channels):
+        sc = np.empty(channels, np.float32)
+        sh = np.empty(channels, np.float32)
+        L.check(self._lib.ics_net_get_bn_affine(self._h, layer.encode(), L.fptr(sc), L.fptr(sh), channels))
+        return sc, sh
+
     def get_weights(self):
         return {n: self.get_tensor(n, s) for n, s, _ in self.tensor_infos()}
 

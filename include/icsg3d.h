@@ -119,6 +119,13 @@ int ics_net_set_tensor(ics_net* net, const char* name, const float* host, size_t
 int ics_net_get_tensor(ics_net* net, const char* name, float* host, size_t count);
 /* gradient of the last train step w.r.t. a trainable tensor (parity tests) */
 int ics_net_get_grad(ics_net* net, const char* name, float* host, size_t count);
+/* stored pre-BatchNorm activation s = pre_act(conv+b) of a conv layer ("c1".."c18", "e0".., "d0"..)
+ * from the most recent forward, (B*S^3*Cout) floats.  Parity tests use it to pin ReLU masks whose
+ * pre-activation is within fp32 rounding of the kink. */
+int ics_net_get_activation(ics_net* net, const char* layer, float* host, size_t count);
+/* the fp32 BatchNorm affine (scale = gamma*rstd, shift = beta - mean*scale) the most recent forward
+ * applied to that layer's output; lets a test reproduce the engine's max-pool routing bit-exactly. */
+int ics_net_get_bn_affine(ics_net* net, const char* layer, float* scale, float* shift, size_t count);
 int ics_net_set_lr(ics_net* net, float lr);
 /* optimizer step counter (Adam t) and reset of its moments */
 int ics_net_reset_optimizer(ics_net* net);

@@ -167,15 +167,19 @@ def maxpool_fwd(x):
     return _windows(x).max(axis=4)
 
 
-def maxpool_bwd(x, y, dy, ties="tf_cpu"):
+def maxpool_bwd(x, y, dy, ties="tf_cpu", route=None):
     """
+    route: optional tensor to take the routing decision from instead of x (tests pass the tested
+        implementation's own fp32 pool input, see apply_kink: the decision is a discontinuity).
     ties="tf_cpu": TensorFlow's CPU MaxPool3DGrad (pooling_ops_3d.cc, recalled; confidence M)
         routes dy to EVERY window element with |x - max| < 1e-5 (Eigen select, no argmax).
     ties="first": cuDNN-like, only the first maximal element in (dz,dy,dx) scan order.
     The two differ whenever ReLU-dead voxels tie inside a window (common in the U-Net, where
     pooling follows BN(ReLU(.)) ), and then only through the BN-backward sums.
     """
-    xw = _windows(x)
+    xw = _windows(x if route is None else route)
+    if route is not None:
+        y = xw.max(axis=4)
     if ties == "tf_cpu":
         mask = (np.abs(xw - y[..., None, :]) < POOL_TIE_TOL).astype(x.dtype)
     elif ties == "first":
@@ -379,8 +383,10 @@ class Block:
     def bwd(self, do, P, S, cache, grads, need_dx=True, param_grads=True):
         n = self.name
         c = cache[n]
+        # "kink_s"/"kink_bn": activations of the implementation under test; they decide act'(.)
+        # where the fp64 value is within rounding of the kink (see apply_kink)
         if self.has_bn:
-            dbn = act_bwd(c["bn"], do, self.post_act)
+            dbn = act_bwd(c.get("kink_bn", c["bn"]), do, self.post_act)
             if c["training"]:
                 ds, dg, dbt = bn_train_bwd(c["s"], P[n + "/gamma"], c["mean"], c["var"], dbn)
             else:
@@ -392,7 +398,7 @@ class Block:
                 grads[n + "/gamma"], grads[n + "/beta"] = dg, dbt
         else:
             ds = do
-        dy = act_bwd(c["s"], ds, self.pre_act)
+        dy = act_bwd(c.get("kink_s", c["s"]), ds, self.pre_act)
         dx, dw, db = conv3d_bwd(c["x"], P[n + "/kernel"], dy, need_dx=need_dx)
         if param_grads:
             grads[n + "/kernel"], grads[n + "/bias"] = dw, db
@@ -406,6 +412,52 @@ class Block:
         mm, mv = bn_moving_update(S[self.name + "/moving_mean"], S[self.name + "/moving_var"],
                                   c["mean"], c["var"], nel, unbias=unbias)
         S[self.name + "/moving_mean"], S[self.name + "/moving_var"] = mm, mv
+
+
+def apply_kink(blocks, cache, P, kink, tol=1e-4, affine=None):
+    """Pin activation-derivative decisions at the kinks of ReLU / LeakyReLU to the implementation
+    under test.  act'(0) is a discontinuity: among ~1e6 pre-activations a few lie within fp32
+    accumulation error of 0 and an fp32 implementation legitimately masks them differently from
+    fp64; each flip moves a gradient sum by O(max|dy|) (~1e-3 relative here).  kink = {layer: the
+    implementation's stored activations s}.  Raises if a sign differs where BOTH values are farther
+    than `tol` (absolute; forward parity is 1e-5 of max|s|) from 0.  Returns flips per layer.
+    affine = {layer: (scale32, shift32)}: the implementation's fp32 BatchNorm affine; with it the
+    implementation's pool input o = act(fma(s, scale, shift)) is reproduced in fp32 and stored as
+    cache[layer]["impl_o"], which maxpool_bwd then uses for the (equally discontinuous) routing."""
+    flips = {}
+    for blk in blocks:
+        n = blk.name
+        if n not in kink or n not in cache:
+            continue
+        c = cache[n]
+        s_ref = c["s"]
+        s_impl = np.asarray(kink[n], s_ref.dtype).reshape(s_ref.shape)
+        pairs = []
+        if blk.pre_act is not None:
+            pairs.append((s_ref, s_impl))
+            c["kink_s"] = s_impl
+        if blk.has_bn and blk.post_act is not None:
+            if c["training"]:
+                inv = P[n + "/gamma"] / np.sqrt(c["var"] + BN_EPS)
+                bn_impl = s_impl * inv + (P[n + "/beta"] - c["mean"] * inv)
+            else:
+                raise ValueError("kink pinning is for training-mode steps")
+            pairs.append((c["bn"], bn_impl))
+            c["kink_bn"] = bn_impl
+        if affine is not None and n in affine:
+            sc, sh = affine[n]
+            o32 = (s_impl.astype(np.float64) * sc.astype(np.float64) + sh.astype(np.float64)).astype(np.float32)
+            c["impl_o"] = act_fwd(o32, blk.post_act).astype(s_ref.dtype)
+        cnt = 0
+        for ref, impl in pairs:
+            diff = (impl > 0) != (ref > 0)
+            bad = diff & (np.minimum(np.abs(ref), np.abs(impl)) > tol)
+            if bad.any():
+                raise AssertionError("activation signs of %s differ away from the kink (%d elements)"
+                                     % (n, int(bad.sum())))
+            cnt += int(diff.sum())
+        flips[n] = cnt
+    return flips
 
 
 # --------------------------------------------------------------------------------------
@@ -494,11 +546,11 @@ class UnetOracle:
         dc6_skip, du1 = d[..., :256], d[..., 256:]
         d = upsample_bwd(du1)
         d = bw("c10", d); d = bw("c9", d)
-        d = maxpool_bwd(o["c6"], o["p3"], d, self.pool_ties) + dc6_skip
+        d = maxpool_bwd(o["c6"], o["p3"], d, self.pool_ties, cache["c6"].get("impl_o")) + dc6_skip
         d = bw("c6", d); d = bw("c5", d)
-        d = maxpool_bwd(o["c4"], o["p2"], d, self.pool_ties) + dc4_skip
+        d = maxpool_bwd(o["c4"], o["p2"], d, self.pool_ties, cache["c4"].get("impl_o")) + dc4_skip
         d = bw("c4", d); d = bw("c3", d)
-        d = maxpool_bwd(o["c2"], o["p1"], d, self.pool_ties) + dc2_skip
+        d = maxpool_bwd(o["c2"], o["p1"], d, self.pool_ties, cache["c2"].get("impl_o")) + dc2_skip
         d = bw("c2", d); bw("c1", d, need_dx=False)
         return g
 
@@ -508,11 +560,13 @@ class UnetOracle:
             self.P[k], self.m[k], self.v[k] = adam_update(
                 self.P[k], grads[k], self.m[k], self.v[k], self.t, self.lr)
 
-    def train_on_batch(self, x, labels):
-        """One Keras train_on_batch: returns [Loss, lsoft, lsig, f1, wr] (pre-update forward)."""
+    def train_on_batch(self, x, labels, kink=None, kink_tol=1e-4, affine=None):
+        """One Keras train_on_batch: returns [Loss, lsoft, lsig, f1, wr] (pre-update forward).
+        kink: optional {layer: stored activations of the implementation under test} (apply_kink)."""
         cache = {}
         soft, sig = self.forward(x, training=True, cache=cache)
         metrics = self.loss_and_metrics(soft, sig, labels)
+        self.kink_flips = apply_kink(self.blocks.values(), cache, self.P, kink, kink_tol, affine) if kink else {}
         grads = self.backward(labels, cache)
         for blk in self.blocks.values():
             blk.moving_update(self.S, cache, self.bn_unbias)
@@ -543,17 +597,17 @@ class UnetOracle:
                 ds = bn_eval_bwd(P[n + "/gamma"], S[n + "/moving_var"], do)
             if dtap is not None:
                 ds = ds + dtap
-            dy = act_bwd(c["s"], ds, blk.pre_act)
+            dy = act_bwd(c.get("kink_s", c["s"]), ds, blk.pre_act)
             dx, _, _ = conv3d_bwd(c["x"], P[n + "/kernel"], dy)
             return dx
 
         z = np.zeros_like
         d = bw("c10", z(cache["c10"]["s"]), dtaps[3]); d = bw("c9", d)
-        d = maxpool_bwd(o["c6"], o["p3"], d, self.pool_ties)
+        d = maxpool_bwd(o["c6"], o["p3"], d, self.pool_ties, cache["c6"].get("impl_o"))
         d = bw("c6", d, dtaps[2]); d = bw("c5", d)
-        d = maxpool_bwd(o["c4"], o["p2"], d, self.pool_ties)
+        d = maxpool_bwd(o["c4"], o["p2"], d, self.pool_ties, cache["c4"].get("impl_o"))
         d = bw("c4", d, dtaps[1]); d = bw("c3", d)
-        d = maxpool_bwd(o["c2"], o["p1"], d, self.pool_ties)
+        d = maxpool_bwd(o["c2"], o["p1"], d, self.pool_ties, cache["c2"].get("impl_o"))
         d = bw("c2", d, dtaps[0]); d = bw("c1", d)
         return d
 
@@ -701,12 +755,12 @@ class VaeOracle:
         dzlv = dz * eps * 0.5 * np.exp(0.5 * zlv) + self.beta * (-0.5) * (1 - np.exp(zlv)) / B
         dh1, g["z_mean/kernel"], g["z_mean/bias"] = dense_bwd(e["hd"], P["z_mean/kernel"], dzm)
         dh2, g["z_log_var/kernel"], g["z_log_var/bias"] = dense_bwd(e["hd"], P["z_log_var/kernel"], dzlv)
-        da = (dh1 + dh2) * (e["a"] > 0)
+        da = (dh1 + dh2) * (e.get("kink_hd", e["a"]) > 0)
         dflat, g["enc_dense/kernel"], g["enc_dense/bias"] = dense_bwd(e["flat"], P["enc_dense/kernel"], da)
         d = self.e4.bwd(dflat.reshape(e["e4shape"]), P, S, cache, g)
         for i in reversed(range(len(self.enc))):
             o, p = cache["_pool"][i]
-            d = maxpool_bwd(o, p, d, self.unet.pool_ties)
+            d = maxpool_bwd(o, p, d, self.unet.pool_ties, cache["e%d" % i].get("impl_o"))
             d = self.enc[i].bwd(d, P, S, cache, g, need_dx=(i > 0))
         return g
 
@@ -716,10 +770,26 @@ class VaeOracle:
             self.P[k], self.m[k], self.v[k] = adam_update(
                 self.P[k], grads[k], self.m[k], self.v[k], self.t, self.lr)
 
-    def train_on_batch(self, x, cond, eps):
+    def train_on_batch(self, x, cond, eps, kink=None, kink_pm=None, kink_tol=1e-4, affine=None, affine_pm=None):
         """model.train_on_batch([M,cond], M) (lattice_vae.py:296) with eps injected.
-        The perceptual U-Net runs BN in batch-stat mode, weights and moving stats frozen (F9)."""
+        The perceptual U-Net runs BN in batch-stat mode, weights and moving stats frozen (F9).
+        kink / kink_pm: stored activations of the implementation under test for the VAE layers and
+        for the perceptual U-Net's pass over the reconstruction (see apply_kink)."""
         metrics, recon, cache, pmc, taps = self.forward_losses(x, cond, eps, True)
+        self.kink_flips = {}
+        if kink:
+            self.kink_flips.update(apply_kink(self._all_blocks(), cache, self.P, kink, kink_tol, affine))
+            if "enc_dense" in kink:
+                a = cache["_enc"]["a"]
+                hd_impl = np.asarray(kink["enc_dense"], a.dtype).reshape(a.shape)
+                diff = (hd_impl > 0) != (a > 0)
+                if (diff & (np.minimum(np.abs(a), np.abs(hd_impl)) > kink_tol)).any():
+                    raise AssertionError("enc_dense relu masks differ away from the kink")
+                cache["_enc"]["kink_hd"] = hd_impl
+                self.kink_flips["enc_dense"] = int(diff.sum())
+        if kink_pm:
+            fl = apply_kink(self.unet.blocks.values(), pmc, self.unet.P, kink_pm, kink_tol, affine_pm)
+            self.kink_flips.update({"pm/" + k: v for k, v in fl.items()})
         grads = self.backward(x, cache, pmc, taps, recon)
         for blk in self._all_blocks():
             blk.moving_update(self.S, cache, self.bn_unbias)

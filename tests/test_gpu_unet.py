@@ -8,7 +8,7 @@ from oracle import numpy_ref as R
 pytestmark = pytest.mark.gpu
 
 FWD_TOL = 1e-5       # north_star: outputs within 1e-5 tensor-relative of the CPU reference
-GRAD_TOL = 2e-4      # fp32 accumulation through 16 conv+BN layers, tensor-relative
+GRAD_TOL = 1e-4      # fp32 rounding through 16 conv+BN layers, tensor-relative (measured <= 4e-5)
 STEP_TOL = 1e-5
 
 
@@ -47,12 +47,34 @@ def test_unet_predict_matches_oracle(B, d, C, relerr):
     np.testing.assert_allclose(m, m_ref, rtol=1e-4, atol=1e-6)
 
 
+UNET_LAYERS = ["c1", "c2", "c3", "c4", "c5", "c6", "c9", "c10", "c13", "c14", "c15", "c16", "c17", "c18"]
+
+
+def _layer_shape(name, B, d):
+    res = {"c1": 1, "c2": 1, "c3": 2, "c4": 2, "c5": 4, "c6": 4, "c9": 8, "c10": 8, "c13": 4, "c14": 4,
+           "c15": 2, "c16": 2, "c17": 1, "c18": 1}[name]
+    cout = dict((n, c) for n, _, c in R.UNET_CONVS)[name]
+    S = d // res
+    return (B, S, S, S, cout)
+
+
 @pytest.mark.parametrize("ties", ["tf_cpu", "first"])
 def test_unet_train_step_matches_oracle(ties, relerr):
+    """Gradients, BN moving statistics and the Adam update of one train step.
+
+    ReLU'(0) is discontinuous, so the fp64 oracle is evaluated with the engine's own ReLU masks
+    (exported activations); the oracle refuses masks that differ anywhere except within 1e-5 of the
+    kink, so this pins everything but the sign of sub-rounding pre-activations."""
     B, d, C = 2, 16, 1
-    orc, eng, X, lab = _setup(B, d, C, ties)
-    m_ref = orc.train_on_batch(X, lab)
+    lr = 1e-3
+    orc, eng, X, lab = _setup(B, d, C, ties, lr=lr)
+    p0 = {k: v.copy() for k, v in orc.P.items()}
     m = eng.train_step(X, lab)
+    kink = {n: eng.get_activation(n, _layer_shape(n, B, d)) for n in UNET_LAYERS}
+    affine = {n: eng.get_bn_affine(n, _layer_shape(n, B, d)[-1]) for n in ("c2", "c4", "c6")}
+    m_ref = orc.train_on_batch(X, lab, kink=kink, affine=affine)
+    print("relu masks flipped within rounding of 0:", sum(orc.kink_flips.values()), "of",
+          sum(np.prod(_layer_shape(n, B, d)) for n in UNET_LAYERS))
     np.testing.assert_allclose(m[:3], m_ref[:3], rtol=1e-5)
     np.testing.assert_allclose(m[3:], m_ref[3:], rtol=1e-4, atol=1e-6)
     worst = 0.0
@@ -62,13 +84,16 @@ def test_unet_train_step_matches_oracle(ties, relerr):
             e = relerr(g, orc.last_grads[name])
             worst = max(worst, e)
             assert e <= GRAD_TOL, (name, e)
-            assert relerr(eng.get_tensor(name, shape), orc.P[name]) <= STEP_TOL, name
+            # Adam (keras 2.3.1 formula) applied to the engine's own gradient, in fp64
+            p_exp, _, _ = R.adam_update(p0[name], g.astype(np.float64), 0.0, 0.0, 1, lr)
+            assert relerr(eng.get_tensor(name, shape), p_exp) <= 1e-6, name
         else:
             assert relerr(eng.get_tensor(name, shape), orc.S[name]) <= STEP_TOL, name
     print("worst grad rel err", worst)
     # a second step exercises Adam's t=2 bias correction and the repacked weights
-    m_ref2 = orc.train_on_batch(X, lab)
+    eng.set_weights(orc.P)
     m2 = eng.train_step(X, lab)
+    m_ref2 = orc.train_on_batch(X, lab)
     np.testing.assert_allclose(m2[:3], m_ref2[:3], rtol=2e-5)
 
 

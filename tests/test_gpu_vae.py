@@ -40,21 +40,53 @@ def test_vae_encode_decode_match_oracle(relerr):
     np.testing.assert_allclose(m, m_r, rtol=2e-5)
 
 
+def _vae_layer_shapes(B, d, C):
+    sh, S, f = {}, d, (16, 32, 64, 128)
+    for i in range(4):
+        sh["e%d" % i] = (B, S, S, S, f[i]); S //= 2
+    sh["e4"] = (B, S, S, S, 4)
+    sh["enc_dense"] = (B, 256)
+    S = d // 8
+    for i in range(4):
+        sh["d%d" % i] = (B, S, S, S, f[3 - i])
+        if i < 3:
+            S *= 2
+    sh["dout"] = (B, d, d, d, C)
+    return sh
+
+
+def _pm_layer_shapes(B, d):
+    res = {"c1": 1, "c2": 1, "c3": 2, "c4": 2, "c5": 4, "c6": 4, "c9": 8, "c10": 8}
+    cout = dict((n, c) for n, _, c in R.UNET_CONVS)
+    return {n: (B, d // r, d // r, d // r, cout[n]) for n, r in res.items()}
+
+
 def test_vae_train_step_matches_oracle(relerr):
-    uo, vo, ue, ve, X, cond, eps = _setup()
-    m_r = vo.train_on_batch(X, cond, eps)
+    """One DFC-VAE train step: [Loss, PM, MSE, KLD], all gradients, BN statistics, frozen U-Net.
+    Activation kinks are pinned to the engine's stored activations (oracle.apply_kink)."""
+    B, d, C = 2, 16, 1
+    uo, vo, ue, ve, X, cond, eps = _setup(B, d, C)
     m = ve.train_step(X, cond, eps)
+    kink = {n: ve.get_activation(n, s) for n, s in _vae_layer_shapes(B, d, C).items()}
+    kink_pm = {n: ue.get_activation(n, s) for n, s in _pm_layer_shapes(B, d).items()}
+    aff = {n: ve.get_bn_affine(n, _vae_layer_shapes(B, d, C)[n][-1]) for n in ("e0", "e1", "e2", "e3")}
+    aff_pm = {n: ue.get_bn_affine(n, _pm_layer_shapes(B, d)[n][-1]) for n in ("c2", "c4", "c6")}
+    m_r = vo.train_on_batch(X, cond, eps, kink=kink, kink_pm=kink_pm, affine=aff, affine_pm=aff_pm)
+    print("kink flips:", {k: v for k, v in vo.kink_flips.items() if v})
     np.testing.assert_allclose(m, m_r, rtol=2e-5)
     gscale = max(np.abs(g).max() for g in vo.last_grads.values())
+    worst = 0.0
     for name, shape, trainable in ve.tensor_infos():
         if trainable:
             g = ve.get_grad(name, shape)
             # conv biases in front of BatchNorm have exactly-zero true gradient: compare on the
             # scale of the largest gradient instead of their own (rounding-noise) scale
             err = np.abs(g - vo.last_grads[name]).max() / max(np.abs(vo.last_grads[name]).max(), 1e-6 * gscale)
-            assert err <= 5e-4, (name, err)
+            worst = max(worst, err)
+            assert err <= 1e-4, (name, err)   # measured <= 4e-5
         else:
             assert relerr(ve.get_tensor(name, shape), vo.S[name]) <= 1e-5, name
+    print("worst grad rel err", worst)
     # the frozen perceptual U-Net must be untouched (weights AND moving statistics, SURVEY F9)
     for name, shape, _ in ue.tensor_infos():
         ref = uo.P[name] if name in uo.P else uo.S[name]
