@@ -340,6 +340,23 @@ static void pick_fwd_tile(const ConvGeom& g, int* bm, int* bn) {
   *bn = BN;
 }
 
+static bool fwd_is_vec(const ConvGeom& g, const ConvSrc& s0, const ConvSrc& s1) {
+  return (g.Cin % 32 == 0) && (s0.C % 32 == 0) && s0.bcast == 0 && s1.bcast == 0;
+}
+
+// name of the kernel instantiation launch_conv_fwd will run (profiling rows / roofline)
+const char* conv_fwd_kernel_id(const ConvGeom& g, const ConvSrc* src, int nsrc) {
+  ConvSrc s0 = src[0], s1 = src[nsrc > 1 ? 1 : 0];
+  const bool vec = fwd_is_vec(g, s0, s1);
+  int bm, bn;
+  pick_fwd_tile(g, &bm, &bn);
+  if (bm == 64) return vec ? "conv_fwd_kernel<2,2,1,1,vec>" : "conv_fwd_kernel<2,2,1,1,scalar>";
+  if (bn == 128) return vec ? "conv_fwd_kernel<2,2,2,2,vec>" : "conv_fwd_kernel<2,2,2,2,scalar>";
+  if (bn == 96) return vec ? "conv_fwd_kernel<4,1,1,3,vec>" : "conv_fwd_kernel<4,1,1,3,scalar>";
+  if (bn == 64) return vec ? "conv_fwd_kernel<2,2,2,1,vec>" : "conv_fwd_kernel<2,2,2,1,scalar>";
+  return vec ? "conv_fwd_kernel<4,1,1,1,vec>" : "conv_fwd_kernel<4,1,1,1,scalar>";
+}
+
 int conv_fwd_rows_per_block(const ConvGeom& g) {
   int bm, bn;
   pick_fwd_tile(g, &bm, &bn);
@@ -351,7 +368,7 @@ int launch_conv_fwd(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int n
                     float* stat_partial, int* rows_per_block) {
   ConvSrc s0 = src[0], s1 = src[nsrc > 1 ? 1 : 0];
   if (nsrc == 1) s1.C = 0;
-  bool vec = (g.Cin % 32 == 0) && (s0.C % 32 == 0) && s0.bcast == 0 && s1.bcast == 0;
+  bool vec = fwd_is_vec(g, s0, s1);
   int bm, bn;
   pick_fwd_tile(g, &bm, &bn);
 #define ICS_FWD(WM, WN, TM, TN)                                                                  \
@@ -602,6 +619,22 @@ static WgradPlan plan_wgrad(const ConvGeom& g, const ConvSrc& s0, int nsrc, cons
   p.rows_per_split = rows;
   p.ksplit = (M + rows - 1) / rows;
   return p;
+}
+
+const char* conv_wgrad_kernel_id(const ConvGeom& g, const ConvSrc* src, int nsrc) {
+  ConvSrc s0 = src[0], s1 = src[nsrc > 1 ? 1 : 0];
+  const WgradPlan p = plan_wgrad(g, s0, nsrc, s1);
+  if (p.kt == 128) {
+    if (p.nt == 128) return p.vec ? "conv_wgrad_kernel<2,2,2,2,vec>" : "conv_wgrad_kernel<2,2,2,2,scalar>";
+    if (p.nt == 96) return p.vec ? "conv_wgrad_kernel<4,1,1,3,vec>" : "conv_wgrad_kernel<4,1,1,3,scalar>";
+    if (p.nt == 64) return p.vec ? "conv_wgrad_kernel<4,1,1,2,vec>" : "conv_wgrad_kernel<4,1,1,2,scalar>";
+    return p.vec ? "conv_wgrad_kernel<4,1,1,1,vec>" : "conv_wgrad_kernel<4,1,1,1,scalar>";
+  }
+  if (p.kt == 64) {
+    if (p.nt == 128) return p.vec ? "conv_wgrad_kernel<2,2,1,2,vec>" : "conv_wgrad_kernel<2,2,1,2,scalar>";
+    return p.vec ? "conv_wgrad_kernel<2,2,1,1,vec>" : "conv_wgrad_kernel<2,2,1,1,scalar>";
+  }
+  return p.vec ? "conv_wgrad_kernel<1,4,1,1,vec>" : "conv_wgrad_kernel<1,4,1,1,scalar>";
 }
 
 size_t conv_wgrad_workspace_floats(const ConvGeom& g, const ConvSrc* src, int nsrc) {

@@ -310,7 +310,7 @@ static int conv_forward(Net& n, ConvLayer& L, int B, bool training, bool update_
   const size_t M = n.rows(L, B);
   const bool stats = L.has_bn && training;
   int rpb = 128;
-  n.prof.begin(n.st, "conv_fwd:" + L.name, 2.0 * M * L.taps * L.Cin * L.Cout,
+  n.prof.begin(n.st, "conv_fwd:" + L.name + "|" + (n.prof.on ? conv_fwd_kernel_id(g, L.src, L.nsrc) : ""), 2.0 * M * L.taps * L.Cin * L.Cout,
                4.0 * (M * L.Cin + M * L.Cout + (double)L.taps * L.Cin * L.Cout));
   ICS_TRY(launch_conv_fwd(n.st, g, L.src, L.nsrc, L.wp, bias, L.s, L.Cout, L.pre_act,
                           stats ? n.ws_stat : nullptr, &rpb));
@@ -345,7 +345,7 @@ static int conv_grads_from_dy(Net& n, ConvLayer& L, int B, bool need_dA, bool pa
   const ConvGeom g = geom_fwd(L, B);
   const size_t M = n.rows(L, B);
   if (param_grads) {
-    n.prof.begin(n.st, "conv_wgrad:" + L.name, 2.0 * M * L.taps * L.Cin * L.Cout,
+    n.prof.begin(n.st, "conv_wgrad:" + L.name + "|" + (n.prof.on ? conv_wgrad_kernel_id(g, L.src, L.nsrc) : ""), 2.0 * M * L.taps * L.Cin * L.Cout,
                  4.0 * (M * L.Cin + M * L.Cout + (double)L.taps * L.Cin * L.Cout));
     ICS_TRY(launch_conv_wgrad(n.st, g, L.src, L.nsrc, L.dy, L.Cout, n.tg(L.t_w), L.Cout, n.ws_wgrad, n.ws_wgrad_n));
     n.prof.end(n.st);
@@ -353,7 +353,7 @@ static int conv_grads_from_dy(Net& n, ConvLayer& L, int B, bool need_dA, bool pa
   if (need_dA) {
     const ConvGeom gb = geom_bwd(L, B);
     ConvSrc sdy = src_plain(L.dy, L.Cout);
-    n.prof.begin(n.st, "conv_dgrad:" + L.name, 2.0 * M * L.taps * L.Cin * L.Cout,
+    n.prof.begin(n.st, "conv_dgrad:" + L.name + "|" + (n.prof.on ? conv_fwd_kernel_id(gb, &sdy, 1) : ""), 2.0 * M * L.taps * L.Cin * L.Cout,
                  4.0 * (M * L.Cin + M * L.Cout + (double)L.taps * L.Cin * L.Cout));
     ICS_TRY(launch_conv_fwd(n.st, gb, &sdy, 1, L.wf, nullptr, L.dA, L.Cin, ACT_NONE, nullptr, nullptr));
     n.prof.end(n.st);
@@ -560,7 +560,7 @@ static int unet_backward(Net& n, int B) {
   const ConvGeom gh = geom_fwd(H, B);
   {
     ConvGeom gs = gh; gs.Cout = n.ncls; gs.Npad = round_up(n.ncls, 32);
-    n.prof.begin(n.st, "conv_wgrad:head", 2.0 * M * 128 * nc1, 4.0 * M * (128 + nc1));
+    n.prof.begin(n.st, std::string("conv_wgrad:head|") + (n.prof.on ? conv_wgrad_kernel_id(gs, H.src, 1) : ""), 2.0 * M * 128 * nc1, 4.0 * M * (128 + nc1));
     ICS_TRY(launch_conv_wgrad(n.st, gs, H.src, 1, H.s, nc1, n.tg(H.t_w), n.ncls, n.ws_wgrad, n.ws_wgrad_n));
     ConvGeom gg = gh; gg.Cout = 1; gg.Npad = 32;
     ICS_TRY(launch_conv_wgrad(n.st, gg, H.src, 1, H.s + n.ncls, nc1, n.tg(H.t_gamma), 1, n.ws_wgrad, n.ws_wgrad_n));
@@ -568,7 +568,7 @@ static int unet_backward(Net& n, int B) {
     ICS_TRY(colsum(n, H.s, M, nc1, nc1, n.tg(H.t_b)));   // soft/bias | sig/bias are contiguous
     const ConvGeom gb = geom_bwd(H, B);
     ConvSrc sdz = src_plain(H.s, nc1);
-    n.prof.begin(n.st, "conv_dgrad:head", 2.0 * M * 128 * nc1, 4.0 * M * (128 + nc1));
+    n.prof.begin(n.st, std::string("conv_dgrad:head|") + (n.prof.on ? conv_fwd_kernel_id(gb, &sdz, 1) : ""), 2.0 * M * 128 * nc1, 4.0 * M * (128 + nc1));
     ICS_TRY(launch_conv_fwd(n.st, gb, &sdz, 1, H.wf, nullptr, H.dA, 128, ACT_NONE, nullptr, nullptr));
     n.prof.end(n.st);
   }

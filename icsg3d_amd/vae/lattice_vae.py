@@ -1,0 +1,224 @@
+"""LatticeDFCVAE on the MI355X engine -- same class/method surface as
+/root/reference/vae/lattice_vae.py (Conditional deep-feature-consistent VAE).
+
+`LatticeDFCVAE(...)`, `._set_model`, `.train`, `.sample_vae`, `.save_`, `.encoder.predict`,
+`.decoder.predict`, `.model.predict / train_on_batch / test_on_batch / load_weights / save_weights /
+save` keep the reference's names, argument meaning and return shapes (lattice_vae.py:69-357).
+`sampling` is the reparameterisation of lattice_vae.py:53-66; the N(0,1) draw is made on the host
+(np.random) and handed to the engine, so every `predict` is stochastic exactly like the reference
+ unless `eps=` is passed.
+"""
+from __future__ import annotations
+
+import os
+import time
+
+import numpy as np
+
+from ..checkpoint import load_npz, save_npz
+from ..engine import UnetEngine, VaeEngine
+from ..synthetic import glorot_params, unet_param_shapes, vae_param_shapes
+from ..unet.unet import custom_objects
+
+
+class Adam:
+    """Stand-in for keras.optimizers.Adam in constructor signatures (only `lr` is consumed)."""
+
+    def __init__(self, lr=0.001, **_):
+        self.lr = lr
+
+
+def sampling(args, epsilon=None):
+    z_mean, z_log_var = args
+    if epsilon is None:
+        epsilon = np.random.normal(size=np.shape(z_mean))
+    return z_mean + np.exp(0.5 * z_log_var) * epsilon
+
+
+def _to_categorical(y, num_classes):
+    y = np.asarray(y, dtype=int).ravel()
+    out = np.zeros((len(y), num_classes), np.float32)
+    out[np.arange(len(y)), y] = 1.0
+    return out
+
+
+class _Encoder:
+    def __init__(self, o):
+        self._o = o
+
+    def predict(self, inputs, eps=None, batch_size=None):
+        M, cond = inputs
+        M = np.asarray(M)
+        if eps is None:
+            eps = np.random.normal(size=(len(M), self._o.latent_dim))
+        return self._o._engine(len(M)).encode(M, cond, eps)     # (z_mean, z_log_var, z)
+
+
+class _Decoder:
+    def __init__(self, o):
+        self._o = o
+
+    def predict(self, inputs, batch_size=None):
+        z, cond = inputs
+        return self._o._engine(len(z)).decode(z, cond)
+
+
+class _VaeModel:
+    """Stands where `self.model` (encoder o decoder, lattice_vae.py:131-145) stands."""
+
+    def __init__(self, o):
+        self._o = o
+
+    def predict(self, inputs, eps=None):
+        M, cond = inputs
+        _, _, z = self._o.encoder.predict([M, cond], eps=eps)    # the SAMPLED z feeds the decoder (F8)
+        return self._o.decoder.predict([z, cond])
+
+    def _eps(self, n, eps):
+        return np.random.normal(size=(n, self._o.latent_dim)) if eps is None else eps
+
+    def train_on_batch(self, inputs, target=None, eps=None):
+        M, cond = inputs
+        return [float(v) for v in self._o._engine(len(M)).train_step(M, cond, self._eps(len(M), eps))]
+
+    def test_on_batch(self, inputs, target=None, eps=None):
+        M, cond = inputs
+        return [float(v) for v in self._o._engine(len(M)).test_step(M, cond, self._eps(len(M), eps))]
+
+    def load_weights(self, path):
+        w, _ = load_npz(path)
+        self._o._set_weights(w)
+
+    def save_weights(self, path):
+        save_npz(path, self._o._get_weights(), {"input_shape": np.asarray(self._o.input_shape)})
+
+    save = save_weights
+
+
+class LatticeDFCVAE:
+    """Conditional VAE with a deep-feature-consistent (perceptual U-Net) loss; parameters as
+    lattice_vae.py:89-105.  `perceptual_model` is a U-Net checkpoint written by
+    `AtomUnet.model.save` (or an AtomUnet / dict of weights); its weights stay frozen and its
+    BatchNorm runs on batch statistics inside train_on_batch."""
+
+    def __init__(self, input_shape=(32, 32, 32, 4), kernel_size=(3, 3, 3), pool_size=(2, 2, 2),
+                 filters=(16, 32, 64, 128), latent_dim=256, beta=3e-4, alpha=0.5, optimizer=None,
+                 perceptual_model="saved_models/unet.h5",
+                 pm_layers=("re_lu_2", "re_lu_4", "re_lu_6", "re_lu_8"),
+                 pm_layer_weights=(1.0, 1.0, 1.0, 1.0), cond_shape=10, custom_objects=custom_objects,
+                 output_dir="output", pool_ties="tf_cpu"):
+        if tuple(kernel_size) != (3, 3, 3) or tuple(pool_size) != (2, 2, 2) or len(filters) != 4:
+            raise ValueError("the engine implements the reference configuration: 3x3x3 kernels, 2x2x2 pools, 4 filter stages")
+        if list(pm_layers) != ["re_lu_2", "re_lu_4", "re_lu_6", "re_lu_8"]:
+            raise ValueError("perceptual taps are fixed to re_lu_2/4/6/8 (= ReLU outputs of c2,c4,c6,c10)")
+        self.input_shape = tuple(input_shape)
+        self.kernel_size, self.pool_size, self.filters = kernel_size, pool_size, list(filters)
+        self.latent_dim = latent_dim
+        self.channels = self.input_shape[-1]
+        self.optimizer = optimizer if optimizer is not None else Adam(5e-4)
+        self.lr = float(getattr(self.optimizer, "lr", self.optimizer))
+        self.beta, self.alpha = beta, alpha
+        self.batch_size = None
+        self.cond_shape = cond_shape
+        self.losses = []
+        self.sdir = output_dir
+        self.pool_ties = pool_ties
+        self.pm_layers, self.pm_layer_weights = list(pm_layers), list(pm_layer_weights)
+        self.metric_names = ["Loss", "PM", "MSE", "KLD"]
+        # perceptual U-Net weights (load_model(perceptual_model, custom_objects), lattice_vae.py:120)
+        if isinstance(perceptual_model, dict):
+            self._pm_weights = perceptual_model
+        elif hasattr(perceptual_model, "_get_weights"):
+            self._pm_weights = perceptual_model._get_weights()
+        else:
+            self._pm_weights, _ = load_npz(perceptual_model)
+        self._eng = self._pm_eng = None
+        self._host_weights = None
+        self.encoder = self.decoder = self.model = None
+
+    # ---- engine management
+    def _engine(self, batch):
+        batch = max(int(batch), 1)
+        if self._eng is None or batch > self._eng.max_batch:
+            carry = self._get_weights()
+            mb = max(batch, self.batch_size or 0)
+            if self._eng is not None:
+                self._eng.close(); self._pm_eng.close()
+            d, C = self.input_shape[0], self.channels
+            self._pm_eng = UnetEngine(in_channels=C, d=d, max_batch=mb, pool_ties=self.pool_ties,
+                                      num_classes=int(self._pm_weights["soft/bias"].shape[0]))
+            self._pm_eng.set_weights(self._pm_weights)
+            self._eng = VaeEngine(self._pm_eng, in_channels=C, cond_shape=self.cond_shape,
+                                  latent_dim=self.latent_dim, filters=self.filters, d=d, max_batch=mb,
+                                  lr=self.lr, alpha=self.alpha, beta=self.beta,
+                                  pm_layer_weights=self.pm_layer_weights)
+            self._eng.set_weights(carry)
+        return self._eng
+
+    def _get_weights(self):
+        return self._eng.get_weights() if self._eng is not None else dict(self._host_weights)
+
+    def _set_weights(self, w):
+        if self._eng is not None:
+            self._eng.set_weights(w)
+        else:
+            self._host_weights.update({k: np.asarray(v, np.float32) for k, v in w.items()})
+
+    # ---- reference methods
+    def _set_model(self, weights=None, batch_size=20):
+        shapes = vae_param_shapes(self.channels, self.cond_shape, tuple(self.filters), self.latent_dim,
+                                  self.input_shape[0])
+        self._host_weights = glorot_params(shapes, seed=int(np.random.randint(0, 2 ** 31 - 1)))
+        self.encoder, self.decoder, self.model = _Encoder(self), _Decoder(self), _VaeModel(self)
+        self.batch_size = batch_size
+        if weights and os.path.exists(weights):
+            self.model.load_weights(weights)
+            self.filepath = weights
+        elif weights:
+            self.filepath = weights
+        else:
+            self.filepath = "saved_models/lattice_dfc_vae_weights.best.hdf5"
+
+    def train(self, train_gen, val_gen, epochs, weights=None):
+        best_loss = np.inf
+        self.train_batch_size, self.val_batch_size = train_gen.batch_size, val_gen.batch_size
+        self.batch_size = self.train_batch_size
+        self.num_epochs = epochs
+        train_steps = int(len(train_gen.list_IDs) / self.train_batch_size)
+        val_steps = int(len(val_gen.list_IDs) / self.val_batch_size)
+        print("Data size %d,    batch_size %d    steps per epoch %d"
+              % (len(train_gen.list_IDs), self.train_batch_size, train_steps))
+        self._set_model(weights, batch_size=self.train_batch_size)
+        self.losses = np.empty((self.num_epochs, 2))
+        for e in range(self.num_epochs):
+            print("Epoch %s:" % e)
+            t0 = time.time()
+            tm = np.mean([self.model.train_on_batch(list(train_gen[i]), train_gen[i][0]) for i in range(train_steps)], axis=0)
+            vm = np.mean([self.model.test_on_batch(list(val_gen[i]), val_gen[i][0]) for i in range(val_steps)], axis=0) \
+                if val_steps else tm
+            s = "Time: %.3f s   " % (time.time() - t0)
+            s += "".join("Train %s: %.3f    " % (n, v) for n, v in zip(self.metric_names, tm))
+            s += "".join("Val %s: %.3f    " % (n, v) for n, v in zip(self.metric_names, vm))
+            print(s)
+            self.losses[e] = [tm[0], vm[0]]
+            if vm[0] < best_loss:
+                best_loss = vm[0]
+                print("Saving Model")
+                self.model.save_weights(self.filepath)
+        if os.path.exists(self.filepath):
+            self.model.load_weights(self.filepath)
+        self.model.save(os.path.splitext(self.filepath)[0] + ".h5")
+        print("Model saved")
+
+    def save_(self, weights, model="saved_models/vae.h5"):
+        self.model.load_weights(weights)
+        self.model.save(model)
+
+    def sample_vae(self, n_samples, cond=None, var=1.0):
+        if cond is None:
+            cond = np.random.randint(low=0, high=self.cond_shape, size=n_samples)
+        cond_tensor = _to_categorical(cond, self.cond_shape)
+        if len(cond_tensor) != n_samples:      # scalar cond: the reference tiles it (lattice_vae.py:349-350)
+            cond_tensor = np.tile(cond_tensor, (n_samples, 1))[:n_samples]
+        z_sample = np.random.normal(0, var, size=(n_samples, self.latent_dim))
+        return z_sample, self.decoder.predict([z_sample, cond_tensor])

@@ -1,0 +1,66 @@
+"""The reference-shaped Python surface (AtomUnet / LatticeDFCVAE) driven the way
+train_unet.py / train_vae.py / generate.py drive the reference, on synthetic generators."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_atomunet_train_save_predict(tmp_path):
+    from icsg3d_amd.unet.data import SyntheticUnetGenerator
+    from icsg3d_amd.unet.unet import AtomUnet, f1_m
+    d, C, B = 16, 1, 2
+    weights = str(tmp_path / "saved_models" / "unet" / "t" / "unet_weights_t.best.hdf5")
+    np.random.seed(0)
+    unet = AtomUnet(num_classes=95, input_shape=(d, d, d, C), weights=weights, lr=3e-4)
+    tg = SyntheticUnetGenerator(6, batch_size=B, dim=(d, d, d), n_channels=C)
+    vg = SyntheticUnetGenerator(2, batch_size=B, dim=(d, d, d), n_channels=C, seed=100)
+    unet.train_generator(tg, vg, epochs=2, output_dir=str(tmp_path / "out"))
+    assert os.path.exists(weights) and os.path.exists(os.path.splitext(weights)[0] + ".h5")
+    X, (y, b) = vg[0]
+    soft, sig = unet.model.predict(X)
+    assert soft.shape == (B, d, d, d, 95) and sig.shape == (B, d, d, d, 1)
+    np.testing.assert_allclose(soft.sum(-1), 1.0, atol=1e-5)
+    # reload into a fresh object (generate.py:176 path): identical predictions
+    unet2 = AtomUnet(weights=os.path.splitext(weights)[0] + ".h5", input_shape=(d, d, d, C))
+    soft2, sig2 = unet2.model.predict(X)
+    assert np.array_equal(soft, soft2) and np.array_equal(sig, sig2)
+    # one-hot targets (reference generator format) and uint8 ids give the same test metrics
+    onehot = np.eye(95, dtype=np.float32)[y]
+    m1 = unet2.model.test_on_batch(X, [onehot, b])
+    m2 = unet2.model.test_on_batch(X, [y, b])
+    assert m1 == m2
+    # f1 metric column equals the reference's formula evaluated on the predictions
+    assert abs(m1[3] - f1_m(onehot, soft2)) < 1e-5
+    sp, mk = unet2.model.predict_labels(X, 0.8)
+    assert np.array_equal(sp, soft2.argmax(-1)) and np.array_equal(mk, (sig2[..., 0] >= 0.8))
+
+
+def test_lattice_vae_train_sample_roundtrip(tmp_path):
+    from icsg3d_amd.unet.unet import AtomUnet
+    from icsg3d_amd.vae.data import SyntheticVAEGenerator
+    from icsg3d_amd.vae.lattice_vae import LatticeDFCVAE
+    d, C, B = 16, 1, 2
+    np.random.seed(1)
+    unet = AtomUnet(input_shape=(d, d, d, C))
+    pm_path = str(tmp_path / "unet.h5")
+    unet.model.save(pm_path)
+    vae = LatticeDFCVAE(input_shape=(d, d, d, C), perceptual_model=pm_path, output_dir=str(tmp_path))
+    tg = SyntheticVAEGenerator(4, batch_size=B, dim=(d, d, d), n_channels=C)
+    vg = SyntheticVAEGenerator(2, batch_size=B, dim=(d, d, d), n_channels=C, seed=50)
+    wpath = str(tmp_path / "vae_weights.best.hdf5")
+    vae.train(tg, vg, epochs=2, weights=wpath)
+    assert os.path.exists(wpath) and np.all(np.isfinite(vae.losses))
+    M, cond = vg[0]
+    zm, zlv, z = vae.encoder.predict([M, cond])
+    assert zm.shape == (B, 256) and not np.allclose(z, zm)          # sampled z
+    rec = vae.decoder.predict([zm, cond])
+    assert rec.shape == (B, d, d, d, C) and rec.min() >= 0.0         # decoder tail is ReLU
+    zs, out = vae.sample_vae(3, var=0.5)
+    assert out.shape == (3, d, d, d, C)
+    # generate.py:172-173 path: fresh object + _set_model(weights)
+    vae2 = LatticeDFCVAE(input_shape=(d, d, d, C), perceptual_model=pm_path)
+    vae2._set_model(wpath, batch_size=B)
+    assert np.array_equal(vae2.decoder.predict([zm, cond]), rec)
