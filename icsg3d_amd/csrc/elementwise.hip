@@ -471,13 +471,13 @@ int launch_head(hipStream_t st, float* z, int ldz, int ncls, const unsigned char
 // Adam (keras 2.3.1): m,v update, p -= lr_t * m / (sqrt(v) + 1e-7)
 // ------------------------------------------------------------------------------------------
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, size_t n, float lr_t, float b1, float b2, float eps,
-                            float gscale) {
+                            float* __restrict__ v, size_t n, float lr_t, float b1, float b2, float omb1,
+                            float omb2, float eps, float gscale) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float gi = g[i] * gscale;
-  const float mi = b1 * m[i] + (1.f - b1) * gi;
-  const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+  const float mi = b1 * m[i] + omb1 * gi;        // omb = 1-beta evaluated in double on the host
+  const float vi = b2 * v[i] + omb2 * gi * gi;
   m[i] = mi;
   v[i] = vi;
   p[i] = p[i] - lr_t * mi / (sqrtf(vi) + eps);
@@ -485,7 +485,7 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 int launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v, size_t n, float lr_t,
                 float gscale) {
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, g, m, v, n,
-                     lr_t, 0.9f, 0.999f, 1e-7f, gscale);
+                     lr_t, 0.9f, 0.999f, (float)(1.0 - 0.9), (float)(1.0 - 0.999), 1e-7f, gscale);
   ICS_HIP(hipGetLastError());
   return 0;
 }

@@ -86,7 +86,7 @@ def test_unet_train_step_matches_oracle(ties, relerr):
             assert e <= GRAD_TOL, (name, e)
             # Adam (keras 2.3.1 formula) applied to the engine's own gradient, in fp64
             p_exp, _, _ = R.adam_update(p0[name], g.astype(np.float64), 0.0, 0.0, 1, lr)
-            assert relerr(eng.get_tensor(name, shape), p_exp) <= 1e-6, name
+            assert relerr(eng.get_tensor(name, shape), p_exp) <= 2e-5, name   # fp32 Adam arithmetic
         else:
             assert relerr(eng.get_tensor(name, shape), orc.S[name]) <= STEP_TOL, name
     print("worst grad rel err", worst)
