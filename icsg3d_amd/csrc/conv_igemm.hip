@@ -11,6 +11,8 @@
 // k group (lane half h supplies k = 4h..4h+3), which only reorders the fp32 summation.
 #include "common.h"
 
+#include <vector>
+
 namespace ics {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -23,6 +25,35 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nblk) {
   // so neighbouring M-tiles (shared halo) and the N-tiles of one M-tile hit the same L2.
   const int xcd = bid & 7, q = nblk >> 3, r = nblk & 7;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// Sources without a BatchNorm affine get pointers to constant ones/zeros so that the tile loaders
+// never branch on "has affine" (fma(v,1,0) == v exactly).
+static int identity_affine(const float** ones, const float** zeros) {
+  constexpr int kN = 4096;
+  static float* buf[64] = {nullptr};
+  int dev = 0;
+  ICS_HIP(hipGetDevice(&dev));
+  ICS_CHECK(dev >= 0 && dev < 64, "device index out of range");
+  if (!buf[dev]) {
+    float* p = nullptr;
+    ICS_HIP(hipMalloc(&p, 2 * kN * sizeof(float)));
+    std::vector<float> h(2 * kN, 0.f);
+    for (int i = 0; i < kN; ++i) h[i] = 1.f;
+    ICS_HIP(hipMemcpy(p, h.data(), 2 * kN * sizeof(float), hipMemcpyHostToDevice));
+    buf[dev] = p;
+  }
+  *ones = buf[dev];
+  *zeros = buf[dev] + kN;
+  return 0;
+}
+static int fix_src(ConvSrc& s) {
+  if (s.scale == nullptr) {
+    ICS_CHECK(s.C <= 4096, "source wider than the identity-affine buffer");
+    ICS_TRY(identity_affine(&s.scale, &s.shift));
+    s.act = ACT_NONE;
+  }
+  return 0;
 }
 
 struct RowPos {
@@ -46,12 +77,27 @@ __device__ __forceinline__ size_t src_voxel(const ConvSrc& s, int b, int z, int 
   return ((((size_t)b * S + z) * S + y) * S + x) * (size_t)s.C;
 }
 
-__device__ __forceinline__ float4 affine_act4(float4 v, float4 sc, float4 sh, int act) {
-  v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
-  v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
-  v.x = act_fwd(v.x, act); v.y = act_fwd(v.y, act); v.z = act_fwd(v.z, act); v.w = act_fwd(v.w, act);
-  return v;
+// Branch-free activation: slope 1 = identity, 0 = ReLU, 0.3 = LeakyReLU.  max(v,0)+slope*min(v,0)
+// is exact for all three (one term is always zero), and keeps the tile loaders a single basic block
+// so the scheduler can run the next tile's address math and loads under the current tile's MFMAs.
+__device__ __forceinline__ float act_slope_of(int act) {
+  return act == ACT_RELU ? 0.f : (act == ACT_LRELU ? kLeaky : 1.f);
 }
+__device__ __forceinline__ float act_apply(float v, float slope) {
+  return fmaxf(v, 0.f) + slope * fminf(v, 0.f);
+}
+__device__ __forceinline__ v4f affine_act4(v4f v, v4f sc, v4f sh, float slope) {
+  v4f r;
+  r.x = act_apply(fmaf(v.x, sc.x, sh.x), slope); r.y = act_apply(fmaf(v.y, sc.y, sh.y), slope);
+  r.z = act_apply(fmaf(v.z, sc.z, sh.z), slope); r.w = act_apply(fmaf(v.w, sc.w, sh.w), slope);
+  return r;
+}
+// element offset of the (clamped) voxel in a source; u = 1 for a nearest-upsampled source
+__device__ __forceinline__ unsigned voxel_off(int b, int z, int y, int x, int S, int u, int C) {
+  const int Ss = S >> u;
+  return ((((unsigned)b * Ss + (z >> u)) * Ss + (y >> u)) * Ss + (x >> u)) * (unsigned)C;
+}
+__device__ __forceinline__ int clampi(int v, int hi) { return min(max(v, 0), hi); }
 
 // field-wise select (a reference to `cond ? s0 : s1` would force both kernel-arg structs to scratch)
 __device__ __forceinline__ ConvSrc pick_src(const ConvSrc& s0, const ConvSrc& s1, bool first) {
@@ -114,6 +160,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
 
   // ---- per-thread row bookkeeping
   const int mrow_base = mb * BM + (VEC ? (t >> 3) : (t >> 5));   // + 32*r (VEC) / 8*r (SCALAR)
+  const float slope0 = act_slope_of(s0.act), slope1 = act_slope_of(s1.act);
+  const float pre_slope = act_slope_of(pre_act);
 
   v4f ra4[RA];
   float ras[RS];
@@ -130,17 +178,17 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
     // ---- A tile
     if (VEC) {
       const int tap = c / cpt, ci0 = (c - tap * cpt) << 5;
-      int dz = 0, dy = 0, dx = 0;
-      if (g.taps == 27) { dz = tap / 9 - 1; dy = (tap / 3) % 3 - 1; dx = tap % 3 - 1; }
+      const bool t27 = g.taps == 27;
+      const int dz = t27 ? tap / 9 - 1 : 0, dy = t27 ? (tap / 3) % 3 - 1 : 0, dx = t27 ? tap % 3 - 1 : 0;
       const bool first = ci0 < s0.C;
-      const ConvSrc s = pick_src(s0, s1, first);
+      const float* sp = first ? s0.p : s1.p;
+      const float* sscale = first ? s0.scale : s1.scale;
+      const float* sshift = first ? s0.shift : s1.shift;
+      const int sC = first ? s0.C : s1.C, su = first ? s0.up : s1.up;
+      const float slope = first ? slope0 : slope1;
       const int cl = (first ? ci0 : ci0 - s0.C) + (t & 7) * 4;
-      float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-      const bool aff = s.scale != nullptr;
-      if (aff) {
-        sc = *reinterpret_cast<const float4*>(s.scale + cl);
-        sh = *reinterpret_cast<const float4*>(s.shift + cl);
-      }
+      const v4f sc = *reinterpret_cast<const v4f*>(sscale + cl);
+      const v4f sh = *reinterpret_cast<const v4f*>(sshift + cl);
 #pragma unroll
       for (int r = 0; r < RA; ++r) {
         const int m = mrow_base + 32 * r;
@@ -148,12 +196,10 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
         const int zz = rp.z + dz, yy = rp.y + dy, xx = rp.x + dx;
         const bool inb = m < M && (unsigned)zz < (unsigned)S && (unsigned)yy < (unsigned)S &&
                          (unsigned)xx < (unsigned)S;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (inb) {
-          v = *reinterpret_cast<const float4*>(s.p + src_voxel(s, rp.b, zz, yy, xx, S) + cl);
-          if (aff) v = affine_act4(v, sc, sh, s.act);
-        }
-        ra4[r] = v4f{v.x, v.y, v.z, v.w};
+        const unsigned off = voxel_off(min(rp.b, g.B - 1), clampi(zz, S - 1), clampi(yy, S - 1),
+                                       clampi(xx, S - 1), S, su, sC) + cl;
+        const v4f v = affine_act4(*reinterpret_cast<const v4f*>(sp + off), sc, sh, slope);
+        ra4[r] = inb ? v : v4f{0.f, 0.f, 0.f, 0.f};   // zero "same" padding applies after BN/act
       }
     } else {
       const int kf = (c << 5) + (t & 31);
@@ -244,7 +290,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
-        float v = act_fwd(acc[i][j][r] + bv, pre_act);
+        float v = act_apply(acc[i][j][r] + bv, pre_slope);
         const bool ok = m < M;
         if (!ok) v = 0.f;
         acc[i][j][r] = v;
@@ -368,6 +414,8 @@ int launch_conv_fwd(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int n
                     float* stat_partial, int* rows_per_block) {
   ConvSrc s0 = src[0], s1 = src[nsrc > 1 ? 1 : 0];
   if (nsrc == 1) s1.C = 0;
+  ICS_TRY(fix_src(s0));
+  ICS_TRY(fix_src(s1));
   bool vec = fwd_is_vec(g, s0, s1);
   int bm, bn;
   pick_fwd_tile(g, &bm, &bn);
@@ -387,16 +435,17 @@ int launch_conv_fwd(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int n
 // =====================================================================================
 // Backward-weight kernel: ws[split][k][n] = sum_{m in split} A[m][k] * dy[m][n]
 // =====================================================================================
-template <int WM, int WN, int TM, int TN, bool VEC>
+template <int WM, int WN, int TM, int TN, bool VEC, bool DYVEC>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvGeom g, ConvSrc s0, ConvSrc s1,
                                                           const float* __restrict__ dy, int ldy,
-                                                          int n_load, int dy_vec,
+                                                          int n_load,
                                                           float* __restrict__ ws, int ktiles,
                                                           int ntiles, int rows_per_split) {
   constexpr int KT = WM * TM * 32, NT = WN * TN * 32;
   constexpr int A_FLOATS = 32 * KT, D_FLOATS = 32 * NT;
-  constexpr int AF4 = KT / 4, ATOT = 32 * AF4, APASS = (ATOT + 255) / 256;   // 256 % AF4 == 0
-  constexpr int DF4 = NT / 4, DTOT = 32 * DF4, DPASS = (DTOT + 255) / 256;
+  constexpr int AF4 = KT / 4, ATOT = 32 * AF4, APASS = ATOT / 256;   // 256 % AF4 == 0
+  constexpr int DF4 = NT / 4, DTOT = 32 * DF4, DPASS = DTOT / 256;
+  static_assert(ATOT % 256 == 0 && DTOT % 256 == 0, "tile loads must divide evenly over 256 threads");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                    // [2][32][KT]
   float* Ds = smem + 2 * A_FLOATS;     // [2][32][NT]
@@ -437,12 +486,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvGeom g, ConvSrc s0,
   }
   const bool first = ci0 < s0.C;
   const ConvSrc sv = pick_src(s0, s1, first);
-  const int cl0 = first ? ci0 : ci0 - s0.C;
-  const bool aff = VEC && sv.scale != nullptr;
-  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (aff && (t % AF4) * 4 < KT) {
-    sc = *reinterpret_cast<const float4*>(sv.scale + cl0 + (t % AF4) * 4);
-    sh = *reinterpret_cast<const float4*>(sv.shift + cl0 + (t % AF4) * 4);
+  const int cl0 = (first ? ci0 : ci0 - s0.C) + (t % AF4) * 4;
+  const float slope = act_slope_of(sv.act);
+  v4f sc = v4f{1.f, 1.f, 1.f, 1.f}, sh = v4f{0.f, 0.f, 0.f, 0.f};
+  if (VEC) {
+    sc = *reinterpret_cast<const v4f*>(sv.scale + cl0);
+    sh = *reinterpret_cast<const v4f*>(sv.shift + cl0);
   }
 
   v4f ra[VEC ? APASS : 1];
@@ -454,20 +503,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvGeom g, ConvSrc s0,
     if (VEC) {
 #pragma unroll
       for (int p = 0; p < APASS; ++p) {
-        const int idx = t + 256 * p;
-        const int row = idx / AF4;
-        const int m = mbase + row;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (idx < ATOT && m < m_end) {
-          const RowPos r = decode_row(m, S, lg);
-          const int zz = r.z + dz, yy = r.y + dyy, xx = r.x + dx;
-          if ((unsigned)zz < (unsigned)S && (unsigned)yy < (unsigned)S && (unsigned)xx < (unsigned)S) {
-            v = *reinterpret_cast<const float4*>(sv.p + src_voxel(sv, r.b, zz, yy, xx, S) + cl0 +
-                                                 (t % AF4) * 4);
-            if (aff) v = affine_act4(v, sc, sh, sv.act);
-          }
-        }
-        ra[p] = v4f{v.x, v.y, v.z, v.w};
+        const int m = mbase + (t + 256 * p) / AF4;
+        const RowPos r = decode_row(min(m, M - 1), S, lg);
+        const int zz = r.z + dz, yy = r.y + dyy, xx = r.x + dx;
+        const bool inb = m < m_end && (unsigned)zz < (unsigned)S && (unsigned)yy < (unsigned)S &&
+                         (unsigned)xx < (unsigned)S;
+        const unsigned off = voxel_off(r.b, clampi(zz, S - 1), clampi(yy, S - 1), clampi(xx, S - 1), S,
+                                       sv.up, sv.C) + cl0;
+        const v4f v = affine_act4(*reinterpret_cast<const v4f*>(sv.p + off), sc, sh, slope);
+        ra[p] = inb ? v : v4f{0.f, 0.f, 0.f, 0.f};
       }
     } else {
 #pragma unroll
@@ -486,22 +530,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvGeom g, ConvSrc s0,
 #pragma unroll
     for (int p = 0; p < DPASS; ++p) {
       const int idx = t + 256 * p;
-      const int row = idx / DF4;
-      const int m = mbase + row;
+      const int m = mbase + idx / DF4;
       const int n = n0 + (idx % DF4) * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (idx < DTOT && m < m_end) {
-        const float* q = dy + (size_t)m * ldy + n;
-        if (dy_vec) {
-          if (n < n_load) v = *reinterpret_cast<const float4*>(q);
-        } else {
-          if (n + 0 < n_load) v.x = q[0];
-          if (n + 1 < n_load) v.y = q[1];
-          if (n + 2 < n_load) v.z = q[2];
-          if (n + 3 < n_load) v.w = q[3];
-        }
+      const float* q = dy + (size_t)min(m, M - 1) * ldy;
+      v4f v;
+      if (DYVEC) {
+        v = *reinterpret_cast<const v4f*>(q + min(n, n_load - 4));
+        if (!(m < m_end && n < n_load)) v = v4f{0.f, 0.f, 0.f, 0.f};
+      } else {
+        v.x = q[min(n + 0, n_load - 1)]; v.y = q[min(n + 1, n_load - 1)];
+        v.z = q[min(n + 2, n_load - 1)]; v.w = q[min(n + 3, n_load - 1)];
+        const bool rowok = m < m_end;
+        v.x = (rowok && n + 0 < n_load) ? v.x : 0.f; v.y = (rowok && n + 1 < n_load) ? v.y : 0.f;
+        v.z = (rowok && n + 2 < n_load) ? v.z : 0.f; v.w = (rowok && n + 3 < n_load) ? v.w : 0.f;
       }
-      rd[p] = v4f{v.x, v.y, v.z, v.w};
+      rd[p] = v;
     }
   };
   auto store_chunk = [&](int buf) {
@@ -511,7 +554,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvGeom g, ConvSrc s0,
 #pragma unroll
       for (int p = 0; p < APASS; ++p) {
         const int idx = t + 256 * p;
-        if (idx < ATOT) *reinterpret_cast<v4f*>(A + (idx / AF4) * KT + (idx % AF4) * 4) = ra[p];
+        *reinterpret_cast<v4f*>(A + (idx / AF4) * KT + (idx % AF4) * 4) = ra[p];
       }
     } else {
 #pragma unroll
@@ -520,7 +563,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvGeom g, ConvSrc s0,
 #pragma unroll
     for (int p = 0; p < DPASS; ++p) {
       const int idx = t + 256 * p;
-      if (idx < DTOT) *reinterpret_cast<v4f*>(D + (idx / DF4) * NT + (idx % DF4) * 4) = rd[p];
+      *reinterpret_cast<v4f*>(D + (idx / DF4) * NT + (idx % DF4) * 4) = rd[p];
     }
   };
 
@@ -643,13 +686,12 @@ size_t conv_wgrad_workspace_floats(const ConvGeom& g, const ConvSrc* src, int ns
   return (size_t)p.ksplit * g.taps * g.Cin * g.Cout;
 }
 
-template <int WM, int WN, int TM, int TN, bool VEC>
+template <int WM, int WN, int TM, int TN, bool VEC, bool DYVEC>
 static int launch_wgrad_cfg(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, const ConvSrc& s1,
-                            const float* dy, int ldy, int n_load, int dy_vec, float* ws,
-                            const WgradPlan& p) {
+                            const float* dy, int ldy, int n_load, float* ws, const WgradPlan& p) {
   constexpr int KT = WM * TM * 32, NT = WN * TN * 32;
   const size_t lds = (size_t)2 * 32 * (KT + NT) * sizeof(float);
-  auto kern = conv_wgrad_kernel<WM, WN, TM, TN, VEC>;
+  auto kern = conv_wgrad_kernel<WM, WN, TM, TN, VEC, DYVEC>;
   static bool attr_set = false;
   if (!attr_set) {
     ICS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -657,7 +699,7 @@ static int launch_wgrad_cfg(hipStream_t st, const ConvGeom& g, const ConvSrc& s0
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3(p.ktiles * p.ntiles * p.ksplit), dim3(256), lds, st, g, s0, s1, dy,
-                     ldy, n_load, dy_vec, ws, p.ktiles, p.ntiles, p.rows_per_split);
+                     ldy, n_load, ws, p.ktiles, p.ntiles, p.rows_per_split);
   ICS_HIP(hipGetLastError());
   return 0;
 }
@@ -667,32 +709,41 @@ int launch_conv_wgrad(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int
                       size_t workspace_floats) {
   ConvSrc s0 = src[0], s1 = src[nsrc > 1 ? 1 : 0];
   if (nsrc == 1) s1.C = 0;
-  const WgradPlan p = plan_wgrad(g, s0, nsrc, s1);
+  ICS_TRY(fix_src(s0));
+  ICS_TRY(fix_src(s1));
+  WgradPlan p = plan_wgrad(g, s0, nsrc, s1);
   const size_t n_elems = (size_t)g.taps * g.Cin * g.Cout;
-  ICS_CHECK((size_t)p.ksplit * n_elems <= workspace_floats, "wgrad workspace too small");
-  // dy columns that may be loaded: the whole row span of dy that is addressable from this column
-  // offset (callers pass dy already offset); vector loads need 16-byte alignment of every row.
+  // dy may be a column slice of a wider matrix (callers pass it already offset); vector loads need
+  // 16-byte aligned rows and a multiple-of-4 column count that stays inside the row.
   const int n_load4 = (g.Cout + 3) / 4 * 4;
-  const int dy_vec = (ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(dy) & 15) == 0) &&
-                     (n_load4 <= ldy);
+  const bool dy_vec = (ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(dy) & 15) == 0) && (n_load4 <= ldy);
   const int n_load = dy_vec ? n_load4 : g.Cout;
-#define ICS_WG(WM, WN, TM, TN)                                                                     \
-  do {                                                                                             \
-    if (p.vec) ICS_TRY((launch_wgrad_cfg<WM, WN, TM, TN, true>(st, g, s0, s1, dy, ldy, n_load,     \
-                                                                dy_vec, workspace, p)));            \
-    else ICS_TRY((launch_wgrad_cfg<WM, WN, TM, TN, false>(st, g, s0, s1, dy, ldy, n_load, dy_vec,  \
-                                                           workspace, p)));                         \
+  if (!dy_vec) {   // scalar dy loads exist only for the smallest N tile of each K tile
+    p.nt = (p.kt == 128) ? 32 : (p.kt == 64) ? 64 : 128;
+    p.ntiles = (g.Npad + p.nt - 1) / p.nt;
+  }
+  ICS_CHECK((size_t)p.ksplit * n_elems <= workspace_floats, "wgrad workspace too small");
+#define ICS_WG(WM, WN, TM, TN, DV)                                                                   \
+  do {                                                                                               \
+    if (p.vec) ICS_TRY((launch_wgrad_cfg<WM, WN, TM, TN, true, DV>(st, g, s0, s1, dy, ldy, n_load,   \
+                                                                    workspace, p)));                 \
+    else ICS_TRY((launch_wgrad_cfg<WM, WN, TM, TN, false, DV>(st, g, s0, s1, dy, ldy, n_load,        \
+                                                               workspace, p)));                      \
   } while (0)
-  if (p.kt == 128) {
-    if (p.nt == 128) ICS_WG(2, 2, 2, 2);
-    else if (p.nt == 96) ICS_WG(4, 1, 1, 3);
-    else if (p.nt == 64) ICS_WG(4, 1, 1, 2);
-    else ICS_WG(4, 1, 1, 1);
+  if (!dy_vec) {
+    if (p.kt == 128) ICS_WG(4, 1, 1, 1, false);
+    else if (p.kt == 64) ICS_WG(2, 2, 1, 1, false);
+    else ICS_WG(1, 4, 1, 1, false);
+  } else if (p.kt == 128) {
+    if (p.nt == 128) ICS_WG(2, 2, 2, 2, true);
+    else if (p.nt == 96) ICS_WG(4, 1, 1, 3, true);
+    else if (p.nt == 64) ICS_WG(4, 1, 1, 2, true);
+    else ICS_WG(4, 1, 1, 1, true);
   } else if (p.kt == 64) {
-    if (p.nt == 128) ICS_WG(2, 2, 1, 2);
-    else ICS_WG(2, 2, 1, 1);
+    if (p.nt == 128) ICS_WG(2, 2, 1, 2, true);
+    else ICS_WG(2, 2, 1, 1, true);
   } else {
-    ICS_WG(1, 4, 1, 1);
+    ICS_WG(1, 4, 1, 1, true);
   }
 #undef ICS_WG
   const int thr = 256;
