@@ -1,0 +1,43 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/icsg3d.h declares
+(no compute calls here: there is no GPU).  Also checks the ctypes table covers the header."""
+import ctypes
+import os
+import re
+
+from icsg3d_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "icsg3d.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ics_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    names = header_functions()
+    assert len(names) >= 35
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), "libicsg3d_hip.so does not export %s" % n
+        assert n in _lib.SIGNATURES, "icsg3d_amd/_lib.py has no prototype for %s" % n
+    assert sorted(_lib.SIGNATURES) == names, "binding declares symbols missing from the header"
+
+
+def test_library_reports_version_and_errors_without_gpu():
+    lib = _lib.load()
+    assert b"gfx950" in lib.ics_version()
+    # a failing call must return non-zero and leave a message; never crash, never fall back to CPU
+    h = ctypes.c_void_p()
+    rc = lib.ics_unet_create(None, ctypes.byref(h))
+    assert rc != 0 and lib.ics_last_error()
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "icsg3d_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), os.path.join(dirpath, f)

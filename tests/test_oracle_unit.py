@@ -1,0 +1,97 @@
+"""Finite-difference and semantic checks of the oracle's ops (Keras semantics of SURVEY App. B)."""
+import numpy as np
+
+from oracle import numpy_ref as R
+
+
+def fd(f, x, h=1e-6):
+    g = np.zeros_like(x)
+    it = np.nditer(x, flags=["multi_index"])
+    while not it.finished:
+        i = it.multi_index
+        old = x[i]
+        x[i] = old + h; fp = f()
+        x[i] = old - h; fm = f()
+        x[i] = old
+        g[i] = (fp - fm) / (2 * h)
+        it.iternext()
+    return g
+
+
+def test_conv_bn_act_block_gradients():
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((2, 4, 4, 4, 3))
+    P = {"b/kernel": rng.standard_normal((3, 3, 3, 3, 2)) * 0.3, "b/bias": rng.standard_normal(2),
+         "b/gamma": rng.uniform(0.5, 1.5, 2), "b/beta": rng.standard_normal(2)}
+    w = rng.standard_normal((2, 4, 4, 4, 2))
+    for pre, post in (("relu", None), (None, "lrelu"), (None, "relu")):
+        blk = R.Block("b", pre, True, post)
+
+        def loss():
+            return float((blk.fwd(x, P, {}, True, {}) * w).sum())
+        cache, g = {}, {}
+        blk.fwd(x, P, {}, True, cache)
+        dx = blk.bwd(w, P, {}, cache, g)
+        np.testing.assert_allclose(dx, fd(loss, x), rtol=1e-5, atol=1e-7)
+        for k in P:
+            np.testing.assert_allclose(g[k], fd(loss, P[k]), rtol=1e-5, atol=1e-6, err_msg=k)
+
+
+def test_pool_and_upsample():
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((1, 4, 4, 4, 2))
+    y = R.maxpool_fwd(x)
+    assert y.shape == (1, 2, 2, 2, 2)
+    dy = rng.standard_normal(y.shape)
+    for ties in ("tf_cpu", "first"):   # no ties in random data: both route to the argmax
+        dx = R.maxpool_bwd(x, y, dy, ties)
+        assert np.isclose(dx.sum(), dy.sum()) and np.count_nonzero(dx) == dy.size
+    # exact ties (ReLU-dead voxels behind BN): TF-CPU rule duplicates, "first" does not
+    xt = np.zeros((1, 2, 2, 2, 1)); yt = R.maxpool_fwd(xt); dt = np.ones_like(yt)
+    assert R.maxpool_bwd(xt, yt, dt, "tf_cpu").sum() == 8 and R.maxpool_bwd(xt, yt, dt, "first").sum() == 1
+    u = R.upsample_fwd(y)
+    assert u.shape == x.shape and np.array_equal(u[0, :2, :2, :2, 0], np.full((2, 2, 2), y[0, 0, 0, 0, 0]))
+    assert np.allclose(R.upsample_bwd(np.ones_like(x)), 8.0)
+
+
+def test_unet_losses_and_metrics():
+    rng = np.random.default_rng(2)
+    z = rng.standard_normal((2, 2, 2, 2, 5)) * 3
+    lab = rng.integers(0, 5, (2, 2, 2, 2))
+    y = R.one_hot(lab, 5)
+    p = R.softmax(z)
+
+    def loss():
+        return float(R.wcce_loss(y, R.softmax(z), 5.0).mean())
+    dz = R.softmax_bwd(p, R.wcce_bwd(y, p, 5.0, np.full(2, 0.5)))
+    np.testing.assert_allclose(dz, fd(loss, z), rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(dz, 5.0 * (p - y) / (2 * 8), rtol=1e-9)   # closed form used on the GPU
+    # clip: a true-class probability below 1e-7 contributes log(1e-7) and no gradient
+    z2 = np.zeros((1, 1, 1, 1, 3)); z2[..., 0] = 40.0
+    y2 = R.one_hot(np.array([[[[1]]]]), 3)
+    assert np.isclose(R.wcce_loss(y2, R.softmax(z2), 3.0)[0], -3.0 * np.log(1e-7))
+    assert np.all(R.wcce_bwd(y2, R.softmax(z2), 3.0, np.ones(1)) == 0)
+    # metrics: round-half-even => p == 0.5 is not a positive
+    yy = np.array([[[[[1.0, 0.0]]]]]); pp = np.array([[[[[0.5, 0.5]]]]])
+    assert R.f1_m(yy, pp) == 0.0
+    pp = np.array([[[[[0.6, 0.4]]]]])
+    assert np.isclose(R.f1_m(yy, pp), 2 * (1 * 1) / (1 + 1 + 1e-7), rtol=1e-6)
+    assert R.wr_m(yy, pp) == 0.0      # class 0 carries zero weight
+
+
+def test_adam_and_bn_moving_update():
+    p, m, v = R.adam_update(np.array([1.0]), np.array([0.5]), 0.0, 0.0, 1, 1e-3)
+    lr_t = 1e-3 * np.sqrt(1 - 0.999) / (1 - 0.9)
+    assert np.isclose(p[0], 1.0 - lr_t * 0.05 / (np.sqrt(0.001 * 0.25) + 1e-7))
+    mm, mv = R.bn_moving_update(np.zeros(1), np.ones(1), np.array([2.0]), np.array([4.0]), 100)
+    assert np.isclose(mm[0], 0.02) and np.isclose(mv[0], 0.99 + 0.01 * 4.0 * 100 / (100 - 1.001))
+
+
+def test_vae_cond_tiling_and_shapes():
+    u = R.UnetOracle(in_ch=4, seed=1)
+    v = R.VaeOracle(u, in_ch=4, d=16, seed=3)
+    assert v.P["e0/kernel"].shape == (3, 3, 3, 44, 16)        # C + C*cond
+    cond = np.eye(10)[[3]]
+    t = v.tile_cond(cond, 16)
+    assert t.shape == (1, 16, 16, 16, 40) and t[0, 5, 6, 7, 13] == 1.0 and t[0, 0, 0, 0, 12] == 0.0
+    assert dict(R.vae_param_shapes(1, d=64))["dec_dense/kernel"] == (266, 2048)  # seed (d/8)^3*4 (F12 extension)
