@@ -79,6 +79,7 @@ SIGNATURES = {
     "ics_net_comm_init": (C.c_int, [_H, C.c_int, C.c_int, C.c_char_p]),
     "ics_net_comm_allreduce_max": (C.c_int, [_H, C.POINTER(C.c_double)]),
     "ics_op_conv3d_forward": (C.c_int, [_F, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _F]),
+    "ics_op_conv3d_bench": (C.c_int, [C.c_int] * 8 + [_F]),
     "ics_op_conv3d_backward": (C.c_int, [_F, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _F, _F]),
 }
 

@@ -77,14 +77,14 @@ __device__ __forceinline__ size_t src_voxel(const ConvSrc& s, int b, int z, int 
   return ((((size_t)b * S + z) * S + y) * S + x) * (size_t)s.C;
 }
 
-// Branch-free activation: slope 1 = identity, 0 = ReLU, 0.3 = LeakyReLU.  max(v,0)+slope*min(v,0)
-// is exact for all three (one term is always zero), and keeps the tile loaders a single basic block
+// Branch-free activation: slope 1 = identity, 0 = ReLU, 0.3 = LeakyReLU.  max(v, v*slope)
+// is exact for all three, and keeps the tile loaders a single basic block
 // so the scheduler can run the next tile's address math and loads under the current tile's MFMAs.
 __device__ __forceinline__ float act_slope_of(int act) {
   return act == ACT_RELU ? 0.f : (act == ACT_LRELU ? kLeaky : 1.f);
 }
 __device__ __forceinline__ float act_apply(float v, float slope) {
-  return fmaxf(v, 0.f) + slope * fminf(v, 0.f);
+  return fmaxf(v, v * slope);   // slope in [0,1]: v>0 -> v ; v<0 -> v*slope ; exact for 0, 0.3, 1
 }
 __device__ __forceinline__ v4f affine_act4(v4f v, v4f sc, v4f sh, float slope) {
   v4f r;
@@ -131,7 +131,11 @@ __device__ __forceinline__ float gather_scalar(const ConvSrc& s0, const ConvSrc&
 // =====================================================================================
 // Forward / backward-data kernel
 // =====================================================================================
-template <int WM, int WN, int TM, int TN, bool VEC>
+// ABL (ablation, benchmarking only): 0 = full kernel; 1 = no global loads / LDS stores in the loop
+// (MFMA + LDS reads only); 2 = MFMA only.  Results of ABL != 0 are meaningless by construction.
+// AFF: some source carries a BatchNorm affine/activation; UP: some source is nearest-upsampled
+// (both compile the corresponding loader work out when false: backward-data launches are <false,false>).
+template <int WM, int WN, int TM, int TN, bool VEC, int ABL = 0, bool AFF = true, bool UP = true>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, ConvSrc s1,
                                                         const float* __restrict__ wp,
                                                         const float* __restrict__ bias,
@@ -163,6 +167,36 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
   const float slope0 = act_slope_of(s0.act), slope1 = act_slope_of(s1.act);
   const float pre_slope = act_slope_of(pre_act);
 
+  // VEC path per-row state, computed once: bits 0..26 = "tap t reads inside the grid", bits 27..29 =
+  // parity of (z,y,x); rvh = voxel index of the row in a half-resolution (upsampled) source.
+  // Per chunk the same-resolution voxel index is simply m + (dz*S+dy)*S+dx.
+  unsigned rmask[RA];
+  int rvh[RA];
+  if (VEC) {
+#pragma unroll
+    for (int r = 0; r < RA; ++r) {
+      const int m = mrow_base + 32 * r;
+      const RowPos rp = decode_row(m, S, lg);
+      unsigned mk = 0;
+      if (m < M) {
+        if (g.taps == 27) {
+          const unsigned zm = (rp.z > 0 ? 1u : 0u) | 2u | (rp.z < S - 1 ? 4u : 0u);
+          const unsigned ym = (rp.y > 0 ? 1u : 0u) | 2u | (rp.y < S - 1 ? 4u : 0u);
+          const unsigned xm = (rp.x > 0 ? 1u : 0u) | 2u | (rp.x < S - 1 ? 4u : 0u);
+#pragma unroll
+          for (int tp = 0; tp < 27; ++tp)
+            mk |= (((zm >> (tp / 9)) & (ym >> ((tp / 3) % 3)) & (xm >> (tp % 3))) & 1u) << tp;
+        } else {
+          mk = 1u;
+        }
+      }
+      mk |= ((unsigned)(rp.z & 1) << 29) | ((unsigned)(rp.y & 1) << 28) | ((unsigned)(rp.x & 1) << 27);
+      rmask[r] = mk;
+      const int Sh = S >> 1;
+      rvh[r] = ((rp.b * Sh + (rp.z >> 1)) * Sh + (rp.y >> 1)) * Sh + (rp.x >> 1);
+    }
+  }
+
   v4f ra4[RA];
   float ras[RS];
   v4f rb[NB];
@@ -189,16 +223,28 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
       const int cl = (first ? ci0 : ci0 - s0.C) + (t & 7) * 4;
       const v4f sc = *reinterpret_cast<const v4f*>(sscale + cl);
       const v4f sh = *reinterpret_cast<const v4f*>(sshift + cl);
+      const int sdelta = (dz * S + dy) * S + dx;   // scalar: same-resolution voxel index shift
+      const int Sh = S >> 1;
 #pragma unroll
       for (int r = 0; r < RA; ++r) {
-        const int m = mrow_base + 32 * r;
-        const RowPos rp = decode_row(m, S, lg);
-        const int zz = rp.z + dz, yy = rp.y + dy, xx = rp.x + dx;
-        const bool inb = m < M && (unsigned)zz < (unsigned)S && (unsigned)yy < (unsigned)S &&
-                         (unsigned)xx < (unsigned)S;
-        const unsigned off = voxel_off(min(rp.b, g.B - 1), clampi(zz, S - 1), clampi(yy, S - 1),
-                                       clampi(xx, S - 1), S, su, sC) + cl;
-        const v4f v = affine_act4(*reinterpret_cast<const v4f*>(sp + off), sc, sh, slope);
+        const unsigned mk = rmask[r];
+        const bool inb = (mk >> tap) & 1u;
+        int idx = mrow_base + 32 * r + sdelta;
+        if (UP) {
+          // (z+dz)>>1 = (z>>1) + ((dz + (z&1)) >> 1), likewise y, x
+          const int ez = (dz + (int)((mk >> 29) & 1u)) >> 1;
+          const int ey = (dy + (int)((mk >> 28) & 1u)) >> 1;
+          const int ex = (dx + (int)((mk >> 27) & 1u)) >> 1;
+          const int idx_up = rvh[r] + (ez * Sh + ey) * Sh + ex;
+          idx = su ? idx_up : idx;
+        }
+        const unsigned off = inb ? (unsigned)idx * (unsigned)sC + cl : (unsigned)cl;
+        if (ABL == 3) {   // trivial addressing, no affine/act/select: isolates the address-math cost
+          ra4[r] = *reinterpret_cast<const v4f*>(sp + (((unsigned)(mrow_base + 32 * r) * sC + c * 32 + cl) & 0xffffffu));
+          continue;
+        }
+        v4f v = *reinterpret_cast<const v4f*>(sp + off);
+        if (AFF && ABL != 4) v = affine_act4(v, sc, sh, slope);
         ra4[r] = inb ? v : v4f{0.f, 0.f, 0.f, 0.f};   // zero "same" padding applies after BN/act
       }
     } else {
@@ -256,22 +302,43 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
       for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4*>(A + i * 32 * kLDA + g8 * 8);
 #pragma unroll
       for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const float4*>(Bw + (g8 * 2 * BN + j * 32) * 4);
+      // rotate over the TM*TN accumulators inside each k step: the next MFMA on the same
+      // accumulator is TM*TN issues away, so interleaved VALU/LDS never sits between dependents
+#pragma unroll
+      for (int tk = 0; tk < 4; ++tk)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const float av = tk == 0 ? a[i].x : tk == 1 ? a[i].y : tk == 2 ? a[i].z : a[i].w;
+            const float bv = tk == 0 ? b[j].x : tk == 1 ? b[j].y : tk == 2 ? b[j].z : b[j].w;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+          }
+    }
+  };
+  auto compute_regs_only = [&]() {
+    float av = (float)li, bv = (float)lh;
+#pragma unroll
+    for (int g8 = 0; g8 < 16; ++g8)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
-        }
-    }
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
   };
-  for (int c = 0; c + 1 < nchunks; ++c) {
-    load_chunk(c + 1);
-    compute(c & 1);
-    store_chunk((c + 1) & 1);
-    __syncthreads();
+  if (ABL == 0 || ABL >= 3) {
+    for (int c = 0; c + 1 < nchunks; ++c) {
+      // (sched_barrier fences around the MFMA stream were measured: -4 %; hipcc's own interleave wins)
+      load_chunk(c + 1);
+      compute(c & 1);
+      store_chunk((c + 1) & 1);
+      __syncthreads();
+    }
+  } else {
+    for (int c = 0; c + 1 < nchunks; ++c) {
+      if (ABL == 1) compute(c & 1);
+      else compute_regs_only();
+      __syncthreads();
+    }
   }
   compute((nchunks - 1) & 1);
   __syncthreads();
@@ -350,7 +417,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
   }
 }
 
-template <int WM, int WN, int TM, int TN, bool VEC>
+template <int WM, int WN, int TM, int TN, bool VEC, int ABL = 0, bool AFF = true, bool UP = true>
 static int launch_fwd_cfg(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, const ConvSrc& s1,
                           const float* wp, const float* bias, float* out, int ldo, int pre_act,
                           float* stat_partial, int* rows_per_block) {
@@ -358,7 +425,7 @@ static int launch_fwd_cfg(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, 
   const int M = g.B << (3 * g.lgS);
   const int gridM = (M + BM - 1) / BM, gridN = g.Npad / BN;
   const size_t lds = (size_t)2 * (BM * kLDA + 32 * BN) * sizeof(float);
-  auto kern = conv_fwd_kernel<WM, WN, TM, TN, VEC>;
+  auto kern = conv_fwd_kernel<WM, WN, TM, TN, VEC, ABL, AFF, UP>;
   static bool attr_set = false;
   if (!attr_set) {
     ICS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -414,22 +481,50 @@ int launch_conv_fwd(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int n
                     float* stat_partial, int* rows_per_block) {
   ConvSrc s0 = src[0], s1 = src[nsrc > 1 ? 1 : 0];
   if (nsrc == 1) s1.C = 0;
+  // loader variants: 0 = plain sources (backward-data, pooled inputs), 1 = BN affine/activation,
+  // 2 = affine + a nearest-upsampled source (the U-Net's concat layers, the VAE decoder)
+  const bool aff = s0.scale != nullptr || (nsrc > 1 && s1.scale != nullptr);
+  const bool up = s0.up || (nsrc > 1 && s1.up);
+  const int variant = up ? 2 : (aff ? 1 : 0);
   ICS_TRY(fix_src(s0));
   ICS_TRY(fix_src(s1));
   bool vec = fwd_is_vec(g, s0, s1);
   int bm, bn;
   pick_fwd_tile(g, &bm, &bn);
-#define ICS_FWD(WM, WN, TM, TN)                                                                  \
-  return vec ? launch_fwd_cfg<WM, WN, TM, TN, true>(st, g, s0, s1, wp, bias, out, ldo, pre_act,  \
-                                                    stat_partial, rows_per_block)                \
-             : launch_fwd_cfg<WM, WN, TM, TN, false>(st, g, s0, s1, wp, bias, out, ldo, pre_act, \
-                                                     stat_partial, rows_per_block)
+#define ICS_FWD_ARGS st, g, s0, s1, wp, bias, out, ldo, pre_act, stat_partial, rows_per_block
+#define ICS_FWD(WM, WN, TM, TN)                                                                 \
+  do {                                                                                          \
+    if (!vec) return launch_fwd_cfg<WM, WN, TM, TN, false, 0, true, true>(ICS_FWD_ARGS);        \
+    if (variant == 0) return launch_fwd_cfg<WM, WN, TM, TN, true, 0, false, false>(ICS_FWD_ARGS); \
+    if (variant == 1) return launch_fwd_cfg<WM, WN, TM, TN, true, 0, true, false>(ICS_FWD_ARGS);  \
+    return launch_fwd_cfg<WM, WN, TM, TN, true, 0, true, true>(ICS_FWD_ARGS);                   \
+  } while (0)
   if (bm == 64) { ICS_FWD(2, 2, 1, 1); }
   if (bn == 128) { ICS_FWD(2, 2, 2, 2); }
   if (bn == 96) { ICS_FWD(4, 1, 1, 3); }
   if (bn == 64) { ICS_FWD(2, 2, 2, 1); }
   ICS_FWD(4, 1, 1, 1);
+#undef ICS_FWD_ARGS
 #undef ICS_FWD
+}
+
+// benchmarking-only: the 128x128 vector-path instantiation with part of the loop removed
+int launch_conv_fwd_ablate(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int nsrc, const float* wp,
+                           float* out, int ldo, int ablate) {
+  ConvSrc s0 = src[0], s1 = src[nsrc > 1 ? 1 : 0];
+  if (nsrc == 1) s1.C = 0;
+  ICS_TRY(fix_src(s0));
+  ICS_TRY(fix_src(s1));
+  ICS_CHECK(fwd_is_vec(g, s0, s1) && g.Npad % 128 == 0, "ablation bench needs the vector 128x128 configuration");
+#define ICS_ABL_ARGS st, g, s0, s1, wp, nullptr, out, ldo, 0, nullptr, nullptr
+  if (ablate == 1) return launch_fwd_cfg<2, 2, 2, 2, true, 1, true, false>(ICS_ABL_ARGS);
+  if (ablate == 2) return launch_fwd_cfg<2, 2, 2, 2, true, 2, true, false>(ICS_ABL_ARGS);
+  if (ablate == 3) return launch_fwd_cfg<2, 2, 2, 2, true, 3, true, false>(ICS_ABL_ARGS);
+  if (ablate == 4) return launch_fwd_cfg<2, 2, 2, 2, true, 4, true, false>(ICS_ABL_ARGS);
+  if (ablate == 5) return launch_fwd_cfg<2, 2, 2, 2, true, 0, true, false>(ICS_ABL_ARGS);   // affine, no upsample
+  if (ablate == 6) return launch_fwd_cfg<2, 2, 2, 2, true, 0, true, true>(ICS_ABL_ARGS);    // affine + upsample math
+  return launch_fwd_cfg<2, 2, 2, 2, true, 0, false, false>(ICS_ABL_ARGS);
+#undef ICS_ABL_ARGS
 }
 
 // =====================================================================================

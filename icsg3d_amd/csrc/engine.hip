@@ -1289,6 +1289,50 @@ int ics_op_conv3d_forward(const float* x, const float* w, const float* bias, int
   return 0;
 }
 
+// micro-benchmark of one conv layer on device-resident data (HIP events): mode 0 fwd (ablate 0/1/2),
+// 1 backward-data, 2 backward-weight.  Returns average milliseconds per launch.
+int ics_op_conv3d_bench(int B, int S, int Cin, int Cout, int taps, int mode, int ablate, int iters, float* ms_out) {
+  ICS_CHECK(ms_out && iters >= 1, "bad arguments");
+  Net n;
+  ICS_TRY(op_prepare(n));
+  const size_t M = (size_t)B * S * S * S;
+  const int Kpad = round_up(taps * Cin, 32), Npad = round_up(Cout, 32);
+  const int Kpad_b = round_up(taps * Cout, 32), Npad_b = round_up(Cin, 32);
+  float *dx, *dw, *dwp, *dwf, *dyv, *dgx, *dgw, *ws;
+  ICS_TRY(n.alloc(&dx, M * Cin)); ICS_TRY(n.alloc(&dw, (size_t)taps * Cin * Cout));
+  ICS_TRY(n.alloc(&dwp, (size_t)Kpad * Npad)); ICS_TRY(n.alloc(&dwf, (size_t)Kpad_b * Npad_b));
+  ICS_TRY(n.alloc(&dyv, M * Cout)); ICS_TRY(n.alloc(&dgx, M * Cin)); ICS_TRY(n.alloc(&dgw, (size_t)taps * Cin * Cout));
+  ICS_TRY(fill(n, dx, M * Cin, 0.37f)); ICS_TRY(fill(n, dw, (size_t)taps * Cin * Cout, 0.011f));
+  ICS_TRY(fill(n, dyv, M * Cout, 0.23f));
+  ICS_TRY(launch_pack_fwd(n.st, dw, taps * Cin, Cout, dwp, Kpad, Npad, 0, 0, 1));
+  ICS_TRY(launch_pack_bwd(n.st, dw, taps, Cin, Cout, dwf, Kpad_b, Npad_b, Cout, 0, 1));
+  ConvGeom g{B, S, ilog2(S), Cin, Cout, taps, Kpad, Npad};
+  ConvGeom gb{B, S, ilog2(S), Cout, Cin, taps, Kpad_b, Npad_b};
+  ConvSrc sx = src_plain(dx, Cin), sd = src_plain(dyv, Cout);
+  const size_t wsn = conv_wgrad_workspace_floats(g, &sx, 1);
+  ICS_TRY(n.alloc(&ws, wsn + 16));
+  hipEvent_t e0, e1;
+  ICS_HIP(hipEventCreate(&e0)); ICS_HIP(hipEventCreate(&e1));
+  for (int it = -2; it < iters; ++it) {
+    if (it == 0) ICS_HIP(hipEventRecord(e0, n.st));
+    if (mode == 0) {
+      if (ablate) ICS_TRY(launch_conv_fwd_ablate(n.st, g, &sx, 1, dwp, dyv, Cout, ablate));
+      else ICS_TRY(launch_conv_fwd(n.st, g, &sx, 1, dwp, nullptr, dyv, Cout, ACT_RELU, nullptr, nullptr));
+    } else if (mode == 1) {
+      ICS_TRY(launch_conv_fwd(n.st, gb, &sd, 1, dwf, nullptr, dgx, Cin, ACT_NONE, nullptr, nullptr));
+    } else {
+      ICS_TRY(launch_conv_wgrad(n.st, g, &sx, 1, dyv, Cout, dgw, Cout, ws, wsn));
+    }
+  }
+  ICS_HIP(hipEventRecord(e1, n.st));
+  ICS_HIP(hipStreamSynchronize(n.st));
+  float ms = 0.f;
+  ICS_HIP(hipEventElapsedTime(&ms, e0, e1));
+  *ms_out = ms / iters;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return 0;
+}
+
 int ics_op_conv3d_backward(const float* x, const float* w, const float* dy, int B, int S, int Cin, int Cout,
                            int taps, float* dxo, float* dwo) {
   ICS_CHECK(x && w && dy && (taps == 27 || taps == 1) && S >= 1 && (S & (S - 1)) == 0, "bad conv arguments");

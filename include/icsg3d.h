@@ -151,6 +151,11 @@ int ics_op_conv3d_forward(const float* x, const float* w, const float* bias, int
 int ics_op_conv3d_backward(const float* x, const float* w, const float* dy, int B, int S, int Cin,
                            int Cout, int taps, float* dx, float* dw);
 
+/* kernel micro-benchmark on device-resident constant data, HIP-event timed: mode 0 forward
+ * (ablate 0 = full kernel, 1 = MFMA+LDS reads only, 2 = MFMA only), 1 backward-data, 2 backward-weight. */
+int ics_op_conv3d_bench(int B, int S, int Cin, int Cout, int taps, int mode, int ablate, int iters,
+                        float* ms_per_launch);
+
 #ifdef __cplusplus
 }
 #endif
