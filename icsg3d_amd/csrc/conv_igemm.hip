@@ -530,7 +530,7 @@ int launch_conv_fwd_ablate(hipStream_t st, const ConvGeom& g, const ConvSrc* src
 // =====================================================================================
 // Backward-weight kernel: ws[split][k][n] = sum_{m in split} A[m][k] * dy[m][n]
 // =====================================================================================
-template <int WM, int WN, int TM, int TN, bool VEC, bool DYVEC>
+template <int WM, int WN, int TM, int TN, bool VEC, bool DYVEC, bool AFF = true, bool UP = true>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvGeom g, ConvSrc s0, ConvSrc s1,
                                                           const float* __restrict__ dy, int ldy,
                                                           int n_load,
@@ -561,16 +561,35 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvGeom g, ConvSrc s0,
   const int m_end = min(M, m_begin + rows_per_split);
   const int nchunks = (m_end - m_begin + 31) >> 5;
 
-  // VEC: the k tile lies in one tap and one source
-  int dz = 0, dyy = 0, dx = 0, ci0 = 0, k0;
+  // k tiles are runs of KT consecutive flattened k = tap*Cin + ci.  VEC (Cin % 32 == 0): a thread's
+  // float4 column sits inside one 32-channel group, hence one tap and one source -- all per-thread
+  // constants for the whole block, so tiles may span taps (thin Cin) and sources (concat layers).
+  const int k0 = kt_i * KT;
+  int tdz = 0, tdy = 0, tdx = 0, sdelta = 0, xbad = -1, ybad = -1, zbad = -1;
+  bool kvalid = false;
+  const float* sp = s0.p;
+  int sC = s0.C, su = 0, cl0 = 0;
+  float slope = 1.f;
+  v4f sc = v4f{1.f, 1.f, 1.f, 1.f}, sh = v4f{0.f, 0.f, 0.f, 0.f};
   if (VEC) {
-    const int tpt = g.Cin / KT;   // k tiles per tap
-    const int tap = kt_i / tpt;
-    ci0 = (kt_i - tap * tpt) * KT;
-    k0 = tap * g.Cin + ci0;
-    if (g.taps == 27) { dz = tap / 9 - 1; dyy = (tap / 3) % 3 - 1; dx = tap % 3 - 1; }
-  } else {
-    k0 = kt_i * KT;   // KT == 32, flattened (tap, ci)
+    const int kf = k0 + (t % AF4) * 4;
+    const int tap = kf / g.Cin, ci = kf - tap * g.Cin;
+    kvalid = kf < K;
+    if (g.taps == 27 && kvalid) { tdz = tap / 9 - 1; tdy = (tap / 3) % 3 - 1; tdx = tap % 3 - 1; }
+    sdelta = (tdz * S + tdy) * S + tdx;
+    // a shifted coordinate leaves the grid iff it starts on the face the tap points away from
+    xbad = tdx < 0 ? 0 : (tdx > 0 ? S - 1 : -1);
+    ybad = tdy < 0 ? 0 : (tdy > 0 ? S - 1 : -1);
+    zbad = tdz < 0 ? 0 : (tdz > 0 ? S - 1 : -1);
+    const bool first = ci < s0.C;
+    const ConvSrc sv = pick_src(s0, s1, first);
+    sp = sv.p; sC = sv.C; su = sv.up;
+    cl0 = kvalid ? (first ? ci : ci - s0.C) : 0;
+    slope = act_slope_of(sv.act);
+    if (AFF) {
+      sc = *reinterpret_cast<const v4f*>(sv.scale + cl0);
+      sh = *reinterpret_cast<const v4f*>(sv.shift + cl0);
+    }
   }
   // SCALAR: this thread's fixed k
   int s_tap = 0, s_ci = 0; bool s_kvalid = false; int sdz = 0, sdy = 0, sdx = 0;
@@ -578,15 +597,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvGeom g, ConvSrc s0,
     const int kf = k0 + (t & 31);
     s_tap = kf / g.Cin; s_ci = kf - s_tap * g.Cin; s_kvalid = kf < K;
     if (g.taps == 27) { sdz = s_tap / 9 - 1; sdy = (s_tap / 3) % 3 - 1; sdx = s_tap % 3 - 1; }
-  }
-  const bool first = ci0 < s0.C;
-  const ConvSrc sv = pick_src(s0, s1, first);
-  const int cl0 = (first ? ci0 : ci0 - s0.C) + (t % AF4) * 4;
-  const float slope = act_slope_of(sv.act);
-  v4f sc = v4f{1.f, 1.f, 1.f, 1.f}, sh = v4f{0.f, 0.f, 0.f, 0.f};
-  if (VEC) {
-    sc = *reinterpret_cast<const v4f*>(sv.scale + cl0);
-    sh = *reinterpret_cast<const v4f*>(sv.shift + cl0);
   }
 
   v4f ra[VEC ? APASS : 1];
@@ -596,16 +606,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvGeom g, ConvSrc s0,
   auto load_chunk = [&](int c) {
     const int mbase = m_begin + (c << 5);
     if (VEC) {
+      const int Sh = S >> 1;
 #pragma unroll
       for (int p = 0; p < APASS; ++p) {
         const int m = mbase + (t + 256 * p) / AF4;
-        const RowPos r = decode_row(min(m, M - 1), S, lg);
-        const int zz = r.z + dz, yy = r.y + dyy, xx = r.x + dx;
-        const bool inb = m < m_end && (unsigned)zz < (unsigned)S && (unsigned)yy < (unsigned)S &&
-                         (unsigned)xx < (unsigned)S;
-        const unsigned off = voxel_off(r.b, clampi(zz, S - 1), clampi(yy, S - 1), clampi(xx, S - 1), S,
-                                       sv.up, sv.C) + cl0;
-        const v4f v = affine_act4(*reinterpret_cast<const v4f*>(sv.p + off), sc, sh, slope);
+        const int x = m & (S - 1), y = (m >> lg) & (S - 1), z = (m >> (2 * lg)) & (S - 1);
+        const bool inb = kvalid && m < m_end && x != xbad && y != ybad && z != zbad;
+        int idx = m + sdelta;            // same-resolution voxel index of the tap-shifted row
+        if (UP) {
+          const int b = m >> (3 * lg);
+          const int idx_up = ((b * Sh + ((z + tdz) >> 1)) * Sh + ((y + tdy) >> 1)) * Sh + ((x + tdx) >> 1);
+          idx = su ? idx_up : idx;
+        }
+        const unsigned off = inb ? (unsigned)idx * (unsigned)sC + cl0 : (unsigned)cl0;
+        v4f v = *reinterpret_cast<const v4f*>(sp + off);
+        if (AFF) v = affine_act4(v, sc, sh, slope);
         ra[p] = inb ? v : v4f{0.f, 0.f, 0.f, 0.f};
       }
     } else {
@@ -734,9 +749,8 @@ static WgradPlan plan_wgrad(const ConvGeom& g, const ConvSrc& s0, int nsrc, cons
   const int M = g.B << (3 * g.lgS);
   p.vec = (g.Cin % 32 == 0) && (s0.C % 32 == 0) && s0.bcast == 0 && (nsrc < 2 || s1.bcast == 0);
   if (p.vec) {
-    auto divides = [&](int kt) { return s0.C % kt == 0 && g.Cin % kt == 0; };
-    p.kt = divides(128) ? 128 : divides(64) ? 64 : 32;
-    p.ktiles = g.taps * (g.Cin / p.kt);
+    p.kt = (g.taps * g.Cin >= 128) ? 128 : (g.taps * g.Cin >= 64 ? 64 : 32);
+    p.ktiles = (g.taps * g.Cin + p.kt - 1) / p.kt;
   } else {
     p.kt = 32;
     p.ktiles = g.Kpad / 32;
@@ -781,12 +795,12 @@ size_t conv_wgrad_workspace_floats(const ConvGeom& g, const ConvSrc* src, int ns
   return (size_t)p.ksplit * g.taps * g.Cin * g.Cout;
 }
 
-template <int WM, int WN, int TM, int TN, bool VEC, bool DYVEC>
+template <int WM, int WN, int TM, int TN, bool VEC, bool DYVEC, bool AFF = true, bool UP = true>
 static int launch_wgrad_cfg(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, const ConvSrc& s1,
                             const float* dy, int ldy, int n_load, float* ws, const WgradPlan& p) {
   constexpr int KT = WM * TM * 32, NT = WN * TN * 32;
   const size_t lds = (size_t)2 * 32 * (KT + NT) * sizeof(float);
-  auto kern = conv_wgrad_kernel<WM, WN, TM, TN, VEC, DYVEC>;
+  auto kern = conv_wgrad_kernel<WM, WN, TM, TN, VEC, DYVEC, AFF, UP>;
   static bool attr_set = false;
   if (!attr_set) {
     ICS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -818,12 +832,15 @@ int launch_conv_wgrad(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int
     p.ntiles = (g.Npad + p.nt - 1) / p.nt;
   }
   ICS_CHECK((size_t)p.ksplit * n_elems <= workspace_floats, "wgrad workspace too small");
-#define ICS_WG(WM, WN, TM, TN, DV)                                                                   \
-  do {                                                                                               \
-    if (p.vec) ICS_TRY((launch_wgrad_cfg<WM, WN, TM, TN, true, DV>(st, g, s0, s1, dy, ldy, n_load,   \
-                                                                    workspace, p)));                 \
-    else ICS_TRY((launch_wgrad_cfg<WM, WN, TM, TN, false, DV>(st, g, s0, s1, dy, ldy, n_load,        \
-                                                               workspace, p)));                      \
+  const bool aff = src[0].scale != nullptr || (nsrc > 1 && src[1].scale != nullptr);
+  const bool up = src[0].up || (nsrc > 1 && src[1].up);
+#define ICS_WG_ARGS st, g, s0, s1, dy, ldy, n_load, workspace, p
+#define ICS_WG(WM, WN, TM, TN, DV)                                                                 \
+  do {                                                                                             \
+    if (!p.vec) ICS_TRY((launch_wgrad_cfg<WM, WN, TM, TN, false, DV, true, true>(ICS_WG_ARGS)));   \
+    else if (up) ICS_TRY((launch_wgrad_cfg<WM, WN, TM, TN, true, DV, true, true>(ICS_WG_ARGS)));   \
+    else if (aff) ICS_TRY((launch_wgrad_cfg<WM, WN, TM, TN, true, DV, true, false>(ICS_WG_ARGS))); \
+    else ICS_TRY((launch_wgrad_cfg<WM, WN, TM, TN, true, DV, false, false>(ICS_WG_ARGS)));         \
   } while (0)
   if (!dy_vec) {
     if (p.kt == 128) ICS_WG(4, 1, 1, 1, false);
@@ -840,6 +857,7 @@ int launch_conv_wgrad(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int
   } else {
     ICS_WG(1, 4, 1, 1, true);
   }
+#undef ICS_WG_ARGS
 #undef ICS_WG
   const int thr = 256;
   hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((n_elems + thr - 1) / thr)), dim3(thr), 0,

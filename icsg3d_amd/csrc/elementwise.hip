@@ -148,47 +148,92 @@ struct ElemCtx {
   int b, z, y, x, c;
 };
 
-__device__ __forceinline__ float gather_do(const GradSrc& g, const LayerBwd& L, size_t row,
-                                           const ElemCtx& e, float o) {
-  if (g.kind == GS_DIRECT) return g.p[row * g.ld + g.off + e.c];
+// VW = 1 or 4 consecutive channels per thread (float4 global accesses when C % 4 == 0)
+template <int VW>
+struct Vec {
+  float v[VW];
+};
+template <int VW>
+__device__ __forceinline__ Vec<VW> vload(const float* p) {
+  Vec<VW> r;
+  if (VW == 4) {
+    const float4 q = *reinterpret_cast<const float4*>(p);
+    r.v[0] = q.x; r.v[1 % VW] = q.y; r.v[2 % VW] = q.z; r.v[3 % VW] = q.w;
+  } else {
+    r.v[0] = p[0];
+  }
+  return r;
+}
+template <int VW>
+__device__ __forceinline__ void vstore(float* p, const Vec<VW>& r) {
+  if (VW == 4) *reinterpret_cast<float4*>(p) = make_float4(r.v[0], r.v[1 % VW], r.v[2 % VW], r.v[3 % VW]);
+  else p[0] = r.v[0];
+}
+
+template <int VW>
+__device__ __forceinline__ Vec<VW> gather_do(const GradSrc& g, const LayerBwd& L, size_t row,
+                                             const ElemCtx& e, const Vec<VW>& o) {
+  Vec<VW> r;
+#pragma unroll
+  for (int k = 0; k < VW; ++k) r.v[k] = 0.f;
+  if (g.kind == GS_DIRECT) return vload<VW>(g.p + row * g.ld + g.off + e.c);
   if (g.kind == GS_UP) {
     // consumer ran at 2S on the nearest-upsampled tensor: sum the 8 children (UpSampling3D bwd)
     const int S2 = L.S * 2;
-    float acc = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int zz = 2 * e.z + (k >> 2), yy = 2 * e.y + ((k >> 1) & 1), xx = 2 * e.x + (k & 1);
-      acc += g.p[((((size_t)e.b * S2 + zz) * S2 + yy) * S2 + xx) * g.ld + g.off + e.c];
+      const Vec<VW> q = vload<VW>(g.p + ((((size_t)e.b * S2 + zz) * S2 + yy) * S2 + xx) * g.ld + g.off + e.c);
+#pragma unroll
+      for (int j = 0; j < VW; ++j) r.v[j] += q.v[j];
     }
-    return acc;
+    return r;
   }
   if (g.kind == GS_POOL) {
     const int Sh = L.S >> 1;
     const size_t prow = (((size_t)e.b * Sh + (e.z >> 1)) * Sh + (e.y >> 1)) * Sh + (e.x >> 1);
-    const float up = g.p[prow * g.ld + g.off + e.c];
+    const Vec<VW> up = vload<VW>(g.p + prow * g.ld + g.off + e.c);
     if (L.pool_ties_all) {
       // TF CPU MaxPool3DGrad: every window element within 1e-5 of the max receives the gradient
-      const float ymax = g.pooled[prow * L.C + e.c];
-      return fabsf(o - ymax) < kPoolTieTol ? up : 0.f;
+      const Vec<VW> ymax = vload<VW>(g.pooled + prow * L.C + e.c);
+#pragma unroll
+      for (int j = 0; j < VW; ++j) r.v[j] = fabsf(o.v[j] - ymax.v[j]) < kPoolTieTol ? up.v[j] : 0.f;
+      return r;
     }
     const int k = ((e.z & 1) << 2) | ((e.y & 1) << 1) | (e.x & 1);
-    return g.pool_idx[prow * L.C + e.c] == k ? up : 0.f;
+#pragma unroll
+    for (int j = 0; j < VW; ++j) r.v[j] = g.pool_idx[prow * L.C + e.c + j] == k ? up.v[j] : 0.f;
+    return r;
   }
-  return 0.f;
+  return r;
 }
 
 // d = dO * post_act'(bn_out);  also returns xhat
-__device__ __forceinline__ float elem_d(const LayerBwd& L, size_t row, const ElemCtx& e, float sv,
-                                        float* xhat) {
-  float bnout = sv, xh = 0.f;
+template <int VW>
+__device__ __forceinline__ Vec<VW> elem_d(const LayerBwd& L, size_t row, const ElemCtx& e, const Vec<VW>& sv,
+                                          Vec<VW>* xhat) {
+  Vec<VW> bnout = sv, xh, o;
+#pragma unroll
+  for (int j = 0; j < VW; ++j) xh.v[j] = 0.f;
   if (L.has_bn) {
-    bnout = fmaf(sv, L.scale[e.c], L.shift[e.c]);
-    xh = (sv - L.mean[e.c]) * L.rstd[e.c];
+    const Vec<VW> sc = vload<VW>(L.scale + e.c), sh = vload<VW>(L.shift + e.c);
+    const Vec<VW> mu = vload<VW>(L.mean + e.c), rs = vload<VW>(L.rstd + e.c);
+#pragma unroll
+    for (int j = 0; j < VW; ++j) {
+      bnout.v[j] = fmaf(sv.v[j], sc.v[j], sh.v[j]);
+      xh.v[j] = (sv.v[j] - mu.v[j]) * rs.v[j];
+    }
   }
-  const float o = act_fwd(bnout, L.post_act);
-  float d = gather_do(L.g0, L, row, e, o);
-  if (L.g1.kind != GS_NONE) d += gather_do(L.g1, L, row, e, o);
-  d *= act_grad(bnout, L.post_act);
+#pragma unroll
+  for (int j = 0; j < VW; ++j) o.v[j] = act_fwd(bnout.v[j], L.post_act);
+  Vec<VW> d = gather_do<VW>(L.g0, L, row, e, o);
+  if (L.g1.kind != GS_NONE) {
+    const Vec<VW> d1 = gather_do<VW>(L.g1, L, row, e, o);
+#pragma unroll
+    for (int j = 0; j < VW; ++j) d.v[j] += d1.v[j];
+  }
+#pragma unroll
+  for (int j = 0; j < VW; ++j) d.v[j] *= act_grad(bnout.v[j], L.post_act);
   *xhat = xh;
   return d;
 }
@@ -203,33 +248,39 @@ __device__ __forceinline__ ElemCtx decode_elem(size_t row, int c, int S, int lg)
   return e;
 }
 
-// Thread layout for [M][C] tensors with power-of-two C: CB = min(C,256) channels across threads,
-// RPP = 256/CB rows per pass; channel groups of 256 looped when C > 256.
+// Thread layout for [M][C] tensors with power-of-two C: CB = min(C/VW, 256) column groups across
+// threads, RPP = 256/CB rows per pass; column groups of 256*VW looped when C/VW > 256.
+template <int VW>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(LayerBwd L, int rows_per_block,
                                                              float* __restrict__ partial) {
-  __shared__ float sh1[256], sh2[256];
-  const int C = L.C, CB = C < 256 ? C : 256, RPP = 256 / CB;
+  __shared__ float sh1[256 * VW], sh2[256 * VW];
+  const int C = L.C, CV = C / VW, CB = CV < 256 ? CV : 256, RPP = 256 / CB;
   const int t = threadIdx.x, tc = t % CB, tr = t / CB;
   const size_t M = (size_t)L.B << (3 * L.lgS);
   const size_t r0 = (size_t)blockIdx.x * rows_per_block;
   const size_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
-  for (int cg = 0; cg < C; cg += 256) {
-    const int c = cg + tc;
-    float a1 = 0.f, a2 = 0.f;
+  for (int cg = 0; cg < CV; cg += 256) {
+    const int c = (cg + tc) * VW;
+    float a1[VW], a2[VW];
+#pragma unroll
+    for (int j = 0; j < VW; ++j) a1[j] = a2[j] = 0.f;
     for (size_t row = r0 + tr; row < r1; row += RPP) {
       const ElemCtx e = decode_elem(row, c, L.S, L.lgS);
-      float xh;
-      const float d = elem_d(L, row, e, L.s[row * C + c], &xh);
-      a1 += d;
-      a2 += d * xh;
+      Vec<VW> xh;
+      const Vec<VW> d = elem_d<VW>(L, row, e, vload<VW>(L.s + row * C + c), &xh);
+#pragma unroll
+      for (int j = 0; j < VW; ++j) { a1[j] += d.v[j]; a2[j] += d.v[j] * xh.v[j]; }
     }
-    sh1[t] = a1; sh2[t] = a2;
+#pragma unroll
+    for (int j = 0; j < VW; ++j) { sh1[t * VW + j] = a1[j]; sh2[t * VW + j] = a2[j]; }
     __syncthreads();
-    if (t < CB) {
+    for (int col = t; col < CB * VW; col += 256) {
+      // column `col` of this group: thread (r, tc = col / VW) holds it at [.. * VW + col % VW]
+      const int tcc = col / VW, jj = col % VW;
       float s1 = 0.f, s2 = 0.f;
-      for (int r = 0; r < RPP; ++r) { s1 += sh1[r * CB + t]; s2 += sh2[r * CB + t]; }
-      partial[((size_t)blockIdx.x * 2 + 0) * C + cg + t] = s1;
-      partial[((size_t)blockIdx.x * 2 + 1) * C + cg + t] = s2;
+      for (int r = 0; r < RPP; ++r) { s1 += sh1[(r * CB + tcc) * VW + jj]; s2 += sh2[(r * CB + tcc) * VW + jj]; }
+      partial[((size_t)blockIdx.x * 2 + 0) * C + cg * VW + col] = s1;
+      partial[((size_t)blockIdx.x * 2 + 1) * C + cg * VW + col] = s2;
     }
     __syncthreads();
   }
@@ -258,40 +309,54 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   }
 }
 
+template <int VW>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(LayerBwd L, int rows_per_block,
                                                             const float* __restrict__ c1,
                                                             const float* __restrict__ c2,
                                                             float* __restrict__ dy,
                                                             float* __restrict__ db_partial) {
-  __shared__ float sh1[256];
-  const int C = L.C, CB = C < 256 ? C : 256, RPP = 256 / CB;
+  __shared__ float sh1[256 * VW];
+  const int C = L.C, CV = C / VW, CB = CV < 256 ? CV : 256, RPP = 256 / CB;
   const int t = threadIdx.x, tc = t % CB, tr = t / CB;
   const size_t M = (size_t)L.B << (3 * L.lgS);
   const size_t r0 = (size_t)blockIdx.x * rows_per_block;
   const size_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
-  for (int cg = 0; cg < C; cg += 256) {
-    const int c = cg + tc;
-    const float k1 = L.has_bn ? c1[c] : 0.f, k2 = L.has_bn ? c2[c] : 0.f;
-    const float sg = L.has_bn ? L.scale[c] : 1.f;
-    float acc = 0.f;
+  for (int cg = 0; cg < CV; cg += 256) {
+    const int c = (cg + tc) * VW;
+    Vec<VW> k1, k2, sg;
+#pragma unroll
+    for (int j = 0; j < VW; ++j) { k1.v[j] = 0.f; k2.v[j] = 0.f; sg.v[j] = 1.f; }
+    if (L.has_bn) { k1 = vload<VW>(c1 + c); k2 = vload<VW>(c2 + c); sg = vload<VW>(L.scale + c); }
+    float acc[VW];
+#pragma unroll
+    for (int j = 0; j < VW; ++j) acc[j] = 0.f;
     for (size_t row = r0 + tr; row < r1; row += RPP) {
       const ElemCtx e = decode_elem(row, c, L.S, L.lgS);
-      const float sv = L.s[row * C + c];
-      float xh;
-      const float d = elem_d(L, row, e, sv, &xh);
-      float ds = L.has_bn ? sg * (d - k1 - xh * k2) : d;
-      if (L.dtap) ds += L.dtap[row * C + c];
-      const float g = ds * act_grad(sv, L.pre_act);
-      dy[row * C + c] = g;
-      acc += g;
+      const Vec<VW> sv = vload<VW>(L.s + row * C + c);
+      Vec<VW> xh, g;
+      const Vec<VW> d = elem_d<VW>(L, row, e, sv, &xh);
+      Vec<VW> tap;
+#pragma unroll
+      for (int j = 0; j < VW; ++j) tap.v[j] = 0.f;
+      if (L.dtap) tap = vload<VW>(L.dtap + row * C + c);
+#pragma unroll
+      for (int j = 0; j < VW; ++j) {
+        float ds = L.has_bn ? sg.v[j] * (d.v[j] - k1.v[j] - xh.v[j] * k2.v[j]) : d.v[j];
+        ds += tap.v[j];
+        g.v[j] = ds * act_grad(sv.v[j], L.pre_act);
+        acc[j] += g.v[j];
+      }
+      vstore<VW>(dy + row * C + c, g);
     }
     if (db_partial) {
-      sh1[t] = acc;
+#pragma unroll
+      for (int j = 0; j < VW; ++j) sh1[t * VW + j] = acc[j];
       __syncthreads();
-      if (t < CB) {
-        float s = 0.f;
-        for (int r = 0; r < RPP; ++r) s += sh1[r * CB + t];
-        db_partial[(size_t)blockIdx.x * C + cg + t] = s;
+      for (int col = t; col < CB * VW; col += 256) {
+        const int tcc = col / VW, jj = col % VW;
+        float sacc = 0.f;
+        for (int r = 0; r < RPP; ++r) sacc += sh1[(r * CB + tcc) * VW + jj];
+        db_partial[(size_t)blockIdx.x * C + cg * VW + col] = sacc;
       }
       __syncthreads();
     }
@@ -313,7 +378,8 @@ int bn_bwd_num_blocks(const LayerBwd& L, int* rows_per_block) {
   // aim for ~2048 blocks, at least 64 rows each
   size_t rpb = (M + 2047) / 2048;
   if (rpb < 64) rpb = 64;
-  const int CB = L.C < 256 ? L.C : 256, RPP = 256 / CB;
+  const int VW = (L.C % 4 == 0) ? 4 : 1;
+  const int CV = L.C / VW, CB = CV < 256 ? CV : 256, RPP = 256 / CB;
   rpb = (rpb + RPP - 1) / RPP * RPP;
   *rows_per_block = (int)rpb;
   return (int)((M + rpb - 1) / rpb);
@@ -326,15 +392,19 @@ int launch_layer_bwd(hipStream_t st, const LayerBwd& L, float* dy, float* ws_par
   const double n = (double)((size_t)L.B << (3 * L.lgS));
   float* c1 = c1c2;
   float* c2 = c1c2 + L.C;
+  const bool v4 = (L.C % 4 == 0);
   if (L.has_bn) {
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, st, L, rpb, ws_partial);
+    if (v4) hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, dim3(nblk), dim3(256), 0, st, L, rpb, ws_partial);
+    else hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(nblk), dim3(256), 0, st, L, rpb, ws_partial);
     ICS_HIP(hipGetLastError());
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(L.C), dim3(256), 0, st, ws_partial, nblk, L.C, n, c1,
                        c2, dgamma, dbeta);
     ICS_HIP(hipGetLastError());
   }
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblk), dim3(256), 0, st, L, rpb, c1, c2, dy,
-                     dbias ? ws_partial : nullptr);
+  if (v4) hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(nblk), dim3(256), 0, st, L, rpb, c1, c2, dy,
+                             dbias ? ws_partial : nullptr);
+  else hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(nblk), dim3(256), 0, st, L, rpb, c1, c2, dy,
+                          dbias ? ws_partial : nullptr);
   ICS_HIP(hipGetLastError());
   if (dbias) {
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3(L.C), dim3(256), 0, st, ws_partial, nblk, L.C, dbias);
