@@ -131,6 +131,14 @@ def main():
         scale = (d / 32.0) ** 3
         step_flop = UNET_FLOP_PER_GRID * scale * B
         step_bytes = UNET_BYTES_PER_GRID * scale * B + UNET_PARAM_BYTES_PER_STEP
+        # HBM bytes per launch of that kernel from the committed PMC passes (rocprofv3 --pmc cannot run
+        # inside this process); null when the profile does not cover the dominant kernel
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
+                traffic = json.load(f)["kernels"][dom_name]["traffic_bytes_per_launch"]
+        except Exception:
+            traffic = None
         out = {
             "metric": "voxel-grids/s (fwd+bwd) for 32^3 U-Net at batch 32 per GPU",
             "value": round(value, 2), "unit": "voxel-grids/s", "n_gpus": world, "steps": args.steps,
@@ -142,7 +150,9 @@ def main():
                        "bn": "local per-replica batch statistics"},
             "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2),
                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
-                         "traffic": None, "launches": dom["launches"],
+                         "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC: 2*FETCH_SIZE+WRITE_SIZE, profiles/r1_pmc_traffic.json)",
+                         "algorithmic_bytes_per_launch": int(dom["bytes"] / max(dom["launches"], 1)),
+                         "launches": dom["launches"],
                          "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 4),
                          "share_of_device_time": round(dom["ms"] / sum(v["ms"] for v in by_kernel.values()), 4)},
             "roofline_step": {"compute_frac": round(step_flop / (ms_per_step * 1e-3) / (PEAK_FP32_TFLOPS * 1e12), 4),

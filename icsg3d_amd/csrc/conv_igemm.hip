@@ -243,6 +243,15 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
           ra4[r] = *reinterpret_cast<const v4f*>(sp + (((unsigned)(mrow_base + 32 * r) * sC + c * 32 + cl) & 0xffffffu));
           continue;
         }
+        if (ABL == 8) {   // real (clamp-free) addresses, no zero-select
+          ra4[r] = *reinterpret_cast<const v4f*>(sp + ((unsigned)max(idx, 0) * (unsigned)sC + cl));
+          continue;
+        }
+        if (ABL == 9) {   // dense addresses + the real mask/select
+          const v4f vv = *reinterpret_cast<const v4f*>(sp + (((unsigned)(mrow_base + 32 * r) * sC + c * 32 + cl) & 0xffffffu));
+          ra4[r] = inb ? vv : v4f{0.f, 0.f, 0.f, 0.f};
+          continue;
+        }
         v4f v = *reinterpret_cast<const v4f*>(sp + off);
         if (AFF && ABL != 4) v = affine_act4(v, sc, sh, slope);
         ra4[r] = inb ? v : v4f{0.f, 0.f, 0.f, 0.f};   // zero "same" padding applies after BN/act
@@ -521,6 +530,8 @@ int launch_conv_fwd_ablate(hipStream_t st, const ConvGeom& g, const ConvSrc* src
   if (ablate == 2) return launch_fwd_cfg<2, 2, 2, 2, true, 2, true, false>(ICS_ABL_ARGS);
   if (ablate == 3) return launch_fwd_cfg<2, 2, 2, 2, true, 3, true, false>(ICS_ABL_ARGS);
   if (ablate == 4) return launch_fwd_cfg<2, 2, 2, 2, true, 4, true, false>(ICS_ABL_ARGS);
+  if (ablate == 8) return launch_fwd_cfg<2, 2, 2, 2, true, 8, false, false>(ICS_ABL_ARGS);
+  if (ablate == 9) return launch_fwd_cfg<2, 2, 2, 2, true, 9, false, false>(ICS_ABL_ARGS);
   if (ablate == 5) return launch_fwd_cfg<2, 2, 2, 2, true, 0, true, false>(ICS_ABL_ARGS);   // affine, no upsample
   if (ablate == 6) return launch_fwd_cfg<2, 2, 2, 2, true, 0, true, true>(ICS_ABL_ARGS);    // affine + upsample math
   return launch_fwd_cfg<2, 2, 2, 2, true, 0, false, false>(ICS_ABL_ARGS);
@@ -530,24 +541,35 @@ int launch_conv_fwd_ablate(hipStream_t st, const ConvGeom& g, const ConvSrc* src
 // =====================================================================================
 // Backward-weight kernel: ws[split][k][n] = sum_{m in split} A[m][k] * dy[m][n]
 // =====================================================================================
+// LDS images are TRANSPOSED: At[k][m], Dt[n][m] with 32 voxels (m) per row, so that -- exactly as in
+// the forward kernel -- each MFMA operand is a ds_read_b128 of 4 consecutive m with the fixed
+// k-permutation (lane half h supplies m = 8g+4h..+3 of every 8-voxel group): 16 LDS reads per 64
+// MFMAs instead of 64.  Rows are XOR-swizzled in 16-byte groups, phys = (m>>2) ^ f(row) with
+// f(row) = ((row>>1 ^ row>>4) & 1) | ((row>>1) & 6): both the ds_read_b128 lane groups
+// ({0-3,12-15,20-27}, ...) and the transposing ds_write_b32 (8 channel quads x 4 voxels per
+// half-wave) then touch 16 / 32 distinct bank slots -- conflict-free on both sides.
+__device__ __forceinline__ int lds_t_off(int row, int m) {
+  const int f = (((row >> 1) ^ (row >> 4)) & 1) | ((row >> 1) & 6);
+  return row * 32 + ((((m >> 2) ^ f) & 7) << 2) + (m & 3);
+}
+
 template <int WM, int WN, int TM, int TN, bool VEC, bool DYVEC, bool AFF = true, bool UP = true>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvGeom g, ConvSrc s0, ConvSrc s1,
                                                           const float* __restrict__ dy, int ldy,
-                                                          int n_load,
-                                                          float* __restrict__ ws, int ktiles,
+                                                          int n_load, float* __restrict__ ws, int ktiles,
                                                           int ntiles, int rows_per_split) {
   constexpr int KT = WM * TM * 32, NT = WN * TN * 32;
+  constexpr int AP = KT / 32, DP = NT / 32;          // 32-channel groups ("passes") per tile
   constexpr int A_FLOATS = 32 * KT, D_FLOATS = 32 * NT;
-  constexpr int AF4 = KT / 4, ATOT = 32 * AF4, APASS = ATOT / 256;   // 256 % AF4 == 0
-  constexpr int DF4 = NT / 4, DTOT = 32 * DF4, DPASS = DTOT / 256;
-  static_assert(ATOT % 256 == 0 && DTOT % 256 == 0, "tile loads must divide evenly over 256 threads");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                    // [2][32][KT]
-  float* Ds = smem + 2 * A_FLOATS;     // [2][32][NT]
+  float* As = smem;                    // [2][KT][32]
+  float* Ds = smem + 2 * A_FLOATS;     // [2][NT][32]
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 31, lh = lane >> 5;
+  // loader mapping: per pass a wave covers 8 voxel rows x 8 float4 columns (one 32-channel group)
+  const int rl = 8 * wave + (lane >> 3), cq = lane & 7;
   const int S = g.S, lg = g.lgS;
   const int M = g.B << (3 * lg);
   const int K = g.taps * g.Cin;
@@ -560,97 +582,99 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvGeom g, ConvSrc s0,
   const int m_begin = split * rows_per_split;
   const int m_end = min(M, m_begin + rows_per_split);
   const int nchunks = (m_end - m_begin + 31) >> 5;
-
-  // k tiles are runs of KT consecutive flattened k = tap*Cin + ci.  VEC (Cin % 32 == 0): a thread's
-  // float4 column sits inside one 32-channel group, hence one tap and one source -- all per-thread
-  // constants for the whole block, so tiles may span taps (thin Cin) and sources (concat layers).
   const int k0 = kt_i * KT;
-  int tdz = 0, tdy = 0, tdx = 0, sdelta = 0, xbad = -1, ybad = -1, zbad = -1;
-  bool kvalid = false;
-  const float* sp = s0.p;
-  int sC = s0.C, su = 0, cl0 = 0;
-  float slope = 1.f;
-  v4f sc = v4f{1.f, 1.f, 1.f, 1.f}, sh = v4f{0.f, 0.f, 0.f, 0.f};
+
+  // VEC (Cin % 32 == 0): every 32-channel group of the K tile lies in ONE tap and ONE source, so
+  // its tap shift / source are block-uniform (SGPRs); K tiles may span taps and sources.
+  int p_sdelta[AP], p_xbad[AP], p_ybad[AP], p_zbad[AP], p_dz[AP], p_dy[AP], p_dx[AP], p_C[AP], p_up[AP], p_cl[AP];
+  bool p_valid[AP];
+  const float* p_ptr[AP];
+  float p_slope[AP];
+  v4f p_sc[AFF ? AP : 1], p_sh[AFF ? AP : 1];
   if (VEC) {
-    const int kf = k0 + (t % AF4) * 4;
-    const int tap = kf / g.Cin, ci = kf - tap * g.Cin;
-    kvalid = kf < K;
-    if (g.taps == 27 && kvalid) { tdz = tap / 9 - 1; tdy = (tap / 3) % 3 - 1; tdx = tap % 3 - 1; }
-    sdelta = (tdz * S + tdy) * S + tdx;
-    // a shifted coordinate leaves the grid iff it starts on the face the tap points away from
-    xbad = tdx < 0 ? 0 : (tdx > 0 ? S - 1 : -1);
-    ybad = tdy < 0 ? 0 : (tdy > 0 ? S - 1 : -1);
-    zbad = tdz < 0 ? 0 : (tdz > 0 ? S - 1 : -1);
-    const bool first = ci < s0.C;
-    const ConvSrc sv = pick_src(s0, s1, first);
-    sp = sv.p; sC = sv.C; su = sv.up;
-    cl0 = kvalid ? (first ? ci : ci - s0.C) : 0;
-    slope = act_slope_of(sv.act);
-    if (AFF) {
-      sc = *reinterpret_cast<const v4f*>(sv.scale + cl0);
-      sh = *reinterpret_cast<const v4f*>(sv.shift + cl0);
+#pragma unroll
+    for (int p = 0; p < AP; ++p) {
+      const int kf = k0 + 32 * p;
+      const int tap = kf / g.Cin, ci = kf - tap * g.Cin;
+      p_valid[p] = kf < K;
+      int dz = 0, dyy = 0, dx = 0;
+      if (g.taps == 27 && p_valid[p]) { dz = tap / 9 - 1; dyy = (tap / 3) % 3 - 1; dx = tap % 3 - 1; }
+      p_dz[p] = dz; p_dy[p] = dyy; p_dx[p] = dx;
+      p_sdelta[p] = (dz * S + dyy) * S + dx;
+      // a shifted coordinate leaves the grid iff it starts on the face the tap points away from
+      p_xbad[p] = dx < 0 ? 0 : (dx > 0 ? S - 1 : -1);
+      p_ybad[p] = dyy < 0 ? 0 : (dyy > 0 ? S - 1 : -1);
+      p_zbad[p] = dz < 0 ? 0 : (dz > 0 ? S - 1 : -1);
+      const bool first = ci < s0.C;
+      const ConvSrc sv = pick_src(s0, s1, first);
+      p_ptr[p] = sv.p; p_C[p] = sv.C; p_up[p] = sv.up;
+      p_cl[p] = (p_valid[p] ? (first ? ci : ci - s0.C) : 0) + cq * 4;
+      p_slope[p] = act_slope_of(sv.act);
+      if (AFF) {
+        p_sc[p] = *reinterpret_cast<const v4f*>(sv.scale + p_cl[p]);
+        p_sh[p] = *reinterpret_cast<const v4f*>(sv.shift + p_cl[p]);
+      }
     }
   }
-  // SCALAR: this thread's fixed k
-  int s_tap = 0, s_ci = 0; bool s_kvalid = false; int sdz = 0, sdy = 0, sdx = 0;
+  // SCALAR (KT == 32): this thread's fixed flattened k
+  int s_ci = 0; bool s_kvalid = false; int sdz = 0, sdy = 0, sdx = 0;
   if (!VEC) {
     const int kf = k0 + (t & 31);
-    s_tap = kf / g.Cin; s_ci = kf - s_tap * g.Cin; s_kvalid = kf < K;
+    const int s_tap = kf / g.Cin;
+    s_ci = kf - s_tap * g.Cin; s_kvalid = kf < K;
     if (g.taps == 27) { sdz = s_tap / 9 - 1; sdy = (s_tap / 3) % 3 - 1; sdx = s_tap % 3 - 1; }
   }
 
-  v4f ra[VEC ? APASS : 1];
+  v4f ra[VEC ? AP : 1];
   float ras[4];
-  v4f rd[DPASS];
+  v4f rd[DP];
 
   auto load_chunk = [&](int c) {
     const int mbase = m_begin + (c << 5);
+    const int m = mbase + rl;
+    const bool rowok = m < m_end;
     if (VEC) {
+      const int x = m & (S - 1), y = (m >> lg) & (S - 1), z = (m >> (2 * lg)) & (S - 1);
       const int Sh = S >> 1;
 #pragma unroll
-      for (int p = 0; p < APASS; ++p) {
-        const int m = mbase + (t + 256 * p) / AF4;
-        const int x = m & (S - 1), y = (m >> lg) & (S - 1), z = (m >> (2 * lg)) & (S - 1);
-        const bool inb = kvalid && m < m_end && x != xbad && y != ybad && z != zbad;
-        int idx = m + sdelta;            // same-resolution voxel index of the tap-shifted row
+      for (int p = 0; p < AP; ++p) {
+        const bool inb = rowok && p_valid[p] && x != p_xbad[p] && y != p_ybad[p] && z != p_zbad[p];
+        int idx = m + p_sdelta[p];           // same-resolution voxel index of the tap-shifted row
         if (UP) {
           const int b = m >> (3 * lg);
-          const int idx_up = ((b * Sh + ((z + tdz) >> 1)) * Sh + ((y + tdy) >> 1)) * Sh + ((x + tdx) >> 1);
-          idx = su ? idx_up : idx;
+          const int idx_up = ((b * Sh + ((z + p_dz[p]) >> 1)) * Sh + ((y + p_dy[p]) >> 1)) * Sh + ((x + p_dx[p]) >> 1);
+          idx = p_up[p] ? idx_up : idx;
         }
-        const unsigned off = inb ? (unsigned)idx * (unsigned)sC + cl0 : (unsigned)cl0;
-        v4f v = *reinterpret_cast<const v4f*>(sp + off);
-        if (AFF) v = affine_act4(v, sc, sh, slope);
+        const unsigned off = inb ? (unsigned)idx * (unsigned)p_C[p] + p_cl[p] : (unsigned)p_cl[p];
+        v4f v = *reinterpret_cast<const v4f*>(p_ptr[p] + off);
+        if (AFF) v = affine_act4(v, p_sc[p], p_sh[p], p_slope[p]);
         ra[p] = inb ? v : v4f{0.f, 0.f, 0.f, 0.f};
       }
     } else {
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const int m = mbase + (t >> 5) + 8 * p;
+      for (int q = 0; q < 4; ++q) {
+        const int mm = mbase + (t >> 5) + 8 * q;
         float v = 0.f;
-        if (s_kvalid && m < m_end) {
-          const RowPos r = decode_row(m, S, lg);
+        if (s_kvalid && mm < m_end) {
+          const RowPos r = decode_row(mm, S, lg);
           const int zz = r.z + sdz, yy = r.y + sdy, xx = r.x + sdx;
           if ((unsigned)zz < (unsigned)S && (unsigned)yy < (unsigned)S && (unsigned)xx < (unsigned)S)
             v = gather_scalar(s0, s1, s_ci, r.b, zz, yy, xx, S);
         }
-        ras[p] = v;
+        ras[q] = v;
       }
     }
+    const float* qrow = dy + (size_t)min(m, M - 1) * ldy;
 #pragma unroll
-    for (int p = 0; p < DPASS; ++p) {
-      const int idx = t + 256 * p;
-      const int m = mbase + idx / DF4;
-      const int n = n0 + (idx % DF4) * 4;
-      const float* q = dy + (size_t)min(m, M - 1) * ldy;
+    for (int p = 0; p < DP; ++p) {
+      const int n = n0 + 32 * p + cq * 4;
       v4f v;
       if (DYVEC) {
-        v = *reinterpret_cast<const v4f*>(q + min(n, n_load - 4));
-        if (!(m < m_end && n < n_load)) v = v4f{0.f, 0.f, 0.f, 0.f};
+        v = *reinterpret_cast<const v4f*>(qrow + max(min(n, n_load - 4), 0));
+        if (!(rowok && n < n_load)) v = v4f{0.f, 0.f, 0.f, 0.f};
       } else {
-        v.x = q[min(n + 0, n_load - 1)]; v.y = q[min(n + 1, n_load - 1)];
-        v.z = q[min(n + 2, n_load - 1)]; v.w = q[min(n + 3, n_load - 1)];
-        const bool rowok = m < m_end;
+        v.x = qrow[min(n + 0, n_load - 1)]; v.y = qrow[min(n + 1, n_load - 1)];
+        v.z = qrow[min(n + 2, n_load - 1)]; v.w = qrow[min(n + 3, n_load - 1)];
         v.x = (rowok && n + 0 < n_load) ? v.x : 0.f; v.y = (rowok && n + 1 < n_load) ? v.y : 0.f;
         v.z = (rowok && n + 2 < n_load) ? v.z : 0.f; v.w = (rowok && n + 3 < n_load) ? v.w : 0.f;
       }
@@ -662,18 +686,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvGeom g, ConvSrc s0,
     float* D = Ds + buf * D_FLOATS;
     if (VEC) {
 #pragma unroll
-      for (int p = 0; p < APASS; ++p) {
-        const int idx = t + 256 * p;
-        *reinterpret_cast<v4f*>(A + (idx / AF4) * KT + (idx % AF4) * 4) = ra[p];
+      for (int p = 0; p < AP; ++p) {
+        const int kk = 32 * p + cq * 4;
+        A[lds_t_off(kk + 0, rl)] = ra[p].x; A[lds_t_off(kk + 1, rl)] = ra[p].y;
+        A[lds_t_off(kk + 2, rl)] = ra[p].z; A[lds_t_off(kk + 3, rl)] = ra[p].w;
       }
     } else {
 #pragma unroll
-      for (int p = 0; p < 4; ++p) A[((t >> 5) + 8 * p) * KT + (t & 31)] = ras[p];
+      for (int q = 0; q < 4; ++q) A[lds_t_off(t & 31, (t >> 5) + 8 * q)] = ras[q];
     }
 #pragma unroll
-    for (int p = 0; p < DPASS; ++p) {
-      const int idx = t + 256 * p;
-      *reinterpret_cast<v4f*>(D + (idx / DF4) * NT + (idx % DF4) * 4) = rd[p];
+    for (int p = 0; p < DP; ++p) {
+      const int nn = 32 * p + cq * 4;
+      D[lds_t_off(nn + 0, rl)] = rd[p].x; D[lds_t_off(nn + 1, rl)] = rd[p].y;
+      D[lds_t_off(nn + 2, rl)] = rd[p].z; D[lds_t_off(nn + 3, rl)] = rd[p].w;
     }
   };
 
@@ -691,20 +717,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvGeom g, ConvSrc s0,
   }
   __syncthreads();
   auto compute = [&](int buf) {
-    const float* A = As + buf * A_FLOATS + lh * KT + wm * TM * 32 + li;
-    const float* D = Ds + buf * D_FLOATS + lh * NT + wn * TN * 32 + li;
+    const float* A = As + buf * A_FLOATS;
+    const float* D = Ds + buf * D_FLOATS;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      float a[TM], b[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = A[s * 2 * KT + i * 32];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = D[s * 2 * NT + j * 32];
+    for (int g8 = 0; g8 < 4; ++g8) {
+      v4f a[TM], b[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
+        a[i] = *reinterpret_cast<const v4f*>(A + lds_t_off(wm * TM * 32 + i * 32 + li, g8 * 8 + lh * 4));
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < TN; ++j)
+        b[j] = *reinterpret_cast<const v4f*>(D + lds_t_off(wn * TN * 32 + j * 32 + li, g8 * 8 + lh * 4));
+#pragma unroll
+      for (int tk = 0; tk < 4; ++tk)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const float av = tk == 0 ? a[i].x : tk == 1 ? a[i].y : tk == 2 ? a[i].z : a[i].w;
+            const float bv = tk == 0 ? b[j].x : tk == 1 ? b[j].y : tk == 2 ? b[j].z : b[j].w;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+          }
     }
   };
   for (int c = 0; c + 1 < nchunks; ++c) {
