@@ -90,7 +90,9 @@ const char* conv_fwd_kernel_id(const ConvGeom& g, const ConvSrc* src, int nsrc);
 const char* conv_wgrad_kernel_id(const ConvGeom& g, const ConvSrc* src, int nsrc);
 // weight packing: Keras [taps][Cin][Cout] -> [Kpad/4][Npad][4]
 int launch_pack_fwd(hipStream_t st, const float* w, int K, int N, float* dst, int Kpad, int Npad,
-                    int k_off, int n_off, int zero_first);
+                    int k_off, int n_off, int zero_first, int cin_log = 0, int cin_phys = 0);
+int launch_materialize_input(hipStream_t st, const ConvSrc* src, int nsrc, int Cin, int CinG, int B, int S,
+                             float* out);
 int launch_pack_bwd(hipStream_t st, const float* w, int taps, int Cin, int Cout, float* dst,
                     int Kpad, int Npad, int cout_total, int co_off, int zero_first);
 

@@ -135,7 +135,9 @@ __device__ __forceinline__ float gather_scalar(const ConvSrc& s0, const ConvSrc&
 // (MFMA + LDS reads only); 2 = MFMA only.  Results of ABL != 0 are meaningless by construction.
 // AFF: some source carries a BatchNorm affine/activation; UP: some source is nearest-upsampled
 // (both compile the corresponding loader work out when false: backward-data launches are <false,false>).
-template <int WM, int WN, int TM, int TN, bool VEC, int ABL = 0, bool AFF = true, bool UP = true>
+// THIN (VEC only): Cin is a power of two < 32 (4, 8, 16), single source: a 32-wide K chunk then spans
+// 32/Cin taps and every thread's float4 column carries its OWN tap (per-thread instead of uniform).
+template <int WM, int WN, int TM, int TN, bool VEC, int ABL = 0, bool AFF = true, bool UP = true, bool THIN = false>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, ConvSrc s1,
                                                         const float* __restrict__ wp,
                                                         const float* __restrict__ bias,
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
   const int M = g.B << (3 * lg);
   const int n0 = nb * BN;
   const int nchunks = g.Kpad >> 5;
-  const int cpt = VEC ? (g.Cin >> 5) : 1;   // 32-channel chunks per tap (VEC only)
+  const int cpt = (VEC && !THIN) ? (g.Cin >> 5) : 1;   // 32-channel chunks per tap (VEC only)
 
   // ---- per-thread row bookkeeping
   const int mrow_base = mb * BM + (VEC ? (t >> 3) : (t >> 5));   // + 32*r (VEC) / 8*r (SCALAR)
@@ -211,16 +213,25 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
     }
     // ---- A tile
     if (VEC) {
-      const int tap = c / cpt, ci0 = (c - tap * cpt) << 5;
+      int tap, ci0;
+      bool kvalid = true;
+      if (THIN) {
+        const int kq = (c << 5) + (t & 7) * 4;          // this thread's flattened k = tap*Cin + ci
+        const int lgC = 31 - __clz(g.Cin);
+        tap = kq >> lgC; ci0 = kq & (g.Cin - 1);
+        kvalid = tap < g.taps;                           // K is padded up to a multiple of 32
+      } else {
+        tap = c / cpt; ci0 = (c - tap * cpt) << 5;
+      }
       const bool t27 = g.taps == 27;
       const int dz = t27 ? tap / 9 - 1 : 0, dy = t27 ? (tap / 3) % 3 - 1 : 0, dx = t27 ? tap % 3 - 1 : 0;
-      const bool first = ci0 < s0.C;
+      const bool first = THIN ? true : (ci0 < s0.C);
       const float* sp = first ? s0.p : s1.p;
       const float* sscale = first ? s0.scale : s1.scale;
       const float* sshift = first ? s0.shift : s1.shift;
       const int sC = first ? s0.C : s1.C, su = first ? s0.up : s1.up;
       const float slope = first ? slope0 : slope1;
-      const int cl = (first ? ci0 : ci0 - s0.C) + (t & 7) * 4;
+      const int cl = THIN ? ci0 : (first ? ci0 : ci0 - s0.C) + (t & 7) * 4;
       const v4f sc = *reinterpret_cast<const v4f*>(sscale + cl);
       const v4f sh = *reinterpret_cast<const v4f*>(sshift + cl);
       const int sdelta = (dz * S + dy) * S + dx;   // scalar: same-resolution voxel index shift
@@ -228,7 +239,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
 #pragma unroll
       for (int r = 0; r < RA; ++r) {
         const unsigned mk = rmask[r];
-        const bool inb = (mk >> tap) & 1u;
+        const bool inb = kvalid && ((mk >> (tap & 31)) & 1u);
         int idx = mrow_base + 32 * r + sdelta;
         if (UP) {
           // (z+dz)>>1 = (z>>1) + ((dz + (z&1)) >> 1), likewise y, x
@@ -426,7 +437,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
   }
 }
 
-template <int WM, int WN, int TM, int TN, bool VEC, int ABL = 0, bool AFF = true, bool UP = true>
+template <int WM, int WN, int TM, int TN, bool VEC, int ABL = 0, bool AFF = true, bool UP = true, bool THIN = false>
 static int launch_fwd_cfg(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, const ConvSrc& s1,
                           const float* wp, const float* bias, float* out, int ldo, int pre_act,
                           float* stat_partial, int* rows_per_block) {
@@ -434,7 +445,7 @@ static int launch_fwd_cfg(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, 
   const int M = g.B << (3 * g.lgS);
   const int gridM = (M + BM - 1) / BM, gridN = g.Npad / BN;
   const size_t lds = (size_t)2 * (BM * kLDA + 32 * BN) * sizeof(float);
-  auto kern = conv_fwd_kernel<WM, WN, TM, TN, VEC, ABL, AFF, UP>;
+  auto kern = conv_fwd_kernel<WM, WN, TM, TN, VEC, ABL, AFF, UP, THIN>;
   static bool attr_set = false;
   if (!attr_set) {
     ICS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -465,11 +476,15 @@ static void pick_fwd_tile(const ConvGeom& g, int* bm, int* bn) {
 static bool fwd_is_vec(const ConvGeom& g, const ConvSrc& s0, const ConvSrc& s1) {
   return (g.Cin % 32 == 0) && (s0.C % 32 == 0) && s0.bcast == 0 && s1.bcast == 0;
 }
+// thin vector path: one source, Cin in {4, 8, 16}
+static bool conv_is_thin(const ConvGeom& g, const ConvSrc& s0, int nsrc) {
+  return nsrc == 1 && s0.bcast == 0 && s0.C == g.Cin && (g.Cin == 4 || g.Cin == 8 || g.Cin == 16);
+}
 
 // name of the kernel instantiation launch_conv_fwd will run (profiling rows / roofline)
 const char* conv_fwd_kernel_id(const ConvGeom& g, const ConvSrc* src, int nsrc) {
   ConvSrc s0 = src[0], s1 = src[nsrc > 1 ? 1 : 0];
-  const bool vec = fwd_is_vec(g, s0, s1);
+  const bool vec = fwd_is_vec(g, s0, s1) || conv_is_thin(g, s0, nsrc);
   int bm, bn;
   pick_fwd_tile(g, &bm, &bn);
   if (bm == 64) return vec ? "conv_fwd_kernel<2,2,1,1,vec>" : "conv_fwd_kernel<2,2,1,1,scalar>";
@@ -498,11 +513,13 @@ int launch_conv_fwd(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int n
   ICS_TRY(fix_src(s0));
   ICS_TRY(fix_src(s1));
   bool vec = fwd_is_vec(g, s0, s1);
+  const bool thin = conv_is_thin(g, s0, nsrc);
   int bm, bn;
   pick_fwd_tile(g, &bm, &bn);
 #define ICS_FWD_ARGS st, g, s0, s1, wp, bias, out, ldo, pre_act, stat_partial, rows_per_block
 #define ICS_FWD(WM, WN, TM, TN)                                                                 \
   do {                                                                                          \
+    if (thin) return launch_fwd_cfg<WM, WN, TM, TN, true, 0, true, true, true>(ICS_FWD_ARGS);   \
     if (!vec) return launch_fwd_cfg<WM, WN, TM, TN, false, 0, true, true>(ICS_FWD_ARGS);        \
     if (variant == 0) return launch_fwd_cfg<WM, WN, TM, TN, true, 0, false, false>(ICS_FWD_ARGS); \
     if (variant == 1) return launch_fwd_cfg<WM, WN, TM, TN, true, 0, true, false>(ICS_FWD_ARGS);  \
@@ -553,7 +570,7 @@ __device__ __forceinline__ int lds_t_off(int row, int m) {
   return row * 32 + ((((m >> 2) ^ f) & 7) << 2) + (m & 3);
 }
 
-template <int WM, int WN, int TM, int TN, bool VEC, bool DYVEC, bool AFF = true, bool UP = true>
+template <int WM, int WN, int TM, int TN, bool VEC, bool DYVEC, bool AFF = true, bool UP = true, bool THIN = false>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvGeom g, ConvSrc s0, ConvSrc s1,
                                                           const float* __restrict__ dy, int ldy,
                                                           int n_load, float* __restrict__ ws, int ktiles,
@@ -594,7 +611,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvGeom g, ConvSrc s0,
   if (VEC) {
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
-      const int kf = k0 + 32 * p;
+      // THIN: the float4 column of this thread has its own tap (these become per-thread VGPRs)
+      const int kf = k0 + 32 * p + (THIN ? cq * 4 : 0);
       const int tap = kf / g.Cin, ci = kf - tap * g.Cin;
       p_valid[p] = kf < K;
       int dz = 0, dyy = 0, dx = 0;
@@ -608,7 +626,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvGeom g, ConvSrc s0,
       const bool first = ci < s0.C;
       const ConvSrc sv = pick_src(s0, s1, first);
       p_ptr[p] = sv.p; p_C[p] = sv.C; p_up[p] = sv.up;
-      p_cl[p] = (p_valid[p] ? (first ? ci : ci - s0.C) : 0) + cq * 4;
+      p_cl[p] = (p_valid[p] ? (first ? ci : ci - s0.C) : 0) + (THIN ? 0 : cq * 4);
       p_slope[p] = act_slope_of(sv.act);
       if (AFF) {
         p_sc[p] = *reinterpret_cast<const v4f*>(sv.scale + p_cl[p]);
@@ -774,13 +792,14 @@ __global__ void reduce_splits_kernel(const float* __restrict__ ws, int nsplit, s
 
 struct WgradPlan {
   int kt, nt, ktiles, ntiles, ksplit, rows_per_split;
-  bool vec;
+  bool vec, thin;
 };
 
 static WgradPlan plan_wgrad(const ConvGeom& g, const ConvSrc& s0, int nsrc, const ConvSrc& s1) {
   WgradPlan p;
   const int M = g.B << (3 * g.lgS);
-  p.vec = (g.Cin % 32 == 0) && (s0.C % 32 == 0) && s0.bcast == 0 && (nsrc < 2 || s1.bcast == 0);
+  p.thin = conv_is_thin(g, s0, nsrc);
+  p.vec = p.thin || ((g.Cin % 32 == 0) && (s0.C % 32 == 0) && s0.bcast == 0 && (nsrc < 2 || s1.bcast == 0));
   if (p.vec) {
     p.kt = (g.taps * g.Cin >= 128) ? 128 : (g.taps * g.Cin >= 64 ? 64 : 32);
     p.ktiles = (g.taps * g.Cin + p.kt - 1) / p.kt;
@@ -828,12 +847,12 @@ size_t conv_wgrad_workspace_floats(const ConvGeom& g, const ConvSrc* src, int ns
   return (size_t)p.ksplit * g.taps * g.Cin * g.Cout;
 }
 
-template <int WM, int WN, int TM, int TN, bool VEC, bool DYVEC, bool AFF = true, bool UP = true>
+template <int WM, int WN, int TM, int TN, bool VEC, bool DYVEC, bool AFF = true, bool UP = true, bool THIN = false>
 static int launch_wgrad_cfg(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, const ConvSrc& s1,
                             const float* dy, int ldy, int n_load, float* ws, const WgradPlan& p) {
   constexpr int KT = WM * TM * 32, NT = WN * TN * 32;
   const size_t lds = (size_t)2 * 32 * (KT + NT) * sizeof(float);
-  auto kern = conv_wgrad_kernel<WM, WN, TM, TN, VEC, DYVEC, AFF, UP>;
+  auto kern = conv_wgrad_kernel<WM, WN, TM, TN, VEC, DYVEC, AFF, UP, THIN>;
   static bool attr_set = false;
   if (!attr_set) {
     ICS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -870,7 +889,8 @@ int launch_conv_wgrad(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int
 #define ICS_WG_ARGS st, g, s0, s1, dy, ldy, n_load, workspace, p
 #define ICS_WG(WM, WN, TM, TN, DV)                                                                 \
   do {                                                                                             \
-    if (!p.vec) ICS_TRY((launch_wgrad_cfg<WM, WN, TM, TN, false, DV, true, true>(ICS_WG_ARGS)));   \
+    if (p.thin) ICS_TRY((launch_wgrad_cfg<WM, WN, TM, TN, true, DV, true, true, true>(ICS_WG_ARGS)));  \
+    else if (!p.vec) ICS_TRY((launch_wgrad_cfg<WM, WN, TM, TN, false, DV, true, true>(ICS_WG_ARGS)));   \
     else if (up) ICS_TRY((launch_wgrad_cfg<WM, WN, TM, TN, true, DV, true, true>(ICS_WG_ARGS)));   \
     else if (aff) ICS_TRY((launch_wgrad_cfg<WM, WN, TM, TN, true, DV, true, false>(ICS_WG_ARGS))); \
     else ICS_TRY((launch_wgrad_cfg<WM, WN, TM, TN, true, DV, false, false>(ICS_WG_ARGS)));         \
@@ -904,8 +924,11 @@ int launch_conv_wgrad(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int
 // =====================================================================================
 // dst[(kq*Npad + n)*4 + t] = w[(k_src)*N + n_src] with k = kq*4+t; region outside is zero-filled
 // only when zero_first (the head packs two weight tensors into one buffer).
+// cin_phys > 0: the GEMM runs on an input zero-padded from cin_log to cin_phys channels per tap
+// (K = taps*cin_phys); rows of the padding channels are zero.
 __global__ void pack_fwd_kernel(const float* __restrict__ w, int K, int N, float* __restrict__ dst,
-                                int Kpad, int Npad, int k_off, int n_off, int zero_first) {
+                                int Kpad, int Npad, int k_off, int n_off, int zero_first, int cin_log,
+                                int cin_phys) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)Kpad * Npad;
   if (i >= total) return;
@@ -913,9 +936,38 @@ __global__ void pack_fwd_kernel(const float* __restrict__ w, int K, int N, float
   const size_t rest = i >> 2;
   const int n = rest % Npad;
   const int k = (int)(rest / Npad) * 4 + tq;
-  const int ks = k - k_off, ns = n - n_off;
-  if (ks >= 0 && ks < K && ns >= 0 && ns < N) dst[i] = w[(size_t)ks * N + ns];
+  int ks = k - k_off;
+  const int ns = n - n_off;
+  bool ok = ks >= 0 && ks < K && ns >= 0 && ns < N;
+  if (ok && cin_phys > 0) {
+    const int tap = ks / cin_phys, ci = ks - tap * cin_phys;
+    ok = ci < cin_log;
+    ks = tap * cin_log + ci;
+  }
+  if (ok) dst[i] = w[(size_t)ks * N + ns];
   else if (zero_first) dst[i] = 0.f;
+}
+
+// materialise the virtual (concatenated / broadcast / BN-applied) input zero-padded to CinG channels
+__global__ void materialize_input_kernel(ConvSrc s0, ConvSrc s1, int Cin, int CinG, int S, int lg, size_t total,
+                                         float* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % CinG);
+  const RowPos r = decode_row((int)(i / CinG), S, lg);
+  out[i] = c < Cin ? gather_scalar(s0, s1, c, r.b, r.z, r.y, r.x, S) : 0.f;
+}
+int launch_materialize_input(hipStream_t st, const ConvSrc* src, int nsrc, int Cin, int CinG, int B, int S,
+                             float* out) {
+  ConvSrc s0 = src[0], s1 = src[nsrc > 1 ? 1 : 0];
+  if (nsrc == 1) s1.C = 0;
+  int lg = 0;
+  while ((1 << lg) < S) ++lg;
+  const size_t total = (size_t)B * S * S * S * CinG;
+  hipLaunchKernelGGL(materialize_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, s0, s1, Cin,
+                     CinG, S, lg, total, out);
+  ICS_HIP(hipGetLastError());
+  return 0;
 }
 
 // backward-data weights: k' = t'*cout_total + co_off + co, n' = ci, value = w[26-t'][ci][co]
@@ -936,10 +988,10 @@ __global__ void pack_bwd_kernel(const float* __restrict__ w, int taps, int Cin, 
 }
 
 int launch_pack_fwd(hipStream_t st, const float* w, int K, int N, float* dst, int Kpad, int Npad,
-                    int k_off, int n_off, int zero_first) {
+                    int k_off, int n_off, int zero_first, int cin_log, int cin_phys) {
   const size_t total = (size_t)Kpad * Npad;
   hipLaunchKernelGGL(pack_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, K, N,
-                     dst, Kpad, Npad, k_off, n_off, zero_first);
+                     dst, Kpad, Npad, k_off, n_off, zero_first, cin_log, cin_phys);
   ICS_HIP(hipGetLastError());
   return 0;
 }

@@ -79,6 +79,12 @@ struct Profiler {
 struct ConvLayer {
   std::string name;
   int Cin = 0, Cout = 0, taps = 27, S = 1;
+  int CinG = 0;                         // GEMM input channels: Cin, or Cin zero-padded to 4/16/32k when the
+                                        // virtual input is materialised (thin / broadcast inputs: c1, e0)
+  float* pad_in = nullptr;              // [M][CinG] materialised input (padded layers only)
+  float* dw_phys = nullptr;             // [taps*CinG][Cout] weight gradient before un-padding
+  ConvSrc vsrc[2];                      // the virtual sources feeding pad_in
+  int nvsrc = 0;
   int pre_act = ACT_NONE, has_bn = 0, post_act = ACT_NONE;
   int Kpad = 0, Npad = 0, Kpad_b = 0, Npad_b = 0;
   int t_w = -1, t_b = -1, t_gamma = -1, t_beta = -1;   // tensor indices
@@ -175,13 +181,20 @@ struct Net {
 // ------------------------------------------------------------------------------------------
 // layer construction
 // ------------------------------------------------------------------------------------------
+// channel count the fast (vector) loaders accept for a given logical Cin
+static int padded_cin(int Cin) {
+  if (Cin % 32 == 0 || Cin == 4 || Cin == 8 || Cin == 16) return Cin;
+  return Cin < 4 ? 4 : (Cin < 8 ? 8 : (Cin < 16 ? 16 : round_up(Cin, 32)));
+}
+
 static ConvLayer* add_conv(Net& n, const std::string& name, int Cin, int Cout, int taps, int S, int pre_act,
-                           int has_bn, int post_act, bool dense, bool register_params = true) {
+                           int has_bn, int post_act, bool dense, bool register_params = true, bool pad_input = false) {
   auto L = std::make_unique<ConvLayer>();
   L->name = name; L->Cin = Cin; L->Cout = Cout; L->taps = taps; L->S = S;
+  L->CinG = pad_input ? padded_cin(Cin) : Cin;
   L->pre_act = pre_act; L->has_bn = has_bn; L->post_act = post_act;
-  L->Kpad = round_up(taps * Cin, 32); L->Npad = round_up(Cout, 32);
-  L->Kpad_b = round_up(taps * Cout, 32); L->Npad_b = round_up(Cin, 32);
+  L->Kpad = round_up(taps * L->CinG, 32); L->Npad = round_up(Cout, 32);
+  L->Kpad_b = round_up(taps * Cout, 32); L->Npad_b = round_up(L->CinG, 32);
   if (register_params) {
     if (dense) L->t_w = n.add_tensor(name + "/kernel", {Cin, Cout}, true);
     else L->t_w = n.add_tensor(name + "/kernel", {taps == 27 ? 3 : 1, taps == 27 ? 3 : 1, taps == 27 ? 3 : 1, Cin, Cout}, true);
@@ -202,7 +215,7 @@ static int alloc_layer(Net& n, ConvLayer& L, bool need_bwd, bool pooled) {
   if (need_bwd) {
     ICS_TRY(n.alloc(&L.wf, (size_t)L.Kpad_b * L.Npad_b));
     ICS_TRY(n.alloc(&L.dy, M * L.Cout));
-    ICS_TRY(n.alloc(&L.dA, M * L.Cin));
+    ICS_TRY(n.alloc(&L.dA, M * L.CinG));
     ICS_TRY(n.alloc(&L.c1c2, (size_t)2 * L.Cout));
   }
   if (L.has_bn) {
@@ -213,6 +226,10 @@ static int alloc_layer(Net& n, ConvLayer& L, bool need_bwd, bool pooled) {
     n.tensors[ti].ptr = L.mm;
     ti = n.add_tensor(L.name + "/moving_var", {L.Cout}, false);
     n.tensors[ti].ptr = L.mv;
+  }
+  if (L.CinG != L.Cin) {
+    ICS_TRY(n.alloc(&L.pad_in, M * L.CinG));
+    if (need_bwd) ICS_TRY(n.alloc(&L.dw_phys, (size_t)L.taps * L.CinG * L.Cout));
   }
   if (pooled) {
     ICS_TRY(n.alloc(&L.pooled, M / 8 * L.Cout));
@@ -228,10 +245,10 @@ static ConvSrc src_layer(const ConvLayer& L, int up) {
 }
 
 static ConvGeom geom_fwd(const ConvLayer& L, int B) {
-  return ConvGeom{B, L.S, ilog2(L.S), L.Cin, L.Cout, L.taps, L.Kpad, L.Npad};
+  return ConvGeom{B, L.S, ilog2(L.S), L.CinG, L.Cout, L.taps, L.Kpad, L.Npad};
 }
 static ConvGeom geom_bwd(const ConvLayer& L, int B) {
-  return ConvGeom{B, L.S, ilog2(L.S), L.Cout, L.Cin, L.taps, L.Kpad_b, L.Npad_b};
+  return ConvGeom{B, L.S, ilog2(L.S), L.Cout, L.CinG, L.taps, L.Kpad_b, L.Npad_b};
 }
 
 // workspace sizing over all layers (max batch)
@@ -295,7 +312,8 @@ static int init_bn_defaults(Net& n) {
 // weight packing (after every parameter change)
 // ------------------------------------------------------------------------------------------
 static int pack_layer(Net& n, ConvLayer& L, bool need_bwd) {
-  ICS_TRY(launch_pack_fwd(n.st, n.tp(L.t_w), L.taps * L.Cin, L.Cout, L.wp, L.Kpad, L.Npad, 0, 0, 1));
+  ICS_TRY(launch_pack_fwd(n.st, n.tp(L.t_w), L.taps * L.CinG, L.Cout, L.wp, L.Kpad, L.Npad, 0, 0, 1,
+                          L.CinG != L.Cin ? L.Cin : 0, L.CinG != L.Cin ? L.CinG : 0));
   if (need_bwd && L.wf)
     ICS_TRY(launch_pack_bwd(n.st, n.tp(L.t_w), L.taps, L.Cin, L.Cout, L.wf, L.Kpad_b, L.Npad_b, L.Cout, 0, 1));
   return 0;
@@ -310,6 +328,11 @@ static int conv_forward(Net& n, ConvLayer& L, int B, bool training, bool update_
   const size_t M = n.rows(L, B);
   const bool stats = L.has_bn && training;
   int rpb = 128;
+  if (L.pad_in) {
+    n.prof.begin(n.st, "materialize_input", 0, 4.0 * M * (L.Cin + L.CinG));
+    ICS_TRY(launch_materialize_input(n.st, L.vsrc, L.nvsrc, L.Cin, L.CinG, B, L.S, L.pad_in));
+    n.prof.end(n.st);
+  }
   n.prof.begin(n.st, "conv_fwd:" + L.name + "|" + (n.prof.on ? conv_fwd_kernel_id(g, L.src, L.nsrc) : ""), 2.0 * M * L.taps * L.Cin * L.Cout,
                4.0 * (M * L.Cin + M * L.Cout + (double)L.taps * L.Cin * L.Cout));
   ICS_TRY(launch_conv_fwd(n.st, g, L.src, L.nsrc, L.wp, bias, L.s, L.Cout, L.pre_act,
@@ -333,6 +356,30 @@ static int conv_forward(Net& n, ConvLayer& L, int B, bool training, bool update_
   return 0;
 }
 
+// dw_phys[(tap*CinG + ci)*N + n] -> dw[(tap*Cin + ci)*N + n]
+__global__ void unpad_dw_kernel(const float* __restrict__ src, int Cin, int CinG, int N, size_t total,
+                                float* __restrict__ dst) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const size_t row = i / N, n = i - row * N;
+  const size_t tap = row / Cin, ci = row - tap * Cin;
+  dst[i] = src[(tap * CinG + ci) * N + n];
+}
+// y[m*C + c] += x[m*ldx + c]
+__global__ void axpy_strided_kernel(float* __restrict__ y, const float* __restrict__ x, size_t rows, int C, int ldx) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * C) return;
+  const size_t m = i / C, c = i - m * C;
+  y[i] += x[m * ldx + c];
+}
+// route a padded layer through its materialised input buffer
+static void use_padded_input(ConvLayer& L) {
+  if (L.CinG == L.Cin) return;
+  L.vsrc[0] = L.src[0]; L.vsrc[1] = L.src[1]; L.nvsrc = L.nsrc;
+  L.src[0] = ConvSrc{L.pad_in, nullptr, nullptr, L.CinG, 0, ACT_NONE, 0};
+  L.nsrc = 1;
+}
+
 static GradSrc gs_none() { return GradSrc{nullptr, 0, 0, GS_NONE, nullptr, nullptr}; }
 static GradSrc gs_direct(const float* p, int ld, int off) { return GradSrc{p, ld, off, GS_DIRECT, nullptr, nullptr}; }
 static GradSrc gs_up(const float* p, int ld, int off) { return GradSrc{p, ld, off, GS_UP, nullptr, nullptr}; }
@@ -347,7 +394,14 @@ static int conv_grads_from_dy(Net& n, ConvLayer& L, int B, bool need_dA, bool pa
   if (param_grads) {
     n.prof.begin(n.st, "conv_wgrad:" + L.name + "|" + (n.prof.on ? conv_wgrad_kernel_id(g, L.src, L.nsrc) : ""), 2.0 * M * L.taps * L.Cin * L.Cout,
                  4.0 * (M * L.Cin + M * L.Cout + (double)L.taps * L.Cin * L.Cout));
-    ICS_TRY(launch_conv_wgrad(n.st, g, L.src, L.nsrc, L.dy, L.Cout, n.tg(L.t_w), L.Cout, n.ws_wgrad, n.ws_wgrad_n));
+    float* dw = L.dw_phys ? L.dw_phys : n.tg(L.t_w);
+    ICS_TRY(launch_conv_wgrad(n.st, g, L.src, L.nsrc, L.dy, L.Cout, dw, L.Cout, n.ws_wgrad, n.ws_wgrad_n));
+    if (L.dw_phys) {
+      const size_t cnt = (size_t)L.taps * L.Cin * L.Cout;
+      hipLaunchKernelGGL(unpad_dw_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, n.st, L.dw_phys, L.Cin,
+                         L.CinG, L.Cout, cnt, n.tg(L.t_w));
+      ICS_HIP(hipGetLastError());
+    }
     n.prof.end(n.st);
   }
   if (need_dA) {
@@ -355,7 +409,7 @@ static int conv_grads_from_dy(Net& n, ConvLayer& L, int B, bool need_dA, bool pa
     ConvSrc sdy = src_plain(L.dy, L.Cout);
     n.prof.begin(n.st, "conv_dgrad:" + L.name + "|" + (n.prof.on ? conv_fwd_kernel_id(gb, &sdy, 1) : ""), 2.0 * M * L.taps * L.Cin * L.Cout,
                  4.0 * (M * L.Cin + M * L.Cout + (double)L.taps * L.Cin * L.Cout));
-    ICS_TRY(launch_conv_fwd(n.st, gb, &sdy, 1, L.wf, nullptr, L.dA, L.Cin, ACT_NONE, nullptr, nullptr));
+    ICS_TRY(launch_conv_fwd(n.st, gb, &sdy, 1, L.wf, nullptr, L.dA, L.CinG, ACT_NONE, nullptr, nullptr));
     n.prof.end(n.st);
   }
   return 0;
@@ -425,7 +479,8 @@ static int unet_build(Net& n, const ics_unet_config& cfg) {
       {"c13", 768, 512, d / 4, false},       {"c14", 512, 256, d / 4, false},
       {"c15", 384, 256, d / 2, false},       {"c16", 256, 128, d / 2, false},
       {"c17", 192, 128, d, false},           {"c18", 128, 128, d, false}};
-  for (auto& s : specs) add_conv(n, s.name, s.cin, s.cout, 27, s.S, ACT_RELU, 1, ACT_NONE, false);
+  for (auto& s : specs)
+    add_conv(n, s.name, s.cin, s.cout, 27, s.S, ACT_RELU, 1, ACT_NONE, false, true, /*pad_input=*/&s == &specs[0]);
   // heads: one 1x1x1 GEMM with N = num_classes + 1; params keep the reference's two layers
   n.head = add_conv(n, "head", 128, cfg.num_classes + 1, 1, d, ACT_NONE, 0, ACT_NONE, false, false);
   const int t_sw = n.add_tensor("soft/kernel", {1, 1, 1, 128, cfg.num_classes}, true);
@@ -456,6 +511,7 @@ static int unet_build(Net& n, const ics_unet_config& cfg) {
   r.c17->src[0] = src_layer(*r.c2, 0); r.c17->src[1] = src_layer(*r.c16, 1); r.c17->nsrc = 2;
   r.c18->src[0] = src_layer(*r.c17, 0);
   n.head->src[0] = src_layer(*r.c18, 0);
+  use_padded_input(*r.c1);
   ICS_TRY(alloc_workspaces(n, true));
   ICS_TRY(init_bn_defaults(n));
   return 0;
@@ -480,7 +536,7 @@ static int unet_pack(Net& n) {
 static int unet_forward_trunk(Net& n, int B, bool training, bool update_moving, bool upto_c10, const float* input) {
   ICS_TRY(unet_pack(n));
   UnetRefs r = unet_refs(n);
-  r.c1->src[0].p = input;
+  (r.c1->pad_in ? r.c1->vsrc[0] : r.c1->src[0]).p = input;
   const int last = upto_c10 ? 8 : 14;
   for (int i = 0; i < last; ++i) {
     ConvLayer& L = *n.layers[i];
@@ -659,7 +715,7 @@ static int vae_build(Net& n, const ics_vae_config& cfg, Net* pm) {
   int cin = C + C * cfg.cond_shape;   // K.tile quirk: cond channels = C*cond_shape
   int S = d;
   for (int i = 0; i < 4; ++i) {
-    add_conv(n, "e" + std::to_string(i), cin, cfg.filters[i], 27, S, ACT_NONE, 1, ACT_LRELU, false);
+    add_conv(n, "e" + std::to_string(i), cin, cfg.filters[i], 27, S, ACT_NONE, 1, ACT_LRELU, false, true, i == 0);
     cin = cfg.filters[i]; S /= 2;
   }
   add_conv(n, "e4", cin, 4, 27, S, ACT_LRELU, 0, ACT_NONE, false);        // S = d/16
@@ -713,6 +769,7 @@ static int vae_build(Net& n, const ics_vae_config& cfg, Net* pm) {
   r.dl[0]->src[0] = src_plain(r.decd->s, 4);
   for (int i = 1; i < 4; ++i) r.dl[i]->src[0] = src_layer(*r.dl[i - 1], 1);   // UpSampling3D after d0..d2
   r.dout->src[0] = src_layer(*r.dl[3], 0);
+  use_padded_input(*r.e[0]);
   ICS_TRY(alloc_workspaces(n, true));
   ICS_TRY(init_bn_defaults(n));
   if (pm) {
@@ -821,7 +878,8 @@ static int vae_step(Net& n, int B, bool training, float* metrics) {
                               pm_part, n.d_pm_counts, n.d_pm_w, n.alpha, n.beta, n.d_metrics))) break;
     if (training) {
       if ((rc = unet_pm_backward(u, B))) break;
-      if ((rc = launch_axpy(n.st, n.drecon, ur.c1->dA, M * n.C, 1.f))) break;
+      hipLaunchKernelGGL(axpy_strided_kernel, dim3((unsigned)((M * n.C + 255) / 256)), dim3(256), 0, n.st, n.drecon,
+                         ur.c1->dA, M, n.C, ur.c1->CinG);
       // decoder
       if ((rc = conv_backward(n, *r.dout, B, gs_direct(n.drecon, n.C, 0), gs_none(), nullptr, true, true))) break;
       if ((rc = conv_backward(n, *r.dl[3], B, gs_direct(r.dout->dA, r.dout->Cin, 0), gs_none(), nullptr, true, true))) break;
