@@ -64,3 +64,21 @@ def test_lattice_vae_train_sample_roundtrip(tmp_path):
     vae2 = LatticeDFCVAE(input_shape=(d, d, d, C), perceptual_model=pm_path)
     vae2._set_model(wpath, batch_size=B)
     assert np.array_equal(vae2.decoder.predict([zm, cond]), rec)
+
+
+def test_training_scripts_run_on_synthetic_data(tmp_path):
+    """train_unet.py then train_vae.py (which loads the U-Net checkpoint as perceptual model), CLI as
+    in the reference README, on --synthetic grids."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root)
+    common = ["--name", "t", "--synthetic", "8", "--channels", "1", "--d", "16", "--epochs", "1", "--batch_size", "2"]
+    subprocess.run([sys.executable, os.path.join(root, "train_unet.py")] + common, cwd=tmp_path, env=env, check=True)
+    assert os.path.exists(tmp_path / "saved_models" / "unet" / "t" / "unet_weights_t.best.h5")
+    subprocess.run([sys.executable, os.path.join(root, "train_vae.py")] + common, cwd=tmp_path, env=env, check=True)
+    assert os.path.exists(tmp_path / "saved_models" / "vae" / "t" / "vae_weights_t.best.h5")
+    subprocess.run([sys.executable, os.path.join(root, "generate.py"), "--name", "t", "--channels", "1", "--d", "16",
+                    "--batch_size", "2", "--nsamples", "4"], cwd=tmp_path, env=env, check=True)
+    sp = np.load(tmp_path / "output" / "results" / "synthetic__v=0.5" / "species" / "3.npy")
+    assert sp.shape == (16, 16, 16) and sp.dtype == np.uint8

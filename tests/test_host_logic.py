@@ -95,3 +95,18 @@ def test_shard_range_partitions_the_global_batch():
         assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
     with pytest.raises(ValueError):
         shard_range(8, 8, 8)
+
+
+def test_data_split_is_deterministic_and_disjoint(tmp_path):
+    from icsg3d_amd.utils import data_split
+    folder = tmp_path / "density_matrices"
+    os.makedirs(folder)
+    for i in range(10):
+        np.save(folder / ("mp-%d.npy" % i), np.zeros(1))
+        for k in range(2):
+            np.save(folder / ("mp-%d_rot_%d.npy" % (i, k)), np.zeros(1))
+    tr, va = data_split(str(tmp_path), 30, frac=0.8, n_rot=2)
+    tr2, va2 = data_split(str(tmp_path), 30, frac=0.8, n_rot=2)
+    assert tr == tr2 and va == va2 and not set(tr) & set(va)
+    assert len(tr) == 24 and len(va) == 6            # 8 + 2 base ids, each with 2 rotations
+    assert {f.split("_rot_")[0].replace(".npy", "") for f in tr}.isdisjoint({f.split("_rot_")[0].replace(".npy", "") for f in va})

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Train the U-Net segmentation network on the MI355X engine.
+
+Same flags and defaults as /root/reference/train_unet.py:27-79 (--name --samples --d --epochs --lr
+--batch_size --nrot --nclasses --split), same paths (data/<name>/matrices, saved_models/unet/<name>/
+unet_weights_<name>.best.hdf5, output/unet/<name>).  Added: --channels (the reference hard-codes 4,
+train_unet.py:84) and --synthetic N (Gaussian-blob grids of SURVEY 8(d); no dataset exists offline).
+
+  python3 train_unet.py --name heusler --samples 5000 --epochs 100
+  python3 train_unet.py --name demo --synthetic 64 --channels 1 --epochs 2 --batch_size 8
+"""
+import argparse
+import os
+
+import numpy as np
+
+from icsg3d_amd.unet.data import SyntheticUnetGenerator, UnetDataGenerator
+from icsg3d_amd.unet.get_weights import get_weights
+from icsg3d_amd.unet.unet import AtomUnet
+from icsg3d_amd.utils import data_split
+
+if __name__ == "__main__":
+    p = argparse.ArgumentParser()
+    p.add_argument("--name", type=str, help="Name of data folder")
+    p.add_argument("--samples", type=int, default=20000, help="Total number of training and validation samples")
+    p.add_argument("--d", type=int, default=32, help="Dimension of density matrices (number of voxels)")
+    p.add_argument("--epochs", type=int, default=50)
+    p.add_argument("--lr", type=float, default=3e-6)
+    p.add_argument("--batch_size", type=int, default=10)
+    p.add_argument("--nrot", type=int, default=10)
+    p.add_argument("--nclasses", type=int, default=95)
+    p.add_argument("--split", type=float, default=0.8)
+    p.add_argument("--channels", type=int, default=4, help="input channels (density + 3 coordinate grids)")
+    p.add_argument("--synthetic", type=int, default=0, help="train on N synthetic grids instead of data/<name>")
+    a = p.parse_args()
+
+    mode, d = a.name, a.d
+    path = os.path.join("data", mode, "matrices")
+    input_shape = (d, d, d, a.channels)
+    weights_dir = os.path.join("saved_models", "unet", mode)
+    os.makedirs(weights_dir, exist_ok=True)
+    os.makedirs(os.path.join("output/unet", mode), exist_ok=True)
+    weights = os.path.join(weights_dir, "unet_weights_" + mode + ".best.hdf5")
+
+    if a.synthetic:
+        n_train = int(a.synthetic * a.split)
+        training_generator = SyntheticUnetGenerator(n_train, a.batch_size, (d, d, d), a.channels, a.nclasses, seed=0)
+        validation_generator = SyntheticUnetGenerator(a.synthetic - n_train, a.batch_size, (d, d, d), a.channels,
+                                                      a.nclasses, seed=10 ** 6)
+        class_weights = get_weights()
+    else:
+        training_ids, validation_ids = data_split(path, a.samples, frac=a.split, n_rot=a.nrot)
+        training_generator = UnetDataGenerator(training_ids, data_path=path, batch_size=a.batch_size, dim=(d, d, d),
+                                               n_channels=a.channels, shuffle=True)
+        validation_generator = UnetDataGenerator(validation_ids, data_path=path, batch_size=a.batch_size, dim=(d, d, d),
+                                                 n_channels=a.channels, shuffle=True)
+        try:
+            class_weights = np.load(weights_dir + "/class_weights.npy")
+        except Exception:
+            class_weights = get_weights(path, training_ids, a.nclasses)
+            class_weights[0] = 0.0
+            np.save(weights_dir + "/class_weights.npy", class_weights)
+
+    unet = AtomUnet(num_classes=a.nclasses, class_weights=class_weights, input_shape=input_shape, weights=weights,
+                    lr=a.lr, max_batch=a.batch_size)
+    unet.train_generator(training_generator, validation_generator, epochs=a.epochs,
+                         output_dir=os.path.join("output", "unet", mode))
+    unet.save_(weights, os.path.splitext(weights)[0] + ".h5")

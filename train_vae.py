@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Train the Cond-DFC-VAE on the MI355X engine.
+
+Same flags and defaults as /root/reference/train_vae.py:29-83 (--name --samples --epochs --batch_size
+--ncond --nrot --cond --split --d), same paths; the perceptual model is the U-Net checkpoint
+saved_models/unet/<name>/unet_weights_<name>.best.h5 written by train_unet.py.  Unlike the reference
+ --d reaches the model.  Added: --channels, --synthetic N.
+"""
+import argparse
+import os
+
+from icsg3d_amd.utils import data_split
+from icsg3d_amd.vae.data import SyntheticVAEGenerator, VAEDataGenerator
+from icsg3d_amd.vae.lattice_vae import LatticeDFCVAE
+
+if __name__ == "__main__":
+    p = argparse.ArgumentParser()
+    p.add_argument("--name", type=str, help="Name of data folder")
+    p.add_argument("--samples", type=int, default=40000)
+    p.add_argument("--epochs", type=int, default=50)
+    p.add_argument("--batch_size", type=int, default=20)
+    p.add_argument("--ncond", type=int, default=10)
+    p.add_argument("--nrot", type=int, default=10)
+    p.add_argument("--cond", type=str, default="formation_energy_per_atom")
+    p.add_argument("--split", type=float, default=0.8)
+    p.add_argument("--d", type=int, default=32)
+    p.add_argument("--channels", type=int, default=4)
+    p.add_argument("--synthetic", type=int, default=0)
+    a = p.parse_args()
+
+    mode, d, bs = a.name, a.d, a.batch_size
+    path = os.path.join("data", mode, "matrices")
+    csv_path = os.path.join("data", mode, mode + ".csv")
+    input_shape = (d, d, d, a.channels)
+    weights_dir = os.path.join("saved_models", "vae", mode)
+    os.makedirs(weights_dir, exist_ok=True)
+    os.makedirs(os.path.join("output", "vae", mode), exist_ok=True)
+    weights = os.path.join(weights_dir, "vae_weights_" + mode + ".best.hdf5")
+    perceptual_model = os.path.join("saved_models", "unet", mode, "unet_weights_" + mode + ".best.h5")
+
+    if a.synthetic:
+        n_train = int(a.synthetic * a.split) // bs * bs
+        n_val = (a.synthetic - n_train) // bs * bs
+        training_generator = SyntheticVAEGenerator(n_train, bs, (d, d, d), a.channels, a.ncond, seed=0)
+        validation_generator = SyntheticVAEGenerator(n_val, bs, (d, d, d), a.channels, a.ncond, seed=10 ** 6)
+    else:
+        training_ids, validation_ids = data_split(path, a.samples, frac=a.split, n_rot=a.nrot)
+        if len(training_ids) % bs != 0:          # ids must be a multiple of the batch size (train_vae.py:108-111)
+            training_ids = training_ids[:-1 * int(len(training_ids) % bs)]
+        if len(validation_ids) % bs != 0:
+            validation_ids = validation_ids[:-1 * int(len(validation_ids) % bs)]
+        print(len(training_ids), len(validation_ids))
+        kw = dict(data_path=path, property_csv=csv_path, batch_size=bs, dim=(d, d, d), n_channels=a.channels,
+                  shuffle=True, n_bins=a.ncond, target=a.cond)
+        training_generator = VAEDataGenerator(training_ids, **kw)
+        validation_generator = VAEDataGenerator(validation_ids, **kw)
+
+    lattice_vae = LatticeDFCVAE(input_shape=input_shape, perceptual_model=perceptual_model, cond_shape=a.ncond,
+                                output_dir=os.path.join("output", "vae", mode))
+    lattice_vae.train(training_generator, validation_generator, epochs=a.epochs, weights=weights)
