@@ -11,6 +11,7 @@
 // k group (lane half h supplies k = 4h..4h+3), which only reorders the fp32 summation.
 #include "common.h"
 
+#include <cstdlib>
 #include <vector>
 
 namespace ics {
@@ -137,7 +138,11 @@ __device__ __forceinline__ float gather_scalar(const ConvSrc& s0, const ConvSrc&
 // (both compile the corresponding loader work out when false: backward-data launches are <false,false>).
 // THIN (VEC only): Cin is a power of two < 32 (4, 8, 16), single source: a 32-wide K chunk then spans
 // 32/Cin taps and every thread's float4 column carries its OWN tap (per-thread instead of uniform).
-template <int WM, int WN, int TM, int TN, bool VEC, int ABL = 0, bool AFF = true, bool UP = true, bool THIN = false>
+// REUSE (VEC, 27 taps, 4 <= S <= BM): an M tile is a whole number of x-lines; in LDS every line is
+// followed by a zero row, so the dx = -1/0/+1 taps of a (dz,dy) pair read the SAME staged A tile at
+// row offsets -1/0/+1.  A tiles are then loaded, BN-transformed and stored once per 3 chunks.
+template <int WM, int WN, int TM, int TN, bool VEC, int ABL = 0, bool AFF = true, bool UP = true, bool THIN = false,
+          bool REUSE = false>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, ConvSrc s1,
                                                         const float* __restrict__ wp,
                                                         const float* __restrict__ bias,
@@ -145,12 +150,14 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
                                                         float* __restrict__ stat_partial, int gridM,
                                                         int gridN) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  constexpr int A_FLOATS = BM * kLDA, B_FLOATS = 32 * BN;
+  constexpr int B_FLOATS = 32 * BN;
   constexpr int RA = BM / 32;    // VEC: float4 A loads per thread per chunk
   constexpr int RS = BM / 8;     // SCALAR: scalar A loads per thread per chunk
   constexpr int NB = BN / 32;    // float4 B loads per thread per chunk
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                      // [2][BM][36]
+  // REUSE: BM rows + one zero row after each of the BM/S lines + one leading zero row
+  const int A_FLOATS = (REUSE ? BM + (BM >> g.lgS) + 1 : BM) * kLDA;
+  float* As = smem;                      // [2][rows][36]
   float* Bs = smem + 2 * A_FLOATS;       // [2][8][BN][4]
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -203,14 +210,63 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
   float ras[RS];
   v4f rb[NB];
 
-  auto load_chunk = [&](int c) {
-    // ---- B tile: packed weights [Kpad/4][Npad][4]
+  // ---- B tile of K rows [krow4*4, krow4*4+32): packed weights [Kpad/4][Npad][4]
+  auto load_b = [&](int krow4) {
 #pragma unroll
     for (int r = 0; r < NB; ++r) {
       const int idx = t + 256 * r;
       const int kq = idx / BN, n = idx % BN;
-      rb[r] = *reinterpret_cast<const v4f*>(wp + ((size_t)(c * 8 + kq) * g.Npad + n0 + n) * 4);
+      rb[r] = *reinterpret_cast<const v4f*>(wp + ((size_t)(krow4 + kq) * g.Npad + n0 + n) * 4);
     }
+  };
+  auto store_b = [&](int buf) {
+    float* Bw = Bs + buf * B_FLOATS;
+#pragma unroll
+    for (int r = 0; r < NB; ++r) *reinterpret_cast<v4f*>(Bw + (t + 256 * r) * 4) = rb[r];
+  };
+  // REUSE: A tile of group G = (dz*3+dy)*cpt + cc, i.e. the dx = 0 rows of 32 channels
+  auto load_a_group = [&](int G) {
+    const int gzy = G / cpt, ci0 = (G - gzy * cpt) << 5;
+    const int dz = gzy / 3 - 1, dy = gzy % 3 - 1;
+    const bool first = ci0 < s0.C;
+    const float* sp = first ? s0.p : s1.p;
+    const float* sscale = first ? s0.scale : s1.scale;
+    const float* sshift = first ? s0.shift : s1.shift;
+    const int sC = first ? s0.C : s1.C, su = first ? s0.up : s1.up;
+    const float slope = first ? slope0 : slope1;
+    const int cl = (first ? ci0 : ci0 - s0.C) + (t & 7) * 4;
+    const v4f sc = *reinterpret_cast<const v4f*>(sscale + cl);
+    const v4f sh = *reinterpret_cast<const v4f*>(sshift + cl);
+    const int sdelta = (dz * S + dy) * S;
+    const int Sh = S >> 1;
+#pragma unroll
+    for (int r = 0; r < RA; ++r) {
+      const unsigned mk = rmask[r];
+      const bool inb = (mk >> (gzy * 3 + 1)) & 1u;        // validity of the centre (dx = 0) tap
+      int idx = mrow_base + 32 * r + sdelta;
+      if (UP) {
+        const int ez = (dz + (int)((mk >> 29) & 1u)) >> 1;
+        const int ey = (dy + (int)((mk >> 28) & 1u)) >> 1;
+        const int idx_up = rvh[r] + (ez * Sh + ey) * Sh;
+        idx = su ? idx_up : idx;
+      }
+      const unsigned off = inb ? (unsigned)idx * (unsigned)sC + cl : (unsigned)cl;
+      v4f v = *reinterpret_cast<const v4f*>(sp + off);
+      if (AFF) v = affine_act4(v, sc, sh, slope);
+      ra4[r] = inb ? v : v4f{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto store_a_group = [&](int buf) {
+    float* A = As + buf * A_FLOATS;
+#pragma unroll
+    for (int r = 0; r < RA; ++r) {
+      const int row = (t >> 3) + 32 * r;
+      *reinterpret_cast<v4f*>(A + (row + (row >> lg) + 1) * kLDA + (t & 7) * 4) = ra4[r];
+    }
+  };
+
+  auto load_chunk = [&](int c) {
+    load_b(c * 8);
     // ---- A tile
     if (VEC) {
       int tap, ci0;
@@ -287,9 +343,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
 
   auto store_chunk = [&](int buf) {
     float* A = As + buf * A_FLOATS;
-    float* Bw = Bs + buf * B_FLOATS;
-#pragma unroll
-    for (int r = 0; r < NB; ++r) *reinterpret_cast<v4f*>(Bw + (t + 256 * r) * 4) = rb[r];
+    store_b(buf);
     if (VEC) {
 #pragma unroll
       for (int r = 0; r < RA; ++r)
@@ -308,18 +362,15 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  load_chunk(0);
-  store_chunk(0);
-  __syncthreads();
-
-  auto compute = [&](int buf) {
-    const float* A = As + buf * A_FLOATS + (wm * TM * 32 + li) * kLDA + lh * 4;
-    const float* Bw = Bs + buf * B_FLOATS + (lh * BN + wn * TN * 32 + li) * 4;
+  // generic MFMA stream over one staged chunk; arow0 = LDS row of this lane's first A row
+  auto compute_at = [&](const float* Abase, int arow_stride_rows, int bbuf) {
+    const float* Bw = Bs + bbuf * B_FLOATS + (lh * BN + wn * TN * 32 + li) * 4;
 #pragma unroll
     for (int g8 = 0; g8 < 4; ++g8) {
       float4 a[TM], b[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4*>(A + i * 32 * kLDA + g8 * 8);
+      for (int i = 0; i < TM; ++i)
+        a[i] = *reinterpret_cast<const float4*>(Abase + i * arow_stride_rows * kLDA + g8 * 8);
 #pragma unroll
       for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const float4*>(Bw + (g8 * 2 * BN + j * 32) * 4);
       // rotate over the TM*TN accumulators inside each k step: the next MFMA on the same
@@ -335,6 +386,96 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
           }
     }
+  };
+
+  if (REUSE) {
+    // ---- dx-reuse pipeline: groups G = ((dz*3+dy), 32-channel slice); chunks c = 3G + (dx+1)
+    const int nG = 9 * cpt;
+    const int lines = BM >> lg;
+    for (int i = t; i < 2 * (lines + 1) * kLDA; i += 256) {      // the separator rows stay zero
+      const int b = i / ((lines + 1) * kLDA), rem = i - b * (lines + 1) * kLDA;
+      As[b * A_FLOATS + (rem / kLDA) * (S + 1) * kLDA + rem % kLDA] = 0.f;
+    }
+    // this lane's A rows inside the padded image (MFMA tile rows never straddle... a 32-row MFMA tile
+    // may span lines when S < 32, so every tile row gets its own padded index)
+    int arow[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int row = wm * TM * 32 + i * 32 + li;
+      arow[i] = row + (row >> lg) + 1;
+    }
+    auto b_rows = [&](int c) {   // first packed K row (in units of 4) of chunk c
+      const int G = c / 3, dxi = c - 3 * G;
+      const int gzy = G / cpt, cc = G - gzy * cpt;
+      return (((gzy * 3 + dxi) * g.Cin + (cc << 5)) >> 2);
+    };
+    auto compute_reuse = [&](int abuf, int bbuf, int dx) {
+      const float* Bw = Bs + bbuf * B_FLOATS + (lh * BN + wn * TN * 32 + li) * 4;
+      const float* A = As + abuf * A_FLOATS + lh * 4 + dx * kLDA;
+#pragma unroll
+      for (int g8 = 0; g8 < 4; ++g8) {
+        float4 a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4*>(A + arow[i] * kLDA + g8 * 8);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const float4*>(Bw + (g8 * 2 * BN + j * 32) * 4);
+#pragma unroll
+        for (int tk = 0; tk < 4; ++tk)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              const float av = tk == 0 ? a[i].x : tk == 1 ? a[i].y : tk == 2 ? a[i].z : a[i].w;
+              const float bv = tk == 0 ? b[j].x : tk == 1 ? b[j].y : tk == 2 ? b[j].z : b[j].w;
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+            }
+      }
+    };
+    load_a_group(0);
+    store_a_group(0);
+    load_b(b_rows(0));
+    store_b(0);
+    __syncthreads();
+    for (int G = 0; G + 1 < nG; ++G) {
+      const int c0 = 3 * G;
+      // dx = -1 : also fetch the next group's A rows (kept in registers for three chunks)
+      load_a_group(G + 1);
+      load_b(b_rows(c0 + 1));
+      compute_reuse(G & 1, c0 & 1, -1);
+      store_b((c0 + 1) & 1);
+      __syncthreads();
+      // dx = 0
+      load_b(b_rows(c0 + 2));
+      compute_reuse(G & 1, (c0 + 1) & 1, 0);
+      store_b((c0 + 2) & 1);
+      __syncthreads();
+      // dx = +1 : stage the next group's A tile
+      load_b(b_rows(c0 + 3));
+      compute_reuse(G & 1, (c0 + 2) & 1, 1);
+      store_a_group((G + 1) & 1);
+      store_b((c0 + 3) & 1);
+      __syncthreads();
+    }
+    {
+      const int G = nG - 1, c0 = 3 * G;
+      load_b(b_rows(c0 + 1));
+      compute_reuse(G & 1, c0 & 1, -1);
+      store_b((c0 + 1) & 1);
+      __syncthreads();
+      load_b(b_rows(c0 + 2));
+      compute_reuse(G & 1, (c0 + 1) & 1, 0);
+      store_b((c0 + 2) & 1);
+      __syncthreads();
+      compute_reuse(G & 1, (c0 + 2) & 1, 1);
+      __syncthreads();
+    }
+  } else {
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+
+  auto compute = [&](int buf) {
+    compute_at(As + buf * A_FLOATS + (wm * TM * 32 + li) * kLDA + lh * 4, 32, buf);
   };
   auto compute_regs_only = [&]() {
     float av = (float)li, bv = (float)lh;
@@ -362,6 +503,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
   }
   compute((nchunks - 1) & 1);
   __syncthreads();
+  }   // !REUSE
 
   // ---- epilogue: bias + activation, store, per-block BatchNorm partial statistics
   const int mrow0 = mb * BM + wm * TM * 32 + 4 * lh;
@@ -437,19 +579,22 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
   }
 }
 
-template <int WM, int WN, int TM, int TN, bool VEC, int ABL = 0, bool AFF = true, bool UP = true, bool THIN = false>
+template <int WM, int WN, int TM, int TN, bool VEC, int ABL = 0, bool AFF = true, bool UP = true, bool THIN = false,
+          bool REUSE = false>
 static int launch_fwd_cfg(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, const ConvSrc& s1,
                           const float* wp, const float* bias, float* out, int ldo, int pre_act,
                           float* stat_partial, int* rows_per_block) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const int M = g.B << (3 * g.lgS);
   const int gridM = (M + BM - 1) / BM, gridN = g.Npad / BN;
-  const size_t lds = (size_t)2 * (BM * kLDA + 32 * BN) * sizeof(float);
-  auto kern = conv_fwd_kernel<WM, WN, TM, TN, VEC, ABL, AFF, UP, THIN>;
+  const int arows = REUSE ? BM + (BM >> g.lgS) + 1 : BM;
+  const size_t lds = (size_t)2 * (arows * kLDA + 32 * BN) * sizeof(float);
+  auto kern = conv_fwd_kernel<WM, WN, TM, TN, VEC, ABL, AFF, UP, THIN, REUSE>;
   static bool attr_set = false;
   if (!attr_set) {
+    const size_t lds_max = (size_t)2 * ((REUSE ? BM + BM / 4 + 1 : BM) * kLDA + 32 * BN) * sizeof(float);
     ICS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
     attr_set = true;
   }
   if (rows_per_block) *rows_per_block = BM;
@@ -514,6 +659,7 @@ int launch_conv_fwd(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int n
   ICS_TRY(fix_src(s1));
   bool vec = fwd_is_vec(g, s0, s1);
   const bool thin = conv_is_thin(g, s0, nsrc);
+  static const bool no_reuse = getenv("ICSG3D_NO_REUSE") != nullptr;   // A/B switch for benchmarking
   int bm, bn;
   pick_fwd_tile(g, &bm, &bn);
 #define ICS_FWD_ARGS st, g, s0, s1, wp, bias, out, ldo, pre_act, stat_partial, rows_per_block
@@ -521,6 +667,11 @@ int launch_conv_fwd(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int n
   do {                                                                                          \
     if (thin) return launch_fwd_cfg<WM, WN, TM, TN, true, 0, true, true, true>(ICS_FWD_ARGS);   \
     if (!vec) return launch_fwd_cfg<WM, WN, TM, TN, false, 0, true, true>(ICS_FWD_ARGS);        \
+    if (g.taps == 27 && g.S >= 4 && g.S <= (WM) * (TM) * 32 && !no_reuse) {                      \
+      if (variant == 0) return launch_fwd_cfg<WM, WN, TM, TN, true, 0, false, false, false, true>(ICS_FWD_ARGS); \
+      if (variant == 1) return launch_fwd_cfg<WM, WN, TM, TN, true, 0, true, false, false, true>(ICS_FWD_ARGS);  \
+      return launch_fwd_cfg<WM, WN, TM, TN, true, 0, true, true, false, true>(ICS_FWD_ARGS);    \
+    }                                                                                           \
     if (variant == 0) return launch_fwd_cfg<WM, WN, TM, TN, true, 0, false, false>(ICS_FWD_ARGS); \
     if (variant == 1) return launch_fwd_cfg<WM, WN, TM, TN, true, 0, true, false>(ICS_FWD_ARGS);  \
     return launch_fwd_cfg<WM, WN, TM, TN, true, 0, true, true>(ICS_FWD_ARGS);                   \
