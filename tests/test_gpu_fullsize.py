@@ -1,0 +1,92 @@
+"""Size-independent properties at BASELINE.json's full configuration (B=32, 32^3 x 1), where the fp64
+oracle is too slow to be the checker: softmax rows sum to 1, fused argmax == host argmax, conv
+linearity, run-to-run bit-stability, training actually reduces the loss, C=4 inputs work."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def full():
+    from icsg3d_amd.engine import UnetEngine
+    from icsg3d_amd.synthetic import glorot_params, synthetic_batch, unet_param_shapes
+    B, d = 32, 32
+    eng = UnetEngine(in_channels=1, d=d, max_batch=B, lr=1e-4)
+    P = glorot_params(unet_param_shapes(1, 95), 1)
+    eng.set_weights(P)
+    X, lab, _ = synthetic_batch(B, d, 1, seed=0, noise=1e-3)
+    return eng, P, X, lab
+
+
+def test_full_batch_training_reduces_loss_and_is_bit_stable(full):
+    eng, P, X, lab = full
+    losses = [eng.train_step(X, lab)[0] for _ in range(4)]
+    assert np.all(np.isfinite(losses)) and losses[-1] < losses[0]
+    w1 = eng.get_weights()
+    eng.set_weights(P); eng.reset_optimizer()
+    for k in w1:                                        # BN moving statistics are state too
+        if k.endswith("moving_mean"):
+            eng.set_tensor(k, np.zeros_like(w1[k]))
+        if k.endswith("moving_var"):
+            eng.set_tensor(k, np.ones_like(w1[k]))
+    losses2 = [eng.train_step(X, lab)[0] for _ in range(4)]
+    assert losses == losses2                            # no float atomics anywhere: bit-identical reruns
+    w2 = eng.get_weights()
+    assert all(np.array_equal(w1[k], w2[k]) for k in w1)
+    mv = np.concatenate([w1[k] for k in w1 if k.endswith("moving_var")])
+    assert np.all(mv > 0) and np.all(np.isfinite(mv))
+
+
+def test_full_batch_predict_properties(full):
+    eng, P, X, lab = full
+    soft, sig = eng.predict(X[:8])
+    np.testing.assert_allclose(soft.sum(-1), 1.0, atol=2e-6)
+    assert soft.min() >= 0 and sig.min() >= 0 and sig.max() <= 1
+    sp, mk = eng.predict_labels(X[:8], 0.8)
+    assert np.array_equal(sp, soft.argmax(-1)) and np.array_equal(mk, sig[..., 0] >= 0.8)
+    # batch independence in eval mode (BN uses moving statistics): any sub-batch gives the same rows
+    soft2, _ = eng.predict(X[2:5])
+    assert np.array_equal(soft2, soft[2:5])
+    # metrics of test_step equal the reference formulas evaluated on the predictions
+    from icsg3d_amd.unet.unet import f1_m, weighted_categorical_crossentropy, wr_m
+    m = eng.test_step(X[:8], lab[:8])
+    y = np.eye(95, dtype=np.float32)[lab[:8]]
+    assert abs(m[1] - weighted_categorical_crossentropy(95)(y, soft).mean()) <= 2e-5 * abs(m[1])
+    assert abs(m[3] - f1_m(y, soft)) < 1e-6 and abs(m[4] - wr_m(y, soft)) < 1e-6
+
+
+def test_conv_linearity_at_full_size():
+    """conv(a*x1 + x2) == a*conv(x1) + conv(x2) for the largest layer shape (c17: 32^3 x 192 -> 128)."""
+    from icsg3d_amd import engine as E
+    rng = np.random.default_rng(0)
+    x1 = rng.standard_normal((1, 32, 32, 32, 192)).astype(np.float32)
+    x2 = rng.standard_normal((1, 32, 32, 32, 192)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 3, 192, 128)) / 72).astype(np.float32)
+    y1, y2 = E.conv3d_forward(x1, w), E.conv3d_forward(x2, w)
+    y3 = E.conv3d_forward(2.0 * x1 + x2, w)
+    assert np.abs(y3 - (2.0 * y1 + y2)).max() <= 2e-5 * np.abs(y3).max()
+    # borders really are zero-padded: an all-ones input through an all-ones 1-channel slice counts taps
+    xo = np.ones((1, 8, 8, 8, 32), np.float32)
+    wo = np.zeros((3, 3, 3, 32, 32), np.float32); wo[..., 0, 0] = 1.0
+    yo = E.conv3d_forward(xo, wo)[0, ..., 0]
+    assert yo[0, 0, 0] == 8 and yo[0, 0, 4] == 12 and yo[0, 4, 4] == 18 and yo[4, 4, 4] == 27
+
+
+def test_four_channel_inputs_match_oracle_forward():
+    """The reference scripts run input_shape=(d,d,d,4): density + coordinate grids."""
+    from icsg3d_amd.engine import UnetEngine, VaeEngine
+    from oracle import numpy_ref as R
+    B, d, C = 2, 16, 4
+    uo = R.UnetOracle(in_ch=C, seed=1)
+    vo = R.VaeOracle(uo, in_ch=C, d=d, seed=3)
+    ue = UnetEngine(in_channels=C, d=d, max_batch=B); ue.set_weights(uo.P)
+    ve = VaeEngine(ue, in_channels=C, d=d, max_batch=B); ve.set_weights(vo.P)
+    X, lab, cond = R.synthetic_batch(B, d, C, seed=0, dtype=np.float64)
+    X = X + 1e-3 * np.random.default_rng(5).uniform(size=X.shape)
+    eps = np.random.default_rng(2).standard_normal((B, 256))
+    m_ref = vo.train_on_batch(X, cond.astype(np.float64), eps)      # e0 has Cin = 4 + 4*10 = 44 (F7)
+    m = ve.train_step(X, cond, eps)
+    np.testing.assert_allclose(m, m_ref, rtol=3e-5)
+    m_u = ue.test_step(X, lab)
+    np.testing.assert_allclose(m_u, uo.test_on_batch(X, lab), rtol=1e-4, atol=1e-6)
