@@ -84,6 +84,8 @@ int launch_conv_wgrad(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int
                       size_t workspace_floats);
 size_t conv_wgrad_workspace_floats(const ConvGeom& g, const ConvSrc* src, int nsrc);
 int conv_fwd_rows_per_block(const ConvGeom& g);
+int launch_conv_wgrad_ablate(hipStream_t st, const ConvGeom& g, const ConvSrc* src, const float* dy, int ldy,
+                             float* workspace, int ablate);
 int launch_conv_fwd_ablate(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int nsrc, const float* wp,
                            float* out, int ldo, int ablate);
 const char* conv_fwd_kernel_id(const ConvGeom& g, const ConvSrc* src, int nsrc);

@@ -709,35 +709,25 @@ int launch_conv_fwd_ablate(hipStream_t st, const ConvGeom& g, const ConvSrc* src
 // =====================================================================================
 // Backward-weight kernel: ws[split][k][n] = sum_{m in split} A[m][k] * dy[m][n]
 // =====================================================================================
-// LDS images are TRANSPOSED: At[k][m], Dt[n][m] with 32 voxels (m) per row, so that -- exactly as in
-// the forward kernel -- each MFMA operand is a ds_read_b128 of 4 consecutive m with the fixed
-// k-permutation (lane half h supplies m = 8g+4h..+3 of every 8-voxel group): 16 LDS reads per 64
-// MFMAs instead of 64.  Rows are XOR-swizzled in 16-byte groups, phys = (m>>2) ^ f(row) with
-// f(row) = ((row>>1 ^ row>>4) & 1) | ((row>>1) & 6): both the ds_read_b128 lane groups
-// ({0-3,12-15,20-27}, ...) and the transposing ds_write_b32 (8 channel quads x 4 voxels per
-// half-wave) then touch 16 / 32 distinct bank slots -- conflict-free on both sides.
-__device__ __forceinline__ int lds_t_off(int row, int m) {
-  const int f = (((row >> 1) ^ (row >> 4)) & 1) | ((row >> 1) & 6);
-  return row * 32 + ((((m >> 2) ^ f) & 7) << 2) + (m & 3);
-}
-
-template <int WM, int WN, int TM, int TN, bool VEC, bool DYVEC, bool AFF = true, bool UP = true, bool THIN = false>
+template <int WM, int WN, int TM, int TN, bool VEC, bool DYVEC, bool AFF = true, bool UP = true, bool THIN = false,
+          int ABL = 0>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvGeom g, ConvSrc s0, ConvSrc s1,
                                                           const float* __restrict__ dy, int ldy,
-                                                          int n_load, float* __restrict__ ws, int ktiles,
+                                                          int n_load,
+                                                          float* __restrict__ ws, int ktiles,
                                                           int ntiles, int rows_per_split) {
   constexpr int KT = WM * TM * 32, NT = WN * TN * 32;
-  constexpr int AP = KT / 32, DP = NT / 32;          // 32-channel groups ("passes") per tile
   constexpr int A_FLOATS = 32 * KT, D_FLOATS = 32 * NT;
+  constexpr int AF4 = KT / 4, ATOT = 32 * AF4, APASS = ATOT / 256;   // 256 % AF4 == 0
+  constexpr int DF4 = NT / 4, DTOT = 32 * DF4, DPASS = DTOT / 256;
+  static_assert(ATOT % 256 == 0 && DTOT % 256 == 0, "tile loads must divide evenly over 256 threads");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                    // [2][KT][32]
-  float* Ds = smem + 2 * A_FLOATS;     // [2][NT][32]
+  float* As = smem;                    // [2][32][KT]
+  float* Ds = smem + 2 * A_FLOATS;     // [2][32][NT]
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 31, lh = lane >> 5;
-  // loader mapping: per pass a wave covers 8 voxel rows x 8 float4 columns (one 32-channel group)
-  const int rl = 8 * wave + (lane >> 3), cq = lane & 7;
   const int S = g.S, lg = g.lgS;
   const int M = g.B << (3 * lg);
   const int K = g.taps * g.Cin;
@@ -750,100 +740,97 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvGeom g, ConvSrc s0,
   const int m_begin = split * rows_per_split;
   const int m_end = min(M, m_begin + rows_per_split);
   const int nchunks = (m_end - m_begin + 31) >> 5;
-  const int k0 = kt_i * KT;
 
-  // VEC (Cin % 32 == 0): every 32-channel group of the K tile lies in ONE tap and ONE source, so
-  // its tap shift / source are block-uniform (SGPRs); K tiles may span taps and sources.
-  int p_sdelta[AP], p_xbad[AP], p_ybad[AP], p_zbad[AP], p_dz[AP], p_dy[AP], p_dx[AP], p_C[AP], p_up[AP], p_cl[AP];
-  bool p_valid[AP];
-  const float* p_ptr[AP];
-  float p_slope[AP];
-  v4f p_sc[AFF ? AP : 1], p_sh[AFF ? AP : 1];
+  // k tiles are runs of KT consecutive flattened k = tap*Cin + ci.  VEC (Cin % 32 == 0): a thread's
+  // float4 column sits inside one 32-channel group, hence one tap and one source -- all per-thread
+  // constants for the whole block, so tiles may span taps (thin Cin) and sources (concat layers).
+  const int k0 = kt_i * KT;
+  int tdz = 0, tdy = 0, tdx = 0, sdelta = 0, xbad = -1, ybad = -1, zbad = -1;
+  bool kvalid = false;
+  const float* sp = s0.p;
+  int sC = s0.C, su = 0, cl0 = 0;
+  float slope = 1.f;
+  v4f sc = v4f{1.f, 1.f, 1.f, 1.f}, sh = v4f{0.f, 0.f, 0.f, 0.f};
   if (VEC) {
-#pragma unroll
-    for (int p = 0; p < AP; ++p) {
-      // THIN: the float4 column of this thread has its own tap (these become per-thread VGPRs)
-      const int kf = k0 + 32 * p + (THIN ? cq * 4 : 0);
-      const int tap = kf / g.Cin, ci = kf - tap * g.Cin;
-      p_valid[p] = kf < K;
-      int dz = 0, dyy = 0, dx = 0;
-      if (g.taps == 27 && p_valid[p]) { dz = tap / 9 - 1; dyy = (tap / 3) % 3 - 1; dx = tap % 3 - 1; }
-      p_dz[p] = dz; p_dy[p] = dyy; p_dx[p] = dx;
-      p_sdelta[p] = (dz * S + dyy) * S + dx;
-      // a shifted coordinate leaves the grid iff it starts on the face the tap points away from
-      p_xbad[p] = dx < 0 ? 0 : (dx > 0 ? S - 1 : -1);
-      p_ybad[p] = dyy < 0 ? 0 : (dyy > 0 ? S - 1 : -1);
-      p_zbad[p] = dz < 0 ? 0 : (dz > 0 ? S - 1 : -1);
-      const bool first = ci < s0.C;
-      const ConvSrc sv = pick_src(s0, s1, first);
-      p_ptr[p] = sv.p; p_C[p] = sv.C; p_up[p] = sv.up;
-      p_cl[p] = (p_valid[p] ? (first ? ci : ci - s0.C) : 0) + (THIN ? 0 : cq * 4);
-      p_slope[p] = act_slope_of(sv.act);
-      if (AFF) {
-        p_sc[p] = *reinterpret_cast<const v4f*>(sv.scale + p_cl[p]);
-        p_sh[p] = *reinterpret_cast<const v4f*>(sv.shift + p_cl[p]);
-      }
+    const int kf = k0 + (t % AF4) * 4;
+    const int tap = kf / g.Cin, ci = kf - tap * g.Cin;
+    kvalid = kf < K;
+    if (g.taps == 27 && kvalid) { tdz = tap / 9 - 1; tdy = (tap / 3) % 3 - 1; tdx = tap % 3 - 1; }
+    sdelta = (tdz * S + tdy) * S + tdx;
+    // a shifted coordinate leaves the grid iff it starts on the face the tap points away from
+    xbad = tdx < 0 ? 0 : (tdx > 0 ? S - 1 : -1);
+    ybad = tdy < 0 ? 0 : (tdy > 0 ? S - 1 : -1);
+    zbad = tdz < 0 ? 0 : (tdz > 0 ? S - 1 : -1);
+    const bool first = ci < s0.C;
+    const ConvSrc sv = pick_src(s0, s1, first);
+    sp = sv.p; sC = sv.C; su = sv.up;
+    cl0 = kvalid ? (first ? ci : ci - s0.C) : 0;
+    slope = act_slope_of(sv.act);
+    if (AFF) {
+      sc = *reinterpret_cast<const v4f*>(sv.scale + cl0);
+      sh = *reinterpret_cast<const v4f*>(sv.shift + cl0);
     }
   }
-  // SCALAR (KT == 32): this thread's fixed flattened k
-  int s_ci = 0; bool s_kvalid = false; int sdz = 0, sdy = 0, sdx = 0;
+  // SCALAR: this thread's fixed k
+  int s_tap = 0, s_ci = 0; bool s_kvalid = false; int sdz = 0, sdy = 0, sdx = 0;
   if (!VEC) {
     const int kf = k0 + (t & 31);
-    const int s_tap = kf / g.Cin;
-    s_ci = kf - s_tap * g.Cin; s_kvalid = kf < K;
+    s_tap = kf / g.Cin; s_ci = kf - s_tap * g.Cin; s_kvalid = kf < K;
     if (g.taps == 27) { sdz = s_tap / 9 - 1; sdy = (s_tap / 3) % 3 - 1; sdx = s_tap % 3 - 1; }
   }
 
-  v4f ra[VEC ? AP : 1];
+  v4f ra[VEC ? APASS : 1];
   float ras[4];
-  v4f rd[DP];
+  v4f rd[DPASS];
 
   auto load_chunk = [&](int c) {
     const int mbase = m_begin + (c << 5);
-    const int m = mbase + rl;
-    const bool rowok = m < m_end;
     if (VEC) {
-      const int x = m & (S - 1), y = (m >> lg) & (S - 1), z = (m >> (2 * lg)) & (S - 1);
       const int Sh = S >> 1;
 #pragma unroll
-      for (int p = 0; p < AP; ++p) {
-        const bool inb = rowok && p_valid[p] && x != p_xbad[p] && y != p_ybad[p] && z != p_zbad[p];
-        int idx = m + p_sdelta[p];           // same-resolution voxel index of the tap-shifted row
+      for (int p = 0; p < APASS; ++p) {
+        const int m = mbase + (t + 256 * p) / AF4;
+        const int x = m & (S - 1), y = (m >> lg) & (S - 1), z = (m >> (2 * lg)) & (S - 1);
+        const bool inb = kvalid && m < m_end && x != xbad && y != ybad && z != zbad;
+        int idx = m + sdelta;            // same-resolution voxel index of the tap-shifted row
         if (UP) {
           const int b = m >> (3 * lg);
-          const int idx_up = ((b * Sh + ((z + p_dz[p]) >> 1)) * Sh + ((y + p_dy[p]) >> 1)) * Sh + ((x + p_dx[p]) >> 1);
-          idx = p_up[p] ? idx_up : idx;
+          const int idx_up = ((b * Sh + ((z + tdz) >> 1)) * Sh + ((y + tdy) >> 1)) * Sh + ((x + tdx) >> 1);
+          idx = su ? idx_up : idx;
         }
-        const unsigned off = inb ? (unsigned)idx * (unsigned)p_C[p] + p_cl[p] : (unsigned)p_cl[p];
-        v4f v = *reinterpret_cast<const v4f*>(p_ptr[p] + off);
-        if (AFF) v = affine_act4(v, p_sc[p], p_sh[p], p_slope[p]);
+        const unsigned off = inb ? (unsigned)idx * (unsigned)sC + cl0 : (unsigned)cl0;
+        v4f v = *reinterpret_cast<const v4f*>(sp + off);
+        if (AFF) v = affine_act4(v, sc, sh, slope);
         ra[p] = inb ? v : v4f{0.f, 0.f, 0.f, 0.f};
       }
     } else {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int mm = mbase + (t >> 5) + 8 * q;
+      for (int p = 0; p < 4; ++p) {
+        const int m = mbase + (t >> 5) + 8 * p;
         float v = 0.f;
-        if (s_kvalid && mm < m_end) {
-          const RowPos r = decode_row(mm, S, lg);
+        if (s_kvalid && m < m_end) {
+          const RowPos r = decode_row(m, S, lg);
           const int zz = r.z + sdz, yy = r.y + sdy, xx = r.x + sdx;
           if ((unsigned)zz < (unsigned)S && (unsigned)yy < (unsigned)S && (unsigned)xx < (unsigned)S)
             v = gather_scalar(s0, s1, s_ci, r.b, zz, yy, xx, S);
         }
-        ras[q] = v;
+        ras[p] = v;
       }
     }
-    const float* qrow = dy + (size_t)min(m, M - 1) * ldy;
 #pragma unroll
-    for (int p = 0; p < DP; ++p) {
-      const int n = n0 + 32 * p + cq * 4;
+    for (int p = 0; p < DPASS; ++p) {
+      const int idx = t + 256 * p;
+      const int m = mbase + idx / DF4;
+      const int n = n0 + (idx % DF4) * 4;
+      const float* q = dy + (size_t)min(m, M - 1) * ldy;
       v4f v;
       if (DYVEC) {
-        v = *reinterpret_cast<const v4f*>(qrow + max(min(n, n_load - 4), 0));
-        if (!(rowok && n < n_load)) v = v4f{0.f, 0.f, 0.f, 0.f};
+        v = *reinterpret_cast<const v4f*>(q + min(n, n_load - 4));
+        if (!(m < m_end && n < n_load)) v = v4f{0.f, 0.f, 0.f, 0.f};
       } else {
-        v.x = qrow[min(n + 0, n_load - 1)]; v.y = qrow[min(n + 1, n_load - 1)];
-        v.z = qrow[min(n + 2, n_load - 1)]; v.w = qrow[min(n + 3, n_load - 1)];
+        v.x = q[min(n + 0, n_load - 1)]; v.y = q[min(n + 1, n_load - 1)];
+        v.z = q[min(n + 2, n_load - 1)]; v.w = q[min(n + 3, n_load - 1)];
+        const bool rowok = m < m_end;
         v.x = (rowok && n + 0 < n_load) ? v.x : 0.f; v.y = (rowok && n + 1 < n_load) ? v.y : 0.f;
         v.z = (rowok && n + 2 < n_load) ? v.z : 0.f; v.w = (rowok && n + 3 < n_load) ? v.w : 0.f;
       }
@@ -855,20 +842,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvGeom g, ConvSrc s0,
     float* D = Ds + buf * D_FLOATS;
     if (VEC) {
 #pragma unroll
-      for (int p = 0; p < AP; ++p) {
-        const int kk = 32 * p + cq * 4;
-        A[lds_t_off(kk + 0, rl)] = ra[p].x; A[lds_t_off(kk + 1, rl)] = ra[p].y;
-        A[lds_t_off(kk + 2, rl)] = ra[p].z; A[lds_t_off(kk + 3, rl)] = ra[p].w;
+      for (int p = 0; p < APASS; ++p) {
+        const int idx = t + 256 * p;
+        *reinterpret_cast<v4f*>(A + (idx / AF4) * KT + (idx % AF4) * 4) = ra[p];
       }
     } else {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) A[lds_t_off(t & 31, (t >> 5) + 8 * q)] = ras[q];
+      for (int p = 0; p < 4; ++p) A[((t >> 5) + 8 * p) * KT + (t & 31)] = ras[p];
     }
 #pragma unroll
-    for (int p = 0; p < DP; ++p) {
-      const int nn = 32 * p + cq * 4;
-      D[lds_t_off(nn + 0, rl)] = rd[p].x; D[lds_t_off(nn + 1, rl)] = rd[p].y;
-      D[lds_t_off(nn + 2, rl)] = rd[p].z; D[lds_t_off(nn + 3, rl)] = rd[p].w;
+    for (int p = 0; p < DPASS; ++p) {
+      const int idx = t + 256 * p;
+      *reinterpret_cast<v4f*>(D + (idx / DF4) * NT + (idx % DF4) * 4) = rd[p];
     }
   };
 
@@ -885,34 +870,50 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvGeom g, ConvSrc s0,
     store_chunk(0);
   }
   __syncthreads();
+  // LDS keeps the natural [voxel m][channel] images (b128 stores straight from the global loads).
+  // Operand fetch is COMPONENT-SPLIT: lane i reads TM (TN) consecutive channels k = TM*i + tm with one
+  // ds_read_b64/b32 and component tm feeds the accumulator that owns the row set {TM*i + tm}; the
+  // contraction index of one MFMA is the voxel pair (2s, 2s+1) selected by the lane half.  No
+  // transposition anywhere; 32 b64 reads per 64 MFMAs for the 128x128 tile.  T = 3 falls back to the
+  // block mapping k = 32*tm + i (three b32 reads) because ds_read_b96 needs 16-byte alignment.
+  constexpr bool SPLIT_M = (TM != 3), SPLIT_N = (TN != 3);
   auto compute = [&](int buf) {
-    const float* A = As + buf * A_FLOATS;
-    const float* D = Ds + buf * D_FLOATS;
+    const float* A = As + buf * A_FLOATS + lh * KT + wm * TM * 32 + (SPLIT_M ? TM * li : li);
+    const float* D = Ds + buf * D_FLOATS + lh * NT + wn * TN * 32 + (SPLIT_N ? TN * li : li);
 #pragma unroll
-    for (int g8 = 0; g8 < 4; ++g8) {
-      v4f a[TM], b[TN];
+    for (int s = 0; s < 16; ++s) {
+      float a[TM], b[TN];
+      if (SPLIT_M && TM == 2) {
+        const float2 q = *reinterpret_cast<const float2*>(A + s * 2 * KT);
+        a[0] = q.x; a[1 % TM] = q.y;
+      } else if (SPLIT_M && TM == 4) {
+        const float4 q = *reinterpret_cast<const float4*>(A + s * 2 * KT);
+        a[0] = q.x; a[1 % TM] = q.y; a[2 % TM] = q.z; a[3 % TM] = q.w;
+      } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = A[s * 2 * KT + i * 32];
+      }
+      if (SPLIT_N && TN == 2) {
+        const float2 q = *reinterpret_cast<const float2*>(D + s * 2 * NT);
+        b[0] = q.x; b[1 % TN] = q.y;
+      } else if (SPLIT_N && TN == 4) {
+        const float4 q = *reinterpret_cast<const float4*>(D + s * 2 * NT);
+        b[0] = q.x; b[1 % TN] = q.y; b[2 % TN] = q.z; b[3 % TN] = q.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = D[s * 2 * NT + j * 32];
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
-        a[i] = *reinterpret_cast<const v4f*>(A + lds_t_off(wm * TM * 32 + i * 32 + li, g8 * 8 + lh * 4));
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
-        b[j] = *reinterpret_cast<const v4f*>(D + lds_t_off(wn * TN * 32 + j * 32 + li, g8 * 8 + lh * 4));
-#pragma unroll
-      for (int tk = 0; tk < 4; ++tk)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            const float av = tk == 0 ? a[i].x : tk == 1 ? a[i].y : tk == 2 ? a[i].z : a[i].w;
-            const float bv = tk == 0 ? b[j].x : tk == 1 ? b[j].y : tk == 2 ? b[j].z : b[j].w;
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
-          }
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
   };
   for (int c = 0; c + 1 < nchunks; ++c) {
-    load_chunk(c + 1);
+    if (ABL == 0 || ABL == 2) load_chunk(ABL == 2 ? 1 : c + 1);   // ABL 2: same rows every chunk (L1/L2-hot)
     compute(c & 1);
-    store_chunk((c + 1) & 1);
+    if (ABL == 0 || ABL == 2) store_chunk((c + 1) & 1);
     __syncthreads();
   }
   if (nchunks > 0) compute((nchunks - 1) & 1);
@@ -921,12 +922,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvGeom g, ConvSrc s0,
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wn * TN * 32 + j * 32 + li;
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;     // MFMA output row held in register r
+      const int k = k0 + wm * TM * 32 + (SPLIT_M ? TM * row + i : 32 * i + row);
+      if (k >= K) continue;
+      if (SPLIT_N && TN == 2) {
+        const int n = n0 + wn * TN * 32 + 2 * li;
+        float* q = wsp + (size_t)k * g.Cout + n;
+        if (n + 1 < g.Cout && (g.Cout & 1) == 0) *reinterpret_cast<float2*>(q) = make_float2(acc[i][0][r], acc[i][1 % TN][r]);
+        else {
+          if (n < g.Cout) q[0] = acc[i][0][r];
+          if (n + 1 < g.Cout) q[1] = acc[i][1 % TN][r];
+        }
+      } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int k = k0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (k < K && n < g.Cout) wsp[(size_t)k * g.Cout + n] = acc[i][j][r];
+        for (int j = 0; j < TN; ++j) {
+          const int n = n0 + wn * TN * 32 + (SPLIT_N ? TN * li + j : 32 * j + li);
+          if (n < g.Cout) wsp[(size_t)k * g.Cout + n] = acc[i][j][r];
+        }
       }
     }
 }
@@ -998,12 +1011,13 @@ size_t conv_wgrad_workspace_floats(const ConvGeom& g, const ConvSrc* src, int ns
   return (size_t)p.ksplit * g.taps * g.Cin * g.Cout;
 }
 
-template <int WM, int WN, int TM, int TN, bool VEC, bool DYVEC, bool AFF = true, bool UP = true, bool THIN = false>
+template <int WM, int WN, int TM, int TN, bool VEC, bool DYVEC, bool AFF = true, bool UP = true, bool THIN = false,
+          int ABL = 0>
 static int launch_wgrad_cfg(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, const ConvSrc& s1,
                             const float* dy, int ldy, int n_load, float* ws, const WgradPlan& p) {
   constexpr int KT = WM * TM * 32, NT = WN * TN * 32;
   const size_t lds = (size_t)2 * 32 * (KT + NT) * sizeof(float);
-  auto kern = conv_wgrad_kernel<WM, WN, TM, TN, VEC, DYVEC, AFF, UP, THIN>;
+  auto kern = conv_wgrad_kernel<WM, WN, TM, TN, VEC, DYVEC, AFF, UP, THIN, ABL>;
   static bool attr_set = false;
   if (!attr_set) {
     ICS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1014,6 +1028,19 @@ static int launch_wgrad_cfg(hipStream_t st, const ConvGeom& g, const ConvSrc& s0
                      ldy, n_load, ws, p.ktiles, p.ntiles, p.rows_per_split);
   ICS_HIP(hipGetLastError());
   return 0;
+}
+
+// benchmarking-only: 128x128 vector wgrad with the staging removed (1) or made cache-hot (2)
+int launch_conv_wgrad_ablate(hipStream_t st, const ConvGeom& g, const ConvSrc* src, const float* dy, int ldy,
+                             float* workspace, int ablate) {
+  ConvSrc s0 = src[0], s1 = src[0];
+  s1.C = 0;
+  ICS_TRY(fix_src(s0));
+  ICS_TRY(fix_src(s1));
+  WgradPlan p = plan_wgrad(g, s0, 1, s1);
+  ICS_CHECK(p.vec && p.kt == 128 && p.nt == 128, "ablation bench needs the vector 128x128 configuration");
+  if (ablate == 1) return launch_wgrad_cfg<2, 2, 2, 2, true, true, false, false, false, 1>(st, g, s0, s1, dy, ldy, g.Cout, workspace, p);
+  return launch_wgrad_cfg<2, 2, 2, 2, true, true, false, false, false, 2>(st, g, s0, s1, dy, ldy, g.Cout, workspace, p);
 }
 
 int launch_conv_wgrad(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int nsrc,

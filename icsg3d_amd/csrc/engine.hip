@@ -838,8 +838,6 @@ static int vae_step(Net& n, int B, bool training, float* metrics) {
   Net& u = *n.pm;
   hipStream_t saved = u.st;
   u.st = n.st;
-  Profiler* uprof_on = nullptr; (void)uprof_on;
-  const bool uprof = u.prof.on; u.prof.on = false;
   int rc = 0;
   do {
     VaeRefs r = vae_refs(n);
@@ -917,7 +915,6 @@ static int vae_step(Net& n, int B, bool training, float* metrics) {
     }
   } while (0);
   u.st = saved;
-  u.prof.on = uprof;
   return rc;
 }
 
@@ -1378,6 +1375,8 @@ int ics_op_conv3d_bench(int B, int S, int Cin, int Cout, int taps, int mode, int
       else ICS_TRY(launch_conv_fwd(n.st, g, &sx, 1, dwp, nullptr, dyv, Cout, ACT_RELU, nullptr, nullptr));
     } else if (mode == 1) {
       ICS_TRY(launch_conv_fwd(n.st, gb, &sd, 1, dwf, nullptr, dgx, Cin, ACT_NONE, nullptr, nullptr));
+    } else if (ablate) {
+      ICS_TRY(launch_conv_wgrad_ablate(n.st, g, &sx, dyv, Cout, ws, ablate));
     } else {
       ICS_TRY(launch_conv_wgrad(n.st, g, &sx, 1, dyv, Cout, dgw, Cout, ws, wsn));
     }

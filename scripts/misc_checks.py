@@ -29,9 +29,13 @@ if "vae" in what:
     for _ in range(5): ve.train_step_resident(False)
     ve.sync(); dt = (time.perf_counter() - t0) / 5
     print("DFC-VAE step B=32 d=32: %.2f ms  %.1f grids/s" % (dt * 1e3, B / dt))
-    ve.profile_enable(True)
+    ve.profile_enable(True); ue.profile_enable(True)
     for _ in range(2): ve.train_step_resident(False)
     ve.sync()
+    urows = sorted(ue.profile_rows(), key=lambda r: -r["ms"])
+    print("profiled perceptual U-Net ms/step %.2f" % (sum(r["ms"] for r in urows) / 2))
+    for r in urows[:14]:
+        print("  PM %-44s n=%3d %8.3f ms/step" % (r["label"], r["launches"], r["ms"] / 2))
     rows = sorted(ve.profile_rows(), key=lambda r: -r["ms"])
     print("profiled VAE-engine ms/step %.2f (perceptual U-Net launches are not in these rows)" % (sum(r["ms"] for r in rows) / 2))
     for r in rows[:12]:
