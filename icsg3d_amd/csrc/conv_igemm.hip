@@ -977,12 +977,24 @@ static WgradPlan plan_wgrad(const ConvGeom& g, const ConvSrc& s0, int nsrc, cons
   else if (p.kt == 64) p.nt = (n32 <= 64) ? 64 : 128;
   else p.nt = 128;
   p.ntiles = (g.Npad + p.nt - 1) / p.nt;
+  // Split-K count against the machine's block capacity: 256 CUs x 2 resident 256-thread blocks.
+  // total = base*ksplit should fill whole "rounds" of 512 blocks (1539 blocks = 3.006 rounds leave a
+  // nearly empty 4th round: measured -20 %); pick the round count 1..6 with the best fill whose
+  // splits still have >= 512 voxel rows each.
   const long base = (long)p.ktiles * p.ntiles;
-  long want = (1536 + base - 1) / base;
-  long maxsplit = M / 256 > 0 ? M / 256 : 1;
-  if (want > maxsplit) want = maxsplit;
-  if (want < 1) want = 1;
-  if (want > 512) want = 512;
+  const long slots = 512;
+  long want = 1;
+  double best = -1.0;
+  for (long r = 1; r <= 6; ++r) {
+    long ks = (r * slots) / base;
+    if (ks < 1) ks = 1;
+    if (ks > 512) ks = 512;
+    const long rows_each = (M + ks - 1) / ks;
+    if (ks > 1 && rows_each < 512) break;
+    const long total = base * ks;
+    const double fill = (double)total / (double)(((total + slots - 1) / slots) * slots);
+    if (fill > best + 0.02 || (fill > best - 0.005 && ks > want)) { best = fill > best ? fill : best; want = ks; }
+  }
   int rows = (int)(((M + want - 1) / want + 31) / 32 * 32);
   p.rows_per_split = rows;
   p.ksplit = (M + rows - 1) / rows;
