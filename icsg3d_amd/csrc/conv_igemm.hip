@@ -11,6 +11,7 @@
 // k group (lane half h supplies k = 4h..4h+3), which only reorders the fp32 summation.
 #include "common.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <vector>
 
@@ -944,6 +945,164 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvGeom g, ConvSrc s0,
     }
 }
 
+// =====================================================================================
+// Backward-weight with dx-reuse ("wgrad3"): one block owns the three dx taps of a (dz,dy) pair for a
+// group of 64 input channels and 128 output channels: dW[(dz,dy,dx)][c0..c0+63][n0..n0+127].  The A
+// image holds the dx = 0 voxel lines (natural [m][64] layout) with a zero row after every x-line, so
+// tap dx reads the SAME image at row offset dx; per 32-voxel chunk we stage 8 KB of A + 16 KB of dy
+// for 96 MFMAs per wave (the plain kernel stages 32 KB for 64).  Waves split N (32 columns each);
+// lane i fetches channels 2i,2i+1 with one ds_read_b64 per tap (component-split), 6 accumulators.
+// Requires 27 taps, S <= 32 (chunks are whole x-lines), Cin % 64 == 0 with sources 64-aligned.
+// =====================================================================================
+template <bool AFF, bool UP>
+__global__ __launch_bounds__(256) void conv_wgrad3_kernel(ConvGeom g, ConvSrc s0, ConvSrc s1,
+                                                           const float* __restrict__ dy, int ldy, int n_load,
+                                                           float* __restrict__ ws, int cgroups, int ntiles,
+                                                           int rows_per_split) {
+  constexpr int CK = 64, NT = 128;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int S = g.S, lg = g.lgS;
+  const int arows = 32 + (32 >> lg) + 1;
+  const int A_FLOATS = arows * CK;
+  constexpr int D_FLOATS = 32 * NT;
+  float* As = smem;                    // [2][arows][64]
+  float* Ds = smem + 2 * A_FLOATS;     // [2][32][128]
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int M = g.B << (3 * lg);
+  const int K = g.taps * g.Cin;
+
+  int bid = blockIdx.x;
+  const int nt_i = bid % ntiles; bid /= ntiles;
+  const int cg = bid % cgroups; bid /= cgroups;
+  const int gzy = bid % 9; bid /= 9;
+  const int split = bid;
+  const int n0 = nt_i * NT;
+  const int c0 = cg * CK;
+  const int m_begin = split * rows_per_split;
+  const int m_end = min(M, m_begin + rows_per_split);
+  const int nchunks = (m_end - m_begin + 31) >> 5;
+
+  // block-uniform tap pair and source
+  const int dz = gzy / 3 - 1, dyy = gzy % 3 - 1;
+  const int sdelta = (dz * S + dyy) * S;
+  const int ybad = dyy < 0 ? 0 : (dyy > 0 ? S - 1 : -1);
+  const int zbad = dz < 0 ? 0 : (dz > 0 ? S - 1 : -1);
+  const bool first = c0 < s0.C;
+  const float* sp = first ? s0.p : s1.p;
+  const int sC = first ? s0.C : s1.C, su = first ? s0.up : s1.up;
+  const float slope = act_slope_of(first ? s0.act : s1.act);
+  const int ac4 = t & 15;                                  // this thread's float4 column of the A tile
+  const int cl = (first ? c0 : c0 - s0.C) + ac4 * 4;
+  v4f sc = v4f{1.f, 1.f, 1.f, 1.f}, sh = v4f{0.f, 0.f, 0.f, 0.f};
+  if (AFF) {
+    sc = *reinterpret_cast<const v4f*>((first ? s0.scale : s1.scale) + cl);
+    sh = *reinterpret_cast<const v4f*>((first ? s0.shift : s1.shift) + cl);
+  }
+
+  v4f ra[2], rd[4];
+  auto load_chunk = [&](int c) {
+    const int mbase = m_begin + (c << 5);
+    const int Sh = S >> 1;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int m = mbase + (t >> 4) + 16 * p;
+      const int y = (m >> lg) & (S - 1), z = (m >> (2 * lg)) & (S - 1);
+      const bool inb = m < m_end && y != ybad && z != zbad;
+      int idx = m + sdelta;
+      if (UP) {
+        const int x = m & (S - 1), b = m >> (3 * lg);
+        const int idx_up = ((b * Sh + ((z + dz) >> 1)) * Sh + ((y + dyy) >> 1)) * Sh + (x >> 1);
+        idx = su ? idx_up : idx;
+      }
+      const unsigned off = inb ? (unsigned)idx * (unsigned)sC + cl : (unsigned)cl;
+      v4f v = *reinterpret_cast<const v4f*>(sp + off);
+      if (AFF) v = affine_act4(v, sc, sh, slope);
+      ra[p] = inb ? v : v4f{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int m = mbase + (t >> 5) + 8 * p;
+      const int n = n0 + (t & 31) * 4;
+      const float* q = dy + (size_t)min(m, M - 1) * ldy;
+      v4f v = *reinterpret_cast<const v4f*>(q + max(min(n, n_load - 4), 0));
+      if (!(m < m_end && n < n_load)) v = v4f{0.f, 0.f, 0.f, 0.f};
+      rd[p] = v;
+    }
+  };
+  auto store_chunk = [&](int buf) {
+    float* A = As + buf * A_FLOATS;
+    float* D = Ds + buf * D_FLOATS;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int r = (t >> 4) + 16 * p;
+      *reinterpret_cast<v4f*>(A + (r + (r >> lg) + 1) * CK + ac4 * 4) = ra[p];
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) *reinterpret_cast<v4f*>(D + ((t >> 5) + 8 * p) * NT + (t & 31) * 4) = rd[p];
+  };
+
+  f32x16 acc[3][2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // zero separator rows (row 0 and the row after every x-line) of both A buffers
+  {
+    const int lines = 32 >> lg;
+    for (int i = t; i < 2 * (lines + 1) * CK; i += 256) {
+      const int b = i / ((lines + 1) * CK), rem = i - b * (lines + 1) * CK;
+      As[b * A_FLOATS + (rem / CK) * (S + 1) * CK + rem % CK] = 0.f;
+    }
+  }
+  if (nchunks > 0) {
+    load_chunk(0);
+    store_chunk(0);
+  }
+  __syncthreads();
+  auto compute = [&](int buf) {
+    const float* A = As + buf * A_FLOATS + 2 * li;
+    const float* D = Ds + buf * D_FLOATS + 32 * wave + li;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int prow = 2 * s + ((2 * s) >> lg) + 1 + lh;     // padded A row of voxel 2s+lh (dx = 0)
+      const float b = D[(2 * s + lh) * NT];
+      float2 a[3];
+#pragma unroll
+      for (int dxi = 0; dxi < 3; ++dxi) a[dxi] = *reinterpret_cast<const float2*>(A + (prow + dxi - 1) * CK);
+#pragma unroll
+      for (int dxi = 0; dxi < 3; ++dxi) {
+        acc[dxi][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[dxi].x, b, acc[dxi][0], 0, 0, 0);
+        acc[dxi][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[dxi].y, b, acc[dxi][1], 0, 0, 0);
+      }
+    }
+  };
+  for (int c = 0; c + 1 < nchunks; ++c) {
+    load_chunk(c + 1);
+    compute(c & 1);
+    store_chunk((c + 1) & 1);
+    __syncthreads();
+  }
+  if (nchunks > 0) compute((nchunks - 1) & 1);
+
+  float* wsp = ws + (size_t)split * K * g.Cout;
+  const int n = n0 + 32 * wave + li;
+#pragma unroll
+  for (int dxi = 0; dxi < 3; ++dxi)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int k = (gzy * 3 + dxi) * g.Cin + c0 + 2 * row + j;
+        if (n < g.Cout) wsp[(size_t)k * g.Cout + n] = acc[dxi][j][r];
+      }
+}
+
 __global__ void reduce_splits_kernel(const float* __restrict__ ws, int nsplit, size_t n_elems,
                                      int N, float* __restrict__ dw, int ldw) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1001,8 +1160,48 @@ static WgradPlan plan_wgrad(const ConvGeom& g, const ConvSrc& s0, int nsrc, cons
   return p;
 }
 
+// split-K count that fills whole rounds of the 512 resident blocks (see plan_wgrad)
+static int pick_ksplit(long base, long M) {
+  const long slots = 512;
+  long want = 1;
+  double best = -1.0;
+  for (long r = 1; r <= 6; ++r) {
+    long ks = (r * slots) / base;
+    if (ks < 1) ks = 1;
+    if (ks > 512) ks = 512;
+    const long rows_each = (M + ks - 1) / ks;
+    if (ks > 1 && rows_each < 512) break;
+    const long total = base * ks;
+    const double fill = (double)total / (double)(((total + slots - 1) / slots) * slots);
+    if (fill > best + 0.02 || (fill > best - 0.005 && ks > want)) { best = fill > best ? fill : best; want = ks; }
+  }
+  return (int)want;
+}
+
+// can the dx-reuse kernel run this geometry?  (27 taps, whole x-lines per 32-voxel chunk, 64-aligned
+// channel groups inside one source, full 128-wide vectorisable dy rows)
+static bool wgrad3_ok(const ConvGeom& g, const ConvSrc& s0, int nsrc, const ConvSrc& s1) {
+  static const bool off = getenv("ICSG3D_NO_WGRAD3") != nullptr;
+  if (off || g.taps != 27 || g.S > 32 || g.S < 2 || g.Cin % 64 != 0 || g.Cout % 128 != 0) return false;
+  if (s0.bcast || (nsrc > 1 && s1.bcast)) return false;
+  if (nsrc > 1 && (s0.C % 64 != 0)) return false;
+  return true;
+}
+struct Wgrad3Plan { int cgroups, ntiles, ksplit, rows_per_split; };
+static Wgrad3Plan plan_wgrad3(const ConvGeom& g) {
+  Wgrad3Plan p;
+  const long M = (long)g.B << (3 * g.lgS);
+  p.cgroups = g.Cin / 64;
+  p.ntiles = g.Cout / 128;
+  const int want = pick_ksplit(9L * p.cgroups * p.ntiles, M);
+  p.rows_per_split = (int)(((M + want - 1) / want + 31) / 32 * 32);
+  p.ksplit = (int)((M + p.rows_per_split - 1) / p.rows_per_split);
+  return p;
+}
+
 const char* conv_wgrad_kernel_id(const ConvGeom& g, const ConvSrc* src, int nsrc) {
   ConvSrc s0 = src[0], s1 = src[nsrc > 1 ? 1 : 0];
+  if (wgrad3_ok(g, s0, nsrc, s1)) return "conv_wgrad3_kernel";
   const WgradPlan p = plan_wgrad(g, s0, nsrc, s1);
   if (p.kt == 128) {
     if (p.nt == 128) return p.vec ? "conv_wgrad_kernel<2,2,2,2,vec>" : "conv_wgrad_kernel<2,2,2,2,scalar>";
@@ -1020,7 +1219,9 @@ const char* conv_wgrad_kernel_id(const ConvGeom& g, const ConvSrc* src, int nsrc
 size_t conv_wgrad_workspace_floats(const ConvGeom& g, const ConvSrc* src, int nsrc) {
   ConvSrc s0 = src[0], s1 = src[nsrc > 1 ? 1 : 0];
   WgradPlan p = plan_wgrad(g, s0, nsrc, s1);
-  return (size_t)p.ksplit * g.taps * g.Cin * g.Cout;
+  int ks = p.ksplit;
+  if (wgrad3_ok(g, s0, nsrc, s1)) ks = std::max(ks, plan_wgrad3(g).ksplit);
+  return (size_t)ks * g.taps * g.Cin * g.Cout;
 }
 
 template <int WM, int WN, int TM, int TN, bool VEC, bool DYVEC, bool AFF = true, bool UP = true, bool THIN = false,
@@ -1073,9 +1274,27 @@ int launch_conv_wgrad(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int
     p.nt = (p.kt == 128) ? 32 : (p.kt == 64) ? 64 : 128;
     p.ntiles = (g.Npad + p.nt - 1) / p.nt;
   }
-  ICS_CHECK((size_t)p.ksplit * n_elems <= workspace_floats, "wgrad workspace too small");
   const bool aff = src[0].scale != nullptr || (nsrc > 1 && src[1].scale != nullptr);
   const bool up = src[0].up || (nsrc > 1 && src[1].up);
+  if (dy_vec && wgrad3_ok(g, s0, nsrc, s1)) {
+    const Wgrad3Plan q = plan_wgrad3(g);
+    ICS_CHECK((size_t)q.ksplit * n_elems <= workspace_floats, "wgrad workspace too small");
+    const int arows = 32 + (32 >> g.lgS) + 1;
+    const size_t lds = (size_t)2 * (arows * 64 + 32 * 128) * sizeof(float);
+    const dim3 grid(9 * q.cgroups * q.ntiles * q.ksplit);
+    if (up) hipLaunchKernelGGL((conv_wgrad3_kernel<true, true>), grid, dim3(256), lds, st, g, s0, s1, dy, ldy, n_load,
+                               workspace, q.cgroups, q.ntiles, q.rows_per_split);
+    else if (aff) hipLaunchKernelGGL((conv_wgrad3_kernel<true, false>), grid, dim3(256), lds, st, g, s0, s1, dy, ldy,
+                                     n_load, workspace, q.cgroups, q.ntiles, q.rows_per_split);
+    else hipLaunchKernelGGL((conv_wgrad3_kernel<false, false>), grid, dim3(256), lds, st, g, s0, s1, dy, ldy, n_load,
+                            workspace, q.cgroups, q.ntiles, q.rows_per_split);
+    ICS_HIP(hipGetLastError());
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((n_elems + 255) / 256)), dim3(256), 0, st, workspace,
+                       q.ksplit, n_elems, g.Cout, dw, ldw);
+    ICS_HIP(hipGetLastError());
+    return 0;
+  }
+  ICS_CHECK((size_t)p.ksplit * n_elems <= workspace_floats, "wgrad workspace too small");
 #define ICS_WG_ARGS st, g, s0, s1, dy, ldy, n_load, workspace, p
 #define ICS_WG(WM, WN, TM, TN, DV)                                                                 \
   do {                                                                                             \
