@@ -81,7 +81,9 @@ int launch_conv_fwd(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int n
 // partial[split][k][n] = sum_{m in split} A[m][k] * dy[m*ldy + n];  then reduced into dw[k*ldw+n].
 int launch_conv_wgrad(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int nsrc,
                       const float* dy, int ldy, float* dw, int ldw, float* workspace,
-                      size_t workspace_floats);
+                      size_t workspace_floats, int sub_rows = 0, int row_pitch = 0, int row_off = 0);
+int launch_pack_sub(hipStream_t st, const float* w, int taps, int Cin_total, int Cout, int c_off, int Csub,
+                    int flip, float* dst, int Kpad, int Npad);
 size_t conv_wgrad_workspace_floats(const ConvGeom& g, const ConvSrc* src, int nsrc);
 int conv_fwd_rows_per_block(const ConvGeom& g);
 int launch_conv_wgrad_ablate(hipStream_t st, const ConvGeom& g, const ConvSrc* src, const float* dy, int ldy,

@@ -32,7 +32,7 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nblk) {
 // Sources without a BatchNorm affine get pointers to constant ones/zeros so that the tile loaders
 // never branch on "has affine" (fma(v,1,0) == v exactly).
 static int identity_affine(const float** ones, const float** zeros) {
-  constexpr int kN = 4096;
+  constexpr int kN = 16384;
   static float* buf[64] = {nullptr};
   int dev = 0;
   ICS_HIP(hipGetDevice(&dev));
@@ -51,7 +51,7 @@ static int identity_affine(const float** ones, const float** zeros) {
 }
 static int fix_src(ConvSrc& s) {
   if (s.scale == nullptr) {
-    ICS_CHECK(s.C <= 4096, "source wider than the identity-affine buffer");
+    ICS_CHECK(s.C <= 16384, "source wider than the identity-affine buffer");
     ICS_TRY(identity_affine(&s.scale, &s.shift));
     s.act = ACT_NONE;
   }
@@ -1103,13 +1103,18 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(ConvGeom g, ConvSrc s0
       }
 }
 
+// sub_rows > 0: the GEMM covered a channel subset: its row k = tap*sub_rows + c lands on row
+// tap*row_pitch + row_off + c of the full [taps*Cin][N] weight-gradient tensor.
 __global__ void reduce_splits_kernel(const float* __restrict__ ws, int nsplit, size_t n_elems,
-                                     int N, float* __restrict__ dw, int ldw) {
+                                     int N, float* __restrict__ dw, int ldw, int sub_rows, int row_pitch,
+                                     int row_off) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_elems) return;
   float s = 0.f;
   for (int p = 0; p < nsplit; ++p) s += ws[(size_t)p * n_elems + i];   // fixed order: deterministic
-  const size_t k = i / N, n = i - k * N;
+  size_t k = i / N;
+  const size_t n = i - k * N;
+  if (sub_rows > 0) k = (k / sub_rows) * row_pitch + row_off + k % sub_rows;
   dw[k * ldw + n] = s;
 }
 
@@ -1258,7 +1263,7 @@ int launch_conv_wgrad_ablate(hipStream_t st, const ConvGeom& g, const ConvSrc* s
 
 int launch_conv_wgrad(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int nsrc,
                       const float* dy, int ldy, float* dw, int ldw, float* workspace,
-                      size_t workspace_floats) {
+                      size_t workspace_floats, int sub_rows, int row_pitch, int row_off) {
   ConvSrc s0 = src[0], s1 = src[nsrc > 1 ? 1 : 0];
   if (nsrc == 1) s1.C = 0;
   ICS_TRY(fix_src(s0));
@@ -1290,7 +1295,7 @@ int launch_conv_wgrad(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int
                             workspace, q.cgroups, q.ntiles, q.rows_per_split);
     ICS_HIP(hipGetLastError());
     hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((n_elems + 255) / 256)), dim3(256), 0, st, workspace,
-                       q.ksplit, n_elems, g.Cout, dw, ldw);
+                       q.ksplit, n_elems, g.Cout, dw, ldw, sub_rows, row_pitch, row_off);
     ICS_HIP(hipGetLastError());
     return 0;
   }
@@ -1323,7 +1328,7 @@ int launch_conv_wgrad(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int
 #undef ICS_WG
   const int thr = 256;
   hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((n_elems + thr - 1) / thr)), dim3(thr), 0,
-                     st, workspace, p.ksplit, n_elems, g.Cout, dw, ldw);
+                     st, workspace, p.ksplit, n_elems, g.Cout, dw, ldw, sub_rows, row_pitch, row_off);
   ICS_HIP(hipGetLastError());
   return 0;
 }
@@ -1394,6 +1399,32 @@ __global__ void pack_bwd_kernel(const float* __restrict__ w, int taps, int Cin, 
   if (tp < taps && co >= 0 && co < Cout && n < Cin)
     dst[i] = w[((size_t)(taps - 1 - tp) * Cin + n) * Cout + co];
   else if (zero_first) dst[i] = 0.f;
+}
+
+// Packed GEMM weights over a channel SUBSET [c_off, c_off+Csub) of w[taps][Cin_total][Cout]:
+//   k = tp*Cout + co, n = c:  dst[k][n] = w[flip ? taps-1-tp : tp][c_off + c][co]
+// flip = 1: backward-data weights of the subset; flip = 0: the "up-split" GEMM dxl = dyS x W.
+__global__ void pack_sub_kernel(const float* __restrict__ w, int taps, int Cin_total, int Cout, int c_off,
+                                int Csub, int flip, float* __restrict__ dst, int Kpad, int Npad) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)Kpad * Npad;
+  if (i >= total) return;
+  const int tq = i & 3;
+  const size_t rest = i >> 2;
+  const int n = rest % Npad;
+  const int k = (int)(rest / Npad) * 4 + tq;
+  const int tp = k / Cout, co = k - tp * Cout;
+  float v = 0.f;
+  if (tp < taps && n < Csub) v = w[((size_t)(flip ? taps - 1 - tp : tp) * Cin_total + c_off + n) * Cout + co];
+  dst[i] = v;
+}
+int launch_pack_sub(hipStream_t st, const float* w, int taps, int Cin_total, int Cout, int c_off, int Csub,
+                    int flip, float* dst, int Kpad, int Npad) {
+  const size_t total = (size_t)Kpad * Npad;
+  hipLaunchKernelGGL(pack_sub_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, taps, Cin_total,
+                     Cout, c_off, Csub, flip, dst, Kpad, Npad);
+  ICS_HIP(hipGetLastError());
+  return 0;
 }
 
 int launch_pack_fwd(hipStream_t st, const float* w, int K, int N, float* dst, int Kpad, int Npad,

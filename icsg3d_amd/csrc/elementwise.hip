@@ -538,6 +538,90 @@ int launch_head(hipStream_t st, float* z, int ldz, int ncls, const unsigned char
 }
 
 // ------------------------------------------------------------------------------------------
+// Up-split backward (see engine.hip "split_up"): for a conv whose input channels come from a
+// nearest-upsampled tensor xl, dW[tap] = xl^T * dyS[tap] and dxl = sum_tap dyS[tap] * W[tap]^T with
+//   dyS[vl][tap][n] = sum over the <= 8 output voxels v with (v + off(tap)) >> 1 == vl of dy[v][n].
+// Per axis, tap offset d and low-res coordinate a: v in {2a-d, 2a+1-d}; with slots s = 0..3 <->
+// coordinate 2a-1+s:  d=+1 -> slots {0,1}, d=0 -> {1,2}, d=-1 -> {2,3}.  Separable sums in registers.
+// ------------------------------------------------------------------------------------------
+__global__ void pool27_kernel(const float* __restrict__ dy, int B, int S, int N, size_t total,
+                              float* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int Sh = S >> 1;
+  const int n = (int)(i % N);
+  size_t vl = i / N;
+  const int c = vl % Sh; size_t r = vl / Sh;
+  const int bq = r % Sh; r /= Sh;
+  const int a = r % Sh;
+  const int b = (int)(r / Sh);
+  float o[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) o[k] = 0.f;
+#pragma unroll
+  for (int sz = 0; sz < 4; ++sz) {
+    const int z = 2 * a - 1 + sz;
+    if ((unsigned)z >= (unsigned)S) continue;
+    float lx[4][3];
+#pragma unroll
+    for (int sy = 0; sy < 4; ++sy) {
+      const int y = 2 * bq - 1 + sy;
+      float v[4];
+#pragma unroll
+      for (int sx = 0; sx < 4; ++sx) {
+        const int x = 2 * c - 1 + sx;
+        const bool ok = (unsigned)y < (unsigned)S && (unsigned)x < (unsigned)S;
+        v[sx] = ok ? dy[((((size_t)b * S + z) * S + y) * S + x) * N + n] : 0.f;
+      }
+      lx[sy][2] = v[0] + v[1];   // dx = +1  (tap index dx+1 = 2)
+      lx[sy][1] = v[1] + v[2];   // dx =  0
+      lx[sy][0] = v[2] + v[3];   // dx = -1
+    }
+    float P[3][3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      P[2][dx] = lx[0][dx] + lx[1][dx];   // dy = +1
+      P[1][dx] = lx[1][dx] + lx[2][dx];   // dy =  0
+      P[0][dx] = lx[2][dx] + lx[3][dx];   // dy = -1
+    }
+#pragma unroll
+    for (int dyi = 0; dyi < 3; ++dyi)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        if (sz <= 1) o[2 * 9 + dyi * 3 + dx] += P[dyi][dx];             // dz = +1: slots 0,1
+        if (sz >= 1 && sz <= 2) o[1 * 9 + dyi * 3 + dx] += P[dyi][dx];  // dz =  0: slots 1,2
+        if (sz >= 2) o[0 * 9 + dyi * 3 + dx] += P[dyi][dx];            // dz = -1: slots 2,3
+      }
+  }
+#pragma unroll
+  for (int k = 0; k < 27; ++k) out[(vl * 27 + k) * N + n] = o[k];
+}
+int launch_pool27(hipStream_t st, const float* dy, int B, int S, int N, float* out) {
+  const size_t total = (size_t)B * (S / 2) * (S / 2) * (S / 2) * N;
+  hipLaunchKernelGGL(pool27_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dy, B, S, N, total, out);
+  ICS_HIP(hipGetLastError());
+  return 0;
+}
+// dw[(tap*Cin + c_off + c)*N + n] = tmp[c*(27N) + tap*N + n]
+__global__ void permute_up_dw_kernel(const float* __restrict__ tmp, int Cu, int N, int Cin, int c_off,
+                                     size_t total, float* __restrict__ dw) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int n = (int)(i % N);
+  size_t r = i / N;
+  const int c = (int)(r % Cu);
+  const int tap = (int)(r / Cu);
+  dw[((size_t)tap * Cin + c_off + c) * N + n] = tmp[(size_t)c * 27 * N + (size_t)tap * N + n];
+}
+int launch_permute_up_dw(hipStream_t st, const float* tmp, int Cu, int N, int Cin, int c_off, float* dw) {
+  const size_t total = (size_t)27 * Cu * N;
+  hipLaunchKernelGGL(permute_up_dw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, tmp, Cu, N, Cin,
+                     c_off, total, dw);
+  ICS_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
 // Adam (keras 2.3.1): m,v update, p -= lr_t * m / (sqrt(v) + 1e-7)
 // ------------------------------------------------------------------------------------------
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,

@@ -99,6 +99,14 @@ struct ConvLayer {
   unsigned char* pool_idx = nullptr;
   ConvSrc src[2];
   int nsrc = 1;
+  // "up-split" backward for [skip | nearest-upsampled] concat inputs (c13/c15/c17): the up channels'
+  // gradients are GEMMs over the LOW-RES grid against dy pooled per tap (27 -> 27/8 of the FLOPs).
+  bool split_up = false;
+  int Cs = 0, Cu = 0;
+  float *wf_skip = nullptr, *w_up = nullptr;   // packed: dgrad of the skip channels; dxl = dyS x W_up
+  float *dyS = nullptr;                        // [M/8][27*Cout] tap-pooled dy
+  float *dA_skip = nullptr, *dxl = nullptr;    // [M][Cs] grad of the skip input; [M/8][Cu] grad of the low-res input
+  float *dw_up = nullptr;                      // [Cu][27*Cout] GEMM result before the permute into G
 };
 
 struct Net {
@@ -251,6 +259,36 @@ static ConvGeom geom_bwd(const ConvLayer& L, int B) {
   return ConvGeom{B, L.S, ilog2(L.S), L.Cout, L.CinG, L.taps, L.Kpad_b, L.Npad_b};
 }
 
+// up-split GEMM geometries (see ConvLayer::split_up)
+static ConvGeom geom_up_wgrad(const ConvLayer& L, int B) {   // dw_up[Cu][27N] = xl^T x dyS over the S/2 grid
+  return ConvGeom{B, L.S / 2, ilog2(L.S / 2), L.Cu, 27 * L.Cout, 1, round_up(L.Cu, 32), round_up(27 * L.Cout, 32)};
+}
+static ConvGeom geom_up_dgrad(const ConvLayer& L, int B) {   // dxl[M/8][Cu] = dyS x W_up
+  return ConvGeom{B, L.S / 2, ilog2(L.S / 2), 27 * L.Cout, L.Cu, 1, round_up(27 * L.Cout, 32), round_up(L.Cu, 32)};
+}
+static ConvGeom geom_skip_wgrad(const ConvLayer& L, int B) {
+  return ConvGeom{B, L.S, ilog2(L.S), L.Cs, L.Cout, L.taps, round_up(L.taps * L.Cs, 32), L.Npad};
+}
+static ConvGeom geom_skip_dgrad(const ConvLayer& L, int B) {
+  return ConvGeom{B, L.S, ilog2(L.S), L.Cout, L.Cs, L.taps, L.Kpad_b, round_up(L.Cs, 32)};
+}
+static ConvSrc src_lowres(const ConvLayer& L) { ConvSrc u = L.src[1]; u.up = 0; return u; }
+
+static int enable_split_up(Net& n, ConvLayer& L) {
+  if (getenv("ICSG3D_NO_UPSPLIT")) return 0;
+  if (L.nsrc != 2 || !L.src[1].up || L.taps != 27 || L.S < 2 || L.CinG != L.Cin) return 0;
+  L.split_up = true;
+  L.Cs = L.src[0].C; L.Cu = L.src[1].C;
+  const size_t M = n.rows(L, n.maxB);
+  ICS_TRY(n.alloc(&L.wf_skip, (size_t)L.Kpad_b * round_up(L.Cs, 32)));
+  ICS_TRY(n.alloc(&L.w_up, (size_t)round_up(27 * L.Cout, 32) * round_up(L.Cu, 32)));
+  ICS_TRY(n.alloc(&L.dyS, M / 8 * 27 * L.Cout));
+  ICS_TRY(n.alloc(&L.dA_skip, M * L.Cs));
+  ICS_TRY(n.alloc(&L.dxl, M / 8 * L.Cu));
+  ICS_TRY(n.alloc(&L.dw_up, (size_t)L.Cu * 27 * L.Cout));
+  return 0;
+}
+
 // workspace sizing over all layers (max batch)
 static int alloc_workspaces(Net& n, bool need_bwd) {
   size_t stat = 0, bwd = 0, wg = 0;
@@ -266,6 +304,11 @@ static int alloc_workspaces(Net& n, bool need_bwd) {
       // Cout may be a non power of two only for the head, which never goes through layer_bwd
       if ((L.Cout & (L.Cout - 1)) == 0) bwd = std::max(bwd, layer_bwd_workspace_floats(lb));
       wg = std::max(wg, conv_wgrad_workspace_floats(g, L.src, L.nsrc));
+      if (L.split_up) {
+        const ConvSrc lo = src_lowres(L);
+        wg = std::max(wg, conv_wgrad_workspace_floats(geom_up_wgrad(L, n.maxB), &lo, 1));
+        wg = std::max(wg, conv_wgrad_workspace_floats(geom_skip_wgrad(L, n.maxB), L.src, 1));
+      }
     }
   }
   n.ws_stat_n = stat; n.ws_bwd_n = std::max(bwd, (size_t)4096 * 128); n.ws_wgrad_n = wg;
@@ -316,6 +359,11 @@ static int pack_layer(Net& n, ConvLayer& L, bool need_bwd) {
                           L.CinG != L.Cin ? L.Cin : 0, L.CinG != L.Cin ? L.CinG : 0));
   if (need_bwd && L.wf)
     ICS_TRY(launch_pack_bwd(n.st, n.tp(L.t_w), L.taps, L.Cin, L.Cout, L.wf, L.Kpad_b, L.Npad_b, L.Cout, 0, 1));
+  if (need_bwd && L.split_up) {
+    ICS_TRY(launch_pack_sub(n.st, n.tp(L.t_w), L.taps, L.Cin, L.Cout, 0, L.Cs, 1, L.wf_skip, L.Kpad_b, round_up(L.Cs, 32)));
+    ICS_TRY(launch_pack_sub(n.st, n.tp(L.t_w), L.taps, L.Cin, L.Cout, L.Cs, L.Cu, 0, L.w_up, round_up(27 * L.Cout, 32),
+                            round_up(L.Cu, 32)));
+  }
   return 0;
 }
 
@@ -387,8 +435,54 @@ static GradSrc gs_pool(const float* p, int ld, const ConvLayer& producer) {
   return GradSrc{p, ld, 0, GS_POOL, producer.pooled, producer.pool_idx};
 }
 
+// Up-split backward of a [skip | upsampled] concat conv: with dyS = dy pooled per tap onto the low-res
+// grid (pool27), the up channels need only  dW_up = xl^T dyS  and  dxl = dyS W_up  on M/8 rows; the skip
+// channels run the ordinary kernels on a Cs-channel problem.  Exact (a reassociation of the same sums).
+static int conv_grads_split_up(Net& n, ConvLayer& L, int B) {
+  const size_t M = n.rows(L, B);
+  const double fl_skip = 2.0 * M * 27 * L.Cs * L.Cout, fl_up = 2.0 * (M / 8) * 27 * L.Cu * L.Cout;
+  n.prof.begin(n.st, "pool27:" + L.name, 0, 4.0 * M * L.Cout * (1 + 27.0 / 8));
+  ICS_TRY(launch_pool27(n.st, L.dy, B, L.S, L.Cout, L.dyS));
+  n.prof.end(n.st);
+  {
+    const ConvGeom g = geom_skip_wgrad(L, B);
+    n.prof.begin(n.st, "conv_wgrad:" + L.name + ".skip|" + (n.prof.on ? conv_wgrad_kernel_id(g, L.src, 1) : ""), fl_skip,
+                 4.0 * (M * L.Cs + M * L.Cout + 27.0 * L.Cs * L.Cout));
+    ICS_TRY(launch_conv_wgrad(n.st, g, L.src, 1, L.dy, L.Cout, n.tg(L.t_w), L.Cout, n.ws_wgrad, n.ws_wgrad_n, L.Cs,
+                              L.Cin, 0));
+    n.prof.end(n.st);
+  }
+  {
+    const ConvGeom g = geom_up_wgrad(L, B);
+    const ConvSrc lo = src_lowres(L);
+    n.prof.begin(n.st, "conv_wgrad:" + L.name + ".up|" + (n.prof.on ? conv_wgrad_kernel_id(g, &lo, 1) : ""), fl_up,
+                 4.0 * (M / 8 * L.Cu + M / 8 * 27.0 * L.Cout + 27.0 * L.Cu * L.Cout));
+    ICS_TRY(launch_conv_wgrad(n.st, g, &lo, 1, L.dyS, 27 * L.Cout, L.dw_up, 27 * L.Cout, n.ws_wgrad, n.ws_wgrad_n));
+    ICS_TRY(launch_permute_up_dw(n.st, L.dw_up, L.Cu, L.Cout, L.Cin, L.Cs, n.tg(L.t_w)));
+    n.prof.end(n.st);
+  }
+  {
+    const ConvGeom g = geom_skip_dgrad(L, B);
+    ConvSrc sdy = src_plain(L.dy, L.Cout);
+    n.prof.begin(n.st, "conv_dgrad:" + L.name + ".skip|" + (n.prof.on ? conv_fwd_kernel_id(g, &sdy, 1) : ""), fl_skip,
+                 4.0 * (M * L.Cs + M * L.Cout + 27.0 * L.Cs * L.Cout));
+    ICS_TRY(launch_conv_fwd(n.st, g, &sdy, 1, L.wf_skip, nullptr, L.dA_skip, L.Cs, ACT_NONE, nullptr, nullptr));
+    n.prof.end(n.st);
+  }
+  {
+    const ConvGeom g = geom_up_dgrad(L, B);
+    ConvSrc sd = src_plain(L.dyS, 27 * L.Cout);
+    n.prof.begin(n.st, "conv_dgrad:" + L.name + ".up|" + (n.prof.on ? conv_fwd_kernel_id(g, &sd, 1) : ""), fl_up,
+                 4.0 * (M / 8 * L.Cu + M / 8 * 27.0 * L.Cout + 27.0 * L.Cu * L.Cout));
+    ICS_TRY(launch_conv_fwd(n.st, g, &sd, 1, L.w_up, nullptr, L.dxl, L.Cu, ACT_NONE, nullptr, nullptr));
+    n.prof.end(n.st);
+  }
+  return 0;
+}
+
 // weight / input gradients given L.dy
 static int conv_grads_from_dy(Net& n, ConvLayer& L, int B, bool need_dA, bool param_grads) {
+  if (L.split_up && need_dA && param_grads) return conv_grads_split_up(n, L, B);
   const ConvGeom g = geom_fwd(L, B);
   const size_t M = n.rows(L, B);
   if (param_grads) {
@@ -512,6 +606,7 @@ static int unet_build(Net& n, const ics_unet_config& cfg) {
   r.c18->src[0] = src_layer(*r.c17, 0);
   n.head->src[0] = src_layer(*r.c18, 0);
   use_padded_input(*r.c1);
+  ICS_TRY(enable_split_up(n, *r.c13)); ICS_TRY(enable_split_up(n, *r.c15)); ICS_TRY(enable_split_up(n, *r.c17));
   ICS_TRY(alloc_workspaces(n, true));
   ICS_TRY(init_bn_defaults(n));
   return 0;
@@ -631,19 +726,22 @@ static int unet_backward(Net& n, int B) {
   auto bw = [&](ConvLayer* L, GradSrc g0, GradSrc g1, bool need_dA) {
     return conv_backward(n, *L, B, g0, g1, nullptr, need_dA, true);
   };
+  // gradient of a concat consumer w.r.t. its skip / upsampled producer
+  auto g_skip = [&](ConvLayer* c) { return c->split_up ? gs_direct(c->dA_skip, c->Cs, 0) : gs_direct(c->dA, c->Cin, 0); };
+  auto g_up = [&](ConvLayer* c) { return c->split_up ? gs_direct(c->dxl, c->Cu, 0) : gs_up(c->dA, c->Cin, c->src[0].C); };
   ICS_TRY(bw(r.c18, gs_direct(H.dA, 128, 0), gs_none(), true));
   ICS_TRY(bw(r.c17, gs_direct(r.c18->dA, 128, 0), gs_none(), true));
-  ICS_TRY(bw(r.c16, gs_up(r.c17->dA, 192, 64), gs_none(), true));
+  ICS_TRY(bw(r.c16, g_up(r.c17), gs_none(), true));
   ICS_TRY(bw(r.c15, gs_direct(r.c16->dA, 256, 0), gs_none(), true));
-  ICS_TRY(bw(r.c14, gs_up(r.c15->dA, 384, 128), gs_none(), true));
+  ICS_TRY(bw(r.c14, g_up(r.c15), gs_none(), true));
   ICS_TRY(bw(r.c13, gs_direct(r.c14->dA, 512, 0), gs_none(), true));
-  ICS_TRY(bw(r.c10, gs_up(r.c13->dA, 768, 256), gs_none(), true));
+  ICS_TRY(bw(r.c10, g_up(r.c13), gs_none(), true));
   ICS_TRY(bw(r.c9, gs_direct(r.c10->dA, 512, 0), gs_none(), true));
-  ICS_TRY(bw(r.c6, gs_pool(r.c9->dA, 256, *r.c6), gs_direct(r.c13->dA, 768, 0), true));
+  ICS_TRY(bw(r.c6, gs_pool(r.c9->dA, 256, *r.c6), g_skip(r.c13), true));
   ICS_TRY(bw(r.c5, gs_direct(r.c6->dA, 128, 0), gs_none(), true));
-  ICS_TRY(bw(r.c4, gs_pool(r.c5->dA, 128, *r.c4), gs_direct(r.c15->dA, 384, 0), true));
+  ICS_TRY(bw(r.c4, gs_pool(r.c5->dA, 128, *r.c4), g_skip(r.c15), true));
   ICS_TRY(bw(r.c3, gs_direct(r.c4->dA, 64, 0), gs_none(), true));
-  ICS_TRY(bw(r.c2, gs_pool(r.c3->dA, 64, *r.c2), gs_direct(r.c17->dA, 192, 0), true));
+  ICS_TRY(bw(r.c2, gs_pool(r.c3->dA, 64, *r.c2), g_skip(r.c17), true));
   ICS_TRY(bw(r.c1, gs_direct(r.c2->dA, 32, 0), gs_none(), false));
   return 0;
 }
