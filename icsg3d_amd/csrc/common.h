@@ -77,7 +77,14 @@ struct ConvGeom {
 // stat_partial: optional [gridM][3][Npad] (count, mean, M2) of the stored values per block column.
 int launch_conv_fwd(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int nsrc,
                     const float* wpacked, const float* bias, float* out, int ldo, int pre_act,
-                    float* stat_partial, int* stat_rows_per_block);
+                    float* stat_partial, int* stat_rows_per_block, int accumulate = 0);
+int launch_conv_fwd_par(hipStream_t st, const ConvGeom& g_lowres, const ConvSrc& src, const float* wpar, float* out,
+                        int ldo);
+const char* conv_fwd_par_kernel_id(const ConvGeom& g_lowres);
+int launch_pack_par(hipStream_t st, const float* w, int Cin_total, int Cout, int c_off, int Cu, float* dst, int Kpad,
+                    int Npad);
+int launch_pack_fwd_sub(hipStream_t st, const float* w, int taps, int Cin_total, int Cout, int c_off, int Csub,
+                        float* dst, int Kpad, int Npad);
 // partial[split][k][n] = sum_{m in split} A[m][k] * dy[m*ldy + n];  then reduced into dw[k*ldw+n].
 int launch_conv_wgrad(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int nsrc,
                       const float* dy, int ldy, float* dw, int ldw, float* workspace,

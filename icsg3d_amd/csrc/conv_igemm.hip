@@ -142,14 +142,18 @@ __device__ __forceinline__ float gather_scalar(const ConvSrc& s0, const ConvSrc&
 // REUSE (VEC, 27 taps, 4 <= S <= BM): an M tile is a whole number of x-lines; in LDS every line is
 // followed by a zero row, so the dx = -1/0/+1 taps of a (dz,dy) pair read the SAME staged A tile at
 // row offsets -1/0/+1.  A tiles are then loaded, BN-transformed and stored once per 3 chunks.
+// PAR (VEC, taps == 8): one of the 8 output-parity classes of a 3x3x3 conv over a nearest-upsampled
+// input, run on the LOW-RES grid: class p = blockIdx.y = (pz,py,px) reads the 2x2x2 neighbourhood
+// a + e + p - 1 (e in {0,1}^3) with pre-summed weights wp[p] and scatters row a to fine voxel 2a + p.
+// accumulate: the epilogue adds the previous contents of out before bias / activation / statistics.
 template <int WM, int WN, int TM, int TN, bool VEC, int ABL = 0, bool AFF = true, bool UP = true, bool THIN = false,
-          bool REUSE = false>
+          bool REUSE = false, bool PAR = false>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, ConvSrc s1,
                                                         const float* __restrict__ wp,
                                                         const float* __restrict__ bias,
                                                         float* __restrict__ out, int ldo, int pre_act,
                                                         float* __restrict__ stat_partial, int gridM,
-                                                        int gridN) {
+                                                        int gridN, int accumulate) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int B_FLOATS = 32 * BN;
   constexpr int RA = BM / 32;    // VEC: float4 A loads per thread per chunk
@@ -171,6 +175,9 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
   const int n0 = nb * BN;
   const int nchunks = g.Kpad >> 5;
   const int cpt = (VEC && !THIN) ? (g.Cin >> 5) : 1;   // 32-channel chunks per tap (VEC only)
+  const int cls = PAR ? (int)blockIdx.y : 0;
+  const int pz = cls >> 2, py = (cls >> 1) & 1, px = cls & 1;
+  if (PAR) wp += (size_t)cls * g.Kpad * g.Npad;
 
   // ---- per-thread row bookkeeping
   const int mrow_base = mb * BM + (VEC ? (t >> 3) : (t >> 5));   // + 32*r (VEC) / 8*r (SCALAR)
@@ -189,7 +196,14 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
       const RowPos rp = decode_row(m, S, lg);
       unsigned mk = 0;
       if (m < M) {
-        if (g.taps == 27) {
+        if (PAR) {
+#pragma unroll
+          for (int tp = 0; tp < 8; ++tp) {
+            const int zz = rp.z + (tp >> 2) + pz - 1, yy = rp.y + ((tp >> 1) & 1) + py - 1, xx = rp.x + (tp & 1) + px - 1;
+            const bool ok = (unsigned)zz < (unsigned)S && (unsigned)yy < (unsigned)S && (unsigned)xx < (unsigned)S;
+            mk |= (ok ? 1u : 0u) << tp;
+          }
+        } else if (g.taps == 27) {
           const unsigned zm = (rp.z > 0 ? 1u : 0u) | 2u | (rp.z < S - 1 ? 4u : 0u);
           const unsigned ym = (rp.y > 0 ? 1u : 0u) | 2u | (rp.y < S - 1 ? 4u : 0u);
           const unsigned xm = (rp.x > 0 ? 1u : 0u) | 2u | (rp.x < S - 1 ? 4u : 0u);
@@ -281,7 +295,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
         tap = c / cpt; ci0 = (c - tap * cpt) << 5;
       }
       const bool t27 = g.taps == 27;
-      const int dz = t27 ? tap / 9 - 1 : 0, dy = t27 ? (tap / 3) % 3 - 1 : 0, dx = t27 ? tap % 3 - 1 : 0;
+      int dz = t27 ? tap / 9 - 1 : 0, dy = t27 ? (tap / 3) % 3 - 1 : 0, dx = t27 ? tap % 3 - 1 : 0;
+      if (PAR) { dz = (tap >> 2) + pz - 1; dy = ((tap >> 1) & 1) + py - 1; dx = (tap & 1) + px - 1; }
       const bool first = THIN ? true : (ci0 < s0.C);
       const float* sp = first ? s0.p : s1.p;
       const float* sscale = first ? s0.scale : s1.scale;
@@ -520,12 +535,19 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
-        float v = act_apply(acc[i][j][r] + bv, pre_slope);
         const bool ok = m < M;
+        size_t mo = m;
+        if (PAR) {
+          const RowPos rp = decode_row(m, S, lg);
+          mo = ((((size_t)rp.b * (2 * S) + 2 * rp.z + pz) * (2 * S) + 2 * rp.y + py) * (2 * S)) + 2 * rp.x + px;
+        }
+        float a = acc[i][j][r] + bv;
+        if (accumulate && ok && nvalid) a += out[mo * ldo + n];
+        float v = act_apply(a, pre_slope);
         if (!ok) v = 0.f;
         acc[i][j][r] = v;
         cs += v;
-        if (ok && nvalid) out[(size_t)m * ldo + n] = v;
+        if (ok && nvalid) out[mo * ldo + n] = v;
       }
     colsum[j] = cs;
   }
@@ -581,16 +603,16 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
 }
 
 template <int WM, int WN, int TM, int TN, bool VEC, int ABL = 0, bool AFF = true, bool UP = true, bool THIN = false,
-          bool REUSE = false>
+          bool REUSE = false, bool PAR = false>
 static int launch_fwd_cfg(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, const ConvSrc& s1,
                           const float* wp, const float* bias, float* out, int ldo, int pre_act,
-                          float* stat_partial, int* rows_per_block) {
+                          float* stat_partial, int* rows_per_block, int accumulate = 0) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const int M = g.B << (3 * g.lgS);
   const int gridM = (M + BM - 1) / BM, gridN = g.Npad / BN;
   const int arows = REUSE ? BM + (BM >> g.lgS) + 1 : BM;
   const size_t lds = (size_t)2 * (arows * kLDA + 32 * BN) * sizeof(float);
-  auto kern = conv_fwd_kernel<WM, WN, TM, TN, VEC, ABL, AFF, UP, THIN, REUSE>;
+  auto kern = conv_fwd_kernel<WM, WN, TM, TN, VEC, ABL, AFF, UP, THIN, REUSE, PAR>;
   static bool attr_set = false;
   if (!attr_set) {
     const size_t lds_max = (size_t)2 * ((REUSE ? BM + BM / 4 + 1 : BM) * kLDA + 32 * BN) * sizeof(float);
@@ -599,8 +621,8 @@ static int launch_fwd_cfg(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, 
     attr_set = true;
   }
   if (rows_per_block) *rows_per_block = BM;
-  hipLaunchKernelGGL(kern, dim3(gridM * gridN), dim3(256), lds, st, g, s0, s1, wp, bias, out, ldo,
-                     pre_act, stat_partial, gridM, gridN);
+  hipLaunchKernelGGL(kern, dim3(gridM * gridN, PAR ? 8 : 1), dim3(256), lds, st, g, s0, s1, wp, bias, out, ldo,
+                     pre_act, stat_partial, gridM, gridN, accumulate);
   ICS_HIP(hipGetLastError());
   return 0;
 }
@@ -648,7 +670,7 @@ int conv_fwd_rows_per_block(const ConvGeom& g) {
 
 int launch_conv_fwd(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int nsrc,
                     const float* wp, const float* bias, float* out, int ldo, int pre_act,
-                    float* stat_partial, int* rows_per_block) {
+                    float* stat_partial, int* rows_per_block, int accumulate) {
   ConvSrc s0 = src[0], s1 = src[nsrc > 1 ? 1 : 0];
   if (nsrc == 1) s1.C = 0;
   // loader variants: 0 = plain sources (backward-data, pooled inputs), 1 = BN affine/activation,
@@ -663,7 +685,7 @@ int launch_conv_fwd(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int n
   static const bool no_reuse = getenv("ICSG3D_NO_REUSE") != nullptr;   // A/B switch for benchmarking
   int bm, bn;
   pick_fwd_tile(g, &bm, &bn);
-#define ICS_FWD_ARGS st, g, s0, s1, wp, bias, out, ldo, pre_act, stat_partial, rows_per_block
+#define ICS_FWD_ARGS st, g, s0, s1, wp, bias, out, ldo, pre_act, stat_partial, rows_per_block, accumulate
 #define ICS_FWD(WM, WN, TM, TN)                                                                 \
   do {                                                                                          \
     if (thin) return launch_fwd_cfg<WM, WN, TM, TN, true, 0, true, true, true>(ICS_FWD_ARGS);   \
@@ -684,6 +706,104 @@ int launch_conv_fwd(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int n
   ICS_FWD(4, 1, 1, 1);
 #undef ICS_FWD_ARGS
 #undef ICS_FWD
+}
+
+// The 8 parity-class GEMMs of a 3x3x3 conv over a nearest-upsampled source (see PAR above).
+// g: geometry of the LOW-RES grid with taps = 8, Cin = channels of the source, Kpad = 8*Cin;
+// wp: [8][Kpad/4][Npad][4] pre-summed weights (launch_pack_par); out: fine-grid rows [8*M][ldo], raw sums.
+// block count heuristics of pick_fwd_tile see one class; the launch has 8x the blocks: prefer the large tile
+static void pick_par_tile(const ConvGeom& g, int* bm, int* bn) {
+  pick_fwd_tile(g, bm, bn);
+  if (*bm == 64 && g.Npad % 128 == 0 && (long)(((g.B << (3 * g.lgS)) + 127) / 128) * (g.Npad / 128) * 8 >= 384) {
+    *bm = 128; *bn = 128;
+  }
+}
+const char* conv_fwd_par_kernel_id(const ConvGeom& g) {
+  int bm, bn;
+  pick_par_tile(g, &bm, &bn);
+  if (bm == 64) return "conv_fwd_kernel<2,2,1,1,vec,par>";
+  if (bn == 128) return "conv_fwd_kernel<2,2,2,2,vec,par>";
+  if (bn == 96) return "conv_fwd_kernel<4,1,1,3,vec,par>";
+  if (bn == 64) return "conv_fwd_kernel<2,2,2,1,vec,par>";
+  return "conv_fwd_kernel<4,1,1,1,vec,par>";
+}
+int launch_conv_fwd_par(hipStream_t st, const ConvGeom& g, const ConvSrc& src, const float* wp, float* out,
+                        int ldo) {
+  ConvSrc s0 = src, s1 = src;
+  s1.C = 0;
+  ICS_CHECK(g.taps == 8 && g.Cin % 32 == 0 && s0.C == g.Cin && !s0.up && !s0.bcast && g.Kpad == 8 * g.Cin,
+            "parity-class conv needs a direct 32k-channel source");
+  ICS_TRY(fix_src(s0));
+  ICS_TRY(fix_src(s1));
+  int bm, bn;
+  pick_par_tile(g, &bm, &bn);
+#define ICS_PAR_ARGS st, g, s0, s1, wp, nullptr, out, ldo, ACT_NONE, nullptr, nullptr
+  if (bm == 64) return launch_fwd_cfg<2, 2, 1, 1, true, 0, true, false, false, false, true>(ICS_PAR_ARGS);
+  if (bn == 128) return launch_fwd_cfg<2, 2, 2, 2, true, 0, true, false, false, false, true>(ICS_PAR_ARGS);
+  if (bn == 96) return launch_fwd_cfg<4, 1, 1, 3, true, 0, true, false, false, false, true>(ICS_PAR_ARGS);
+  if (bn == 64) return launch_fwd_cfg<2, 2, 2, 1, true, 0, true, false, false, false, true>(ICS_PAR_ARGS);
+  return launch_fwd_cfg<4, 1, 1, 1, true, 0, true, false, false, false, true>(ICS_PAR_ARGS);
+#undef ICS_PAR_ARGS
+}
+
+// pre-summed parity weights: dst[cls][k = e*Cu + c][n] = sum over taps d with (per axis)
+//   p=0: e=0 -> {-1}, e=1 -> {0,+1};  p=1: e=0 -> {-1,0}, e=1 -> {+1}   of w[d][c_off + c][n]
+__global__ void pack_par_kernel(const float* __restrict__ w, int Cin_total, int Cout, int c_off, int Cu,
+                                float* __restrict__ dst, int Kpad, int Npad) {
+  const size_t per = (size_t)Kpad * Npad;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 8 * per) return;
+  const int cls = (int)(i / per);
+  const size_t j = i - (size_t)cls * per;
+  const int tq = j & 3;
+  const size_t rest = j >> 2;
+  const int n = rest % Npad;
+  const int k = (int)(rest / Npad) * 4 + tq;
+  const int e = k / Cu, c = k - e * Cu;
+  float v = 0.f;
+  if (e < 8 && n < Cout) {
+    const int p3[3] = {cls >> 2, (cls >> 1) & 1, cls & 1};
+    const int e3[3] = {e >> 2, (e >> 1) & 1, e & 1};
+    int lo[3], hi[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      if (p3[a] == 0) { lo[a] = e3[a] ? 1 : 0; hi[a] = e3[a] ? 2 : 0; }
+      else { lo[a] = e3[a] ? 2 : 0; hi[a] = e3[a] ? 2 : 1; }
+    }
+    for (int dz = lo[0]; dz <= hi[0]; ++dz)
+      for (int dy = lo[1]; dy <= hi[1]; ++dy)
+        for (int dx = lo[2]; dx <= hi[2]; ++dx)
+          v += w[((size_t)((dz * 3 + dy) * 3 + dx) * Cin_total + c_off + c) * Cout + n];
+  }
+  dst[i] = v;
+}
+int launch_pack_par(hipStream_t st, const float* w, int Cin_total, int Cout, int c_off, int Cu, float* dst,
+                    int Kpad, int Npad) {
+  const size_t total = (size_t)8 * Kpad * Npad;
+  hipLaunchKernelGGL(pack_par_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, Cin_total, Cout,
+                     c_off, Cu, dst, Kpad, Npad);
+  ICS_HIP(hipGetLastError());
+  return 0;
+}
+// forward weights of a channel subset: dst[k = tap*Csub + c][n] = w[tap][c_off + c][n]
+__global__ void pack_fwd_sub_kernel(const float* __restrict__ w, int taps, int Cin_total, int Cout, int c_off,
+                                    int Csub, float* __restrict__ dst, int Kpad, int Npad) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)Kpad * Npad) return;
+  const int tq = i & 3;
+  const size_t rest = i >> 2;
+  const int n = rest % Npad;
+  const int k = (int)(rest / Npad) * 4 + tq;
+  const int tap = k / Csub, c = k - tap * Csub;
+  dst[i] = (tap < taps && n < Cout) ? w[((size_t)tap * Cin_total + c_off + c) * Cout + n] : 0.f;
+}
+int launch_pack_fwd_sub(hipStream_t st, const float* w, int taps, int Cin_total, int Cout, int c_off, int Csub,
+                        float* dst, int Kpad, int Npad) {
+  const size_t total = (size_t)Kpad * Npad;
+  hipLaunchKernelGGL(pack_fwd_sub_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, taps,
+                     Cin_total, Cout, c_off, Csub, dst, Kpad, Npad);
+  ICS_HIP(hipGetLastError());
+  return 0;
 }
 
 // benchmarking-only: the 128x128 vector-path instantiation with part of the loop removed

@@ -104,6 +104,7 @@ struct ConvLayer {
   bool split_up = false;
   int Cs = 0, Cu = 0;
   float *wf_skip = nullptr, *w_up = nullptr;   // packed: dgrad of the skip channels; dxl = dyS x W_up
+  float *wp_skip = nullptr, *wp_par = nullptr; // packed forward: skip channels (27 taps); 8 parity classes x 8 taps
   float *dyS = nullptr;                        // [M/8][27*Cout] tap-pooled dy
   float *dA_skip = nullptr, *dxl = nullptr;    // [M][Cs] grad of the skip input; [M/8][Cu] grad of the low-res input
   float *dw_up = nullptr;                      // [Cu][27*Cout] GEMM result before the permute into G
@@ -272,11 +273,19 @@ static ConvGeom geom_skip_wgrad(const ConvLayer& L, int B) {
 static ConvGeom geom_skip_dgrad(const ConvLayer& L, int B) {
   return ConvGeom{B, L.S, ilog2(L.S), L.Cout, L.Cs, L.taps, L.Kpad_b, round_up(L.Cs, 32)};
 }
+static ConvGeom geom_skip_fwd(const ConvLayer& L, int B) {
+  return ConvGeom{B, L.S, ilog2(L.S), L.Cs, L.Cout, L.taps, round_up(L.taps * L.Cs, 32), L.Npad};
+}
+static ConvGeom geom_par_fwd(const ConvLayer& L, int B) {    // one parity class over the S/2 grid
+  return ConvGeom{B, L.S / 2, ilog2(L.S / 2), L.Cu, L.Cout, 8, 8 * L.Cu, L.Npad};
+}
 static ConvSrc src_lowres(const ConvLayer& L) { ConvSrc u = L.src[1]; u.up = 0; return u; }
 
 static int enable_split_up(Net& n, ConvLayer& L) {
   if (getenv("ICSG3D_NO_UPSPLIT")) return 0;
-  if (L.nsrc != 2 || !L.src[1].up || L.taps != 27 || L.S < 2 || L.CinG != L.Cin) return 0;
+  if (L.nsrc != 2 || !L.src[1].up || L.taps != 27 || L.S < 2 || L.CinG != L.Cin || L.src[0].C % 32 ||
+      L.src[1].C % 32)
+    return 0;
   L.split_up = true;
   L.Cs = L.src[0].C; L.Cu = L.src[1].C;
   const size_t M = n.rows(L, n.maxB);
@@ -286,6 +295,8 @@ static int enable_split_up(Net& n, ConvLayer& L) {
   ICS_TRY(n.alloc(&L.dA_skip, M * L.Cs));
   ICS_TRY(n.alloc(&L.dxl, M / 8 * L.Cu));
   ICS_TRY(n.alloc(&L.dw_up, (size_t)L.Cu * 27 * L.Cout));
+  ICS_TRY(n.alloc(&L.wp_skip, (size_t)round_up(L.taps * L.Cs, 32) * L.Npad));
+  ICS_TRY(n.alloc(&L.wp_par, (size_t)8 * 8 * L.Cu * L.Npad));
   return 0;
 }
 
@@ -359,6 +370,11 @@ static int pack_layer(Net& n, ConvLayer& L, bool need_bwd) {
                           L.CinG != L.Cin ? L.Cin : 0, L.CinG != L.Cin ? L.CinG : 0));
   if (need_bwd && L.wf)
     ICS_TRY(launch_pack_bwd(n.st, n.tp(L.t_w), L.taps, L.Cin, L.Cout, L.wf, L.Kpad_b, L.Npad_b, L.Cout, 0, 1));
+  if (L.split_up) {
+    ICS_TRY(launch_pack_fwd_sub(n.st, n.tp(L.t_w), L.taps, L.Cin, L.Cout, 0, L.Cs, L.wp_skip, round_up(L.taps * L.Cs, 32),
+                                L.Npad));
+    ICS_TRY(launch_pack_par(n.st, n.tp(L.t_w), L.Cin, L.Cout, L.Cs, L.Cu, L.wp_par, 8 * L.Cu, L.Npad));
+  }
   if (need_bwd && L.split_up) {
     ICS_TRY(launch_pack_sub(n.st, n.tp(L.t_w), L.taps, L.Cin, L.Cout, 0, L.Cs, 1, L.wf_skip, L.Kpad_b, round_up(L.Cs, 32)));
     ICS_TRY(launch_pack_sub(n.st, n.tp(L.t_w), L.taps, L.Cin, L.Cout, L.Cs, L.Cu, 0, L.w_up, round_up(27 * L.Cout, 32),
@@ -381,11 +397,28 @@ static int conv_forward(Net& n, ConvLayer& L, int B, bool training, bool update_
     ICS_TRY(launch_materialize_input(n.st, L.vsrc, L.nvsrc, L.Cin, L.CinG, B, L.S, L.pad_in));
     n.prof.end(n.st);
   }
+  if (L.split_up) {
+    // [skip | upsampled] input: the upsampled channels are 8 parity-class GEMMs over the low-res grid with
+    // pre-summed 2x2x2 weights (8/27 of the FLOPs); the skip channels then accumulate on top and finish
+    // the epilogue (bias, activation, BatchNorm statistics).
+    const ConvGeom gp = geom_par_fwd(L, B), gs = geom_skip_fwd(L, B);
+    const ConvSrc lo = src_lowres(L);
+    n.prof.begin(n.st, "conv_fwd:" + L.name + ".up|" + (n.prof.on ? conv_fwd_par_kernel_id(gp) : ""), 2.0 * M * 8 * L.Cu * L.Cout,
+                 4.0 * (M / 8 * L.Cu + M * L.Cout + 64.0 * L.Cu * L.Cout));
+    ICS_TRY(launch_conv_fwd_par(n.st, gp, lo, L.wp_par, L.s, L.Cout));
+    n.prof.end(n.st);
+    n.prof.begin(n.st, "conv_fwd:" + L.name + ".skip|" + (n.prof.on ? conv_fwd_kernel_id(gs, L.src, 1) : ""), 2.0 * M * 27 * L.Cs * L.Cout,
+                 4.0 * (M * L.Cs + 2 * M * L.Cout + 27.0 * L.Cs * L.Cout));
+    ICS_TRY(launch_conv_fwd(n.st, gs, L.src, 1, L.wp_skip, bias, L.s, L.Cout, L.pre_act, stats ? n.ws_stat : nullptr,
+                            &rpb, 1));
+    n.prof.end(n.st);
+  } else {
   n.prof.begin(n.st, "conv_fwd:" + L.name + "|" + (n.prof.on ? conv_fwd_kernel_id(g, L.src, L.nsrc) : ""), 2.0 * M * L.taps * L.Cin * L.Cout,
                4.0 * (M * L.Cin + M * L.Cout + (double)L.taps * L.Cin * L.Cout));
   ICS_TRY(launch_conv_fwd(n.st, g, L.src, L.nsrc, L.wp, bias, L.s, L.Cout, L.pre_act,
                           stats ? n.ws_stat : nullptr, &rpb));
   n.prof.end(n.st);
+  }
   if (L.has_bn) {
     BnParams bn{n.tp(L.t_gamma), n.tp(L.t_beta), L.mm, L.mv, L.mean, L.rstd, L.scale, L.shift};
     if (training) {
