@@ -447,12 +447,20 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
             }
       }
     };
-    load_a_group(0);
-    store_a_group(0);
-    load_b(b_rows(0));
-    store_b(0);
+    // a tile inside one z-plane (BM <= S*S) at the z = 0 / S-1 face reads only padding through the
+    // dz = -1 / +1 groups: skip them (block-uniform loop bounds; 2/(3S) of the MFMA work)
+    int G0 = 0, G1 = nG;
+    if (BM <= (S << lg)) {
+      const int zb = ((mb * BM) >> (2 * lg)) & (S - 1);
+      if (zb == 0) G0 = 3 * cpt;
+      if (zb == S - 1) G1 = 6 * cpt;
+    }
+    load_a_group(G0);
+    store_a_group(G0 & 1);
+    load_b(b_rows(3 * G0));
+    store_b((3 * G0) & 1);
     __syncthreads();
-    for (int G = 0; G + 1 < nG; ++G) {
+    for (int G = G0; G + 1 < G1; ++G) {
       const int c0 = 3 * G;
       // dx = -1 : also fetch the next group's A rows (kept in registers for three chunks)
       load_a_group(G + 1);
@@ -473,7 +481,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
       __syncthreads();
     }
     {
-      const int G = nG - 1, c0 = 3 * G;
+      const int G = G1 - 1, c0 = 3 * G;
       load_b(b_rows(c0 + 1));
       compute_reuse(G & 1, c0 & 1, -1);
       store_b((c0 + 1) & 1);
@@ -1267,14 +1275,14 @@ static WgradPlan plan_wgrad(const ConvGeom& g, const ConvSrc& s0, int nsrc, cons
   // splits still have >= 512 voxel rows each.
   const long base = (long)p.ktiles * p.ntiles;
   const long slots = 512;
+  const long ks_max = std::max<long>(1, M / 256);
   long want = 1;
   double best = -1.0;
   for (long r = 1; r <= 6; ++r) {
     long ks = (r * slots) / base;
     if (ks < 1) ks = 1;
     if (ks > 512) ks = 512;
-    const long rows_each = (M + ks - 1) / ks;
-    if (ks > 1 && rows_each < 512) break;
+    if (ks > ks_max) { if (r > 1) break; ks = ks_max; }   // small M: as many >= 256-row splits as there are
     const long total = base * ks;
     const double fill = (double)total / (double)(((total + slots - 1) / slots) * slots);
     if (fill > best + 0.02 || (fill > best - 0.005 && ks > want)) { best = fill > best ? fill : best; want = ks; }
@@ -1288,14 +1296,14 @@ static WgradPlan plan_wgrad(const ConvGeom& g, const ConvSrc& s0, int nsrc, cons
 // split-K count that fills whole rounds of the 512 resident blocks (see plan_wgrad)
 static int pick_ksplit(long base, long M) {
   const long slots = 512;
+  const long ks_max = std::max<long>(1, M / 256);
   long want = 1;
   double best = -1.0;
   for (long r = 1; r <= 6; ++r) {
     long ks = (r * slots) / base;
     if (ks < 1) ks = 1;
     if (ks > 512) ks = 512;
-    const long rows_each = (M + ks - 1) / ks;
-    if (ks > 1 && rows_each < 512) break;
+    if (ks > ks_max) { if (r > 1) break; ks = ks_max; }   // small M: as many >= 256-row splits as there are
     const long total = base * ks;
     const double fill = (double)total / (double)(((total + slots - 1) / slots) * slots);
     if (fill > best + 0.02 || (fill > best - 0.005 && ks > want)) { best = fill > best ? fill : best; want = ks; }

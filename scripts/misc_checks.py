@@ -34,11 +34,11 @@ if "vae" in what:
     ve.sync()
     urows = sorted(ue.profile_rows(), key=lambda r: -r["ms"])
     print("profiled perceptual U-Net ms/step %.2f" % (sum(r["ms"] for r in urows) / 2))
-    for r in urows[:14]:
+    for r in urows[:30]:
         print("  PM %-44s n=%3d %8.3f ms/step" % (r["label"], r["launches"], r["ms"] / 2))
     rows = sorted(ve.profile_rows(), key=lambda r: -r["ms"])
     print("profiled VAE-engine ms/step %.2f (perceptual U-Net launches are not in these rows)" % (sum(r["ms"] for r in rows) / 2))
-    for r in rows[:12]:
+    for r in rows[:40]:
         print("  %-44s n=%3d %8.3f ms/step" % (r["label"], r["launches"], r["ms"] / 2))
 if "d64" in what:
     B, d = 2, 64
