@@ -163,7 +163,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
   // REUSE: BM rows + one zero row after each of the BM/S lines + one leading zero row
   const int A_FLOATS = (REUSE ? BM + (BM >> g.lgS) + 1 : BM) * kLDA;
   float* As = smem;                      // [2][rows][36]
-  float* Bs = smem + 2 * A_FLOATS;       // [2][8][BN][4]
+  constexpr int NABUF = REUSE ? 1 : 2;   // REUSE: one A buffer (3 blocks/CU fit in LDS), restaged behind a barrier
+  float* Bs = smem + NABUF * A_FLOATS;   // [2][8][BN][4]
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -408,7 +409,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
     // ---- dx-reuse pipeline: groups G = ((dz*3+dy), 32-channel slice); chunks c = 3G + (dx+1)
     const int nG = 9 * cpt;
     const int lines = BM >> lg;
-    for (int i = t; i < 2 * (lines + 1) * kLDA; i += 256) {      // the separator rows stay zero
+    for (int i = t; i < NABUF * (lines + 1) * kLDA; i += 256) {      // the separator rows stay zero
       const int b = i / ((lines + 1) * kLDA), rem = i - b * (lines + 1) * kLDA;
       As[b * A_FLOATS + (rem / kLDA) * (S + 1) * kLDA + rem % kLDA] = 0.f;
     }
@@ -456,7 +457,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
       if (zb == S - 1) G1 = 6 * cpt;
     }
     load_a_group(G0);
-    store_a_group(G0 & 1);
+    store_a_group(0);
     load_b(b_rows(3 * G0));
     store_b((3 * G0) & 1);
     __syncthreads();
@@ -465,32 +466,33 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
       // dx = -1 : also fetch the next group's A rows (kept in registers for three chunks)
       load_a_group(G + 1);
       load_b(b_rows(c0 + 1));
-      compute_reuse(G & 1, c0 & 1, -1);
+      compute_reuse(0, c0 & 1, -1);
       store_b((c0 + 1) & 1);
       __syncthreads();
       // dx = 0
       load_b(b_rows(c0 + 2));
-      compute_reuse(G & 1, (c0 + 1) & 1, 0);
+      compute_reuse(0, (c0 + 1) & 1, 0);
       store_b((c0 + 2) & 1);
       __syncthreads();
-      // dx = +1 : stage the next group's A tile
+      // dx = +1 : then restage the (single) A buffer with the next group's tile
       load_b(b_rows(c0 + 3));
-      compute_reuse(G & 1, (c0 + 2) & 1, 1);
-      store_a_group((G + 1) & 1);
+      compute_reuse(0, (c0 + 2) & 1, 1);
       store_b((c0 + 3) & 1);
+      __syncthreads();
+      store_a_group(0);
       __syncthreads();
     }
     {
       const int G = G1 - 1, c0 = 3 * G;
       load_b(b_rows(c0 + 1));
-      compute_reuse(G & 1, c0 & 1, -1);
+      compute_reuse(0, c0 & 1, -1);
       store_b((c0 + 1) & 1);
       __syncthreads();
       load_b(b_rows(c0 + 2));
-      compute_reuse(G & 1, (c0 + 1) & 1, 0);
+      compute_reuse(0, (c0 + 1) & 1, 0);
       store_b((c0 + 2) & 1);
       __syncthreads();
-      compute_reuse(G & 1, (c0 + 2) & 1, 1);
+      compute_reuse(0, (c0 + 2) & 1, 1);
       __syncthreads();
     }
   } else {
@@ -619,11 +621,11 @@ static int launch_fwd_cfg(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, 
   const int M = g.B << (3 * g.lgS);
   const int gridM = (M + BM - 1) / BM, gridN = g.Npad / BN;
   const int arows = REUSE ? BM + (BM >> g.lgS) + 1 : BM;
-  const size_t lds = (size_t)2 * (arows * kLDA + 32 * BN) * sizeof(float);
+  const size_t lds = (size_t)((REUSE ? 1 : 2) * arows * kLDA + 2 * 32 * BN) * sizeof(float);
   auto kern = conv_fwd_kernel<WM, WN, TM, TN, VEC, ABL, AFF, UP, THIN, REUSE, PAR>;
   static bool attr_set = false;
   if (!attr_set) {
-    const size_t lds_max = (size_t)2 * ((REUSE ? BM + BM / 4 + 1 : BM) * kLDA + 32 * BN) * sizeof(float);
+    const size_t lds_max = (size_t)((REUSE ? 1 : 2) * (REUSE ? BM + BM / 4 + 1 : BM) * kLDA + 2 * 32 * BN) * sizeof(float);
     ICS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
     attr_set = true;
