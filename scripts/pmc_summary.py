@@ -1,6 +1,24 @@
 """Summarise rocprofv3 --pmc counter_collection CSVs per kernel (averages per dispatch).
-usage: pmc_summary.py <dir> [kernel-substring ...]"""
-import csv, glob, sys, collections
+usage: pmc_summary.py <dir> [kernel-substring ...]
+Also writes <dir>/traffic.json: per bench.py kernel id, HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KB
+(gfx950: FETCH_SIZE counts 64-B requests for 128-B wide reads, MI355X_MICROARCH.md HBM/rocprofv3 section)."""
+import csv, glob, json, re, sys, collections
+
+
+def bench_id(short):
+    """template instantiation name -> the kernel id bench.py / the engine profiler use"""
+    m = re.match(r"(\w+)<(.*)>$", short.strip())
+    if not m:
+        return short.strip()
+    base, args = m.group(1), [a.strip() for a in m.group(2).split(",")]
+    if base == "conv_fwd_kernel":
+        par = len(args) > 10 and args[10] == "true"
+        return "conv_fwd_kernel<%s,%s%s>" % (",".join(args[:4]), "vec" if args[4] == "true" else "scalar",
+                                             ",par" if par else "")
+    if base == "conv_wgrad_kernel":
+        return "conv_wgrad_kernel<%s,%s>" % (",".join(args[:4]), "vec" if args[4] == "true" else "scalar")
+    return base
+
 d = sys.argv[1]
 filt = sys.argv[2:]
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
@@ -25,3 +43,28 @@ for k in sorted(acc, key=lambda k: -acc[k].get("SQ_WAVE_CYCLES", acc[k].get("GRB
         for w in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS"):
             if w in c:
                 print("   %s/WAVE_CYCLES = %.3f" % (w, c[w] / c["SQ_WAVE_CYCLES"]))
+
+# ---- traffic.json keyed by bench.py kernel ids (dispatch-weighted over the loader variants of one tile)
+agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+for k in acc:
+    for n, v in acc[k].items():
+        a = agg[bench_id(k)][n]
+        a[0] += v[0]; a[1] += v[1]
+out = {"source": "rocprofv3 --kernel-trace --pmc <one counter group per pass> (scripts/run_pmc.sh); "
+                 "traffic = (2*FETCH_SIZE + WRITE_SIZE) KB per launch (gfx950 correction for wide reads)",
+       "kernels": {}}
+for k, cs in agg.items():
+    c = {n: v[0] / v[1] for n, v in cs.items()}
+    e = {"launches_sampled": max(v[1] for v in cs.values())}
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        e["fetch_size_kb_avg"] = round(c["FETCH_SIZE"], 1)
+        e["write_size_kb_avg"] = round(c["WRITE_SIZE"], 1)
+        e["traffic_bytes_per_launch"] = int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "SQ_BUSY_CU_CYCLES" in c and c["SQ_BUSY_CU_CYCLES"] > 0:
+        e["mfma_busy_frac"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / c["SQ_BUSY_CU_CYCLES"] / 4, 4)
+    if "SQ_LDS_BANK_CONFLICT" in c and c.get("SQ_LDS_IDX_ACTIVE", 0) > 0:
+        e["lds_bank_conflict_frac"] = round(c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"], 4)
+    if "SQ_WAIT_ANY" in c and c.get("SQ_WAVE_CYCLES", 0) > 0:
+        e["wave_wait_any_frac"] = round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 4)
+    out["kernels"][k] = e
+json.dump(out, open(d + "/traffic.json", "w"), indent=1)
