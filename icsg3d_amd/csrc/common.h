@@ -77,7 +77,9 @@ struct ConvGeom {
 // stat_partial: optional [gridM][3][Npad] (count, mean, M2) of the stored values per block column.
 int launch_conv_fwd(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int nsrc,
                     const float* wpacked, const float* bias, float* out, int ldo, int pre_act,
-                    float* stat_partial, int* stat_rows_per_block, int accumulate = 0);
+                    float* stat_partial, int* stat_rows_per_block, int accumulate = 0,
+                    float* splitk_ws = nullptr, size_t splitk_ws_floats = 0);
+size_t conv_fwd_workspace_floats(const ConvGeom& g, const ConvSrc* src, int nsrc);
 int launch_conv_fwd_par(hipStream_t st, const ConvGeom& g_lowres, const ConvSrc& src, const float* wpar, float* out,
                         int ldo);
 const char* conv_fwd_par_kernel_id(const ConvGeom& g_lowres);
@@ -88,7 +90,10 @@ int launch_pack_fwd_sub(hipStream_t st, const float* w, int taps, int Cin_total,
 // partial[split][k][n] = sum_{m in split} A[m][k] * dy[m*ldy + n];  then reduced into dw[k*ldw+n].
 int launch_conv_wgrad(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int nsrc,
                       const float* dy, int ldy, float* dw, int ldw, float* workspace,
-                      size_t workspace_floats, int sub_rows = 0, int row_pitch = 0, int row_off = 0);
+                      size_t workspace_floats, int sub_rows = 0, int row_pitch = 0, int row_off = 0,
+                      int phase = 0);   // 0: GEMM + split reduction; 1: GEMM only; 2: reduction only
+// exact template instantiation (as rocprofv3 names it) of the last conv GEMM kernel launched by this thread
+const char* conv_last_kernel_id();
 int launch_pack_sub(hipStream_t st, const float* w, int taps, int Cin_total, int Cout, int c_off, int Csub,
                     int flip, float* dst, int Kpad, int Npad);
 size_t conv_wgrad_workspace_floats(const ConvGeom& g, const ConvSrc* src, int nsrc);

@@ -29,6 +29,11 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nblk) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
+// Exact template instantiation (the name rocprofv3 prints) of the last conv GEMM kernel this thread launched.
+static thread_local const char* g_last_kernel_id = "";
+const char* conv_last_kernel_id() { return g_last_kernel_id; }
+static const char* tf(bool b) { return b ? "true" : "false"; }
+
 // Sources without a BatchNorm affine get pointers to constant ones/zeros so that the tile loaders
 // never branch on "has affine" (fma(v,1,0) == v exactly).
 static int identity_affine(const float** ones, const float** zeros) {
@@ -82,7 +87,7 @@ __device__ __forceinline__ size_t src_voxel(const ConvSrc& s, int b, int z, int 
 // Branch-free activation: slope 1 = identity, 0 = ReLU, 0.3 = LeakyReLU.  max(v, v*slope)
 // is exact for all three, and keeps the tile loaders a single basic block
 // so the scheduler can run the next tile's address math and loads under the current tile's MFMAs.
-__device__ __forceinline__ float act_slope_of(int act) {
+__host__ __device__ __forceinline__ float act_slope_of(int act) {
   return act == ACT_RELU ? 0.f : (act == ACT_LRELU ? kLeaky : 1.f);
 }
 __device__ __forceinline__ float act_apply(float v, float slope) {
@@ -456,6 +461,12 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
       if (zb == 0) G0 = 3 * cpt;
       if (zb == S - 1) G1 = 6 * cpt;
     }
+    if (gridDim.z > 1) {   // split-K: this block's slice of the groups; partial sums go to the workspace
+      const int per = (nG + (int)gridDim.z - 1) / (int)gridDim.z;
+      G0 = max(G0, (int)blockIdx.z * per);
+      G1 = min(G1, ((int)blockIdx.z + 1) * per);
+    }
+    if (G0 < G1) {
     load_a_group(G0);
     store_a_group(0);
     load_b(b_rows(3 * G0));
@@ -495,9 +506,17 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
       compute_reuse(0, (c0 + 2) & 1, 1);
       __syncthreads();
     }
+    }   // G0 < G1
   } else {
-  load_chunk(0);
-  store_chunk(0);
+  int cb = 0, ce = nchunks;
+  if (gridDim.z > 1) {
+    const int per = (nchunks + (int)gridDim.z - 1) / (int)gridDim.z;
+    cb = (int)blockIdx.z * per;
+    ce = min(nchunks, cb + per);
+  }
+  if (cb < ce) {
+  load_chunk(cb);
+  store_chunk(cb & 1);
   __syncthreads();
 
   auto compute = [&](int buf) {
@@ -513,7 +532,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
   };
   if (ABL == 0 || ABL >= 3) {
-    for (int c = 0; c + 1 < nchunks; ++c) {
+    for (int c = cb; c + 1 < ce; ++c) {
       // (sched_barrier fences around the MFMA stream were measured: -4 %; hipcc's own interleave wins)
       load_chunk(c + 1);
       compute(c & 1);
@@ -527,9 +546,11 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
       __syncthreads();
     }
   }
-  compute((nchunks - 1) & 1);
+  compute((ce - 1) & 1);
   __syncthreads();
+  }   // cb < ce
   }   // !REUSE
+  if (gridDim.z > 1) out += (size_t)blockIdx.z * (size_t)M * ldo;
 
   // ---- epilogue: bias + activation, store, per-block BatchNorm partial statistics
   const int mrow0 = mb * BM + wm * TM * 32 + 4 * lh;
@@ -616,7 +637,7 @@ template <int WM, int WN, int TM, int TN, bool VEC, int ABL = 0, bool AFF = true
           bool REUSE = false, bool PAR = false>
 static int launch_fwd_cfg(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, const ConvSrc& s1,
                           const float* wp, const float* bias, float* out, int ldo, int pre_act,
-                          float* stat_partial, int* rows_per_block, int accumulate = 0) {
+                          float* stat_partial, int* rows_per_block, int accumulate = 0, int ksplit = 1) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const int M = g.B << (3 * g.lgS);
   const int gridM = (M + BM - 1) / BM, gridN = g.Npad / BN;
@@ -631,7 +652,12 @@ static int launch_fwd_cfg(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, 
     attr_set = true;
   }
   if (rows_per_block) *rows_per_block = BM;
-  hipLaunchKernelGGL(kern, dim3(gridM * gridN, PAR ? 8 : 1), dim3(256), lds, st, g, s0, s1, wp, bias, out, ldo,
+  static const std::string id = std::string("conv_fwd_kernel<") + std::to_string(WM) + ", " + std::to_string(WN) + ", " +
+                                std::to_string(TM) + ", " + std::to_string(TN) + ", " + tf(VEC) + ", " +
+                                std::to_string(ABL) + ", " + tf(AFF) + ", " + tf(UP) + ", " + tf(THIN) + ", " +
+                                tf(REUSE) + ", " + tf(PAR) + ">";
+  g_last_kernel_id = id.c_str();
+  hipLaunchKernelGGL(kern, dim3(gridM * gridN, PAR ? 8 : 1, ksplit), dim3(256), lds, st, g, s0, s1, wp, bias, out, ldo,
                      pre_act, stat_partial, gridM, gridN, accumulate);
   ICS_HIP(hipGetLastError());
   return 0;
@@ -678,9 +704,106 @@ int conv_fwd_rows_per_block(const ConvGeom& g) {
   return bm;
 }
 
+// Split-K for launches that cannot fill the chip (64x64 tiles on the S <= 8 layers): ksplit blocks share a
+// tile, each sums a slice of K into ws[split][M][Npad]; splitk_finish_kernel adds the slices in fixed order
+// and runs the epilogue (bias, activation, store, BatchNorm partial statistics of 64-row blocks).
+static int fwd_splitk_plan(const ConvGeom& g, const ConvSrc& s0, const ConvSrc& s1, int nsrc) {
+  static const bool off = getenv("ICSG3D_NO_FWD_SPLITK") != nullptr;
+  if (off || !fwd_is_vec(g, s0, s1) || conv_is_thin(g, s0, nsrc)) return 1;
+  int bm, bn;
+  pick_fwd_tile(g, &bm, &bn);
+  if (bm != 64) return 1;
+  const long M = (long)g.B << (3 * g.lgS);
+  const long blocks = ((M + 63) / 64) * (g.Npad / 64);
+  const bool reuse = g.taps == 27 && g.S >= 4 && g.S <= 64;
+  const long units = reuse ? 9L * (g.Cin / 32) : g.Kpad / 32;     // groups (3 chunks) or chunks
+  const long min_units = reuse ? 3 : 8;
+  long ks = std::min(768 / std::max(blocks, 1L), units / min_units);
+  return (int)std::max(1L, std::min(ks, 16L));
+}
+size_t conv_fwd_workspace_floats(const ConvGeom& g, const ConvSrc* src, int nsrc) {
+  ConvSrc s0 = src[0], s1 = src[nsrc > 1 ? 1 : 0];
+  if (nsrc == 1) s1.C = 0;
+  const int ks = fwd_splitk_plan(g, s0, s1, nsrc);
+  return ks > 1 ? (size_t)ks * ((size_t)g.B << (3 * g.lgS)) * g.Npad : 0;
+}
+
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ ws, int nsplit, int M, int N,
+                                                             int Npad, const float* __restrict__ bias,
+                                                             float slope, float* __restrict__ out, int ldo,
+                                                             int accumulate, float* __restrict__ stat_partial) {
+  __shared__ float red[4][64];
+  __shared__ float bmean[64];
+  const int t = threadIdx.x, tx = t & 63, ty = t >> 6;
+  const int col = blockIdx.y * 64 + tx;
+  const int row0 = blockIdx.x * 64 + ty * 16;
+  const bool cvalid = col < N;
+  const float bv = (bias != nullptr && cvalid) ? bias[col] : 0.f;
+  float v[16];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int m = row0 + i;
+    float a = 0.f;
+    if (m < M && cvalid) {
+      for (int p = 0; p < nsplit; ++p) a += ws[((size_t)p * M + m) * Npad + col];   // fixed order: deterministic
+      a += bv;
+      if (accumulate) a += out[(size_t)m * ldo + col];
+      a = act_apply(a, slope);
+      out[(size_t)m * ldo + col] = a;
+    }
+    v[i] = a;
+    sum += a;
+  }
+  if (stat_partial == nullptr) return;
+  const int nvalid_rows = min(64, M - (int)blockIdx.x * 64);
+  red[ty][tx] = sum;
+  __syncthreads();
+  if (ty == 0) bmean[tx] = (red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]) / (float)nvalid_rows;
+  __syncthreads();
+  const float mu = bmean[tx];
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const float d = v[i] - mu;
+    q += (row0 + i < M) ? d * d : 0.f;
+  }
+  __syncthreads();
+  red[ty][tx] = q;
+  __syncthreads();
+  if (ty == 0 && col < Npad) {
+    float* sp = stat_partial + (size_t)blockIdx.x * 3 * Npad + col;
+    sp[0] = (float)nvalid_rows;
+    sp[Npad] = mu;
+    sp[2 * Npad] = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+  }
+}
+
+static int launch_conv_fwd_inner(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int nsrc,
+                                 const float* wp, const float* bias, float* out, int ldo, int pre_act,
+                                 float* stat_partial, int* rows_per_block, int accumulate, int ksplit);
+
 int launch_conv_fwd(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int nsrc,
                     const float* wp, const float* bias, float* out, int ldo, int pre_act,
-                    float* stat_partial, int* rows_per_block, int accumulate) {
+                    float* stat_partial, int* rows_per_block, int accumulate, float* ws, size_t ws_floats) {
+  ConvSrc s0 = src[0], s1 = src[nsrc > 1 ? 1 : 0];
+  if (nsrc == 1) s1.C = 0;
+  const int ks = ws ? fwd_splitk_plan(g, s0, s1, nsrc) : 1;
+  if (ks <= 1) return launch_conv_fwd_inner(st, g, src, nsrc, wp, bias, out, ldo, pre_act, stat_partial,
+                                            rows_per_block, accumulate, 1);
+  const int M = g.B << (3 * g.lgS);
+  ICS_CHECK((size_t)ks * M * g.Npad <= ws_floats, "forward split-K workspace too small");
+  ICS_TRY(launch_conv_fwd_inner(st, g, src, nsrc, wp, nullptr, ws, g.Npad, ACT_NONE, nullptr, nullptr, 0, ks));
+  hipLaunchKernelGGL(splitk_finish_kernel, dim3((M + 63) / 64, g.Npad / 64), dim3(256), 0, st, ws, ks, M, g.Cout,
+                     g.Npad, bias, act_slope_of(pre_act), out, ldo, accumulate, stat_partial);
+  ICS_HIP(hipGetLastError());
+  if (rows_per_block) *rows_per_block = 64;
+  return 0;
+}
+
+static int launch_conv_fwd_inner(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int nsrc,
+                                 const float* wp, const float* bias, float* out, int ldo, int pre_act,
+                                 float* stat_partial, int* rows_per_block, int accumulate, int ksplit) {
   ConvSrc s0 = src[0], s1 = src[nsrc > 1 ? 1 : 0];
   if (nsrc == 1) s1.C = 0;
   // loader variants: 0 = plain sources (backward-data, pooled inputs), 1 = BN affine/activation,
@@ -695,7 +818,7 @@ int launch_conv_fwd(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int n
   static const bool no_reuse = getenv("ICSG3D_NO_REUSE") != nullptr;   // A/B switch for benchmarking
   int bm, bn;
   pick_fwd_tile(g, &bm, &bn);
-#define ICS_FWD_ARGS st, g, s0, s1, wp, bias, out, ldo, pre_act, stat_partial, rows_per_block, accumulate
+#define ICS_FWD_ARGS st, g, s0, s1, wp, bias, out, ldo, pre_act, stat_partial, rows_per_block, accumulate, ksplit
 #define ICS_FWD(WM, WN, TM, TN)                                                                 \
   do {                                                                                          \
     if (thin) return launch_fwd_cfg<WM, WN, TM, TN, true, 0, true, true, true>(ICS_FWD_ARGS);   \
@@ -1372,6 +1495,11 @@ static int launch_wgrad_cfg(hipStream_t st, const ConvGeom& g, const ConvSrc& s0
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
+  static const std::string id = std::string("conv_wgrad_kernel<") + std::to_string(WM) + ", " + std::to_string(WN) +
+                                ", " + std::to_string(TM) + ", " + std::to_string(TN) + ", " + tf(VEC) + ", " +
+                                tf(DYVEC) + ", " + tf(AFF) + ", " + tf(UP) + ", " + tf(THIN) + ", " +
+                                std::to_string(ABL) + ">";
+  g_last_kernel_id = id.c_str();
   hipLaunchKernelGGL(kern, dim3(p.ktiles * p.ntiles * p.ksplit), dim3(256), lds, st, g, s0, s1, dy,
                      ldy, n_load, ws, p.ktiles, p.ntiles, p.rows_per_split);
   ICS_HIP(hipGetLastError());
@@ -1393,7 +1521,7 @@ int launch_conv_wgrad_ablate(hipStream_t st, const ConvGeom& g, const ConvSrc* s
 
 int launch_conv_wgrad(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int nsrc,
                       const float* dy, int ldy, float* dw, int ldw, float* workspace,
-                      size_t workspace_floats, int sub_rows, int row_pitch, int row_off) {
+                      size_t workspace_floats, int sub_rows, int row_pitch, int row_off, int phase) {
   ConvSrc s0 = src[0], s1 = src[nsrc > 1 ? 1 : 0];
   if (nsrc == 1) s1.C = 0;
   ICS_TRY(fix_src(s0));
@@ -1417,19 +1545,26 @@ int launch_conv_wgrad(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int
     const int arows = 32 + (32 >> g.lgS) + 1;
     const size_t lds = (size_t)2 * (arows * 64 + 32 * 128) * sizeof(float);
     const dim3 grid(9 * q.cgroups * q.ntiles * q.ksplit);
-    if (up) hipLaunchKernelGGL((conv_wgrad3_kernel<true, true>), grid, dim3(256), lds, st, g, s0, s1, dy, ldy, n_load,
-                               workspace, q.cgroups, q.ntiles, q.rows_per_split);
-    else if (aff) hipLaunchKernelGGL((conv_wgrad3_kernel<true, false>), grid, dim3(256), lds, st, g, s0, s1, dy, ldy,
-                                     n_load, workspace, q.cgroups, q.ntiles, q.rows_per_split);
-    else hipLaunchKernelGGL((conv_wgrad3_kernel<false, false>), grid, dim3(256), lds, st, g, s0, s1, dy, ldy, n_load,
-                            workspace, q.cgroups, q.ntiles, q.rows_per_split);
-    ICS_HIP(hipGetLastError());
-    hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((n_elems + 255) / 256)), dim3(256), 0, st, workspace,
-                       q.ksplit, n_elems, g.Cout, dw, ldw, sub_rows, row_pitch, row_off);
-    ICS_HIP(hipGetLastError());
+    if (phase != 2) {
+      g_last_kernel_id = up ? "conv_wgrad3_kernel<true, true>" : aff ? "conv_wgrad3_kernel<true, false>"
+                                                                      : "conv_wgrad3_kernel<false, false>";
+      if (up) hipLaunchKernelGGL((conv_wgrad3_kernel<true, true>), grid, dim3(256), lds, st, g, s0, s1, dy, ldy, n_load,
+                                 workspace, q.cgroups, q.ntiles, q.rows_per_split);
+      else if (aff) hipLaunchKernelGGL((conv_wgrad3_kernel<true, false>), grid, dim3(256), lds, st, g, s0, s1, dy, ldy,
+                                       n_load, workspace, q.cgroups, q.ntiles, q.rows_per_split);
+      else hipLaunchKernelGGL((conv_wgrad3_kernel<false, false>), grid, dim3(256), lds, st, g, s0, s1, dy, ldy, n_load,
+                              workspace, q.cgroups, q.ntiles, q.rows_per_split);
+      ICS_HIP(hipGetLastError());
+    }
+    if (phase != 1) {
+      hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((n_elems + 255) / 256)), dim3(256), 0, st, workspace,
+                         q.ksplit, n_elems, g.Cout, dw, ldw, sub_rows, row_pitch, row_off);
+      ICS_HIP(hipGetLastError());
+    }
     return 0;
   }
   ICS_CHECK((size_t)p.ksplit * n_elems <= workspace_floats, "wgrad workspace too small");
+  if (phase != 2) {
 #define ICS_WG_ARGS st, g, s0, s1, dy, ldy, n_load, workspace, p
 #define ICS_WG(WM, WN, TM, TN, DV)                                                                 \
   do {                                                                                             \
@@ -1456,10 +1591,13 @@ int launch_conv_wgrad(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int
   }
 #undef ICS_WG_ARGS
 #undef ICS_WG
-  const int thr = 256;
-  hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((n_elems + thr - 1) / thr)), dim3(thr), 0,
-                     st, workspace, p.ksplit, n_elems, g.Cout, dw, ldw, sub_rows, row_pitch, row_off);
-  ICS_HIP(hipGetLastError());
+  }
+  if (phase != 1) {
+    const int thr = 256;
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((n_elems + thr - 1) / thr)), dim3(thr), 0,
+                       st, workspace, p.ksplit, n_elems, g.Cout, dw, ldw, sub_rows, row_pitch, row_off);
+    ICS_HIP(hipGetLastError());
+  }
   return 0;
 }
 

@@ -40,7 +40,7 @@ struct Tensor {
 
 struct Profiler {
   struct Row { std::string label; int64_t launches = 0; double ms = 0, flop = 0, bytes = 0; };
-  struct Pending { int row; hipEvent_t a, b; };
+  struct Pending { int row; hipEvent_t a, b; std::string label; double flop, bytes; };
   bool on = false;
   std::vector<Row> rows;
   std::map<std::string, int> index;
@@ -50,20 +50,25 @@ struct Profiler {
     if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
     hipEvent_t e; (void)hipEventCreate(&e); return e;
   }
+  // A label ending in '|' gets the exact template instantiation of the conv kernel launched inside the
+  // bracket appended at end() (conv_last_kernel_id(): the name rocprofv3 prints for the same launch).
   void begin(hipStream_t st, const std::string& label, double flop, double bytes) {
     if (!on) return;
-    auto it = index.find(label);
-    int r;
-    if (it == index.end()) { r = (int)rows.size(); rows.push_back(Row{label}); index[label] = r; }
-    else r = it->second;
-    rows[r].launches += 1; rows[r].flop += flop; rows[r].bytes += bytes;
-    Pending p{r, get(), get()};
+    Pending p{-1, get(), get(), label, flop, bytes};
     (void)hipEventRecord(p.a, st);
     pending.push_back(p);
   }
   void end(hipStream_t st) {
     if (!on) return;
-    (void)hipEventRecord(pending.back().b, st);
+    Pending& p = pending.back();
+    (void)hipEventRecord(p.b, st);
+    if (!p.label.empty() && p.label.back() == '|') p.label += conv_last_kernel_id();
+    auto it = index.find(p.label);
+    int r;
+    if (it == index.end()) { r = (int)rows.size(); rows.push_back(Row{p.label}); index[p.label] = r; }
+    else r = it->second;
+    rows[r].launches += 1; rows[r].flop += p.flop; rows[r].bytes += p.bytes;
+    p.row = r;
   }
   void resolve() {   // call after a stream sync
     for (auto& p : pending) {
@@ -130,6 +135,10 @@ struct Net {
   float* ws_stat = nullptr;  size_t ws_stat_n = 0;
   float* ws_bwd = nullptr;   size_t ws_bwd_n = 0;
   float* ws_wgrad = nullptr; size_t ws_wgrad_n = 0;
+  float* ws_fwd = nullptr;   size_t ws_fwd_n = 0;     // forward / backward-data split-K partial sums
+  bool splitk = false;       // split-K only inside train steps: its plan depends on the batch size, and
+                             // inference keeps "a sample's output does not depend on its batch" bit-exact
+  float* fws() const { return splitk ? ws_fwd : nullptr; }
   double* ws_dbl = nullptr;  size_t ws_dbl_n = 0;
   float* d_metrics = nullptr;
   // data parallel
@@ -302,14 +311,22 @@ static int enable_split_up(Net& n, ConvLayer& L) {
 
 // workspace sizing over all layers (max batch)
 static int alloc_workspaces(Net& n, bool need_bwd) {
-  size_t stat = 0, bwd = 0, wg = 0;
+  size_t stat = 0, bwd = 0, wg = 0, fw = 0;
   for (auto& Lp : n.layers) {
     ConvLayer& L = *Lp;
     const size_t M = n.rows(L, n.maxB);
     const ConvGeom g = geom_fwd(L, n.maxB);
     const int rpb = conv_fwd_rows_per_block(g);
     stat = std::max(stat, (M + rpb - 1) / rpb * 3 * (size_t)L.Npad);
+    fw = std::max(fw, conv_fwd_workspace_floats(g, L.src, L.nsrc));
     if (need_bwd) {
+      const ConvSrc sdy = src_plain(L.dy, L.Cout);
+      fw = std::max(fw, conv_fwd_workspace_floats(geom_bwd(L, n.maxB), &sdy, 1));
+      if (L.split_up) {
+        const ConvSrc sd = src_plain(L.dyS, 27 * L.Cout);
+        fw = std::max(fw, conv_fwd_workspace_floats(geom_up_dgrad(L, n.maxB), &sd, 1));
+        fw = std::max(fw, conv_fwd_workspace_floats(geom_skip_dgrad(L, n.maxB), &sdy, 1));
+      }
       LayerBwd lb{};
       lb.B = n.maxB; lb.S = L.S; lb.lgS = ilog2(L.S); lb.C = L.Cout;
       // Cout may be a non power of two only for the head, which never goes through layer_bwd
@@ -324,6 +341,8 @@ static int alloc_workspaces(Net& n, bool need_bwd) {
   }
   n.ws_stat_n = stat; n.ws_bwd_n = std::max(bwd, (size_t)4096 * 128); n.ws_wgrad_n = wg;
   ICS_TRY(n.alloc(&n.ws_stat, stat + 16));
+  n.ws_fwd_n = fw;
+  if (fw) ICS_TRY(n.alloc(&n.ws_fwd, fw + 16));
   if (need_bwd) {
     ICS_TRY(n.alloc(&n.ws_bwd, n.ws_bwd_n + 16));
     ICS_TRY(n.alloc(&n.ws_wgrad, wg + 16));
@@ -403,20 +422,20 @@ static int conv_forward(Net& n, ConvLayer& L, int B, bool training, bool update_
     // the epilogue (bias, activation, BatchNorm statistics).
     const ConvGeom gp = geom_par_fwd(L, B), gs = geom_skip_fwd(L, B);
     const ConvSrc lo = src_lowres(L);
-    n.prof.begin(n.st, "conv_fwd:" + L.name + ".up|" + (n.prof.on ? conv_fwd_par_kernel_id(gp) : ""), 2.0 * M * 8 * L.Cu * L.Cout,
+    n.prof.begin(n.st, "conv_fwd:" + L.name + ".up|", 2.0 * M * 8 * L.Cu * L.Cout,
                  4.0 * (M / 8 * L.Cu + M * L.Cout + 64.0 * L.Cu * L.Cout));
     ICS_TRY(launch_conv_fwd_par(n.st, gp, lo, L.wp_par, L.s, L.Cout));
     n.prof.end(n.st);
-    n.prof.begin(n.st, "conv_fwd:" + L.name + ".skip|" + (n.prof.on ? conv_fwd_kernel_id(gs, L.src, 1) : ""), 2.0 * M * 27 * L.Cs * L.Cout,
+    n.prof.begin(n.st, "conv_fwd:" + L.name + ".skip|", 2.0 * M * 27 * L.Cs * L.Cout,
                  4.0 * (M * L.Cs + 2 * M * L.Cout + 27.0 * L.Cs * L.Cout));
     ICS_TRY(launch_conv_fwd(n.st, gs, L.src, 1, L.wp_skip, bias, L.s, L.Cout, L.pre_act, stats ? n.ws_stat : nullptr,
                             &rpb, 1));
     n.prof.end(n.st);
   } else {
-  n.prof.begin(n.st, "conv_fwd:" + L.name + "|" + (n.prof.on ? conv_fwd_kernel_id(g, L.src, L.nsrc) : ""), 2.0 * M * L.taps * L.Cin * L.Cout,
+  n.prof.begin(n.st, "conv_fwd:" + L.name + "|", 2.0 * M * L.taps * L.Cin * L.Cout,
                4.0 * (M * L.Cin + M * L.Cout + (double)L.taps * L.Cin * L.Cout));
   ICS_TRY(launch_conv_fwd(n.st, g, L.src, L.nsrc, L.wp, bias, L.s, L.Cout, L.pre_act,
-                          stats ? n.ws_stat : nullptr, &rpb));
+                          stats ? n.ws_stat : nullptr, &rpb, 0, n.fws(), n.ws_fwd_n));
   n.prof.end(n.st);
   }
   if (L.has_bn) {
@@ -479,35 +498,46 @@ static int conv_grads_split_up(Net& n, ConvLayer& L, int B) {
   n.prof.end(n.st);
   {
     const ConvGeom g = geom_skip_wgrad(L, B);
-    n.prof.begin(n.st, "conv_wgrad:" + L.name + ".skip|" + (n.prof.on ? conv_wgrad_kernel_id(g, L.src, 1) : ""), fl_skip,
+    n.prof.begin(n.st, "conv_wgrad:" + L.name + ".skip|", fl_skip,
                  4.0 * (M * L.Cs + M * L.Cout + 27.0 * L.Cs * L.Cout));
     ICS_TRY(launch_conv_wgrad(n.st, g, L.src, 1, L.dy, L.Cout, n.tg(L.t_w), L.Cout, n.ws_wgrad, n.ws_wgrad_n, L.Cs,
-                              L.Cin, 0));
+                              L.Cin, 0, 1));
+    n.prof.end(n.st);
+    n.prof.begin(n.st, "wgrad_reduce_splits", 0, 0);
+    ICS_TRY(launch_conv_wgrad(n.st, g, L.src, 1, L.dy, L.Cout, n.tg(L.t_w), L.Cout, n.ws_wgrad, n.ws_wgrad_n, L.Cs,
+                              L.Cin, 0, 2));
     n.prof.end(n.st);
   }
   {
     const ConvGeom g = geom_up_wgrad(L, B);
     const ConvSrc lo = src_lowres(L);
-    n.prof.begin(n.st, "conv_wgrad:" + L.name + ".up|" + (n.prof.on ? conv_wgrad_kernel_id(g, &lo, 1) : ""), fl_up,
+    n.prof.begin(n.st, "conv_wgrad:" + L.name + ".up|", fl_up,
                  4.0 * (M / 8 * L.Cu + M / 8 * 27.0 * L.Cout + 27.0 * L.Cu * L.Cout));
-    ICS_TRY(launch_conv_wgrad(n.st, g, &lo, 1, L.dyS, 27 * L.Cout, L.dw_up, 27 * L.Cout, n.ws_wgrad, n.ws_wgrad_n));
+    ICS_TRY(launch_conv_wgrad(n.st, g, &lo, 1, L.dyS, 27 * L.Cout, L.dw_up, 27 * L.Cout, n.ws_wgrad, n.ws_wgrad_n, 0, 0,
+                              0, 1));
+    n.prof.end(n.st);
+    n.prof.begin(n.st, "wgrad_reduce_splits", 0, 0);
+    ICS_TRY(launch_conv_wgrad(n.st, g, &lo, 1, L.dyS, 27 * L.Cout, L.dw_up, 27 * L.Cout, n.ws_wgrad, n.ws_wgrad_n, 0, 0,
+                              0, 2));
     ICS_TRY(launch_permute_up_dw(n.st, L.dw_up, L.Cu, L.Cout, L.Cin, L.Cs, n.tg(L.t_w)));
     n.prof.end(n.st);
   }
   {
     const ConvGeom g = geom_skip_dgrad(L, B);
     ConvSrc sdy = src_plain(L.dy, L.Cout);
-    n.prof.begin(n.st, "conv_dgrad:" + L.name + ".skip|" + (n.prof.on ? conv_fwd_kernel_id(g, &sdy, 1) : ""), fl_skip,
+    n.prof.begin(n.st, "conv_dgrad:" + L.name + ".skip|", fl_skip,
                  4.0 * (M * L.Cs + M * L.Cout + 27.0 * L.Cs * L.Cout));
-    ICS_TRY(launch_conv_fwd(n.st, g, &sdy, 1, L.wf_skip, nullptr, L.dA_skip, L.Cs, ACT_NONE, nullptr, nullptr));
+    ICS_TRY(launch_conv_fwd(n.st, g, &sdy, 1, L.wf_skip, nullptr, L.dA_skip, L.Cs, ACT_NONE, nullptr, nullptr, 0,
+                            n.fws(), n.ws_fwd_n));
     n.prof.end(n.st);
   }
   {
     const ConvGeom g = geom_up_dgrad(L, B);
     ConvSrc sd = src_plain(L.dyS, 27 * L.Cout);
-    n.prof.begin(n.st, "conv_dgrad:" + L.name + ".up|" + (n.prof.on ? conv_fwd_kernel_id(g, &sd, 1) : ""), fl_up,
+    n.prof.begin(n.st, "conv_dgrad:" + L.name + ".up|", fl_up,
                  4.0 * (M / 8 * L.Cu + M / 8 * 27.0 * L.Cout + 27.0 * L.Cu * L.Cout));
-    ICS_TRY(launch_conv_fwd(n.st, g, &sd, 1, L.w_up, nullptr, L.dxl, L.Cu, ACT_NONE, nullptr, nullptr));
+    ICS_TRY(launch_conv_fwd(n.st, g, &sd, 1, L.w_up, nullptr, L.dxl, L.Cu, ACT_NONE, nullptr, nullptr, 0, n.fws(),
+                            n.ws_fwd_n));
     n.prof.end(n.st);
   }
   return 0;
@@ -519,10 +549,13 @@ static int conv_grads_from_dy(Net& n, ConvLayer& L, int B, bool need_dA, bool pa
   const ConvGeom g = geom_fwd(L, B);
   const size_t M = n.rows(L, B);
   if (param_grads) {
-    n.prof.begin(n.st, "conv_wgrad:" + L.name + "|" + (n.prof.on ? conv_wgrad_kernel_id(g, L.src, L.nsrc) : ""), 2.0 * M * L.taps * L.Cin * L.Cout,
+    n.prof.begin(n.st, "conv_wgrad:" + L.name + "|", 2.0 * M * L.taps * L.Cin * L.Cout,
                  4.0 * (M * L.Cin + M * L.Cout + (double)L.taps * L.Cin * L.Cout));
     float* dw = L.dw_phys ? L.dw_phys : n.tg(L.t_w);
-    ICS_TRY(launch_conv_wgrad(n.st, g, L.src, L.nsrc, L.dy, L.Cout, dw, L.Cout, n.ws_wgrad, n.ws_wgrad_n));
+    ICS_TRY(launch_conv_wgrad(n.st, g, L.src, L.nsrc, L.dy, L.Cout, dw, L.Cout, n.ws_wgrad, n.ws_wgrad_n, 0, 0, 0, 1));
+    n.prof.end(n.st);
+    n.prof.begin(n.st, "wgrad_reduce_splits", 0, 0);
+    ICS_TRY(launch_conv_wgrad(n.st, g, L.src, L.nsrc, L.dy, L.Cout, dw, L.Cout, n.ws_wgrad, n.ws_wgrad_n, 0, 0, 0, 2));
     if (L.dw_phys) {
       const size_t cnt = (size_t)L.taps * L.Cin * L.Cout;
       hipLaunchKernelGGL(unpad_dw_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, n.st, L.dw_phys, L.Cin,
@@ -534,9 +567,10 @@ static int conv_grads_from_dy(Net& n, ConvLayer& L, int B, bool need_dA, bool pa
   if (need_dA) {
     const ConvGeom gb = geom_bwd(L, B);
     ConvSrc sdy = src_plain(L.dy, L.Cout);
-    n.prof.begin(n.st, "conv_dgrad:" + L.name + "|" + (n.prof.on ? conv_fwd_kernel_id(gb, &sdy, 1) : ""), 2.0 * M * L.taps * L.Cin * L.Cout,
+    n.prof.begin(n.st, "conv_dgrad:" + L.name + "|", 2.0 * M * L.taps * L.Cin * L.Cout,
                  4.0 * (M * L.Cin + M * L.Cout + (double)L.taps * L.Cin * L.Cout));
-    ICS_TRY(launch_conv_fwd(n.st, gb, &sdy, 1, L.wf, nullptr, L.dA, L.CinG, ACT_NONE, nullptr, nullptr));
+    ICS_TRY(launch_conv_fwd(n.st, gb, &sdy, 1, L.wf, nullptr, L.dA, L.CinG, ACT_NONE, nullptr, nullptr, 0, n.fws(),
+                            n.ws_fwd_n));
     n.prof.end(n.st);
   }
   return 0;
@@ -744,7 +778,7 @@ static int unet_backward(Net& n, int B) {
   const ConvGeom gh = geom_fwd(H, B);
   {
     ConvGeom gs = gh; gs.Cout = n.ncls; gs.Npad = round_up(n.ncls, 32);
-    n.prof.begin(n.st, std::string("conv_wgrad:head|") + (n.prof.on ? conv_wgrad_kernel_id(gs, H.src, 1) : ""), 2.0 * M * 128 * nc1, 4.0 * M * (128 + nc1));
+    n.prof.begin(n.st, "conv_wgrad:head|", 2.0 * M * 128 * nc1, 4.0 * M * (128 + nc1));
     ICS_TRY(launch_conv_wgrad(n.st, gs, H.src, 1, H.s, nc1, n.tg(H.t_w), n.ncls, n.ws_wgrad, n.ws_wgrad_n));
     ConvGeom gg = gh; gg.Cout = 1; gg.Npad = 32;
     ICS_TRY(launch_conv_wgrad(n.st, gg, H.src, 1, H.s + n.ncls, nc1, n.tg(H.t_gamma), 1, n.ws_wgrad, n.ws_wgrad_n));
@@ -752,7 +786,7 @@ static int unet_backward(Net& n, int B) {
     ICS_TRY(colsum(n, H.s, M, nc1, nc1, n.tg(H.t_b)));   // soft/bias | sig/bias are contiguous
     const ConvGeom gb = geom_bwd(H, B);
     ConvSrc sdz = src_plain(H.s, nc1);
-    n.prof.begin(n.st, std::string("conv_dgrad:head|") + (n.prof.on ? conv_fwd_kernel_id(gb, &sdz, 1) : ""), 2.0 * M * 128 * nc1, 4.0 * M * (128 + nc1));
+    n.prof.begin(n.st, "conv_dgrad:head|", 2.0 * M * 128 * nc1, 4.0 * M * (128 + nc1));
     ICS_TRY(launch_conv_fwd(n.st, gb, &sdz, 1, H.wf, nullptr, H.dA, 128, ACT_NONE, nullptr, nullptr));
     n.prof.end(n.st);
   }
@@ -796,7 +830,14 @@ static int unet_pm_backward(Net& n, int B) {
   return 0;
 }
 
+static int unet_train_resident_impl(Net& n, int B, float* metrics);
 static int unet_train_resident(Net& n, int B, float* metrics) {
+  n.splitk = true;
+  const int rc = unet_train_resident_impl(n, B, metrics);
+  n.splitk = false;
+  return rc;
+}
+static int unet_train_resident_impl(Net& n, int B, float* metrics) {
   ICS_TRY(unet_forward_trunk(n, B, true, true, false, n.x_in));
   ICS_TRY(unet_head_forward(n, B));
   ICS_TRY(unet_loss(n, B, 1, 1));
@@ -969,6 +1010,7 @@ static int vae_step(Net& n, int B, bool training, float* metrics) {
   Net& u = *n.pm;
   hipStream_t saved = u.st;
   u.st = n.st;
+  n.splitk = u.splitk = training;
   int rc = 0;
   do {
     VaeRefs r = vae_refs(n);
@@ -1046,6 +1088,7 @@ static int vae_step(Net& n, int B, bool training, float* metrics) {
     }
   } while (0);
   u.st = saved;
+  n.splitk = u.splitk = false;
   return rc;
 }
 

@@ -6,18 +6,8 @@ import csv, glob, json, re, sys, collections
 
 
 def bench_id(short):
-    """template instantiation name -> the kernel id bench.py / the engine profiler use"""
-    m = re.match(r"(\w+)<(.*)>$", short.strip())
-    if not m:
-        return short.strip()
-    base, args = m.group(1), [a.strip() for a in m.group(2).split(",")]
-    if base == "conv_fwd_kernel":
-        par = len(args) > 10 and args[10] == "true"
-        return "conv_fwd_kernel<%s,%s%s>" % (",".join(args[:4]), "vec" if args[4] == "true" else "scalar",
-                                             ",par" if par else "")
-    if base == "conv_wgrad_kernel":
-        return "conv_wgrad_kernel<%s,%s>" % (",".join(args[:4]), "vec" if args[4] == "true" else "scalar")
-    return base
+    """bench.py / the engine profiler label kernels by their exact template instantiation"""
+    return short.strip()
 
 d = sys.argv[1]
 filt = sys.argv[2:]
