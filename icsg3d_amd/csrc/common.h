@@ -81,7 +81,8 @@ int launch_conv_fwd(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int n
                     float* splitk_ws = nullptr, size_t splitk_ws_floats = 0);
 size_t conv_fwd_workspace_floats(const ConvGeom& g, const ConvSrc* src, int nsrc);
 int launch_conv_fwd_par(hipStream_t st, const ConvGeom& g_lowres, const ConvSrc& src, const float* wpar, float* out,
-                        int ldo);
+                        int ldo, const float* bias = nullptr, int pre_act = ACT_NONE, float* stat_partial = nullptr,
+                        int* stat_blocks = nullptr);
 const char* conv_fwd_par_kernel_id(const ConvGeom& g_lowres);
 int launch_pack_par(hipStream_t st, const float* w, int Cin_total, int Cout, int c_off, int Cu, float* dst, int Kpad,
                     int Npad);

@@ -626,7 +626,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
     float q = 0.f;
 #pragma unroll
     for (int w = 0; w < WM; ++w) q += red[w * BN + t];
-    float* sp = stat_partial + (size_t)mb * 3 * g.Npad + n0 + t;
+    float* sp = stat_partial + (size_t)(cls * gridM + mb) * 3 * g.Npad + n0 + t;   // PAR: 8 x gridM blocks
     sp[0] = (float)nvalid_rows;
     sp[g.Npad] = bmean[t];
     sp[2 * g.Npad] = q;
@@ -861,7 +861,7 @@ const char* conv_fwd_par_kernel_id(const ConvGeom& g) {
   return "conv_fwd_kernel<4,1,1,1,vec,par>";
 }
 int launch_conv_fwd_par(hipStream_t st, const ConvGeom& g, const ConvSrc& src, const float* wp, float* out,
-                        int ldo) {
+                        int ldo, const float* bias, int pre_act, float* stat_partial, int* stat_blocks) {
   ConvSrc s0 = src, s1 = src;
   s1.C = 0;
   ICS_CHECK(g.taps == 8 && g.Cin % 32 == 0 && s0.C == g.Cin && !s0.up && !s0.bcast && g.Kpad == 8 * g.Cin,
@@ -870,13 +870,17 @@ int launch_conv_fwd_par(hipStream_t st, const ConvGeom& g, const ConvSrc& src, c
   ICS_TRY(fix_src(s1));
   int bm, bn;
   pick_par_tile(g, &bm, &bn);
-#define ICS_PAR_ARGS st, g, s0, s1, wp, nullptr, out, ldo, ACT_NONE, nullptr, nullptr
-  if (bm == 64) return launch_fwd_cfg<2, 2, 1, 1, true, 0, true, false, false, false, true>(ICS_PAR_ARGS);
-  if (bn == 128) return launch_fwd_cfg<2, 2, 2, 2, true, 0, true, false, false, false, true>(ICS_PAR_ARGS);
-  if (bn == 96) return launch_fwd_cfg<4, 1, 1, 3, true, 0, true, false, false, false, true>(ICS_PAR_ARGS);
-  if (bn == 64) return launch_fwd_cfg<2, 2, 2, 1, true, 0, true, false, false, false, true>(ICS_PAR_ARGS);
-  return launch_fwd_cfg<4, 1, 1, 1, true, 0, true, false, false, false, true>(ICS_PAR_ARGS);
+  int rpb = 0;
+#define ICS_PAR_ARGS st, g, s0, s1, wp, bias, out, ldo, pre_act, stat_partial, &rpb
+  int rc;
+  if (bm == 64) rc = launch_fwd_cfg<2, 2, 1, 1, true, 0, true, false, false, false, true>(ICS_PAR_ARGS);
+  else if (bn == 128) rc = launch_fwd_cfg<2, 2, 2, 2, true, 0, true, false, false, false, true>(ICS_PAR_ARGS);
+  else if (bn == 96) rc = launch_fwd_cfg<4, 1, 1, 3, true, 0, true, false, false, false, true>(ICS_PAR_ARGS);
+  else if (bn == 64) rc = launch_fwd_cfg<2, 2, 2, 1, true, 0, true, false, false, false, true>(ICS_PAR_ARGS);
+  else rc = launch_fwd_cfg<4, 1, 1, 1, true, 0, true, false, false, false, true>(ICS_PAR_ARGS);
 #undef ICS_PAR_ARGS
+  if (stat_blocks) *stat_blocks = 8 * (((g.B << (3 * g.lgS)) + rpb - 1) / rpb);
+  return rc;
 }
 
 // pre-summed parity weights: dst[cls][k = e*Cu + c][n] = sum over taps d with (per axis)

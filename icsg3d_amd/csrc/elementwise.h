@@ -65,7 +65,7 @@ int launch_vae_dz(hipStream_t st, const float* mulv, int ld, int latent, int B, 
 int launch_relu_bwd(hipStream_t st, const float* a, float* g, size_t n);
 int launch_colsum_small(hipStream_t st, const float* a, int rows, int cols, int ld, float* out);
 int launch_axpy(hipStream_t st, float* y, const float* x, size_t n, float a);
-int launch_pool27(hipStream_t st, const float* dy, int B, int S, int N, float* out);
+int launch_pool27(hipStream_t st, const float* dy, int B, int S, int N, float* out, int ldo);
 int launch_permute_up_dw(hipStream_t st, const float* tmp, int Cu, int N, int Cin, int c_off, float* dw);
 
 }  // namespace ics

@@ -545,7 +545,7 @@ int launch_head(hipStream_t st, float* z, int ldz, int ncls, const unsigned char
 // coordinate 2a-1+s:  d=+1 -> slots {0,1}, d=0 -> {1,2}, d=-1 -> {2,3}.  Separable sums in registers.
 // ------------------------------------------------------------------------------------------
 __global__ void pool27_kernel(const float* __restrict__ dy, int B, int S, int N, size_t total,
-                              float* __restrict__ out) {
+                              float* __restrict__ out, int ldo) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int Sh = S >> 1;
@@ -594,11 +594,11 @@ __global__ void pool27_kernel(const float* __restrict__ dy, int B, int S, int N,
       }
   }
 #pragma unroll
-  for (int k = 0; k < 27; ++k) out[(vl * 27 + k) * N + n] = o[k];
+  for (int k = 0; k < 27; ++k) out[vl * ldo + (size_t)k * N + n] = o[k];
 }
-int launch_pool27(hipStream_t st, const float* dy, int B, int S, int N, float* out) {
+int launch_pool27(hipStream_t st, const float* dy, int B, int S, int N, float* out, int ldo) {
   const size_t total = (size_t)B * (S / 2) * (S / 2) * (S / 2) * N;
-  hipLaunchKernelGGL(pool27_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dy, B, S, N, total, out);
+  hipLaunchKernelGGL(pool27_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dy, B, S, N, total, out, ldo);
   ICS_HIP(hipGetLastError());
   return 0;
 }

@@ -110,7 +110,8 @@ struct ConvLayer {
   int Cs = 0, Cu = 0;
   float *wf_skip = nullptr, *w_up = nullptr;   // packed: dgrad of the skip channels; dxl = dyS x W_up
   float *wp_skip = nullptr, *wp_par = nullptr; // packed forward: skip channels (27 taps); 8 parity classes x 8 taps
-  float *dyS = nullptr;                        // [M/8][27*Cout] tap-pooled dy
+  float *dyS = nullptr;                        // [M/8][ldS] tap-pooled dy, ldS = 27*Cout rounded up to 32 (pad = 0)
+  int ldS = 0;
   float *dA_skip = nullptr, *dxl = nullptr;    // [M][Cs] grad of the skip input; [M/8][Cu] grad of the low-res input
   float *dw_up = nullptr;                      // [Cu][27*Cout] GEMM result before the permute into G
 };
@@ -271,10 +272,10 @@ static ConvGeom geom_bwd(const ConvLayer& L, int B) {
 
 // up-split GEMM geometries (see ConvLayer::split_up)
 static ConvGeom geom_up_wgrad(const ConvLayer& L, int B) {   // dw_up[Cu][27N] = xl^T x dyS over the S/2 grid
-  return ConvGeom{B, L.S / 2, ilog2(L.S / 2), L.Cu, 27 * L.Cout, 1, round_up(L.Cu, 32), round_up(27 * L.Cout, 32)};
+  return ConvGeom{B, L.S / 2, ilog2(L.S / 2), L.Cu, 27 * L.Cout, 1, round_up(L.Cu, 32), L.ldS};
 }
 static ConvGeom geom_up_dgrad(const ConvLayer& L, int B) {   // dxl[M/8][Cu] = dyS x W_up
-  return ConvGeom{B, L.S / 2, ilog2(L.S / 2), 27 * L.Cout, L.Cu, 1, round_up(27 * L.Cout, 32), round_up(L.Cu, 32)};
+  return ConvGeom{B, L.S / 2, ilog2(L.S / 2), L.ldS, L.Cu, 1, L.ldS, round_up(L.Cu, 32)};
 }
 static ConvGeom geom_skip_wgrad(const ConvLayer& L, int B) {
   return ConvGeom{B, L.S, ilog2(L.S), L.Cs, L.Cout, L.taps, round_up(L.taps * L.Cs, 32), L.Npad};
@@ -288,24 +289,32 @@ static ConvGeom geom_skip_fwd(const ConvLayer& L, int B) {
 static ConvGeom geom_par_fwd(const ConvLayer& L, int B) {    // one parity class over the S/2 grid
   return ConvGeom{B, L.S / 2, ilog2(L.S / 2), L.Cu, L.Cout, 8, 8 * L.Cu, L.Npad};
 }
-static ConvSrc src_lowres(const ConvLayer& L) { ConvSrc u = L.src[1]; u.up = 0; return u; }
+static ConvSrc src_lowres(const ConvLayer& L) { ConvSrc u = L.src[L.nsrc - 1]; u.up = 0; return u; }
 
+// Layers whose (last) source is nearest-upsampled: [skip | up] concat convs (U-Net c13/c15/c17) and the VAE
+// decoder's d1..d3 (Cs = 0).
 static int enable_split_up(Net& n, ConvLayer& L) {
   if (getenv("ICSG3D_NO_UPSPLIT")) return 0;
-  if (L.nsrc != 2 || !L.src[1].up || L.taps != 27 || L.S < 2 || L.CinG != L.Cin || L.src[0].C % 32 ||
-      L.src[1].C % 32)
+  const ConvSrc& up = L.src[L.nsrc - 1];
+  const int Cs = L.nsrc == 2 ? L.src[0].C : 0;
+  if (!up.up || (L.nsrc == 2 && L.src[0].up) || L.taps != 27 || L.S < 2 || L.CinG != L.Cin || Cs % 32 || up.C % 32 ||
+      up.bcast)
     return 0;
   L.split_up = true;
-  L.Cs = L.src[0].C; L.Cu = L.src[1].C;
+  L.Cs = Cs; L.Cu = up.C;
+  L.ldS = round_up(27 * L.Cout, 32);
   const size_t M = n.rows(L, n.maxB);
-  ICS_TRY(n.alloc(&L.wf_skip, (size_t)L.Kpad_b * round_up(L.Cs, 32)));
-  ICS_TRY(n.alloc(&L.w_up, (size_t)round_up(27 * L.Cout, 32) * round_up(L.Cu, 32)));
-  ICS_TRY(n.alloc(&L.dyS, M / 8 * 27 * L.Cout));
-  ICS_TRY(n.alloc(&L.dA_skip, M * L.Cs));
+  ICS_TRY(n.alloc(&L.w_up, (size_t)L.ldS * round_up(L.Cu, 32)));
+  ICS_TRY(n.alloc(&L.dyS, M / 8 * L.ldS));
+  ICS_HIP(hipMemsetAsync(L.dyS, 0, M / 8 * L.ldS * sizeof(float), n.st));   // pad columns stay zero
   ICS_TRY(n.alloc(&L.dxl, M / 8 * L.Cu));
   ICS_TRY(n.alloc(&L.dw_up, (size_t)L.Cu * 27 * L.Cout));
-  ICS_TRY(n.alloc(&L.wp_skip, (size_t)round_up(L.taps * L.Cs, 32) * L.Npad));
   ICS_TRY(n.alloc(&L.wp_par, (size_t)8 * 8 * L.Cu * L.Npad));
+  if (L.Cs) {
+    ICS_TRY(n.alloc(&L.wf_skip, (size_t)L.Kpad_b * round_up(L.Cs, 32)));
+    ICS_TRY(n.alloc(&L.dA_skip, M * L.Cs));
+    ICS_TRY(n.alloc(&L.wp_skip, (size_t)round_up(L.taps * L.Cs, 32) * L.Npad));
+  }
   return 0;
 }
 
@@ -318,14 +327,15 @@ static int alloc_workspaces(Net& n, bool need_bwd) {
     const ConvGeom g = geom_fwd(L, n.maxB);
     const int rpb = conv_fwd_rows_per_block(g);
     stat = std::max(stat, (M + rpb - 1) / rpb * 3 * (size_t)L.Npad);
+    if (L.split_up) stat = std::max(stat, 8 * ((M / 8 + 63) / 64) * 3 * (size_t)L.Npad);   // parity launch: 8 x gridM blocks
     fw = std::max(fw, conv_fwd_workspace_floats(g, L.src, L.nsrc));
     if (need_bwd) {
       const ConvSrc sdy = src_plain(L.dy, L.Cout);
       fw = std::max(fw, conv_fwd_workspace_floats(geom_bwd(L, n.maxB), &sdy, 1));
       if (L.split_up) {
-        const ConvSrc sd = src_plain(L.dyS, 27 * L.Cout);
+        const ConvSrc sd = src_plain(L.dyS, L.ldS);
         fw = std::max(fw, conv_fwd_workspace_floats(geom_up_dgrad(L, n.maxB), &sd, 1));
-        fw = std::max(fw, conv_fwd_workspace_floats(geom_skip_dgrad(L, n.maxB), &sdy, 1));
+        if (L.Cs) fw = std::max(fw, conv_fwd_workspace_floats(geom_skip_dgrad(L, n.maxB), &sdy, 1));
       }
       LayerBwd lb{};
       lb.B = n.maxB; lb.S = L.S; lb.lgS = ilog2(L.S); lb.C = L.Cout;
@@ -335,7 +345,7 @@ static int alloc_workspaces(Net& n, bool need_bwd) {
       if (L.split_up) {
         const ConvSrc lo = src_lowres(L);
         wg = std::max(wg, conv_wgrad_workspace_floats(geom_up_wgrad(L, n.maxB), &lo, 1));
-        wg = std::max(wg, conv_wgrad_workspace_floats(geom_skip_wgrad(L, n.maxB), L.src, 1));
+        if (L.Cs) wg = std::max(wg, conv_wgrad_workspace_floats(geom_skip_wgrad(L, n.maxB), L.src, 1));
       }
     }
   }
@@ -390,14 +400,16 @@ static int pack_layer(Net& n, ConvLayer& L, bool need_bwd) {
   if (need_bwd && L.wf)
     ICS_TRY(launch_pack_bwd(n.st, n.tp(L.t_w), L.taps, L.Cin, L.Cout, L.wf, L.Kpad_b, L.Npad_b, L.Cout, 0, 1));
   if (L.split_up) {
-    ICS_TRY(launch_pack_fwd_sub(n.st, n.tp(L.t_w), L.taps, L.Cin, L.Cout, 0, L.Cs, L.wp_skip, round_up(L.taps * L.Cs, 32),
-                                L.Npad));
+    if (L.Cs)
+      ICS_TRY(launch_pack_fwd_sub(n.st, n.tp(L.t_w), L.taps, L.Cin, L.Cout, 0, L.Cs, L.wp_skip,
+                                  round_up(L.taps * L.Cs, 32), L.Npad));
     ICS_TRY(launch_pack_par(n.st, n.tp(L.t_w), L.Cin, L.Cout, L.Cs, L.Cu, L.wp_par, 8 * L.Cu, L.Npad));
   }
   if (need_bwd && L.split_up) {
-    ICS_TRY(launch_pack_sub(n.st, n.tp(L.t_w), L.taps, L.Cin, L.Cout, 0, L.Cs, 1, L.wf_skip, L.Kpad_b, round_up(L.Cs, 32)));
-    ICS_TRY(launch_pack_sub(n.st, n.tp(L.t_w), L.taps, L.Cin, L.Cout, L.Cs, L.Cu, 0, L.w_up, round_up(27 * L.Cout, 32),
-                            round_up(L.Cu, 32)));
+    if (L.Cs)
+      ICS_TRY(launch_pack_sub(n.st, n.tp(L.t_w), L.taps, L.Cin, L.Cout, 0, L.Cs, 1, L.wf_skip, L.Kpad_b,
+                              round_up(L.Cs, 32)));
+    ICS_TRY(launch_pack_sub(n.st, n.tp(L.t_w), L.taps, L.Cin, L.Cout, L.Cs, L.Cu, 0, L.w_up, L.ldS, round_up(L.Cu, 32)));
   }
   return 0;
 }
@@ -410,7 +422,7 @@ static int conv_forward(Net& n, ConvLayer& L, int B, bool training, bool update_
   const ConvGeom g = geom_fwd(L, B);
   const size_t M = n.rows(L, B);
   const bool stats = L.has_bn && training;
-  int rpb = 128;
+  int rpb = 128, par_blocks = 0;
   if (L.pad_in) {
     n.prof.begin(n.st, "materialize_input", 0, 4.0 * M * (L.Cin + L.CinG));
     ICS_TRY(launch_materialize_input(n.st, L.vsrc, L.nvsrc, L.Cin, L.CinG, B, L.S, L.pad_in));
@@ -422,15 +434,20 @@ static int conv_forward(Net& n, ConvLayer& L, int B, bool training, bool update_
     // the epilogue (bias, activation, BatchNorm statistics).
     const ConvGeom gp = geom_par_fwd(L, B), gs = geom_skip_fwd(L, B);
     const ConvSrc lo = src_lowres(L);
+    const bool only_up = L.Cs == 0;   // no skip part: the parity launch carries bias, activation and statistics
     n.prof.begin(n.st, "conv_fwd:" + L.name + ".up|", 2.0 * M * 8 * L.Cu * L.Cout,
                  4.0 * (M / 8 * L.Cu + M * L.Cout + 64.0 * L.Cu * L.Cout));
-    ICS_TRY(launch_conv_fwd_par(n.st, gp, lo, L.wp_par, L.s, L.Cout));
+    ICS_TRY(launch_conv_fwd_par(n.st, gp, lo, L.wp_par, L.s, L.Cout, only_up ? bias : nullptr,
+                                only_up ? L.pre_act : ACT_NONE, (only_up && stats) ? n.ws_stat : nullptr, &par_blocks));
     n.prof.end(n.st);
-    n.prof.begin(n.st, "conv_fwd:" + L.name + ".skip|", 2.0 * M * 27 * L.Cs * L.Cout,
-                 4.0 * (M * L.Cs + 2 * M * L.Cout + 27.0 * L.Cs * L.Cout));
-    ICS_TRY(launch_conv_fwd(n.st, gs, L.src, 1, L.wp_skip, bias, L.s, L.Cout, L.pre_act, stats ? n.ws_stat : nullptr,
-                            &rpb, 1));
-    n.prof.end(n.st);
+    if (!only_up) {
+      n.prof.begin(n.st, "conv_fwd:" + L.name + ".skip|", 2.0 * M * 27 * L.Cs * L.Cout,
+                   4.0 * (M * L.Cs + 2 * M * L.Cout + 27.0 * L.Cs * L.Cout));
+      ICS_TRY(launch_conv_fwd(n.st, gs, L.src, 1, L.wp_skip, bias, L.s, L.Cout, L.pre_act, stats ? n.ws_stat : nullptr,
+                              &rpb, 1));
+      n.prof.end(n.st);
+      par_blocks = 0;
+    }
   } else {
   n.prof.begin(n.st, "conv_fwd:" + L.name + "|", 2.0 * M * L.taps * L.Cin * L.Cout,
                4.0 * (M * L.Cin + M * L.Cout + (double)L.taps * L.Cin * L.Cout));
@@ -441,7 +458,7 @@ static int conv_forward(Net& n, ConvLayer& L, int B, bool training, bool update_
   if (L.has_bn) {
     BnParams bn{n.tp(L.t_gamma), n.tp(L.t_beta), L.mm, L.mv, L.mean, L.rstd, L.scale, L.shift};
     if (training) {
-      const int nblk = (int)((M + rpb - 1) / rpb);
+      const int nblk = par_blocks ? par_blocks : (int)((M + rpb - 1) / rpb);
       ICS_TRY(launch_bn_finalize(n.st, n.ws_stat, nblk, L.Npad, bn, L.Cout, update_moving ? 1 : 0, n.bn_unbias));
     } else {
       ICS_TRY(launch_bn_eval_prepare(n.st, bn, L.Cout));
@@ -494,9 +511,9 @@ static int conv_grads_split_up(Net& n, ConvLayer& L, int B) {
   const size_t M = n.rows(L, B);
   const double fl_skip = 2.0 * M * 27 * L.Cs * L.Cout, fl_up = 2.0 * (M / 8) * 27 * L.Cu * L.Cout;
   n.prof.begin(n.st, "pool27:" + L.name, 0, 4.0 * M * L.Cout * (1 + 27.0 / 8));
-  ICS_TRY(launch_pool27(n.st, L.dy, B, L.S, L.Cout, L.dyS));
+  ICS_TRY(launch_pool27(n.st, L.dy, B, L.S, L.Cout, L.dyS, L.ldS));
   n.prof.end(n.st);
-  {
+  if (L.Cs) {
     const ConvGeom g = geom_skip_wgrad(L, B);
     n.prof.begin(n.st, "conv_wgrad:" + L.name + ".skip|", fl_skip,
                  4.0 * (M * L.Cs + M * L.Cout + 27.0 * L.Cs * L.Cout));
@@ -513,16 +530,14 @@ static int conv_grads_split_up(Net& n, ConvLayer& L, int B) {
     const ConvSrc lo = src_lowres(L);
     n.prof.begin(n.st, "conv_wgrad:" + L.name + ".up|", fl_up,
                  4.0 * (M / 8 * L.Cu + M / 8 * 27.0 * L.Cout + 27.0 * L.Cu * L.Cout));
-    ICS_TRY(launch_conv_wgrad(n.st, g, &lo, 1, L.dyS, 27 * L.Cout, L.dw_up, 27 * L.Cout, n.ws_wgrad, n.ws_wgrad_n, 0, 0,
-                              0, 1));
+    ICS_TRY(launch_conv_wgrad(n.st, g, &lo, 1, L.dyS, L.ldS, L.dw_up, 27 * L.Cout, n.ws_wgrad, n.ws_wgrad_n, 0, 0, 0, 1));
     n.prof.end(n.st);
     n.prof.begin(n.st, "wgrad_reduce_splits", 0, 0);
-    ICS_TRY(launch_conv_wgrad(n.st, g, &lo, 1, L.dyS, 27 * L.Cout, L.dw_up, 27 * L.Cout, n.ws_wgrad, n.ws_wgrad_n, 0, 0,
-                              0, 2));
+    ICS_TRY(launch_conv_wgrad(n.st, g, &lo, 1, L.dyS, L.ldS, L.dw_up, 27 * L.Cout, n.ws_wgrad, n.ws_wgrad_n, 0, 0, 0, 2));
     ICS_TRY(launch_permute_up_dw(n.st, L.dw_up, L.Cu, L.Cout, L.Cin, L.Cs, n.tg(L.t_w)));
     n.prof.end(n.st);
   }
-  {
+  if (L.Cs) {
     const ConvGeom g = geom_skip_dgrad(L, B);
     ConvSrc sdy = src_plain(L.dy, L.Cout);
     n.prof.begin(n.st, "conv_dgrad:" + L.name + ".skip|", fl_skip,
@@ -533,7 +548,7 @@ static int conv_grads_split_up(Net& n, ConvLayer& L, int B) {
   }
   {
     const ConvGeom g = geom_up_dgrad(L, B);
-    ConvSrc sd = src_plain(L.dyS, 27 * L.Cout);
+    ConvSrc sd = src_plain(L.dyS, L.ldS);
     n.prof.begin(n.st, "conv_dgrad:" + L.name + ".up|", fl_up,
                  4.0 * (M / 8 * L.Cu + M / 8 * 27.0 * L.Cout + 27.0 * L.Cu * L.Cout));
     ICS_TRY(launch_conv_fwd(n.st, g, &sd, 1, L.w_up, nullptr, L.dxl, L.Cu, ACT_NONE, nullptr, nullptr, 0, n.fws(),
@@ -942,6 +957,7 @@ static int vae_build(Net& n, const ics_vae_config& cfg, Net* pm) {
   for (int i = 1; i < 4; ++i) r.dl[i]->src[0] = src_layer(*r.dl[i - 1], 1);   // UpSampling3D after d0..d2
   r.dout->src[0] = src_layer(*r.dl[3], 0);
   use_padded_input(*r.e[0]);
+  for (int i = 1; i < 4; ++i) ICS_TRY(enable_split_up(n, *r.dl[i]));
   ICS_TRY(alloc_workspaces(n, true));
   ICS_TRY(init_bn_defaults(n));
   if (pm) {
@@ -1055,7 +1071,10 @@ static int vae_step(Net& n, int B, bool training, float* metrics) {
       if ((rc = conv_backward(n, *r.dout, B, gs_direct(n.drecon, n.C, 0), gs_none(), nullptr, true, true))) break;
       if ((rc = conv_backward(n, *r.dl[3], B, gs_direct(r.dout->dA, r.dout->Cin, 0), gs_none(), nullptr, true, true))) break;
       for (int i = 2; i >= 0; --i)
-        if ((rc = conv_backward(n, *r.dl[i], B, gs_up(r.dl[i + 1]->dA, r.dl[i + 1]->Cin, 0), gs_none(), nullptr, true, true))) break;
+        if ((rc = conv_backward(n, *r.dl[i], B,
+                                r.dl[i + 1]->split_up ? gs_direct(r.dl[i + 1]->dxl, r.dl[i + 1]->Cu, 0)
+                                                      : gs_up(r.dl[i + 1]->dA, r.dl[i + 1]->Cin, 0),
+                                gs_none(), nullptr, true, true))) break;
       if (rc) break;
       if ((rc = conv_backward(n, *r.decd, B, gs_direct(r.dl[0]->dA, r.decd->Cout, 0), gs_none(), nullptr, true, true))) break;
       // sampling + KL
