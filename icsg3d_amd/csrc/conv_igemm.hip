@@ -1219,7 +1219,10 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(ConvGeom g, ConvSrc s0
   constexpr int CK = 64, NT = 128;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int S = g.S, lg = g.lgS;
-  const int arows = 32 + (32 >> lg) + 1;
+  // S <= 32: a chunk is 32/S whole x-lines, each followed by a zero row.  S = 64: a chunk is half a line; rows
+  // 0 / 33 then hold the real neighbours x0-1 / x0+32 (zero at the line ends), loaded with every chunk.
+  const bool halo = lg > 5;
+  const int arows = 32 + (halo ? 1 : (32 >> lg)) + 1;
   const int A_FLOATS = arows * CK;
   constexpr int D_FLOATS = 32 * NT;
   float* As = smem;                    // [2][arows][64]
@@ -1258,10 +1261,27 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(ConvGeom g, ConvSrc s0
     sh = *reinterpret_cast<const v4f*>((first ? s0.shift : s1.shift) + cl);
   }
 
-  v4f ra[2], rd[4];
+  v4f ra[2], rd[4], rah = v4f{0.f, 0.f, 0.f, 0.f};
+  const int hside = (t >> 4) & 1;   // halo loaders: threads 0..15 left row, 16..31 right row
   auto load_chunk = [&](int c) {
     const int mbase = m_begin + (c << 5);
     const int Sh = S >> 1;
+    if (halo) {
+      const int x0 = mbase & (S - 1);
+      const int m = hside ? mbase + 32 : mbase - 1;
+      const int y = (mbase >> lg) & (S - 1), z = (mbase >> (2 * lg)) & (S - 1);
+      const bool inb = t < 32 && mbase < m_end && (hside ? x0 == 0 : x0 != 0) && y != ybad && z != zbad;
+      int idx = m + sdelta;
+      if (UP) {
+        const int x = m & (S - 1), b = mbase >> (3 * lg);
+        const int idx_up = ((b * Sh + ((z + dz) >> 1)) * Sh + ((y + dyy) >> 1)) * Sh + (x >> 1);
+        idx = su ? idx_up : idx;
+      }
+      const unsigned off = inb ? (unsigned)idx * (unsigned)sC + cl : (unsigned)cl;
+      v4f v = *reinterpret_cast<const v4f*>(sp + off);
+      if (AFF) v = affine_act4(v, sc, sh, slope);
+      rah = inb ? v : v4f{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const int m = mbase + (t >> 4) + 16 * p;
@@ -1296,6 +1316,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(ConvGeom g, ConvSrc s0
       const int r = (t >> 4) + 16 * p;
       *reinterpret_cast<v4f*>(A + (r + (r >> lg) + 1) * CK + ac4 * 4) = ra[p];
     }
+    if (halo && t < 32) *reinterpret_cast<v4f*>(A + (hside ? 33 : 0) * CK + ac4 * 4) = rah;
 #pragma unroll
     for (int p = 0; p < 4; ++p) *reinterpret_cast<v4f*>(D + ((t >> 5) + 8 * p) * NT + (t & 31) * 4) = rd[p];
   };
@@ -1375,6 +1396,38 @@ __global__ void reduce_splits_kernel(const float* __restrict__ ws, int nsplit, s
   dw[k * ldw + n] = s;
 }
 
+// Many splits of a small weight tensor (thin layers: n_elems ~ 1e4, nsplit up to 512): 64 elements per
+// block, the split loop shared by 4 thread rows, combined in fixed order (deterministic).
+__global__ __launch_bounds__(256) void reduce_splits_wide_kernel(const float* __restrict__ ws, int nsplit,
+                                                                  size_t n_elems, int N, float* __restrict__ dw,
+                                                                  int ldw, int sub_rows, int row_pitch, int row_off) {
+  __shared__ float part[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const size_t i = (size_t)blockIdx.x * 64 + tx;
+  float s = 0.f;
+  if (i < n_elems)
+    for (int p = ty; p < nsplit; p += 4) s += ws[(size_t)p * n_elems + i];
+  part[ty][tx] = s;
+  __syncthreads();
+  if (ty != 0 || i >= n_elems) return;
+  s = ((part[0][tx] + part[1][tx]) + part[2][tx]) + part[3][tx];
+  size_t k = i / N;
+  const size_t n = i - k * N;
+  if (sub_rows > 0) k = (k / sub_rows) * row_pitch + row_off + k % sub_rows;
+  dw[k * ldw + n] = s;
+}
+static int launch_reduce_splits(hipStream_t st, const float* ws, int nsplit, size_t n_elems, int N, float* dw, int ldw,
+                                int sub_rows, int row_pitch, int row_off) {
+  if (nsplit >= 16 && n_elems * 4 < (size_t)1 << 20)
+    hipLaunchKernelGGL(reduce_splits_wide_kernel, dim3((unsigned)((n_elems + 63) / 64)), dim3(256), 0, st, ws, nsplit,
+                       n_elems, N, dw, ldw, sub_rows, row_pitch, row_off);
+  else
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((n_elems + 255) / 256)), dim3(256), 0, st, ws, nsplit,
+                       n_elems, N, dw, ldw, sub_rows, row_pitch, row_off);
+  ICS_HIP(hipGetLastError());
+  return 0;
+}
+
 struct WgradPlan {
   int kt, nt, ktiles, ntiles, ksplit, rows_per_split;
   bool vec, thin;
@@ -1444,7 +1497,7 @@ static int pick_ksplit(long base, long M) {
 // channel groups inside one source, full 128-wide vectorisable dy rows)
 static bool wgrad3_ok(const ConvGeom& g, const ConvSrc& s0, int nsrc, const ConvSrc& s1) {
   static const bool off = getenv("ICSG3D_NO_WGRAD3") != nullptr;
-  if (off || g.taps != 27 || g.S > 32 || g.S < 2 || g.Cin % 64 != 0 || g.Cout % 128 != 0) return false;
+  if (off || g.taps != 27 || g.S > 64 || g.S < 2 || g.Cin % 64 != 0 || g.Cout % 128 != 0) return false;
   if (s0.bcast || (nsrc > 1 && s1.bcast)) return false;
   if (nsrc > 1 && (s0.C % 64 != 0)) return false;
   return true;
@@ -1546,7 +1599,7 @@ int launch_conv_wgrad(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int
   if (dy_vec && wgrad3_ok(g, s0, nsrc, s1)) {
     const Wgrad3Plan q = plan_wgrad3(g);
     ICS_CHECK((size_t)q.ksplit * n_elems <= workspace_floats, "wgrad workspace too small");
-    const int arows = 32 + (32 >> g.lgS) + 1;
+    const int arows = 32 + std::max(32 >> g.lgS, 1) + 1;
     const size_t lds = (size_t)2 * (arows * 64 + 32 * 128) * sizeof(float);
     const dim3 grid(9 * q.cgroups * q.ntiles * q.ksplit);
     if (phase != 2) {
@@ -1561,9 +1614,7 @@ int launch_conv_wgrad(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int
       ICS_HIP(hipGetLastError());
     }
     if (phase != 1) {
-      hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((n_elems + 255) / 256)), dim3(256), 0, st, workspace,
-                         q.ksplit, n_elems, g.Cout, dw, ldw, sub_rows, row_pitch, row_off);
-      ICS_HIP(hipGetLastError());
+      ICS_TRY(launch_reduce_splits(st, workspace, q.ksplit, n_elems, g.Cout, dw, ldw, sub_rows, row_pitch, row_off));
     }
     return 0;
   }
@@ -1597,10 +1648,7 @@ int launch_conv_wgrad(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int
 #undef ICS_WG
   }
   if (phase != 1) {
-    const int thr = 256;
-    hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((n_elems + thr - 1) / thr)), dim3(thr), 0,
-                       st, workspace, p.ksplit, n_elems, g.Cout, dw, ldw, sub_rows, row_pitch, row_off);
-    ICS_HIP(hipGetLastError());
+    ICS_TRY(launch_reduce_splits(st, workspace, p.ksplit, n_elems, g.Cout, dw, ldw, sub_rows, row_pitch, row_off));
   }
   return 0;
 }

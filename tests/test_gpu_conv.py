@@ -17,6 +17,7 @@ CASES = [
     (2, 4, 512, 512, 3),
     # resolutions of the benchmark (S=32) and of the d=64 extension: the dx-reuse kernels' line padding
     (1, 32, 64, 128, 3), (1, 64, 32, 32, 3), (1, 32, 128, 128, 3),
+    (1, 64, 64, 128, 3),   # S = 64 through the dx-reuse backward-weight kernel (half-line chunks with halo rows)
 ]
 
 
