@@ -701,15 +701,222 @@ const char* conv_fwd_kernel_id(const ConvGeom& g, const ConvSrc* src, int nsrc) 
 int conv_fwd_rows_per_block(const ConvGeom& g) {
   int bm, bn;
   pick_fwd_tile(g, &bm, &bn);
+  // the thin-N direct kernel (Cout <= 4) has 256 / (Cin/4) voxels per block; size for the smaller of the two
+  if (g.taps == 27 && g.Cout <= 4 && g.Cin % 4 == 0 && g.Cin >= 4 && g.Cin <= 64) {
+    bm = std::min(bm, g.Cin <= 16 ? 256 : 64);
+  }
   return bm;
 }
+
+// =====================================================================================
+// Thin-N direct kernels (Cout <= 4: the VAE's decoder_output conv, backward-data of the first conv).
+// A 32-wide MFMA tile would be >= 87 % padding here; these are HBM/L1-bound stencils on the vector ALU:
+// one thread per output voxel (forward) / one thread per weight row (backward-weight).
+// =====================================================================================
+static bool thin_n_ok(const ConvGeom& g, const ConvSrc& s0, int nsrc) {
+  static const bool off = getenv("ICSG3D_NO_THIN_N") != nullptr;
+  return !off && nsrc == 1 && g.taps == 27 && g.Cout <= 4 && g.Cin % 4 == 0 && g.Cin >= 4 && g.Cin <= 64 &&
+         s0.C == g.Cin && !s0.up && !s0.bcast && g.S >= 2;
+}
+
+template <int NOUT, bool AFF, int lgLPV>
+__global__ __launch_bounds__(256) void conv_thin_n_fwd_kernel(ConvGeom g, ConvSrc s0, const float* __restrict__ wp,
+                                                               const float* __restrict__ bias,
+                                                               float* __restrict__ out, int ldo, int pre_act,
+                                                               float* __restrict__ stat_partial, int accumulate) {
+  // LPV = 2^lgLPV lanes share one voxel (1 for Cin <= 16, 4 above), each owning the float4 channel columns
+  // cq, cq+LPV, ...: wider rows then still load whole cache lines per wave instruction (measured on c1's
+  // backward-data, Cin = 32: LPV 1 / 2 / 4 / 8 -> 0.41 / 0.45 / 0.23 / 0.26 ms).
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* w = smem;                                   // [27*Cin][NOUT]
+  const int t = threadIdx.x;
+  const int S = g.S, lg = g.lgS, C = g.Cin;
+  const int M = g.B << (3 * lg);
+  const int K = 27 * C;
+  for (int i = t; i < K * NOUT; i += 256) {
+    const int k = i / NOUT, n = i - k * NOUT;
+    w[i] = n < g.Cout ? wp[((size_t)(k >> 2) * g.Npad + n) * 4 + (k & 3)] : 0.f;
+  }
+  __syncthreads();
+  constexpr int LPV = 1 << lgLPV, VPB = 256 >> lgLPV;    // lanes per voxel, voxels per block
+  const int cq = t & (LPV - 1);
+  const int m = blockIdx.x * VPB + (t >> lgLPV);
+  const bool mvalid = m < M;
+  const RowPos rp = decode_row(mvalid ? m : 0, S, lg);
+  const float slope = act_slope_of(s0.act);
+  float acc[NOUT];
+#pragma unroll
+  for (int n = 0; n < NOUT; ++n) acc[n] = 0.f;
+  for (int tap = 0; tap < 27; ++tap) {
+    const int dz = tap / 9 - 1, dy = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
+    const bool inb = mvalid && (unsigned)(rp.z + dz) < (unsigned)S && (unsigned)(rp.y + dy) < (unsigned)S &&
+                     (unsigned)(rp.x + dx) < (unsigned)S;
+    const unsigned base = inb ? (unsigned)(m + (dz * S + dy) * S + dx) * (unsigned)C : 0u;
+    const float* wk = w + tap * C * NOUT;
+    for (int c = cq * 4; c < C; c += 4 * LPV) {
+      v4f v = *reinterpret_cast<const v4f*>(s0.p + base + c);
+      if (AFF) {
+        const v4f sc = *reinterpret_cast<const v4f*>(s0.scale + c);
+        const v4f sh = *reinterpret_cast<const v4f*>(s0.shift + c);
+        v = affine_act4(v, sc, sh, slope);
+      }
+      if (!inb) v = v4f{0.f, 0.f, 0.f, 0.f};     // zero "same" padding applies after BN / activation
+#pragma unroll
+      for (int n = 0; n < NOUT; ++n) {
+        acc[n] = fmaf(v.x, wk[(c + 0) * NOUT + n], acc[n]);
+        acc[n] = fmaf(v.y, wk[(c + 1) * NOUT + n], acc[n]);
+        acc[n] = fmaf(v.z, wk[(c + 2) * NOUT + n], acc[n]);
+        acc[n] = fmaf(v.w, wk[(c + 3) * NOUT + n], acc[n]);
+      }
+    }
+  }
+  const float pre_slope = act_slope_of(pre_act);
+  const bool owner = mvalid && cq == 0;
+#pragma unroll
+  for (int n = 0; n < NOUT; ++n) {
+    float a = acc[n];
+    for (int o = LPV >> 1; o > 0; o >>= 1) a += __shfl_xor(a, o);     // fixed tree: deterministic
+    a += (bias != nullptr && n < g.Cout) ? bias[n] : 0.f;
+    if (accumulate && owner && n < g.Cout) a += out[(size_t)m * ldo + n];
+    a = act_apply(a, pre_slope);
+    if (!owner) a = 0.f;
+    acc[n] = a;
+    if (owner && n < g.Cout) out[(size_t)m * ldo + n] = a;
+  }
+  if (stat_partial == nullptr) return;
+  // block (count, mean, M2) per column: two passes inside the block, as the MFMA kernels do
+  __syncthreads();
+  float* red = smem;   // [4 waves][NOUT]   (weights are no longer needed)
+  const int nvalid_rows = min(VPB, M - (int)blockIdx.x * VPB);
+  const int lane = t & 63, wave = t >> 6;
+  float mu[NOUT];
+#pragma unroll
+  for (int n = 0; n < NOUT; ++n) {
+    float v = acc[n];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) red[wave * NOUT + n] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int n = 0; n < NOUT; ++n)
+    mu[n] = (red[n] + red[NOUT + n] + red[2 * NOUT + n] + red[3 * NOUT + n]) / (float)nvalid_rows;
+  __syncthreads();
+#pragma unroll
+  for (int n = 0; n < NOUT; ++n) {
+    const float d = acc[n] - mu[n];
+    float q = owner ? d * d : 0.f;
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    if (lane == 0) red[wave * NOUT + n] = q;
+  }
+  __syncthreads();
+  if (t < NOUT && t < g.Npad) {
+    float* sp = stat_partial + (size_t)blockIdx.x * 3 * g.Npad + t;
+    sp[0] = (float)nvalid_rows;
+    sp[g.Npad] = mu[t];
+    sp[2 * g.Npad] = red[t] + red[NOUT + t] + red[2 * NOUT + t] + red[3 * NOUT + t];
+  }
+}
+
+static int thin_n_lg_lpv(const ConvGeom& g) { return g.Cin <= 16 ? 0 : 2; }
+static int launch_thin_n_fwd(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, const float* wp, const float* bias,
+                             float* out, int ldo, int pre_act, float* stat_partial, int* rows_per_block,
+                             int accumulate) {
+  const int M = g.B << (3 * g.lgS);
+  const int lgv = thin_n_lg_lpv(g), vpb = 256 >> lgv;
+  const dim3 grid((M + vpb - 1) / vpb);
+  const size_t lds = (size_t)std::max(27 * g.Cin * 4, 64) * sizeof(float);
+  const bool aff = s0.scale != nullptr;
+  ConvSrc s = s0;
+  if (rows_per_block) *rows_per_block = vpb;
+#define ICS_TN(NOUT, AFFV, LGV)                                                                                   \
+  do {                                                                                                            \
+    g_last_kernel_id = "conv_thin_n_fwd_kernel<" #NOUT ", " #AFFV ", " #LGV ">";                                  \
+    hipLaunchKernelGGL((conv_thin_n_fwd_kernel<NOUT, AFFV, LGV>), grid, dim3(256), lds, st, g, s, wp, bias, out,   \
+                       ldo, pre_act, stat_partial, accumulate);                                                   \
+  } while (0)
+#define ICS_TN_L(NOUT, AFFV)                                          \
+  do {                                                                \
+    if (lgv == 0) ICS_TN(NOUT, AFFV, 0); else ICS_TN(NOUT, AFFV, 2);  \
+  } while (0)
+  if (g.Cout == 1) { if (aff) ICS_TN_L(1, true); else ICS_TN_L(1, false); }
+  else { if (aff) ICS_TN_L(4, true); else ICS_TN_L(4, false); }
+#undef ICS_TN_L
+#undef ICS_TN
+  ICS_HIP(hipGetLastError());
+  return 0;
+}
+
+// Backward-weight for Cout <= 4:  ws[split][k][n] = sum_{m in split} A[m + off(tap_k)][c_k] * dy[m][n].
+// Thread t owns weight rows k = t, t + 256, ... (lanes = consecutive channels: coalesced A reads); the voxel
+// loop is block-uniform, so the row decode and the dy row come from scalar registers.
+template <int NOUT, bool AFF, int KPT>
+__global__ __launch_bounds__(256) void conv_thin_n_wgrad_kernel(ConvGeom g, ConvSrc s0, const float* __restrict__ dy,
+                                                                 int ldy, float* __restrict__ ws, int rows_per_split) {
+  const int t = threadIdx.x;
+  const int S = g.S, lg = g.lgS, C = g.Cin;
+  const int M = g.B << (3 * lg);
+  const int K = 27 * C;
+  const int m_begin = blockIdx.x * rows_per_split;
+  const int m_end = min(M, m_begin + rows_per_split);
+  const float slope = act_slope_of(s0.act);
+  int koff[KPT], kdz[KPT], kdy[KPT], kdx[KPT], kc[KPT];
+  float ksc[KPT], ksh[KPT];
+  bool kvalid[KPT];
+  float acc[KPT][NOUT];
+#pragma unroll
+  for (int i = 0; i < KPT; ++i) {
+    const int k = t + 256 * i;
+    kvalid[i] = k < K;
+    const int tap = kvalid[i] ? k / C : 0;
+    kc[i] = kvalid[i] ? k - tap * C : 0;
+    kdz[i] = tap / 9 - 1; kdy[i] = (tap / 3) % 3 - 1; kdx[i] = tap % 3 - 1;
+    koff[i] = ((kdz[i] * S + kdy[i]) * S + kdx[i]) * C + kc[i];
+    ksc[i] = AFF ? s0.scale[kc[i]] : 1.f;
+    ksh[i] = AFF ? s0.shift[kc[i]] : 0.f;
+#pragma unroll
+    for (int n = 0; n < NOUT; ++n) acc[i][n] = 0.f;
+  }
+#pragma unroll 8
+  for (int m = m_begin; m < m_end; ++m) {
+    const int x = m & (S - 1), y = (m >> lg) & (S - 1), z = (m >> (2 * lg)) & (S - 1);
+    float d[NOUT];
+#pragma unroll
+    for (int n = 0; n < NOUT; ++n) d[n] = n < g.Cout ? dy[(size_t)m * ldy + n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+      const bool inb = kvalid[i] && (unsigned)(z + kdz[i]) < (unsigned)S && (unsigned)(y + kdy[i]) < (unsigned)S &&
+                       (unsigned)(x + kdx[i]) < (unsigned)S;
+      float a = s0.p[inb ? (size_t)((long)m * C + koff[i]) : (size_t)kc[i]];
+      if (AFF) a = act_apply(fmaf(a, ksc[i], ksh[i]), slope);
+      a = inb ? a : 0.f;
+#pragma unroll
+      for (int n = 0; n < NOUT; ++n) acc[i][n] = fmaf(a, d[n], acc[i][n]);
+    }
+  }
+  float* wsp = ws + (size_t)blockIdx.x * K * g.Cout;
+#pragma unroll
+  for (int i = 0; i < KPT; ++i) {
+    const int k = t + 256 * i;
+    if (k < K)
+#pragma unroll
+      for (int n = 0; n < NOUT; ++n)
+        if (n < g.Cout) wsp[(size_t)k * g.Cout + n] = acc[i][n];
+  }
+}
+
+static int thin_n_wgrad_splits(const ConvGeom& g) {
+  const long M = (long)g.B << (3 * g.lgS);
+  // >= 4 resident blocks per CU, but at least 256 voxels per block
+  return (int)std::max(1L, std::min(4096L, M / 128));
+}
+
 
 // Split-K for launches that cannot fill the chip (64x64 tiles on the S <= 8 layers): ksplit blocks share a
 // tile, each sums a slice of K into ws[split][M][Npad]; splitk_finish_kernel adds the slices in fixed order
 // and runs the epilogue (bias, activation, store, BatchNorm partial statistics of 64-row blocks).
 static int fwd_splitk_plan(const ConvGeom& g, const ConvSrc& s0, const ConvSrc& s1, int nsrc) {
   static const bool off = getenv("ICSG3D_NO_FWD_SPLITK") != nullptr;
-  if (off || !fwd_is_vec(g, s0, s1) || conv_is_thin(g, s0, nsrc)) return 1;
+  if (off || !fwd_is_vec(g, s0, s1) || conv_is_thin(g, s0, nsrc) || thin_n_ok(g, s0, nsrc)) return 1;
   int bm, bn;
   pick_fwd_tile(g, &bm, &bn);
   if (bm != 64) return 1;
@@ -804,6 +1011,8 @@ int launch_conv_fwd(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int n
 static int launch_conv_fwd_inner(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int nsrc,
                                  const float* wp, const float* bias, float* out, int ldo, int pre_act,
                                  float* stat_partial, int* rows_per_block, int accumulate, int ksplit) {
+  if (ksplit == 1 && thin_n_ok(g, src[0], nsrc))
+    return launch_thin_n_fwd(st, g, src[0], wp, bias, out, ldo, pre_act, stat_partial, rows_per_block, accumulate);
   ConvSrc s0 = src[0], s1 = src[nsrc > 1 ? 1 : 0];
   if (nsrc == 1) s1.C = 0;
   // loader variants: 0 = plain sources (backward-data, pooled inputs), 1 = BN affine/activation,
@@ -963,6 +1172,7 @@ int launch_conv_fwd_ablate(hipStream_t st, const ConvGeom& g, const ConvSrc* src
   return launch_fwd_cfg<2, 2, 2, 2, true, 0, false, false>(ICS_ABL_ARGS);
 #undef ICS_ABL_ARGS
 }
+
 
 // =====================================================================================
 // Backward-weight kernel: ws[split][k][n] = sum_{m in split} A[m][k] * dy[m][n]
@@ -1532,6 +1742,7 @@ const char* conv_wgrad_kernel_id(const ConvGeom& g, const ConvSrc* src, int nsrc
 }
 
 size_t conv_wgrad_workspace_floats(const ConvGeom& g, const ConvSrc* src, int nsrc) {
+  if (thin_n_ok(g, src[0], nsrc)) return (size_t)thin_n_wgrad_splits(g) * g.taps * g.Cin * g.Cout;
   ConvSrc s0 = src[0], s1 = src[nsrc > 1 ? 1 : 0];
   WgradPlan p = plan_wgrad(g, s0, nsrc, s1);
   int ks = p.ksplit;
@@ -1579,6 +1790,38 @@ int launch_conv_wgrad_ablate(hipStream_t st, const ConvGeom& g, const ConvSrc* s
 int launch_conv_wgrad(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int nsrc,
                       const float* dy, int ldy, float* dw, int ldw, float* workspace,
                       size_t workspace_floats, int sub_rows, int row_pitch, int row_off, int phase) {
+  if (thin_n_ok(g, src[0], nsrc)) {
+    const int ns = thin_n_wgrad_splits(g);
+    const size_t n_el = (size_t)g.taps * g.Cin * g.Cout;
+    ICS_CHECK((size_t)ns * n_el <= workspace_floats, "wgrad workspace too small");
+    const int M = g.B << (3 * g.lgS);
+    const int rows = (M + ns - 1) / ns;
+    const int K = 27 * g.Cin;
+    const bool aff = src[0].scale != nullptr;
+    if (phase != 2) {
+#define ICS_TNW(NOUT, AFFV, KPT, NAME)                                                                         \
+  do {                                                                                                         \
+    g_last_kernel_id = NAME;                                                                                   \
+    hipLaunchKernelGGL((conv_thin_n_wgrad_kernel<NOUT, AFFV, KPT>), dim3((M + rows - 1) / rows), dim3(256), 0,  \
+                       st, g, src[0], dy, ldy, workspace, rows);                                               \
+  } while (0)
+#define ICS_TNW_K(NOUT, AFFV, TAG)                                                                  \
+  do {                                                                                              \
+    if (K <= 512) ICS_TNW(NOUT, AFFV, 2, "conv_thin_n_wgrad_kernel<" TAG ", 2>");                   \
+    else if (K <= 1024) ICS_TNW(NOUT, AFFV, 4, "conv_thin_n_wgrad_kernel<" TAG ", 4>");             \
+    else ICS_TNW(NOUT, AFFV, 7, "conv_thin_n_wgrad_kernel<" TAG ", 7>");                            \
+  } while (0)
+      if (g.Cout == 1) { if (aff) ICS_TNW_K(1, true, "1, true"); else ICS_TNW_K(1, false, "1, false"); }
+      else { if (aff) ICS_TNW_K(4, true, "4, true"); else ICS_TNW_K(4, false, "4, false"); }
+#undef ICS_TNW_K
+#undef ICS_TNW
+      ICS_HIP(hipGetLastError());
+    }
+    if (phase != 1)
+      ICS_TRY(launch_reduce_splits(st, workspace, (M + rows - 1) / rows, n_el, g.Cout, dw, ldw, sub_rows, row_pitch,
+                                   row_off));
+    return 0;
+  }
   ConvSrc s0 = src[0], s1 = src[nsrc > 1 ? 1 : 0];
   if (nsrc == 1) s1.C = 0;
   ICS_TRY(fix_src(s0));

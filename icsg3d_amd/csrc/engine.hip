@@ -580,7 +580,8 @@ static int conv_grads_from_dy(Net& n, ConvLayer& L, int B, bool need_dA, bool pa
     n.prof.end(n.st);
   }
   if (need_dA) {
-    const ConvGeom gb = geom_bwd(L, B);
+    ConvGeom gb = geom_bwd(L, B);
+    gb.Cout = L.Cin;   // a padded input (CinG > Cin) only needs its logical gradient columns
     ConvSrc sdy = src_plain(L.dy, L.Cout);
     n.prof.begin(n.st, "conv_dgrad:" + L.name + "|", 2.0 * M * L.taps * L.Cin * L.Cout,
                  4.0 * (M * L.Cin + M * L.Cout + (double)L.taps * L.Cin * L.Cout));

@@ -14,7 +14,7 @@ CASES = [
     (2, 8, 32, 64, 3), (1, 16, 64, 128, 3), (1, 8, 128, 256, 3), (2, 8, 192, 128, 3),
     (2, 8, 1, 32, 3), (2, 8, 11, 16, 3), (1, 4, 4, 128, 3), (2, 8, 16, 1, 3), (2, 8, 16, 32, 3),
     (2, 8, 128, 96, 1), (3, 4, 32, 32, 3), (1, 2, 128, 4, 3), (5, 1, 266, 256, 1), (3, 1, 32, 256, 1),
-    (2, 4, 512, 512, 3),
+    (2, 4, 512, 512, 3), (2, 8, 32, 4, 3), (1, 16, 64, 1, 3), (3, 4, 8, 2, 3),   # thin-N direct kernels
     # resolutions of the benchmark (S=32) and of the d=64 extension: the dx-reuse kernels' line padding
     (1, 32, 64, 128, 3), (1, 64, 32, 32, 3), (1, 32, 128, 128, 3),
     (1, 64, 64, 128, 3),   # S = 64 through the dx-reuse backward-weight kernel (half-line chunks with halo rows)
