@@ -1421,8 +1421,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvGeom g, ConvSrc s0,
 // lane i fetches channels 2i,2i+1 with one ds_read_b64 per tap (component-split), 6 accumulators.
 // Requires 27 taps, S <= 32 (chunks are whole x-lines), Cin % 64 == 0 with sources 64-aligned.
 // =====================================================================================
-template <bool AFF, bool UP>
-__global__ __launch_bounds__(256) void conv_wgrad3_kernel(ConvGeom g, ConvSrc s0, ConvSrc s1,
+template <bool AFF, bool UP, bool HALO>
+__global__ __launch_bounds__(256, HALO ? 2 : 3) void conv_wgrad3_kernel(ConvGeom g, ConvSrc s0, ConvSrc s1,
                                                            const float* __restrict__ dy, int ldy, int n_load,
                                                            float* __restrict__ ws, int cgroups, int ntiles,
                                                            int rows_per_split) {
@@ -1431,7 +1431,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(ConvGeom g, ConvSrc s0
   const int S = g.S, lg = g.lgS;
   // S <= 32: a chunk is 32/S whole x-lines, each followed by a zero row.  S = 64: a chunk is half a line; rows
   // 0 / 33 then hold the real neighbours x0-1 / x0+32 (zero at the line ends), loaded with every chunk.
-  const bool halo = lg > 5;
+  constexpr bool halo = HALO;   // S = 64
   const int arows = 32 + (halo ? 1 : (32 >> lg)) + 1;
   const int A_FLOATS = arows * CK;
   constexpr int D_FLOATS = 32 * NT;
@@ -1465,10 +1465,12 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(ConvGeom g, ConvSrc s0
   const float slope = act_slope_of(first ? s0.act : s1.act);
   const int ac4 = t & 15;                                  // this thread's float4 column of the A tile
   const int cl = (first ? c0 : c0 - s0.C) + ac4 * 4;
-  v4f sc = v4f{1.f, 1.f, 1.f, 1.f}, sh = v4f{0.f, 0.f, 0.f, 0.f};
-  if (AFF) {
-    sc = *reinterpret_cast<const v4f*>((first ? s0.scale : s1.scale) + cl);
-    sh = *reinterpret_cast<const v4f*>((first ? s0.shift : s1.shift) + cl);
+  // the block's 64 BN scale/shift values live in LDS (re-read per chunk): 8 fewer live VGPRs, which is what
+  // lets the affine variants fit 3 waves/SIMD (168 registers) without spilling
+  float* Aff = Ds + 2 * D_FLOATS;      // [2][64]
+  if (AFF && t < 32) {
+    const float* src = (t < 16) ? (first ? s0.scale : s1.scale) : (first ? s0.shift : s1.shift);
+    *reinterpret_cast<v4f*>(Aff + t * 4) = *reinterpret_cast<const v4f*>(src + (first ? c0 : c0 - s0.C) + (t & 15) * 4);
   }
 
   v4f ra[2], rd[4], rah = v4f{0.f, 0.f, 0.f, 0.f};
@@ -1489,7 +1491,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(ConvGeom g, ConvSrc s0
       }
       const unsigned off = inb ? (unsigned)idx * (unsigned)sC + cl : (unsigned)cl;
       v4f v = *reinterpret_cast<const v4f*>(sp + off);
-      if (AFF) v = affine_act4(v, sc, sh, slope);
+      if (AFF) v = affine_act4(v, *reinterpret_cast<const v4f*>(Aff + ac4 * 4), *reinterpret_cast<const v4f*>(Aff + 64 + ac4 * 4), slope);
       rah = inb ? v : v4f{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
@@ -1505,7 +1507,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(ConvGeom g, ConvSrc s0
       }
       const unsigned off = inb ? (unsigned)idx * (unsigned)sC + cl : (unsigned)cl;
       v4f v = *reinterpret_cast<const v4f*>(sp + off);
-      if (AFF) v = affine_act4(v, sc, sh, slope);
+      if (AFF) v = affine_act4(v, *reinterpret_cast<const v4f*>(Aff + ac4 * 4), *reinterpret_cast<const v4f*>(Aff + 64 + ac4 * 4), slope);
       ra[p] = inb ? v : v4f{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
@@ -1547,6 +1549,7 @@ __global__ __launch_bounds__(256) void conv_wgrad3_kernel(ConvGeom g, ConvSrc s0
       As[b * A_FLOATS + (rem / CK) * (S + 1) * CK + rem % CK] = 0.f;
     }
   }
+  __syncthreads();   // the BN affine vectors in LDS are read by the very first load_chunk
   if (nchunks > 0) {
     load_chunk(0);
     store_chunk(0);
@@ -1843,17 +1846,21 @@ int launch_conv_wgrad(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int
     const Wgrad3Plan q = plan_wgrad3(g);
     ICS_CHECK((size_t)q.ksplit * n_elems <= workspace_floats, "wgrad workspace too small");
     const int arows = 32 + std::max(32 >> g.lgS, 1) + 1;
-    const size_t lds = (size_t)2 * (arows * 64 + 32 * 128) * sizeof(float);
+    const size_t lds = (size_t)(2 * (arows * 64 + 32 * 128) + 128) * sizeof(float);
     const dim3 grid(9 * q.cgroups * q.ntiles * q.ksplit);
     if (phase != 2) {
-      g_last_kernel_id = up ? "conv_wgrad3_kernel<true, true>" : aff ? "conv_wgrad3_kernel<true, false>"
-                                                                      : "conv_wgrad3_kernel<false, false>";
-      if (up) hipLaunchKernelGGL((conv_wgrad3_kernel<true, true>), grid, dim3(256), lds, st, g, s0, s1, dy, ldy, n_load,
-                                 workspace, q.cgroups, q.ntiles, q.rows_per_split);
-      else if (aff) hipLaunchKernelGGL((conv_wgrad3_kernel<true, false>), grid, dim3(256), lds, st, g, s0, s1, dy, ldy,
-                                       n_load, workspace, q.cgroups, q.ntiles, q.rows_per_split);
-      else hipLaunchKernelGGL((conv_wgrad3_kernel<false, false>), grid, dim3(256), lds, st, g, s0, s1, dy, ldy, n_load,
-                              workspace, q.cgroups, q.ntiles, q.rows_per_split);
+#define ICS_W3(AFFV, UPV, HALOV)                                                                                 \
+  do {                                                                                                           \
+    g_last_kernel_id = "conv_wgrad3_kernel<" #AFFV ", " #UPV ", " #HALOV ">";                                    \
+    hipLaunchKernelGGL((conv_wgrad3_kernel<AFFV, UPV, HALOV>), grid, dim3(256), lds, st, g, s0, s1, dy, ldy,      \
+                       n_load, workspace, q.cgroups, q.ntiles, q.rows_per_split);                                \
+  } while (0)
+      if (g.lgS > 5) {
+        if (up) ICS_W3(true, true, true); else if (aff) ICS_W3(true, false, true); else ICS_W3(false, false, true);
+      } else {
+        if (up) ICS_W3(true, true, false); else if (aff) ICS_W3(true, false, false); else ICS_W3(false, false, false);
+      }
+#undef ICS_W3
       ICS_HIP(hipGetLastError());
     }
     if (phase != 1) {
