@@ -209,6 +209,11 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
             const bool ok = (unsigned)zz < (unsigned)S && (unsigned)yy < (unsigned)S && (unsigned)xx < (unsigned)S;
             mk |= (ok ? 1u : 0u) << tp;
           }
+#pragma unroll
+          for (int gz = 0; gz < 4; ++gz) {   // bits 8..11: the (ez,ey) pair reads inside the grid at dx = 0
+            const int zz = rp.z + (gz >> 1) + pz - 1, yy = rp.y + (gz & 1) + py - 1;
+            mk |= (((unsigned)zz < (unsigned)S && (unsigned)yy < (unsigned)S) ? 1u : 0u) << (8 + gz);
+          }
         } else if (g.taps == 27) {
           const unsigned zm = (rp.z > 0 ? 1u : 0u) | 2u | (rp.z < S - 1 ? 4u : 0u);
           const unsigned ym = (rp.y > 0 ? 1u : 0u) | 2u | (rp.y < S - 1 ? 4u : 0u);
@@ -246,9 +251,10 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
     for (int r = 0; r < NB; ++r) *reinterpret_cast<v4f*>(Bw + (t + 256 * r) * 4) = rb[r];
   };
   // REUSE: A tile of group G = (dz*3+dy)*cpt + cc, i.e. the dx = 0 rows of 32 channels
+  // (PAR: G = (ez*2+ey)*cpt + cc with dz = ez+pz-1, dy = ey+py-1; two dx chunks per group instead of three)
   auto load_a_group = [&](int G) {
     const int gzy = G / cpt, ci0 = (G - gzy * cpt) << 5;
-    const int dz = gzy / 3 - 1, dy = gzy % 3 - 1;
+    const int dz = PAR ? (gzy >> 1) + pz - 1 : gzy / 3 - 1, dy = PAR ? (gzy & 1) + py - 1 : gzy % 3 - 1;
     const bool first = ci0 < s0.C;
     const float* sp = first ? s0.p : s1.p;
     const float* sscale = first ? s0.scale : s1.scale;
@@ -263,7 +269,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
 #pragma unroll
     for (int r = 0; r < RA; ++r) {
       const unsigned mk = rmask[r];
-      const bool inb = (mk >> (gzy * 3 + 1)) & 1u;        // validity of the centre (dx = 0) tap
+      const bool inb = (mk >> (PAR ? 8 + gzy : gzy * 3 + 1)) & 1u;   // validity of the centre (dx = 0) tap
       int idx = mrow_base + 32 * r + sdelta;
       if (UP) {
         const int ez = (dz + (int)((mk >> 29) & 1u)) >> 1;
@@ -411,15 +417,17 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
   };
 
   if (REUSE) {
-    // ---- dx-reuse pipeline: groups G = ((dz*3+dy), 32-channel slice); chunks c = 3G + (dx+1)
-    const int nG = 9 * cpt;
+    // ---- dx-reuse pipeline: groups G = ((dz*3+dy), 32-channel slice); chunks c = NDX*G + i, i = dx index
+    constexpr int NDX = PAR ? 2 : 3;
+    const int nG = (PAR ? 4 : 9) * cpt;
+    const int dx_first = PAR ? px - 1 : -1;                        // dx of chunk i is dx_first + i
     const int lines = BM >> lg;
     for (int i = t; i < NABUF * (lines + 1) * kLDA; i += 256) {      // the separator rows stay zero
       const int b = i / ((lines + 1) * kLDA), rem = i - b * (lines + 1) * kLDA;
       As[b * A_FLOATS + (rem / kLDA) * (S + 1) * kLDA + rem % kLDA] = 0.f;
     }
-    // this lane's A rows inside the padded image (MFMA tile rows never straddle... a 32-row MFMA tile
-    // may span lines when S < 32, so every tile row gets its own padded index)
+    // this lane's A rows inside the padded image (a 32-row MFMA tile may span lines when S < 32, so every
+    // tile row gets its own padded index)
     int arow[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -427,9 +435,9 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
       arow[i] = row + (row >> lg) + 1;
     }
     auto b_rows = [&](int c) {   // first packed K row (in units of 4) of chunk c
-      const int G = c / 3, dxi = c - 3 * G;
+      const int G = c / NDX, dxi = c - NDX * G;
       const int gzy = G / cpt, cc = G - gzy * cpt;
-      return (((gzy * 3 + dxi) * g.Cin + (cc << 5)) >> 2);
+      return (((gzy * NDX + dxi) * g.Cin + (cc << 5)) >> 2);
     };
     auto compute_reuse = [&](int abuf, int bbuf, int dx) {
       const float* Bw = Bs + bbuf * B_FLOATS + (lh * BN + wn * TN * 32 + li) * 4;
@@ -456,7 +464,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
     // a tile inside one z-plane (BM <= S*S) at the z = 0 / S-1 face reads only padding through the
     // dz = -1 / +1 groups: skip them (block-uniform loop bounds; 2/(3S) of the MFMA work)
     int G0 = 0, G1 = nG;
-    if (BM <= (S << lg)) {
+    if (!PAR && BM <= (S << lg)) {
       const int zb = ((mb * BM) >> (2 * lg)) & (S - 1);
       if (zb == 0) G0 = 3 * cpt;
       if (zb == S - 1) G1 = 6 * cpt;
@@ -469,41 +477,34 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
     if (G0 < G1) {
     load_a_group(G0);
     store_a_group(0);
-    load_b(b_rows(3 * G0));
-    store_b((3 * G0) & 1);
+    load_b(b_rows(NDX * G0));
+    store_b((NDX * G0) & 1);
     __syncthreads();
     for (int G = G0; G + 1 < G1; ++G) {
-      const int c0 = 3 * G;
-      // dx = -1 : also fetch the next group's A rows (kept in registers for three chunks)
+      const int c0 = NDX * G;
+      // first dx chunk: also fetch the next group's A rows (kept in registers until the group is done)
       load_a_group(G + 1);
-      load_b(b_rows(c0 + 1));
-      compute_reuse(0, c0 & 1, -1);
-      store_b((c0 + 1) & 1);
-      __syncthreads();
-      // dx = 0
-      load_b(b_rows(c0 + 2));
-      compute_reuse(0, (c0 + 1) & 1, 0);
-      store_b((c0 + 2) & 1);
-      __syncthreads();
-      // dx = +1 : then restage the (single) A buffer with the next group's tile
-      load_b(b_rows(c0 + 3));
-      compute_reuse(0, (c0 + 2) & 1, 1);
-      store_b((c0 + 3) & 1);
-      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < NDX; ++i) {
+        load_b(b_rows(c0 + i + 1));
+        compute_reuse(0, (c0 + i) & 1, dx_first + i);
+        store_b((c0 + i + 1) & 1);
+        __syncthreads();
+      }
+      // restage the (single) A buffer with the next group's tile
       store_a_group(0);
       __syncthreads();
     }
     {
-      const int G = G1 - 1, c0 = 3 * G;
-      load_b(b_rows(c0 + 1));
-      compute_reuse(0, c0 & 1, -1);
-      store_b((c0 + 1) & 1);
-      __syncthreads();
-      load_b(b_rows(c0 + 2));
-      compute_reuse(0, (c0 + 1) & 1, 0);
-      store_b((c0 + 2) & 1);
-      __syncthreads();
-      compute_reuse(0, (c0 + 2) & 1, 1);
+      const int G = G1 - 1, c0 = NDX * G;
+#pragma unroll
+      for (int i = 0; i + 1 < NDX; ++i) {
+        load_b(b_rows(c0 + i + 1));
+        compute_reuse(0, (c0 + i) & 1, dx_first + i);
+        store_b((c0 + i + 1) & 1);
+        __syncthreads();
+      }
+      compute_reuse(0, (c0 + NDX - 1) & 1, dx_first + NDX - 1);
       __syncthreads();
     }
     }   // G0 < G1
@@ -1082,11 +1083,17 @@ int launch_conv_fwd_par(hipStream_t st, const ConvGeom& g, const ConvSrc& src, c
   int rpb = 0;
 #define ICS_PAR_ARGS st, g, s0, s1, wp, bias, out, ldo, pre_act, stat_partial, &rpb
   int rc;
-  if (bm == 64) rc = launch_fwd_cfg<2, 2, 1, 1, true, 0, true, false, false, false, true>(ICS_PAR_ARGS);
-  else if (bn == 128) rc = launch_fwd_cfg<2, 2, 2, 2, true, 0, true, false, false, false, true>(ICS_PAR_ARGS);
-  else if (bn == 96) rc = launch_fwd_cfg<4, 1, 1, 3, true, 0, true, false, false, false, true>(ICS_PAR_ARGS);
-  else if (bn == 64) rc = launch_fwd_cfg<2, 2, 2, 1, true, 0, true, false, false, false, true>(ICS_PAR_ARGS);
-  else rc = launch_fwd_cfg<4, 1, 1, 1, true, 0, true, false, false, false, true>(ICS_PAR_ARGS);
+  static const bool no_reuse = getenv("ICSG3D_NO_REUSE") != nullptr;
+  const bool reuse = !no_reuse && g.S >= 4 && g.S <= bm;   // dx-reuse: the two ex taps share a staged A tile
+#define ICS_PAR(WM, WN, TM, TN)                                                                              \
+  (reuse ? launch_fwd_cfg<WM, WN, TM, TN, true, 0, true, false, false, true, true>(ICS_PAR_ARGS)             \
+         : launch_fwd_cfg<WM, WN, TM, TN, true, 0, true, false, false, false, true>(ICS_PAR_ARGS))
+  if (bm == 64) rc = ICS_PAR(2, 2, 1, 1);
+  else if (bn == 128) rc = ICS_PAR(2, 2, 2, 2);
+  else if (bn == 96) rc = ICS_PAR(4, 1, 1, 3);
+  else if (bn == 64) rc = ICS_PAR(2, 2, 2, 1);
+  else rc = ICS_PAR(4, 1, 1, 1);
+#undef ICS_PAR
 #undef ICS_PAR_ARGS
   if (stat_blocks) *stat_blocks = 8 * (((g.B << (3 * g.lgS)) + rpb - 1) / rpb);
   return rc;

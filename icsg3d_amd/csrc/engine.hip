@@ -154,6 +154,7 @@ struct Net {
   unsigned char* labels = nullptr;    // [maxB][d^3]
   ConvLayer* head = nullptr;
   float* head_bias_grad = nullptr;
+  float* head_dw_tmp = nullptr;       // [128][ncls+1] head weight gradient before the soft | sig split
   float* tap_copy[4] = {nullptr, nullptr, nullptr, nullptr};   // perceptual taps of the x pass
   float* dtap[4] = {nullptr, nullptr, nullptr, nullptr};
   int resident_batch = 0;
@@ -672,6 +673,7 @@ static int unet_build(Net& n, const ics_unet_config& cfg) {
   for (int i = 0; i < 14; ++i) ICS_TRY(alloc_layer(n, *n.layers[i], true, specs[i].pooled));
   ICS_TRY(alloc_layer(n, *n.head, true, false));
   ICS_TRY(n.alloc(&n.head_bias_grad, (size_t)256));
+  ICS_TRY(n.alloc(&n.head_dw_tmp, (size_t)128 * (n.ncls + 1)));
   UnetRefs r = unet_refs(n);
   r.c1->src[0] = src_plain(n.x_in, n.C);
   r.c2->src[0] = src_layer(*r.c1, 0);
@@ -785,6 +787,16 @@ static int colsum(Net& n, const float* a, size_t M, int C, int ld, float* out) {
   return 0;
 }
 
+// tmp[K][na + nb] -> a[K][na], b[K][nb]
+__global__ void split_cols_kernel(const float* __restrict__ tmp, int K, int N, int na, float* __restrict__ a,
+                                  float* __restrict__ b) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= K * N) return;
+  const int k = i / N, c = i - k * N;
+  if (c < na) a[k * na + c] = tmp[i];
+  else b[k * (N - na) + (c - na)] = tmp[i];
+}
+
 static int unet_backward(Net& n, int B) {
   UnetRefs r = unet_refs(n);
   ConvLayer& H = *n.head;
@@ -793,11 +805,16 @@ static int unet_backward(Net& n, int B) {
   // head: dz is in H.s (written by the loss kernel)
   const ConvGeom gh = geom_fwd(H, B);
   {
-    ConvGeom gs = gh; gs.Cout = n.ncls; gs.Npad = round_up(n.ncls, 32);
+    // one GEMM over the [soft | sig] columns (one pass over c18's activations), then split into the two tensors
+    ConvGeom gs = gh; gs.Cout = nc1; gs.Npad = round_up(nc1, 32);
     n.prof.begin(n.st, "conv_wgrad:head|", 2.0 * M * 128 * nc1, 4.0 * M * (128 + nc1));
-    ICS_TRY(launch_conv_wgrad(n.st, gs, H.src, 1, H.s, nc1, n.tg(H.t_w), n.ncls, n.ws_wgrad, n.ws_wgrad_n));
-    ConvGeom gg = gh; gg.Cout = 1; gg.Npad = 32;
-    ICS_TRY(launch_conv_wgrad(n.st, gg, H.src, 1, H.s + n.ncls, nc1, n.tg(H.t_gamma), 1, n.ws_wgrad, n.ws_wgrad_n));
+    ICS_TRY(launch_conv_wgrad(n.st, gs, H.src, 1, H.s, nc1, n.head_dw_tmp, nc1, n.ws_wgrad, n.ws_wgrad_n, 0, 0, 0, 1));
+    n.prof.end(n.st);
+    n.prof.begin(n.st, "wgrad_reduce_splits", 0, 0);
+    ICS_TRY(launch_conv_wgrad(n.st, gs, H.src, 1, H.s, nc1, n.head_dw_tmp, nc1, n.ws_wgrad, n.ws_wgrad_n, 0, 0, 0, 2));
+    hipLaunchKernelGGL(split_cols_kernel, dim3((128 * nc1 + 255) / 256), dim3(256), 0, n.st, n.head_dw_tmp, 128, nc1,
+                       n.ncls, n.tg(H.t_w), n.tg(H.t_gamma));
+    ICS_HIP(hipGetLastError());
     n.prof.end(n.st);
     ICS_TRY(colsum(n, H.s, M, nc1, nc1, n.tg(H.t_b)));   // soft/bias | sig/bias are contiguous
     const ConvGeom gb = geom_bwd(H, B);
