@@ -1653,6 +1653,7 @@ struct WgradPlan {
   bool vec, thin;
 };
 
+static int pick_ksplit(long base, long M, long slots);
 static WgradPlan plan_wgrad(const ConvGeom& g, const ConvSrc& s0, int nsrc, const ConvSrc& s1) {
   WgradPlan p;
   const int M = g.B << (3 * g.lgS);
@@ -1671,33 +1672,19 @@ static WgradPlan plan_wgrad(const ConvGeom& g, const ConvSrc& s0, int nsrc, cons
   else if (p.kt == 64) p.nt = (n32 <= 64) ? 64 : 128;
   else p.nt = 128;
   p.ntiles = (g.Npad + p.nt - 1) / p.nt;
-  // Split-K count against the machine's block capacity: 256 CUs x 2 resident 256-thread blocks.
-  // total = base*ksplit should fill whole "rounds" of 512 blocks (1539 blocks = 3.006 rounds leave a
-  // nearly empty 4th round: measured -20 %); pick the round count 1..6 with the best fill whose
-  // splits still have >= 512 voxel rows each.
-  const long base = (long)p.ktiles * p.ntiles;
-  const long slots = 512;
-  const long ks_max = std::max<long>(1, M / 256);
-  long want = 1;
-  double best = -1.0;
-  for (long r = 1; r <= 6; ++r) {
-    long ks = (r * slots) / base;
-    if (ks < 1) ks = 1;
-    if (ks > 512) ks = 512;
-    if (ks > ks_max) { if (r > 1) break; ks = ks_max; }   // small M: as many >= 256-row splits as there are
-    const long total = base * ks;
-    const double fill = (double)total / (double)(((total + slots - 1) / slots) * slots);
-    if (fill > best + 0.02 || (fill > best - 0.005 && ks > want)) { best = fill > best ? fill : best; want = ks; }
-  }
+  // 65.5 KB of LDS per block: 2 resident blocks per CU
+  const long want = pick_ksplit((long)p.ktiles * p.ntiles, M, 512);
   int rows = (int)(((M + want - 1) / want + 31) / 32 * 32);
   p.rows_per_split = rows;
   p.ksplit = (M + rows - 1) / rows;
   return p;
 }
 
-// split-K count that fills whole rounds of the 512 resident blocks (see plan_wgrad)
-static int pick_ksplit(long base, long M) {
-  const long slots = 512;
+// Split-K count: base*ks blocks should fill whole "rounds" of the resident block slots (1539 blocks on 512
+// slots = 3.006 rounds leave a nearly empty 4th round: measured -20 %).  Every split costs a pass of the
+// reduction over the weight tensor, so take the FEWEST rounds whose last round is >= 95 % full (c18: 170 splits
+// filled 6 rounds and cost a 300 MB reduction; 42 splits fill one), else the best fill; splits keep >= 256 rows.
+static int pick_ksplit(long base, long M, long slots) {
   const long ks_max = std::max<long>(1, M / 256);
   long want = 1;
   double best = -1.0;
@@ -1708,7 +1695,8 @@ static int pick_ksplit(long base, long M) {
     if (ks > ks_max) { if (r > 1) break; ks = ks_max; }   // small M: as many >= 256-row splits as there are
     const long total = base * ks;
     const double fill = (double)total / (double)(((total + slots - 1) / slots) * slots);
-    if (fill > best + 0.02 || (fill > best - 0.005 && ks > want)) { best = fill > best ? fill : best; want = ks; }
+    if (fill > best + 1e-9) { best = fill; want = ks; }
+    if (fill >= 0.95) break;
   }
   return (int)want;
 }
@@ -1728,7 +1716,7 @@ static Wgrad3Plan plan_wgrad3(const ConvGeom& g) {
   const long M = (long)g.B << (3 * g.lgS);
   p.cgroups = g.Cin / 64;
   p.ntiles = g.Cout / 128;
-  const int want = pick_ksplit(9L * p.cgroups * p.ntiles, M);
+  const int want = pick_ksplit(9L * p.cgroups * p.ntiles, M, g.lgS > 5 ? 512 : 768);   // 3 blocks/CU (2 at S = 64)
   p.rows_per_split = (int)(((M + want - 1) / want + 31) / 32 * 32);
   p.ksplit = (int)((M + p.rows_per_split - 1) / p.rows_per_split);
   return p;
