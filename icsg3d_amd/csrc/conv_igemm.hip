@@ -1621,16 +1621,20 @@ __global__ void reduce_splits_kernel(const float* __restrict__ ws, int nsplit, s
 __global__ __launch_bounds__(256) void reduce_splits_wide_kernel(const float* __restrict__ ws, int nsplit,
                                                                   size_t n_elems, int N, float* __restrict__ dw,
                                                                   int ldw, int sub_rows, int row_pitch, int row_off) {
-  __shared__ float part[4][64];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const size_t i = (size_t)blockIdx.x * 64 + tx;
+  __shared__ float part[8][32];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const size_t i = (size_t)blockIdx.x * 32 + tx;
   float s = 0.f;
-  if (i < n_elems)
-    for (int p = ty; p < nsplit; p += 4) s += ws[(size_t)p * n_elems + i];
+  if (i < n_elems) {
+#pragma unroll 4
+    for (int p = ty; p < nsplit; p += 8) s += ws[(size_t)p * n_elems + i];
+  }
   part[ty][tx] = s;
   __syncthreads();
   if (ty != 0 || i >= n_elems) return;
-  s = ((part[0][tx] + part[1][tx]) + part[2][tx]) + part[3][tx];
+  s = part[0][tx];
+#pragma unroll
+  for (int q = 1; q < 8; ++q) s += part[q][tx];   // fixed order: deterministic
   size_t k = i / N;
   const size_t n = i - k * N;
   if (sub_rows > 0) k = (k / sub_rows) * row_pitch + row_off + k % sub_rows;
@@ -1639,7 +1643,7 @@ __global__ __launch_bounds__(256) void reduce_splits_wide_kernel(const float* __
 static int launch_reduce_splits(hipStream_t st, const float* ws, int nsplit, size_t n_elems, int N, float* dw, int ldw,
                                 int sub_rows, int row_pitch, int row_off) {
   if (nsplit >= 16 && n_elems * 4 < (size_t)1 << 20)
-    hipLaunchKernelGGL(reduce_splits_wide_kernel, dim3((unsigned)((n_elems + 63) / 64)), dim3(256), 0, st, ws, nsplit,
+    hipLaunchKernelGGL(reduce_splits_wide_kernel, dim3((unsigned)((n_elems + 31) / 32)), dim3(256), 0, st, ws, nsplit,
                        n_elems, N, dw, ldw, sub_rows, row_pitch, row_off);
   else
     hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((n_elems + 255) / 256)), dim3(256), 0, st, ws, nsplit,
@@ -1672,8 +1676,9 @@ static WgradPlan plan_wgrad(const ConvGeom& g, const ConvSrc& s0, int nsrc, cons
   else if (p.kt == 64) p.nt = (n32 <= 64) ? 64 : 128;
   else p.nt = 128;
   p.ntiles = (g.Npad + p.nt - 1) / p.nt;
-  // 65.5 KB of LDS per block: 2 resident blocks per CU
-  const long want = pick_ksplit((long)p.ktiles * p.ntiles, M, 512);
+  // resident blocks per CU follow the LDS footprint 2*32*(kt+nt)*4 B: 2 for the 128x128 tile, up to 4 for thin ones
+  const long per_cu = std::max(1L, std::min(4L, 163840L / (2L * 32 * (p.kt + p.nt) * 4)));
+  const long want = pick_ksplit((long)p.ktiles * p.ntiles, M, 256 * per_cu);
   int rows = (int)(((M + want - 1) / want + 31) / 32 * 32);
   p.rows_per_split = rows;
   p.ksplit = (M + rows - 1) / rows;
