@@ -74,8 +74,17 @@ def main():
     lib = _lib.load()
     _lib.check(lib.ics_set_device(local_rank))
 
+    # ICSG3D_BENCH_FORCE_DIST=1 takes the multi-process path (gloo rendezvous, ncclUniqueId hand-off, RCCL
+    # communicator, all-reduce inside Adam) even with one rank: the only way to exercise it on a 1-GPU box
+    use_dist = world > 1 or (os.environ.get("ICSG3D_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
     dist = None
-    if world > 1:
+    json_fd = None
+    if use_dist:
+        # RCCL prints its version banner on STDOUT from ncclCommInitRank; the contract is ONE JSON line there.
+        # Everything else this process writes to fd 1 goes to stderr; the JSON line is written to the saved fd.
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
         import torch  # noqa: F401  (control plane only: gloo rendezvous, barrier, max-reduce)
         import torch.distributed as dist
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -86,7 +95,7 @@ def main():
     X, labels, _ = synthetic_batch(B, d, C, seed=rank)   # each rank its own shard of the global batch
     eng.upload_batch(X, labels)
 
-    if world > 1:
+    if use_dist:
         import torch
         uid = [comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
@@ -171,7 +180,11 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
+        if json_fd is not None:
+            sys.stdout.flush()
+            os.write(json_fd, (json.dumps(out) + "\n").encode())
+        else:
+            print(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
