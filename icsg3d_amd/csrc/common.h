@@ -83,7 +83,6 @@ size_t conv_fwd_workspace_floats(const ConvGeom& g, const ConvSrc* src, int nsrc
 int launch_conv_fwd_par(hipStream_t st, const ConvGeom& g_lowres, const ConvSrc& src, const float* wpar, float* out,
                         int ldo, const float* bias = nullptr, int pre_act = ACT_NONE, float* stat_partial = nullptr,
                         int* stat_blocks = nullptr);
-const char* conv_fwd_par_kernel_id(const ConvGeom& g_lowres);
 int launch_pack_par(hipStream_t st, const float* w, int Cin_total, int Cout, int c_off, int Cu, float* dst, int Kpad,
                     int Npad);
 int launch_pack_fwd_sub(hipStream_t st, const float* w, int taps, int Cin_total, int Cout, int c_off, int Csub,
@@ -103,8 +102,6 @@ int launch_conv_wgrad_ablate(hipStream_t st, const ConvGeom& g, const ConvSrc* s
                              float* workspace, int ablate);
 int launch_conv_fwd_ablate(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int nsrc, const float* wp,
                            float* out, int ldo, int ablate);
-const char* conv_fwd_kernel_id(const ConvGeom& g, const ConvSrc* src, int nsrc);
-const char* conv_wgrad_kernel_id(const ConvGeom& g, const ConvSrc* src, int nsrc);
 // weight packing: Keras [taps][Cin][Cout] -> [Kpad/4][Npad][4]
 int launch_pack_fwd(hipStream_t st, const float* w, int K, int N, float* dst, int Kpad, int Npad,
                     int k_off, int n_off, int zero_first, int cin_log = 0, int cin_phys = 0);

@@ -686,18 +686,6 @@ static bool conv_is_thin(const ConvGeom& g, const ConvSrc& s0, int nsrc) {
   return nsrc == 1 && s0.bcast == 0 && s0.C == g.Cin && (g.Cin == 4 || g.Cin == 8 || g.Cin == 16);
 }
 
-// name of the kernel instantiation launch_conv_fwd will run (profiling rows / roofline)
-const char* conv_fwd_kernel_id(const ConvGeom& g, const ConvSrc* src, int nsrc) {
-  ConvSrc s0 = src[0], s1 = src[nsrc > 1 ? 1 : 0];
-  const bool vec = fwd_is_vec(g, s0, s1) || conv_is_thin(g, s0, nsrc);
-  int bm, bn;
-  pick_fwd_tile(g, &bm, &bn);
-  if (bm == 64) return vec ? "conv_fwd_kernel<2,2,1,1,vec>" : "conv_fwd_kernel<2,2,1,1,scalar>";
-  if (bn == 128) return vec ? "conv_fwd_kernel<2,2,2,2,vec>" : "conv_fwd_kernel<2,2,2,2,scalar>";
-  if (bn == 96) return vec ? "conv_fwd_kernel<4,1,1,3,vec>" : "conv_fwd_kernel<4,1,1,3,scalar>";
-  if (bn == 64) return vec ? "conv_fwd_kernel<2,2,2,1,vec>" : "conv_fwd_kernel<2,2,2,1,scalar>";
-  return vec ? "conv_fwd_kernel<4,1,1,1,vec>" : "conv_fwd_kernel<4,1,1,1,scalar>";
-}
 
 int conv_fwd_rows_per_block(const ConvGeom& g) {
   int bm, bn;
@@ -1060,15 +1048,6 @@ static void pick_par_tile(const ConvGeom& g, int* bm, int* bn) {
   if (*bm == 64 && g.Npad % 128 == 0 && (long)(((g.B << (3 * g.lgS)) + 127) / 128) * (g.Npad / 128) * 8 >= 384) {
     *bm = 128; *bn = 128;
   }
-}
-const char* conv_fwd_par_kernel_id(const ConvGeom& g) {
-  int bm, bn;
-  pick_par_tile(g, &bm, &bn);
-  if (bm == 64) return "conv_fwd_kernel<2,2,1,1,vec,par>";
-  if (bn == 128) return "conv_fwd_kernel<2,2,2,2,vec,par>";
-  if (bn == 96) return "conv_fwd_kernel<4,1,1,3,vec,par>";
-  if (bn == 64) return "conv_fwd_kernel<2,2,2,1,vec,par>";
-  return "conv_fwd_kernel<4,1,1,1,vec,par>";
 }
 int launch_conv_fwd_par(hipStream_t st, const ConvGeom& g, const ConvSrc& src, const float* wp, float* out,
                         int ldo, const float* bias, int pre_act, float* stat_partial, int* stat_blocks) {
@@ -1727,22 +1706,6 @@ static Wgrad3Plan plan_wgrad3(const ConvGeom& g) {
   return p;
 }
 
-const char* conv_wgrad_kernel_id(const ConvGeom& g, const ConvSrc* src, int nsrc) {
-  ConvSrc s0 = src[0], s1 = src[nsrc > 1 ? 1 : 0];
-  if (wgrad3_ok(g, s0, nsrc, s1)) return "conv_wgrad3_kernel";
-  const WgradPlan p = plan_wgrad(g, s0, nsrc, s1);
-  if (p.kt == 128) {
-    if (p.nt == 128) return p.vec ? "conv_wgrad_kernel<2,2,2,2,vec>" : "conv_wgrad_kernel<2,2,2,2,scalar>";
-    if (p.nt == 96) return p.vec ? "conv_wgrad_kernel<4,1,1,3,vec>" : "conv_wgrad_kernel<4,1,1,3,scalar>";
-    if (p.nt == 64) return p.vec ? "conv_wgrad_kernel<4,1,1,2,vec>" : "conv_wgrad_kernel<4,1,1,2,scalar>";
-    return p.vec ? "conv_wgrad_kernel<4,1,1,1,vec>" : "conv_wgrad_kernel<4,1,1,1,scalar>";
-  }
-  if (p.kt == 64) {
-    if (p.nt == 128) return p.vec ? "conv_wgrad_kernel<2,2,1,2,vec>" : "conv_wgrad_kernel<2,2,1,2,scalar>";
-    return p.vec ? "conv_wgrad_kernel<2,2,1,1,vec>" : "conv_wgrad_kernel<2,2,1,1,scalar>";
-  }
-  return p.vec ? "conv_wgrad_kernel<1,4,1,1,vec>" : "conv_wgrad_kernel<1,4,1,1,scalar>";
-}
 
 size_t conv_wgrad_workspace_floats(const ConvGeom& g, const ConvSrc* src, int nsrc) {
   if (thin_n_ok(g, src[0], nsrc)) return (size_t)thin_n_wgrad_splits(g) * g.taps * g.Cin * g.Cout;
