@@ -389,6 +389,21 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // accumulate: the accumulators START from the previous contents of out (the parity-class pass of an up-split
+  // layer), so the read's latency hides under the prologue instead of stalling the epilogue
+  if (accumulate && !PAR && gridDim.z == 1) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * TN * 32 + j * 32 + li;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mb * BM + wm * TM * 32 + 4 * lh + i * 32 + (r & 3) + 8 * (r >> 2);
+          if (m < M && n < g.Cout) acc[i][j][r] = out[(size_t)m * ldo + n];
+        }
+    }
+  }
 
   // generic MFMA stream over one staged chunk; arow0 = LDS row of this lane's first A row
   auto compute_at = [&](const float* Abase, int arow_stride_rows, int bbuf) {
@@ -574,7 +589,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
           mo = ((((size_t)rp.b * (2 * S) + 2 * rp.z + pz) * (2 * S) + 2 * rp.y + py) * (2 * S)) + 2 * rp.x + px;
         }
         float a = acc[i][j][r] + bv;
-        if (accumulate && ok && nvalid) a += out[mo * ldo + n];
+        if (PAR && accumulate && ok && nvalid) a += out[mo * ldo + n];
         float v = act_apply(a, pre_slope);
         if (!ok) v = 0.f;
         acc[i][j][r] = v;
