@@ -999,7 +999,9 @@ int launch_conv_fwd(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int n
                     float* stat_partial, int* rows_per_block, int accumulate, float* ws, size_t ws_floats) {
   ConvSrc s0 = src[0], s1 = src[nsrc > 1 ? 1 : 0];
   if (nsrc == 1) s1.C = 0;
-  const int ks = ws ? fwd_splitk_plan(g, s0, s1, nsrc) : 1;
+  int ks = ws ? fwd_splitk_plan(g, s0, s1, nsrc) : 1;
+  // workspaces are sized at the handle's maximum batch; a smaller batch may plan more splits than fit: run unsplit
+  if (ks > 1 && (size_t)ks * ((size_t)g.B << (3 * g.lgS)) * g.Npad > ws_floats) ks = 1;
   if (ks <= 1) return launch_conv_fwd_inner(st, g, src, nsrc, wp, bias, out, ldo, pre_act, stat_partial,
                                             rows_per_block, accumulate, 1);
   const int M = g.B << (3 * g.lgS);

@@ -352,8 +352,10 @@ static int alloc_workspaces(Net& n, bool need_bwd) {
   }
   n.ws_stat_n = stat; n.ws_bwd_n = std::max(bwd, (size_t)4096 * 128); n.ws_wgrad_n = wg;
   ICS_TRY(n.alloc(&n.ws_stat, stat + 16));
-  n.ws_fwd_n = fw;
-  if (fw) ICS_TRY(n.alloc(&n.ws_fwd, fw + 16));
+  // ks*M*Npad <= 768 slots x 64 x 64 floats whatever the batch: keep at least that much so that batches below
+  // max_batch (which plan more splits) can still split
+  n.ws_fwd_n = std::max(fw, (size_t)768 * 64 * 64);
+  ICS_TRY(n.alloc(&n.ws_fwd, n.ws_fwd_n + 16));
   if (need_bwd) {
     ICS_TRY(n.alloc(&n.ws_bwd, n.ws_bwd_n + 16));
     ICS_TRY(n.alloc(&n.ws_wgrad, wg + 16));

@@ -82,3 +82,40 @@ def test_training_scripts_run_on_synthetic_data(tmp_path):
                     "--batch_size", "2", "--nsamples", "4"], cwd=tmp_path, env=env, check=True)
     sp = np.load(tmp_path / "output" / "results" / "synthetic__v=0.5" / "species" / "3.npy")
     assert sp.shape == (16, 16, 16) and sp.dtype == np.uint8
+
+
+def test_batches_below_max_batch_match_a_right_sized_engine():
+    """The last batch of an epoch is smaller than max_batch: workspaces and split-K plans are sized at
+    max_batch, results must not depend on it (bit-equal to an engine created for exactly that batch)."""
+    from icsg3d_amd.engine import UnetEngine, VaeEngine
+    from icsg3d_amd.synthetic import glorot_params, synthetic_batch, unet_param_shapes, vae_param_shapes
+    d = 16
+    PU, PV = glorot_params(unet_param_shapes(1, 95), 1), glorot_params(vae_param_shapes(1, d=d), 3)
+
+    def fresh(eng, P):   # weights, BatchNorm moving statistics and optimizer state back to their initial values
+        eng.set_weights(P)
+        for name, shape, trainable in eng.tensor_infos():
+            if name.endswith("moving_mean"):
+                eng.set_tensor(name, np.zeros(shape, np.float32))
+            if name.endswith("moving_var"):
+                eng.set_tensor(name, np.ones(shape, np.float32))
+        eng.reset_optimizer()
+
+    big_u = UnetEngine(d=d, max_batch=8, lr=1e-4)
+    big_pm = UnetEngine(d=d, max_batch=8)
+    big_v = VaeEngine(big_pm, d=d, max_batch=8, lr=1e-4)
+    for B in (1, 3, 8):
+        X, lab, cond = synthetic_batch(B, d, 1, seed=B, noise=1e-3)
+        eps = np.random.default_rng(B).standard_normal((B, 256)).astype(np.float32)
+        u = UnetEngine(d=d, max_batch=B, lr=1e-4)
+        fresh(u, PU); fresh(big_u, PU)
+        np.testing.assert_array_equal(big_u.predict(X)[0], u.predict(X)[0])
+        np.testing.assert_array_equal(big_u.train_step(X, lab), u.train_step(X, lab))
+        wa, wb = big_u.get_weights(), u.get_weights()
+        assert all(np.array_equal(wa[k], wb[k]) for k in wa)
+        pm = UnetEngine(d=d, max_batch=B)
+        v = VaeEngine(pm, d=d, max_batch=B, lr=1e-4)
+        fresh(pm, PU); fresh(big_pm, PU); fresh(v, PV); fresh(big_v, PV)
+        np.testing.assert_array_equal(big_v.train_step(X, cond, eps), v.train_step(X, cond, eps))
+        wa, wb = big_v.get_weights(), v.get_weights()
+        assert all(np.array_equal(wa[k], wb[k]) for k in wa)
