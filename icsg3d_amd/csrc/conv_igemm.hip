@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
   // REUSE: BM rows + one zero row after each of the BM/S lines + one leading zero row
   const int A_FLOATS = (REUSE ? BM + (BM >> g.lgS) + 1 : BM) * kLDA;
   float* As = smem;                      // [2][rows][36]
-  constexpr int NABUF = REUSE ? 1 : 2;   // REUSE: one A buffer (3 blocks/CU fit in LDS), restaged behind a barrier
+  constexpr int NABUF = 1;   // one A buffer, restaged behind a barrier: 52 instead of 70 KB of LDS -> 3 blocks/CU
   float* Bs = smem + NABUF * A_FLOATS;   // [2][8][BN][4]
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -369,9 +369,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
     }
   };
 
-  auto store_chunk = [&](int buf) {
-    float* A = As + buf * A_FLOATS;
-    store_b(buf);
+  auto store_a_chunk = [&]() {
+    float* A = As;
     if (VEC) {
 #pragma unroll
       for (int r = 0; r < RA; ++r)
@@ -532,11 +531,12 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
   }
   if (cb < ce) {
   load_chunk(cb);
-  store_chunk(cb & 1);
+  store_b(cb & 1);
+  store_a_chunk();
   __syncthreads();
 
   auto compute = [&](int buf) {
-    compute_at(As + buf * A_FLOATS + (wm * TM * 32 + li) * kLDA + lh * 4, 32, buf);
+    compute_at(As + (wm * TM * 32 + li) * kLDA + lh * 4, 32, buf);
   };
   auto compute_regs_only = [&]() {
     float av = (float)li, bv = (float)lh;
@@ -552,7 +552,9 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
       // (sched_barrier fences around the MFMA stream were measured: -4 %; hipcc's own interleave wins)
       load_chunk(c + 1);
       compute(c & 1);
-      store_chunk((c + 1) & 1);
+      store_b((c + 1) & 1);
+      __syncthreads();
+      store_a_chunk();
       __syncthreads();
     }
   } else {
@@ -658,11 +660,11 @@ static int launch_fwd_cfg(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, 
   const int M = g.B << (3 * g.lgS);
   const int gridM = (M + BM - 1) / BM, gridN = g.Npad / BN;
   const int arows = REUSE ? BM + (BM >> g.lgS) + 1 : BM;
-  const size_t lds = (size_t)((REUSE ? 1 : 2) * arows * kLDA + 2 * 32 * BN) * sizeof(float);
+  const size_t lds = (size_t)(arows * kLDA + 2 * 32 * BN) * sizeof(float);
   auto kern = conv_fwd_kernel<WM, WN, TM, TN, VEC, ABL, AFF, UP, THIN, REUSE, PAR>;
   static bool attr_set = false;
   if (!attr_set) {
-    const size_t lds_max = (size_t)((REUSE ? 1 : 2) * (REUSE ? BM + BM / 4 + 1 : BM) * kLDA + 2 * 32 * BN) * sizeof(float);
+    const size_t lds_max = (size_t)((REUSE ? BM + BM / 4 + 1 : BM) * kLDA + 2 * 32 * BN) * sizeof(float);
     ICS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
     attr_set = true;
