@@ -50,6 +50,98 @@ def cpu_baseline(sample_grids=4):
                 "sample": "cpu baseline failed: %s" % e}
 
 
+def run_vae_or_joint(args, rank, local_rank, world, use_dist, dist, json_fd):
+    """Secondary workloads (not the driver's default line): --workload vae = BASELINE configs[2] (DFC-VAE step with
+    the frozen perceptual U-Net), --workload joint = one U-Net step + one DFC-VAE step per iteration on the same
+    grids (configs[3]/[4] shape: both engines resident, both gradient all-reduces per iteration)."""
+    from icsg3d_amd.engine import UnetEngine, VaeEngine, comm_unique_id
+    from icsg3d_amd.synthetic import glorot_params, synthetic_batch, unet_param_shapes, vae_param_shapes
+    B, d, C = args.batch, args.d, 1
+    joint = args.workload == "joint"
+    PU = glorot_params(unet_param_shapes(C, 95), seed=1)
+    pm = UnetEngine(in_channels=C, d=d, max_batch=B); pm.set_weights(PU)
+    vae = VaeEngine(pm, in_channels=C, d=d, max_batch=B, lr=5e-4)
+    vae.set_weights(glorot_params(vae_param_shapes(C, d=d), seed=3))
+    X, labels, cond = synthetic_batch(B, d, C, seed=rank)
+    eps = np.random.default_rng(2 + rank).standard_normal((B, 256)).astype(np.float32)
+    vae.upload_batch(X, cond, eps)
+    engines = [vae]
+    unet = None
+    if joint:
+        unet = UnetEngine(in_channels=C, d=d, max_batch=B, lr=3e-6); unet.set_weights(PU)
+        unet.upload_batch(X, labels)
+        engines.append(unet)
+    if use_dist:
+        for e in engines:
+            uid = [comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            e.comm_init(rank, world, uid[0])
+
+    def step(m=False):
+        if unet is not None:
+            unet.train_step_resident(False)
+        return vae.train_step_resident(m)
+
+    def barrier():
+        for e in engines:
+            e.sync()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    for e in engines + [pm]:
+        e.profile_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    rows = [r for e in engines + [pm] for r in e.profile_rows()]
+    metrics = step(True)
+    if not np.all(np.isfinite(metrics)):
+        raise SystemExit("non-finite training metrics: %s" % metrics)
+    if rank == 0:
+        by_kernel = {}
+        for r in rows:
+            kid = r["label"].split("|")[1] if "|" in r["label"] and r["label"].split("|")[1] else r["label"]
+            a = by_kernel.setdefault(kid, {"ms": 0.0, "flop": 0.0, "launches": 0})
+            a["ms"] += r["ms"]; a["flop"] += r["flop"]; a["launches"] += r["launches"]
+        dom_name, dom = max(by_kernel.items(), key=lambda kv: kv[1]["ms"])
+        achieved = dom["flop"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+        exec_flop = sum(r["flop"] for r in rows) / args.steps
+        ms_per_step = elapsed / args.steps * 1e3
+        out = {"metric": "voxel-grids/s (fwd+bwd) for %d^3 %s at batch %d per GPU"
+                         % (d, "U-Net step + DFC-VAE step" if joint else "DFC-VAE step", B),
+               "value": round(world * B * args.steps / elapsed, 2), "unit": "voxel-grids/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "%s, %d x %d^3 x 1 grids per GPU" % (args.workload, B, d),
+                          "global_batch": world * B, "grid": d, "parallelism": "dp%d" % world},
+               "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2),
+                            "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": None,
+                            "launches": dom["launches"]},
+               "roofline_step": {"executed_tflop_per_step": round(exec_flop / 1e12, 3),
+                                 "compute_frac": round(exec_flop / (ms_per_step * 1e-3) / (PEAK_FP32_TFLOPS * 1e12), 4)},
+               "cpu_baseline": None}
+        line = json.dumps(out) + "\n"
+        if json_fd is not None:
+            sys.stdout.flush(); os.write(json_fd, line.encode())
+        else:
+            sys.stdout.write(line)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -58,6 +150,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="grids per GPU")
     ap.add_argument("--d", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=("unet", "vae", "joint"), default="unet",
+                    help="unet = the contract line (BASELINE configs[1]); vae / joint = secondary measurements")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -88,6 +182,9 @@ def main():
         import torch  # noqa: F401  (control plane only: gloo rendezvous, barrier, max-reduce)
         import torch.distributed as dist
         dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    if args.workload != "unet":
+        return run_vae_or_joint(args, rank, local_rank, world, use_dist, dist, json_fd)
 
     B, d, C = args.batch, args.d, 1
     eng = UnetEngine(in_channels=C, num_classes=95, d=d, max_batch=B, lr=3e-6)
