@@ -1,0 +1,61 @@
+"""Every fast path has an A/B switch (ICSG3D_NO_*) that routes the same layer through the general kernels.
+Most switches are read once per process, so each configuration runs in a subprocess; all of them must give
+the same forward results and train-step metrics as the default configuration (different summation orders:
+<= 2e-5), which keeps the fallback kernels covered at the network's real layer shapes."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r"""
+import json, sys
+import numpy as np
+sys.path.insert(0, %r)
+from icsg3d_amd.engine import UnetEngine, VaeEngine
+from icsg3d_amd.synthetic import glorot_params, synthetic_batch, unet_param_shapes, vae_param_shapes
+B, d = 2, 16
+PU = glorot_params(unet_param_shapes(1, 95), 1)
+X, lab, cond = synthetic_batch(B, d, 1, seed=0, noise=1e-3)
+eps = np.random.default_rng(2).standard_normal((B, 256)).astype(np.float32)
+u = UnetEngine(d=d, max_batch=B, lr=1e-4); u.set_weights(PU)
+soft, sig = u.predict(X)
+mu = u.train_step(X, lab)
+pm = UnetEngine(d=d, max_batch=B); pm.set_weights(PU)
+v = VaeEngine(pm, d=d, max_batch=B, lr=1e-4); v.set_weights(glorot_params(vae_param_shapes(1, d=d), 3))
+zm, zlv, z = v.encode(X, cond, eps)
+rec = v.decode(z, cond)
+mv = v.train_step(X, cond, eps)
+g = u.get_grad("soft/kernel", (1, 1, 1, 128, 95))
+print(json.dumps({"soft": soft[:, ::5, ::5, ::5].ravel().tolist(), "sig": sig[:, ::5, ::5, ::5].ravel().tolist(),
+                  "mu": np.asarray(mu).tolist(), "mv": np.asarray(mv).tolist(), "zm": zm.ravel()[::7].tolist(),
+                  "rec": rec[:, ::5, ::5, ::5].ravel().tolist(), "g": g.ravel()[::37].tolist()}))
+""" % ROOT
+
+
+def _run(env_extra):
+    env = dict(os.environ)
+    env.update(env_extra)
+    out = subprocess.run([sys.executable, "-c", SCRIPT], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return {k: np.asarray(v) for k, v in json.loads(out.stdout.strip().splitlines()[-1]).items()}
+
+
+@pytest.fixture(scope="module")
+def default_run():
+    return _run({})
+
+
+@pytest.mark.parametrize("switch", ["ICSG3D_NO_REUSE", "ICSG3D_NO_WGRAD3", "ICSG3D_NO_FWD_SPLITK",
+                                    "ICSG3D_NO_THIN_N", "ICSG3D_NO_UPSPLIT"])
+def test_fallback_path_matches_default(default_run, switch):
+    alt = _run({switch: "1"})
+    for k, ref in default_run.items():
+        scale = max(float(np.abs(ref).max()), 1e-30)
+        assert float(np.abs(alt[k] - ref).max()) <= 2e-5 * scale, (switch, k)
