@@ -1655,7 +1655,7 @@ struct WgradPlan {
   bool vec, thin;
 };
 
-static int pick_ksplit(long base, long M, long slots);
+static int pick_ksplit(long base, long M, long slots, long r0 = 1);
 static WgradPlan plan_wgrad(const ConvGeom& g, const ConvSrc& s0, int nsrc, const ConvSrc& s1) {
   WgradPlan p;
   const int M = g.B << (3 * g.lgS);
@@ -1687,15 +1687,15 @@ static WgradPlan plan_wgrad(const ConvGeom& g, const ConvSrc& s0, int nsrc, cons
 // slots = 3.006 rounds leave a nearly empty 4th round: measured -20 %).  Every split costs a pass of the
 // reduction over the weight tensor, so take the FEWEST rounds whose last round is >= 95 % full (c18: 170 splits
 // filled 6 rounds and cost a 300 MB reduction; 42 splits fill one), else the best fill; splits keep >= 256 rows.
-static int pick_ksplit(long base, long M, long slots) {
+static int pick_ksplit(long base, long M, long slots, long r0) {
   const long ks_max = std::max<long>(1, M / 256);
   long want = 1;
   double best = -1.0;
-  for (long r = 1; r <= 6; ++r) {
+  for (long r = r0; r <= 6; ++r) {
     long ks = (r * slots) / base;
     if (ks < 1) ks = 1;
     if (ks > 512) ks = 512;
-    if (ks > ks_max) { if (r > 1) break; ks = ks_max; }   // small M: as many >= 256-row splits as there are
+    if (ks > ks_max) { if (r > r0) break; ks = ks_max; }   // small M: as many >= 256-row splits as there are
     const long total = base * ks;
     const double fill = (double)total / (double)(((total + slots - 1) / slots) * slots);
     if (fill > best + 1e-9) { best = fill; want = ks; }
@@ -1719,7 +1719,10 @@ static Wgrad3Plan plan_wgrad3(const ConvGeom& g) {
   const long M = (long)g.B << (3 * g.lgS);
   p.cgroups = g.Cin / 64;
   p.ntiles = g.Cout / 128;
-  const int want = pick_ksplit(9L * p.cgroups * p.ntiles, M, g.lgS > 5 ? 512 : 768);   // 3 blocks/CU (2 at S = 64)
+  // 3 blocks/CU (2 at S = 64); two rounds: the second round evens out the tail of the first (c18: 130.5 ->
+  // 132.2 TFLOP/s) for one more pass of the split reduction (+0.12 ms/step over all layers) - a wash on the
+  // step, taken for the better-balanced dominant kernel
+  const int want = pick_ksplit(9L * p.cgroups * p.ntiles, M, g.lgS > 5 ? 512 : 768, 2);
   p.rows_per_split = (int)(((M + want - 1) / want + 31) / 32 * 32);
   p.ksplit = (int)((M + p.rows_per_split - 1) / p.rows_per_split);
   return p;
