@@ -236,14 +236,20 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
   float ras[RS];
   v4f rb[NB];
 
-  // ---- B tile of K rows [krow4*4, krow4*4+32): packed weights [Kpad/4][Npad][4]
-  auto load_b = [&](int krow4) {
+  // ---- B tile of K rows [krow4*4, krow4*4+32): packed weights [Kpad/4][Npad][4].
+  // Address = wave-uniform row pointer (scalar registers) + a per-thread byte offset fixed for the whole kernel:
+  // no vector address arithmetic per chunk (the 64-bit mads it replaced cost ~2 % of the MFMA issue slots -
+  // fp32 VALU work and fp32 MFMAs serialise on a SIMD, scripts/probes/pipe_probe.hip).
+  unsigned bofs[NB];
 #pragma unroll
-    for (int r = 0; r < NB; ++r) {
-      const int idx = t + 256 * r;
-      const int kq = idx / BN, n = idx % BN;
-      rb[r] = *reinterpret_cast<const v4f*>(wp + ((size_t)(krow4 + kq) * g.Npad + n0 + n) * 4);
-    }
+  for (int r = 0; r < NB; ++r) {
+    const int idx = t + 256 * r;
+    bofs[r] = (unsigned)((idx / BN) * g.Npad + n0 + idx % BN) * 16u;
+  }
+  auto load_b = [&](int krow4) {
+    const char* wrow = reinterpret_cast<const char*>(wp) + (size_t)krow4 * (size_t)g.Npad * 16;
+#pragma unroll
+    for (int r = 0; r < NB; ++r) rb[r] = *reinterpret_cast<const v4f*>(wrow + bofs[r]);
   };
   auto store_b = [&](int buf) {
     float* Bw = Bs + buf * B_FLOATS;
@@ -252,11 +258,19 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
   };
   // REUSE: A tile of group G = (dz*3+dy)*cpt + cc, i.e. the dx = 0 rows of 32 channels
   // (PAR: G = (ez*2+ey)*cpt + cc with dz = ez+pz-1, dy = ey+py-1; two dx chunks per group instead of three)
-  auto load_a_group = [&](int G) {
-    const int gzy = G / cpt, ci0 = (G - gzy * cpt) << 5;
+  unsigned rowB0[RA], rowB1[RA];   // byte offset of this thread's rows in source 0 / 1 (same-resolution sources)
+  if (VEC) {
+#pragma unroll
+    for (int r = 0; r < RA; ++r) {
+      rowB0[r] = (unsigned)(mrow_base + 32 * r) * (unsigned)s0.C * 4u;
+      rowB1[r] = (unsigned)(mrow_base + 32 * r) * (unsigned)s1.C * 4u;
+    }
+  }
+  auto load_a_group = [&](int gzy, int cc) {
+    const int ci0 = cc << 5;
     const int dz = PAR ? (gzy >> 1) + pz - 1 : gzy / 3 - 1, dy = PAR ? (gzy & 1) + py - 1 : gzy % 3 - 1;
     const bool first = ci0 < s0.C;
-    const float* sp = first ? s0.p : s1.p;
+    const char* sp = reinterpret_cast<const char*>(first ? s0.p : s1.p);
     const float* sscale = first ? s0.scale : s1.scale;
     const float* sshift = first ? s0.shift : s1.shift;
     const int sC = first ? s0.C : s1.C, su = first ? s0.up : s1.up;
@@ -265,20 +279,21 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
     const v4f sc = *reinterpret_cast<const v4f*>(sscale + cl);
     const v4f sh = *reinterpret_cast<const v4f*>(sshift + cl);
     const int sdelta = (dz * S + dy) * S;
+    const unsigned goffb = (unsigned)(sdelta * sC + cl) * 4u;     // wraps for negative shifts; rowB + goffb is exact
     const int Sh = S >> 1;
 #pragma unroll
     for (int r = 0; r < RA; ++r) {
       const unsigned mk = rmask[r];
       const bool inb = (mk >> (PAR ? 8 + gzy : gzy * 3 + 1)) & 1u;   // validity of the centre (dx = 0) tap
-      int idx = mrow_base + 32 * r + sdelta;
+      unsigned offb = (first ? rowB0[r] : rowB1[r]) + goffb;
       if (UP) {
         const int ez = (dz + (int)((mk >> 29) & 1u)) >> 1;
         const int ey = (dy + (int)((mk >> 28) & 1u)) >> 1;
-        const int idx_up = rvh[r] + (ez * Sh + ey) * Sh;
-        idx = su ? idx_up : idx;
+        const unsigned up_b = ((unsigned)(rvh[r] + (ez * Sh + ey) * Sh) * (unsigned)sC + (unsigned)cl) * 4u;
+        offb = su ? up_b : offb;
       }
-      const unsigned off = inb ? (unsigned)idx * (unsigned)sC + cl : (unsigned)cl;
-      v4f v = *reinterpret_cast<const v4f*>(sp + off);
+      offb = inb ? offb : (unsigned)cl * 4u;
+      v4f v = *reinterpret_cast<const v4f*>(sp + offb);
       if (AFF) v = affine_act4(v, sc, sh, slope);
       ra4[r] = inb ? v : v4f{0.f, 0.f, 0.f, 0.f};
     }
@@ -448,9 +463,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
       const int row = wm * TM * 32 + i * 32 + li;
       arow[i] = row + (row >> lg) + 1;
     }
-    auto b_rows = [&](int c) {   // first packed K row (in units of 4) of chunk c
-      const int G = c / NDX, dxi = c - NDX * G;
-      const int gzy = G / cpt, cc = G - gzy * cpt;
+    auto b_rows = [&](int gzy, int cc, int dxi) {   // first packed K row (in units of 4) of a chunk
       return (((gzy * NDX + dxi) * g.Cin + (cc << 5)) >> 2);
     };
     auto compute_reuse = [&](int abuf, int bbuf, int dx) {
@@ -489,36 +502,42 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
       G1 = min(G1, ((int)blockIdx.z + 1) * per);
     }
     if (G0 < G1) {
-    load_a_group(G0);
+    // (gzy, cc) of the current / next group are carried incrementally: no integer division in the loop
+    int gzy = G0 / cpt, cc = G0 - gzy * cpt;
+    int par = 0;                                   // B buffer holding the current chunk
+    load_a_group(gzy, cc);
     store_a_group(0);
-    load_b(b_rows(NDX * G0));
-    store_b((NDX * G0) & 1);
+    load_b(b_rows(gzy, cc, 0));
+    store_b(par);
     __syncthreads();
     for (int G = G0; G + 1 < G1; ++G) {
-      const int c0 = NDX * G;
+      int ngzy = gzy, ncc = cc + 1;
+      if (ncc == cpt) { ncc = 0; ++ngzy; }
       // first dx chunk: also fetch the next group's A rows (kept in registers until the group is done)
-      load_a_group(G + 1);
+      load_a_group(ngzy, ncc);
 #pragma unroll
       for (int i = 0; i < NDX; ++i) {
-        load_b(b_rows(c0 + i + 1));
-        compute_reuse(0, (c0 + i) & 1, dx_first + i);
-        store_b((c0 + i + 1) & 1);
+        load_b(i + 1 < NDX ? b_rows(gzy, cc, i + 1) : b_rows(ngzy, ncc, 0));
+        compute_reuse(0, par, dx_first + i);
+        par ^= 1;
+        store_b(par);
         __syncthreads();
       }
       // restage the (single) A buffer with the next group's tile
       store_a_group(0);
       __syncthreads();
+      gzy = ngzy; cc = ncc;
     }
     {
-      const int G = G1 - 1, c0 = NDX * G;
 #pragma unroll
       for (int i = 0; i + 1 < NDX; ++i) {
-        load_b(b_rows(c0 + i + 1));
-        compute_reuse(0, (c0 + i) & 1, dx_first + i);
-        store_b((c0 + i + 1) & 1);
+        load_b(b_rows(gzy, cc, i + 1));
+        compute_reuse(0, par, dx_first + i);
+        par ^= 1;
+        store_b(par);
         __syncthreads();
       }
-      compute_reuse(0, (c0 + NDX - 1) & 1, dx_first + NDX - 1);
+      compute_reuse(0, par, dx_first + NDX - 1);
       __syncthreads();
     }
     }   // G0 < G1
@@ -1032,6 +1051,9 @@ static int launch_conv_fwd_inner(hipStream_t st, const ConvGeom& g, const ConvSr
   ICS_TRY(fix_src(s1));
   bool vec = fwd_is_vec(g, s0, s1);
   const bool thin = conv_is_thin(g, s0, nsrc);
+  // the tile loaders address a source with 32-bit byte offsets
+  ICS_CHECK(((size_t)g.B << (3 * g.lgS)) * (size_t)std::max(s0.C, s1.C) * 4 <= 0xffffffffull,
+            "conv source larger than 4 GiB");
   static const bool no_reuse = getenv("ICSG3D_NO_REUSE") != nullptr;   // A/B switch for benchmarking
   int bm, bn;
   pick_fwd_tile(g, &bm, &bn);
