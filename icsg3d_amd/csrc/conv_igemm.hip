@@ -1745,6 +1745,173 @@ static int pick_ksplit(long base, long M, long slots, long r0) {
   return (int)want;
 }
 
+// wgrad3 with wave-uniform loaders (the hot variant): S = 2^LGC in {16, 32, 64}, M % 32 == 0, one same-resolution
+// source per 64-channel group, Cout % 128 == 0.  A 32-voxel chunk then lies inside one x-line (or two, S = 16), so
+// its (y, z) validity is a SCALAR; every global address is a wave-uniform base plus a per-thread byte offset fixed
+// for the whole kernel, LDS offsets are immediates, and no row / column bound checks remain:
+// 134 -> ~35 vector ALU instructions per 96 MFMAs (fp32 VALU and fp32 MFMA share the issue pipe).
+template <bool AFF, bool NOACT, int LGC>
+__global__ __launch_bounds__(256, LGC == 6 ? 2 : 3) void conv_wgrad3s_kernel(ConvGeom g, ConvSrc s0, ConvSrc s1,
+                                                                              const float* __restrict__ dy, int ldy,
+                                                                              float* __restrict__ ws, int cgroups,
+                                                                              int ntiles, int rows_per_split) {
+  constexpr int CK = 64, NT = 128;
+  constexpr int lg = LGC, S = 1 << LGC;
+  constexpr bool halo = LGC == 6;
+  constexpr int lines = halo ? 1 : (32 >> lg);           // x-lines (zero separators) per chunk
+  constexpr int arows = 32 + lines + 1;
+  constexpr int A_FLOATS = arows * CK, D_FLOATS = 32 * NT;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                    // [2][arows][64]
+  float* Ds = smem + 2 * A_FLOATS;     // [2][32][128]
+  float* Aff = Ds + 2 * D_FLOATS;      // [2][64] BN scale | shift of this block's channels
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int M = g.B << (3 * lg);
+  const int K = g.taps * g.Cin;
+
+  int bid = blockIdx.x;
+  const int nt_i = bid % ntiles; bid /= ntiles;
+  const int cg = bid % cgroups; bid /= cgroups;
+  const int gzy = bid % 9; bid /= 9;
+  const int split = bid;
+  const int n0 = nt_i * NT;
+  const int c0 = cg * CK;
+  const int m_begin = split * rows_per_split;            // multiples of 32 (M % 32 == 0, rows_per_split % 32 == 0)
+  const int m_end = min(M, m_begin + rows_per_split);
+  const int nchunks = (m_end - m_begin) >> 5;
+
+  const int dz = gzy / 3 - 1, dyy = gzy % 3 - 1;
+  const int sdelta = (dz * S + dyy) * S;
+  const int ybad = dyy < 0 ? 0 : (dyy > 0 ? S - 1 : -1);
+  const int zbad = dz < 0 ? 0 : (dz > 0 ? S - 1 : -1);
+  const bool first = c0 < s0.C;
+  const char* sp = reinterpret_cast<const char*>(first ? s0.p : s1.p);
+  const int sC = first ? s0.C : s1.C;
+  const float slope = act_slope_of(first ? s0.act : s1.act);
+  const int ac4 = t & 15;
+  const int cl = (first ? c0 : c0 - s0.C) + ac4 * 4;
+  if (AFF && t < 32) {
+    const float* src = (t < 16) ? (first ? s0.scale : s1.scale) : (first ? s0.shift : s1.shift);
+    *reinterpret_cast<v4f*>(Aff + t * 4) = *reinterpret_cast<const v4f*>(src + (first ? c0 : c0 - s0.C) + (t & 15) * 4);
+  }
+  // per-thread byte offsets, fixed for the kernel
+  const unsigned aoff = (unsigned)((t >> 4) * sC + cl) * 4u;                 // row (t>>4) of a 16-row half
+  const unsigned hoff = (unsigned)cl * 4u;                                   // halo row (S = 64)
+  unsigned doff[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) doff[p] = (unsigned)(((t >> 5) + 8 * p) * ldy + n0 + (t & 31) * 4) * 4u;
+  const int hside = (t >> 4) & 1;
+
+  v4f ra[2], rd[4], rah = v4f{0.f, 0.f, 0.f, 0.f};
+  auto load_chunk = [&](int c) {
+    const int mbase = m_begin + (c << 5);
+    v4f sc = v4f{1.f, 1.f, 1.f, 1.f}, sh = v4f{0.f, 0.f, 0.f, 0.f};
+    if (AFF) { sc = *reinterpret_cast<const v4f*>(Aff + ac4 * 4); sh = *reinterpret_cast<const v4f*>(Aff + 64 + ac4 * 4); }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int row0 = mbase + 16 * p;                                       // uniform
+      const int y = (row0 >> lg) & (S - 1), z = (row0 >> (2 * lg)) & (S - 1);
+      const bool inb = (y != ybad) & (z != zbad);                            // scalar
+      const float msk = inb ? 1.f : 0.f;
+      const char* base = sp + (inb ? (long)(row0 + sdelta) * sC * 4 : 0L);   // wave-uniform pointer
+      v4f v = *reinterpret_cast<const v4f*>(base + aoff);
+      if (AFF) v = affine_only_or_act4<NOACT>(v, sc, sh, slope);
+      ra[p] = v4f{v.x * msk, v.y * msk, v.z * msk, v.w * msk};               // zero padding AFTER BN / activation
+    }
+    if (halo) {   // S = 64: rows 0 / 33 of the tile are the real neighbours x0-1 / x0+32 (zero at the line ends)
+      const int x0 = mbase & (S - 1);
+      const int y = (mbase >> lg) & (S - 1), z = (mbase >> (2 * lg)) & (S - 1);
+      const bool lineok = (y != ybad) & (z != zbad);
+      const bool inl = lineok & (x0 != 0), inr = lineok & (x0 == 0);         // scalars
+      const char* bl = sp + (inl ? (long)(mbase - 1 + sdelta) * sC * 4 : 0L);
+      const char* br = sp + (inr ? (long)(mbase + 32 + sdelta) * sC * 4 : 0L);
+      const float msk = (hside ? inr : inl) ? 1.f : 0.f;
+      v4f v = *reinterpret_cast<const v4f*>((hside ? br : bl) + hoff);
+      if (AFF) v = affine_only_or_act4<NOACT>(v, sc, sh, slope);
+      rah = v4f{v.x * msk, v.y * msk, v.z * msk, v.w * msk};
+    }
+    const char* dbase = reinterpret_cast<const char*>(dy) + (size_t)mbase * (size_t)ldy * 4;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) rd[p] = *reinterpret_cast<const v4f*>(dbase + doff[p]);
+  };
+  // LDS positions of this thread's stores (constant)
+  float* a_st[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int r = (t >> 4) + 16 * p;
+    a_st[p] = As + (r + (halo ? 0 : (r >> lg)) + 1) * CK + ac4 * 4;
+  }
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) *reinterpret_cast<v4f*>(a_st[p] + buf * A_FLOATS) = ra[p];
+    if (halo && t < 32) *reinterpret_cast<v4f*>(As + buf * A_FLOATS + (hside ? 33 : 0) * CK + ac4 * 4) = rah;
+    float* D = Ds + buf * D_FLOATS;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) *reinterpret_cast<v4f*>(D + ((t >> 5) + 8 * p) * NT + (t & 31) * 4) = rd[p];
+  };
+
+  f32x16 acc[3][2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (!halo) {   // zero separator rows (row 0 and the row after every x-line) of both A buffers
+    for (int i = t; i < 2 * (lines + 1) * CK; i += 256) {
+      const int b = i / ((lines + 1) * CK), rem = i - b * (lines + 1) * CK;
+      As[b * A_FLOATS + (rem / CK) * (S + 1) * CK + rem % CK] = 0.f;
+    }
+  }
+  __syncthreads();   // the BN affine vectors in LDS are read by the very first load_chunk
+  if (nchunks > 0) {
+    load_chunk(0);
+    store_chunk(0);
+  }
+  __syncthreads();
+  auto compute = [&](int buf) {
+    const float* A = As + buf * A_FLOATS + 2 * li + lh * CK;
+    const float* D = Ds + buf * D_FLOATS + 32 * wave + li + lh * NT;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      constexpr int dummy = 0; (void)dummy;
+      const int prow = 2 * s + (halo ? 0 : ((2 * s) >> lg)) + 1;   // compile-time: padded A row of voxel 2s (+lh above)
+      const float b = D[(2 * s) * NT];
+      float2 a[3];
+#pragma unroll
+      for (int dxi = 0; dxi < 3; ++dxi) a[dxi] = *reinterpret_cast<const float2*>(A + (prow + dxi - 1) * CK);
+#pragma unroll
+      for (int dxi = 0; dxi < 3; ++dxi) {
+        acc[dxi][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[dxi].x, b, acc[dxi][0], 0, 0, 0);
+        acc[dxi][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[dxi].y, b, acc[dxi][1], 0, 0, 0);
+      }
+    }
+  };
+  for (int c = 0; c + 1 < nchunks; ++c) {
+    load_chunk(c + 1);
+    compute(c & 1);
+    store_chunk((c + 1) & 1);
+    __syncthreads();
+  }
+  if (nchunks > 0) compute((nchunks - 1) & 1);
+
+  float* wsp = ws + (size_t)split * K * g.Cout;
+  const int n = n0 + 32 * wave + li;
+#pragma unroll
+  for (int dxi = 0; dxi < 3; ++dxi)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int k = (gzy * 3 + dxi) * g.Cin + c0 + 2 * row + j;
+        wsp[(size_t)k * g.Cout + n] = acc[dxi][j][r];
+      }
+}
+
 // can the dx-reuse kernel run this geometry?  (27 taps, whole x-lines per 32-voxel chunk, 64-aligned
 // channel groups inside one source, full 128-wide vectorisable dy rows)
 static bool wgrad3_ok(const ConvGeom& g, const ConvSrc& s0, int nsrc, const ConvSrc& s1) {
@@ -1874,7 +2041,33 @@ int launch_conv_wgrad(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int
     const int arows = 32 + std::max(32 >> g.lgS, 1) + 1;
     const size_t lds = (size_t)(2 * (arows * 64 + 32 * 128) + 128) * sizeof(float);
     const dim3 grid(9 * q.cgroups * q.ntiles * q.ksplit);
-    if (phase != 2) {
+    const int M3 = g.B << (3 * g.lgS);
+    const bool fast = !up && g.lgS >= 4 && g.lgS <= 6 && M3 % 32 == 0 && n_load == g.Cout &&
+                      getenv("ICSG3D_NO_WGRAD3S") == nullptr;
+    if (phase != 2 && fast) {   // wave-uniform loaders (conv_wgrad3s_kernel)
+      const bool noact = aff && (src[0].scale == nullptr || src[0].act == ACT_NONE) &&
+                         (nsrc < 2 || src[1].scale == nullptr || src[1].act == ACT_NONE);
+      const int ar = 32 + (g.lgS == 6 ? 1 : (32 >> g.lgS)) + 1;
+      const size_t lds3 = (size_t)(2 * (ar * 64 + 32 * 128) + 128) * sizeof(float);
+#define ICS_W3S(AFFV, NOACTV, LGV)                                                                              \
+  do {                                                                                                          \
+    g_last_kernel_id = "conv_wgrad3s_kernel<" #AFFV ", " #NOACTV ", " #LGV ">";                                 \
+    hipLaunchKernelGGL((conv_wgrad3s_kernel<AFFV, NOACTV, LGV>), grid, dim3(256), lds3, st, g, s0, s1, dy, ldy,  \
+                       workspace, q.cgroups, q.ntiles, q.rows_per_split);                                       \
+  } while (0)
+#define ICS_W3S_L(AFFV, NOACTV)                                                       \
+  do {                                                                                \
+    if (g.lgS == 4) ICS_W3S(AFFV, NOACTV, 4);                                         \
+    else if (g.lgS == 5) ICS_W3S(AFFV, NOACTV, 5);                                    \
+    else ICS_W3S(AFFV, NOACTV, 6);                                                    \
+  } while (0)
+      if (!aff) ICS_W3S_L(false, false);
+      else if (noact) ICS_W3S_L(true, true);
+      else ICS_W3S_L(true, false);
+#undef ICS_W3S_L
+#undef ICS_W3S
+      ICS_HIP(hipGetLastError());
+    } else if (phase != 2) {
 #define ICS_W3(AFFV, UPV, HALOV)                                                                                 \
   do {                                                                                                           \
     g_last_kernel_id = "conv_wgrad3_kernel<" #AFFV ", " #UPV ", " #HALOV ">";                                    \
