@@ -396,6 +396,37 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
     }
   };
 
+  // taps == 1 over same-resolution sources is a plain [M][K] x [K][N] GEMM (dense layers, the 1x1x1 heads, the
+  // coarse-grid GEMMs of the up-split backward): row byte offsets are fixed, the channel offset is wave-uniform,
+  // and rows >= M just re-read row M-1 (their outputs are never stored): no address or mask arithmetic per chunk.
+  unsigned rowG0[RA], rowG1[RA];
+  if (VEC) {
+#pragma unroll
+    for (int r = 0; r < RA; ++r) {
+      const unsigned mc = (unsigned)min(mrow_base + 32 * r, M - 1);
+      rowG0[r] = (mc * (unsigned)s0.C + (unsigned)(t & 7) * 4u) * 4u;
+      rowG1[r] = (mc * (unsigned)s1.C + (unsigned)(t & 7) * 4u) * 4u;
+    }
+  }
+  auto load_chunk_gemm = [&](int c) {
+    load_b(c * 8);
+    const int ci0 = c << 5;
+    const bool first = ci0 < s0.C;
+    const int cbase = first ? ci0 : ci0 - s0.C;
+    const char* sp = reinterpret_cast<const char*>(first ? s0.p : s1.p) + (size_t)cbase * 4;
+    const float slope = first ? slope0 : slope1;
+    v4f sc = v4f{1.f, 1.f, 1.f, 1.f}, sh = v4f{0.f, 0.f, 0.f, 0.f};
+    if (AFF) {
+      sc = *reinterpret_cast<const v4f*>((first ? s0.scale : s1.scale) + cbase + (t & 7) * 4);
+      sh = *reinterpret_cast<const v4f*>((first ? s0.shift : s1.shift) + cbase + (t & 7) * 4);
+    }
+#pragma unroll
+    for (int r = 0; r < RA; ++r) {
+      v4f v = *reinterpret_cast<const v4f*>(sp + (first ? rowG0[r] : rowG1[r]));
+      if (AFF) v = affine_only_or_act4<NOACT>(v, sc, sh, slope);
+      ra4[r] = v;
+    }
+  };
   auto store_a_chunk = [&]() {
     float* A = As;
     if (VEC) {
@@ -560,7 +591,24 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
     cb = (int)blockIdx.z * per;
     ce = min(nchunks, cb + per);
   }
-  if (cb < ce) {
+  const bool gemm = VEC && !THIN && !PAR && !UP && ABL == 0 && g.taps == 1;   // block-uniform
+  if (cb < ce && gemm) {
+    auto compute_g = [&](int buf) { compute_at(As + (wm * TM * 32 + li) * kLDA + lh * 4, 32, buf); };
+    load_chunk_gemm(cb);
+    store_b(cb & 1);
+    store_a_chunk();
+    __syncthreads();
+    for (int c = cb; c + 1 < ce; ++c) {
+      load_chunk_gemm(c + 1);
+      compute_g(c & 1);
+      store_b((c + 1) & 1);
+      __syncthreads();
+      store_a_chunk();
+      __syncthreads();
+    }
+    compute_g((ce - 1) & 1);
+    __syncthreads();
+  } else if (cb < ce) {
   load_chunk(cb);
   store_b(cb & 1);
   store_a_chunk();
