@@ -12,6 +12,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 #include <vector>
 
@@ -1399,6 +1400,38 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvGeom g, ConvSrc s0,
       rd[p] = v;
     }
   };
+  // taps == 1 over a same-resolution source with whole 32-row chunks and whole N tiles (the coarse-grid GEMMs of the
+  // up-split backward, the heads): a plain A^T x dY.  Wave-uniform chunk pointers + per-thread byte offsets fixed
+  // for the kernel, no validity arithmetic (a thread whose k >= K loads column 0; its rows are never written).
+  const bool gemm = VEC && DYVEC && !UP && !THIN && ABL == 0 && g.taps == 1 && (M & 31) == 0 &&
+                    (rows_per_split & 31) == 0 && n0 + NT <= n_load;
+  const bool noact_g = slope == 1.f;
+  unsigned aoffg[VEC ? APASS : 1], doffg[DPASS];
+  if (VEC) {
+#pragma unroll
+    for (int p = 0; p < APASS; ++p) aoffg[p] = (unsigned)(((t + 256 * p) / AF4) * sC + cl0) * 4u;
+  }
+#pragma unroll
+  for (int p = 0; p < DPASS; ++p) {
+    const int idx = t + 256 * p;
+    doffg[p] = (unsigned)((idx / DF4) * ldy + n0 + (idx % DF4) * 4) * 4u;
+  }
+  auto load_chunk_gemm = [&](int c, auto noact_tag) {
+    constexpr bool NA = decltype(noact_tag)::value;
+    const int mbase = m_begin + (c << 5);
+    const char* abase = reinterpret_cast<const char*>(sp) + (size_t)mbase * (size_t)sC * 4;
+    const char* dbase = reinterpret_cast<const char*>(dy) + (size_t)mbase * (size_t)ldy * 4;
+    if (VEC) {
+#pragma unroll
+      for (int p = 0; p < APASS; ++p) {
+        v4f v = *reinterpret_cast<const v4f*>(abase + aoffg[p]);
+        if (AFF) v = affine_only_or_act4<NA>(v, sc, sh, slope);
+        ra[p] = v;
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < DPASS; ++p) rd[p] = *reinterpret_cast<const v4f*>(dbase + doffg[p]);
+  };
   auto store_chunk = [&](int buf) {
     float* A = As + buf * A_FLOATS;
     float* D = Ds + buf * D_FLOATS;
@@ -1428,7 +1461,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvGeom g, ConvSrc s0,
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   if (nchunks > 0) {
-    load_chunk(0);
+    if (gemm && noact_g) load_chunk_gemm(0, std::true_type{});
+    else if (gemm) load_chunk_gemm(0, std::false_type{});
+    else load_chunk(0);
     store_chunk(0);
   }
   __syncthreads();
@@ -1472,11 +1507,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvGeom g, ConvSrc s0,
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
   };
+  if (gemm) {
+    for (int c = 0; c + 1 < nchunks; ++c) {
+      if (noact_g) load_chunk_gemm(c + 1, std::true_type{}); else load_chunk_gemm(c + 1, std::false_type{});
+      compute(c & 1);
+      store_chunk((c + 1) & 1);
+      __syncthreads();
+    }
+  } else {
   for (int c = 0; c + 1 < nchunks; ++c) {
     if (ABL == 0 || ABL == 2) load_chunk(ABL == 2 ? 1 : c + 1);   // ABL 2: same rows every chunk (L1/L2-hot)
     compute(c & 1);
     if (ABL == 0 || ABL == 2) store_chunk((c + 1) & 1);
     __syncthreads();
+  }
   }
   if (nchunks > 0) compute((nchunks - 1) & 1);
 
