@@ -426,71 +426,117 @@ size_t layer_bwd_workspace_floats(const LayerBwd& L) {
 // weighted_categorical_crossentropy (unet.py:196-221) with scalar weight, keras binary_crossentropy,
 // f1_m / wr_m (unet.py:159-193).
 // ------------------------------------------------------------------------------------------
+// Four voxels per wave: 16 lanes own one voxel's logits (classes sl, sl+16, ... : up to 8 per lane, ncls <= 128),
+// so the three row reductions are 4 xor-shuffle steps inside a 16-lane group instead of a 64-lane wave reduction
+// per voxel (the one-wave-per-voxel version was instruction-bound at 1.8 TB/s).
 __global__ __launch_bounds__(256) void head_kernel(float* __restrict__ z, int ldz, int ncls,
                                                    const unsigned char* __restrict__ labels, size_t M,
                                                    int rows_per_block, int mode, int want_grad,
                                                    float wsoft, float inv_bv, double* __restrict__ partial) {
-  __shared__ double shd[4][6];
+  constexpr int J = 8;
+  __shared__ double shd[16][6];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sl = lane & 15, grp = lane >> 4;           // class slot, voxel slot inside the wave
+  const int nj = (ncls + 15) >> 4;                     // class columns per lane actually used (6 for 95)
   const size_t r0 = (size_t)blockIdx.x * rows_per_block;
   const size_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
   double a_ls = 0, a_lg = 0, a_tp = 0, a_pred = 0, a_tpw = 0, a_posw = 0;
-  for (size_t row = r0 + wave; row < r1; row += 4) {
-    float* zr = z + row * ldz;
-    const int c0 = lane, c1 = lane + 64;
-    const float z0 = c0 < ncls ? zr[c0] : -INFINITY;
-    const float z1 = c1 < ncls ? zr[c1] : -INFINITY;
-    const float zsig = zr[ncls];   // uniform broadcast load
-    const float mx = wave_max_f(fmaxf(z0, z1));
-    const float e0 = c0 < ncls ? expf(z0 - mx) : 0.f;
-    const float e1 = c1 < ncls ? expf(z1 - mx) : 0.f;
-    const float sum = wave_sum_f(e0 + e1);
-    const float p0 = e0 / sum, p1 = e1 / sum;
+  auto gsum = [](float v) {
+    v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+    return v;
+  };
+  auto gmax = [](float v) {
+    v = fmaxf(v, __shfl_xor(v, 8)); v = fmaxf(v, __shfl_xor(v, 4));
+    v = fmaxf(v, __shfl_xor(v, 2)); v = fmaxf(v, __shfl_xor(v, 1));
+    return v;
+  };
+  for (size_t rowb = r0 + (size_t)wave * 4; rowb < r1; rowb += 16) {
+    const size_t row = rowb + grp;
+    const bool rv = row < r1;
+    float* zr = z + (rv ? row : r0) * ldz;
+    float zz[J], p[J];
+    float mxl = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int c = sl + 16 * j;
+      zz[j] = (j < nj && c < ncls) ? zr[c] : -INFINITY;
+      mxl = fmaxf(mxl, zz[j]);
+    }
+    const float zsig = zr[ncls];
+    const float mx = gmax(mxl);
+    float sl_sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int c = sl + 16 * j;
+      p[j] = (j < nj && c < ncls) ? expf(zz[j] - mx) : 0.f;
+      sl_sum += p[j];
+    }
+    const float sum = gsum(sl_sum);
+    float psl = 0.f;
+#pragma unroll
+    for (int j = 0; j < J; ++j) { p[j] = p[j] / sum; psl += p[j]; }
     const float ps = 1.f / (1.f + expf(-zsig));
     if (mode == 0) {
-      if (c0 < ncls) zr[c0] = p0;
-      if (c1 < ncls) zr[c1] = p1;
-      if (lane == 0) zr[ncls] = ps;
+      if (rv) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+          const int c = sl + 16 * j;
+          if (j < nj && c < ncls) zr[c] = p[j];
+        }
+        if (sl == 0) zr[ncls] = ps;
+      }
       continue;
     }
-    const int lab = labels[row];
+    const int lab = rv ? labels[row] : 0;
     // renormalise (p /= sum p), clip, -w*log  (only the true class contributes)
-    const float psum = wave_sum_f(p0 + p1);
-    const float pt_raw = (lab < 64) ? __shfl(p0, lab) : __shfl(p1, lab - 64);
+    const float psum = gsum(psl);
+    float mine = 0.f, cnt = 0.f;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int c = sl + 16 * j;
+      mine = (c == lab) ? p[j] : mine;
+      // predicted positives: round(clip(p,0,1)) == 1  <=>  p > 0.5 (round-half-even: 0.5 -> 0)
+      cnt += (j < nj && c < ncls && p[j] > 0.5f) ? 1.f : 0.f;
+    }
+    const float pt_raw = gsum(mine);
+    const float npred = gsum(cnt);
     const float qt = pt_raw / psum;
     const bool inside = qt >= kKEps && qt <= 1.f - kKEps;
     const float qc = fminf(fmaxf(qt, kKEps), 1.f - kKEps);
     const float tsig = lab != 0 ? 1.f : 0.f;
     const bool inside_s = ps >= kKEps && ps <= 1.f - kKEps;
     const float pc = fminf(fmaxf(ps, kKEps), 1.f - kKEps);
-    // predicted positives: round(clip(p,0,1)) == 1  <=>  p > 0.5 (round-half-even: 0.5 -> 0)
-    const unsigned long long b0 = __ballot(c0 < ncls && p0 > 0.5f);
-    const unsigned long long b1 = __ballot(c1 < ncls && p1 > 0.5f);
-    if (lane == 0) {
+    if (sl == 0 && rv) {
       a_ls += (double)(-wsoft * logf(qc));
       a_lg += (double)(-(tsig * logf(pc) + (1.f - tsig) * logf(1.f - pc)));
       const bool hit = pt_raw > 0.5f;
       a_tp += hit ? 1.0 : 0.0;
-      a_pred += (double)(__popcll(b0) + __popcll(b1));
+      a_pred += (double)npred;
       if (lab != 0) { a_posw += 1.0; a_tpw += hit ? 1.0 : 0.0; }
     }
-    if (want_grad) {
+    if (want_grad && rv) {
       // d lsoft/dz = w*(p - y)/(B*V) when the true-class probability is not clipped, else 0
       const float gs = inside ? wsoft * inv_bv : 0.f;
-      if (c0 < ncls) zr[c0] = gs * (p0 - (c0 == lab ? 1.f : 0.f));
-      if (c1 < ncls) zr[c1] = gs * (p1 - (c1 == lab ? 1.f : 0.f));
-      if (lane == 0) zr[ncls] = inside_s ? (ps - tsig) * inv_bv : 0.f;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const int c = sl + 16 * j;
+        if (j < nj && c < ncls) zr[c] = gs * (p[j] - (c == lab ? 1.f : 0.f));
+      }
+      if (sl == 0) zr[ncls] = inside_s ? (ps - tsig) * inv_bv : 0.f;
     }
   }
   if (mode == 0) return;
-  if (lane == 0) {
-    shd[wave][0] = a_ls; shd[wave][1] = a_lg; shd[wave][2] = a_tp;
-    shd[wave][3] = a_pred; shd[wave][4] = a_tpw; shd[wave][5] = a_posw;
+  if (sl == 0) {
+    const int q = wave * 4 + grp;
+    shd[q][0] = a_ls; shd[q][1] = a_lg; shd[q][2] = a_tp;
+    shd[q][3] = a_pred; shd[q][4] = a_tpw; shd[q][5] = a_posw;
   }
   __syncthreads();
   if (threadIdx.x < 6) {
     const int k = threadIdx.x;
-    partial[(size_t)blockIdx.x * 6 + k] = shd[0][k] + shd[1][k] + shd[2][k] + shd[3][k];
+    double acc = 0.0;
+    for (int q = 0; q < 16; ++q) acc += shd[q][k];
+    partial[(size_t)blockIdx.x * 6 + k] = acc;
   }
 }
 
@@ -525,7 +571,7 @@ int launch_head(hipStream_t st, float* z, int ldz, int ncls, const unsigned char
                 float* metrics) {
   ICS_CHECK(ncls <= 128, "head kernel supports at most 128 classes");
   int rpb = (int)((M + partial_blocks - 1) / partial_blocks);
-  rpb = (rpb + 3) / 4 * 4;
+  rpb = (rpb + 15) / 16 * 16;
   const int nblk = (int)((M + rpb - 1) / rpb);
   hipLaunchKernelGGL(head_kernel, dim3(nblk), dim3(256), 0, st, z, ldz, ncls, labels, M, rpb, mode,
                      want_grad, wsoft, (float)(1.0 / (double)M), partial);
