@@ -1,32 +1,40 @@
 """The one piece of /root/reference/utils.py the training scripts need: data_split (utils.py:36-61).
-Everything else there (voxelisation, lattice parameters, pymatgen) is out of scope."""
+Everything else there (voxelisation, lattice parameters, pymatgen) is out of scope.
+
+data_split is index work, so it is reproduced bit-exactly -- including the reference's quirks:
+  * the cap `n` counts UN-rotated base ids and is applied BEFORE the shuffle (utils.py:44);
+  * the shuffle is Python's `random` module seeded through the GLOBAL generator (utils.py:46-48);
+  * every base id is expanded to `n_rot` names "<id>_rot_<k>.npy" whether or not the file exists
+    (utils.py:53-60);
+  * the stem is taken with str.strip(".npy"), which strips the CHARACTERS '.', 'n', 'p', 'y' from both
+    ends, not the suffix (utils.py:55,59) -- "mp-123.npy" -> "mp-123", "nacl.npy" -> "acl".
+tests/golden/data_split_golden.json holds id lists produced by the reference function itself
+(tests/golden/make_data_split_golden.py); tests/test_host_logic.py compares against them."""
 import os
+import random
 
-import numpy as np
+
+def _rotated_names(base_name, n_rot):
+    stem = base_name.strip(".npy")          # character strip, as the reference does
+    return [stem + "_rot_" + str(k) + ".npy" for k in range(n_rot)]
 
 
-def data_split(path, n, frac=0.8, n_rot=10, seed=28):
-    """Deterministic train/validation split over the UN-rotated ids found in
-    <path>/density_matrices (sorted, shuffled with `seed`), each expanded to its `n_rot` rotated
-    copies "<id>_rot_<k>.npy" as create_matrices.py names them.  n caps the number of base ids * n_rot."""
-    folder = os.path.join(path, "density_matrices")
-    base = sorted(f[:-4] for f in os.listdir(folder) if f.endswith(".npy") and "_rot_" not in f)
-    rng = np.random.RandomState(seed)
-    rng.shuffle(base)
-    n_base = max(1, min(len(base), int(n / max(n_rot, 1)) if n_rot else n))
-    base = base[:n_base]
-    cut = int(len(base) * frac)
-
-    def expand(ids):
-        out = []
-        for i in ids:
-            out.append(i + ".npy")
-            for k in range(n_rot):
-                f = "%s_rot_%d.npy" % (i, k)
-                if os.path.exists(os.path.join(folder, f)):
-                    out.append(f)
-        return out
-
-    train, val = expand(base[:cut]), expand(base[cut:])
-    assert not set(train) & set(val)
-    return train, val
+def data_split(path, n=None, frac=0.80, n_rot=10, shuffle=True, seed=28):
+    """Train/validation split of the matrices under <path>/density_matrices -> (training_ids, validation_ids)."""
+    listing = sorted(f for f in os.listdir(path + "/density_matrices") if f.endswith(".npy"))
+    base = [f for f in listing if "_rot_" not in f][:n]
+    if shuffle:
+        if seed is not None:
+            random.seed(seed)               # the global generator, like the reference (callers see the reseed)
+        random.shuffle(base)
+    cut = int(frac * len(base))
+    split = []
+    for part in (base[:cut], base[cut:]):
+        ids = []
+        for name in part:
+            ids.append(name)
+            ids.extend(_rotated_names(name, n_rot))
+        split.append(ids)
+    training_ids, validation_ids = split
+    assert not set(training_ids) & set(validation_ids)
+    return training_ids, validation_ids
