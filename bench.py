@@ -3,8 +3,10 @@
 
 One "step" = one U-Net training step (forward, loss, backward, BN moving-stat update, Adam) on a
 batch of 32 synthetic 32^3 x 1 voxel grids per GPU, inputs resident in HBM when the timed region
-starts (BASELINE.json configs[1]; weak scaling over N GPUs with one RCCL all-reduce of the flat
-gradient buffer per step).  Prints ONE JSON line on rank 0.
+starts (BASELINE.json configs[1]; weak scaling over N GPUs, gradients all-reduced with RCCL in buckets
+overlapped with the backward pass).  The same JSON line carries a `secondary` block for the other half
+of BASELINE.json's metric, the DFC-VAE step (configs[2]), timed right after the U-Net region.
+Prints ONE JSON line on rank 0.
 
   python bench.py --gpus 1 --steps 20 --warmup 5
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -30,6 +32,8 @@ PEAK_HBM_GBS = 8000.0         # HBM3E spec
 UNET_FLOP_PER_GRID = 377.66e9          # fwd 125.886 GFLOP x 3
 UNET_BYTES_PER_GRID = 499.6e6          # fused-minimum activation traffic
 UNET_PARAM_BYTES_PER_STEP = 1.25e9     # 124.6 MB x (1 fwd + 2 bwd + 7 Adam)
+VAE_FLOP_PER_GRID = 33.73e9            # VAE 3 x 2.126 + perceptual 3 x 9.116 GFLOP
+PMC_TRAFFIC_FILES = ("r2_pmc_traffic.json", "r1_pmc_traffic.json")
 
 
 def cpu_baseline(sample_grids=4):
@@ -50,96 +54,40 @@ def cpu_baseline(sample_grids=4):
                 "sample": "cpu baseline failed: %s" % e}
 
 
-def run_vae_or_joint(args, rank, local_rank, world, use_dist, dist, json_fd):
-    """Secondary workloads (not the driver's default line): --workload vae = BASELINE configs[2] (DFC-VAE step with
-    the frozen perceptual U-Net), --workload joint = one U-Net step + one DFC-VAE step per iteration on the same
-    grids (configs[3]/[4] shape: both engines resident, both gradient all-reduces per iteration)."""
-    from icsg3d_amd.engine import UnetEngine, VaeEngine, comm_unique_id
-    from icsg3d_amd.synthetic import glorot_params, synthetic_batch, unet_param_shapes, vae_param_shapes
-    B, d, C = args.batch, args.d, 1
-    joint = args.workload == "joint"
-    PU = glorot_params(unet_param_shapes(C, 95), seed=1)
-    pm = UnetEngine(in_channels=C, d=d, max_batch=B); pm.set_weights(PU)
-    vae = VaeEngine(pm, in_channels=C, d=d, max_batch=B, lr=5e-4)
-    vae.set_weights(glorot_params(vae_param_shapes(C, d=d), seed=3))
-    X, labels, cond = synthetic_batch(B, d, C, seed=rank)
-    eps = np.random.default_rng(2 + rank).standard_normal((B, 256)).astype(np.float32)
-    vae.upload_batch(X, cond, eps)
-    engines = [vae]
-    unet = None
-    if joint:
-        unet = UnetEngine(in_channels=C, d=d, max_batch=B, lr=3e-6); unet.set_weights(PU)
-        unet.upload_batch(X, labels)
-        engines.append(unet)
-    if use_dist:
-        for e in engines:
-            uid = [comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            e.comm_init(rank, world, uid[0])
+def by_kernel(rows):
+    """engine profile rows -> {kernel instantiation (the name rocprofv3 prints): ms / flop / bytes / launches}"""
+    acc = {}
+    for r in rows:
+        kid = r["label"].split("|")[1] if "|" in r["label"] and r["label"].split("|")[1] else r["label"]
+        a = acc.setdefault(kid, {"ms": 0.0, "flop": 0.0, "launches": 0, "bytes": 0.0})
+        a["ms"] += r["ms"]; a["flop"] += r["flop"]; a["launches"] += r["launches"]; a["bytes"] += r["bytes"]
+    return acc
 
-    def step(m=False):
-        if unet is not None:
-            unet.train_step_resident(False)
-        return vae.train_step_resident(m)
 
-    def barrier():
-        for e in engines:
-            e.sync()
-        if dist is not None:
-            dist.barrier()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    for e in engines + [pm]:
-        e.profile_enable(True)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    rows = [r for e in engines + [pm] for r in e.profile_rows()]
-    metrics = step(True)
-    if not np.all(np.isfinite(metrics)):
-        raise SystemExit("non-finite training metrics: %s" % metrics)
-    if rank == 0:
-        by_kernel = {}
-        for r in rows:
-            kid = r["label"].split("|")[1] if "|" in r["label"] and r["label"].split("|")[1] else r["label"]
-            a = by_kernel.setdefault(kid, {"ms": 0.0, "flop": 0.0, "launches": 0})
-            a["ms"] += r["ms"]; a["flop"] += r["flop"]; a["launches"] += r["launches"]
-        dom_name, dom = max(by_kernel.items(), key=lambda kv: kv[1]["ms"])
-        achieved = dom["flop"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
-        exec_flop = sum(r["flop"] for r in rows) / args.steps
-        ms_per_step = elapsed / args.steps * 1e3
-        out = {"metric": "voxel-grids/s (fwd+bwd) for %d^3 %s at batch %d per GPU"
-                         % (d, "U-Net step + DFC-VAE step" if joint else "DFC-VAE step", B),
-               "value": round(world * B * args.steps / elapsed, 2), "unit": "voxel-grids/s", "n_gpus": world,
-               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "%s, %d x %d^3 x 1 grids per GPU" % (args.workload, B, d),
-                          "global_batch": world * B, "grid": d, "parallelism": "dp%d" % world},
-               "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2),
-                            "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                            "frac": round(achieved / PEAK_FP32_TFLOPS, 4), "traffic": None,
-                            "launches": dom["launches"]},
-               "roofline_step": {"executed_tflop_per_step": round(exec_flop / 1e12, 3),
-                                 "compute_frac": round(exec_flop / (ms_per_step * 1e-3) / (PEAK_FP32_TFLOPS * 1e12), 4)},
-               "cpu_baseline": None}
-        line = json.dumps(out) + "\n"
-        if json_fd is not None:
-            sys.stdout.flush(); os.write(json_fd, line.encode())
-        else:
-            sys.stdout.write(line)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+def pmc_traffic(kernel, live_avg_ms):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc cannot run inside this
+    process).  The file records the kernel's average duration in the profiled run; if this run's live
+    HIP-event average disagrees by more than 15 % the kernel has changed since and the figure is stale -> null
+    with the reason, never a silently outdated number."""
+    for name in PMC_TRAFFIC_FILES:
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        try:
+            with open(path) as f:
+                e = json.load(f)["kernels"].get(kernel)
+        except Exception as ex:
+            return None, "unreadable %s: %s" % (name, ex)
+        if e is None or "traffic_bytes_per_launch" not in e:
+            return None, "profiles/%s has no PMC pass for this kernel" % name
+        ref_ms = e.get("avg_ms")
+        if ref_ms and abs(live_avg_ms - ref_ms) > 0.15 * ref_ms:
+            return None, "stale: profiles/%s measured %.3f ms/launch, this run %.3f" % (name, ref_ms, live_avg_ms)
+        note = "profiles/%s (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes)" % name
+        if not ref_ms:
+            note += "; file carries no avg_ms, staleness unchecked"
+        return e["traffic_bytes_per_launch"], note
+    return None, "no PMC traffic profile committed"
 
 
 def main():
@@ -150,8 +98,11 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="grids per GPU")
     ap.add_argument("--d", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the DFC-VAE block (profiling runs)")
     ap.add_argument("--workload", choices=("unet", "vae", "joint"), default="unet",
-                    help="unet = the contract line (BASELINE configs[1]); vae / joint = secondary measurements")
+                    help="unet = the contract line (BASELINE configs[1] + the configs[2] secondary block); "
+                         "vae / joint = profiling runs of the DFC-VAE step alone / U-Net + DFC-VAE step per iteration")
+    ap.add_argument("--sync-bn", action="store_true", help="data parallel: global-batch BatchNorm statistics")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -163,14 +114,17 @@ def main():
 
     # the engine binds system ROCm; load it before anything else can pull in another HIP runtime
     from icsg3d_amd import _lib
-    from icsg3d_amd.engine import UnetEngine, comm_unique_id
-    from icsg3d_amd.synthetic import glorot_params, synthetic_batch, unet_param_shapes
+    from icsg3d_amd.dataparallel import init_engine_comm
+    from icsg3d_amd.engine import UnetEngine, VaeEngine
+    from icsg3d_amd.synthetic import glorot_params, synthetic_batch, unet_param_shapes, vae_param_shapes
     lib = _lib.load()
     _lib.check(lib.ics_set_device(local_rank))
 
     # ICSG3D_BENCH_FORCE_DIST=1 takes the multi-process path (gloo rendezvous, ncclUniqueId hand-off, RCCL
-    # communicator, all-reduce inside Adam) even with one rank: the only way to exercise it on a 1-GPU box
-    use_dist = world > 1 or (os.environ.get("ICSG3D_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
+    # communicator, state broadcast, bucketed all-reduce on the comm stream) even with one rank: the only way
+    # to exercise it on a 1-GPU box
+    force = os.environ.get("ICSG3D_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ
+    use_dist = world > 1 or force
     dist = None
     json_fd = None
     if use_dist:
@@ -183,105 +137,185 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    if args.workload != "unet":
-        return run_vae_or_joint(args, rank, local_rank, world, use_dist, dist, json_fd)
-
     B, d, C = args.batch, args.d, 1
-    eng = UnetEngine(in_channels=C, num_classes=95, d=d, max_batch=B, lr=3e-6)
-    eng.set_weights(glorot_params(unet_param_shapes(C, 95), seed=1))
-    X, labels, _ = synthetic_batch(B, d, C, seed=rank)   # each rank its own shard of the global batch
-    eng.upload_batch(X, labels)
+    X, labels, cond = synthetic_batch(B, d, C, seed=rank)   # each rank its own shard of the global batch
+    PU = glorot_params(unet_param_shapes(C, 95), seed=1)
 
-    if use_dist:
+    def max_over_ranks(v):
+        if dist is None:
+            return v
         import torch
-        uid = [comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        eng.comm_init(rank, world, uid[0])
-
-    def barrier():
-        eng.sync()
-        if dist is not None:
-            dist.barrier()
-
-    for _ in range(args.warmup):
-        eng.train_step_resident(False)
-    barrier()
-    eng.profile_enable(True)     # HIP events around every launch on the engine's stream
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.train_step_resident(False)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
+        t = torch.tensor([v], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    rows = eng.profile_rows()
-    metrics = eng.train_step_resident(True)   # untimed: sanity that the job is still finite
-    if not np.all(np.isfinite(metrics)):
-        raise SystemExit("non-finite training metrics: %s" % metrics)
+        return float(t.item())
+
+    def timed(step, engines, profiled):
+        """W warm-up steps, then EXACTLY K steps between barrier + device sync on both sides; max over ranks."""
+        def barrier():
+            for e in engines:
+                e.sync()
+            if dist is not None:
+                dist.barrier()
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        for e in profiled:
+            e.profile_enable(True)     # HIP events around every launch, on the stream it is launched on
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        rows = [r for e in profiled for r in e.profile_rows()]
+        for e in profiled:
+            e.profile_enable(False)
+        # the same K steps without the per-launch events (what a training job sees)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        elapsed_plain = max_over_ranks(time.perf_counter() - t0)
+        return elapsed, elapsed_plain, rows
+
+    out = None
+    unet = None
+    if args.workload in ("unet", "joint"):
+        unet = UnetEngine(in_channels=C, num_classes=95, d=d, max_batch=B, lr=3e-6)
+        unet.set_weights(PU)
+        unet.upload_batch(X, labels)
+        if use_dist:
+            init_engine_comm(unet, dist, rank, world, sync_bn=args.sync_bn, force=force)
+
+    if args.workload == "unet":
+        elapsed, elapsed_plain, rows = timed(lambda: unet.train_step_resident(False), [unet], [unet])
+        metrics = unet.train_step_resident(True)   # untimed: sanity that the job is still finite
+        if not np.all(np.isfinite(metrics)):
+            raise SystemExit("non-finite training metrics: %s" % metrics)
+        comm = unet.comm_info()
+        if rank == 0:
+            ms_per_step = elapsed / args.steps * 1e3
+            value = world * B * args.steps / elapsed
+            kern = by_kernel(rows)
+            gemms = {k: v for k, v in kern.items() if v["flop"] > 0}
+            dom_name, dom = max(gemms.items(), key=lambda kv: kv[1]["ms"])   # largest share of device time
+            achieved = dom["flop"] / (dom["ms"] * 1e-3) / 1e12
+            avg_ms = dom["ms"] / max(dom["launches"], 1)
+            traffic, traffic_note = pmc_traffic(dom_name, avg_ms)
+            scale = (d / 32.0) ** 3
+            step_flop = UNET_FLOP_PER_GRID * scale * B
+            exec_flop = sum(r["flop"] for r in rows) / args.steps
+            step_bytes = UNET_BYTES_PER_GRID * scale * B + UNET_PARAM_BYTES_PER_STEP
+            out = {
+                "metric": "voxel-grids/s (fwd+bwd) for 32^3 U-Net at batch 32 per GPU",
+                "value": round(value, 2), "unit": "voxel-grids/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "AtomUnet fwd+bwd+Adam train step, %d x %d^3 x 1 grids per GPU "
+                                       "(BASELINE.json configs[1]), Glorot weights PCG64(1)" % (B, d),
+                           "global_batch": world * B, "grid": d, "parallelism": "dp%d" % world,
+                           "bn": "sync (global-batch statistics)" if args.sync_bn and use_dist
+                                 else "local per-replica batch statistics, moving statistics averaged over ranks",
+                           "grad_allreduce": ("%d RCCL buckets per step on a second stream, overlapped with the "
+                                              "backward pass" % comm["buckets_last_step"]) if comm["nranks"] else "none"},
+                # value / ms_per_step come from the region timed WITH per-launch HIP events (the roofline below is
+                # measured over exactly those steps); the same K steps without events:
+                "ms_per_step_events_off": round(elapsed_plain / args.steps * 1e3, 3),
+                "value_events_off": round(world * B * args.steps / elapsed_plain, 2),
+                "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2),
+                             "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
+                             "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_note,
+                             "algorithmic_bytes_per_launch": int(dom["bytes"] / max(dom["launches"], 1)),
+                             "launches": dom["launches"], "avg_launch_ms": round(avg_ms, 4),
+                             "share_of_device_time": round(dom["ms"] / sum(v["ms"] for v in kern.values()), 4)},
+                # executed = the FLOPs of the GEMMs actually launched (the [skip | upsampled] convs run their
+                # upsampled channels on the low-res grid: 8/27 of the direct count, an exact reassociation);
+                # direct = the textbook 27-tap count of the reference graph (fwd x 3)
+                "roofline_step": {"executed_tflop_per_step": round(exec_flop / 1e12, 3),
+                                  "compute_frac": round(exec_flop / (ms_per_step * 1e-3) / (PEAK_FP32_TFLOPS * 1e12), 4),
+                                  "direct_conv_tflop_per_step": round(step_flop / 1e12, 3),
+                                  "direct_conv_equivalent_tflops": round(step_flop / (ms_per_step * 1e-3) / 1e12, 2),
+                                  "hbm_frac": round(step_bytes / (ms_per_step * 1e-3) / (PEAK_HBM_GBS * 1e9), 4),
+                                  "algorithmic_gb_per_step": round(step_bytes / 1e9, 3),
+                                  "gemm_ms_per_step": round(sum(v["ms"] for v in gemms.values()) / args.steps, 3),
+                                  "non_gemm_ms_per_step": round(sum(v["ms"] for k, v in kern.items() if k not in gemms) / args.steps, 3)},
+                "kernels": {k: {"ms_per_step": round(v["ms"] / args.steps, 3),
+                                "tflops": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 and v["flop"] > 0 else None}
+                            for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:10]},
+            }
+
+    # ---- DFC-VAE step (BASELINE configs[2]): encoder + decoder + frozen perceptual U-Net (batch-statistics BN)
+    if not (args.workload == "unet" and args.no_secondary):
+        pm = unet if args.workload == "unet" else UnetEngine(in_channels=C, d=d, max_batch=B)
+        if pm is not unet:
+            pm.set_weights(PU)
+        vae = VaeEngine(pm, in_channels=C, d=d, max_batch=B, lr=5e-4)
+        vae.set_weights(glorot_params(vae_param_shapes(C, d=d), seed=3))
+        eps = np.random.default_rng(2 + rank).standard_normal((B, 256)).astype(np.float32)
+        vae.upload_batch(X, cond, eps)
+        if use_dist:
+            init_engine_comm(vae, dist, rank, world, sync_bn=args.sync_bn, force=force)
+        if args.workload == "joint":
+            def step():
+                unet.train_step_resident(False)
+                vae.train_step_resident(False)
+            engines, profiled = [unet, vae], [unet, vae, pm]
+        else:
+            step = lambda: vae.train_step_resident(False)  # noqa: E731
+            engines, profiled = [vae], [vae, pm]
+        elapsed_v, elapsed_v_plain, rows_v = timed(step, engines, profiled)
+        mv = vae.train_step_resident(True)
+        if not np.all(np.isfinite(mv)):
+            raise SystemExit("non-finite DFC-VAE metrics: %s" % mv)
+        if rank == 0:
+            kern = by_kernel(rows_v)
+            gemms = {k: v for k, v in kern.items() if v["flop"] > 0}
+            dom_name, dom = max(gemms.items(), key=lambda kv: kv[1]["ms"])
+            ms_v = elapsed_v / args.steps * 1e3
+            exec_flop = sum(r["flop"] for r in rows_v) / args.steps
+            blk = {"workload": ("U-Net step + DFC-VAE step per iteration" if args.workload == "joint" else
+                                "LatticeDFCVAE train step (encoder + decoder + frozen perceptual U-Net c1..c10 x2 fwd "
+                                "+ bwd-data, Adam), %d x %d^3 x 1 grids per GPU (BASELINE.json configs[2])" % (B, d)),
+                   "value": round(world * B * args.steps / elapsed_v, 2), "unit": "voxel-grids/s",
+                   "ms_per_step": round(ms_v, 3), "ms_per_step_events_off": round(elapsed_v_plain / args.steps * 1e3, 3),
+                   "steps": args.steps, "warmup": args.warmup,
+                   "executed_tflop_per_step": round(exec_flop / 1e12, 3),
+                   "compute_frac": round(exec_flop / (ms_v * 1e-3) / (PEAK_FP32_TFLOPS * 1e12), 4),
+                   "algorithmic_tflop_per_step": round(VAE_FLOP_PER_GRID * (d / 32.0) ** 3 * B / 1e12, 3),
+                   "launches_per_step": round(sum(v["launches"] for v in kern.values()) / args.steps, 1),
+                   "dominant_kernel": {"kernel": dom_name, "tflops": round(dom["flop"] / (dom["ms"] * 1e-3) / 1e12, 2),
+                                       "ms_per_step": round(dom["ms"] / args.steps, 3)},
+                   "kernels": {k: {"ms_per_step": round(v["ms"] / args.steps, 3),
+                                   "tflops": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 and v["flop"] > 0 else None}
+                               for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:8]}}
+            if out is not None:
+                out["secondary"] = blk
+                # one U-Net step + one DFC-VAE step per batch, back to back (BASELINE metric "U-Net+VAE")
+                out["unet_plus_vae"] = {"ms_per_batch": round(out["ms_per_step"] + ms_v, 3),
+                                        "value": round(world * B / ((out["ms_per_step"] + ms_v) * 1e-3), 2),
+                                        "unit": "voxel-grids/s"}
+            else:
+                out = {"metric": "voxel-grids/s (fwd+bwd) for %d^3 %s at batch %d per GPU" % (d, args.workload, B),
+                       "n_gpus": world, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                       "data": "synthetic", "config": {"workload": blk["workload"], "global_batch": world * B, "grid": d,
+                                                       "parallelism": "dp%d" % world}}
+                out.update({k: blk[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup")})
+                out["roofline"] = {"bound": "mfma", "kernel": dom_name, "achieved": blk["dominant_kernel"]["tflops"],
+                                   "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": round(blk["dominant_kernel"]["tflops"] / PEAK_FP32_TFLOPS, 4), "traffic": None}
+                out["detail"] = blk
+                out["cpu_baseline"] = None
 
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = world * B * args.steps / elapsed
-        # dominant kernel = the instantiation with the largest share of device time
-        by_kernel = {}
-        for r in rows:
-            kid = r["label"].split("|")[1] if "|" in r["label"] and r["label"].split("|")[1] else r["label"]
-            a = by_kernel.setdefault(kid, {"ms": 0.0, "flop": 0.0, "launches": 0, "bytes": 0.0})
-            a["ms"] += r["ms"]; a["flop"] += r["flop"]; a["launches"] += r["launches"]; a["bytes"] += r["bytes"]
-        dom_name, dom = max(by_kernel.items(), key=lambda kv: kv[1]["ms"])
-        achieved = dom["flop"] / (dom["ms"] * 1e-3) / 1e12
-        scale = (d / 32.0) ** 3
-        step_flop = UNET_FLOP_PER_GRID * scale * B
-        exec_flop = sum(r["flop"] for r in rows) / args.steps
-        step_bytes = UNET_BYTES_PER_GRID * scale * B + UNET_PARAM_BYTES_PER_STEP
-        # HBM bytes per launch of that kernel from the committed PMC passes (rocprofv3 --pmc cannot run
-        # inside this process); null when the profile does not cover the dominant kernel
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
-                traffic = json.load(f)["kernels"][dom_name]["traffic_bytes_per_launch"]
-        except Exception:
-            traffic = None
-        out = {
-            "metric": "voxel-grids/s (fwd+bwd) for 32^3 U-Net at batch 32 per GPU",
-            "value": round(value, 2), "unit": "voxel-grids/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "AtomUnet fwd+bwd+Adam train step, %d x %d^3 x 1 grids per GPU "
-                                   "(BASELINE.json configs[1]), Glorot weights PCG64(1)" % (B, d),
-                       "global_batch": world * B, "grid": d, "parallelism": "dp%d" % world,
-                       "bn": "local per-replica batch statistics"},
-            "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2),
-                         "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
-                         "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC: 2*FETCH_SIZE+WRITE_SIZE, profiles/r1_pmc_traffic.json)",
-                         "algorithmic_bytes_per_launch": int(dom["bytes"] / max(dom["launches"], 1)),
-                         "launches": dom["launches"],
-                         "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 4),
-                         "share_of_device_time": round(dom["ms"] / sum(v["ms"] for v in by_kernel.values()), 4)},
-            # executed = the FLOPs of the GEMMs actually launched (the [skip | upsampled] convs run their
-            # upsampled channels on the low-res grid: 8/27 of the direct count, an exact reassociation);
-            # direct = the textbook 27-tap count of the reference graph (fwd x 3)
-            "roofline_step": {"executed_tflop_per_step": round(exec_flop / 1e12, 3),
-                              "compute_frac": round(exec_flop / (ms_per_step * 1e-3) / (PEAK_FP32_TFLOPS * 1e12), 4),
-                              "direct_conv_tflop_per_step": round(step_flop / 1e12, 3),
-                              "direct_conv_equivalent_tflops": round(step_flop / (ms_per_step * 1e-3) / 1e12, 2),
-                              "hbm_frac": round(step_bytes / (ms_per_step * 1e-3) / (PEAK_HBM_GBS * 1e9), 4),
-                              "algorithmic_gb_per_step": round(step_bytes / 1e9, 3)},
-            "kernels": {k: {"ms_per_step": round(v["ms"] / args.steps, 3),
-                            "tflops": round(v["flop"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 and v["flop"] > 0 else None}
-                        for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1]["ms"])[:8]},
-        }
-        if world == 1 and not args.no_cpu_baseline:
+        if args.workload == "unet" and world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+        line = json.dumps(out) + "\n"
         if json_fd is not None:
             sys.stdout.flush()
-            os.write(json_fd, (json.dumps(out) + "\n").encode())
+            os.write(json_fd, line.encode())
         else:
-            print(json.dumps(out))
+            sys.stdout.write(line)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

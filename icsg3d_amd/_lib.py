@@ -59,6 +59,7 @@ SIGNATURES = {
     "ics_vae_test_step": (C.c_int, [_H, _F, _F, _F, C.c_int, _F]),
     "ics_vae_upload_batch": (C.c_int, [_H, _F, _F, _F, C.c_int]),
     "ics_vae_train_step_resident": (C.c_int, [_H, _F]),
+    "ics_vae_decode_to_unet_labels": (C.c_int, [_H, _H, _F, _F, C.c_int, C.c_float, _U8, _U8, _F, _F]),
     "ics_net_destroy": (C.c_int, [_H]),
     "ics_net_sync": (C.c_int, [_H]),
     "ics_net_num_tensors": (C.c_int, [_H, C.POINTER(C.c_int)]),
@@ -71,6 +72,9 @@ SIGNATURES = {
     "ics_net_get_bn_affine": (C.c_int, [_H, C.c_char_p, _F, _F, C.c_size_t]),
     "ics_net_set_lr": (C.c_int, [_H, C.c_float]),
     "ics_net_reset_optimizer": (C.c_int, [_H]),
+    "ics_net_num_params": (C.c_int, [_H, C.POINTER(C.c_size_t)]),
+    "ics_net_get_optimizer_state": (C.c_int, [_H, _F, _F, C.c_size_t, C.POINTER(C.c_int)]),
+    "ics_net_set_optimizer_state": (C.c_int, [_H, _F, _F, C.c_size_t, C.c_int]),
     "ics_net_profile_enable": (C.c_int, [_H, C.c_int]),
     "ics_net_profile_count": (C.c_int, [_H, C.POINTER(C.c_int)]),
     "ics_net_profile_row": (C.c_int, [_H, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64),
@@ -78,6 +82,9 @@ SIGNATURES = {
     "ics_comm_unique_id": (C.c_int, [C.c_char_p]),
     "ics_net_comm_init": (C.c_int, [_H, C.c_int, C.c_int, C.c_char_p]),
     "ics_net_comm_allreduce_max": (C.c_int, [_H, C.POINTER(C.c_double)]),
+    "ics_net_comm_broadcast_state": (C.c_int, [_H, C.c_int]),
+    "ics_net_set_sync_bn": (C.c_int, [_H, C.c_int]),
+    "ics_net_comm_info": (C.c_int, [_H, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ics_op_conv3d_forward": (C.c_int, [_F, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _F]),
     "ics_op_conv3d_bench": (C.c_int, [C.c_int] * 8 + [_F]),
     "ics_op_conv3d_backward": (C.c_int, [_F, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _F, _F]),

@@ -2,6 +2,8 @@
 #pragma once
 #include "common.h"
 
+#include <rccl/rccl.h>
+
 namespace ics {
 
 struct BnParams {
@@ -13,6 +15,15 @@ struct BnParams {
   float* rstd;    // 1/sqrt(var+eps)
   float* scale;   // gamma*rstd
   float* shift;   // beta - mean*scale
+};
+
+// SyncBN exchange (opt-in data-parallel mode): `local` holds 3*C doubles (forward: n, mean, M2) or 2*C
+// (backward: sum d, sum d*xhat); `gathered` nranks * 3*C.
+struct BnSync {
+  ncclComm_t comm;
+  int nranks;
+  double* local;
+  double* gathered;
 };
 
 enum GradSrcKind : int { GS_NONE = 0, GS_DIRECT = 1, GS_UP = 2, GS_POOL = 3 };
@@ -39,16 +50,19 @@ struct LayerBwd {
 };
 
 int launch_bn_finalize(hipStream_t st, const float* partial, int nblk, int Npad, const BnParams& bn,
-                       int C, int update_moving, int unbias);
+                       int C, int update_moving, int unbias, const BnSync* sync = nullptr);
 int launch_bn_eval_prepare(hipStream_t st, const BnParams& bn, int C);
 int launch_pool_fwd(hipStream_t st, const float* s, const float* scale, const float* shift, int act,
                     int B, int S, int C, float* out, unsigned char* idx);
 int launch_layer_bwd(hipStream_t st, const LayerBwd& L, float* dy, float* ws_partial, float* c1c2,
-                     float* dgamma, float* dbeta, float* dbias);
+                     float* dgamma, float* dbeta, float* dbias, const BnSync* sync = nullptr);
 size_t layer_bwd_workspace_floats(const LayerBwd& L);
 int launch_head(hipStream_t st, float* z, int ldz, int ncls, const unsigned char* labels, size_t M,
                 int mode, int want_grad, float wsoft, double* partial, int partial_blocks,
-                float* metrics);
+                float* metrics, int* nblk_out = nullptr);
+// phase 0: reduce block partials + finalize; 1: reduce only -> sums[7]; 2: finalize from sums[7]
+int launch_head_metrics(hipStream_t st, const double* partial, int nblk, double M, float* metrics, double* sums,
+                        int phase);
 int launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v, size_t n, float lr_t,
                 float gscale);
 int launch_bn_apply(hipStream_t st, const float* s, const float* scale, const float* shift, int act,
@@ -59,7 +73,8 @@ int launch_sampling(hipStream_t st, const float* mulv, int ld, int latent, const
                     const float* cond, int ncond, int B, float* z, float* zc);
 int launch_vae_loss(hipStream_t st, const float* mulv, int ld, int latent, int B, const double* mse_partial,
                     int n_mse, double n_elems, const double* pm_partial, const int* pm_counts,
-                    const float* pm_w, float alpha, float beta, float* metrics);
+                    const float* pm_w, float alpha, float beta, float* metrics, double* sums = nullptr,
+                    int phase = 0);
 int launch_vae_dz(hipStream_t st, const float* mulv, int ld, int latent, int B, const float* eps,
                   const float* dzc, int ldzc, float beta, float* dmulv);
 int launch_relu_bwd(hipStream_t st, const float* a, float* g, size_t n);

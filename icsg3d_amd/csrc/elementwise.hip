@@ -89,8 +89,71 @@ __global__ void bn_eval_prepare_kernel(BnParams bn, int C) {
   bn.shift[c] = bn.beta[c] - bn.moving_mean[c] * sc;
 }
 
+// ---- SyncBN (data parallel, opt-in): every rank merges its block partials into per-channel
+// (n, mean, M2) in fp64, the ranks exchange those 3*C doubles with one all-gather, and each rank merges
+// them in RANK ORDER (Chan et al.) -- the same result on every rank, equal to the statistics of the
+// global batch.
+__global__ __launch_bounds__(256) void bn_local_merge_kernel(const float* __restrict__ partial, int nblk,
+                                                              int Npad, int C, double* __restrict__ out) {
+  __shared__ double sh[4];
+  const int c = blockIdx.x;
+  double n = 0.0, s = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += 256) {
+    const float* p = partial + (size_t)b * 3 * Npad + c;
+    n += (double)p[0];
+    s += (double)p[0] * (double)p[Npad];
+  }
+  n = block_sum_d(n, sh);
+  s = block_sum_d(s, sh);
+  const double mean = s / n;
+  double m2 = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += 256) {
+    const float* p = partial + (size_t)b * 3 * Npad + c;
+    const double d = (double)p[Npad] - mean;
+    m2 += (double)p[2 * Npad] + (double)p[0] * d * d;
+  }
+  m2 = block_sum_d(m2, sh);
+  if (threadIdx.x == 0) { out[c] = n; out[C + c] = mean; out[2 * C + c] = m2; }
+}
+__global__ void bn_sync_finalize_kernel(const double* __restrict__ gathered, int nranks, int C, BnParams bn,
+                                        int update_moving, float momentum, int unbias) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double n = 0.0, mean = 0.0, m2 = 0.0;
+  for (int r = 0; r < nranks; ++r) {
+    const double* g = gathered + (size_t)r * 3 * C;
+    const double nb = g[c], mb = g[C + c], qb = g[2 * C + c];
+    const double nt = n + nb, d = mb - mean;
+    m2 += qb + d * d * n * nb / nt;
+    mean += d * nb / nt;
+    n = nt;
+  }
+  const double var = m2 / n;
+  const float rstd = (float)(1.0 / sqrt(var + (double)kBnEps));
+  const float sc = bn.gamma[c] * rstd;
+  bn.mean[c] = (float)mean;
+  bn.rstd[c] = rstd;
+  bn.scale[c] = sc;
+  bn.shift[c] = bn.beta[c] - (float)mean * sc;
+  if (update_moving) {
+    const double v = unbias ? var * (n / (n - (1.0 + (double)kBnEps))) : var;
+    bn.moving_mean[c] = bn.moving_mean[c] * momentum + (float)mean * (1.f - momentum);
+    bn.moving_var[c] = bn.moving_var[c] * momentum + (float)v * (1.f - momentum);
+  }
+}
+
 int launch_bn_finalize(hipStream_t st, const float* partial, int nblk, int Npad, const BnParams& bn,
-                       int C, int update_moving, int unbias) {
+                       int C, int update_moving, int unbias, const BnSync* sync) {
+  if (sync != nullptr) {
+    hipLaunchKernelGGL(bn_local_merge_kernel, dim3(C), dim3(256), 0, st, partial, nblk, Npad, C, sync->local);
+    ICS_HIP(hipGetLastError());
+    ncclResult_t r = ncclAllGather(sync->local, sync->gathered, (size_t)3 * C, ncclDouble, sync->comm, st);
+    ICS_CHECK(r == ncclSuccess, std::string("ncclAllGather(SyncBN): ") + ncclGetErrorString(r));
+    hipLaunchKernelGGL(bn_sync_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, sync->gathered, sync->nranks, C,
+                       bn, update_moving, 0.99f, unbias);
+    ICS_HIP(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, st, partial, nblk, Npad, bn,
                      update_moving, 0.99f, unbias);
   ICS_HIP(hipGetLastError());
@@ -286,13 +349,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(LayerBwd L, int rows
   }
 }
 
-// merges the block partials: c1 = sum d / n, c2 = sum d*xhat / n ; writes dgamma/dbeta if asked
+// merges the block partials: c1 = sum d / n, c2 = sum d*xhat / n ; writes dgamma/dbeta if asked.
+// sums != nullptr (SyncBN): the raw fp64 sums go to sums[0..C) / sums[C..2C) instead of c1/c2; after
+// the all-reduce over ranks bn_bwd_sync_c_kernel divides by the GLOBAL element count.  dgamma/dbeta
+// stay the local sums (the gradient all-reduce adds the ranks later).
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial,
                                                                int nblk, int C, double n,
                                                                float* __restrict__ c1,
                                                                float* __restrict__ c2,
                                                                float* __restrict__ dgamma,
-                                                               float* __restrict__ dbeta) {
+                                                               float* __restrict__ dbeta,
+                                                               double* __restrict__ sums) {
   __shared__ double sh[4];
   const int c = blockIdx.x;
   double s1 = 0.0, s2 = 0.0;
@@ -303,10 +370,17 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   s1 = block_sum_d(s1, sh);
   s2 = block_sum_d(s2, sh);
   if (threadIdx.x == 0) {
-    c1[c] = (float)(s1 / n);
-    c2[c] = (float)(s2 / n);
+    if (sums) { sums[c] = s1; sums[C + c] = s2; }
+    else { c1[c] = (float)(s1 / n); c2[c] = (float)(s2 / n); }
     if (dgamma) { dgamma[c] = (float)s2; dbeta[c] = (float)s1; }
   }
+}
+__global__ void bn_bwd_sync_c_kernel(const double* __restrict__ sums, int C, double n_global,
+                                     float* __restrict__ c1, float* __restrict__ c2) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  c1[c] = (float)(sums[c] / n_global);
+  c2[c] = (float)(sums[C + c] / n_global);
 }
 
 template <int VW>
@@ -386,7 +460,7 @@ int bn_bwd_num_blocks(const LayerBwd& L, int* rows_per_block) {
 }
 
 int launch_layer_bwd(hipStream_t st, const LayerBwd& L, float* dy, float* ws_partial, float* c1c2,
-                     float* dgamma, float* dbeta, float* dbias) {
+                     float* dgamma, float* dbeta, float* dbias, const BnSync* sync) {
   int rpb;
   const int nblk = bn_bwd_num_blocks(L, &rpb);
   const double n = (double)((size_t)L.B << (3 * L.lgS));
@@ -398,8 +472,15 @@ int launch_layer_bwd(hipStream_t st, const LayerBwd& L, float* dy, float* ws_par
     else hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(nblk), dim3(256), 0, st, L, rpb, ws_partial);
     ICS_HIP(hipGetLastError());
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(L.C), dim3(256), 0, st, ws_partial, nblk, L.C, n, c1,
-                       c2, dgamma, dbeta);
+                       c2, dgamma, dbeta, sync ? sync->local : nullptr);
     ICS_HIP(hipGetLastError());
+    if (sync) {   // every rank holds the same number of rows (equal shards): n_global = n * nranks
+      ncclResult_t r = ncclAllReduce(sync->local, sync->local, (size_t)2 * L.C, ncclDouble, ncclSum, sync->comm, st);
+      ICS_CHECK(r == ncclSuccess, std::string("ncclAllReduce(SyncBN bwd): ") + ncclGetErrorString(r));
+      hipLaunchKernelGGL(bn_bwd_sync_c_kernel, dim3((L.C + 63) / 64), dim3(64), 0, st, sync->local, L.C,
+                         n * (double)sync->nranks, c1, c2);
+      ICS_HIP(hipGetLastError());
+    }
   }
   if (v4) hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(nblk), dim3(256), 0, st, L, rpb, c1, c2, dy,
                              dbias ? ws_partial : nullptr);
@@ -540,35 +621,56 @@ __global__ __launch_bounds__(256) void head_kernel(float* __restrict__ z, int ld
   }
 }
 
-// metrics[5] = [Loss, lsoft, lsig, f1, wr]
+// metrics[5] = [Loss, lsoft, lsig, f1, wr].  Data parallel: the six sums and the voxel count are the
+// numerators / denominators SURVEY 8(e) asks to all-reduce (not the ratios):
+//   phase 0: reduce the block partials and finalize (single GPU);
+//   phase 1: reduce only -> sums[0..5], sums[6] = M;   phase 2: finalize from (all-reduced) sums.
 __global__ __launch_bounds__(256) void head_finalize_kernel(const double* __restrict__ partial, int nblk,
-                                                            double M, float* __restrict__ metrics) {
+                                                            double M, float* __restrict__ metrics,
+                                                            double* __restrict__ sums, int phase) {
   __shared__ double sh[4];
   double acc[6];
+  if (phase == 2) {
 #pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    double s = 0.0;
-    for (int b = threadIdx.x; b < nblk; b += 256) s += partial[(size_t)b * 6 + k];
-    acc[k] = block_sum_d(s, sh);
+    for (int k = 0; k < 6; ++k) acc[k] = sums[k];
+    M = sums[6];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      double s = 0.0;
+      for (int b = threadIdx.x; b < nblk; b += 256) s += partial[(size_t)b * 6 + k];
+      acc[k] = block_sum_d(s, sh);
+    }
   }
-  if (threadIdx.x == 0) {
-    const double eps = 1e-7;
-    const double lsoft = acc[0] / M, lsig = acc[1] / M;
-    const double tp = acc[2], predicted = acc[3], possible = M;
-    const double precision = tp / (predicted + eps), recall = tp / (possible + eps);
-    const double f1 = 2.0 * ((precision * recall) / (precision + recall + eps));
-    const double wr = acc[4] / (acc[5] + eps);
-    metrics[0] = (float)(lsoft + lsig);
-    metrics[1] = (float)lsoft;
-    metrics[2] = (float)lsig;
-    metrics[3] = (float)f1;
-    metrics[4] = (float)wr;
+  if (threadIdx.x != 0) return;
+  if (phase == 1) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) sums[k] = acc[k];
+    sums[6] = M;
+    return;
   }
+  const double eps = 1e-7;
+  const double lsoft = acc[0] / M, lsig = acc[1] / M;
+  const double tp = acc[2], predicted = acc[3], possible = M;
+  const double precision = tp / (predicted + eps), recall = tp / (possible + eps);
+  const double f1 = 2.0 * ((precision * recall) / (precision + recall + eps));
+  const double wr = acc[4] / (acc[5] + eps);
+  metrics[0] = (float)(lsoft + lsig);
+  metrics[1] = (float)lsoft;
+  metrics[2] = (float)lsig;
+  metrics[3] = (float)f1;
+  metrics[4] = (float)wr;
+}
+int launch_head_metrics(hipStream_t st, const double* partial, int nblk, double M, float* metrics, double* sums,
+                        int phase) {
+  hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(256), 0, st, partial, nblk, M, metrics, sums, phase);
+  ICS_HIP(hipGetLastError());
+  return 0;
 }
 
 int launch_head(hipStream_t st, float* z, int ldz, int ncls, const unsigned char* labels, size_t M,
                 int mode, int want_grad, float wsoft, double* partial, int partial_blocks,
-                float* metrics) {
+                float* metrics, int* nblk_out) {
   ICS_CHECK(ncls <= 128, "head kernel supports at most 128 classes");
   int rpb = (int)((M + partial_blocks - 1) / partial_blocks);
   rpb = (rpb + 15) / 16 * 16;
@@ -576,10 +678,8 @@ int launch_head(hipStream_t st, float* z, int ldz, int ncls, const unsigned char
   hipLaunchKernelGGL(head_kernel, dim3(nblk), dim3(256), 0, st, z, ldz, ncls, labels, M, rpb, mode,
                      want_grad, wsoft, (float)(1.0 / (double)M), partial);
   ICS_HIP(hipGetLastError());
-  if (mode != 0) {
-    hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(256), 0, st, partial, nblk, (double)M, metrics);
-    ICS_HIP(hipGetLastError());
-  }
+  if (nblk_out) *nblk_out = nblk;
+  if (mode != 0 && metrics != nullptr) ICS_TRY(launch_head_metrics(st, partial, nblk, (double)M, metrics, nullptr, 0));
   return 0;
 }
 
@@ -771,41 +871,49 @@ int launch_sampling(hipStream_t st, const float* mulv, int ld, int latent, const
 //   kld_b = -0.5*sum_j(1 + lv - mu^2 - exp(lv));  Loss = mse + alpha*mean_b(pm_b) + beta*mean_b(kld_b)
 // metrics[4] = [Loss, PM, MSE, KLD]; dmulv[b][0:latent] = dz + beta*mu/B ;
 // dmulv[b][latent:] = dz*eps*0.5*exp(0.5 lv) + beta*(-0.5)*(1-exp(lv))/B
+// phase 0: everything; phase 1: raw sums only -> sums[5] = {kl, squared error, weighted pm, B, n_elems};
+// phase 2: metrics from the (all-reduced) sums  (data parallel: numerators / denominators)
 __global__ __launch_bounds__(256) void vae_loss_kernel(const float* __restrict__ mulv, int ld, int latent,
                                                        int B, const double* __restrict__ mse_partial,
                                                        int n_mse, double n_elems,
                                                        const double* __restrict__ pm_partial,
                                                        const int* __restrict__ pm_counts /*[4][2]: nblk/sample, per-sample elems*/,
                                                        const float* __restrict__ pm_w, float alpha,
-                                                       float beta, float* __restrict__ metrics) {
+                                                       float beta, float* __restrict__ metrics,
+                                                       double* __restrict__ sums, int phase) {
   __shared__ double sh[4];
-  double kl = 0.0;
-  for (int i = threadIdx.x; i < B * latent; i += 256) {
-    const int b = i / latent, j = i % latent;
-    const double mu = mulv[b * ld + j], lv = mulv[b * ld + latent + j];
-    kl += -0.5 * (1.0 + lv - mu * mu - exp(lv));
+  double kl = 0.0, mse = 0.0, pm = 0.0, nb_tot = (double)B;
+  if (phase == 2) {
+    kl = sums[0]; mse = sums[1]; pm = sums[2]; nb_tot = sums[3]; n_elems = sums[4];
+  } else {
+    for (int i = threadIdx.x; i < B * latent; i += 256) {
+      const int b = i / latent, j = i % latent;
+      const double mu = mulv[b * ld + j], lv = mulv[b * ld + latent + j];
+      kl += -0.5 * (1.0 + lv - mu * mu - exp(lv));
+    }
+    kl = block_sum_d(kl, sh);
+    for (int i = threadIdx.x; i < n_mse; i += 256) mse += mse_partial[i];
+    mse = block_sum_d(mse, sh);
+    size_t off = 0;
+    for (int l = 0; l < 4; ++l) {
+      const int nb = pm_counts[2 * l] * B;
+      double s = 0.0;
+      for (int i = threadIdx.x; i < nb; i += 256) s += pm_partial[off + i];
+      s = block_sum_d(s, sh);
+      pm += (double)pm_w[l] * s / (double)pm_counts[2 * l + 1];
+      off += nb;
+    }
   }
-  kl = block_sum_d(kl, sh);
-  double mse = 0.0;
-  for (int i = threadIdx.x; i < n_mse; i += 256) mse += mse_partial[i];
-  mse = block_sum_d(mse, sh) / n_elems;
-  double pm = 0.0;
-  size_t off = 0;
-  for (int l = 0; l < 4; ++l) {
-    const int nb = pm_counts[2 * l] * B;
-    double s = 0.0;
-    for (int i = threadIdx.x; i < nb; i += 256) s += pm_partial[off + i];
-    s = block_sum_d(s, sh);
-    pm += (double)pm_w[l] * s / (double)pm_counts[2 * l + 1];
-    off += nb;
+  if (threadIdx.x != 0) return;
+  if (phase == 1) {
+    sums[0] = kl; sums[1] = mse; sums[2] = pm; sums[3] = nb_tot; sums[4] = n_elems;
+    return;
   }
-  if (threadIdx.x == 0) {
-    const double pm_mean = pm / B, kl_mean = kl / B;
-    metrics[0] = (float)(mse + alpha * pm_mean + beta * kl_mean);
-    metrics[1] = (float)pm_mean;
-    metrics[2] = (float)mse;
-    metrics[3] = (float)kl_mean;
-  }
+  const double mse_mean = mse / n_elems, pm_mean = pm / nb_tot, kl_mean = kl / nb_tot;
+  metrics[0] = (float)(mse_mean + alpha * pm_mean + beta * kl_mean);
+  metrics[1] = (float)pm_mean;
+  metrics[2] = (float)mse_mean;
+  metrics[3] = (float)kl_mean;
 }
 __global__ void vae_dz_kernel(const float* __restrict__ mulv, int ld, int latent, int B,
                               const float* __restrict__ eps, const float* __restrict__ dzc, int ldzc,
@@ -821,9 +929,9 @@ __global__ void vae_dz_kernel(const float* __restrict__ mulv, int ld, int latent
 }
 int launch_vae_loss(hipStream_t st, const float* mulv, int ld, int latent, int B, const double* mse_partial,
                     int n_mse, double n_elems, const double* pm_partial, const int* pm_counts,
-                    const float* pm_w, float alpha, float beta, float* metrics) {
+                    const float* pm_w, float alpha, float beta, float* metrics, double* sums, int phase) {
   hipLaunchKernelGGL(vae_loss_kernel, dim3(1), dim3(256), 0, st, mulv, ld, latent, B, mse_partial, n_mse,
-                     n_elems, pm_partial, pm_counts, pm_w, alpha, beta, metrics);
+                     n_elems, pm_partial, pm_counts, pm_w, alpha, beta, metrics, sums, phase);
   ICS_HIP(hipGetLastError());
   return 0;
 }

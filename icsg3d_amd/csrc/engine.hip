@@ -142,10 +142,26 @@ struct Net {
   float* fws() const { return splitk ? ws_fwd : nullptr; }
   double* ws_dbl = nullptr;  size_t ws_dbl_n = 0;
   float* d_metrics = nullptr;
-  // data parallel
+  // data parallel: gradient buckets are all-reduced on comm_st while the backward pass
+  // continues on st; BN moving statistics are averaged over the ranks every step; sync_bn = global-batch
+  // BatchNorm statistics (per-layer all-gather / all-reduce of the per-channel sums on st)
   ncclComm_t comm = nullptr;
   int rank = 0, nranks = 1;
-  double* d_red = nullptr;
+  double* d_red = nullptr;           // [16] small reductions (timing max, metric sums)
+  hipStream_t comm_st = nullptr;
+  hipEvent_t ev_grad = nullptr, ev_comm = nullptr;
+  size_t bucket_hi = 0, bucket_min = 0;   // gradients at offsets >= bucket_hi are already being reduced
+  int buckets_issued = 0;
+  bool overlap = true;               // ICSG3D_DP_NO_OVERLAP=1: one all-reduce on st after the backward pass
+  int sync_bn = 0;
+  float* bn_slab = nullptr;          // all BN moving means / variances, contiguous (one all-reduce)
+  size_t bn_slab_n = 0, bn_slab_used = 0;
+  double* sync_local = nullptr;      // [3*Cmax]
+  double* sync_gathered = nullptr;   // [nranks][3*Cmax]
+  int sync_cmax = 0;
+  BnSync bn_sync{};
+  const BnSync* sync() const { return (sync_bn && comm) ? &bn_sync : nullptr; }
+  int head_nblk = 0;
 
   // U-Net specifics
   int ncls = 95;
@@ -172,6 +188,9 @@ struct Net {
   ~Net() {
     if (comm) ncclCommDestroy(comm);
     for (void* p : allocs) (void)hipFree(p);
+    if (ev_grad) (void)hipEventDestroy(ev_grad);
+    if (ev_comm) (void)hipEventDestroy(ev_comm);
+    if (comm_st) (void)hipStreamDestroy(comm_st);
     if (st) (void)hipStreamDestroy(st);
   }
   template <typename T>
@@ -239,7 +258,16 @@ static int alloc_layer(Net& n, ConvLayer& L, bool need_bwd, bool pooled) {
     ICS_TRY(n.alloc(&L.c1c2, (size_t)2 * L.Cout));
   }
   if (L.has_bn) {
-    ICS_TRY(n.alloc(&L.mm, (size_t)L.Cout)); ICS_TRY(n.alloc(&L.mv, (size_t)L.Cout));
+    if (!n.bn_slab) {   // one slab for every layer's moving statistics (data parallel: one all-reduce)
+      size_t tot = 0;
+      for (auto& q : n.layers) if (q->has_bn) tot += 2 * (size_t)q->Cout;
+      ICS_TRY(n.alloc(&n.bn_slab, tot));
+      n.bn_slab_n = tot;
+    }
+    ICS_CHECK(n.bn_slab_used + 2 * (size_t)L.Cout <= n.bn_slab_n, "BN slab overflow");
+    L.mm = n.bn_slab + n.bn_slab_used; L.mv = L.mm + L.Cout;
+    n.bn_slab_used += 2 * (size_t)L.Cout;
+    n.sync_cmax = std::max(n.sync_cmax, L.Cout);
     ICS_TRY(n.alloc(&L.mean, (size_t)L.Cout)); ICS_TRY(n.alloc(&L.rstd, (size_t)L.Cout));
     ICS_TRY(n.alloc(&L.scale, (size_t)L.Cout)); ICS_TRY(n.alloc(&L.shift, (size_t)L.Cout));
     int ti = n.add_tensor(L.name + "/moving_mean", {L.Cout}, false);
@@ -363,7 +391,7 @@ static int alloc_workspaces(Net& n, bool need_bwd) {
   n.ws_dbl_n = 1 << 16;
   ICS_TRY(n.alloc(&n.ws_dbl, n.ws_dbl_n));
   ICS_TRY(n.alloc(&n.d_metrics, (size_t)16));
-  ICS_TRY(n.alloc(&n.d_red, (size_t)2));
+  ICS_TRY(n.alloc(&n.d_red, (size_t)16));
   return 0;
 }
 
@@ -462,7 +490,7 @@ static int conv_forward(Net& n, ConvLayer& L, int B, bool training, bool update_
     BnParams bn{n.tp(L.t_gamma), n.tp(L.t_beta), L.mm, L.mv, L.mean, L.rstd, L.scale, L.shift};
     if (training) {
       const int nblk = par_blocks ? par_blocks : (int)((M + rpb - 1) / rpb);
-      ICS_TRY(launch_bn_finalize(n.st, n.ws_stat, nblk, L.Npad, bn, L.Cout, update_moving ? 1 : 0, n.bn_unbias));
+      ICS_TRY(launch_bn_finalize(n.st, n.ws_stat, nblk, L.Npad, bn, L.Cout, update_moving ? 1 : 0, n.bn_unbias, n.sync()));
     } else {
       ICS_TRY(launch_bn_eval_prepare(n.st, bn, L.Cout));
     }
@@ -608,18 +636,61 @@ static int conv_backward(Net& n, ConvLayer& L, int B, GradSrc g0, GradSrc g1, co
   ICS_TRY(launch_layer_bwd(n.st, lb, L.dy, n.ws_bwd, L.c1c2,
                            (param_grads && L.has_bn) ? n.tg(L.t_gamma) : nullptr,
                            (param_grads && L.has_bn) ? n.tg(L.t_beta) : nullptr,
-                           param_grads ? n.tg(L.t_b) : nullptr));
+                           param_grads ? n.tg(L.t_b) : nullptr, n.sync()));
   n.prof.end(n.st);
   return conv_grads_from_dy(n, L, B, need_dA, param_grads);
 }
 
+// ---- data parallel gradient exchange.  The flat gradient buffer is laid out in layer order and the
+// backward pass walks the layers last-to-first, so "all gradients at offsets >= lo are final" holds after
+// each layer; a bucket [lo, bucket_hi) is handed to RCCL on comm_st (behind an event on st) as soon as it
+// holds >= bucket_min floats, and overlaps with the rest of the backward pass.  Adam waits for comm_st.
+static int grads_begin(Net& n) {
+  n.bucket_hi = n.nparams;
+  n.buckets_issued = 0;
+  if (!n.comm || n.nranks < 1) return 0;
+  if (!n.sync_bn && n.bn_slab_n) {
+    // local BN: average the moving statistics the forward pass just updated (every rank then checkpoints
+    // the same values; the update is linear, so this is the moving average of the rank-mean statistics)
+    ICS_HIP(hipEventRecord(n.ev_grad, n.st));
+    ICS_HIP(hipStreamWaitEvent(n.comm_st, n.ev_grad, 0));
+    n.prof.begin(n.comm_st, "rccl_allreduce_bn_moving", 0, 4.0 * n.bn_slab_n);
+    ncclResult_t r = ncclAllReduce(n.bn_slab, n.bn_slab, n.bn_slab_n, ncclFloat, ncclAvg, n.comm, n.comm_st);
+    n.prof.end(n.comm_st);
+    ICS_CHECK(r == ncclSuccess, std::string("ncclAllReduce(bn moving): ") + ncclGetErrorString(r));
+  }
+  return 0;
+}
+static int grads_ready(Net& n, size_t lo) {
+  if (!n.comm || !n.overlap) return 0;
+  if (lo >= n.bucket_hi) return 0;
+  if (lo != 0 && n.bucket_hi - lo < n.bucket_min) return 0;
+  ICS_HIP(hipEventRecord(n.ev_grad, n.st));
+  ICS_HIP(hipStreamWaitEvent(n.comm_st, n.ev_grad, 0));
+  n.prof.begin(n.comm_st, "rccl_allreduce_grads", 0, 4.0 * (n.bucket_hi - lo));
+  ncclResult_t r = ncclAllReduce(n.G + lo, n.G + lo, n.bucket_hi - lo, ncclFloat, ncclSum, n.comm, n.comm_st);
+  n.prof.end(n.comm_st);
+  ICS_CHECK(r == ncclSuccess, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+  n.bucket_hi = lo;
+  n.buckets_issued += 1;
+  return 0;
+}
+static size_t layer_lo(const Net& n, const ConvLayer& L) { return n.tensors[L.t_w].off; }
+
 static int adam_step(Net& n) {
   float gscale = 1.f;
   if (n.comm) {
-    n.prof.begin(n.st, "rccl_allreduce_grads", 0, 4.0 * n.nparams);
-    ncclResult_t r = ncclAllReduce(n.G, n.G, n.nparams, ncclFloat, ncclSum, n.comm, n.st);
-    n.prof.end(n.st);
-    ICS_CHECK(r == ncclSuccess, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+    if (n.overlap) {
+      ICS_TRY(grads_ready(n, 0));
+    } else {
+      n.prof.begin(n.st, "rccl_allreduce_grads", 0, 4.0 * n.nparams);
+      ncclResult_t r = ncclAllReduce(n.G, n.G, n.nparams, ncclFloat, ncclSum, n.comm, n.st);
+      n.prof.end(n.st);
+      ICS_CHECK(r == ncclSuccess, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+      n.buckets_issued = 1;
+    }
+    ICS_HIP(hipEventRecord(n.ev_comm, n.comm_st));
+    ICS_HIP(hipStreamWaitEvent(n.st, n.ev_comm, 0));
     gscale = 1.f / (float)n.nranks;
   }
   n.adam_t += 1;
@@ -732,12 +803,22 @@ static int unet_head_forward(Net& n, int B) {
   return conv_forward(n, H, B, false, false, n.tp(H.t_b));
 }
 
-static int unet_loss(Net& n, int B, int mode, int want_grad) {
+// mode 1 metrics: single GPU -> finalized on the spot.  With a communicator the six sums and the voxel
+// count are all-reduced first (numerators / denominators, not ratios: SURVEY 8(e)); that costs a small
+// collective on st, so it only happens when the caller reads the metrics (want_metrics) -- every rank
+// must then ask on the same steps.
+static int unet_loss(Net& n, int B, int mode, int want_grad, bool want_metrics = true) {
   const size_t M = n.rows(*n.head, B);
   n.prof.begin(n.st, "head_softmax_loss", 0, 4.0 * M * (n.ncls + 1) * 2);
   ICS_TRY(launch_head(n.st, n.head->s, n.ncls + 1, n.ncls, n.labels, M, mode, want_grad, n.loss_weight,
-                      n.ws_dbl, 2048, n.d_metrics));
+                      n.ws_dbl, 2048, n.comm ? nullptr : n.d_metrics, &n.head_nblk));
   n.prof.end(n.st);
+  if (mode != 0 && n.comm && want_metrics) {
+    ICS_TRY(launch_head_metrics(n.st, n.ws_dbl, n.head_nblk, (double)M, n.d_metrics, n.d_red, 1));
+    ncclResult_t r = ncclAllReduce(n.d_red, n.d_red, 7, ncclDouble, ncclSum, n.comm, n.st);
+    ICS_CHECK(r == ncclSuccess, std::string("ncclAllReduce(metrics): ") + ncclGetErrorString(r));
+    ICS_TRY(launch_head_metrics(n.st, n.ws_dbl, n.head_nblk, (double)M, n.d_metrics, n.d_red, 2));
+  }
   return 0;
 }
 
@@ -831,14 +912,21 @@ static int unet_backward(Net& n, int B) {
   // gradient of a concat consumer w.r.t. its skip / upsampled producer
   auto g_skip = [&](ConvLayer* c) { return c->split_up ? gs_direct(c->dA_skip, c->Cs, 0) : gs_direct(c->dA, c->Cin, 0); };
   auto g_up = [&](ConvLayer* c) { return c->split_up ? gs_direct(c->dxl, c->Cu, 0) : gs_up(c->dA, c->Cin, c->src[0].C); };
+  // after each layer its gradients (and everything behind them in the flat buffer) are final: grads_ready
+  ICS_TRY(grads_ready(n, layer_lo(n, H)));
   ICS_TRY(bw(r.c18, gs_direct(H.dA, 128, 0), gs_none(), true));
   ICS_TRY(bw(r.c17, gs_direct(r.c18->dA, 128, 0), gs_none(), true));
   ICS_TRY(bw(r.c16, g_up(r.c17), gs_none(), true));
   ICS_TRY(bw(r.c15, gs_direct(r.c16->dA, 256, 0), gs_none(), true));
+  ICS_TRY(grads_ready(n, layer_lo(n, *r.c15)));
   ICS_TRY(bw(r.c14, g_up(r.c15), gs_none(), true));
+  ICS_TRY(grads_ready(n, layer_lo(n, *r.c14)));
   ICS_TRY(bw(r.c13, gs_direct(r.c14->dA, 512, 0), gs_none(), true));
+  ICS_TRY(grads_ready(n, layer_lo(n, *r.c13)));
   ICS_TRY(bw(r.c10, g_up(r.c13), gs_none(), true));
+  ICS_TRY(grads_ready(n, layer_lo(n, *r.c10)));
   ICS_TRY(bw(r.c9, gs_direct(r.c10->dA, 512, 0), gs_none(), true));
+  ICS_TRY(grads_ready(n, layer_lo(n, *r.c9)));
   ICS_TRY(bw(r.c6, gs_pool(r.c9->dA, 256, *r.c6), g_skip(r.c13), true));
   ICS_TRY(bw(r.c5, gs_direct(r.c6->dA, 128, 0), gs_none(), true));
   ICS_TRY(bw(r.c4, gs_pool(r.c5->dA, 128, *r.c4), g_skip(r.c15), true));
@@ -875,7 +963,8 @@ static int unet_train_resident(Net& n, int B, float* metrics) {
 static int unet_train_resident_impl(Net& n, int B, float* metrics) {
   ICS_TRY(unet_forward_trunk(n, B, true, true, false, n.x_in));
   ICS_TRY(unet_head_forward(n, B));
-  ICS_TRY(unet_loss(n, B, 1, 1));
+  ICS_TRY(unet_loss(n, B, 1, 1, metrics != nullptr));
+  ICS_TRY(grads_begin(n));
   ICS_TRY(unet_backward(n, B));
   ICS_TRY(adam_step(n));
   if (metrics) {
@@ -1047,6 +1136,11 @@ static int vae_step(Net& n, int B, bool training, float* metrics) {
   hipStream_t saved = u.st;
   u.st = n.st;
   n.splitk = u.splitk = training;
+  // SyncBN covers the perceptual U-Net's batch-statistics BatchNorm too (it borrows the VAE's communicator)
+  ncclComm_t saved_comm = u.comm;
+  const int saved_sync = u.sync_bn;
+  const BnSync saved_bs = u.bn_sync;
+  if (n.sync()) { u.comm = n.comm; u.sync_bn = 1; u.bn_sync = n.bn_sync; }
   int rc = 0;
   do {
     VaeRefs r = vae_refs(n);
@@ -1081,9 +1175,21 @@ static int vae_step(Net& n, int B, bool training, float* metrics) {
       poff += (size_t)B * 8;
     }
     if (rc) break;
-    if ((rc = launch_vae_loss(n.st, r.zml->s, 2 * n.latent, n.latent, B, mse_part, B * mse_bps, (double)M * n.C,
-                              pm_part, n.d_pm_counts, n.d_pm_w, n.alpha, n.beta, n.d_metrics))) break;
+    if (!n.comm) {
+      if ((rc = launch_vae_loss(n.st, r.zml->s, 2 * n.latent, n.latent, B, mse_part, B * mse_bps, (double)M * n.C,
+                                pm_part, n.d_pm_counts, n.d_pm_w, n.alpha, n.beta, n.d_metrics))) break;
+    } else if (metrics) {
+      // data parallel: all-reduce the sums (numerators / denominators), then form the means
+      if ((rc = launch_vae_loss(n.st, r.zml->s, 2 * n.latent, n.latent, B, mse_part, B * mse_bps, (double)M * n.C,
+                                pm_part, n.d_pm_counts, n.d_pm_w, n.alpha, n.beta, n.d_metrics, n.d_red, 1))) break;
+      if (ncclAllReduce(n.d_red, n.d_red, 5, ncclDouble, ncclSum, n.comm, n.st) != ncclSuccess) {
+        set_error("ncclAllReduce(vae metrics) failed"); rc = -1; break;
+      }
+      if ((rc = launch_vae_loss(n.st, r.zml->s, 2 * n.latent, n.latent, B, mse_part, B * mse_bps, (double)M * n.C,
+                                pm_part, n.d_pm_counts, n.d_pm_w, n.alpha, n.beta, n.d_metrics, n.d_red, 2))) break;
+    }
     if (training) {
+      if ((rc = grads_begin(n))) break;
       if ((rc = unet_pm_backward(u, B))) break;
       hipLaunchKernelGGL(axpy_strided_kernel, dim3((unsigned)((M * n.C + 255) / 256)), dim3(256), 0, n.st, n.drecon,
                          ur.c1->dA, M, n.C, ur.c1->CinG);
@@ -1097,6 +1203,7 @@ static int vae_step(Net& n, int B, bool training, float* metrics) {
                                 gs_none(), nullptr, true, true))) break;
       if (rc) break;
       if ((rc = conv_backward(n, *r.decd, B, gs_direct(r.dl[0]->dA, r.decd->Cout, 0), gs_none(), nullptr, true, true))) break;
+      if ((rc = grads_ready(n, layer_lo(n, *r.decd)))) break;   // decoder gradients (the tail of the flat buffer)
       // sampling + KL
       if ((rc = launch_vae_dz(n.st, r.zml->s, 2 * n.latent, n.latent, B, n.eps_in, r.decd->dA, r.decd->Cin, n.beta, n.dmulv))) break;
       // zmulv given dy = dmulv
@@ -1127,6 +1234,7 @@ static int vae_step(Net& n, int B, bool training, float* metrics) {
     }
   } while (0);
   u.st = saved;
+  u.comm = saved_comm; u.sync_bn = saved_sync; u.bn_sync = saved_bs;
   n.splitk = u.splitk = false;
   return rc;
 }
@@ -1163,6 +1271,30 @@ __global__ void labels_kernel(const float* __restrict__ p, int ld, int ncls, siz
     if (pr[c] > bv) { bv = pr[c]; best = c; }   // np.argmax: first maximum
   species[row] = (unsigned char)best;
   mask[row] = pr[ncls] >= thresh ? 1 : 0;
+}
+
+// per-sample min / max of channels [c0, c0+nch) of an NDHWC tensor: out[(b*nch + j)*2 + {0,1}]
+// (to_lattice_params, /root/reference/utils.py:160-178, needs nothing else of the coordinate channels)
+__global__ __launch_bounds__(256) void chan_minmax_kernel(const float* __restrict__ x, size_t per_sample, int C, int c0,
+                                                           int nch, float* __restrict__ out) {
+  __shared__ float smin[256], smax[256];
+  const int b = blockIdx.x / nch, j = blockIdx.x % nch;
+  const float* p = x + (size_t)b * per_sample * C + c0 + j;
+  float lo = INFINITY, hi = -INFINITY;
+  for (size_t i = threadIdx.x; i < per_sample; i += 256) {
+    const float v = p[i * C];
+    lo = fminf(lo, v); hi = fmaxf(hi, v);
+  }
+  smin[threadIdx.x] = lo; smax[threadIdx.x] = hi;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      smin[threadIdx.x] = fminf(smin[threadIdx.x], smin[threadIdx.x + o]);
+      smax[threadIdx.x] = fmaxf(smax[threadIdx.x], smax[threadIdx.x + o]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out[blockIdx.x * 2] = smin[0]; out[blockIdx.x * 2 + 1] = smax[0]; }
 }
 
 }  // namespace ics
@@ -1334,6 +1466,32 @@ int ics_net_reset_optimizer(ics_net* net) {
   return 0;
 }
 
+int ics_net_get_optimizer_state(ics_net* net, float* m, float* v, size_t count, int* step) {
+  ICS_CHECK(net, "null handle");
+  Net& n = net->n;
+  ICS_CHECK(count == n.nparams, "optimizer state size mismatch");
+  if (m) ICS_HIP(hipMemcpyAsync(m, n.Mo, count * sizeof(float), hipMemcpyDeviceToHost, n.st));
+  if (v) ICS_HIP(hipMemcpyAsync(v, n.Vo, count * sizeof(float), hipMemcpyDeviceToHost, n.st));
+  ICS_HIP(hipStreamSynchronize(n.st));
+  if (step) *step = n.adam_t;
+  return 0;
+}
+int ics_net_set_optimizer_state(ics_net* net, const float* m, const float* v, size_t count, int step) {
+  ICS_CHECK(net && m && v, "null argument");
+  Net& n = net->n;
+  ICS_CHECK(count == n.nparams && step >= 0, "optimizer state size mismatch");
+  ICS_HIP(hipMemcpyAsync(n.Mo, m, count * sizeof(float), hipMemcpyHostToDevice, n.st));
+  ICS_HIP(hipMemcpyAsync(n.Vo, v, count * sizeof(float), hipMemcpyHostToDevice, n.st));
+  ICS_HIP(hipStreamSynchronize(n.st));
+  n.adam_t = step;
+  return 0;
+}
+int ics_net_num_params(ics_net* net, size_t* count) {
+  ICS_CHECK(net && count, "null argument");
+  *count = net->n.nparams;
+  return 0;
+}
+
 int ics_net_profile_enable(ics_net* net, int on) {
   ICS_CHECK(net, "null handle");
   ICS_HIP(hipStreamSynchronize(net->n.st));
@@ -1500,6 +1658,61 @@ int ics_vae_test_step(ics_net* net, const float* x, const float* cond, const flo
   return vae_step(net->n, batch, false, metrics);
 }
 
+// Fused inference tail of generate.py:204-225 / eval.py:163-175: decoder.predict -> unet.model.predict ->
+// argmax / threshold, all on the device.  The reconstruction never leaves HBM: the U-Net reads it where the
+// decoder wrote it (driven on the VAE's stream), and what comes back is 2 bytes per voxel plus, on request,
+// the density channel (watershed input) and the coordinate channels' min/max (to_lattice_params).
+int ics_vae_decode_to_unet_labels(ics_net* vae, ics_net* unet, const float* z, const float* cond, int batch,
+                                  float thresh, uint8_t* species, uint8_t* mask, float* density,
+                                  float* coord_minmax) {
+  ICS_TRY(require_kind(vae, 1));
+  ICS_TRY(require_kind(unet, 0));
+  Net& n = vae->n;
+  Net& u = unet->n;
+  ICS_CHECK(z && cond, "null argument");
+  ICS_CHECK(u.d == n.d && u.C == n.C && u.device == n.device, "U-Net / VAE engines do not match (grid, channels, device)");
+  ICS_CHECK(batch >= 1 && batch <= n.maxB && batch <= u.maxB, "batch exceeds max_batch");
+  const size_t lat = n.latent, W = lat + n.ncond;
+  ICS_HIP(hipStreamSynchronize(u.st));
+  ICS_HIP(hipMemcpy2DAsync(n.zc, W * 4, z, lat * 4, lat * 4, batch, hipMemcpyHostToDevice, n.st));
+  ICS_HIP(hipMemcpy2DAsync(n.zc + lat, W * 4, cond, n.ncond * 4, n.ncond * 4, batch, hipMemcpyHostToDevice, n.st));
+  ICS_TRY(vae_decode_fwd(n, batch, false));
+  hipStream_t saved = u.st;
+  u.st = n.st;
+  int rc = 0;
+  const size_t M = (size_t)batch * n.d * n.d * n.d;
+  unsigned char* d_species = reinterpret_cast<unsigned char*>(u.head->dy);   // [M][ncls+1] float scratch
+  unsigned char* d_mask = d_species + M;
+  float* d_aux = reinterpret_cast<float*>(d_mask + M);                       // density [M] | minmax [B][3][2]
+  do {
+    if ((rc = unet_forward_trunk(u, batch, false, false, false, n.recon))) break;
+    if ((rc = unet_head_forward(u, batch))) break;
+    if ((rc = unet_loss(u, batch, 0, 0))) break;
+    hipLaunchKernelGGL(labels_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, n.st, u.head->s, u.ncls + 1,
+                       u.ncls, M, thresh, d_species, d_mask);
+    if (density) {
+      hipLaunchKernelGGL(gather_cols_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, n.st, n.recon, n.C, 0, 1,
+                         M, d_aux);
+    }
+    if (coord_minmax && n.C >= 4) {
+      hipLaunchKernelGGL(chan_minmax_kernel, dim3(batch * 3), dim3(256), 0, n.st, n.recon, M / batch, n.C, 1, 3,
+                         d_aux + M);
+    }
+    if (hipGetLastError() != hipSuccess) { set_error("inference tail launch failed"); rc = -1; break; }
+  } while (0);
+  u.st = saved;
+  ICS_TRY(rc);
+  if (species) ICS_HIP(hipMemcpyAsync(species, d_species, M, hipMemcpyDeviceToHost, n.st));
+  if (mask) ICS_HIP(hipMemcpyAsync(mask, d_mask, M, hipMemcpyDeviceToHost, n.st));
+  if (density) ICS_HIP(hipMemcpyAsync(density, d_aux, M * 4, hipMemcpyDeviceToHost, n.st));
+  if (coord_minmax) {
+    if (n.C >= 4) ICS_HIP(hipMemcpyAsync(coord_minmax, d_aux + M, (size_t)batch * 6 * 4, hipMemcpyDeviceToHost, n.st));
+    else std::memset(coord_minmax, 0, (size_t)batch * 6 * 4);
+  }
+  ICS_HIP(hipStreamSynchronize(n.st));
+  return 0;
+}
+
 // ---------------------------------------------------------------- data parallel
 int ics_comm_unique_id(char uid[128]) {
   static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
@@ -1512,12 +1725,66 @@ int ics_comm_unique_id(char uid[128]) {
 int ics_net_comm_init(ics_net* net, int rank, int nranks, const char uid[128]) {
   ICS_CHECK(net && uid && nranks >= 1 && rank >= 0 && rank < nranks, "bad comm arguments");
   Net& n = net->n;
+  ICS_CHECK(n.comm == nullptr, "communicator already initialised");
   ICS_HIP(hipSetDevice(n.device));
   ncclUniqueId id;
   std::memcpy(&id, uid, 128);
   ncclResult_t r = ncclCommInitRank(&n.comm, nranks, id, rank);
   ICS_CHECK(r == ncclSuccess, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
   n.rank = rank; n.nranks = nranks;
+  ICS_HIP(hipStreamCreateWithFlags(&n.comm_st, hipStreamNonBlocking));
+  ICS_HIP(hipEventCreateWithFlags(&n.ev_grad, hipEventDisableTiming));
+  ICS_HIP(hipEventCreateWithFlags(&n.ev_comm, hipEventDisableTiming));
+  n.overlap = getenv("ICSG3D_DP_NO_OVERLAP") == nullptr;
+  // ~4 buckets, last-layer-first; small nets (the VAE: 3.4 MB of gradients) go out as one or two messages
+  n.bucket_min = std::max<size_t>(n.nparams / 4, (size_t)1 << 18);
+  // SyncBN exchange buffers, wide enough for the perceptual U-Net a VAE engine drives
+  int cmax = n.sync_cmax;
+  if (n.pm) cmax = std::max(cmax, n.pm->sync_cmax);
+  cmax = std::max(cmax, 1);
+  ICS_TRY(n.alloc(&n.sync_local, (size_t)3 * cmax));
+  ICS_TRY(n.alloc(&n.sync_gathered, (size_t)nranks * 3 * cmax));
+  n.bn_sync = BnSync{n.comm, nranks, n.sync_local, n.sync_gathered};
+  ICS_HIP(hipStreamSynchronize(n.st));
+  return 0;
+}
+/* Replicas must start identical: parameters, BN moving statistics, Adam moments and step count of `root`
+ * overwrite every other rank's (the class API draws its initial weights from an unseeded RNG). */
+int ics_net_comm_broadcast_state(ics_net* net, int root) {
+  ICS_CHECK(net, "null handle");
+  Net& n = net->n;
+  if (!n.comm) return 0;
+  ICS_CHECK(root >= 0 && root < n.nranks, "bad root rank");
+  ICS_HIP(hipSetDevice(n.device));
+  float* bufs[3] = {n.P, n.Mo, n.Vo};
+  for (float* b : bufs) {
+    ncclResult_t r = ncclBroadcast(b, b, n.nparams, ncclFloat, root, n.comm, n.st);
+    ICS_CHECK(r == ncclSuccess, std::string("ncclBroadcast: ") + ncclGetErrorString(r));
+  }
+  if (n.bn_slab_n) {
+    ncclResult_t r = ncclBroadcast(n.bn_slab, n.bn_slab, n.bn_slab_n, ncclFloat, root, n.comm, n.st);
+    ICS_CHECK(r == ncclSuccess, std::string("ncclBroadcast(bn): ") + ncclGetErrorString(r));
+  }
+  double t = (double)n.adam_t;
+  ICS_HIP(hipMemcpyAsync(n.d_red, &t, sizeof(double), hipMemcpyHostToDevice, n.st));
+  ncclResult_t r = ncclBroadcast(n.d_red, n.d_red, 1, ncclDouble, root, n.comm, n.st);
+  ICS_CHECK(r == ncclSuccess, std::string("ncclBroadcast(t): ") + ncclGetErrorString(r));
+  ICS_HIP(hipMemcpyAsync(&t, n.d_red, sizeof(double), hipMemcpyDeviceToHost, n.st));
+  ICS_HIP(hipStreamSynchronize(n.st));
+  n.adam_t = (int)t;
+  n.packed_valid = false;
+  return 0;
+}
+int ics_net_set_sync_bn(ics_net* net, int on) {
+  ICS_CHECK(net, "null handle");
+  net->n.sync_bn = on ? 1 : 0;
+  return 0;
+}
+int ics_net_comm_info(ics_net* net, int* rank, int* nranks, int* buckets_last_step) {
+  ICS_CHECK(net, "null handle");
+  if (rank) *rank = net->n.rank;
+  if (nranks) *nranks = net->n.comm ? net->n.nranks : 0;
+  if (buckets_last_step) *buckets_last_step = net->n.buckets_issued;
   return 0;
 }
 int ics_net_comm_allreduce_max(ics_net* net, double* value) {

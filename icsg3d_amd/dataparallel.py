@@ -1,11 +1,14 @@
 """Data-parallel host logic (new -- the reference is single-process).
 
 One process per GPU.  The control plane (rendezvous, barriers, timing reduction, exchange of the
-128-byte ncclUniqueId) runs over torch.distributed (gloo); the data path is ONE RCCL all-reduce of
-the engine's flat fp32 gradient buffer per step, issued inside libicsg3d_hip.so on the engine's own
-stream (ics_net_comm_init / adam_step in csrc/engine.hip), followed by the 1/N scale fused into Adam.
-Each replica normalises BatchNorm with its own 32-grid batch statistics ("local BN": every replica
-is the reference at B=32; see DESIGN.md for the SyncBN caveat).
+128-byte ncclUniqueId) runs over torch.distributed (gloo); the data path lives inside libicsg3d_hip.so
+(csrc/engine.hip): the flat fp32 gradient buffer is all-reduced with RCCL in ~4 buckets, last layer first,
+on a second HIP stream while the backward pass continues, and the 1/N scale is fused into Adam.
+Default "local BN": each replica normalises with its own batch statistics (= the reference at its local
+batch) and the BN moving statistics are averaged over the ranks every step; `sync_bn=True` exchanges the
+per-channel statistics instead, so N x B grids normalise exactly like one process at N*B.
+`init_engine_comm` also makes the replicas identical (rank 0's parameters, BN statistics and Adam state are
+broadcast): the class API draws its initial weights from an unseeded RNG.
 """
 from __future__ import annotations
 
@@ -31,12 +34,41 @@ def exchange_unique_id(dist, rank: int, make_uid):
     return bytes(uid)
 
 
-def init_engine_comm(engine, dist, rank: int, world: int):
-    """Attach an RCCL communicator to an engine (no-op for world == 1)."""
-    if world <= 1:
+def init_engine_comm(engine, dist, rank: int, world: int, sync_bn: bool = False, force: bool = False):
+    """Attach an RCCL communicator to an engine and synchronise the replicas: rank 0's parameters, BN moving
+    statistics and Adam state overwrite everyone's.  No-op for world == 1 unless `force` (single-rank
+    communicator: exercises the whole data-parallel path on a 1-GPU box)."""
+    if world <= 1 and not force:
         return
     from .engine import comm_unique_id
     engine.comm_init(rank, world, exchange_unique_id(dist, rank, comm_unique_id))
+    engine.set_sync_bn(sync_bn)
+    engine.broadcast_state(0)
+
+
+def syncbn_moments(dist, x):
+    """Host reference of the SyncBN exchange (tests): per-channel (mean, biased var) of the GLOBAL batch from
+    each rank's shard x (..., C): all-gather (n, mean, M2) and merge in rank order (Chan et al.) -- the same
+    arithmetic bn_local_merge / bn_sync_finalize perform on the device."""
+    import torch
+    xf = np.asarray(x, np.float64).reshape(-1, np.shape(x)[-1])
+    n = float(xf.shape[0])
+    mean = xf.mean(0)
+    m2 = ((xf - mean) ** 2).sum(0)
+    local = torch.from_numpy(np.concatenate([[n], mean, m2]))
+    parts = [torch.zeros_like(local) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, local)
+    C = xf.shape[1]
+    N, mu, M2 = 0.0, np.zeros(C), np.zeros(C)
+    for p in parts:
+        p = p.numpy()
+        nb, mb, qb = p[0], p[1:1 + C], p[1 + C:]
+        nt = N + nb
+        dlt = mb - mu
+        M2 = M2 + qb + dlt * dlt * N * nb / nt
+        mu = mu + dlt * nb / nt
+        N = nt
+    return mu, M2 / N, N
 
 
 def allreduce_mean_host(dist, arrays: dict):

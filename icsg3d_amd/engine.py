@@ -93,6 +93,22 @@ class _Net:
     def reset_optimizer(self):
         L.check(self._lib.ics_net_reset_optimizer(self._h))
 
+    def num_params(self):
+        n = C.c_size_t(0)
+        L.check(self._lib.ics_net_num_params(self._h, C.byref(n)))
+        return int(n.value)
+
+    def get_optimizer_state(self):
+        """(m, v, t): Adam moments over the flat parameter buffer and the step count."""
+        n = self.num_params()
+        m, v, t = np.empty(n, np.float32), np.empty(n, np.float32), C.c_int(0)
+        L.check(self._lib.ics_net_get_optimizer_state(self._h, L.fptr(m), L.fptr(v), n, C.byref(t)))
+        return m, v, int(t.value)
+
+    def set_optimizer_state(self, m, v, t):
+        m, v = _f32(m), _f32(v)
+        L.check(self._lib.ics_net_set_optimizer_state(self._h, L.fptr(m), L.fptr(v), m.size, int(t)))
+
     def sync(self):
         L.check(self._lib.ics_net_sync(self._h))
 
@@ -117,6 +133,18 @@ class _Net:
     # ---- data parallel
     def comm_init(self, rank, nranks, uid):
         L.check(self._lib.ics_net_comm_init(self._h, int(rank), int(nranks), uid))
+
+    def broadcast_state(self, root=0):
+        """rank `root`'s parameters, BN moving statistics and Adam state overwrite every replica's."""
+        L.check(self._lib.ics_net_comm_broadcast_state(self._h, int(root)))
+
+    def set_sync_bn(self, on=True):
+        L.check(self._lib.ics_net_set_sync_bn(self._h, 1 if on else 0))
+
+    def comm_info(self):
+        r, n, b = C.c_int(0), C.c_int(0), C.c_int(0)
+        L.check(self._lib.ics_net_comm_info(self._h, C.byref(r), C.byref(n), C.byref(b)))
+        return {"rank": r.value, "nranks": n.value, "buckets_last_step": b.value}
 
     def allreduce_max(self, value):
         v = C.c_double(float(value))
@@ -248,6 +276,23 @@ class VaeEngine(_Net):
             s = slice(i, i + self.max_batch)
             L.check(self._lib.ics_vae_decode(self._h, L.fptr(z[s]), L.fptr(cond[s]), z[s].shape[0], L.fptr(out[s])))
         return out
+
+    def decode_to_labels(self, unet, z, cond, thresh=0.8, want_density=True):
+        """decoder.predict -> unet.model.predict -> argmax / threshold without leaving the device
+        (generate.py:204-225).  Returns dict(species u8, mask u8, density f32 | None, coord_minmax (B,3,2))."""
+        z, cond = _f32(z), _f32(cond)
+        B, d = z.shape[0], self.d
+        mb = min(self.max_batch, unet.max_batch)
+        sp = np.empty((B, d, d, d), np.uint8)
+        mk = np.empty((B, d, d, d), np.uint8)
+        dens = np.empty((B, d, d, d), np.float32) if want_density else None
+        mm = np.zeros((B, 3, 2), np.float32)
+        for i in range(0, B, mb):
+            s = slice(i, i + mb)
+            L.check(self._lib.ics_vae_decode_to_unet_labels(
+                self._h, unet._h, L.fptr(z[s]), L.fptr(cond[s]), z[s].shape[0], float(thresh), L.u8ptr(sp[s]),
+                L.u8ptr(mk[s]), L.fptr(dens[s]) if want_density else None, L.fptr(mm[s])))
+        return {"species": sp, "mask": mk, "density": dens, "coord_minmax": mm}
 
     def train_step(self, x, cond, eps):
         x, cond, eps, B = self._args(x, cond, eps)

@@ -13,7 +13,8 @@ import os
 
 import numpy as np
 
-from ..checkpoint import load_npz, save_npz
+from ..checkpoint import load_weights as _load_weight_file
+from ..checkpoint import save_weights as _save_weight_file
 from ..engine import UnetEngine
 from ..synthetic import glorot_params, unet_param_shapes
 from .get_weights import get_weights
@@ -112,16 +113,17 @@ class _UnetModel:
     def __init__(self, owner):
         self._o = owner
 
-    # -- inference (generate.py:220, eval.py:166, view_results.py:136)
+    # -- inference (generate.py:220, eval.py:166, view_results.py:136).  Keras' predict streams the input in
+    # batches of `batch_size` (default 32); the engine does the same in chunks of its max_batch and is never
+    # re-created (and never loses optimizer state) because of an inference call.
     def predict(self, X, batch_size=None, verbose=0):
         X = np.asarray(X)
-        eng = self._o._engine(min(len(X), batch_size or len(X)) or 1)
-        return list(eng.predict(X))
+        return list(self._o._engine(min(len(X), batch_size or 32)).predict(X))
 
-    def predict_labels(self, X, thresh=0.8):
+    def predict_labels(self, X, thresh=0.8, batch_size=None):
         """Fused generate.py:220-225 tail: uint8 argmax species and (sig >= thresh) mask."""
         X = np.asarray(X)
-        return self._o._engine(len(X)).predict_labels(X, thresh)
+        return self._o._engine(min(len(X), batch_size or 32)).predict_labels(X, thresh)
 
     def predict_generator(self, gen):
         soft, sig = [], []
@@ -134,21 +136,32 @@ class _UnetModel:
     # -- training steps
     def train_on_batch(self, X, y):
         labels = _to_labels(y[0] if isinstance(y, (list, tuple)) else y, self._o.num_classes)
-        return [float(v) for v in self._o._engine(len(X)).train_step(X, labels)]
+        return [float(v) for v in self._o._engine(len(X), grow=True).train_step(X, labels)]
 
     def test_on_batch(self, X, y):
         labels = _to_labels(y[0] if isinstance(y, (list, tuple)) else y, self._o.num_classes)
-        return [float(v) for v in self._o._engine(len(X)).test_step(X, labels)]
+        return [float(v) for v in self._o._engine(len(X), grow=True).test_step(X, labels)]
 
     def fit_generator(self, generator, validation_data=None, epochs=1, callbacks=None, workers=4,
-                      use_multiprocessing=False, verbose=1):
-        """Epoch loop of unet/unet.py:370-377: mean of per-batch metrics as the epoch log."""
+                      use_multiprocessing=False, verbose=1, max_queue_size=10):
+        """Epoch loop of unet/unet.py:370-377: mean of per-batch metrics as the epoch log.  `workers` loader
+        threads fill a bounded queue with ready batches (labels already reduced to uint8 class ids) while
+        the GPU runs the previous step -- Keras' OrderedEnqueuer with use_multiprocessing=False."""
+        from ..prefetch import prefetched
+        nc = self._o.num_classes
+
+        def prep(item):
+            X, y = item
+            return np.asarray(X, np.float32), _to_labels(y[0] if isinstance(y, (list, tuple)) else y, nc)
+
         history = []
         for e in range(epochs):
-            tm = np.mean([self.train_on_batch(*generator[i]) for i in range(len(generator))], axis=0)
+            tm = np.mean([[float(v) for v in self._o._engine(len(X), grow=True).train_step(X, lab)]
+                          for X, lab in prefetched(generator, workers, max_queue_size, prep)], axis=0)
             logs = dict(zip(self.metrics_names, tm))
             if validation_data is not None and len(validation_data):
-                vm = np.mean([self.test_on_batch(*validation_data[i]) for i in range(len(validation_data))], axis=0)
+                vm = np.mean([[float(v) for v in self._o._engine(len(X), grow=True).test_step(X, lab)]
+                              for X, lab in prefetched(validation_data, workers, max_queue_size, prep)], axis=0)
                 logs.update({"val_" + k: v for k, v in zip(self.metrics_names, vm)})
             if verbose:
                 print("Epoch %d/%d  " % (e + 1, epochs) + "  ".join("%s: %.4f" % kv for kv in logs.items()))
@@ -165,14 +178,18 @@ class _UnetModel:
         return self._o._get_weights()
 
     def load_weights(self, path):
-        w, _ = load_npz(path)
-        self._o._set_weights(w)
+        """Keras HDF5 (save_weights or full-model files, e.g. the published models/unet/*.h5) or a round-1
+        .npz; tensor shapes are validated against this model's input_shape / num_classes."""
+        o = self._o
+        exp = dict(unet_param_shapes(o.input_shape[-1], o.num_classes))
+        self._o._set_weights(_load_weight_file(path, "unet", expected_shapes=exp))
 
     def save_weights(self, path):
-        save_npz(path, self._o._get_weights(), {"input_shape": np.asarray(self._o.input_shape),
-                                               "num_classes": self._o.num_classes})
+        _save_weight_file(path, self._o._get_weights(), "unet")
 
-    save = save_weights   # the reference's full-model .h5 carries the same tensors
+    def save(self, path):
+        """model.save(.h5) (unet/unet.py:379,389): the weight tree under /model_weights."""
+        _save_weight_file(path, self._o._get_weights(), "unet", full_model=True)
 
 
 class _BestCheckpoint:
@@ -222,17 +239,25 @@ class AtomUnet:
         else:
             self.filepath = "./saved_models/unet_%d_channel_weights.best.hdf5" % self.input_shape[-1]
 
-    # ---- engine management: Keras models take any batch size; the engine is sized on first use
-    def _engine(self, batch):
+    # ---- engine management: Keras models take any batch size; the engine is sized on first use.  Inference
+    # never re-creates it (the engine streams larger inputs in chunks of max_batch); a TRAINING batch larger
+    # than max_batch does, and then weights, BN moving statistics AND the Adam state (moments, step count)
+    # move to the new engine -- keras.optimizers.Adam keeps its state for the life of the model.
+    def _engine(self, batch, grow=False):
         batch = max(int(batch), 1)
-        if self._eng is None or batch > self._eng.max_batch:
-            carry = self._get_weights()
-            mb = max(batch, self._max_batch or 0)
-            if self._eng is not None:
-                self._eng.close()
+        if self._eng is None:
+            carry = dict(self._host_weights)
             self._eng = UnetEngine(in_channels=self.input_shape[-1], num_classes=self.num_classes,
-                                   d=self.input_shape[0], max_batch=mb, lr=self.lr, pool_ties=self.pool_ties)
+                                   d=self.input_shape[0], max_batch=max(batch, self._max_batch or 0), lr=self.lr,
+                                   pool_ties=self.pool_ties)
             self._eng.set_weights(carry)
+        elif grow and batch > self._eng.max_batch:
+            carry, opt = self._eng.get_weights(), self._eng.get_optimizer_state()
+            self._eng.close()
+            self._eng = UnetEngine(in_channels=self.input_shape[-1], num_classes=self.num_classes,
+                                   d=self.input_shape[0], max_batch=batch, lr=self.lr, pool_ties=self.pool_ties)
+            self._eng.set_weights(carry)
+            self._eng.set_optimizer_state(*opt)
         return self._eng
 
     def _get_weights(self):

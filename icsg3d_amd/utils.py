@@ -13,6 +13,8 @@ tests/golden/data_split_golden.json holds id lists produced by the reference fun
 import os
 import random
 
+import numpy as np
+
 
 def _rotated_names(base_name, n_rot):
     stem = base_name.strip(".npy")          # character strip, as the reference does
@@ -38,3 +40,28 @@ def data_split(path, n=None, frac=0.80, n_rot=10, shuffle=True, seed=28):
     training_ids, validation_ids = split
     assert not set(training_ids) & set(validation_ids)
     return training_ids, validation_ids
+
+
+def to_lattice_params_from_minmax(coord_minmax, eps_frac=0.25, d=32):
+    """to_lattice_params (/root/reference/utils.py:160-178) given only what it reads of the coordinate
+    channels: per sample and channel the {min, max} over the grid, as returned by the fused inference tail
+    (ics_vae_decode_to_unet_labels).  coord_minmax: (B, 3, 2) -> lattice params (B, 3)."""
+    mm = np.asarray(coord_minmax, dtype=np.float64)
+    lp = mm[:, :, 1] - mm[:, :, 0]
+    lp = lp / (1 + 2 * eps_frac)
+    lp = lp / (1 - 1.0 / d)
+    lp -= lp / d
+    return lp
+
+
+def to_lattice_params(p, eps_frac=0.25, d=32):
+    """Same from the coordinate grids themselves, (B, d, d, d, 3) (utils.py:160-178)."""
+    p = np.asarray(p)
+    mm = np.stack([p[..., :3].min(axis=(1, 2, 3)), p[..., :3].max(axis=(1, 2, 3))], axis=-1)
+    return to_lattice_params_from_minmax(mm, eps_frac, d)
+
+
+def to_voxel_params(lp, eps=0.25, d=32):
+    """Voxel edge lengths from lattice params (utils.py:181-190)."""
+    lp = np.asarray(lp, dtype=np.float64)
+    return (lp + 2 * lp * eps) / d

@@ -15,7 +15,8 @@ import time
 
 import numpy as np
 
-from ..checkpoint import load_npz, save_npz
+from ..checkpoint import load_weights as _load_weight_file
+from ..checkpoint import save_weights as _save_weight_file
 from ..engine import UnetEngine, VaeEngine
 from ..synthetic import glorot_params, unet_param_shapes, vae_param_shapes
 from ..unet.unet import custom_objects
@@ -51,7 +52,7 @@ class _Encoder:
         M = np.asarray(M)
         if eps is None:
             eps = np.random.normal(size=(len(M), self._o.latent_dim))
-        return self._o._engine(len(M)).encode(M, cond, eps)     # (z_mean, z_log_var, z)
+        return self._o._engine(min(len(M), batch_size or 32)).encode(M, cond, eps)     # (z_mean, z_log_var, z)
 
 
 class _Decoder:
@@ -60,7 +61,7 @@ class _Decoder:
 
     def predict(self, inputs, batch_size=None):
         z, cond = inputs
-        return self._o._engine(len(z)).decode(z, cond)
+        return self._o._engine(min(len(z), batch_size or 32)).decode(z, cond)
 
 
 class _VaeModel:
@@ -79,20 +80,22 @@ class _VaeModel:
 
     def train_on_batch(self, inputs, target=None, eps=None):
         M, cond = inputs
-        return [float(v) for v in self._o._engine(len(M)).train_step(M, cond, self._eps(len(M), eps))]
+        return [float(v) for v in self._o._engine(len(M), grow=True).train_step(M, cond, self._eps(len(M), eps))]
 
     def test_on_batch(self, inputs, target=None, eps=None):
         M, cond = inputs
-        return [float(v) for v in self._o._engine(len(M)).test_step(M, cond, self._eps(len(M), eps))]
+        return [float(v) for v in self._o._engine(len(M), grow=True).test_step(M, cond, self._eps(len(M), eps))]
 
     def load_weights(self, path):
-        w, _ = load_npz(path)
-        self._o._set_weights(w)
+        o = self._o
+        exp = dict(vae_param_shapes(o.channels, o.cond_shape, tuple(o.filters), o.latent_dim, o.input_shape[0]))
+        o._set_weights(_load_weight_file(path, "vae", expected_shapes=exp))
 
     def save_weights(self, path):
-        save_npz(path, self._o._get_weights(), {"input_shape": np.asarray(self._o.input_shape)})
+        _save_weight_file(path, self._o._get_weights(), "vae")
 
-    save = save_weights
+    def save(self, path):
+        _save_weight_file(path, self._o._get_weights(), "vae", full_model=True)
 
 
 class LatticeDFCVAE:
@@ -130,29 +133,36 @@ class LatticeDFCVAE:
             self._pm_weights = perceptual_model
         elif hasattr(perceptual_model, "_get_weights"):
             self._pm_weights = perceptual_model._get_weights()
-        else:
-            self._pm_weights, _ = load_npz(perceptual_model)
+        else:   # load_model(perceptual_model, custom_objects): the U-Net's .h5 (Keras HDF5, or a round-1 .npz)
+            self._pm_weights = _load_weight_file(perceptual_model, "unet")
         self._eng = self._pm_eng = None
         self._host_weights = None
         self.encoder = self.decoder = self.model = None
 
-    # ---- engine management
-    def _engine(self, batch):
+    # ---- engine management: sized on first use; inference streams in chunks of max_batch and never re-creates
+    # the engines; a larger TRAINING batch does, carrying weights, BN statistics and the Adam state across.
+    def _build(self, mb):
+        d, C = self.input_shape[0], self.channels
+        self._pm_eng = UnetEngine(in_channels=C, d=d, max_batch=mb, pool_ties=self.pool_ties,
+                                  num_classes=int(self._pm_weights["soft/bias"].shape[0]))
+        self._pm_eng.set_weights(self._pm_weights)
+        self._eng = VaeEngine(self._pm_eng, in_channels=C, cond_shape=self.cond_shape,
+                              latent_dim=self.latent_dim, filters=self.filters, d=d, max_batch=mb,
+                              lr=self.lr, alpha=self.alpha, beta=self.beta,
+                              pm_layer_weights=self.pm_layer_weights)
+
+    def _engine(self, batch, grow=False):
         batch = max(int(batch), 1)
-        if self._eng is None or batch > self._eng.max_batch:
-            carry = self._get_weights()
-            mb = max(batch, self.batch_size or 0)
-            if self._eng is not None:
-                self._eng.close(); self._pm_eng.close()
-            d, C = self.input_shape[0], self.channels
-            self._pm_eng = UnetEngine(in_channels=C, d=d, max_batch=mb, pool_ties=self.pool_ties,
-                                      num_classes=int(self._pm_weights["soft/bias"].shape[0]))
-            self._pm_eng.set_weights(self._pm_weights)
-            self._eng = VaeEngine(self._pm_eng, in_channels=C, cond_shape=self.cond_shape,
-                                  latent_dim=self.latent_dim, filters=self.filters, d=d, max_batch=mb,
-                                  lr=self.lr, alpha=self.alpha, beta=self.beta,
-                                  pm_layer_weights=self.pm_layer_weights)
+        if self._eng is None:
+            carry = dict(self._host_weights)
+            self._build(max(batch, self.batch_size or 0))
             self._eng.set_weights(carry)
+        elif grow and batch > self._eng.max_batch:
+            carry, opt = self._eng.get_weights(), self._eng.get_optimizer_state()
+            self._eng.close(); self._pm_eng.close()
+            self._build(batch)
+            self._eng.set_weights(carry)
+            self._eng.set_optimizer_state(*opt)
         return self._eng
 
     def _get_weights(self):
@@ -193,8 +203,9 @@ class LatticeDFCVAE:
         for e in range(self.num_epochs):
             print("Epoch %s:" % e)
             t0 = time.time()
-            tm = np.mean([self.model.train_on_batch(list(train_gen[i]), train_gen[i][0]) for i in range(train_steps)], axis=0)
-            vm = np.mean([self.model.test_on_batch(list(val_gen[i]), val_gen[i][0]) for i in range(val_steps)], axis=0) \
+            # each batch is read from disk ONCE (the target is the input) and one batch ahead of the GPU step
+            tm = np.mean([self.model.train_on_batch([M, cond], M) for M, cond in self._batches(train_gen, train_steps)], axis=0)
+            vm = np.mean([self.model.test_on_batch([M, cond], M) for M, cond in self._batches(val_gen, val_steps)], axis=0) \
                 if val_steps else tm
             s = "Time: %.3f s   " % (time.time() - t0)
             s += "".join("Train %s: %.3f    " % (n, v) for n, v in zip(self.metric_names, tm))
@@ -209,6 +220,26 @@ class LatticeDFCVAE:
             self.model.load_weights(self.filepath)
         self.model.save(os.path.splitext(self.filepath)[0] + ".h5")
         print("Model saved")
+
+    @staticmethod
+    def _batches(gen, steps):
+        from ..prefetch import prefetched
+
+        class _First:
+            def __len__(self):
+                return steps
+
+            def __getitem__(self, i):
+                return gen[i]
+        return prefetched(_First(), workers=1, max_queue_size=2, prepare=lambda it: (it[0], it[1]))
+
+    def decode_segment(self, z, cond, unet, thresh=0.8):
+        """generate.py:204-225 as ONE device-resident chain: decoder.predict -> unet.model.predict -> argmax /
+        (sig >= thresh).  `unet` is an AtomUnet.  Returns dict(species, mask uint8 (B,d,d,d); density float32
+        (B,d,d,d); coord_minmax (B,3,2)) -- see icsg3d_amd.utils.to_lattice_params_from_minmax."""
+        z = np.asarray(z)
+        eng = self._engine(min(len(z), self.batch_size or 32))
+        return eng.decode_to_labels(unet._engine(min(len(z), eng.max_batch)), z, cond, thresh)
 
     def save_(self, weights, model="saved_models/vae.h5"):
         self.model.load_weights(weights)

@@ -106,6 +106,17 @@ int ics_vae_test_step(ics_net* net, const float* x, const float* cond, const flo
 int ics_vae_upload_batch(ics_net* net, const float* x, const float* cond, const float* eps, int batch);
 int ics_vae_train_step_resident(ics_net* net, float metrics_or_null[4]);
 
+/* Fused inference tail (generate.py:204-225, eval.py:163-175): decoder.predict([z, cond]) ->
+ * unet.model.predict -> np.argmax(soft, -1) / (sig >= thresh), device-resident end to end (the
+ * reconstruction is never copied to the host).  `unet` is any U-Net engine with the VAE's grid and
+ * channel count.  Outputs, each optional (NULL to skip): species/mask uint8 (B,d,d,d); density = channel 0
+ * of the reconstruction, float (B,d,d,d) (watershed input, generate.py:232); coord_minmax float (B,3,2) =
+ * per-sample {min,max} of channels 1..3 -- all that to_lattice_params (utils.py:160-178) reads of the
+ * coordinate channels (zeros when in_channels == 1). */
+int ics_vae_decode_to_unet_labels(ics_net* vae, ics_net* unet, const float* z, const float* cond, int batch,
+                                  float thresh, uint8_t* species, uint8_t* mask, float* density,
+                                  float* coord_minmax);
+
 /* ---------------------------------------------------------------- common to both engines */
 int ics_net_destroy(ics_net* net);
 int ics_net_sync(ics_net* net);
@@ -129,6 +140,12 @@ int ics_net_get_bn_affine(ics_net* net, const char* layer, float* scale, float* 
 int ics_net_set_lr(ics_net* net, float lr);
 /* optimizer step counter (Adam t) and reset of its moments */
 int ics_net_reset_optimizer(ics_net* net);
+/* Adam moments over the flat parameter buffer (same order as the trainable tensors) + step count: lets the
+ * host keep the optimizer state of keras.optimizers.Adam (unet/unet.py:245) when it re-creates an engine
+ * for a larger batch.  count = ics_net_num_params. */
+int ics_net_num_params(ics_net* net, size_t* count);
+int ics_net_get_optimizer_state(ics_net* net, float* m, float* v, size_t count, int* step);
+int ics_net_set_optimizer_state(ics_net* net, const float* m, const float* v, size_t count, int step);
 
 /* Per-kernel timing with HIP events on the engine's stream (bench.py roofline): enable, run steps,
  * then read back rows {label, launches, total_ms, total_flop, total_bytes}. */
@@ -138,11 +155,23 @@ int ics_net_profile_row(ics_net* net, int row, const char** label, int64_t* laun
                         double* total_flop, double* total_bytes);
 
 /* ---------------------------------------------------------------- data parallel (new)
- * One process per GPU; gradients are summed with one RCCL all-reduce on the flat fp32 gradient
- * buffer and scaled by 1/nranks before Adam.  uid is an ncclUniqueId (128 bytes) from rank 0. */
+ * One process per GPU; the flat fp32 gradient buffer is summed over the ranks in ~4 buckets (last layer
+ * first) on a second HIP stream while the backward pass continues, and scaled by 1/nranks inside Adam.
+ * Loss / metric numerators and denominators are all-reduced when a step returns metrics (every rank must
+ * ask on the same steps).  uid is an ncclUniqueId (128 bytes) from rank 0. */
 int ics_comm_unique_id(char uid[128]);
 int ics_net_comm_init(ics_net* net, int rank, int nranks, const char uid[128]);
 int ics_net_comm_allreduce_max(ics_net* net, double* value); /* barrier + max over ranks */
+/* rank `root`'s parameters, BN moving statistics, Adam moments and step count overwrite everyone's:
+ * replicas start identical (the class API initialises from an unseeded RNG).  No-op without a communicator. */
+int ics_net_comm_broadcast_state(ics_net* net, int root);
+/* 1: BatchNorm batch statistics (forward) and their gradient sums (backward) are exchanged over the
+ * communicator, so N replicas x B grids normalise exactly like one process at N*B (the reference is
+ * single-process: vae/lattice_vae.py:296, unet/unet.py:370).  0 (default): per-replica statistics; the
+ * moving statistics are then averaged over the ranks after every step. */
+int ics_net_set_sync_bn(ics_net* net, int on);
+/* nranks = 0 without a communicator; buckets_last_step = gradient all-reduce messages of the last step */
+int ics_net_comm_info(ics_net* net, int* rank, int* nranks, int* buckets_last_step);
 
 /* ---------------------------------------------------------------- single-op entry points
  * (kernel parity tests against oracle/; host buffers, NDHWC) */

@@ -109,11 +109,16 @@ def act_bwd(x, dy, kind):
 #   moving update: moving = moving*0.99 + batch*0.01, the variance fed to it rescaled
 #          var * n/(n-(1+eps))   (Keras 2.3.x quirk, confidence M -> switch bn_unbias)
 # --------------------------------------------------------------------------------------
-def bn_train_fwd(x, gamma, beta, eps=BN_EPS):
+def bn_train_fwd(x, gamma, beta, eps=BN_EPS, moments=None):
+    """moments: optional callable x -> (mean, biased var) of the GLOBAL batch (SyncBN under data parallelism:
+    icsg3d_amd.dataparallel.syncbn_moments); default = this process's batch, like the single-process reference."""
     C = x.shape[-1]
     xf = x.reshape(-1, C)
-    mean = xf.mean(0)
-    var = ((xf - mean) ** 2).mean(0)
+    if moments is not None:
+        mean, var = moments(x)
+    else:
+        mean = xf.mean(0)
+        var = ((xf - mean) ** 2).mean(0)
     rstd = 1.0 / np.sqrt(var + eps)
     y = x * (gamma * rstd) + (beta - mean * gamma * rstd)
     return y, mean, var
@@ -124,8 +129,10 @@ def bn_eval_fwd(x, gamma, beta, mmean, mvar, eps=BN_EPS):
     return x * inv + (beta - mmean * inv)
 
 
-def bn_train_bwd(x, gamma, mean, var, dy, eps=BN_EPS):
-    """Returns (dx, dgamma, dbeta) for training-mode BN (gradient flows through batch stats)."""
+def bn_train_bwd(x, gamma, mean, var, dy, eps=BN_EPS, allsum=None):
+    """Returns (dx, dgamma, dbeta) for training-mode BN (gradient flows through batch stats).
+    allsum: optional callable (vector, count) -> (sum over ranks, total count) -- SyncBN: dx uses the sums over the
+    GLOBAL batch, dgamma / dbeta stay this rank's sums (the gradient all-reduce adds the ranks later)."""
     C = x.shape[-1]
     rstd = 1.0 / np.sqrt(var + eps)
     xhat = (x - mean) * rstd
@@ -134,7 +141,11 @@ def bn_train_bwd(x, gamma, mean, var, dy, eps=BN_EPS):
     dbeta = dyf.sum(0)
     dgamma = (dyf * xh).sum(0)
     n = dyf.shape[0]
-    dx = (gamma * rstd) * (dy - dbeta / n - xhat * (dgamma / n))
+    s1, s2 = dbeta, dgamma
+    if allsum is not None:
+        both, n = allsum(np.concatenate([dbeta, dgamma]), n)
+        s1, s2 = both[:C], both[C:]
+    dx = (gamma * rstd) * (dy - s1 / n - xhat * (s2 / n))
     return dx, dgamma, dbeta
 
 
@@ -367,7 +378,7 @@ class Block:
         c = {"x": x, "s": s}
         if self.has_bn:
             if training:
-                bn, mean, var = bn_train_fwd(s, P[n + "/gamma"], P[n + "/beta"])
+                bn, mean, var = bn_train_fwd(s, P[n + "/gamma"], P[n + "/beta"], moments=cache.get("_sync_moments"))
                 c["mean"], c["var"] = mean, var
             else:
                 bn = bn_eval_fwd(s, P[n + "/gamma"], P[n + "/beta"],
@@ -388,7 +399,8 @@ class Block:
         if self.has_bn:
             dbn = act_bwd(c.get("kink_bn", c["bn"]), do, self.post_act)
             if c["training"]:
-                ds, dg, dbt = bn_train_bwd(c["s"], P[n + "/gamma"], c["mean"], c["var"], dbn)
+                ds, dg, dbt = bn_train_bwd(c["s"], P[n + "/gamma"], c["mean"], c["var"], dbn,
+                                           allsum=cache.get("_sync_allsum"))
             else:
                 ds = bn_eval_bwd(P[n + "/gamma"], S[n + "/moving_var"], dbn)
                 xh = (c["s"] - S[n + "/moving_mean"]) / np.sqrt(S[n + "/moving_var"] + BN_EPS)

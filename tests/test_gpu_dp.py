@@ -1,0 +1,113 @@
+"""Data-parallel path on the one GPU this box has: a single-rank RCCL communicator drives everything a multi-rank
+run executes (ncclCommInitRank, state broadcast, BN moving-statistics average, gradient buckets on the comm stream
+behind events, metric-sum all-reduce, SyncBN all-gather / all-reduce) -- with one rank every collective is the
+identity, so results must equal the engine without a communicator BIT FOR BIT.  Multi-rank arithmetic is covered on
+CPU by tests/test_dataparallel_gloo.py; the driver runs the 2/4/8-GPU bench."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _unet_pair(B=2, d=16):
+    from icsg3d_amd.engine import UnetEngine, comm_unique_id
+    from icsg3d_amd.synthetic import glorot_params, synthetic_batch, unet_param_shapes
+    P = glorot_params(unet_param_shapes(1, 95), 1)
+    X, lab, cond = synthetic_batch(B, d, 1, seed=0, noise=1e-3)
+    a = UnetEngine(in_channels=1, d=d, max_batch=B, lr=1e-3); a.set_weights(P)
+    b = UnetEngine(in_channels=1, d=d, max_batch=B, lr=1e-3); b.set_weights(P)
+    b.comm_init(0, 1, comm_unique_id())
+    b.broadcast_state(0)
+    return a, b, X, lab, cond
+
+
+@pytest.mark.parametrize("sync_bn", [False, True])
+def test_single_rank_communicator_is_bit_identical(sync_bn):
+    a, b, X, lab, _ = _unet_pair()
+    b.set_sync_bn(sync_bn)
+    assert b.comm_info()["nranks"] == 1 and a.comm_info()["nranks"] == 0
+    b.profile_enable(True)
+    steps = 3
+    ma = [a.train_step(X, lab) for _ in range(steps)]
+    mb = [b.train_step(X, lab) for _ in range(steps)]
+    for x, y in zip(ma, mb):
+        if sync_bn:      # statistics merged through the fp64 rank-merge: same values to fp32 rounding
+            np.testing.assert_allclose(x, y, rtol=2e-6)
+        else:
+            assert np.array_equal(x, y)
+    wa, wb = a.get_weights(), b.get_weights()
+    for k in wa:
+        if sync_bn:
+            assert np.abs(wa[k] - wb[k]).max() <= 1e-5 * max(np.abs(wa[k]).max(), 1e-12), k
+        else:
+            assert np.array_equal(wa[k], wb[k]), k
+    info = b.comm_info()
+    assert info["buckets_last_step"] >= 3, info            # head..c14 | c13 | c10+c9 | rest
+    rows = {r["label"]: r for r in b.profile_rows()}
+    assert rows["rccl_allreduce_grads"]["launches"] == steps * info["buckets_last_step"]
+    assert abs(rows["rccl_allreduce_grads"]["bytes"] - steps * 4.0 * b.num_params()) < 1.0
+    if not sync_bn:
+        assert rows["rccl_allreduce_bn_moving"]["launches"] == steps
+    # optimizer state travels through the ABI (engine re-creation keeps Adam's moments and step count)
+    m, v, t = b.get_optimizer_state()
+    assert t == steps and np.abs(m).max() > 0 and v.min() >= 0
+    ma2, va2, ta2 = a.get_optimizer_state()
+    if not sync_bn:
+        assert ta2 == t and np.array_equal(m, ma2) and np.array_equal(v, va2)
+
+
+def test_vae_single_rank_communicator_is_bit_identical():
+    from icsg3d_amd.engine import UnetEngine, VaeEngine, comm_unique_id
+    from icsg3d_amd.synthetic import glorot_params, synthetic_batch, unet_param_shapes, vae_param_shapes
+    B, d = 2, 16
+    PU = glorot_params(unet_param_shapes(1, 95), 1)
+    PV = glorot_params(vae_param_shapes(1, d=d), 3)
+    X, _, cond = synthetic_batch(B, d, 1, seed=0, noise=1e-3)
+    eps = np.random.default_rng(2).standard_normal((B, 256)).astype(np.float32)
+    out = []
+    for with_comm in (False, True):
+        pm = UnetEngine(in_channels=1, d=d, max_batch=B); pm.set_weights(PU)
+        ve = VaeEngine(pm, in_channels=1, d=d, max_batch=B); ve.set_weights(PV)
+        if with_comm:
+            ve.comm_init(0, 1, comm_unique_id()); ve.broadcast_state(0)
+        ms = [ve.train_step(X, cond, eps) for _ in range(2)]
+        out.append((ms, ve.get_weights(), ve.comm_info()))
+    (m0, w0, _), (m1, w1, info) = out
+    assert all(np.array_equal(x, y) for x, y in zip(m0, m1))
+    assert all(np.array_equal(w0[k], w1[k]) for k in w0)
+    assert info["buckets_last_step"] >= 1
+
+
+def test_broadcast_state_overwrites_replica_state():
+    a, b, X, lab, _ = _unet_pair()
+    for _ in range(2):
+        b.train_step(X, lab)
+    w, (m, v, t) = b.get_weights(), b.get_optimizer_state()
+    b.broadcast_state(0)                                    # root = self: a no-op on the values
+    w2, (m2, v2, t2) = b.get_weights(), b.get_optimizer_state()
+    assert t2 == t == 2 and np.array_equal(m, m2) and np.array_equal(v, v2)
+    assert all(np.array_equal(w[k], w2[k]) for k in w)
+
+
+@pytest.mark.timeout(900)
+def test_bench_through_torchrun_single_rank():
+    """bench.py under `python -m torch.distributed.run --nproc-per-node 1` with ICSG3D_BENCH_FORCE_DIST=1: gloo
+    rendezvous, ncclUniqueId hand-off, communicator, broadcast, buckets -- the launch line the driver uses for N > 1.
+    The launcher starts before anything touches the GPU."""
+    env = dict(os.environ, ICSG3D_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3",
+           "--warmup", "1", "--batch", "4", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=850)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 1 and r["value"] > 0 and "RCCL buckets" in r["config"]["grad_allreduce"]
+    assert r["secondary"]["value"] > 0 and r["roofline"]["frac"] > 0
