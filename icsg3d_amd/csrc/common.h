@@ -65,11 +65,25 @@ struct ConvSrc {
   int bcast;            // >0: broadcast mode, value = p[b*bcast + (c % bcast)]
 };
 
+// A/B switches that route a layer through the general kernels instead of a fast path (tests/test_gpu_switches.py,
+// benchmarking).  They are read from the environment ONCE PER HANDLE at creation (conv_flags_from_env) and travel
+// with the geometry -- no process-global state decides which kernel a launch takes.
+enum ConvFlags : int {
+  CF_NO_REUSE = 1,        // ICSG3D_NO_REUSE: no dx-reuse forward / backward-data pipeline
+  CF_NO_WGRAD3 = 2,       // ICSG3D_NO_WGRAD3: no dx-reuse backward-weight kernels
+  CF_NO_WGRAD3S = 4,      // ICSG3D_NO_WGRAD3S: no wave-uniform-loader variant of it
+  CF_NO_FWD_SPLITK = 8,   // ICSG3D_NO_FWD_SPLITK
+  CF_NO_THIN_N = 16,      // ICSG3D_NO_THIN_N: Cout <= 4 layers through the MFMA kernels
+  CF_NO_UPSPLIT = 32,     // ICSG3D_NO_UPSPLIT: direct 27-tap evaluation of upsampled inputs
+};
+int conv_flags_from_env();
+
 struct ConvGeom {
   int B, S, lgS;        // batch, cubic spatial extent (power of two) and its log2
   int Cin, Cout;        // logical channel counts of this GEMM (Cin = sum of source C)
   int taps;             // 27 (3x3x3 same) or 1 (1x1x1)
   int Kpad, Npad;       // padded GEMM K (= taps*Cin rounded up to 32) and N (Cout rounded up to 32)
+  int flags = 0;        // ConvFlags of the owning handle
 };
 
 // ---------------------------------------------------------------- kernel launchers (conv_igemm.hip)

@@ -35,6 +35,28 @@ static thread_local const char* g_last_kernel_id = "";
 const char* conv_last_kernel_id() { return g_last_kernel_id; }
 static const char* tf(bool b) { return b ? "true" : "false"; }
 
+int conv_flags_from_env() {
+  int f = 0;
+  if (getenv("ICSG3D_NO_REUSE")) f |= CF_NO_REUSE;
+  if (getenv("ICSG3D_NO_WGRAD3")) f |= CF_NO_WGRAD3;
+  if (getenv("ICSG3D_NO_WGRAD3S")) f |= CF_NO_WGRAD3S;
+  if (getenv("ICSG3D_NO_FWD_SPLITK")) f |= CF_NO_FWD_SPLITK;
+  if (getenv("ICSG3D_NO_THIN_N")) f |= CF_NO_THIN_N;
+  if (getenv("ICSG3D_NO_UPSPLIT")) f |= CF_NO_UPSPLIT;
+  return f;
+}
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remember per (kernel instantiation, device)
+struct DevOnce {
+  bool done[64] = {false};
+  bool need(int* dev) {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) { *dev = -1; return true; }
+    *dev = d;
+    return !done[d];
+  }
+  void mark(int dev) { if (dev >= 0) done[dev] = true; }
+};
+
 // Sources without a BatchNorm affine get pointers to constant ones/zeros so that the tile loaders
 // never branch on "has affine" (fma(v,1,0) == v exactly).
 static int identity_affine(const float** ones, const float** zeros) {
@@ -742,12 +764,13 @@ static int launch_fwd_cfg(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, 
   const int arows = REUSE ? BM + (BM >> g.lgS) + 1 : BM;
   const size_t lds = (size_t)(arows * kLDA + 2 * 32 * BN) * sizeof(float);
   auto kern = conv_fwd_kernel<WM, WN, TM, TN, VEC, ABL, AFF, UP, THIN, REUSE, PAR, NOACT>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DevOnce attr;
+  int dev;
+  if (attr.need(&dev)) {
     const size_t lds_max = (size_t)((REUSE ? BM + BM / 4 + 1 : BM) * kLDA + 2 * 32 * BN) * sizeof(float);
     ICS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
-    attr_set = true;
+    attr.mark(dev);
   }
   if (rows_per_block) *rows_per_block = BM;
   static const std::string id = std::string("conv_fwd_kernel<") + std::to_string(WM) + ", " + std::to_string(WN) + ", " +
@@ -800,8 +823,7 @@ int conv_fwd_rows_per_block(const ConvGeom& g) {
 // one thread per output voxel (forward) / one thread per weight row (backward-weight).
 // =====================================================================================
 static bool thin_n_ok(const ConvGeom& g, const ConvSrc& s0, int nsrc) {
-  static const bool off = getenv("ICSG3D_NO_THIN_N") != nullptr;
-  return !off && nsrc == 1 && g.taps == 27 && g.Cout <= 4 && g.Cin % 4 == 0 && g.Cin >= 4 && g.Cin <= 64 &&
+  return !(g.flags & CF_NO_THIN_N) && nsrc == 1 && g.taps == 27 && g.Cout <= 4 && g.Cin % 4 == 0 && g.Cin >= 4 && g.Cin <= 64 &&
          s0.C == g.Cin && !s0.up && !s0.bcast && g.S >= 2;
 }
 
@@ -1001,8 +1023,7 @@ static int thin_n_wgrad_splits(const ConvGeom& g) {
 // tile, each sums a slice of K into ws[split][M][Npad]; splitk_finish_kernel adds the slices in fixed order
 // and runs the epilogue (bias, activation, store, BatchNorm partial statistics of 64-row blocks).
 static int fwd_splitk_plan(const ConvGeom& g, const ConvSrc& s0, const ConvSrc& s1, int nsrc) {
-  static const bool off = getenv("ICSG3D_NO_FWD_SPLITK") != nullptr;
-  if (off || !fwd_is_vec(g, s0, s1) || conv_is_thin(g, s0, nsrc) || thin_n_ok(g, s0, nsrc)) return 1;
+  if ((g.flags & CF_NO_FWD_SPLITK) || !fwd_is_vec(g, s0, s1) || conv_is_thin(g, s0, nsrc) || thin_n_ok(g, s0, nsrc)) return 1;
   int bm, bn;
   pick_fwd_tile(g, &bm, &bn);
   if (bm != 64) return 1;
@@ -1118,7 +1139,7 @@ static int launch_conv_fwd_inner(hipStream_t st, const ConvGeom& g, const ConvSr
   // the tile loaders address a source with 32-bit byte offsets
   ICS_CHECK(((size_t)g.B << (3 * g.lgS)) * (size_t)std::max(s0.C, s1.C) * 4 <= 0xffffffffull,
             "conv source larger than 4 GiB");
-  static const bool no_reuse = getenv("ICSG3D_NO_REUSE") != nullptr;   // A/B switch for benchmarking
+  const bool no_reuse = (g.flags & CF_NO_REUSE) != 0;   // A/B switch (tests, benchmarking)
   int bm, bn;
   pick_fwd_tile(g, &bm, &bn);
 #define ICS_FWD_ARGS st, g, s0, s1, wp, bias, out, ldo, pre_act, stat_partial, rows_per_block, accumulate, ksplit
@@ -1169,7 +1190,7 @@ int launch_conv_fwd_par(hipStream_t st, const ConvGeom& g, const ConvSrc& src, c
   int rpb = 0;
 #define ICS_PAR_ARGS st, g, s0, s1, wp, bias, out, ldo, pre_act, stat_partial, &rpb
   int rc;
-  static const bool no_reuse = getenv("ICSG3D_NO_REUSE") != nullptr;
+  const bool no_reuse = (g.flags & CF_NO_REUSE) != 0;
   const bool reuse = !no_reuse && g.S >= 4 && g.S <= bm;   // dx-reuse: the two ex taps share a staged A tile
   const bool noact = src.scale != nullptr && src.act == ACT_NONE;   // affine-only loader (see NOACT)
 #define ICS_PAR(WM, WN, TM, TN)                                                                              \
@@ -2007,8 +2028,7 @@ __global__ __launch_bounds__(256, LGC == 6 ? 2 : 3) void conv_wgrad3s_kernel(Con
 // can the dx-reuse kernel run this geometry?  (27 taps, whole x-lines per 32-voxel chunk, 64-aligned
 // channel groups inside one source, full 128-wide vectorisable dy rows)
 static bool wgrad3_ok(const ConvGeom& g, const ConvSrc& s0, int nsrc, const ConvSrc& s1) {
-  static const bool off = getenv("ICSG3D_NO_WGRAD3") != nullptr;
-  if (off || g.taps != 27 || g.S > 64 || g.S < 2 || g.Cin % 64 != 0 || g.Cout % 128 != 0) return false;
+  if ((g.flags & CF_NO_WGRAD3) || g.taps != 27 || g.S > 64 || g.S < 2 || g.Cin % 64 != 0 || g.Cout % 128 != 0) return false;
   if (s0.bcast || (nsrc > 1 && s1.bcast)) return false;
   if (nsrc > 1 && (s0.C % 64 != 0)) return false;
   return true;
@@ -2045,11 +2065,12 @@ static int launch_wgrad_cfg(hipStream_t st, const ConvGeom& g, const ConvSrc& s0
   constexpr int KT = WM * TM * 32, NT = WN * TN * 32;
   const size_t lds = (size_t)2 * 32 * (KT + NT) * sizeof(float);
   auto kern = conv_wgrad_kernel<WM, WN, TM, TN, VEC, DYVEC, AFF, UP, THIN, ABL>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DevOnce attr;
+  int dev;
+  if (attr.need(&dev)) {
     ICS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+    attr.mark(dev);
   }
   static const std::string id = std::string("conv_wgrad_kernel<") + std::to_string(WM) + ", " + std::to_string(WN) +
                                 ", " + std::to_string(TM) + ", " + std::to_string(TN) + ", " + tf(VEC) + ", " +
@@ -2135,7 +2156,7 @@ int launch_conv_wgrad(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int
     const dim3 grid(9 * q.cgroups * q.ntiles * q.ksplit);
     const int M3 = g.B << (3 * g.lgS);
     const bool fast = !up && g.lgS >= 4 && g.lgS <= 6 && M3 % 32 == 0 && n_load == g.Cout &&
-                      getenv("ICSG3D_NO_WGRAD3S") == nullptr;
+                      !(g.flags & CF_NO_WGRAD3S);
     if (phase != 2 && fast) {   // wave-uniform loaders (conv_wgrad3s_kernel)
       const bool noact = aff && (src[0].scale == nullptr || src[0].act == ACT_NONE) &&
                          (nsrc < 2 || src[1].scale == nullptr || src[1].act == ACT_NONE);

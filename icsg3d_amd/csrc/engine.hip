@@ -79,11 +79,16 @@ struct Profiler {
     pending.clear();
   }
   void reset() { resolve(); rows.clear(); index.clear(); }
+  ~Profiler() {
+    for (auto& p : pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (hipEvent_t e : pool) (void)hipEventDestroy(e);
+  }
 };
 
 struct ConvLayer {
   std::string name;
   int Cin = 0, Cout = 0, taps = 27, S = 1;
+  int flags = 0;                        // ConvFlags of the owning handle (carried into every ConvGeom)
   int CinG = 0;                         // GEMM input channels: Cin, or Cin zero-padded to 4/16/32k when the
                                         // virtual input is materialised (thin / broadcast inputs: c1, e0)
   float* pad_in = nullptr;              // [M][CinG] materialised input (padded layers only)
@@ -119,6 +124,7 @@ struct ConvLayer {
 struct Net {
   int kind = 0;   // 0 U-Net, 1 VAE
   int device = 0;
+  int flags = 0;  // ConvFlags, read from the environment when the handle is created
   hipStream_t st = nullptr;
   int maxB = 0, d = 0, C = 0;
   std::vector<void*> allocs;
@@ -230,6 +236,7 @@ static ConvLayer* add_conv(Net& n, const std::string& name, int Cin, int Cout, i
                            int has_bn, int post_act, bool dense, bool register_params = true, bool pad_input = false) {
   auto L = std::make_unique<ConvLayer>();
   L->name = name; L->Cin = Cin; L->Cout = Cout; L->taps = taps; L->S = S;
+  L->flags = n.flags;
   L->CinG = pad_input ? padded_cin(Cin) : Cin;
   L->pre_act = pre_act; L->has_bn = has_bn; L->post_act = post_act;
   L->Kpad = round_up(taps * L->CinG, 32); L->Npad = round_up(Cout, 32);
@@ -293,37 +300,37 @@ static ConvSrc src_layer(const ConvLayer& L, int up) {
 }
 
 static ConvGeom geom_fwd(const ConvLayer& L, int B) {
-  return ConvGeom{B, L.S, ilog2(L.S), L.CinG, L.Cout, L.taps, L.Kpad, L.Npad};
+  return ConvGeom{B, L.S, ilog2(L.S), L.CinG, L.Cout, L.taps, L.Kpad, L.Npad, L.flags};
 }
 static ConvGeom geom_bwd(const ConvLayer& L, int B) {
-  return ConvGeom{B, L.S, ilog2(L.S), L.Cout, L.CinG, L.taps, L.Kpad_b, L.Npad_b};
+  return ConvGeom{B, L.S, ilog2(L.S), L.Cout, L.CinG, L.taps, L.Kpad_b, L.Npad_b, L.flags};
 }
 
 // up-split GEMM geometries (see ConvLayer::split_up)
 static ConvGeom geom_up_wgrad(const ConvLayer& L, int B) {   // dw_up[Cu][27N] = xl^T x dyS over the S/2 grid
-  return ConvGeom{B, L.S / 2, ilog2(L.S / 2), L.Cu, 27 * L.Cout, 1, round_up(L.Cu, 32), L.ldS};
+  return ConvGeom{B, L.S / 2, ilog2(L.S / 2), L.Cu, 27 * L.Cout, 1, round_up(L.Cu, 32), L.ldS, L.flags};
 }
 static ConvGeom geom_up_dgrad(const ConvLayer& L, int B) {   // dxl[M/8][Cu] = dyS x W_up
-  return ConvGeom{B, L.S / 2, ilog2(L.S / 2), L.ldS, L.Cu, 1, L.ldS, round_up(L.Cu, 32)};
+  return ConvGeom{B, L.S / 2, ilog2(L.S / 2), L.ldS, L.Cu, 1, L.ldS, round_up(L.Cu, 32), L.flags};
 }
 static ConvGeom geom_skip_wgrad(const ConvLayer& L, int B) {
-  return ConvGeom{B, L.S, ilog2(L.S), L.Cs, L.Cout, L.taps, round_up(L.taps * L.Cs, 32), L.Npad};
+  return ConvGeom{B, L.S, ilog2(L.S), L.Cs, L.Cout, L.taps, round_up(L.taps * L.Cs, 32), L.Npad, L.flags};
 }
 static ConvGeom geom_skip_dgrad(const ConvLayer& L, int B) {
-  return ConvGeom{B, L.S, ilog2(L.S), L.Cout, L.Cs, L.taps, L.Kpad_b, round_up(L.Cs, 32)};
+  return ConvGeom{B, L.S, ilog2(L.S), L.Cout, L.Cs, L.taps, L.Kpad_b, round_up(L.Cs, 32), L.flags};
 }
 static ConvGeom geom_skip_fwd(const ConvLayer& L, int B) {
-  return ConvGeom{B, L.S, ilog2(L.S), L.Cs, L.Cout, L.taps, round_up(L.taps * L.Cs, 32), L.Npad};
+  return ConvGeom{B, L.S, ilog2(L.S), L.Cs, L.Cout, L.taps, round_up(L.taps * L.Cs, 32), L.Npad, L.flags};
 }
 static ConvGeom geom_par_fwd(const ConvLayer& L, int B) {    // one parity class over the S/2 grid
-  return ConvGeom{B, L.S / 2, ilog2(L.S / 2), L.Cu, L.Cout, 8, 8 * L.Cu, L.Npad};
+  return ConvGeom{B, L.S / 2, ilog2(L.S / 2), L.Cu, L.Cout, 8, 8 * L.Cu, L.Npad, L.flags};
 }
 static ConvSrc src_lowres(const ConvLayer& L) { ConvSrc u = L.src[L.nsrc - 1]; u.up = 0; return u; }
 
 // Layers whose (last) source is nearest-upsampled: [skip | up] concat convs (U-Net c13/c15/c17) and the VAE
 // decoder's d1..d3 (Cs = 0).
 static int enable_split_up(Net& n, ConvLayer& L) {
-  if (getenv("ICSG3D_NO_UPSPLIT")) return 0;
+  if (n.flags & CF_NO_UPSPLIT) return 0;
   const ConvSrc& up = L.src[L.nsrc - 1];
   const int Cs = L.nsrc == 2 ? L.src[0].C : 0;
   if (!up.up || (L.nsrc == 2 && L.src[0].up) || L.taps != 27 || L.S < 2 || L.CinG != L.Cin || Cs % 32 || up.C % 32 ||
@@ -1333,6 +1340,7 @@ int ics_device_info(char* name, int* cus, size_t* hbm) {
 }
 
 static int net_common_init(Net& n) {
+  n.flags = conv_flags_from_env();
   ICS_HIP(hipGetDevice(&n.device));
   ICS_HIP(hipStreamCreateWithFlags(&n.st, hipStreamNonBlocking));
   return 0;
@@ -1816,7 +1824,7 @@ int ics_op_conv3d_forward(const float* x, const float* w, const float* bias, int
   ICS_HIP(hipMemcpyAsync(dw, w, (size_t)taps * Cin * Cout * 4, hipMemcpyHostToDevice, n.st));
   if (bias) ICS_HIP(hipMemcpyAsync(db, bias, (size_t)Cout * 4, hipMemcpyHostToDevice, n.st));
   ICS_TRY(launch_pack_fwd(n.st, dw, taps * Cin, Cout, dwp, Kpad, Npad, 0, 0, 1));
-  ConvGeom g{B, S, ilog2(S), Cin, Cout, taps, Kpad, Npad};
+  ConvGeom g{B, S, ilog2(S), Cin, Cout, taps, Kpad, Npad, n.flags};
   ConvSrc s = src_plain(dx, Cin);
   ICS_TRY(launch_conv_fwd(n.st, g, &s, 1, dwp, bias ? db : nullptr, dyv, Cout, pre_act, nullptr, nullptr));
   ICS_HIP(hipMemcpyAsync(y, dyv, M * Cout * 4, hipMemcpyDeviceToHost, n.st));
@@ -1841,8 +1849,8 @@ int ics_op_conv3d_bench(int B, int S, int Cin, int Cout, int taps, int mode, int
   ICS_TRY(fill(n, dyv, M * Cout, 0.23f));
   ICS_TRY(launch_pack_fwd(n.st, dw, taps * Cin, Cout, dwp, Kpad, Npad, 0, 0, 1));
   ICS_TRY(launch_pack_bwd(n.st, dw, taps, Cin, Cout, dwf, Kpad_b, Npad_b, Cout, 0, 1));
-  ConvGeom g{B, S, ilog2(S), Cin, Cout, taps, Kpad, Npad};
-  ConvGeom gb{B, S, ilog2(S), Cout, Cin, taps, Kpad_b, Npad_b};
+  ConvGeom g{B, S, ilog2(S), Cin, Cout, taps, Kpad, Npad, n.flags};
+  ConvGeom gb{B, S, ilog2(S), Cout, Cin, taps, Kpad_b, Npad_b, n.flags};
   ConvSrc sx = src_plain(dx, Cin), sd = src_plain(dyv, Cout);
   const size_t wsn = conv_wgrad_workspace_floats(g, &sx, 1);
   ICS_TRY(n.alloc(&ws, wsn + 16));
@@ -1885,7 +1893,7 @@ int ics_op_conv3d_backward(const float* x, const float* w, const float* dy, int 
   ICS_HIP(hipMemcpyAsync(dx, x, M * Cin * 4, hipMemcpyHostToDevice, n.st));
   ICS_HIP(hipMemcpyAsync(dw, w, (size_t)taps * Cin * Cout * 4, hipMemcpyHostToDevice, n.st));
   ICS_HIP(hipMemcpyAsync(ddy, dy, M * Cout * 4, hipMemcpyHostToDevice, n.st));
-  ConvGeom g{B, S, ilog2(S), Cin, Cout, taps, Kpad, Npad};
+  ConvGeom g{B, S, ilog2(S), Cin, Cout, taps, Kpad, Npad, n.flags};
   ConvSrc s = src_plain(dx, Cin);
   const size_t wsn = conv_wgrad_workspace_floats(g, &s, 1);
   ICS_TRY(n.alloc(&ws, wsn + 16));
@@ -1895,7 +1903,7 @@ int ics_op_conv3d_backward(const float* x, const float* w, const float* dy, int 
   }
   if (dxo) {
     ICS_TRY(launch_pack_bwd(n.st, dw, taps, Cin, Cout, dwf, Kpad_b, Npad_b, Cout, 0, 1));
-    ConvGeom gb{B, S, ilog2(S), Cout, Cin, taps, Kpad_b, Npad_b};
+    ConvGeom gb{B, S, ilog2(S), Cout, Cin, taps, Kpad_b, Npad_b, n.flags};
     ConvSrc sd = src_plain(ddy, Cout);
     ICS_TRY(launch_conv_fwd(n.st, gb, &sd, 1, dwf, nullptr, dgx, Cin, ACT_NONE, nullptr, nullptr));
     ICS_HIP(hipMemcpyAsync(dxo, dgx, M * Cin * 4, hipMemcpyDeviceToHost, n.st));

@@ -1,0 +1,138 @@
+/* Host driver of the `make asan` build: walks the C ABI of include/icsg3d.h end to end on the stubbed runtime
+ * (hoststub/hip_host_stub.cpp) so that AddressSanitizer / UBSan / LeakSanitizer see every host-side code path:
+ * engine construction (tensor tables, BN slab, workspace planners), named tensor I/O, train / test / predict
+ * call chains (launch planning, split-K and bucket bookkeeping, profiler rows), the data-parallel entry points,
+ * the fused inference tail, optimizer-state export and destruction.  Kernels do not run; results are not checked. */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "icsg3d.h"
+
+#define OK(x)                                                              \
+  do {                                                                     \
+    if ((x) != 0) {                                                        \
+      fprintf(stderr, "FAILED %s: %s\n", #x, ics_last_error());            \
+      return 1;                                                            \
+    }                                                                      \
+  } while (0)
+
+static int tensor_io(ics_net* net) {
+  int n = 0;
+  OK(ics_net_num_tensors(net, &n));
+  for (int i = 0; i < n; ++i) {
+    const char* name; int nd, tr; int64_t dims[5];
+    OK(ics_net_tensor_info(net, i, &name, &nd, dims, &tr));
+    size_t cnt = 1;
+    for (int k = 0; k < nd; ++k) cnt *= (size_t)dims[k];
+    float* buf = (float*)malloc(cnt * sizeof(float));      /* exact size: an over-read/-write is an ASan report */
+    for (size_t k = 0; k < cnt; ++k) buf[k] = 0.01f * (float)(k % 7);
+    OK(ics_net_set_tensor(net, name, buf, cnt));
+    OK(ics_net_get_tensor(net, name, buf, cnt));
+    if (tr) OK(ics_net_get_grad(net, name, buf, cnt));
+    if (ics_net_set_tensor(net, name, buf, cnt + 1) == 0) { fprintf(stderr, "size check missing for %s\n", name); return 1; }
+    free(buf);
+  }
+  return 0;
+}
+
+static int run(int d, int C, int B, int with_comm) {
+  const size_t M = (size_t)B * d * d * d;
+  ics_unet_config uc = {C, 95, d, B, 1e-3f, 0.f, 1, 1};
+  ics_vae_config vc = {C, 10, 256, {16, 32, 64, 128}, d, B, 5e-4f, 0.5f, 3e-4f, {1.f, 1.f, 1.f, 1.f}, 1};
+  ics_net *unet = NULL, *vae = NULL;
+  OK(ics_unet_create(&uc, &unet));
+  OK(ics_vae_create(&vc, unet, &vae));
+  if (tensor_io(unet) || tensor_io(vae)) return 1;
+  if (with_comm) {
+    char uid[128];
+    OK(ics_comm_unique_id(uid));
+    OK(ics_net_comm_init(unet, 0, 1, uid));
+    OK(ics_net_comm_init(vae, 0, 1, uid));
+    OK(ics_net_comm_broadcast_state(unet, 0));
+    OK(ics_net_comm_broadcast_state(vae, 0));
+    OK(ics_net_set_sync_bn(unet, with_comm > 1));
+    OK(ics_net_set_sync_bn(vae, with_comm > 1));
+    double v = 1.0;
+    OK(ics_net_comm_allreduce_max(unet, &v));
+  }
+  float* x = (float*)calloc(M * C, sizeof(float));
+  uint8_t* lab = (uint8_t*)calloc(M, 1);
+  float* soft = (float*)malloc(M * 95 * sizeof(float));
+  float* sig = (float*)malloc(M * sizeof(float));
+  uint8_t* sp = (uint8_t*)malloc(M);
+  uint8_t* mk = (uint8_t*)malloc(M);
+  float* cond = (float*)calloc((size_t)B * 10, sizeof(float));
+  float* eps = (float*)calloc((size_t)B * 256, sizeof(float));
+  float* z = (float*)calloc((size_t)B * 256 * 3, sizeof(float));
+  float* rec = (float*)malloc(M * C * sizeof(float));
+  float mm[5], mv[4], minmax[6 * 8];
+  OK(ics_net_profile_enable(unet, 1));
+  OK(ics_net_profile_enable(vae, 1));
+  for (int b = 1; b <= B; ++b) {   /* every batch size up to max_batch: the split plans depend on it */
+    OK(ics_unet_train_step(unet, x, lab, b, mm));
+    OK(ics_unet_test_step(unet, x, lab, b, mm));
+    OK(ics_unet_predict(unet, x, b, soft, sig));
+    OK(ics_unet_predict_labels(unet, x, b, 0.8f, sp, mk));
+    OK(ics_vae_train_step(vae, x, cond, eps, b, mv));
+    OK(ics_vae_test_step(vae, x, cond, eps, b, mv));
+    OK(ics_vae_encode(vae, x, cond, eps, b, z, z + (size_t)B * 256, z + (size_t)B * 512));
+    OK(ics_vae_decode(vae, z, cond, b, rec));
+    OK(ics_vae_decode_to_unet_labels(vae, unet, z, cond, b, 0.8f, sp, mk, rec, minmax));
+  }
+  OK(ics_unet_upload_batch(unet, x, lab, B));
+  OK(ics_unet_train_step_resident(unet, NULL));
+  OK(ics_vae_upload_batch(vae, x, cond, eps, B));
+  OK(ics_vae_train_step_resident(vae, mv));
+  if (ics_unet_train_step(unet, x, lab, B + 1, mm) == 0) { fprintf(stderr, "max_batch check missing\n"); return 1; }
+  int rows = 0;
+  OK(ics_net_profile_count(unet, &rows));
+  for (int r = 0; r < rows; ++r) {
+    const char* label; int64_t launches; double ms, fl, by;
+    OK(ics_net_profile_row(unet, r, &label, &launches, &ms, &fl, &by));
+  }
+  size_t np = 0;
+  OK(ics_net_num_params(unet, &np));
+  float* m1 = (float*)malloc(np * sizeof(float));
+  float* v1 = (float*)malloc(np * sizeof(float));
+  int step = 0;
+  OK(ics_net_get_optimizer_state(unet, m1, v1, np, &step));
+  OK(ics_net_set_optimizer_state(unet, m1, v1, np, step));
+  OK(ics_net_reset_optimizer(unet));
+  {
+    size_t cnt = (size_t)B * (d / 8) * (d / 8) * (d / 8) * 512;      /* c10 activation */
+    float* act = (float*)malloc(cnt * sizeof(float));
+    float sc[512], sh[512];
+    OK(ics_net_get_activation(unet, "c10", act, cnt));
+    OK(ics_net_get_bn_affine(unet, "c10", sc, sh, 512));
+    free(act);
+  }
+  int rk, nr, nb;
+  OK(ics_net_comm_info(unet, &rk, &nr, &nb));
+  free(m1); free(v1); free(x); free(lab); free(soft); free(sig); free(sp); free(mk); free(cond); free(eps); free(z); free(rec);
+  OK(ics_net_destroy(vae));
+  OK(ics_net_destroy(unet));
+  return 0;
+}
+
+int main(void) {
+  char name[256]; int cus; size_t hbm; int ndev = 0;
+  OK(ics_device_count(&ndev));
+  OK(ics_set_device(0));
+  OK(ics_device_info(name, &cus, &hbm));
+  printf("asan driver on %s (%s)\n", name, ics_version());
+  if (run(16, 1, 3, 0)) return 1;
+  if (run(16, 4, 2, 1)) return 1;      /* 4 channels (Cin 44 -> padded loaders), single-rank communicator */
+  if (run(32, 1, 2, 2)) return 1;      /* d = 32 plans, SyncBN */
+  {   /* single-op entry points */
+    const int B = 1, S = 8, Cin = 32, Cout = 64;
+    size_t nx = (size_t)B * S * S * S * Cin, ny = (size_t)B * S * S * S * Cout, nw = (size_t)27 * Cin * Cout;
+    float *x = calloc(nx, 4), *y = calloc(ny, 4), *w = calloc(nw, 4), *dx = calloc(nx, 4), *dw = calloc(nw, 4);
+    OK(ics_op_conv3d_forward(x, w, NULL, B, S, Cin, Cout, 27, 1, y));
+    OK(ics_op_conv3d_backward(x, w, y, B, S, Cin, Cout, 27, dx, dw));
+    free(x); free(y); free(w); free(dx); free(dw);
+  }
+  printf("asan driver: all entry points walked, no sanitizer report\n");
+  return 0;
+}

@@ -48,6 +48,16 @@ def vae_param_shapes(in_ch=1, cond=10, filters=(16, 32, 64, 128), latent=256, d=
     return sh
 
 
+def bn_state_defaults(shapes):
+    """Keras BatchNormalization initial moving statistics (mean 0, variance 1) for every layer that has a gamma."""
+    out = {}
+    for name, shp in shapes:
+        if name.endswith("/gamma"):
+            out[name[:-5] + "moving_mean"] = np.zeros(shp, np.float32)
+            out[name[:-5] + "moving_var"] = np.ones(shp, np.float32)
+    return out
+
+
 def glorot_params(shapes, seed):
     """Glorot-uniform kernels from PCG64(seed) in list order, zero biases, BN gamma 1 / beta 0."""
     rng = np.random.Generator(np.random.PCG64(seed))

@@ -16,7 +16,7 @@ import numpy as np
 from ..checkpoint import load_weights as _load_weight_file
 from ..checkpoint import save_weights as _save_weight_file
 from ..engine import UnetEngine
-from ..synthetic import glorot_params, unet_param_shapes
+from ..synthetic import bn_state_defaults, glorot_params, unet_param_shapes
 from .get_weights import get_weights
 
 K_EPSILON = 1e-7
@@ -225,8 +225,9 @@ class AtomUnet:
         self.pool_ties = pool_ties
         self._eng = None
         self._max_batch = max_batch
-        self._host_weights = glorot_params(unet_param_shapes(self.input_shape[-1], num_classes),
-                                           seed=int(np.random.randint(0, 2 ** 31 - 1)))
+        shapes = unet_param_shapes(self.input_shape[-1], num_classes)
+        self._host_weights = glorot_params(shapes, seed=int(np.random.randint(0, 2 ** 31 - 1)))
+        self._host_weights.update(bn_state_defaults(shapes))
         self.model = _UnetModel(self)
         self.metrics = {"soft": [f1_m, wr_m]}
         self.metric_names = ["Loss", "lsoft", "lsig", "f1", "wr"]

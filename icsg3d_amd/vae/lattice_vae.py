@@ -18,7 +18,7 @@ import numpy as np
 from ..checkpoint import load_weights as _load_weight_file
 from ..checkpoint import save_weights as _save_weight_file
 from ..engine import UnetEngine, VaeEngine
-from ..synthetic import glorot_params, unet_param_shapes, vae_param_shapes
+from ..synthetic import bn_state_defaults, glorot_params, unet_param_shapes, vae_param_shapes
 from ..unet.unet import custom_objects
 
 
@@ -179,6 +179,7 @@ class LatticeDFCVAE:
         shapes = vae_param_shapes(self.channels, self.cond_shape, tuple(self.filters), self.latent_dim,
                                   self.input_shape[0])
         self._host_weights = glorot_params(shapes, seed=int(np.random.randint(0, 2 ** 31 - 1)))
+        self._host_weights.update(bn_state_defaults(shapes))
         self.encoder, self.decoder, self.model = _Encoder(self), _Decoder(self), _VaeModel(self)
         self.batch_size = batch_size
         if weights and os.path.exists(weights):

@@ -68,6 +68,7 @@ def test_class_api_hdf5_checkpoints_resize_and_generate_tail(tmp_path):
     assert unet._eng is not eng and unet._eng.max_batch == 4
     m, v, t2 = unet._eng.get_optimizer_state()
     assert t1 == 1 and t2 == 2 and np.abs(m).max() > 0
+    soft, sig = unet.model.predict(X)
     # Keras-HDF5 checkpoints behind the reference's file names
     wpath, mpath = str(tmp_path / "unet_weights.best.hdf5"), str(tmp_path / "unet.h5")
     unet.model.save_weights(wpath); unet.model.save(mpath)
