@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <vector>
 
 namespace ics {
 
@@ -88,7 +89,7 @@ struct ConvGeom {
 
 // ---------------------------------------------------------------- kernel launchers (conv_igemm.hip)
 // out[m*ldo + n] = pre_act( sum_k A[m][k] * W[k][n] + bias[n] ),  m over B*S^3 voxels.
-// stat_partial: optional [gridM][3][Npad] (count, mean, M2) of the stored values per block column.
+// stat_partial: optional [3][Npad][gridM] (count, mean, M2) of the stored values per block column (block index fastest).
 int launch_conv_fwd(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int nsrc,
                     const float* wpacked, const float* bias, float* out, int ldo, int pre_act,
                     float* stat_partial, int* stat_rows_per_block, int accumulate = 0,
@@ -119,6 +120,12 @@ int launch_conv_fwd_ablate(hipStream_t st, const ConvGeom& g, const ConvSrc* src
 // weight packing: Keras [taps][Cin][Cout] -> [Kpad/4][Npad][4]
 int launch_pack_fwd(hipStream_t st, const float* w, int K, int N, float* dst, int Kpad, int Npad,
                     int k_off, int n_off, int zero_first, int cin_log = 0, int cin_phys = 0);
+// One-launch packing: between record_begin and record_end the launch_pack_* functions append jobs to a table
+// instead of launching; the engine uploads the table once and replays it with launch_pack_table after every
+// parameter change (destination buffers must be zero-initialised: jobs write only their valid elements).
+void* pack_table_record_begin();
+int pack_table_record_end(void* handle, std::vector<unsigned char>* bytes, int* njobs, unsigned* nblocks);
+int launch_pack_table(hipStream_t st, const void* d_jobs, int njobs, unsigned nblocks);
 int launch_materialize_input(hipStream_t st, const ConvSrc* src, int nsrc, int Cin, int CinG, int B, int S,
                              float* out);
 int launch_pack_bwd(hipStream_t st, const float* w, int taps, int Cin, int Cout, float* dst,

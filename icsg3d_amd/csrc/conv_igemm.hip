@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <type_traits>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 namespace ics {
@@ -746,10 +747,12 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
     float q = 0.f;
 #pragma unroll
     for (int w = 0; w < WM; ++w) q += red[w * BN + t];
-    float* sp = stat_partial + (size_t)(cls * gridM + mb) * 3 * g.Npad + n0 + t;   // PAR: 8 x gridM blocks
+    // layout [3][Npad][nstat] (block index fastest): bn_finalize then reads each channel's partials contiguously
+    const size_t nstat = (size_t)(PAR ? 8 : 1) * gridM;                             // PAR: 8 x gridM blocks
+    float* sp = stat_partial + (size_t)(n0 + t) * nstat + (size_t)(cls * gridM + mb);
     sp[0] = (float)nvalid_rows;
-    sp[g.Npad] = bmean[t];
-    sp[2 * g.Npad] = q;
+    sp[(size_t)g.Npad * nstat] = bmean[t];
+    sp[(size_t)2 * g.Npad * nstat] = q;
   }
 }
 
@@ -918,10 +921,11 @@ __global__ __launch_bounds__(256) void conv_thin_n_fwd_kernel(ConvGeom g, ConvSr
   }
   __syncthreads();
   if (t < NOUT && t < g.Npad) {
-    float* sp = stat_partial + (size_t)blockIdx.x * 3 * g.Npad + t;
+    const size_t nstat = gridDim.x;
+    float* sp = stat_partial + (size_t)t * nstat + blockIdx.x;
     sp[0] = (float)nvalid_rows;
-    sp[g.Npad] = mu[t];
-    sp[2 * g.Npad] = red[t] + red[NOUT + t] + red[2 * NOUT + t] + red[3 * NOUT + t];
+    sp[(size_t)g.Npad * nstat] = mu[t];
+    sp[(size_t)2 * g.Npad * nstat] = red[t] + red[NOUT + t] + red[2 * NOUT + t] + red[3 * NOUT + t];
   }
 }
 
@@ -1086,10 +1090,11 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
   red[ty][tx] = q;
   __syncthreads();
   if (ty == 0 && col < Npad) {
-    float* sp = stat_partial + (size_t)blockIdx.x * 3 * Npad + col;
+    const size_t nstat = gridDim.x;
+    float* sp = stat_partial + (size_t)col * nstat + blockIdx.x;
     sp[0] = (float)nvalid_rows;
-    sp[Npad] = mu;
-    sp[2 * Npad] = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+    sp[(size_t)Npad * nstat] = mu;
+    sp[(size_t)2 * Npad * nstat] = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
   }
 }
 
@@ -1208,13 +1213,25 @@ int launch_conv_fwd_par(hipStream_t st, const ConvGeom& g, const ConvSrc& src, c
   return rc;
 }
 
+// ---- one-launch packing.  After every Adam step ~50 packed weight images are rebuilt (forward, tap-flipped
+// backward-data, skip / parity-class / up-split variants per layer); as separate launches they cost ~5 us each
+// whatever their size.  The engine records the jobs once (the launch_pack_* calls below append to g_pack_rec
+// instead of launching) and replays them with ONE pack_table_kernel launch per step.
+struct PackJob {
+  int kind;                 // 0 fwd, 1 bwd, 2 sub, 3 fwd_sub, 4 par
+  const float* w;
+  float* dst;
+  int a[9];
+  unsigned long long total; // elements of dst this job covers
+  unsigned blk0;            // first block of the job in the table launch
+};
+static thread_local std::vector<PackJob>* g_pack_rec = nullptr;
+
 // pre-summed parity weights: dst[cls][k = e*Cu + c][n] = sum over taps d with (per axis)
 //   p=0: e=0 -> {-1}, e=1 -> {0,+1};  p=1: e=0 -> {-1,0}, e=1 -> {+1}   of w[d][c_off + c][n]
-__global__ void pack_par_kernel(const float* __restrict__ w, int Cin_total, int Cout, int c_off, int Cu,
-                                float* __restrict__ dst, int Kpad, int Npad) {
+__device__ __forceinline__ float pack_par_value(size_t i, const float* __restrict__ w, int Cin_total, int Cout, int c_off,
+                                                int Cu, int Kpad, int Npad) {
   const size_t per = (size_t)Kpad * Npad;
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 8 * per) return;
   const int cls = (int)(i / per);
   const size_t j = i - (size_t)cls * per;
   const int tq = j & 3;
@@ -1237,10 +1254,17 @@ __global__ void pack_par_kernel(const float* __restrict__ w, int Cin_total, int 
         for (int dx = lo[2]; dx <= hi[2]; ++dx)
           v += w[((size_t)((dz * 3 + dy) * 3 + dx) * Cin_total + c_off + c) * Cout + n];
   }
-  dst[i] = v;
+  return v;
+}
+__global__ void pack_par_kernel(const float* __restrict__ w, int Cin_total, int Cout, int c_off, int Cu,
+                                float* __restrict__ dst, int Kpad, int Npad) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 8 * (size_t)Kpad * Npad) return;
+  dst[i] = pack_par_value(i, w, Cin_total, Cout, c_off, Cu, Kpad, Npad);
 }
 int launch_pack_par(hipStream_t st, const float* w, int Cin_total, int Cout, int c_off, int Cu, float* dst,
                     int Kpad, int Npad) {
+  if (g_pack_rec) { g_pack_rec->push_back(PackJob{4, w, dst, {Cin_total, Cout, c_off, Cu, Kpad, Npad, 0, 0, 0}, 8ull * Kpad * Npad, 0}); return 0; }
   const size_t total = (size_t)8 * Kpad * Npad;
   hipLaunchKernelGGL(pack_par_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, Cin_total, Cout,
                      c_off, Cu, dst, Kpad, Npad);
@@ -1248,19 +1272,24 @@ int launch_pack_par(hipStream_t st, const float* w, int Cin_total, int Cout, int
   return 0;
 }
 // forward weights of a channel subset: dst[k = tap*Csub + c][n] = w[tap][c_off + c][n]
-__global__ void pack_fwd_sub_kernel(const float* __restrict__ w, int taps, int Cin_total, int Cout, int c_off,
-                                    int Csub, float* __restrict__ dst, int Kpad, int Npad) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (size_t)Kpad * Npad) return;
+__device__ __forceinline__ float pack_fwd_sub_value(size_t i, const float* __restrict__ w, int taps, int Cin_total,
+                                                    int Cout, int c_off, int Csub, int Npad) {
   const int tq = i & 3;
   const size_t rest = i >> 2;
   const int n = rest % Npad;
   const int k = (int)(rest / Npad) * 4 + tq;
   const int tap = k / Csub, c = k - tap * Csub;
-  dst[i] = (tap < taps && n < Cout) ? w[((size_t)tap * Cin_total + c_off + c) * Cout + n] : 0.f;
+  return (tap < taps && n < Cout) ? w[((size_t)tap * Cin_total + c_off + c) * Cout + n] : 0.f;
+}
+__global__ void pack_fwd_sub_kernel(const float* __restrict__ w, int taps, int Cin_total, int Cout, int c_off,
+                                    int Csub, float* __restrict__ dst, int Kpad, int Npad) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)Kpad * Npad) return;
+  dst[i] = pack_fwd_sub_value(i, w, taps, Cin_total, Cout, c_off, Csub, Npad);
 }
 int launch_pack_fwd_sub(hipStream_t st, const float* w, int taps, int Cin_total, int Cout, int c_off, int Csub,
                         float* dst, int Kpad, int Npad) {
+  if (g_pack_rec) { g_pack_rec->push_back(PackJob{3, w, dst, {taps, Cin_total, Cout, c_off, Csub, Npad, 0, 0, 0}, (unsigned long long)Kpad * Npad, 0}); return 0; }
   const size_t total = (size_t)Kpad * Npad;
   hipLaunchKernelGGL(pack_fwd_sub_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, taps,
                      Cin_total, Cout, c_off, Csub, dst, Kpad, Npad);
@@ -2242,12 +2271,8 @@ int launch_conv_wgrad(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int
 // only when zero_first (the head packs two weight tensors into one buffer).
 // cin_phys > 0: the GEMM runs on an input zero-padded from cin_log to cin_phys channels per tap
 // (K = taps*cin_phys); rows of the padding channels are zero.
-__global__ void pack_fwd_kernel(const float* __restrict__ w, int K, int N, float* __restrict__ dst,
-                                int Kpad, int Npad, int k_off, int n_off, int zero_first, int cin_log,
-                                int cin_phys) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t total = (size_t)Kpad * Npad;
-  if (i >= total) return;
+__device__ __forceinline__ bool pack_fwd_value(size_t i, const float* __restrict__ w, int K, int N, int Npad, int k_off,
+                                               int n_off, int cin_log, int cin_phys, float* v) {
   const int tq = i & 3;
   const size_t rest = i >> 2;
   const int n = rest % Npad;
@@ -2260,8 +2285,17 @@ __global__ void pack_fwd_kernel(const float* __restrict__ w, int K, int N, float
     ok = ci < cin_log;
     ks = tap * cin_log + ci;
   }
-  if (ok) dst[i] = w[(size_t)ks * N + ns];
-  else if (zero_first) dst[i] = 0.f;
+  *v = ok ? w[(size_t)ks * N + ns] : 0.f;
+  return ok;
+}
+__global__ void pack_fwd_kernel(const float* __restrict__ w, int K, int N, float* __restrict__ dst,
+                                int Kpad, int Npad, int k_off, int n_off, int zero_first, int cin_log,
+                                int cin_phys) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)Kpad * Npad;
+  if (i >= total) return;
+  float v;
+  if (pack_fwd_value(i, w, K, N, Npad, k_off, n_off, cin_log, cin_phys, &v) || zero_first) dst[i] = v;
 }
 
 // materialise the virtual (concatenated / broadcast / BN-applied) input zero-padded to CinG channels
@@ -2287,30 +2321,32 @@ int launch_materialize_input(hipStream_t st, const ConvSrc* src, int nsrc, int C
 }
 
 // backward-data weights: k' = t'*cout_total + co_off + co, n' = ci, value = w[26-t'][ci][co]
+__device__ __forceinline__ bool pack_bwd_value(size_t i, const float* __restrict__ w, int taps, int Cin, int Cout,
+                                               int Npad, int cout_total, int co_off, float* v) {
+  const int tq = i & 3;
+  const size_t rest = i >> 2;
+  const int n = rest % Npad;
+  const int k = (int)(rest / Npad) * 4 + tq;
+  const int tp = k / cout_total, co = k - tp * cout_total - co_off;
+  const bool ok = tp < taps && co >= 0 && co < Cout && n < Cin;
+  *v = ok ? w[((size_t)(taps - 1 - tp) * Cin + n) * Cout + co] : 0.f;
+  return ok;
+}
 __global__ void pack_bwd_kernel(const float* __restrict__ w, int taps, int Cin, int Cout,
                                 float* __restrict__ dst, int Kpad, int Npad, int cout_total,
                                 int co_off, int zero_first) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)Kpad * Npad;
   if (i >= total) return;
-  const int tq = i & 3;
-  const size_t rest = i >> 2;
-  const int n = rest % Npad;
-  const int k = (int)(rest / Npad) * 4 + tq;
-  const int tp = k / cout_total, co = k - tp * cout_total - co_off;
-  if (tp < taps && co >= 0 && co < Cout && n < Cin)
-    dst[i] = w[((size_t)(taps - 1 - tp) * Cin + n) * Cout + co];
-  else if (zero_first) dst[i] = 0.f;
+  float v;
+  if (pack_bwd_value(i, w, taps, Cin, Cout, Npad, cout_total, co_off, &v) || zero_first) dst[i] = v;
 }
 
 // Packed GEMM weights over a channel SUBSET [c_off, c_off+Csub) of w[taps][Cin_total][Cout]:
 //   k = tp*Cout + co, n = c:  dst[k][n] = w[flip ? taps-1-tp : tp][c_off + c][co]
 // flip = 1: backward-data weights of the subset; flip = 0: the "up-split" GEMM dxl = dyS x W.
-__global__ void pack_sub_kernel(const float* __restrict__ w, int taps, int Cin_total, int Cout, int c_off,
-                                int Csub, int flip, float* __restrict__ dst, int Kpad, int Npad) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t total = (size_t)Kpad * Npad;
-  if (i >= total) return;
+__device__ __forceinline__ float pack_sub_value(size_t i, const float* __restrict__ w, int taps, int Cin_total, int Cout,
+                                                int c_off, int Csub, int flip, int Npad) {
   const int tq = i & 3;
   const size_t rest = i >> 2;
   const int n = rest % Npad;
@@ -2318,10 +2354,18 @@ __global__ void pack_sub_kernel(const float* __restrict__ w, int taps, int Cin_t
   const int tp = k / Cout, co = k - tp * Cout;
   float v = 0.f;
   if (tp < taps && n < Csub) v = w[((size_t)(flip ? taps - 1 - tp : tp) * Cin_total + c_off + n) * Cout + co];
-  dst[i] = v;
+  return v;
+}
+__global__ void pack_sub_kernel(const float* __restrict__ w, int taps, int Cin_total, int Cout, int c_off,
+                                int Csub, int flip, float* __restrict__ dst, int Kpad, int Npad) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)Kpad * Npad;
+  if (i >= total) return;
+  dst[i] = pack_sub_value(i, w, taps, Cin_total, Cout, c_off, Csub, flip, Npad);
 }
 int launch_pack_sub(hipStream_t st, const float* w, int taps, int Cin_total, int Cout, int c_off, int Csub,
                     int flip, float* dst, int Kpad, int Npad) {
+  if (g_pack_rec) { g_pack_rec->push_back(PackJob{2, w, dst, {taps, Cin_total, Cout, c_off, Csub, flip, Npad, 0, 0}, (unsigned long long)Kpad * Npad, 0}); return 0; }
   const size_t total = (size_t)Kpad * Npad;
   hipLaunchKernelGGL(pack_sub_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, taps, Cin_total,
                      Cout, c_off, Csub, flip, dst, Kpad, Npad);
@@ -2331,6 +2375,7 @@ int launch_pack_sub(hipStream_t st, const float* w, int taps, int Cin_total, int
 
 int launch_pack_fwd(hipStream_t st, const float* w, int K, int N, float* dst, int Kpad, int Npad,
                     int k_off, int n_off, int zero_first, int cin_log, int cin_phys) {
+  if (g_pack_rec) { g_pack_rec->push_back(PackJob{0, w, dst, {K, N, Npad, k_off, n_off, cin_log, cin_phys, 0, 0}, (unsigned long long)Kpad * Npad, 0}); return 0; }
   const size_t total = (size_t)Kpad * Npad;
   hipLaunchKernelGGL(pack_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, K, N,
                      dst, Kpad, Npad, k_off, n_off, zero_first, cin_log, cin_phys);
@@ -2339,9 +2384,69 @@ int launch_pack_fwd(hipStream_t st, const float* w, int K, int N, float* dst, in
 }
 int launch_pack_bwd(hipStream_t st, const float* w, int taps, int Cin, int Cout, float* dst,
                     int Kpad, int Npad, int cout_total, int co_off, int zero_first) {
+  if (g_pack_rec) { g_pack_rec->push_back(PackJob{1, w, dst, {taps, Cin, Cout, Npad, cout_total, co_off, 0, 0, 0}, (unsigned long long)Kpad * Npad, 0}); return 0; }
   const size_t total = (size_t)Kpad * Npad;
   hipLaunchKernelGGL(pack_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, taps,
                      Cin, Cout, dst, Kpad, Npad, cout_total, co_off, zero_first);
+  ICS_HIP(hipGetLastError());
+  return 0;
+}
+
+// One launch for a whole table of pack jobs.  Destination buffers are zero-initialised at allocation and the
+// padding of a packed image never changes, so jobs only write their valid elements (two jobs may share a
+// destination: the head packs soft | sig side by side) -- no ordering between jobs is needed.
+__global__ __launch_bounds__(256) void pack_table_kernel(const PackJob* __restrict__ jobs, int njobs) {
+  __shared__ int sj;
+  if (threadIdx.x == 0) {
+    int lo = 0, hi = njobs - 1;              // last job whose first block is <= blockIdx.x
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (jobs[mid].blk0 <= blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    sj = lo;
+  }
+  __syncthreads();
+  const PackJob J = jobs[sj];
+  const size_t i = (size_t)(blockIdx.x - J.blk0) * 256 + threadIdx.x;
+  if (i >= J.total) return;
+  const int* a = J.a;
+  float v;
+  switch (J.kind) {
+    case 0: if (pack_fwd_value(i, J.w, a[0], a[1], a[2], a[3], a[4], a[5], a[6], &v)) J.dst[i] = v; break;
+    case 1: if (pack_bwd_value(i, J.w, a[0], a[1], a[2], a[3], a[4], a[5], &v)) J.dst[i] = v; break;
+    case 2: J.dst[i] = pack_sub_value(i, J.w, a[0], a[1], a[2], a[3], a[4], a[5], a[6]); break;
+    case 3: J.dst[i] = pack_fwd_sub_value(i, J.w, a[0], a[1], a[2], a[3], a[4], a[5]); break;
+    default: J.dst[i] = pack_par_value(i, J.w, a[0], a[1], a[2], a[3], a[4], a[5]); break;
+  }
+}
+
+// record the launch_pack_* calls made by `fn` instead of executing them
+struct PackTableHost { std::vector<PackJob> jobs; };
+void* pack_table_record_begin() {
+  auto* t = new PackTableHost();
+  g_pack_rec = &t->jobs;
+  return t;
+}
+// finishes the recording: assigns block ranges, returns the table bytes to upload (caller copies them to the
+// device) and the total block count
+int pack_table_record_end(void* handle, std::vector<unsigned char>* bytes, int* njobs, unsigned* nblocks) {
+  g_pack_rec = nullptr;
+  auto* t = static_cast<PackTableHost*>(handle);
+  unsigned blk = 0;
+  for (auto& j : t->jobs) {
+    j.blk0 = blk;
+    blk += (unsigned)((j.total + 255) / 256);
+  }
+  bytes->resize(t->jobs.size() * sizeof(PackJob));
+  if (!t->jobs.empty()) std::memcpy(bytes->data(), t->jobs.data(), bytes->size());
+  *njobs = (int)t->jobs.size();
+  *nblocks = blk;
+  delete t;
+  return 0;
+}
+int launch_pack_table(hipStream_t st, const void* d_jobs, int njobs, unsigned nblocks) {
+  if (njobs == 0) return 0;
+  hipLaunchKernelGGL(pack_table_kernel, dim3(nblocks), dim3(256), 0, st, static_cast<const PackJob*>(d_jobs), njobs);
   ICS_HIP(hipGetLastError());
   return 0;
 }

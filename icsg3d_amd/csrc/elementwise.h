@@ -42,7 +42,10 @@ struct GradSrc {
 struct LayerBwd {
   const float* s;                 // stored pre-BN activations [M][C]
   const float* scale; const float* shift; const float* mean; const float* rstd;
-  const float* dtap;              // optional extra gradient w.r.t. s (perceptual taps)
+  const float* dtap;              // optional extra gradient w.r.t. s
+  const float* tap_ref;           // perceptual tap: the same layer's s in the pass over y_true; adds
+  float tap_coef;                 //   tap_coef * (s - tap_ref) to the gradient w.r.t. s and writes the block's
+  double* tap_partial;            //   sum (s - tap_ref)^2 to tap_partial[blockIdx.x]  (bn_bwd_num_blocks entries)
   GradSrc g0, g1;
   int B, S, lgS, C;
   int has_bn, pre_act, post_act;
@@ -57,6 +60,14 @@ int launch_pool_fwd(hipStream_t st, const float* s, const float* scale, const fl
 int launch_layer_bwd(hipStream_t st, const LayerBwd& L, float* dy, float* ws_partial, float* c1c2,
                      float* dgamma, float* dbeta, float* dbias, const BnSync* sync = nullptr);
 size_t layer_bwd_workspace_floats(const LayerBwd& L);
+int bn_bwd_num_blocks(const LayerBwd& L, int* rows_per_block);
+// perceptual-loss partial sums handed to vae_loss: n[l] partials for tap l, each tap's per-sample element count
+// and layer weight (vae/lattice_vae.py:100-101,266-269)
+struct PmSums {
+  int n[4];
+  double per[4];
+  float w[4];
+};
 int launch_head(hipStream_t st, float* z, int ldz, int ncls, const unsigned char* labels, size_t M,
                 int mode, int want_grad, float wsoft, double* partial, int partial_blocks,
                 float* metrics, int* nblk_out = nullptr);
@@ -72,9 +83,8 @@ int launch_sqdiff(hipStream_t st, const float* a, const float* b, int B, size_t 
 int launch_sampling(hipStream_t st, const float* mulv, int ld, int latent, const float* eps,
                     const float* cond, int ncond, int B, float* z, float* zc);
 int launch_vae_loss(hipStream_t st, const float* mulv, int ld, int latent, int B, const double* mse_partial,
-                    int n_mse, double n_elems, const double* pm_partial, const int* pm_counts,
-                    const float* pm_w, float alpha, float beta, float* metrics, double* sums = nullptr,
-                    int phase = 0);
+                    int n_mse, double n_elems, const double* pm_partial, const PmSums& pmc, float alpha, float beta,
+                    float* metrics, double* sums = nullptr, int phase = 0);
 int launch_vae_dz(hipStream_t st, const float* mulv, int ld, int latent, int B, const float* eps,
                   const float* dzc, int ldzc, float beta, float* dmulv);
 int launch_relu_bwd(hipStream_t st, const float* a, float* g, size_t n);

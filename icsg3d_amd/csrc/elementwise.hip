@@ -45,19 +45,21 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   __shared__ double sh[4];
   const int c = blockIdx.x;
   double n = 0.0, s = 0.0;
+  // partial layout [3][Npad][nblk]: this channel's (count, mean, M2) rows are contiguous
+  const float* pn = partial + (size_t)c * nblk;
+  const float* pm = partial + ((size_t)Npad + c) * nblk;
+  const float* pq = partial + ((size_t)2 * Npad + c) * nblk;
   for (int b = threadIdx.x; b < nblk; b += 256) {
-    const float* p = partial + (size_t)b * 3 * Npad + c;
-    n += (double)p[0];
-    s += (double)p[0] * (double)p[Npad];
+    n += (double)pn[b];
+    s += (double)pn[b] * (double)pm[b];
   }
   n = block_sum_d(n, sh);
   s = block_sum_d(s, sh);
   const double mean = s / n;
   double m2 = 0.0;
   for (int b = threadIdx.x; b < nblk; b += 256) {
-    const float* p = partial + (size_t)b * 3 * Npad + c;
-    const double d = (double)p[Npad] - mean;
-    m2 += (double)p[2 * Npad] + (double)p[0] * d * d;
+    const double d = (double)pm[b] - mean;
+    m2 += (double)pq[b] + (double)pn[b] * d * d;
   }
   m2 = block_sum_d(m2, sh);
   if (threadIdx.x == 0) {
@@ -98,19 +100,21 @@ __global__ __launch_bounds__(256) void bn_local_merge_kernel(const float* __rest
   __shared__ double sh[4];
   const int c = blockIdx.x;
   double n = 0.0, s = 0.0;
+  // partial layout [3][Npad][nblk]: this channel's (count, mean, M2) rows are contiguous
+  const float* pn = partial + (size_t)c * nblk;
+  const float* pm = partial + ((size_t)Npad + c) * nblk;
+  const float* pq = partial + ((size_t)2 * Npad + c) * nblk;
   for (int b = threadIdx.x; b < nblk; b += 256) {
-    const float* p = partial + (size_t)b * 3 * Npad + c;
-    n += (double)p[0];
-    s += (double)p[0] * (double)p[Npad];
+    n += (double)pn[b];
+    s += (double)pn[b] * (double)pm[b];
   }
   n = block_sum_d(n, sh);
   s = block_sum_d(s, sh);
   const double mean = s / n;
   double m2 = 0.0;
   for (int b = threadIdx.x; b < nblk; b += 256) {
-    const float* p = partial + (size_t)b * 3 * Npad + c;
-    const double d = (double)p[Npad] - mean;
-    m2 += (double)p[2 * Npad] + (double)p[0] * d * d;
+    const double d = (double)pm[b] - mean;
+    m2 += (double)pq[b] + (double)pn[b] * d * d;
   }
   m2 = block_sum_d(m2, sh);
   if (threadIdx.x == 0) { out[c] = n; out[C + c] = mean; out[2 * C + c] = m2; }
@@ -383,18 +387,22 @@ __global__ void bn_bwd_sync_c_kernel(const double* __restrict__ sums, int C, dou
   c2[c] = (float)(sums[C + c] / n_global);
 }
 
-template <int VW>
+// TAP: fused perceptual-tap loss term / gradient (compile-time: the fp64 accumulator and the extra load cost
+// registers the plain variant, 97 % of the launches, must not pay for)
+template <int VW, bool TAP>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(LayerBwd L, int rows_per_block,
                                                             const float* __restrict__ c1,
                                                             const float* __restrict__ c2,
                                                             float* __restrict__ dy,
                                                             float* __restrict__ db_partial) {
   __shared__ float sh1[256 * VW];
+  __shared__ double shd[4];
   const int C = L.C, CV = C / VW, CB = CV < 256 ? CV : 256, RPP = 256 / CB;
   const int t = threadIdx.x, tc = t % CB, tr = t / CB;
   const size_t M = (size_t)L.B << (3 * L.lgS);
   const size_t r0 = (size_t)blockIdx.x * rows_per_block;
   const size_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+  double tap_sq = 0.0;       // sum (s - tap_ref)^2 over this block's elements (perceptual loss term)
   for (int cg = 0; cg < CV; cg += 256) {
     const int c = (cg + tc) * VW;
     Vec<VW> k1, k2, sg;
@@ -413,6 +421,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(LayerBwd L, int rows_
 #pragma unroll
       for (int j = 0; j < VW; ++j) tap.v[j] = 0.f;
       if (L.dtap) tap = vload<VW>(L.dtap + row * C + c);
+      if (TAP) {
+        // perceptual tap (vae/lattice_vae.py:257-270): d/ds of tap_coef/2 * (s - ref)^2, ref = the same layer's
+        // activation in the pass over y_true; the loss term itself is summed on the way (no separate pass)
+        const Vec<VW> rf = vload<VW>(L.tap_ref + row * C + c);
+#pragma unroll
+        for (int j = 0; j < VW; ++j) {
+          const float df = sv.v[j] - rf.v[j];
+          tap.v[j] += L.tap_coef * df;
+          tap_sq += (double)df * (double)df;
+        }
+      }
 #pragma unroll
       for (int j = 0; j < VW; ++j) {
         float ds = L.has_bn ? sg.v[j] * (d.v[j] - k1.v[j] - xh.v[j] * k2.v[j]) : d.v[j];
@@ -434,6 +453,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(LayerBwd L, int rows_
       }
       __syncthreads();
     }
+  }
+  if (TAP) {
+    const double tot = block_sum_d(tap_sq, shd);
+    if (threadIdx.x == 0) L.tap_partial[blockIdx.x] = tot;
   }
 }
 
@@ -482,10 +505,14 @@ int launch_layer_bwd(hipStream_t st, const LayerBwd& L, float* dy, float* ws_par
       ICS_HIP(hipGetLastError());
     }
   }
-  if (v4) hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(nblk), dim3(256), 0, st, L, rpb, c1, c2, dy,
-                             dbias ? ws_partial : nullptr);
-  else hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(nblk), dim3(256), 0, st, L, rpb, c1, c2, dy,
-                          dbias ? ws_partial : nullptr);
+  float* dbp = dbias ? ws_partial : nullptr;
+  if (L.tap_ref) {
+    if (v4) hipLaunchKernelGGL((bn_bwd_apply_kernel<4, true>), dim3(nblk), dim3(256), 0, st, L, rpb, c1, c2, dy, dbp);
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<1, true>), dim3(nblk), dim3(256), 0, st, L, rpb, c1, c2, dy, dbp);
+  } else {
+    if (v4) hipLaunchKernelGGL((bn_bwd_apply_kernel<4, false>), dim3(nblk), dim3(256), 0, st, L, rpb, c1, c2, dy, dbp);
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<1, false>), dim3(nblk), dim3(256), 0, st, L, rpb, c1, c2, dy, dbp);
+  }
   ICS_HIP(hipGetLastError());
   if (dbias) {
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3(L.C), dim3(256), 0, st, ws_partial, nblk, L.C, dbias);
@@ -818,16 +845,27 @@ __global__ __launch_bounds__(256) void sqdiff_kernel(const float* __restrict__ a
                                                       float coef, int accumulate) {
   __shared__ double sh[4];
   const int smp = blockIdx.x / blocks_per_sample, blk = blockIdx.x % blocks_per_sample;
-  const size_t chunk = (per_sample + blocks_per_sample - 1) / blocks_per_sample;
+  size_t chunk = (per_sample + blocks_per_sample - 1) / blocks_per_sample;
+  chunk = (chunk + 3) & ~(size_t)3;
   const size_t i0 = (size_t)blk * chunk, i1 = i0 + chunk < per_sample ? i0 + chunk : per_sample;
   const size_t base = (size_t)smp * per_sample;
   double acc = 0.0;
-  for (size_t i = i0 + threadIdx.x; i < i1; i += 256) {
-    const float d = b[base + i] - a[base + i];
-    acc += (double)d * (double)d;
-    if (grad) {
-      const float gv = coef * d;
-      grad[base + i] = accumulate ? grad[base + i] + gv : gv;
+  const bool v4 = (per_sample & 3) == 0 && grad == nullptr;     // eval path of the big taps: 16-byte loads
+  if (v4) {
+    for (size_t i = i0 + 4 * (size_t)threadIdx.x; i < i1; i += 1024) {
+      const float4 x = *reinterpret_cast<const float4*>(a + base + i);
+      const float4 y = *reinterpret_cast<const float4*>(b + base + i);
+      const float d0 = y.x - x.x, d1 = y.y - x.y, d2 = y.z - x.z, d3 = y.w - x.w;
+      acc += (double)d0 * d0 + (double)d1 * d1 + (double)d2 * d2 + (double)d3 * d3;
+    }
+  } else {
+    for (size_t i = i0 + threadIdx.x; i < i1; i += 256) {
+      const float d = b[base + i] - a[base + i];
+      acc += (double)d * (double)d;
+      if (grad) {
+        const float gv = coef * d;
+        grad[base + i] = accumulate ? grad[base + i] + gv : gv;
+      }
     }
   }
   acc = block_sum_d(acc, sh);
@@ -877,8 +915,7 @@ __global__ __launch_bounds__(256) void vae_loss_kernel(const float* __restrict__
                                                        int B, const double* __restrict__ mse_partial,
                                                        int n_mse, double n_elems,
                                                        const double* __restrict__ pm_partial,
-                                                       const int* __restrict__ pm_counts /*[4][2]: nblk/sample, per-sample elems*/,
-                                                       const float* __restrict__ pm_w, float alpha,
+                                                       PmSums pmc, float alpha,
                                                        float beta, float* __restrict__ metrics,
                                                        double* __restrict__ sums, int phase) {
   __shared__ double sh[4];
@@ -896,11 +933,11 @@ __global__ __launch_bounds__(256) void vae_loss_kernel(const float* __restrict__
     mse = block_sum_d(mse, sh);
     size_t off = 0;
     for (int l = 0; l < 4; ++l) {
-      const int nb = pm_counts[2 * l] * B;
+      const int nb = pmc.n[l];
       double s = 0.0;
       for (int i = threadIdx.x; i < nb; i += 256) s += pm_partial[off + i];
       s = block_sum_d(s, sh);
-      pm += (double)pm_w[l] * s / (double)pm_counts[2 * l + 1];
+      pm += (double)pmc.w[l] * s / pmc.per[l];
       off += nb;
     }
   }
@@ -928,10 +965,10 @@ __global__ void vae_dz_kernel(const float* __restrict__ mulv, int ld, int latent
       dz * eps[b * latent + j] * 0.5f * expf(0.5f * lv) + beta * (-0.5f) * (1.f - expf(lv)) / (float)B;
 }
 int launch_vae_loss(hipStream_t st, const float* mulv, int ld, int latent, int B, const double* mse_partial,
-                    int n_mse, double n_elems, const double* pm_partial, const int* pm_counts,
-                    const float* pm_w, float alpha, float beta, float* metrics, double* sums, int phase) {
+                    int n_mse, double n_elems, const double* pm_partial, const PmSums& pmc, float alpha, float beta,
+                    float* metrics, double* sums, int phase) {
   hipLaunchKernelGGL(vae_loss_kernel, dim3(1), dim3(256), 0, st, mulv, ld, latent, B, mse_partial, n_mse,
-                     n_elems, pm_partial, pm_counts, pm_w, alpha, beta, metrics, sums, phase);
+                     n_elems, pm_partial, pmc, alpha, beta, metrics, sums, phase);
   ICS_HIP(hipGetLastError());
   return 0;
 }

@@ -135,6 +135,9 @@ struct Net {
   int adam_t = 0;
   float lr = 1e-6f;
   bool packed_valid = false;
+  void* d_pack_jobs = nullptr;       // device copy of the recorded pack-job table (one launch per step)
+  int pack_njobs = -1;               // -1: not recorded yet
+  unsigned pack_nblocks = 0;
   int pool_ties_all = 1, bn_unbias = 1;
   Profiler prof;
   std::vector<std::unique_ptr<ConvLayer>> layers;
@@ -177,8 +180,10 @@ struct Net {
   ConvLayer* head = nullptr;
   float* head_bias_grad = nullptr;
   float* head_dw_tmp = nullptr;       // [128][ncls+1] head weight gradient before the soft | sig split
-  float* tap_copy[4] = {nullptr, nullptr, nullptr, nullptr};   // perceptual taps of the x pass
-  float* dtap[4] = {nullptr, nullptr, nullptr, nullptr};
+  float* tap_copy[4] = {nullptr, nullptr, nullptr, nullptr};   // perceptual taps of the pass over y_true
+  const float* tap_ref[4] = {nullptr, nullptr, nullptr, nullptr};   // set per VAE step: fused tap loss/gradient
+  float tap_coef[4] = {0, 0, 0, 0};
+  double* tap_partial[4] = {nullptr, nullptr, nullptr, nullptr};
   int resident_batch = 0;
   int last_batch = 0;                 // batch of the most recent forward (activation export)
 
@@ -187,8 +192,7 @@ struct Net {
   int ncond = 10, latent = 256, filters[4] = {16, 32, 64, 128};
   float alpha = 0.5f, beta = 3e-4f, pm_w[4] = {1, 1, 1, 1};
   float *cond_in = nullptr, *eps_in = nullptr, *z_buf = nullptr, *zc = nullptr, *recon = nullptr,
-        *drecon = nullptr, *dmulv = nullptr, *d_pm_w = nullptr;
-  int* d_pm_counts = nullptr;
+        *drecon = nullptr, *dmulv = nullptr;
   ConvLayer *enc_dense = nullptr, *zmulv = nullptr, *dec_dense = nullptr;
 
   ~Net() {
@@ -631,10 +635,11 @@ static int conv_grads_from_dy(Net& n, ConvLayer& L, int B, bool need_dA, bool pa
 }
 
 static int conv_backward(Net& n, ConvLayer& L, int B, GradSrc g0, GradSrc g1, const float* dtap, bool need_dA,
-                         bool param_grads) {
+                         bool param_grads, int tap = -1) {
   LayerBwd lb{};
   lb.s = L.s; lb.scale = L.scale; lb.shift = L.shift; lb.mean = L.mean; lb.rstd = L.rstd;
   lb.dtap = dtap; lb.g0 = g0; lb.g1 = g1;
+  if (tap >= 0) { lb.tap_ref = n.tap_ref[tap]; lb.tap_coef = n.tap_coef[tap]; lb.tap_partial = n.tap_partial[tap]; }
   lb.B = B; lb.S = L.S; lb.lgS = ilog2(L.S); lb.C = L.Cout;
   lb.has_bn = L.has_bn; lb.pre_act = L.pre_act; lb.post_act = L.post_act;
   lb.pool_ties_all = n.pool_ties_all;
@@ -777,8 +782,7 @@ static int unet_build(Net& n, const ics_unet_config& cfg) {
   return 0;
 }
 
-static int unet_pack(Net& n) {
-  if (n.packed_valid) return 0;
+static int unet_pack_jobs(Net& n) {
   for (int i = 0; i < 14; ++i) ICS_TRY(pack_layer(n, *n.layers[i], true));
   ConvLayer& H = *n.head;
   const int ncls = n.ncls;
@@ -788,9 +792,32 @@ static int unet_pack(Net& n) {
   ICS_TRY(launch_pack_fwd(n.st, wsig, 128, 1, H.wp, H.Kpad, H.Npad, 0, ncls, 0));
   ICS_TRY(launch_pack_bwd(n.st, wsoft, 1, 128, ncls, H.wf, H.Kpad_b, H.Npad_b, ncls + 1, 0, 1));
   ICS_TRY(launch_pack_bwd(n.st, wsig, 1, 128, 1, H.wf, H.Kpad_b, H.Npad_b, ncls + 1, ncls, 0));
+  return 0;
+}
+// The packed weight images are rebuilt after every parameter change with ONE launch: the per-layer pack calls
+// are recorded into a job table the first time (pointers and shapes never change for the life of the handle).
+static int run_pack_table(Net& n, int (*jobs)(Net&)) {
+  if (n.packed_valid) return 0;
+  if (n.pack_njobs < 0) {
+    void* rec = pack_table_record_begin();
+    const int rc = jobs(n);
+    std::vector<unsigned char> bytes;
+    int nj = 0; unsigned nb = 0;
+    pack_table_record_end(rec, &bytes, &nj, &nb);
+    ICS_TRY(rc);
+    unsigned char* d = nullptr;
+    ICS_TRY(n.alloc(&d, bytes.size() + 16));
+    ICS_HIP(hipMemcpyAsync(d, bytes.data(), bytes.size(), hipMemcpyHostToDevice, n.st));
+    ICS_HIP(hipStreamSynchronize(n.st));     // `bytes` is a host temporary
+    n.d_pack_jobs = d; n.pack_njobs = nj; n.pack_nblocks = nb;
+  }
+  n.prof.begin(n.st, "pack_weights", 0, 0);
+  ICS_TRY(launch_pack_table(n.st, n.d_pack_jobs, n.pack_njobs, n.pack_nblocks));
+  n.prof.end(n.st);
   n.packed_valid = true;
   return 0;
 }
+static int unet_pack(Net& n) { return run_pack_table(n, unet_pack_jobs); }
 
 // trunk forward; upto_c10 for the perceptual sub-model (lattice_vae.py:257-270)
 static int unet_forward_trunk(Net& n, int B, bool training, bool update_moving, bool upto_c10, const float* input) {
@@ -946,17 +973,19 @@ static int unet_backward(Net& n, int B) {
 // perceptual sub-model backward: gradients w.r.t. the input given dtap (weights frozen)
 static int unet_pm_backward(Net& n, int B) {
   UnetRefs r = unet_refs(n);
-  auto bw = [&](ConvLayer* L, GradSrc g0, const float* dtap, bool need_dA) {
-    return conv_backward(n, *L, B, g0, gs_none(), dtap, need_dA, false);
+  // the taps' squared-difference loss terms and their gradients are formed inside the BN-backward pass of the
+  // tap layers (tap >= 0): no separate sqdiff pass over the four tap tensors, no dtap buffers
+  auto bw = [&](ConvLayer* L, GradSrc g0, int tap, bool need_dA) {
+    return conv_backward(n, *L, B, g0, gs_none(), nullptr, need_dA, false, tap);
   };
-  ICS_TRY(bw(r.c10, gs_none(), n.dtap[3], true));
-  ICS_TRY(bw(r.c9, gs_direct(r.c10->dA, 512, 0), nullptr, true));
-  ICS_TRY(bw(r.c6, gs_pool(r.c9->dA, 256, *r.c6), n.dtap[2], true));
-  ICS_TRY(bw(r.c5, gs_direct(r.c6->dA, 128, 0), nullptr, true));
-  ICS_TRY(bw(r.c4, gs_pool(r.c5->dA, 128, *r.c4), n.dtap[1], true));
-  ICS_TRY(bw(r.c3, gs_direct(r.c4->dA, 64, 0), nullptr, true));
-  ICS_TRY(bw(r.c2, gs_pool(r.c3->dA, 64, *r.c2), n.dtap[0], true));
-  ICS_TRY(bw(r.c1, gs_direct(r.c2->dA, 32, 0), nullptr, true));
+  ICS_TRY(bw(r.c10, gs_none(), 3, true));
+  ICS_TRY(bw(r.c9, gs_direct(r.c10->dA, 512, 0), -1, true));
+  ICS_TRY(bw(r.c6, gs_pool(r.c9->dA, 256, *r.c6), 2, true));
+  ICS_TRY(bw(r.c5, gs_direct(r.c6->dA, 128, 0), -1, true));
+  ICS_TRY(bw(r.c4, gs_pool(r.c5->dA, 128, *r.c4), 1, true));
+  ICS_TRY(bw(r.c3, gs_direct(r.c4->dA, 64, 0), -1, true));
+  ICS_TRY(bw(r.c2, gs_pool(r.c3->dA, 64, *r.c2), 0, true));
+  ICS_TRY(bw(r.c1, gs_direct(r.c2->dA, 32, 0), -1, true));
   return 0;
 }
 
@@ -1050,8 +1079,6 @@ static int vae_build(Net& n, const ics_vae_config& cfg, Net* pm) {
   ICS_TRY(n.alloc(&n.recon, M * C));
   ICS_TRY(n.alloc(&n.drecon, M * C));
   ICS_TRY(n.alloc(&n.dmulv, (size_t)n.maxB * 2 * lat));
-  ICS_TRY(n.alloc(&n.d_pm_w, (size_t)4));
-  ICS_TRY(n.alloc(&n.d_pm_counts, (size_t)8));
   VaeRefs r = vae_refs(n);
   for (int i = 0; i < 4; ++i) ICS_TRY(alloc_layer(n, *r.e[i], true, true));
   ICS_TRY(alloc_layer(n, *r.e4, true, false));
@@ -1081,23 +1108,17 @@ static int vae_build(Net& n, const ics_vae_config& cfg, Net* pm) {
     UnetRefs u = unet_refs(*pm);
     ConvLayer* taps[4] = {u.c2, u.c4, u.c6, u.c10};
     ICS_CHECK(pm->maxB >= n.maxB && pm->d == d && pm->C == C, "perceptual U-Net shape mismatch");
-    int counts[8];
     for (int l = 0; l < 4; ++l) {
       const size_t cnt = pm->rows(*taps[l], pm->maxB) * taps[l]->Cout;
-      if (!pm->tap_copy[l]) { ICS_TRY(pm->alloc(&pm->tap_copy[l], cnt)); ICS_TRY(pm->alloc(&pm->dtap[l], cnt)); }
-      counts[2 * l] = 8;   // blocks per sample
-      counts[2 * l + 1] = taps[l]->S * taps[l]->S * taps[l]->S * taps[l]->Cout;
+      if (!pm->tap_copy[l]) ICS_TRY(pm->alloc(&pm->tap_copy[l], cnt));
     }
-    ICS_HIP(hipMemcpyAsync(n.d_pm_counts, counts, sizeof(counts), hipMemcpyHostToDevice, n.st));
-    ICS_HIP(hipMemcpyAsync(n.d_pm_w, n.pm_w, 4 * sizeof(float), hipMemcpyHostToDevice, n.st));
     ICS_HIP(hipStreamSynchronize(n.st));
     ICS_HIP(hipStreamSynchronize(pm->st));
   }
   return 0;
 }
 
-static int vae_pack(Net& n) {
-  if (n.packed_valid) return 0;
+static int vae_pack_jobs(Net& n) {
   VaeRefs r = vae_refs(n);
   for (auto& Lp : n.layers) {
     ConvLayer& L = *Lp;
@@ -1110,9 +1131,9 @@ static int vae_pack(Net& n) {
   ICS_TRY(launch_pack_fwd(n.st, n.tp(Z.t_gamma), lat, lat, Z.wp, Z.Kpad, Z.Npad, 0, lat, 0));
   ICS_TRY(launch_pack_bwd(n.st, n.tp(Z.t_w), 1, lat, lat, Z.wf, Z.Kpad_b, Z.Npad_b, 2 * lat, 0, 1));
   ICS_TRY(launch_pack_bwd(n.st, n.tp(Z.t_gamma), 1, lat, lat, Z.wf, Z.Kpad_b, Z.Npad_b, 2 * lat, lat, 0));
-  n.packed_valid = true;
   return 0;
 }
+static int vae_pack(Net& n) { return run_pack_table(n, vae_pack_jobs); }
 
 static int vae_encode_fwd(Net& n, int B, bool training) {
   ICS_TRY(vae_pack(n));
@@ -1156,14 +1177,13 @@ static int vae_step(Net& n, int B, bool training, float* metrics) {
     if ((rc = vae_encode_fwd(n, B, training))) break;
     if ((rc = vae_decode_fwd(n, B, training))) break;
     const size_t M = (size_t)B * n.d * n.d * n.d;
-    // perceptual pass on y_true, taps copied aside; then on y_pred (state kept for backward)
-    if ((rc = unet_forward_trunk(u, B, training, false, true, n.x_in))) break;
-    for (int l = 0; l < 4; ++l) {
-      const size_t cnt = u.rows(*taps[l], B) * taps[l]->Cout;
-      if (hipMemcpyAsync(u.tap_copy[l], taps[l]->s, cnt * sizeof(float), hipMemcpyDeviceToDevice, n.st) != hipSuccess) {
-        set_error("tap copy failed"); rc = -1; break;
-      }
-    }
+    // perceptual pass on y_true: the four tap layers write straight into tap_copy (nothing in the c1..c10 trunk
+    // reads a tap layer's s except its own pooling, which takes the pointer at launch time); then the pass on
+    // y_pred into the layers' own buffers (state kept for the backward pass)
+    float* own_s[4];
+    for (int l = 0; l < 4; ++l) { own_s[l] = taps[l]->s; taps[l]->s = u.tap_copy[l]; }
+    rc = unet_forward_trunk(u, B, training, false, true, n.x_in);
+    for (int l = 0; l < 4; ++l) taps[l]->s = own_s[l];
     if (rc) break;
     if ((rc = unet_forward_trunk(u, B, training, false, true, n.recon))) break;
     // loss terms (+ gradients when training)
@@ -1173,31 +1193,47 @@ static int vae_step(Net& n, int B, bool training, float* metrics) {
     if ((rc = launch_sqdiff(n.st, n.x_in, n.recon, B, M / B * n.C, mse_bps, mse_part, training ? n.drecon : nullptr,
                             (float)(2.0 / ((double)M * n.C)), 0))) break;
     double* pm_part = n.ws_dbl + off;
+    PmSums pmc{};
     size_t poff = 0;
     for (int l = 0; l < 4; ++l) {
       const size_t per = (size_t)taps[l]->S * taps[l]->S * taps[l]->S * taps[l]->Cout;
-      const float coef = (float)(2.0 * n.alpha * n.pm_w[l] / ((double)per * B));
-      if ((rc = launch_sqdiff(n.st, u.tap_copy[l], taps[l]->s, B, per, 8, pm_part + poff,
-                              training ? u.dtap[l] : nullptr, coef, 0))) break;
-      poff += (size_t)B * 8;
+      pmc.per[l] = (double)per; pmc.w[l] = n.pm_w[l];
+      if (training) {
+        // formed inside the BN-backward pass of the tap layer (unet_pm_backward): partials per block of that pass
+        LayerBwd lb{};
+        lb.B = B; lb.S = taps[l]->S; lb.lgS = ilog2(taps[l]->S); lb.C = taps[l]->Cout;
+        int rpb;
+        pmc.n[l] = bn_bwd_num_blocks(lb, &rpb);
+        u.tap_ref[l] = u.tap_copy[l];
+        u.tap_coef[l] = (float)(2.0 * n.alpha * n.pm_w[l] / ((double)per * B));
+        u.tap_partial[l] = pm_part + poff;
+      } else {
+        const int bps = (int)std::min<size_t>(256, std::max<size_t>(8, per / 16384));
+        pmc.n[l] = B * bps;
+        if ((rc = launch_sqdiff(n.st, u.tap_copy[l], taps[l]->s, B, per, bps, pm_part + poff, nullptr, 0.f, 0))) break;
+      }
+      poff += (size_t)pmc.n[l];
     }
     if (rc) break;
+    if (off + poff > n.ws_dbl_n) { set_error("loss partial workspace too small"); rc = -1; break; }
+    if (training) {
+      if ((rc = grads_begin(n))) break;
+      if ((rc = unet_pm_backward(u, B))) break;
+    }
     if (!n.comm) {
       if ((rc = launch_vae_loss(n.st, r.zml->s, 2 * n.latent, n.latent, B, mse_part, B * mse_bps, (double)M * n.C,
-                                pm_part, n.d_pm_counts, n.d_pm_w, n.alpha, n.beta, n.d_metrics))) break;
+                                pm_part, pmc, n.alpha, n.beta, n.d_metrics))) break;
     } else if (metrics) {
       // data parallel: all-reduce the sums (numerators / denominators), then form the means
       if ((rc = launch_vae_loss(n.st, r.zml->s, 2 * n.latent, n.latent, B, mse_part, B * mse_bps, (double)M * n.C,
-                                pm_part, n.d_pm_counts, n.d_pm_w, n.alpha, n.beta, n.d_metrics, n.d_red, 1))) break;
+                                pm_part, pmc, n.alpha, n.beta, n.d_metrics, n.d_red, 1))) break;
       if (ncclAllReduce(n.d_red, n.d_red, 5, ncclDouble, ncclSum, n.comm, n.st) != ncclSuccess) {
         set_error("ncclAllReduce(vae metrics) failed"); rc = -1; break;
       }
       if ((rc = launch_vae_loss(n.st, r.zml->s, 2 * n.latent, n.latent, B, mse_part, B * mse_bps, (double)M * n.C,
-                                pm_part, n.d_pm_counts, n.d_pm_w, n.alpha, n.beta, n.d_metrics, n.d_red, 2))) break;
+                                pm_part, pmc, n.alpha, n.beta, n.d_metrics, n.d_red, 2))) break;
     }
     if (training) {
-      if ((rc = grads_begin(n))) break;
-      if ((rc = unet_pm_backward(u, B))) break;
       hipLaunchKernelGGL(axpy_strided_kernel, dim3((unsigned)((M * n.C + 255) / 256)), dim3(256), 0, n.st, n.drecon,
                          ur.c1->dA, M, n.C, ur.c1->CinG);
       // decoder
