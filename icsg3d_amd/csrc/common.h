@@ -87,13 +87,31 @@ struct ConvGeom {
   int flags = 0;        // ConvFlags of the owning handle
 };
 
+// Backward-data launches can fold the NEXT layer's BatchNorm-backward reductions into their epilogue: the tile a
+// block just produced is dO of the producer layer P; with P's stored activations s and batch statistics at hand
+// the block adds its share of  sum d  and  sum d*xhat  (d = dO * post_act'(BN(s)), xhat = (s - mean) * rstd)
+// per channel -- the pass bn_bwd_reduce_kernel would otherwise make over dO and s.
+struct BwdStat {
+  const float* s = nullptr;       // P's stored activations [M][ld]
+  const float* mean = nullptr;
+  const float* rstd = nullptr;
+  const float* scale = nullptr;   // P's BN affine (only read when post_act != ACT_NONE)
+  const float* shift = nullptr;
+  float* partial = nullptr;       // out: [2][Npad][gridM] per-block column sums (block index fastest)
+  int post_act = ACT_NONE;
+  int ld = 0;
+};
+
 // ---------------------------------------------------------------- kernel launchers (conv_igemm.hip)
 // out[m*ldo + n] = pre_act( sum_k A[m][k] * W[k][n] + bias[n] ),  m over B*S^3 voxels.
 // stat_partial: optional [3][Npad][gridM] (count, mean, M2) of the stored values per block column (block index fastest).
 int launch_conv_fwd(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int nsrc,
                     const float* wpacked, const float* bias, float* out, int ldo, int pre_act,
                     float* stat_partial, int* stat_rows_per_block, int accumulate = 0,
-                    float* splitk_ws = nullptr, size_t splitk_ws_floats = 0);
+                    float* splitk_ws = nullptr, size_t splitk_ws_floats = 0, const BwdStat* bwd = nullptr,
+                    int* bwd_blocks = nullptr);
+// bwd / bwd_blocks: see BwdStat; *bwd_blocks = number of row blocks written to bwd->partial, or 0 when this launch
+// could not fold the reductions (split-K or thin-N path) and the caller must run them separately
 size_t conv_fwd_workspace_floats(const ConvGeom& g, const ConvSrc* src, int nsrc);
 int launch_conv_fwd_par(hipStream_t st, const ConvGeom& g_lowres, const ConvSrc& src, const float* wpar, float* out,
                         int ldo, const float* bias = nullptr, int pre_act = ACT_NONE, float* stat_partial = nullptr,

@@ -187,14 +187,16 @@ __device__ __forceinline__ float gather_scalar(const ConvSrc& s0, const ConvSrc&
 // input, run on the LOW-RES grid: class p = blockIdx.y = (pz,py,px) reads the 2x2x2 neighbourhood
 // a + e + p - 1 (e in {0,1}^3) with pre-summed weights wp[p] and scatters row a to fine voxel 2a + p.
 // accumulate: the epilogue adds the previous contents of out before bias / activation / statistics.
+// FOLD (backward-data launches only): the epilogue also sums the NEXT layer's BatchNorm-backward terms over the tile
+// (BwdStat) -- a compile-time variant so that the forward instantiations keep their register budget.
 template <int WM, int WN, int TM, int TN, bool VEC, int ABL = 0, bool AFF = true, bool UP = true, bool THIN = false,
-          bool REUSE = false, bool PAR = false, bool NOACT = false>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, ConvSrc s1,
+          bool REUSE = false, bool PAR = false, bool NOACT = false, bool FOLD = false>
+__global__ __launch_bounds__(256, FOLD ? 2 : ((REUSE && PAR) ? 3 : 1)) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, ConvSrc s1,
                                                         const float* __restrict__ wp,
                                                         const float* __restrict__ bias,
                                                         float* __restrict__ out, int ldo, int pre_act,
                                                         float* __restrict__ stat_partial, int gridM,
-                                                        int gridN, int accumulate) {
+                                                        int gridN, int accumulate, BwdStat bs) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int B_FLOATS = 32 * BN;
   constexpr int RA = BM / 32;    // VEC: float4 A loads per thread per chunk
@@ -675,6 +677,63 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
 
   // ---- epilogue: bias + activation, store, per-block BatchNorm partial statistics
   const int mrow0 = mb * BM + wm * TM * 32 + 4 * lh;
+  if (FOLD) {
+    // backward-data tile = dO of the producer layer P: store it and add this tile's share of P's BatchNorm-backward
+    // sums  S1 = sum d,  S2 = sum d * xhat  (d = dO * post_act'(BN(s)), xhat = (s - mean) * rstd).  P's activations
+    // are fetched 16 rows at a time (the compiler barrier keeps at most 16 loads in flight: register budget).
+    float* red1 = smem;               // [WM][BN]
+    float* red2 = smem + WM * BN;     // [WM][BN]
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * TN * 32 + j * 32 + li;
+      const bool nvalid = n < g.Cout;
+      const int nc = nvalid ? n : 0;
+      const float b_mu = bs.mean[nc], b_rs = bs.rstd[nc];
+      const float b_sc = bs.post_act != ACT_NONE ? bs.scale[nc] : 1.f;
+      const float b_sh = bs.post_act != ACT_NONE ? bs.shift[nc] : 0.f;
+      float a1 = 0.f, a2 = 0.f;
+      // 32-bit byte offsets from wave-uniform bases (sources are < 4 GiB, checked at launch): one VGPR per address
+      const char* sbase = reinterpret_cast<const char*>(bs.s);
+      char* obase = reinterpret_cast<char*>(out);
+      const unsigned s_ldb = (unsigned)bs.ld * 4u, o_ldb = (unsigned)ldo * 4u, colb = (unsigned)nc * 4u;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        float sv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const unsigned m = (unsigned)(mrow0 + i * 32 + (r & 3) + 8 * (r >> 2));
+          sv[r] = *reinterpret_cast<const float*>(sbase + min(m, (unsigned)(M - 1)) * s_ldb + colb);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const unsigned m = (unsigned)(mrow0 + i * 32 + (r & 3) + 8 * (r >> 2));
+          const bool ok = m < (unsigned)M && nvalid;
+          const float v = acc[i][j][r];
+          const float d = ok ? v * act_grad(fmaf(sv[r], b_sc, b_sh), bs.post_act) : 0.f;
+          a1 += d;
+          a2 = fmaf(d, (sv[r] - b_mu) * b_rs, a2);
+          if (ok) *reinterpret_cast<float*>(obase + m * o_ldb + colb) = v;
+        }
+        asm volatile("" ::: "memory");
+      }
+      a1 += __shfl_xor(a1, 32);
+      a2 += __shfl_xor(a2, 32);
+      if (lh == 0) {
+        red1[wm * BN + wn * TN * 32 + j * 32 + li] = a1;
+        red2[wm * BN + wn * TN * 32 + j * 32 + li] = a2;
+      }
+    }
+    __syncthreads();
+    if (t < BN) {
+      float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) { a1 += red1[w * BN + t]; a2 += red2[w * BN + t]; }
+      float* sp = bs.partial + (size_t)(n0 + t) * gridM + mb;
+      sp[0] = a1;
+      sp[(size_t)g.Npad * gridM] = a2;
+    }
+    return;
+  }
   float colsum[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -757,16 +816,17 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(ConvGeom g, ConvSrc s0, C
 }
 
 template <int WM, int WN, int TM, int TN, bool VEC, int ABL = 0, bool AFF = true, bool UP = true, bool THIN = false,
-          bool REUSE = false, bool PAR = false, bool NOACT = false>
+          bool REUSE = false, bool PAR = false, bool NOACT = false, bool FOLD = false>
 static int launch_fwd_cfg(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, const ConvSrc& s1,
                           const float* wp, const float* bias, float* out, int ldo, int pre_act,
-                          float* stat_partial, int* rows_per_block, int accumulate = 0, int ksplit = 1) {
+                          float* stat_partial, int* rows_per_block, int accumulate = 0, int ksplit = 1,
+                          const BwdStat* bwd = nullptr) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const int M = g.B << (3 * g.lgS);
   const int gridM = (M + BM - 1) / BM, gridN = g.Npad / BN;
   const int arows = REUSE ? BM + (BM >> g.lgS) + 1 : BM;
   const size_t lds = (size_t)(arows * kLDA + 2 * 32 * BN) * sizeof(float);
-  auto kern = conv_fwd_kernel<WM, WN, TM, TN, VEC, ABL, AFF, UP, THIN, REUSE, PAR, NOACT>;
+  auto kern = conv_fwd_kernel<WM, WN, TM, TN, VEC, ABL, AFF, UP, THIN, REUSE, PAR, NOACT, FOLD>;
   static DevOnce attr;
   int dev;
   if (attr.need(&dev)) {
@@ -779,10 +839,12 @@ static int launch_fwd_cfg(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, 
   static const std::string id = std::string("conv_fwd_kernel<") + std::to_string(WM) + ", " + std::to_string(WN) + ", " +
                                 std::to_string(TM) + ", " + std::to_string(TN) + ", " + tf(VEC) + ", " +
                                 std::to_string(ABL) + ", " + tf(AFF) + ", " + tf(UP) + ", " + tf(THIN) + ", " +
-                                tf(REUSE) + ", " + tf(PAR) + ", " + tf(NOACT) + ">";
+                                tf(REUSE) + ", " + tf(PAR) + ", " + tf(NOACT) + (FOLD ? ", true>" : ">");
   g_last_kernel_id = id.c_str();
+  BwdStat bs_arg;
+  if (FOLD) bs_arg = *bwd;
   hipLaunchKernelGGL(kern, dim3(gridM * gridN, PAR ? 8 : 1, ksplit), dim3(256), lds, st, g, s0, s1, wp, bias, out, ldo,
-                     pre_act, stat_partial, gridM, gridN, accumulate);
+                     pre_act, stat_partial, gridM, gridN, accumulate, bs_arg);
   ICS_HIP(hipGetLastError());
   return 0;
 }
@@ -1100,18 +1162,31 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
 
 static int launch_conv_fwd_inner(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int nsrc,
                                  const float* wp, const float* bias, float* out, int ldo, int pre_act,
-                                 float* stat_partial, int* rows_per_block, int accumulate, int ksplit);
+                                 float* stat_partial, int* rows_per_block, int accumulate, int ksplit,
+                                 const BwdStat* bwd = nullptr);
 
 int launch_conv_fwd(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int nsrc,
                     const float* wp, const float* bias, float* out, int ldo, int pre_act,
-                    float* stat_partial, int* rows_per_block, int accumulate, float* ws, size_t ws_floats) {
+                    float* stat_partial, int* rows_per_block, int accumulate, float* ws, size_t ws_floats,
+                    const BwdStat* bwd, int* bwd_blocks) {
   ConvSrc s0 = src[0], s1 = src[nsrc > 1 ? 1 : 0];
   if (nsrc == 1) s1.C = 0;
   int ks = ws ? fwd_splitk_plan(g, s0, s1, nsrc) : 1;
   // workspaces are sized at the handle's maximum batch; a smaller batch may plan more splits than fit: run unsplit
   if (ks > 1 && (size_t)ks * ((size_t)g.B << (3 * g.lgS)) * g.Npad > ws_floats) ks = 1;
-  if (ks <= 1) return launch_conv_fwd_inner(st, g, src, nsrc, wp, bias, out, ldo, pre_act, stat_partial,
-                                            rows_per_block, accumulate, 1);
+  if (bwd_blocks) *bwd_blocks = 0;
+  if (ks <= 1) {
+    const bool fold = bwd != nullptr && bwd->partial != nullptr && !thin_n_ok(g, src[0], nsrc) &&
+                      fwd_is_vec(g, s0, s1) && !conv_is_thin(g, s0, nsrc) && s0.scale == nullptr && !s0.up &&
+                      (nsrc < 2 || (s1.scale == nullptr && !s1.up)) && bias == nullptr && stat_partial == nullptr &&
+                      !accumulate;
+    int rpb = 0;
+    ICS_TRY(launch_conv_fwd_inner(st, g, src, nsrc, wp, bias, out, ldo, pre_act, stat_partial, &rpb, accumulate, 1,
+                                  fold ? bwd : nullptr));
+    if (rows_per_block) *rows_per_block = rpb;
+    if (fold && bwd_blocks) *bwd_blocks = (int)((((size_t)g.B << (3 * g.lgS)) + rpb - 1) / rpb);
+    return 0;
+  }
   const int M = g.B << (3 * g.lgS);
   ICS_CHECK((size_t)ks * M * g.Npad <= ws_floats, "forward split-K workspace too small");
   ICS_TRY(launch_conv_fwd_inner(st, g, src, nsrc, wp, nullptr, ws, g.Npad, ACT_NONE, nullptr, nullptr, 0, ks));
@@ -1124,7 +1199,8 @@ int launch_conv_fwd(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int n
 
 static int launch_conv_fwd_inner(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int nsrc,
                                  const float* wp, const float* bias, float* out, int ldo, int pre_act,
-                                 float* stat_partial, int* rows_per_block, int accumulate, int ksplit) {
+                                 float* stat_partial, int* rows_per_block, int accumulate, int ksplit,
+                                 const BwdStat* bwd) {
   if (ksplit == 1 && thin_n_ok(g, src[0], nsrc))
     return launch_thin_n_fwd(st, g, src[0], wp, bias, out, ldo, pre_act, stat_partial, rows_per_block, accumulate);
   ConvSrc s0 = src[0], s1 = src[nsrc > 1 ? 1 : 0];
@@ -1145,20 +1221,27 @@ static int launch_conv_fwd_inner(hipStream_t st, const ConvGeom& g, const ConvSr
   ICS_CHECK(((size_t)g.B << (3 * g.lgS)) * (size_t)std::max(s0.C, s1.C) * 4 <= 0xffffffffull,
             "conv source larger than 4 GiB");
   const bool no_reuse = (g.flags & CF_NO_REUSE) != 0;   // A/B switch (tests, benchmarking)
+  // BatchNorm-backward sums folded into the epilogue: only the plain-source vector instantiations carry the variant
+  const bool fold = bwd != nullptr && bwd->partial != nullptr && ksplit == 1 && vec && !thin && variant == 0 &&
+                    bias == nullptr && stat_partial == nullptr && !accumulate;
   int bm, bn;
   pick_fwd_tile(g, &bm, &bn);
-#define ICS_FWD_ARGS st, g, s0, s1, wp, bias, out, ldo, pre_act, stat_partial, rows_per_block, accumulate, ksplit
+#define ICS_FWD_ARGS st, g, s0, s1, wp, bias, out, ldo, pre_act, stat_partial, rows_per_block, accumulate, ksplit, bwd
 #define ICS_FWD(WM, WN, TM, TN)                                                                 \
   do {                                                                                          \
     if (thin) return launch_fwd_cfg<WM, WN, TM, TN, true, 0, true, true, true>(ICS_FWD_ARGS);   \
     if (!vec) return launch_fwd_cfg<WM, WN, TM, TN, false, 0, true, true>(ICS_FWD_ARGS);        \
     if (g.taps == 27 && g.S >= 4 && g.S <= (WM) * (TM) * 32 && !no_reuse) {                      \
+      if (variant == 0 && fold)                                                                 \
+        return launch_fwd_cfg<WM, WN, TM, TN, true, 0, false, false, false, true, false, false, true>(ICS_FWD_ARGS); \
       if (variant == 0) return launch_fwd_cfg<WM, WN, TM, TN, true, 0, false, false, false, true>(ICS_FWD_ARGS); \
       if (variant == 1 && noact)                                                                \
         return launch_fwd_cfg<WM, WN, TM, TN, true, 0, true, false, false, true, false, true>(ICS_FWD_ARGS);     \
       if (variant == 1) return launch_fwd_cfg<WM, WN, TM, TN, true, 0, true, false, false, true>(ICS_FWD_ARGS);  \
       return launch_fwd_cfg<WM, WN, TM, TN, true, 0, true, true, false, true>(ICS_FWD_ARGS);    \
     }                                                                                           \
+    if (variant == 0 && fold)                                                                   \
+      return launch_fwd_cfg<WM, WN, TM, TN, true, 0, false, false, false, false, false, false, true>(ICS_FWD_ARGS); \
     if (variant == 0) return launch_fwd_cfg<WM, WN, TM, TN, true, 0, false, false>(ICS_FWD_ARGS); \
     if (variant == 1) return launch_fwd_cfg<WM, WN, TM, TN, true, 0, true, false>(ICS_FWD_ARGS);  \
     return launch_fwd_cfg<WM, WN, TM, TN, true, 0, true, true>(ICS_FWD_ARGS);                   \

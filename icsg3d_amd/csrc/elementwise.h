@@ -57,8 +57,15 @@ int launch_bn_finalize(hipStream_t st, const float* partial, int nblk, int Npad,
 int launch_bn_eval_prepare(hipStream_t st, const BnParams& bn, int C);
 int launch_pool_fwd(hipStream_t st, const float* s, const float* scale, const float* shift, int act,
                     int B, int S, int C, float* out, unsigned char* idx);
+// per-block (sum d, sum d*xhat) already produced by the backward-data launch that wrote dO (BwdStat in common.h):
+// [2][ld][nblk]; nblk == 0 -> not available, run bn_bwd_reduce
+struct BwdPre {
+  const float* partial;
+  int nblk, ld;
+};
 int launch_layer_bwd(hipStream_t st, const LayerBwd& L, float* dy, float* ws_partial, float* c1c2,
-                     float* dgamma, float* dbeta, float* dbias, const BnSync* sync = nullptr);
+                     float* dgamma, float* dbeta, float* dbias, const BnSync* sync = nullptr,
+                     const BwdPre* pre = nullptr);
 size_t layer_bwd_workspace_floats(const LayerBwd& L);
 int bn_bwd_num_blocks(const LayerBwd& L, int* rows_per_block);
 // perceptual-loss partial sums handed to vae_loss: n[l] partials for tap l, each tap's per-sample element count
@@ -70,7 +77,8 @@ struct PmSums {
 };
 int launch_head(hipStream_t st, float* z, int ldz, int ncls, const unsigned char* labels, size_t M,
                 int mode, int want_grad, float wsoft, double* partial, int partial_blocks,
-                float* metrics, int* nblk_out = nullptr);
+                float* metrics, int* nblk_out = nullptr, float* dz_colsum = nullptr);
+// dz_colsum: optional [blocks][ncls+1] per-block column sums of the dz the kernel writes (head bias gradients)
 // phase 0: reduce block partials + finalize; 1: reduce only -> sums[7]; 2: finalize from sums[7]
 int launch_head_metrics(hipStream_t st, const double* partial, int nblk, double M, float* metrics, double* sums,
                         int phase);

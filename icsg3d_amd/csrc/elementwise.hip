@@ -346,8 +346,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(LayerBwd L, int rows
       const int tcc = col / VW, jj = col % VW;
       float s1 = 0.f, s2 = 0.f;
       for (int r = 0; r < RPP; ++r) { s1 += sh1[(r * CB + tcc) * VW + jj]; s2 += sh2[(r * CB + tcc) * VW + jj]; }
-      partial[((size_t)blockIdx.x * 2 + 0) * C + cg * VW + col] = s1;
-      partial[((size_t)blockIdx.x * 2 + 1) * C + cg * VW + col] = s2;
+      // layout [2][C][blocks] (block index fastest): the finalize kernel reads a channel's partials contiguously
+      partial[((size_t)0 * C + cg * VW + col) * gridDim.x + blockIdx.x] = s1;
+      partial[((size_t)1 * C + cg * VW + col) * gridDim.x + blockIdx.x] = s2;
     }
     __syncthreads();
   }
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(LayerBwd L, int rows
 // the all-reduce over ranks bn_bwd_sync_c_kernel divides by the GLOBAL element count.  dgamma/dbeta
 // stay the local sums (the gradient all-reduce adds the ranks later).
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial,
-                                                               int nblk, int C, double n,
+                                                               int nblk, int C, int ld, double n,
                                                                float* __restrict__ c1,
                                                                float* __restrict__ c2,
                                                                float* __restrict__ dgamma,
@@ -367,9 +368,11 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   __shared__ double sh[4];
   const int c = blockIdx.x;
   double s1 = 0.0, s2 = 0.0;
+  const float* p1 = partial + (size_t)c * nblk;                 // [2][ld][nblk]
+  const float* p2 = partial + ((size_t)ld + c) * nblk;
   for (int b = threadIdx.x; b < nblk; b += 256) {
-    s1 += (double)partial[((size_t)b * 2 + 0) * C + c];
-    s2 += (double)partial[((size_t)b * 2 + 1) * C + c];
+    s1 += (double)p1[b];
+    s2 += (double)p2[b];
   }
   s1 = block_sum_d(s1, sh);
   s2 = block_sum_d(s2, sh);
@@ -483,7 +486,7 @@ int bn_bwd_num_blocks(const LayerBwd& L, int* rows_per_block) {
 }
 
 int launch_layer_bwd(hipStream_t st, const LayerBwd& L, float* dy, float* ws_partial, float* c1c2,
-                     float* dgamma, float* dbeta, float* dbias, const BnSync* sync) {
+                     float* dgamma, float* dbeta, float* dbias, const BnSync* sync, const BwdPre* pre) {
   int rpb;
   const int nblk = bn_bwd_num_blocks(L, &rpb);
   const double n = (double)((size_t)L.B << (3 * L.lgS));
@@ -491,10 +494,17 @@ int launch_layer_bwd(hipStream_t st, const LayerBwd& L, float* dy, float* ws_par
   float* c2 = c1c2 + L.C;
   const bool v4 = (L.C % 4 == 0);
   if (L.has_bn) {
-    if (v4) hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, dim3(nblk), dim3(256), 0, st, L, rpb, ws_partial);
-    else hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(nblk), dim3(256), 0, st, L, rpb, ws_partial);
-    ICS_HIP(hipGetLastError());
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(L.C), dim3(256), 0, st, ws_partial, nblk, L.C, n, c1,
+    const float* red = ws_partial;
+    int red_n = nblk, red_ld = L.C;
+    if (pre != nullptr && pre->nblk > 0) {
+      // the backward-data launch that produced dO already summed d and d*xhat per block (BwdStat)
+      red = pre->partial; red_n = pre->nblk; red_ld = pre->ld;
+    } else {
+      if (v4) hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, dim3(nblk), dim3(256), 0, st, L, rpb, ws_partial);
+      else hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(nblk), dim3(256), 0, st, L, rpb, ws_partial);
+      ICS_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(L.C), dim3(256), 0, st, red, red_n, L.C, red_ld, n, c1,
                        c2, dgamma, dbeta, sync ? sync->local : nullptr);
     ICS_HIP(hipGetLastError());
     if (sync) {   // every rank holds the same number of rows (equal shards): n_global = n * nranks
@@ -540,9 +550,14 @@ size_t layer_bwd_workspace_floats(const LayerBwd& L) {
 __global__ __launch_bounds__(256) void head_kernel(float* __restrict__ z, int ldz, int ncls,
                                                    const unsigned char* __restrict__ labels, size_t M,
                                                    int rows_per_block, int mode, int want_grad,
-                                                   float wsoft, float inv_bv, double* __restrict__ partial) {
+                                                   float wsoft, float inv_bv, double* __restrict__ partial,
+                                                   float* __restrict__ dz_colsum) {
   constexpr int J = 8;
   __shared__ double shd[16][6];
+  __shared__ float shc[4][132];
+  float cacc[J], cacc_sig = 0.f;          // column sums of dz over this lane's voxels (head bias gradients)
+#pragma unroll
+  for (int j = 0; j < J; ++j) cacc[j] = 0.f;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sl = lane & 15, grp = lane >> 4;           // class slot, voxel slot inside the wave
   const int nj = (ncls + 15) >> 4;                     // class columns per lane actually used (6 for 95)
@@ -628,12 +643,30 @@ __global__ __launch_bounds__(256) void head_kernel(float* __restrict__ z, int ld
 #pragma unroll
       for (int j = 0; j < J; ++j) {
         const int c = sl + 16 * j;
-        if (j < nj && c < ncls) zr[c] = gs * (p[j] - (c == lab ? 1.f : 0.f));
+        const float dzv = gs * (p[j] - (c == lab ? 1.f : 0.f));
+        if (j < nj && c < ncls) { zr[c] = dzv; cacc[j] += dzv; }
       }
-      if (sl == 0) zr[ncls] = inside_s ? (ps - tsig) * inv_bv : 0.f;
+      const float dzs = inside_s ? (ps - tsig) * inv_bv : 0.f;
+      if (sl == 0) { zr[ncls] = dzs; cacc_sig += dzs; }
     }
   }
   if (mode == 0) return;
+  if (want_grad && dz_colsum != nullptr) {
+    // per-block column sums of dz (soft | sig bias gradients): 4 voxel slots x 4 waves, fixed order
+#pragma unroll
+    for (int j = 0; j < J; ++j) { cacc[j] += __shfl_xor(cacc[j], 16); cacc[j] += __shfl_xor(cacc[j], 32); }
+    cacc_sig += __shfl_xor(cacc_sig, 16); cacc_sig += __shfl_xor(cacc_sig, 32);
+    if (grp == 0) {
+#pragma unroll
+      for (int j = 0; j < J; ++j) shc[wave][sl + 16 * j] = cacc[j];
+      if (sl == 0) shc[wave][128] = cacc_sig;
+    }
+    __syncthreads();
+    if (threadIdx.x <= ncls) {
+      const int c = threadIdx.x == ncls ? 128 : threadIdx.x;
+      dz_colsum[(size_t)blockIdx.x * (ncls + 1) + threadIdx.x] = shc[0][c] + shc[1][c] + shc[2][c] + shc[3][c];
+    }
+  }
   if (sl == 0) {
     const int q = wave * 4 + grp;
     shd[q][0] = a_ls; shd[q][1] = a_lg; shd[q][2] = a_tp;
@@ -697,13 +730,13 @@ int launch_head_metrics(hipStream_t st, const double* partial, int nblk, double 
 
 int launch_head(hipStream_t st, float* z, int ldz, int ncls, const unsigned char* labels, size_t M,
                 int mode, int want_grad, float wsoft, double* partial, int partial_blocks,
-                float* metrics, int* nblk_out) {
+                float* metrics, int* nblk_out, float* dz_colsum) {
   ICS_CHECK(ncls <= 128, "head kernel supports at most 128 classes");
   int rpb = (int)((M + partial_blocks - 1) / partial_blocks);
   rpb = (rpb + 15) / 16 * 16;
   const int nblk = (int)((M + rpb - 1) / rpb);
   hipLaunchKernelGGL(head_kernel, dim3(nblk), dim3(256), 0, st, z, ldz, ncls, labels, M, rpb, mode,
-                     want_grad, wsoft, (float)(1.0 / (double)M), partial);
+                     want_grad, wsoft, (float)(1.0 / (double)M), partial, dz_colsum);
   ICS_HIP(hipGetLastError());
   if (nblk_out) *nblk_out = nblk;
   if (mode != 0 && metrics != nullptr) ICS_TRY(launch_head_metrics(st, partial, nblk, (double)M, metrics, nullptr, 0));

@@ -89,6 +89,8 @@ struct ConvLayer {
   std::string name;
   int Cin = 0, Cout = 0, taps = 27, S = 1;
   int flags = 0;                        // ConvFlags of the owning handle (carried into every ConvGeom)
+  int bwd_pre_nblk = 0, bwd_pre_ld = 0; // > 0: this layer's BN-backward sums are in ws_bwd2 (set by the consumer's
+                                        // backward-data launch, consumed by conv_backward)
   int CinG = 0;                         // GEMM input channels: Cin, or Cin zero-padded to 4/16/32k when the
                                         // virtual input is materialised (thin / broadcast inputs: c1, e0)
   float* pad_in = nullptr;              // [M][CinG] materialised input (padded layers only)
@@ -144,6 +146,7 @@ struct Net {
   // shared workspaces
   float* ws_stat = nullptr;  size_t ws_stat_n = 0;
   float* ws_bwd = nullptr;   size_t ws_bwd_n = 0;
+  float* ws_bwd2 = nullptr;  size_t ws_bwd2_n = 0;    // BN-backward sums folded into a backward-data epilogue
   float* ws_wgrad = nullptr; size_t ws_wgrad_n = 0;
   float* ws_fwd = nullptr;   size_t ws_fwd_n = 0;     // forward / backward-data split-K partial sums
   bool splitk = false;       // split-K only inside train steps: its plan depends on the batch size, and
@@ -398,6 +401,11 @@ static int alloc_workspaces(Net& n, bool need_bwd) {
   if (need_bwd) {
     ICS_TRY(n.alloc(&n.ws_bwd, n.ws_bwd_n + 16));
     ICS_TRY(n.alloc(&n.ws_wgrad, wg + 16));
+    size_t b2 = 0;    // [2][Npad][ceil(M/64)] for the widest layer
+    for (auto& Lp : n.layers)
+      if (Lp->has_bn) b2 = std::max(b2, (size_t)2 * Lp->Npad * ((n.rows(*Lp, n.maxB) + 63) / 64));
+    n.ws_bwd2_n = b2;
+    ICS_TRY(n.alloc(&n.ws_bwd2, b2 + 16));
   }
   n.ws_dbl_n = 1 << 16;
   ICS_TRY(n.alloc(&n.ws_dbl, n.ws_dbl_n));
@@ -546,10 +554,25 @@ static GradSrc gs_pool(const float* p, int ld, const ConvLayer& producer) {
   return GradSrc{p, ld, 0, GS_POOL, producer.pooled, producer.pool_idx};
 }
 
+// BwdStat for the backward-data launch whose output is dO of `next` (its only consumer); empty when not applicable
+static BwdStat bwd_stat_for(Net& n, ConvLayer* next, int B) {
+  BwdStat bs;
+  if (next == nullptr || !next->has_bn || getenv("ICSG3D_NO_BWD_FOLD")) return bs;
+  if ((size_t)2 * next->Npad * ((n.rows(*next, B) + 63) / 64) > n.ws_bwd2_n) return bs;
+  bs.s = next->s; bs.mean = next->mean; bs.rstd = next->rstd; bs.scale = next->scale; bs.shift = next->shift;
+  bs.partial = n.ws_bwd2; bs.post_act = next->post_act; bs.ld = next->Cout;
+  return bs;
+}
+static void bwd_stat_done(ConvLayer* next, const BwdStat& bs, int blocks, int npad) {
+  if (next == nullptr) return;
+  next->bwd_pre_nblk = bs.partial ? blocks : 0;
+  next->bwd_pre_ld = npad;
+}
+
 // Up-split backward of a [skip | upsampled] concat conv: with dyS = dy pooled per tap onto the low-res
 // grid (pool27), the up channels need only  dW_up = xl^T dyS  and  dxl = dyS W_up  on M/8 rows; the skip
 // channels run the ordinary kernels on a Cs-channel problem.  Exact (a reassociation of the same sums).
-static int conv_grads_split_up(Net& n, ConvLayer& L, int B) {
+static int conv_grads_split_up(Net& n, ConvLayer& L, int B, ConvLayer* next) {
   const size_t M = n.rows(L, B);
   const double fl_skip = 2.0 * M * 27 * L.Cs * L.Cout, fl_up = 2.0 * (M / 8) * 27 * L.Cu * L.Cout;
   n.prof.begin(n.st, "pool27:" + L.name, 0, 4.0 * M * L.Cout * (1 + 27.0 / 8));
@@ -593,16 +616,20 @@ static int conv_grads_split_up(Net& n, ConvLayer& L, int B) {
     ConvSrc sd = src_plain(L.dyS, L.ldS);
     n.prof.begin(n.st, "conv_dgrad:" + L.name + ".up|", fl_up,
                  4.0 * (M / 8 * L.Cu + M / 8 * 27.0 * L.Cout + 27.0 * L.Cu * L.Cout));
+    const BwdStat bs = bwd_stat_for(n, next, B);    // next = the producer of the upsampled channels
+    int blocks = 0;
     ICS_TRY(launch_conv_fwd(n.st, g, &sd, 1, L.w_up, nullptr, L.dxl, L.Cu, ACT_NONE, nullptr, nullptr, 0, n.fws(),
-                            n.ws_fwd_n));
+                            n.ws_fwd_n, &bs, &blocks));
+    bwd_stat_done(next, bs, blocks, g.Npad);
     n.prof.end(n.st);
   }
   return 0;
 }
 
 // weight / input gradients given L.dy
-static int conv_grads_from_dy(Net& n, ConvLayer& L, int B, bool need_dA, bool param_grads) {
-  if (L.split_up && need_dA && param_grads) return conv_grads_split_up(n, L, B);
+static int conv_grads_from_dy(Net& n, ConvLayer& L, int B, bool need_dA, bool param_grads, ConvLayer* next) {
+  if (L.split_up && need_dA && param_grads) return conv_grads_split_up(n, L, B, next);
+  if (L.split_up) next = nullptr;   // direct path of an up-split layer: dA covers [skip | up] channels
   const ConvGeom g = geom_fwd(L, B);
   const size_t M = n.rows(L, B);
   if (param_grads) {
@@ -627,15 +654,20 @@ static int conv_grads_from_dy(Net& n, ConvLayer& L, int B, bool need_dA, bool pa
     ConvSrc sdy = src_plain(L.dy, L.Cout);
     n.prof.begin(n.st, "conv_dgrad:" + L.name + "|", 2.0 * M * L.taps * L.Cin * L.Cout,
                  4.0 * (M * L.Cin + M * L.Cout + (double)L.taps * L.Cin * L.Cout));
+    const BwdStat bs = bwd_stat_for(n, next, B);
+    int blocks = 0;
     ICS_TRY(launch_conv_fwd(n.st, gb, &sdy, 1, L.wf, nullptr, L.dA, L.CinG, ACT_NONE, nullptr, nullptr, 0, n.fws(),
-                            n.ws_fwd_n));
+                            n.ws_fwd_n, &bs, &blocks));
+    bwd_stat_done(next, bs, blocks, gb.Npad);
     n.prof.end(n.st);
   }
   return 0;
 }
 
 static int conv_backward(Net& n, ConvLayer& L, int B, GradSrc g0, GradSrc g1, const float* dtap, bool need_dA,
-                         bool param_grads, int tap = -1) {
+                         bool param_grads, int tap = -1, ConvLayer* next = nullptr) {
+  // next: the layer whose ONLY gradient source is this layer's backward-data output (same resolution, no pooling /
+  // second consumer in between): its BatchNorm-backward sums are folded into that launch
   LayerBwd lb{};
   lb.s = L.s; lb.scale = L.scale; lb.shift = L.shift; lb.mean = L.mean; lb.rstd = L.rstd;
   lb.dtap = dtap; lb.g0 = g0; lb.g1 = g1;
@@ -644,13 +676,15 @@ static int conv_backward(Net& n, ConvLayer& L, int B, GradSrc g0, GradSrc g1, co
   lb.has_bn = L.has_bn; lb.pre_act = L.pre_act; lb.post_act = L.post_act;
   lb.pool_ties_all = n.pool_ties_all;
   const size_t M = n.rows(L, B);
-  n.prof.begin(n.st, "bn_act_bwd", 0, 4.0 * M * L.Cout * (L.has_bn ? 5.0 : 3.0));
+  const BwdPre pre{n.ws_bwd2, L.bwd_pre_nblk, L.bwd_pre_ld};
+  L.bwd_pre_nblk = 0;
+  n.prof.begin(n.st, "bn_act_bwd", 0, 4.0 * M * L.Cout * (L.has_bn ? (pre.nblk ? 3.0 : 5.0) : 3.0));
   ICS_TRY(launch_layer_bwd(n.st, lb, L.dy, n.ws_bwd, L.c1c2,
                            (param_grads && L.has_bn) ? n.tg(L.t_gamma) : nullptr,
                            (param_grads && L.has_bn) ? n.tg(L.t_beta) : nullptr,
-                           param_grads ? n.tg(L.t_b) : nullptr, n.sync()));
+                           param_grads ? n.tg(L.t_b) : nullptr, n.sync(), &pre));
   n.prof.end(n.st);
-  return conv_grads_from_dy(n, L, B, need_dA, param_grads);
+  return conv_grads_from_dy(n, L, B, need_dA, param_grads, next);
 }
 
 // ---- data parallel gradient exchange.  The flat gradient buffer is laid out in layer order and the
@@ -845,7 +879,7 @@ static int unet_loss(Net& n, int B, int mode, int want_grad, bool want_metrics =
   const size_t M = n.rows(*n.head, B);
   n.prof.begin(n.st, "head_softmax_loss", 0, 4.0 * M * (n.ncls + 1) * 2);
   ICS_TRY(launch_head(n.st, n.head->s, n.ncls + 1, n.ncls, n.labels, M, mode, want_grad, n.loss_weight,
-                      n.ws_dbl, 2048, n.comm ? nullptr : n.d_metrics, &n.head_nblk));
+                      n.ws_dbl, 2048, n.comm ? nullptr : n.d_metrics, &n.head_nblk, want_grad ? n.ws_bwd : nullptr));
   n.prof.end(n.st);
   if (mode != 0 && n.comm && want_metrics) {
     ICS_TRY(launch_head_metrics(n.st, n.ws_dbl, n.head_nblk, (double)M, n.d_metrics, n.d_red, 1));
@@ -856,28 +890,7 @@ static int unet_loss(Net& n, int B, int mode, int want_grad, bool want_metrics =
   return 0;
 }
 
-// small generic column-sum (head bias gradient): rows blocked, 32 columns x 8 rows per pass
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ a, size_t M, int C, int ld,
-                                                              int rows_per_block, float* __restrict__ partial) {
-  __shared__ float sh[256];
-  const int tc = threadIdx.x & 31, tr = threadIdx.x >> 5;
-  const size_t r0 = (size_t)blockIdx.x * rows_per_block;
-  const size_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
-  for (int cg = 0; cg < C; cg += 32) {
-    const int c = cg + tc;
-    float acc = 0.f;
-    if (c < C)
-      for (size_t row = r0 + tr; row < r1; row += 8) acc += a[row * ld + c];
-    sh[threadIdx.x] = acc;
-    __syncthreads();
-    if (threadIdx.x < 32 && c < C) {
-      float s = 0.f;
-      for (int r = 0; r < 8; ++r) s += sh[r * 32 + threadIdx.x];
-      partial[(size_t)blockIdx.x * C + c] = s;
-    }
-    __syncthreads();
-  }
-}
+// merges per-block column partials [nblk][C] (head bias gradients; partials come from head_kernel)
 __global__ __launch_bounds__(256) void colsum_merge_kernel(const float* __restrict__ partial, int nblk, int C,
                                                             float* __restrict__ out) {
   __shared__ double shd[256];
@@ -892,18 +905,6 @@ __global__ __launch_bounds__(256) void colsum_merge_kernel(const float* __restri
   }
   if (threadIdx.x == 0) out[c] = (float)shd[0];
 }
-static int colsum(Net& n, const float* a, size_t M, int C, int ld, float* out) {
-  int nblk = (int)std::min<size_t>(1024, (M + 63) / 64);
-  if ((size_t)nblk * C > n.ws_bwd_n) nblk = (int)(n.ws_bwd_n / C);
-  const int rpb = (int)((M + nblk - 1) / nblk);
-  nblk = (int)((M + rpb - 1) / rpb);
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, n.st, a, M, C, ld, rpb, n.ws_bwd);
-  ICS_HIP(hipGetLastError());
-  hipLaunchKernelGGL(colsum_merge_kernel, dim3(C), dim3(256), 0, n.st, n.ws_bwd, nblk, C, out);
-  ICS_HIP(hipGetLastError());
-  return 0;
-}
-
 // tmp[K][na + nb] -> a[K][na], b[K][nb]
 __global__ void split_cols_kernel(const float* __restrict__ tmp, int K, int N, int na, float* __restrict__ a,
                                   float* __restrict__ b) {
@@ -933,39 +934,46 @@ static int unet_backward(Net& n, int B) {
                        n.ncls, n.tg(H.t_w), n.tg(H.t_gamma));
     ICS_HIP(hipGetLastError());
     n.prof.end(n.st);
-    ICS_TRY(colsum(n, H.s, M, nc1, nc1, n.tg(H.t_b)));   // soft/bias | sig/bias are contiguous
+    // soft/bias | sig/bias (contiguous): the loss kernel left per-block column sums of dz in ws_bwd
+    hipLaunchKernelGGL(colsum_merge_kernel, dim3(nc1), dim3(256), 0, n.st, n.ws_bwd, n.head_nblk, nc1, n.tg(H.t_b));
+    ICS_HIP(hipGetLastError());
     const ConvGeom gb = geom_bwd(H, B);
     ConvSrc sdz = src_plain(H.s, nc1);
     n.prof.begin(n.st, "conv_dgrad:head|", 2.0 * M * 128 * nc1, 4.0 * M * (128 + nc1));
-    ICS_TRY(launch_conv_fwd(n.st, gb, &sdz, 1, H.wf, nullptr, H.dA, 128, ACT_NONE, nullptr, nullptr));
+    const BwdStat bs = bwd_stat_for(n, r.c18, B);
+    int blocks = 0;
+    ICS_TRY(launch_conv_fwd(n.st, gb, &sdz, 1, H.wf, nullptr, H.dA, 128, ACT_NONE, nullptr, nullptr, 0, nullptr, 0, &bs,
+                            &blocks));
+    bwd_stat_done(r.c18, bs, blocks, gb.Npad);
     n.prof.end(n.st);
   }
-  auto bw = [&](ConvLayer* L, GradSrc g0, GradSrc g1, bool need_dA) {
-    return conv_backward(n, *L, B, g0, g1, nullptr, need_dA, true);
+  // last argument: the layer fed ONLY by this layer's backward-data output (BatchNorm-backward sums folded in)
+  auto bw = [&](ConvLayer* L, GradSrc g0, GradSrc g1, bool need_dA, ConvLayer* next = nullptr) {
+    return conv_backward(n, *L, B, g0, g1, nullptr, need_dA, true, -1, next);
   };
   // gradient of a concat consumer w.r.t. its skip / upsampled producer
   auto g_skip = [&](ConvLayer* c) { return c->split_up ? gs_direct(c->dA_skip, c->Cs, 0) : gs_direct(c->dA, c->Cin, 0); };
   auto g_up = [&](ConvLayer* c) { return c->split_up ? gs_direct(c->dxl, c->Cu, 0) : gs_up(c->dA, c->Cin, c->src[0].C); };
   // after each layer its gradients (and everything behind them in the flat buffer) are final: grads_ready
   ICS_TRY(grads_ready(n, layer_lo(n, H)));
-  ICS_TRY(bw(r.c18, gs_direct(H.dA, 128, 0), gs_none(), true));
-  ICS_TRY(bw(r.c17, gs_direct(r.c18->dA, 128, 0), gs_none(), true));
-  ICS_TRY(bw(r.c16, g_up(r.c17), gs_none(), true));
-  ICS_TRY(bw(r.c15, gs_direct(r.c16->dA, 256, 0), gs_none(), true));
+  ICS_TRY(bw(r.c18, gs_direct(H.dA, 128, 0), gs_none(), true, r.c17));
+  ICS_TRY(bw(r.c17, gs_direct(r.c18->dA, 128, 0), gs_none(), true, r.c17->split_up ? r.c16 : nullptr));
+  ICS_TRY(bw(r.c16, g_up(r.c17), gs_none(), true, r.c15));
+  ICS_TRY(bw(r.c15, gs_direct(r.c16->dA, 256, 0), gs_none(), true, r.c15->split_up ? r.c14 : nullptr));
   ICS_TRY(grads_ready(n, layer_lo(n, *r.c15)));
-  ICS_TRY(bw(r.c14, g_up(r.c15), gs_none(), true));
+  ICS_TRY(bw(r.c14, g_up(r.c15), gs_none(), true, r.c13));
   ICS_TRY(grads_ready(n, layer_lo(n, *r.c14)));
-  ICS_TRY(bw(r.c13, gs_direct(r.c14->dA, 512, 0), gs_none(), true));
+  ICS_TRY(bw(r.c13, gs_direct(r.c14->dA, 512, 0), gs_none(), true, r.c13->split_up ? r.c10 : nullptr));
   ICS_TRY(grads_ready(n, layer_lo(n, *r.c13)));
-  ICS_TRY(bw(r.c10, g_up(r.c13), gs_none(), true));
+  ICS_TRY(bw(r.c10, g_up(r.c13), gs_none(), true, r.c9));
   ICS_TRY(grads_ready(n, layer_lo(n, *r.c10)));
   ICS_TRY(bw(r.c9, gs_direct(r.c10->dA, 512, 0), gs_none(), true));
   ICS_TRY(grads_ready(n, layer_lo(n, *r.c9)));
-  ICS_TRY(bw(r.c6, gs_pool(r.c9->dA, 256, *r.c6), g_skip(r.c13), true));
+  ICS_TRY(bw(r.c6, gs_pool(r.c9->dA, 256, *r.c6), g_skip(r.c13), true, r.c5));
   ICS_TRY(bw(r.c5, gs_direct(r.c6->dA, 128, 0), gs_none(), true));
-  ICS_TRY(bw(r.c4, gs_pool(r.c5->dA, 128, *r.c4), g_skip(r.c15), true));
+  ICS_TRY(bw(r.c4, gs_pool(r.c5->dA, 128, *r.c4), g_skip(r.c15), true, r.c3));
   ICS_TRY(bw(r.c3, gs_direct(r.c4->dA, 64, 0), gs_none(), true));
-  ICS_TRY(bw(r.c2, gs_pool(r.c3->dA, 64, *r.c2), g_skip(r.c17), true));
+  ICS_TRY(bw(r.c2, gs_pool(r.c3->dA, 64, *r.c2), g_skip(r.c17), true, r.c1));
   ICS_TRY(bw(r.c1, gs_direct(r.c2->dA, 32, 0), gs_none(), false));
   return 0;
 }
@@ -975,16 +983,16 @@ static int unet_pm_backward(Net& n, int B) {
   UnetRefs r = unet_refs(n);
   // the taps' squared-difference loss terms and their gradients are formed inside the BN-backward pass of the
   // tap layers (tap >= 0): no separate sqdiff pass over the four tap tensors, no dtap buffers
-  auto bw = [&](ConvLayer* L, GradSrc g0, int tap, bool need_dA) {
-    return conv_backward(n, *L, B, g0, gs_none(), nullptr, need_dA, false, tap);
+  auto bw = [&](ConvLayer* L, GradSrc g0, int tap, bool need_dA, ConvLayer* next = nullptr) {
+    return conv_backward(n, *L, B, g0, gs_none(), nullptr, need_dA, false, tap, next);
   };
-  ICS_TRY(bw(r.c10, gs_none(), 3, true));
+  ICS_TRY(bw(r.c10, gs_none(), 3, true, r.c9));
   ICS_TRY(bw(r.c9, gs_direct(r.c10->dA, 512, 0), -1, true));
-  ICS_TRY(bw(r.c6, gs_pool(r.c9->dA, 256, *r.c6), 2, true));
+  ICS_TRY(bw(r.c6, gs_pool(r.c9->dA, 256, *r.c6), 2, true, r.c5));
   ICS_TRY(bw(r.c5, gs_direct(r.c6->dA, 128, 0), -1, true));
-  ICS_TRY(bw(r.c4, gs_pool(r.c5->dA, 128, *r.c4), 1, true));
+  ICS_TRY(bw(r.c4, gs_pool(r.c5->dA, 128, *r.c4), 1, true, r.c3));
   ICS_TRY(bw(r.c3, gs_direct(r.c4->dA, 64, 0), -1, true));
-  ICS_TRY(bw(r.c2, gs_pool(r.c3->dA, 64, *r.c2), 0, true));
+  ICS_TRY(bw(r.c2, gs_pool(r.c3->dA, 64, *r.c2), 0, true, r.c1));
   ICS_TRY(bw(r.c1, gs_direct(r.c2->dA, 32, 0), -1, true));
   return 0;
 }
