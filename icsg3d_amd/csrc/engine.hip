@@ -128,6 +128,13 @@ struct Net {
   int device = 0;
   int flags = 0;  // ConvFlags, read from the environment when the handle is created
   hipStream_t st = nullptr;
+  // second stream for work off the critical path of a step: the weight-gradient GEMMs (they need only a layer's dy;
+  // the chain bn_bwd -> backward-data -> next layer never waits for them until the gradients are consumed).  The two
+  // independent kernel sequences fill each other's tail rounds: U-Net step 66.50 -> 66.15 ms.  Off for the VAE engine
+  // (its small kernels only slow each other down when they share the chip: 12.59 -> 12.71 ms, measured).
+  hipStream_t st2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool side_on = true, side_dirty = false;
   int maxB = 0, d = 0, C = 0;
   std::vector<void*> allocs;
   std::vector<Tensor> tensors;
@@ -201,6 +208,9 @@ struct Net {
   ~Net() {
     if (comm) ncclCommDestroy(comm);
     for (void* p : allocs) (void)hipFree(p);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+    if (st2) (void)hipStreamDestroy(st2);
     if (ev_grad) (void)hipEventDestroy(ev_grad);
     if (ev_comm) (void)hipEventDestroy(ev_comm);
     if (comm_st) (void)hipStreamDestroy(comm_st);
@@ -554,6 +564,23 @@ static GradSrc gs_pool(const float* p, int ld, const ConvLayer& producer) {
   return GradSrc{p, ld, 0, GS_POOL, producer.pooled, producer.pool_idx};
 }
 
+// side stream: everything issued on st so far is visible to work issued on the returned stream
+static hipStream_t side_begin(Net& n) {
+  if (!n.side_on) return n.st;
+  (void)hipEventRecord(n.ev_fork, n.st);
+  (void)hipStreamWaitEvent(n.st2, n.ev_fork, 0);
+  n.side_dirty = true;
+  return n.st2;
+}
+// st waits for everything issued on the side stream (before gradients are consumed / buffers are reused)
+static int side_join(Net& n) {
+  if (!n.side_dirty) return 0;
+  ICS_HIP(hipEventRecord(n.ev_join, n.st2));
+  ICS_HIP(hipStreamWaitEvent(n.st, n.ev_join, 0));
+  n.side_dirty = false;
+  return 0;
+}
+
 // BwdStat for the backward-data launch whose output is dO of `next` (its only consumer); empty when not applicable
 static BwdStat bwd_stat_for(Net& n, ConvLayer* next, int B) {
   BwdStat bs;
@@ -578,29 +605,30 @@ static int conv_grads_split_up(Net& n, ConvLayer& L, int B, ConvLayer* next) {
   n.prof.begin(n.st, "pool27:" + L.name, 0, 4.0 * M * L.Cout * (1 + 27.0 / 8));
   ICS_TRY(launch_pool27(n.st, L.dy, B, L.S, L.Cout, L.dyS, L.ldS));
   n.prof.end(n.st);
+  hipStream_t ws = side_begin(n);   // weight gradients: off the critical path (see Net::st2)
   if (L.Cs) {
     const ConvGeom g = geom_skip_wgrad(L, B);
-    n.prof.begin(n.st, "conv_wgrad:" + L.name + ".skip|", fl_skip,
+    n.prof.begin(ws, "conv_wgrad:" + L.name + ".skip|", fl_skip,
                  4.0 * (M * L.Cs + M * L.Cout + 27.0 * L.Cs * L.Cout));
-    ICS_TRY(launch_conv_wgrad(n.st, g, L.src, 1, L.dy, L.Cout, n.tg(L.t_w), L.Cout, n.ws_wgrad, n.ws_wgrad_n, L.Cs,
+    ICS_TRY(launch_conv_wgrad(ws, g, L.src, 1, L.dy, L.Cout, n.tg(L.t_w), L.Cout, n.ws_wgrad, n.ws_wgrad_n, L.Cs,
                               L.Cin, 0, 1));
-    n.prof.end(n.st);
-    n.prof.begin(n.st, "wgrad_reduce_splits", 0, 0);
-    ICS_TRY(launch_conv_wgrad(n.st, g, L.src, 1, L.dy, L.Cout, n.tg(L.t_w), L.Cout, n.ws_wgrad, n.ws_wgrad_n, L.Cs,
+    n.prof.end(ws);
+    n.prof.begin(ws, "wgrad_reduce_splits", 0, 0);
+    ICS_TRY(launch_conv_wgrad(ws, g, L.src, 1, L.dy, L.Cout, n.tg(L.t_w), L.Cout, n.ws_wgrad, n.ws_wgrad_n, L.Cs,
                               L.Cin, 0, 2));
-    n.prof.end(n.st);
+    n.prof.end(ws);
   }
   {
     const ConvGeom g = geom_up_wgrad(L, B);
     const ConvSrc lo = src_lowres(L);
-    n.prof.begin(n.st, "conv_wgrad:" + L.name + ".up|", fl_up,
+    n.prof.begin(ws, "conv_wgrad:" + L.name + ".up|", fl_up,
                  4.0 * (M / 8 * L.Cu + M / 8 * 27.0 * L.Cout + 27.0 * L.Cu * L.Cout));
-    ICS_TRY(launch_conv_wgrad(n.st, g, &lo, 1, L.dyS, L.ldS, L.dw_up, 27 * L.Cout, n.ws_wgrad, n.ws_wgrad_n, 0, 0, 0, 1));
-    n.prof.end(n.st);
-    n.prof.begin(n.st, "wgrad_reduce_splits", 0, 0);
-    ICS_TRY(launch_conv_wgrad(n.st, g, &lo, 1, L.dyS, L.ldS, L.dw_up, 27 * L.Cout, n.ws_wgrad, n.ws_wgrad_n, 0, 0, 0, 2));
-    ICS_TRY(launch_permute_up_dw(n.st, L.dw_up, L.Cu, L.Cout, L.Cin, L.Cs, n.tg(L.t_w)));
-    n.prof.end(n.st);
+    ICS_TRY(launch_conv_wgrad(ws, g, &lo, 1, L.dyS, L.ldS, L.dw_up, 27 * L.Cout, n.ws_wgrad, n.ws_wgrad_n, 0, 0, 0, 1));
+    n.prof.end(ws);
+    n.prof.begin(ws, "wgrad_reduce_splits", 0, 0);
+    ICS_TRY(launch_conv_wgrad(ws, g, &lo, 1, L.dyS, L.ldS, L.dw_up, 27 * L.Cout, n.ws_wgrad, n.ws_wgrad_n, 0, 0, 0, 2));
+    ICS_TRY(launch_permute_up_dw(ws, L.dw_up, L.Cu, L.Cout, L.Cin, L.Cs, n.tg(L.t_w)));
+    n.prof.end(ws);
   }
   if (L.Cs) {
     const ConvGeom g = geom_skip_dgrad(L, B);
@@ -633,20 +661,22 @@ static int conv_grads_from_dy(Net& n, ConvLayer& L, int B, bool need_dA, bool pa
   const ConvGeom g = geom_fwd(L, B);
   const size_t M = n.rows(L, B);
   if (param_grads) {
-    n.prof.begin(n.st, "conv_wgrad:" + L.name + "|", 2.0 * M * L.taps * L.Cin * L.Cout,
+    hipStream_t ws = side_begin(n);   // weight gradients: off the critical path (Net::st2); ALL of them, the
+                                      // split-K workspace ws_wgrad is only ever touched from that stream
+    n.prof.begin(ws, "conv_wgrad:" + L.name + "|", 2.0 * M * L.taps * L.Cin * L.Cout,
                  4.0 * (M * L.Cin + M * L.Cout + (double)L.taps * L.Cin * L.Cout));
     float* dw = L.dw_phys ? L.dw_phys : n.tg(L.t_w);
-    ICS_TRY(launch_conv_wgrad(n.st, g, L.src, L.nsrc, L.dy, L.Cout, dw, L.Cout, n.ws_wgrad, n.ws_wgrad_n, 0, 0, 0, 1));
-    n.prof.end(n.st);
-    n.prof.begin(n.st, "wgrad_reduce_splits", 0, 0);
-    ICS_TRY(launch_conv_wgrad(n.st, g, L.src, L.nsrc, L.dy, L.Cout, dw, L.Cout, n.ws_wgrad, n.ws_wgrad_n, 0, 0, 0, 2));
+    ICS_TRY(launch_conv_wgrad(ws, g, L.src, L.nsrc, L.dy, L.Cout, dw, L.Cout, n.ws_wgrad, n.ws_wgrad_n, 0, 0, 0, 1));
+    n.prof.end(ws);
+    n.prof.begin(ws, "wgrad_reduce_splits", 0, 0);
+    ICS_TRY(launch_conv_wgrad(ws, g, L.src, L.nsrc, L.dy, L.Cout, dw, L.Cout, n.ws_wgrad, n.ws_wgrad_n, 0, 0, 0, 2));
     if (L.dw_phys) {
       const size_t cnt = (size_t)L.taps * L.Cin * L.Cout;
-      hipLaunchKernelGGL(unpad_dw_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, n.st, L.dw_phys, L.Cin,
+      hipLaunchKernelGGL(unpad_dw_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ws, L.dw_phys, L.Cin,
                          L.CinG, L.Cout, cnt, n.tg(L.t_w));
       ICS_HIP(hipGetLastError());
     }
-    n.prof.end(n.st);
+    n.prof.end(ws);
   }
   if (need_dA) {
     ConvGeom gb = geom_bwd(L, B);
@@ -711,6 +741,7 @@ static int grads_ready(Net& n, size_t lo) {
   if (!n.comm || !n.overlap) return 0;
   if (lo >= n.bucket_hi) return 0;
   if (lo != 0 && n.bucket_hi - lo < n.bucket_min) return 0;
+  ICS_TRY(side_join(n));     // the bucket's weight gradients were computed on the side stream
   ICS_HIP(hipEventRecord(n.ev_grad, n.st));
   ICS_HIP(hipStreamWaitEvent(n.comm_st, n.ev_grad, 0));
   n.prof.begin(n.comm_st, "rccl_allreduce_grads", 0, 4.0 * (n.bucket_hi - lo));
@@ -725,6 +756,7 @@ static size_t layer_lo(const Net& n, const ConvLayer& L) { return n.tensors[L.t_
 
 static int adam_step(Net& n) {
   float gscale = 1.f;
+  ICS_TRY(side_join(n));
   if (n.comm) {
     if (n.overlap) {
       ICS_TRY(grads_ready(n, 0));
@@ -763,6 +795,7 @@ static UnetRefs unet_refs(Net& n) {
 }
 
 static int unet_build(Net& n, const ics_unet_config& cfg) {
+  n.side_on = getenv("ICSG3D_NO_SIDE_STREAM") == nullptr;
   n.kind = 0; n.maxB = cfg.max_batch; n.d = cfg.d; n.C = cfg.in_channels; n.ncls = cfg.num_classes;
   n.lr = cfg.lr; n.loss_weight = cfg.loss_weight > 0 ? cfg.loss_weight : (float)cfg.num_classes;
   n.pool_ties_all = cfg.pool_ties_all; n.bn_unbias = cfg.bn_unbias;
@@ -925,15 +958,16 @@ static int unet_backward(Net& n, int B) {
   {
     // one GEMM over the [soft | sig] columns (one pass over c18's activations), then split into the two tensors
     ConvGeom gs = gh; gs.Cout = nc1; gs.Npad = round_up(nc1, 32);
-    n.prof.begin(n.st, "conv_wgrad:head|", 2.0 * M * 128 * nc1, 4.0 * M * (128 + nc1));
-    ICS_TRY(launch_conv_wgrad(n.st, gs, H.src, 1, H.s, nc1, n.head_dw_tmp, nc1, n.ws_wgrad, n.ws_wgrad_n, 0, 0, 0, 1));
-    n.prof.end(n.st);
-    n.prof.begin(n.st, "wgrad_reduce_splits", 0, 0);
-    ICS_TRY(launch_conv_wgrad(n.st, gs, H.src, 1, H.s, nc1, n.head_dw_tmp, nc1, n.ws_wgrad, n.ws_wgrad_n, 0, 0, 0, 2));
-    hipLaunchKernelGGL(split_cols_kernel, dim3((128 * nc1 + 255) / 256), dim3(256), 0, n.st, n.head_dw_tmp, 128, nc1,
+    hipStream_t ws = side_begin(n);
+    n.prof.begin(ws, "conv_wgrad:head|", 2.0 * M * 128 * nc1, 4.0 * M * (128 + nc1));
+    ICS_TRY(launch_conv_wgrad(ws, gs, H.src, 1, H.s, nc1, n.head_dw_tmp, nc1, n.ws_wgrad, n.ws_wgrad_n, 0, 0, 0, 1));
+    n.prof.end(ws);
+    n.prof.begin(ws, "wgrad_reduce_splits", 0, 0);
+    ICS_TRY(launch_conv_wgrad(ws, gs, H.src, 1, H.s, nc1, n.head_dw_tmp, nc1, n.ws_wgrad, n.ws_wgrad_n, 0, 0, 0, 2));
+    hipLaunchKernelGGL(split_cols_kernel, dim3((128 * nc1 + 255) / 256), dim3(256), 0, ws, n.head_dw_tmp, 128, nc1,
                        n.ncls, n.tg(H.t_w), n.tg(H.t_gamma));
     ICS_HIP(hipGetLastError());
-    n.prof.end(n.st);
+    n.prof.end(ws);
     // soft/bias | sig/bias (contiguous): the loss kernel left per-block column sums of dz in ws_bwd
     hipLaunchKernelGGL(colsum_merge_kernel, dim3(nc1), dim3(256), 0, n.st, n.ws_bwd, n.head_nblk, nc1, n.tg(H.t_b));
     ICS_HIP(hipGetLastError());
@@ -1182,17 +1216,19 @@ static int vae_step(Net& n, int B, bool training, float* metrics) {
     VaeRefs r = vae_refs(n);
     UnetRefs ur = unet_refs(u);
     ConvLayer* taps[4] = {ur.c2, ur.c4, ur.c6, ur.c10};
-    if ((rc = vae_encode_fwd(n, B, training))) break;
-    if ((rc = vae_decode_fwd(n, B, training))) break;
     const size_t M = (size_t)B * n.d * n.d * n.d;
     // perceptual pass on y_true: the four tap layers write straight into tap_copy (nothing in the c1..c10 trunk
     // reads a tap layer's s except its own pooling, which takes the pointer at launch time); then the pass on
     // y_pred into the layers' own buffers (state kept for the backward pass)
+    // (Measured on MI355X: running this pass on a second stream, concurrently with the encoder / decoder, overlaps
+    // 3.8 ms of kernels but each runs slower while sharing the chip -- step 12.69 vs 12.59 ms: not done.)
     float* own_s[4];
     for (int l = 0; l < 4; ++l) { own_s[l] = taps[l]->s; taps[l]->s = u.tap_copy[l]; }
     rc = unet_forward_trunk(u, B, training, false, true, n.x_in);
     for (int l = 0; l < 4; ++l) taps[l]->s = own_s[l];
     if (rc) break;
+    if ((rc = vae_encode_fwd(n, B, training))) break;
+    if ((rc = vae_decode_fwd(n, B, training))) break;
     if ((rc = unet_forward_trunk(u, B, training, false, true, n.recon))) break;
     // loss terms (+ gradients when training)
     double* mse_part = n.ws_dbl;
@@ -1262,8 +1298,9 @@ static int vae_step(Net& n, int B, bool training, float* metrics) {
       const int lat = n.latent;
       {
         ConvGeom g1 = geom_fwd(Z, B); g1.Cout = lat; g1.Npad = round_up(lat, 32);
-        if ((rc = launch_conv_wgrad(n.st, g1, Z.src, 1, n.dmulv, 2 * lat, n.tg(Z.t_w), lat, n.ws_wgrad, n.ws_wgrad_n))) break;
-        if ((rc = launch_conv_wgrad(n.st, g1, Z.src, 1, n.dmulv + lat, 2 * lat, n.tg(Z.t_gamma), lat, n.ws_wgrad, n.ws_wgrad_n))) break;
+        hipStream_t ws = side_begin(n);
+        if ((rc = launch_conv_wgrad(ws, g1, Z.src, 1, n.dmulv, 2 * lat, n.tg(Z.t_w), lat, n.ws_wgrad, n.ws_wgrad_n))) break;
+        if ((rc = launch_conv_wgrad(ws, g1, Z.src, 1, n.dmulv + lat, 2 * lat, n.tg(Z.t_gamma), lat, n.ws_wgrad, n.ws_wgrad_n))) break;
         if ((rc = launch_colsum_small(n.st, n.dmulv, B, 2 * lat, 2 * lat, n.tg(Z.t_b)))) break;
         const ConvGeom gb = geom_bwd(Z, B);
         ConvSrc sd = src_plain(n.dmulv, 2 * lat);
@@ -1387,6 +1424,10 @@ static int net_common_init(Net& n) {
   n.flags = conv_flags_from_env();
   ICS_HIP(hipGetDevice(&n.device));
   ICS_HIP(hipStreamCreateWithFlags(&n.st, hipStreamNonBlocking));
+  ICS_HIP(hipStreamCreateWithFlags(&n.st2, hipStreamNonBlocking));
+  ICS_HIP(hipEventCreateWithFlags(&n.ev_fork, hipEventDisableTiming));
+  ICS_HIP(hipEventCreateWithFlags(&n.ev_join, hipEventDisableTiming));
+  n.side_on = false;   // enabled per engine kind in *_build
   return 0;
 }
 
