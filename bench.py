@@ -103,6 +103,7 @@ def main():
                     help="unet = the contract line (BASELINE configs[1] + the configs[2] secondary block); "
                          "vae / joint = profiling runs of the DFC-VAE step alone / U-Net + DFC-VAE step per iteration")
     ap.add_argument("--sync-bn", action="store_true", help="data parallel: global-batch BatchNorm statistics")
+    ap.add_argument("--dump-rows", type=str, default=None, help="write the per-launch-site profile rows (JSON) here")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -170,6 +171,9 @@ def main():
         rows = [r for e in profiled for r in e.profile_rows()]
         for e in profiled:
             e.profile_enable(False)
+        if args.dump_rows and rank == 0:
+            with open(args.dump_rows, "a") as f:
+                f.write(json.dumps({"steps": args.steps, "rows": rows}) + "\n")
         # the same K steps without the per-launch events (what a training job sees)
         barrier()
         t0 = time.perf_counter()

@@ -128,10 +128,12 @@ struct Net {
   int device = 0;
   int flags = 0;  // ConvFlags, read from the environment when the handle is created
   hipStream_t st = nullptr;
-  // second stream for work off the critical path of a step: the weight-gradient GEMMs (they need only a layer's dy;
-  // the chain bn_bwd -> backward-data -> next layer never waits for them until the gradients are consumed).  The two
-  // independent kernel sequences fill each other's tail rounds: U-Net step 66.50 -> 66.15 ms.  Off for the VAE engine
-  // (its small kernels only slow each other down when they share the chip: 12.59 -> 12.71 ms, measured).
+  // OPT-IN (ICSG3D_SIDE_STREAM=1, U-Net engine only) second stream for the weight-gradient GEMMs: they need only a
+  // layer's dy, and the chain bn_bwd -> backward-data -> next layer never waits for them until the gradients are
+  // consumed, so the two kernel sequences can fill each other's tail rounds.  Measured: U-Net step 66.50 -> 66.15 ms
+  // (-0.5 %); DFC-VAE 12.59 -> 12.71 ms (its small kernels only slow each other down).  Off by default: concurrent
+  // kernels make every per-kernel duration (HIP events, rocprofv3) -- and with it the roofline accounting --
+  // meaningless, for half a percent.
   hipStream_t st2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool side_on = true, side_dirty = false;
@@ -795,7 +797,7 @@ static UnetRefs unet_refs(Net& n) {
 }
 
 static int unet_build(Net& n, const ics_unet_config& cfg) {
-  n.side_on = getenv("ICSG3D_NO_SIDE_STREAM") == nullptr;
+  n.side_on = getenv("ICSG3D_SIDE_STREAM") != nullptr;
   n.kind = 0; n.maxB = cfg.max_batch; n.d = cfg.d; n.C = cfg.in_channels; n.ncls = cfg.num_classes;
   n.lr = cfg.lr; n.loss_weight = cfg.loss_weight > 0 ? cfg.loss_weight : (float)cfg.num_classes;
   n.pool_ties_all = cfg.pool_ties_all; n.bn_unbias = cfg.bn_unbias;
