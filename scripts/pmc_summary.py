@@ -1,5 +1,6 @@
 """Summarise rocprofv3 --pmc counter_collection CSVs per kernel (averages per dispatch).
-usage: pmc_summary.py <dir> [kernel-substring ...]
+usage: pmc_summary.py <dir> [kernel-substring ...]     (env KSTATS=<rocprofv3 --stats kernel_stats.csv> adds each
+kernel's average duration as avg_ms: bench.py compares it with its live HIP-event average to detect a stale profile)
 Also writes <dir>/traffic.json: per bench.py kernel id, HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KB
 (gfx950: FETCH_SIZE counts 64-B requests for 128-B wide reads, MI355X_MICROARCH.md HBM/rocprofv3 section)."""
 import csv, glob, json, re, sys, collections
@@ -9,8 +10,14 @@ def bench_id(short):
     """bench.py / the engine profiler label kernels by their exact template instantiation"""
     return short.strip()
 
+import os
 d = sys.argv[1]
 filt = sys.argv[2:]
+avg_ms = {}
+if os.environ.get("KSTATS") and os.path.exists(os.environ["KSTATS"]):
+    for r in csv.DictReader(open(os.environ["KSTATS"])):
+        short = r["Name"].split("(")[0].replace("void ics::", "").replace("ics::", "")
+        avg_ms[short.strip()] = float(r["AverageNs"]) / 1e6
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 meta = {}
 for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
@@ -46,6 +53,8 @@ out = {"source": "rocprofv3 --kernel-trace --pmc <one counter group per pass> (s
 for k, cs in agg.items():
     c = {n: v[0] / v[1] for n, v in cs.items()}
     e = {"launches_sampled": max(v[1] for v in cs.values())}
+    if k in avg_ms:
+        e["avg_ms"] = round(avg_ms[k], 4)
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         e["fetch_size_kb_avg"] = round(c["FETCH_SIZE"], 1)
         e["write_size_kb_avg"] = round(c["WRITE_SIZE"], 1)

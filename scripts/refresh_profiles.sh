@@ -1,14 +1,18 @@
 #!/bin/bash
-# On the GPU box, from the repo root: full GPU test suite, the contract bench line, the rocprofv3 kernel
-# statistics of the same command, and the PMC passes.  Outputs land in gpurun_out/refresh_<tag>/.
-TAG=${1:-r1}
+# On the GPU box, from the repo root: full GPU test suite, the contract bench line, the rocprofv3 kernel statistics
+# of the same workloads (U-Net step; DFC-VAE step), and the PMC passes.  Outputs land in gpurun_out/refresh_<tag>/;
+# copy what is to be judged into profiles/ (scripts/collect_profiles.py).
+TAG=${1:-r2}
 ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out/refresh_$TAG
 mkdir -p $OUT
 cd $ROOT
-python -m pytest tests -m gpu -q > $OUT/tests.log 2>&1; tail -3 $OUT/tests.log
-python bench.py > $OUT/bench.json 2> $OUT/bench.err; cat $OUT/bench.json | cut -c1-600
+if [ -z "$SKIP_TESTS" ]; then python -m pytest tests -m gpu -q > $OUT/tests.log 2>&1; tail -3 $OUT/tests.log; fi
+python bench.py > $OUT/bench.json 2> $OUT/bench.err; cut -c1-400 $OUT/bench.json
+python bench.py --workload joint --no-cpu-baseline > $OUT/bench_joint.json 2> $OUT/bench_joint.err
+python bench.py --workload joint --d 64 --batch 8 --no-cpu-baseline > $OUT/bench_joint_d64.json 2> $OUT/bench_joint_d64.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof -o prof -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/prof.log 2>&1
-find $OUT/prof -name "*kernel_trace.csv" -delete; find $OUT/prof -name "*.db" -delete
-cd $ROOT && bash scripts/run_pmc.sh $TAG
+rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof_unet -o prof -- python3 $ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-secondary > $OUT/prof_unet.log 2>&1
+rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof_vae -o prof -- python3 $ROOT/bench.py --steps 8 --warmup 2 --workload vae > $OUT/prof_vae.log 2>&1
+find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*.db" -delete
+cd $ROOT && KSTATS=$OUT/prof_unet/prof_kernel_stats.csv bash scripts/run_pmc.sh $TAG
