@@ -76,6 +76,7 @@ enum ConvFlags : int {
   CF_NO_FWD_SPLITK = 8,   // ICSG3D_NO_FWD_SPLITK
   CF_NO_THIN_N = 16,      // ICSG3D_NO_THIN_N: Cout <= 4 layers through the MFMA kernels
   CF_NO_UPSPLIT = 32,     // ICSG3D_NO_UPSPLIT: direct 27-tap evaluation of upsampled inputs
+  CF_NO_THIN_C = 64,      // ICSG3D_NO_THIN_C: thin-input layers (c1, e0, e1) through the MFMA kernels
 };
 int conv_flags_from_env();
 
@@ -113,6 +114,12 @@ int launch_conv_fwd(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int n
 // bwd / bwd_blocks: see BwdStat; *bwd_blocks = number of row blocks written to bwd->partial, or 0 when this launch
 // could not fold the reductions (split-K or thin-N path) and the caller must run them separately
 size_t conv_fwd_workspace_floats(const ConvGeom& g, const ConvSrc* src, int nsrc);
+// Thin-C direct stencil forward (see conv_igemm.hip): plain single source with cin_log in {1,4,16} channels, Cout in
+// {16,32}; wstride = input channels per tap in the packed weights (>= cin_log)
+bool conv_thin_c_ok(const ConvGeom& g, const ConvSrc& s0, int nsrc, int cin_log);
+int launch_conv_fwd_thin_c(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, int cin_log, int wstride,
+                           const float* wp, const float* bias, float* out, int ldo, int pre_act, float* stat_partial,
+                           int* rows_per_block);
 int launch_conv_fwd_par(hipStream_t st, const ConvGeom& g_lowres, const ConvSrc& src, const float* wpar, float* out,
                         int ldo, const float* bias = nullptr, int pre_act = ACT_NONE, float* stat_partial = nullptr,
                         int* stat_blocks = nullptr);

@@ -44,6 +44,7 @@ int conv_flags_from_env() {
   if (getenv("ICSG3D_NO_FWD_SPLITK")) f |= CF_NO_FWD_SPLITK;
   if (getenv("ICSG3D_NO_THIN_N")) f |= CF_NO_THIN_N;
   if (getenv("ICSG3D_NO_UPSPLIT")) f |= CF_NO_UPSPLIT;
+  if (getenv("ICSG3D_NO_THIN_C")) f |= CF_NO_THIN_C;
   return f;
 }
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remember per (kernel instantiation, device)
@@ -883,6 +884,183 @@ int conv_fwd_rows_per_block(const ConvGeom& g) {
 }
 
 // =====================================================================================
+// Thin-C direct forward kernel: few input channels (1, 4, 16) into 16 or 32 output channels at full resolution -- the
+// first convs of both nets (U-Net c1: 32^3 x {1,4} -> 32, VAE e0: 32^3 x 11(16) -> 16, e1: 16^3 x 16 -> 32).  These
+// layers are HBM-bound (AI 13-25 FLOP/B): as implicit GEMMs they ran at 14-28 TFLOP/s with most of a
+// 32-wide MFMA tile being padding.  Here: a 3x3x3 stencil on the vector ALU, weights staged in LDS; a thread owns
+// 4 consecutive x voxels x 4 output channels (16 accumulators), so each weight float4 read from LDS feeds 16 FMAs
+// and each (dz,dy) row needs 6 input positions instead of 12.  LPV = COUT/4 lanes share a voxel group: a wave's
+// stores cover whole 64/128-byte output rows.  Epilogue: bias, activation, store, per-block BatchNorm partials.
+// CIN = channels read per voxel; wstride = channels per tap in the packed weights (>= CIN: c1 at C = 1 reads the
+// un-padded input but the weights are packed for the 4-channel padded problem the backward-weight kernel uses).
+// =====================================================================================
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void conv_thin_c_fwd_kernel(ConvGeom g, const float* __restrict__ x, int wstride,
+                                                               const float* __restrict__ wp,
+                                                               const float* __restrict__ bias,
+                                                               float* __restrict__ out, int ldo, int pre_act,
+                                                               float* __restrict__ stat_partial) {
+  constexpr int LPV = COUT / 4;            // lanes per voxel group
+  constexpr int GPB = 256 / LPV;           // voxel groups (of 4 voxels) per block
+  constexpr int VPB = 4 * GPB;             // voxels per block
+  constexpr int C4 = CIN >= 4 ? CIN / 4 : 1;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* w = smem;                         // [27 * wstride][COUT]
+  const int t = threadIdx.x;
+  const int S = g.S, lg = g.lgS;
+  const int M = g.B << (3 * lg);
+  const int K = 27 * wstride;
+  for (int i = t; i < K * COUT; i += 256) {
+    const int k = i / COUT, n = i - k * COUT;
+    w[i] = wp[((size_t)(k >> 2) * g.Npad + n) * 4 + (k & 3)];
+  }
+  __syncthreads();
+  const int q = t % LPV, grp = t / LPV;
+  const int m0 = ((int)blockIdx.x * GPB + grp) * 4;            // first voxel of this thread's group (x0 % 4 == 0)
+  const bool gvalid = m0 < M;
+  const int x0 = m0 & (S - 1), y = (m0 >> lg) & (S - 1), z = (m0 >> (2 * lg)) & (S - 1);
+  float acc[4][4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[v][j] = 0.f;
+  const float* wq = w + 4 * q;
+#pragma unroll 1
+  for (int gzy = 0; gzy < 9; ++gzy) {
+    const int dz = gzy / 3 - 1, dy = gzy % 3 - 1;
+    const bool rowok = gvalid && (unsigned)(z + dz) < (unsigned)S && (unsigned)(y + dy) < (unsigned)S;
+    const long rowbase = (long)(m0 + (dz * S + dy) * S - 1) * CIN;          // element offset of position x0-1
+#pragma unroll
+    for (int c4 = 0; c4 < C4; ++c4) {
+      float xv[6][4];
+#pragma unroll
+      for (int p = 0; p < 6; ++p) {
+        const bool ok = rowok && (unsigned)(x0 + p - 1) < (unsigned)S;     // zero "same" padding
+        if (CIN >= 4) {
+          v4f tv = v4f{0.f, 0.f, 0.f, 0.f};
+          if (ok) tv = *reinterpret_cast<const v4f*>(x + rowbase + (long)p * CIN + c4 * 4);
+          xv[p][0] = tv.x; xv[p][1] = tv.y; xv[p][2] = tv.z; xv[p][3] = tv.w;
+        } else {
+          xv[p][0] = ok ? x[rowbase + p] : 0.f;
+          xv[p][1] = xv[p][2] = xv[p][3] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const float* wk = wq + (size_t)((gzy * 3 + dx) * wstride + c4 * 4) * COUT;
+#pragma unroll
+        for (int j = 0; j < (CIN >= 4 ? 4 : 1); ++j) {
+          const v4f wv = *reinterpret_cast<const v4f*>(wk + j * COUT);
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const float xs = xv[v + dx][j];
+            acc[v][0] = fmaf(xs, wv.x, acc[v][0]); acc[v][1] = fmaf(xs, wv.y, acc[v][1]);
+            acc[v][2] = fmaf(xs, wv.z, acc[v][2]); acc[v][3] = fmaf(xs, wv.w, acc[v][3]);
+          }
+        }
+      }
+    }
+  }
+  // ---- epilogue: bias, activation, store (each lane one float4 per voxel: LPV lanes = one full output row)
+  const float pre_slope = act_slope_of(pre_act);
+  v4f bv = v4f{0.f, 0.f, 0.f, 0.f};       // (scalar loads: a tensor inside the flat parameter buffer need not be 16-B aligned)
+  if (bias != nullptr) { bv.x = bias[4 * q]; bv.y = bias[4 * q + 1]; bv.z = bias[4 * q + 2]; bv.w = bias[4 * q + 3]; }
+  float csum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    acc[v][0] = act_apply(acc[v][0] + bv.x, pre_slope); acc[v][1] = act_apply(acc[v][1] + bv.y, pre_slope);
+    acc[v][2] = act_apply(acc[v][2] + bv.z, pre_slope); acc[v][3] = act_apply(acc[v][3] + bv.w, pre_slope);
+    if (gvalid) {
+      *reinterpret_cast<v4f*>(out + (size_t)(m0 + v) * ldo + 4 * q) = v4f{acc[v][0], acc[v][1], acc[v][2], acc[v][3]};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) csum[j] += acc[v][j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[v][j] = 0.f;
+    }
+  }
+  if (stat_partial == nullptr) return;
+  // block (count, mean, M2) per column, two passes inside the block (as the MFMA kernels): lanes with equal q hold
+  // the same 4 columns; reduce over the wave's voxel groups (xor strides LPV .. 32), then over the 4 waves via LDS
+  __syncthreads();                         // the weights in LDS are no longer needed
+  float* red = smem;                       // [4 waves][COUT]
+  float* bmean = smem + 4 * COUT;          // [COUT]
+  const int lane = t & 63, wave = t >> 6;
+  const int nvalid = min(VPB, M - (int)blockIdx.x * VPB);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float a = csum[j];
+    for (int o = LPV; o < 64; o <<= 1) a += __shfl_xor(a, o);
+    if (lane < LPV) red[wave * COUT + 4 * lane + j] = a;
+  }
+  __syncthreads();
+  if (t < COUT) bmean[t] = (red[t] + red[COUT + t] + red[2 * COUT + t] + red[3 * COUT + t]) / (float)nvalid;
+  __syncthreads();
+  float mu[4], qs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) mu[j] = bmean[4 * q + j];
+  if (gvalid) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float d = acc[v][j] - mu[j]; qs[j] = fmaf(d, d, qs[j]); }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float a = qs[j];
+    for (int o = LPV; o < 64; o <<= 1) a += __shfl_xor(a, o);
+    if (lane < LPV) red[wave * COUT + 4 * lane + j] = a;
+  }
+  __syncthreads();
+  if (t < COUT) {
+    const size_t nstat = gridDim.x;
+    float* sp = stat_partial + (size_t)t * nstat + blockIdx.x;           // layout [3][Npad][nstat]
+    sp[0] = (float)nvalid;
+    sp[(size_t)g.Npad * nstat] = bmean[t];
+    sp[(size_t)2 * g.Npad * nstat] = red[t] + red[COUT + t] + red[2 * COUT + t] + red[3 * COUT + t];
+  }
+}
+
+// plain (no affine, same resolution) single-channel source; Cout in {16, 32}.  The kernel is generic in CIN, but on
+// MI355X only CIN = 1 beats the MFMA path: measured c1 (1 -> 32, 32^3, B = 32) 0.133 -> 0.062 ms and the backward-data
+// of decoder_output (1 -> 16) 0.167 -> 0.026 ms, while e0 (16 -> 16) 0.356 -> 0.420 ms and e1 (16 -> 32 at 16^3)
+// 0.055 -> 0.119 ms got slower (216 float4 loads per thread: L1-bound) -- so wider inputs stay on the MFMA kernels.
+static bool thin_c_shape_ok(const ConvGeom& g, int cin_log, int cout) {
+  return g.taps == 27 && g.S >= 4 && (cout == 16 || cout == 32) && cin_log == 1 && !(g.flags & CF_NO_THIN_C);
+}
+bool conv_thin_c_ok(const ConvGeom& g, const ConvSrc& s0, int nsrc, int cin_log) {
+  return nsrc == 1 && s0.scale == nullptr && !s0.up && !s0.bcast && s0.C == cin_log && thin_c_shape_ok(g, cin_log, g.Cout);
+}
+int launch_conv_fwd_thin_c(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, int cin_log, int wstride,
+                           const float* wp, const float* bias, float* out, int ldo, int pre_act, float* stat_partial,
+                           int* rows_per_block) {
+  ICS_CHECK(conv_thin_c_ok(g, s0, 1, cin_log) && wstride >= cin_log && ldo % 4 == 0, "thin-C conv: unsupported shape");
+  const int M = g.B << (3 * g.lgS);
+  const int lpv = g.Cout / 4, vpb = 4 * (256 / lpv);
+  const dim3 grid((M + vpb - 1) / vpb);
+  const size_t lds = (size_t)std::max(27 * wstride * g.Cout, 5 * g.Cout) * sizeof(float);
+  if (rows_per_block) *rows_per_block = vpb;
+#define ICS_TC(CINV, COUTV)                                                                                          \
+  do {                                                                                                               \
+    auto kern = conv_thin_c_fwd_kernel<CINV, COUTV>;                                                                 \
+    static DevOnce attr;                                                                                             \
+    int dev;                                                                                                         \
+    if (attr.need(&dev)) {                                                                                           \
+      ICS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                  27 * 8 * COUTV * 4));                                                              \
+      attr.mark(dev);                                                                                                \
+    }                                                                                                                \
+    g_last_kernel_id = "conv_thin_c_fwd_kernel<" #CINV ", " #COUTV ">";                                              \
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, g, s0.p, wstride, wp, bias, out, ldo, pre_act, stat_partial); \
+  } while (0)
+  if (g.Cout == 32) ICS_TC(1, 32); else ICS_TC(1, 16);
+#undef ICS_TC
+  ICS_HIP(hipGetLastError());
+  return 0;
+}
+
+// =====================================================================================
 // Thin-N direct kernels (Cout <= 4: the VAE's decoder_output conv, backward-data of the first conv).
 // A 32-wide MFMA tile would be >= 87 % padding here; these are HBM/L1-bound stencils on the vector ALU:
 // one thread per output voxel (forward) / one thread per weight row (backward-weight).
@@ -1089,7 +1267,9 @@ static int thin_n_wgrad_splits(const ConvGeom& g) {
 // tile, each sums a slice of K into ws[split][M][Npad]; splitk_finish_kernel adds the slices in fixed order
 // and runs the epilogue (bias, activation, store, BatchNorm partial statistics of 64-row blocks).
 static int fwd_splitk_plan(const ConvGeom& g, const ConvSrc& s0, const ConvSrc& s1, int nsrc) {
-  if ((g.flags & CF_NO_FWD_SPLITK) || !fwd_is_vec(g, s0, s1) || conv_is_thin(g, s0, nsrc) || thin_n_ok(g, s0, nsrc)) return 1;
+  if ((g.flags & CF_NO_FWD_SPLITK) || !fwd_is_vec(g, s0, s1) || conv_is_thin(g, s0, nsrc) || thin_n_ok(g, s0, nsrc) ||
+      conv_thin_c_ok(g, s0, nsrc, g.Cin))
+    return 1;
   int bm, bn;
   pick_fwd_tile(g, &bm, &bn);
   if (bm != 64) return 1;
@@ -1203,6 +1383,9 @@ static int launch_conv_fwd_inner(hipStream_t st, const ConvGeom& g, const ConvSr
                                  const BwdStat* bwd) {
   if (ksplit == 1 && thin_n_ok(g, src[0], nsrc))
     return launch_thin_n_fwd(st, g, src[0], wp, bias, out, ldo, pre_act, stat_partial, rows_per_block, accumulate);
+  if (ksplit == 1 && !accumulate && bwd == nullptr && conv_thin_c_ok(g, src[0], nsrc, g.Cin) && ldo % 4 == 0)
+    return launch_conv_fwd_thin_c(st, g, src[0], g.Cin, g.Cin, wp, bias, out, ldo, pre_act, stat_partial,
+                                  rows_per_block);
   ConvSrc s0 = src[0], s1 = src[nsrc > 1 ? 1 : 0];
   if (nsrc == 1) s1.C = 0;
   // loader variants: 0 = plain sources (backward-data, pooled inputs), 1 = BN affine/activation,

@@ -513,8 +513,15 @@ static int conv_forward(Net& n, ConvLayer& L, int B, bool training, bool update_
   } else {
   n.prof.begin(n.st, "conv_fwd:" + L.name + "|", 2.0 * M * L.taps * L.Cin * L.Cout,
                4.0 * (M * L.Cin + M * L.Cout + (double)L.taps * L.Cin * L.Cout));
-  ICS_TRY(launch_conv_fwd(n.st, g, L.src, L.nsrc, L.wp, bias, L.s, L.Cout, L.pre_act,
-                          stats ? n.ws_stat : nullptr, &rpb, 0, n.fws(), n.ws_fwd_n));
+  if (L.pad_in && L.nvsrc == 1 && conv_thin_c_ok(g, L.vsrc[0], 1, L.Cin) && L.Cout % 4 == 0) {
+    // single-channel input (c1 at C = 1): the direct stencil reads the un-padded tensor; the packed weights keep the
+    // padded layout (CinG channels per tap) the backward-weight kernel is built for
+    ICS_TRY(launch_conv_fwd_thin_c(n.st, g, L.vsrc[0], L.Cin, L.CinG, L.wp, bias, L.s, L.Cout, L.pre_act,
+                                   stats ? n.ws_stat : nullptr, &rpb));
+  } else {
+    ICS_TRY(launch_conv_fwd(n.st, g, L.src, L.nsrc, L.wp, bias, L.s, L.Cout, L.pre_act,
+                            stats ? n.ws_stat : nullptr, &rpb, 0, n.fws(), n.ws_fwd_n));
+  }
   n.prof.end(n.st);
   }
   if (L.has_bn) {

@@ -1,5 +1,5 @@
 """Every fast path has an A/B switch (ICSG3D_NO_*) that routes the same layer through the general kernels.
-Most switches are read once per process, so each configuration runs in a subprocess; all of them must give
+The switches are read when an engine is created; each configuration runs in its own subprocess; all of them must give
 the same forward results and train-step metrics as the default configuration (different summation orders:
 <= 2e-5), which keeps the fallback kernels covered at the network's real layer shapes."""
 import json
@@ -53,7 +53,8 @@ def default_run():
 
 
 @pytest.mark.parametrize("switch", ["ICSG3D_NO_REUSE", "ICSG3D_NO_WGRAD3", "ICSG3D_NO_FWD_SPLITK",
-                                    "ICSG3D_NO_THIN_N", "ICSG3D_NO_UPSPLIT"])
+                                    "ICSG3D_NO_THIN_N", "ICSG3D_NO_UPSPLIT", "ICSG3D_NO_THIN_C", "ICSG3D_NO_BWD_FOLD",
+                                    "ICSG3D_NO_WGRAD3S", "ICSG3D_SIDE_STREAM"])
 def test_fallback_path_matches_default(default_run, switch):
     alt = _run({switch: "1"})
     for k, ref in default_run.items():
