@@ -840,7 +840,7 @@ static int launch_fwd_cfg(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, 
   static const std::string id = std::string("conv_fwd_kernel<") + std::to_string(WM) + ", " + std::to_string(WN) + ", " +
                                 std::to_string(TM) + ", " + std::to_string(TN) + ", " + tf(VEC) + ", " +
                                 std::to_string(ABL) + ", " + tf(AFF) + ", " + tf(UP) + ", " + tf(THIN) + ", " +
-                                tf(REUSE) + ", " + tf(PAR) + ", " + tf(NOACT) + (FOLD ? ", true>" : ">");
+                                tf(REUSE) + ", " + tf(PAR) + ", " + tf(NOACT) + ", " + tf(FOLD) + ">";
   g_last_kernel_id = id.c_str();
   BwdStat bs_arg;
   if (FOLD) bs_arg = *bwd;
