@@ -22,7 +22,10 @@ namespace ics {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));   // first-class vector: stays in VGPRs
 
-constexpr int kLDA = 36;   // A-tile row stride in floats: 32 + 4 pad -> conflict-free ds_read_b128
+#ifndef ICS_KLDA
+#define ICS_KLDA 36
+#endif
+constexpr int kLDA = ICS_KLDA;   // A-tile row stride in floats: 32 + 4 pad -> conflict-free ds_read_b128
 
 __device__ __forceinline__ int xcd_swizzle(int bid, int nblk) {
   // blocks are dispatched round-robin over the 8 XCDs; give each XCD a contiguous range of tiles
