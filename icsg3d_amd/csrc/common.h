@@ -76,7 +76,8 @@ enum ConvFlags : int {
   CF_NO_FWD_SPLITK = 8,   // ICSG3D_NO_FWD_SPLITK
   CF_NO_THIN_N = 16,      // ICSG3D_NO_THIN_N: Cout <= 4 layers through the MFMA kernels
   CF_NO_UPSPLIT = 32,     // ICSG3D_NO_UPSPLIT: direct 27-tap evaluation of upsampled inputs
-  CF_NO_THIN_C = 64,      // ICSG3D_NO_THIN_C: thin-input layers (c1, e0, e1) through the MFMA kernels
+  CF_NO_THIN_C = 64,      // ICSG3D_NO_THIN_C: single-channel-input layers through the MFMA kernels
+  CF_NO_COND_FOLD = 128,  // ICSG3D_NO_COND_FOLD: the VAE encoder's K.tile'd condition as materialised input channels
 };
 int conv_flags_from_env();
 
@@ -117,9 +118,14 @@ size_t conv_fwd_workspace_floats(const ConvGeom& g, const ConvSrc* src, int nsrc
 // Thin-C direct stencil forward (see conv_igemm.hip): plain single source with cin_log in {1,4,16} channels, Cout in
 // {16,32}; wstride = input channels per tap in the packed weights (>= cin_log)
 bool conv_thin_c_ok(const ConvGeom& g, const ConvSrc& s0, int nsrc, int cin_log);
+// backward-weight of a single-channel-input layer: dw[(tap*row_pitch)*ldw + co]; phase as launch_conv_wgrad
+size_t conv_thin_c_wgrad_workspace_floats(const ConvGeom& g);
+int launch_conv_wgrad_thin_c(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, const float* dy, int ldy, float* dw,
+                             int ldw, int row_pitch, float* ws, size_t ws_floats, int phase);
 int launch_conv_fwd_thin_c(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, int cin_log, int wstride,
                            const float* wp, const float* bias, float* out, int ldo, int pre_act, float* stat_partial,
-                           int* rows_per_block);
+                           int* rows_per_block, const float* pos_bias = nullptr);
+// pos_bias: optional [B][27][Cout] position-dependent bias (border class = first/interior/last plane per axis)
 int launch_conv_fwd_par(hipStream_t st, const ConvGeom& g_lowres, const ConvSrc& src, const float* wpar, float* out,
                         int ldo, const float* bias = nullptr, int pre_act = ACT_NONE, float* stat_partial = nullptr,
                         int* stat_blocks = nullptr);

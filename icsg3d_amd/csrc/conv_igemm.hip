@@ -48,6 +48,7 @@ int conv_flags_from_env() {
   if (getenv("ICSG3D_NO_THIN_N")) f |= CF_NO_THIN_N;
   if (getenv("ICSG3D_NO_UPSPLIT")) f |= CF_NO_UPSPLIT;
   if (getenv("ICSG3D_NO_THIN_C")) f |= CF_NO_THIN_C;
+  if (getenv("ICSG3D_NO_COND_FOLD")) f |= CF_NO_COND_FOLD;
   return f;
 }
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remember per (kernel instantiation, device)
@@ -902,7 +903,8 @@ __global__ __launch_bounds__(256) void conv_thin_c_fwd_kernel(ConvGeom g, const 
                                                                const float* __restrict__ wp,
                                                                const float* __restrict__ bias,
                                                                float* __restrict__ out, int ldo, int pre_act,
-                                                               float* __restrict__ stat_partial) {
+                                                               float* __restrict__ stat_partial,
+                                                               const float* __restrict__ pos_bias) {
   constexpr int LPV = COUT / 4;            // lanes per voxel group
   constexpr int GPB = 256 / LPV;           // voxel groups (of 4 voxels) per block
   constexpr int VPB = 4 * GPB;             // voxels per block
@@ -969,8 +971,19 @@ __global__ __launch_bounds__(256) void conv_thin_c_fwd_kernel(ConvGeom g, const 
   v4f bv = v4f{0.f, 0.f, 0.f, 0.f};       // (scalar loads: a tensor inside the flat parameter buffer need not be 16-B aligned)
   if (bias != nullptr) { bv.x = bias[4 * q]; bv.y = bias[4 * q + 1]; bv.z = bias[4 * q + 2]; bv.w = bias[4 * q + 3]; }
   float csum[4] = {0.f, 0.f, 0.f, 0.f};
+  // pos_bias [B][27][COUT]: position-dependent bias -- the contribution of spatially constant input channels (the
+  // K.tile'd condition of the VAE encoder, lattice_vae.py:167-169), which differs only between the 27 border classes
+  // (first / interior / last plane per axis) because of the zero "same" padding; it already includes the layer bias
+  const int bsmp = m0 >> (3 * lg);
+  const int czy = ((z == 0 ? 0 : (z == S - 1 ? 2 : 1)) * 3 + (y == 0 ? 0 : (y == S - 1 ? 2 : 1))) * 3;
 #pragma unroll
   for (int v = 0; v < 4; ++v) {
+    if (pos_bias != nullptr && gvalid) {
+      const int xx = x0 + v;
+      const int cls = czy + (xx == 0 ? 0 : (xx == S - 1 ? 2 : 1));
+      const float* pb = pos_bias + ((size_t)bsmp * 27 + cls) * COUT + 4 * q;
+      bv.x = pb[0]; bv.y = pb[1]; bv.z = pb[2]; bv.w = pb[3];
+    }
     acc[v][0] = act_apply(acc[v][0] + bv.x, pre_slope); acc[v][1] = act_apply(acc[v][1] + bv.y, pre_slope);
     acc[v][2] = act_apply(acc[v][2] + bv.z, pre_slope); acc[v][3] = act_apply(acc[v][3] + bv.w, pre_slope);
     if (gvalid) {
@@ -1025,6 +1038,109 @@ __global__ __launch_bounds__(256) void conv_thin_c_fwd_kernel(ConvGeom g, const 
   }
 }
 
+static int launch_reduce_splits(hipStream_t st, const float* ws, int nsplit, size_t n_elems, int N, float* dw, int ldw,
+                                int sub_rows, int row_pitch, int row_off);
+
+// Backward-weight of the same layers for a single-channel input:  dW[tap][co] = sum_v x[v + off(tap)] * dy[v][co]
+// (27 x COUT numbers reduced over all voxels).  Same thread shape as the forward stencil -- a thread owns 4 x-voxels
+// x 4 output channels and keeps its 27 x 4 partial sums in registers over a strip of voxel groups; per group it needs
+// 4 float4 of dy and the 9 x 6 input positions around it (432 FMAs).  Partials are combined across the lanes holding
+// the same channel quad (xor shuffles), the waves (LDS) and the blocks (ws[split][27][COUT] + reduce_splits).
+template <int COUT>
+__global__ __launch_bounds__(256) void conv_thin_c_wgrad_kernel(ConvGeom g, const float* __restrict__ x,
+                                                                 const float* __restrict__ dy, int ldy,
+                                                                 float* __restrict__ ws, int groups_per_block) {
+  constexpr int LPV = COUT / 4;
+  constexpr int GPW = 256 / LPV;            // voxel groups handled per pass of the block
+  __shared__ float red[4][LPV][27 * 4];
+  const int t = threadIdx.x;
+  const int S = g.S, lg = g.lgS;
+  const int M = g.B << (3 * lg);
+  const int q = t % LPV, slot = t / LPV;
+  float acc[27][4];
+#pragma unroll
+  for (int k = 0; k < 27; ++k)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[k][j] = 0.f;
+  const int g_begin = (int)blockIdx.x * groups_per_block;
+  const int g_end = min(g_begin + groups_per_block, M >> 2);
+  for (int gi = g_begin + slot; gi < g_end; gi += GPW) {
+    const int m0 = gi << 2;
+    const int x0 = m0 & (S - 1), y = (m0 >> lg) & (S - 1), z = (m0 >> (2 * lg)) & (S - 1);
+    v4f d[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) d[v] = *reinterpret_cast<const v4f*>(dy + (size_t)(m0 + v) * ldy + 4 * q);
+#pragma unroll
+    for (int gzy = 0; gzy < 9; ++gzy) {
+      const int dz = gzy / 3 - 1, dyo = gzy % 3 - 1;
+      const bool rowok = (unsigned)(z + dz) < (unsigned)S && (unsigned)(y + dyo) < (unsigned)S;
+      const long rowbase = (long)m0 + (long)(dz * S + dyo) * S - 1;
+      float xv[6];
+#pragma unroll
+      for (int p = 0; p < 6; ++p) {
+        const bool ok = rowok && (unsigned)(x0 + p - 1) < (unsigned)S;
+        xv[p] = ok ? x[rowbase + p] : 0.f;
+      }
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const float xs = xv[v + dx];
+          acc[gzy * 3 + dx][0] = fmaf(xs, d[v].x, acc[gzy * 3 + dx][0]);
+          acc[gzy * 3 + dx][1] = fmaf(xs, d[v].y, acc[gzy * 3 + dx][1]);
+          acc[gzy * 3 + dx][2] = fmaf(xs, d[v].z, acc[gzy * 3 + dx][2]);
+          acc[gzy * 3 + dx][3] = fmaf(xs, d[v].w, acc[gzy * 3 + dx][3]);
+        }
+    }
+  }
+  // lanes with equal q (stride LPV inside the wave) hold partials of the same 4 columns: fixed xor tree
+  const int lane = t & 63, wave = t >> 6;
+#pragma unroll
+  for (int k = 0; k < 27; ++k)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float a = acc[k][j];
+      for (int o = LPV; o < 64; o <<= 1) a += __shfl_xor(a, o);
+      if (lane < LPV) red[wave][lane][k * 4 + j] = a;
+    }
+  __syncthreads();
+  float* wsp = ws + (size_t)blockIdx.x * 27 * COUT;
+  for (int i = t; i < 27 * COUT; i += 256) {
+    const int k = i / COUT, co = i - k * COUT;
+    const int qq = co >> 2, j = co & 3;
+    wsp[i] = red[0][qq][k * 4 + j] + red[1][qq][k * 4 + j] + red[2][qq][k * 4 + j] + red[3][qq][k * 4 + j];
+  }
+}
+
+static int thin_c_wgrad_blocks(const ConvGeom& g) {
+  const long groups = ((long)g.B << (3 * g.lgS)) >> 2;
+  return (int)std::max(1L, std::min(2048L, groups / 256));     // >= 256 voxel groups (1024 voxels) per block
+}
+size_t conv_thin_c_wgrad_workspace_floats(const ConvGeom& g) { return (size_t)thin_c_wgrad_blocks(g) * 27 * g.Cout; }
+// dw[(tap * row_pitch) * ldw + co] for the single input channel (row_pitch = input channels per tap of dw's layout)
+int launch_conv_wgrad_thin_c(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, const float* dy, int ldy, float* dw,
+                             int ldw, int row_pitch, float* ws, size_t ws_floats, int phase) {
+  ICS_CHECK(conv_thin_c_ok(g, s0, 1, 1) && ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0,
+            "thin-C wgrad: unsupported shape");
+  const int nb = thin_c_wgrad_blocks(g);
+  ICS_CHECK((size_t)nb * 27 * g.Cout <= ws_floats, "wgrad workspace too small");
+  const long groups = ((long)g.B << (3 * g.lgS)) >> 2;
+  const int gpb = (int)((groups + nb - 1) / nb);
+  if (phase != 2) {
+    if (g.Cout == 32) {
+      g_last_kernel_id = "conv_thin_c_wgrad_kernel<32>";
+      hipLaunchKernelGGL(conv_thin_c_wgrad_kernel<32>, dim3(nb), dim3(256), 0, st, g, s0.p, dy, ldy, ws, gpb);
+    } else {
+      g_last_kernel_id = "conv_thin_c_wgrad_kernel<16>";
+      hipLaunchKernelGGL(conv_thin_c_wgrad_kernel<16>, dim3(nb), dim3(256), 0, st, g, s0.p, dy, ldy, ws, gpb);
+    }
+    ICS_HIP(hipGetLastError());
+  }
+  if (phase != 1)   // rows k = tap (sub_rows = 1) land on row tap * row_pitch of dw
+    ICS_TRY(launch_reduce_splits(st, ws, nb, (size_t)27 * g.Cout, g.Cout, dw, ldw, 1, row_pitch, 0));
+  return 0;
+}
+
 // plain (no affine, same resolution) single-channel source; Cout in {16, 32}.  The kernel is generic in CIN, but on
 // MI355X only CIN = 1 beats the MFMA path: measured c1 (1 -> 32, 32^3, B = 32) 0.133 -> 0.062 ms and the backward-data
 // of decoder_output (1 -> 16) 0.167 -> 0.026 ms, while e0 (16 -> 16) 0.356 -> 0.420 ms and e1 (16 -> 32 at 16^3)
@@ -1037,7 +1153,7 @@ bool conv_thin_c_ok(const ConvGeom& g, const ConvSrc& s0, int nsrc, int cin_log)
 }
 int launch_conv_fwd_thin_c(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, int cin_log, int wstride,
                            const float* wp, const float* bias, float* out, int ldo, int pre_act, float* stat_partial,
-                           int* rows_per_block) {
+                           int* rows_per_block, const float* pos_bias) {
   ICS_CHECK(conv_thin_c_ok(g, s0, 1, cin_log) && wstride >= cin_log && ldo % 4 == 0, "thin-C conv: unsupported shape");
   const int M = g.B << (3 * g.lgS);
   const int lpv = g.Cout / 4, vpb = 4 * (256 / lpv);
@@ -1055,7 +1171,8 @@ int launch_conv_fwd_thin_c(hipStream_t st, const ConvGeom& g, const ConvSrc& s0,
       attr.mark(dev);                                                                                                \
     }                                                                                                                \
     g_last_kernel_id = "conv_thin_c_fwd_kernel<" #CINV ", " #COUTV ">";                                              \
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, g, s0.p, wstride, wp, bias, out, ldo, pre_act, stat_partial); \
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, g, s0.p, wstride, wp, bias, out, ldo, pre_act, stat_partial, \
+                       pos_bias);                                                                                     \
   } while (0)
   if (g.Cout == 32) ICS_TC(1, 32); else ICS_TC(1, 16);
 #undef ICS_TC
@@ -1275,10 +1392,13 @@ static int fwd_splitk_plan(const ConvGeom& g, const ConvSrc& s0, const ConvSrc& 
     return 1;
   int bm, bn;
   pick_fwd_tile(g, &bm, &bn);
-  if (bm != 64) return 1;
+  // 64x64 tiles (S <= 8 layers) and the narrow 128x32 tile when it yields only a handful of blocks (the VAE's e4:
+  // 2^3 x 128 -> 4 and d0's backward-data: 4^3 x 128 -> 4 are 2..16 blocks walking K = 3456 alone: 0.13 ms of latency)
   const long M = (long)g.B << (3 * g.lgS);
-  const long blocks = ((M + 63) / 64) * (g.Npad / 64);
-  const bool reuse = g.taps == 27 && g.S >= 4 && g.S <= 64;
+  const bool narrow = bm == 128 && bn == 32 && (M + 127) / 128 * (g.Npad / 32) <= 64;
+  if (bm != 64 && !narrow) return 1;
+  const long blocks = narrow ? (M + 127) / 128 * (g.Npad / 32) : ((M + 63) / 64) * (g.Npad / 64);
+  const bool reuse = g.taps == 27 && g.S >= 4 && g.S <= bm;
   const long units = reuse ? 9L * (g.Cin / 32) : g.Kpad / 32;     // groups (3 chunks) or chunks
   const long min_units = reuse ? 3 : 8;
   long ks = std::min(768 / std::max(blocks, 1L), units / min_units);
@@ -1373,7 +1493,7 @@ int launch_conv_fwd(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int n
   const int M = g.B << (3 * g.lgS);
   ICS_CHECK((size_t)ks * M * g.Npad <= ws_floats, "forward split-K workspace too small");
   ICS_TRY(launch_conv_fwd_inner(st, g, src, nsrc, wp, nullptr, ws, g.Npad, ACT_NONE, nullptr, nullptr, 0, ks));
-  hipLaunchKernelGGL(splitk_finish_kernel, dim3((M + 63) / 64, g.Npad / 64), dim3(256), 0, st, ws, ks, M, g.Cout,
+  hipLaunchKernelGGL(splitk_finish_kernel, dim3((M + 63) / 64, (g.Npad + 63) / 64), dim3(256), 0, st, ws, ks, M, g.Cout,
                      g.Npad, bias, act_slope_of(pre_act), out, ldo, accumulate, stat_partial);
   ICS_HIP(hipGetLastError());
   if (rows_per_block) *rows_per_block = 64;

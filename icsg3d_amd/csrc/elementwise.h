@@ -95,6 +95,12 @@ int launch_vae_loss(hipStream_t st, const float* mulv, int ld, int latent, int B
                     float* metrics, double* sums = nullptr, int phase = 0);
 int launch_vae_dz(hipStream_t st, const float* mulv, int ld, int latent, int B, const float* eps,
                   const float* dzc, int ldzc, float beta, float* dmulv);
+// spatially constant input channels folded into a position-dependent bias / region sums (see elementwise.hip)
+int launch_cond_bias_table(hipStream_t st, const float* w, const float* bias, const float* cond, int C, int ncond,
+                           int Cin_tot, int Cout, int B, float* T);
+size_t cond_wgrad_workspace_doubles(int B, int Cout);
+int launch_cond_wgrad(hipStream_t st, const float* dy, int B, int S, int Cout, const float* cond, int C0, int nfold,
+                      int ncond, int Cin_tot, float* dw, double* ws, size_t ws_doubles);
 int launch_relu_bwd(hipStream_t st, const float* a, float* g, size_t n);
 int launch_colsum_small(hipStream_t st, const float* a, int rows, int cols, int ld, float* out);
 int launch_axpy(hipStream_t st, float* y, const float* x, size_t n, float a);

@@ -1014,6 +1014,137 @@ int launch_vae_dz(hipStream_t st, const float* mulv, int ld, int latent, int B, 
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// Spatially constant input channels (the VAE encoder's condition: Reshape -> K.tile -> Concatenate,
+// lattice_vae.py:167-169).  A 3x3x3 "same" conv over a channel that is constant in space gives, per sample, one
+// value per BORDER CLASS of the output voxel (first / interior / last plane on each axis: 27 classes) -- the zero
+// padding removes the taps that reach outside.  So instead of materialising C*cond extra input channels:
+//   forward : pos_bias[b][cls][co] = bias[co] + sum_{taps valid for cls} sum_j W[tap][C+j][co] * cond[b][j % ncond]
+//   backward: dW[tap][C+j][co] = sum_b cond[b][j % ncond] * D[b][tap][co],   D[b][tap] = sum of dy over the voxels
+//             whose tap-shifted position lies inside the grid = sums of the 27 REGION sums R[b][cls] of dy.
+// Exact reassociations of the same sums (the border regions are summed directly, the interior one is total - rest).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool tap_valid_for_class(int tapd /*0,1,2 = -1,0,+1*/, int cls /*0 first,1 interior,2 last*/) {
+  return !((cls == 0 && tapd == 0) || (cls == 2 && tapd == 2));
+}
+__global__ void cond_bias_table_kernel(const float* __restrict__ w, const float* __restrict__ bias,
+                                       const float* __restrict__ cond, int C, int ncond, int Cin_tot, int Cout, int B,
+                                       float* __restrict__ T) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * 27 * Cout) return;
+  const int co = i % Cout, cls = (i / Cout) % 27, b = i / (27 * Cout);
+  const int cz = cls / 9, cy = (cls / 3) % 3, cx = cls % 3;
+  double acc = bias ? (double)bias[co] : 0.0;
+  for (int tap = 0; tap < 27; ++tap) {
+    if (!tap_valid_for_class(tap / 9, cz) || !tap_valid_for_class((tap / 3) % 3, cy) || !tap_valid_for_class(tap % 3, cx))
+      continue;
+    for (int j = 0; j < C * ncond; ++j)
+      acc += (double)w[((size_t)tap * Cin_tot + C + j) * Cout + co] * (double)cond[b * ncond + (j % ncond)];
+  }
+  T[i] = (float)acc;
+}
+int launch_cond_bias_table(hipStream_t st, const float* w, const float* bias, const float* cond, int C, int ncond,
+                           int Cin_tot, int Cout, int B, float* T) {
+  const int n = B * 27 * Cout;
+  hipLaunchKernelGGL(cond_bias_table_kernel, dim3((n + 255) / 256), dim3(256), 0, st, w, bias, cond, C, ncond, Cin_tot,
+                     Cout, B, T);
+  ICS_HIP(hipGetLastError());
+  return 0;
+}
+
+// partial[b][blk][co] = sum of dy over chunk blk of sample b (per-sample totals, first stage)
+__global__ __launch_bounds__(256) void sample_colsum_kernel(const float* __restrict__ dy, size_t per_sample, int C,
+                                                             int blocks_per_sample, double* __restrict__ partial) {
+  __shared__ double sh[256];
+  const int b = blockIdx.x / blocks_per_sample, blk = blockIdx.x % blocks_per_sample;
+  const size_t chunk = (per_sample + blocks_per_sample - 1) / blocks_per_sample;
+  const size_t v0 = (size_t)blk * chunk, v1 = v0 + chunk < per_sample ? v0 + chunk : per_sample;
+  const int c = threadIdx.x % C, vr = threadIdx.x / C, VR = 256 / C;        // C divides 256 (16 or 32)
+  double acc = 0.0;
+  const float* base = dy + (size_t)b * per_sample * C;
+  for (size_t v = v0 + vr; v < v1; v += VR) acc += (double)base[v * C + c];
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  if (vr == 0) {
+    double s = 0.0;
+    for (int r = 0; r < VR; ++r) s += sh[r * C + c];
+    partial[((size_t)b * blocks_per_sample + blk) * C + c] = s;
+  }
+}
+// R[b][cls][co] for the 26 border classes (cls != 13): direct sums over the region's voxels
+__global__ __launch_bounds__(256) void border_region_sums_kernel(const float* __restrict__ dy, int S, int C,
+                                                                  double* __restrict__ R) {
+  __shared__ double sh[256];
+  const int b = blockIdx.x / 27, cls = blockIdx.x % 27;
+  const int cz = cls / 9, cy = (cls / 3) % 3, cx = cls % 3;
+  const int c = threadIdx.x % C, vr = threadIdx.x / C, VR = 256 / C;
+  auto lo = [&](int k) { return k == 0 ? 0 : (k == 1 ? 1 : S - 1); };
+  auto cnt = [&](int k) { return k == 1 ? S - 2 : 1; };
+  double acc = 0.0;
+  if (cls != 13) {
+    const int nz = cnt(cz), ny = cnt(cy), nx = cnt(cx);
+    const int total = nz * ny * nx;
+    const float* base = dy + (size_t)b * S * S * S * C;
+    for (int i = vr; i < total; i += VR) {
+      const int ix = i % nx, iy = (i / nx) % ny, iz = i / (nx * ny);
+      const size_t v = ((size_t)(lo(cz) + iz) * S + (lo(cy) + iy)) * S + (lo(cx) + ix);
+      acc += (double)base[v * C + c];
+    }
+  }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  if (vr == 0 && cls != 13) {
+    double s = 0.0;
+    for (int r = 0; r < VR; ++r) s += sh[r * C + c];
+    R[((size_t)b * 27 + cls) * C + c] = s;
+  }
+}
+// one block per tap: D[b][co] for this tap from the region sums, then dW[tap][C0 + j][co] = sum_b cond[b][j%ncond]*D
+__global__ __launch_bounds__(256) void cond_wgrad_kernel(const double* __restrict__ R, const double* __restrict__ tot_partial,
+                                                          int blocks_per_sample, const float* __restrict__ cond, int B,
+                                                          int C0, int nfold, int ncond, int Cin_tot, int Cout,
+                                                          float* __restrict__ dw) {
+  extern __shared__ double D[];            // [B][Cout]
+  const int tap = blockIdx.x;
+  const int tz = tap / 9, ty = (tap / 3) % 3, tx = tap % 3;
+  for (int i = threadIdx.x; i < B * Cout; i += 256) {
+    const int b = i / Cout, co = i % Cout;
+    double tot = 0.0, border = 0.0, d = 0.0;
+    for (int k = 0; k < blocks_per_sample; ++k) tot += tot_partial[((size_t)b * blocks_per_sample + k) * Cout + co];
+    for (int cls = 0; cls < 27; ++cls)
+      if (cls != 13) border += R[((size_t)b * 27 + cls) * Cout + co];
+    for (int cls = 0; cls < 27; ++cls) {
+      if (!tap_valid_for_class(tz, cls / 9) || !tap_valid_for_class(ty, (cls / 3) % 3) || !tap_valid_for_class(tx, cls % 3))
+        continue;
+      d += cls == 13 ? tot - border : R[((size_t)b * 27 + cls) * Cout + co];
+    }
+    D[i] = d;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nfold * Cout; i += 256) {
+    const int j = i / Cout, co = i % Cout;
+    double s = 0.0;
+    for (int b = 0; b < B; ++b) s += (double)cond[b * ncond + (j % ncond)] * D[b * Cout + co];
+    dw[((size_t)tap * Cin_tot + C0 + j) * Cout + co] = (float)s;
+  }
+}
+size_t cond_wgrad_workspace_doubles(int B, int Cout) { return (size_t)B * (64 + 27) * Cout; }
+int launch_cond_wgrad(hipStream_t st, const float* dy, int B, int S, int Cout, const float* cond, int C0, int nfold,
+                      int ncond, int Cin_tot, float* dw, double* ws, size_t ws_doubles) {
+  ICS_CHECK(256 % Cout == 0 && S >= 3, "cond wgrad: unsupported shape");
+  const int bps = 64;
+  ICS_CHECK(cond_wgrad_workspace_doubles(B, Cout) <= ws_doubles, "cond wgrad workspace too small");
+  double* tot_partial = ws;                                  // [B][64][Cout]
+  double* R = ws + (size_t)B * bps * Cout;                   // [B][27][Cout]
+  const size_t per = (size_t)S * S * S;
+  hipLaunchKernelGGL(sample_colsum_kernel, dim3(B * bps), dim3(256), 0, st, dy, per, Cout, bps, tot_partial);
+  hipLaunchKernelGGL(border_region_sums_kernel, dim3(B * 27), dim3(256), 0, st, dy, S, Cout, R);
+  hipLaunchKernelGGL(cond_wgrad_kernel, dim3(27), dim3(256), (size_t)B * Cout * sizeof(double), st, R, tot_partial, bps,
+                     cond, B, C0, nfold, ncond, Cin_tot, Cout, dw);
+  ICS_HIP(hipGetLastError());
+  return 0;
+}
+
 // relu backward for the Dense(256, relu): g *= (a > 0), where a is the stored relu OUTPUT
 __global__ void relu_bwd_kernel(const float* __restrict__ a, float* __restrict__ g, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

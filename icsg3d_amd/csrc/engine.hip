@@ -97,6 +97,8 @@ struct ConvLayer {
   std::string name;
   int Cin = 0, Cout = 0, taps = 27, S = 1;
   int flags = 0;                        // ConvFlags of the owning handle (carried into every ConvGeom)
+  bool cond_fold = false;               // VAE e0 at C = 1: the K.tile'd condition channels are folded into a
+  float* cond_T = nullptr;              // position-dependent bias [maxB][27][Cout] (forward) / region sums (backward)
   int bwd_pre_nblk = 0, bwd_pre_ld = 0; // > 0: this layer's BN-backward sums are in ws_bwd2 (set by the consumer's
                                         // backward-data launch, consumed by conv_backward)
   int CinG = 0;                         // GEMM input channels: Cin, or Cin zero-padded to 4/16/32k when the
@@ -309,7 +311,9 @@ static int alloc_layer(Net& n, ConvLayer& L, bool need_bwd, bool pooled) {
     ti = n.add_tensor(L.name + "/moving_var", {L.Cout}, false);
     n.tensors[ti].ptr = L.mv;
   }
-  if (L.CinG != L.Cin) {
+  if (L.cond_fold) {
+    ICS_TRY(n.alloc(&L.cond_T, (size_t)n.maxB * 27 * L.Cout));
+  } else if (L.CinG != L.Cin) {
     ICS_TRY(n.alloc(&L.pad_in, M * L.CinG));
     if (need_bwd) ICS_TRY(n.alloc(&L.dw_phys, (size_t)L.taps * L.CinG * L.Cout));
   }
@@ -405,6 +409,8 @@ static int alloc_workspaces(Net& n, bool need_bwd) {
       // Cout may be a non power of two only for the head, which never goes through layer_bwd
       if ((L.Cout & (L.Cout - 1)) == 0) bwd = std::max(bwd, layer_bwd_workspace_floats(lb));
       wg = std::max(wg, conv_wgrad_workspace_floats(g, L.src, L.nsrc));
+      if ((L.Cin == 1 || L.cond_fold) && (L.Cout == 16 || L.Cout == 32))
+        wg = std::max(wg, conv_thin_c_wgrad_workspace_floats(g));
       if (L.split_up) {
         const ConvSrc lo = src_lowres(L);
         wg = std::max(wg, conv_wgrad_workspace_floats(geom_up_wgrad(L, n.maxB), &lo, 1));
@@ -428,6 +434,8 @@ static int alloc_workspaces(Net& n, bool need_bwd) {
     ICS_TRY(n.alloc(&n.ws_bwd2, b2 + 16));
   }
   n.ws_dbl_n = 1 << 16;
+  for (auto& Lp : n.layers)
+    if (Lp->cond_fold) n.ws_dbl_n = std::max(n.ws_dbl_n, cond_wgrad_workspace_doubles(n.maxB, Lp->Cout));
   ICS_TRY(n.alloc(&n.ws_dbl, n.ws_dbl_n));
   ICS_TRY(n.alloc(&n.d_metrics, (size_t)16));
   ICS_TRY(n.alloc(&n.d_red, (size_t)16));
@@ -521,7 +529,14 @@ static int conv_forward(Net& n, ConvLayer& L, int B, bool training, bool update_
   } else {
   n.prof.begin(n.st, "conv_fwd:" + L.name + "|", 2.0 * M * L.taps * L.Cin * L.Cout,
                4.0 * (M * L.Cin + M * L.Cout + (double)L.taps * L.Cin * L.Cout));
-  if (L.pad_in && L.nvsrc == 1 && conv_thin_c_ok(g, L.vsrc[0], 1, L.Cin) && L.Cout % 4 == 0) {
+  if (L.cond_fold) {
+    // x (one channel) through the direct stencil; the spatially constant condition channels enter as a bias that
+    // depends only on the sample and on the voxel's border class (see launch_cond_bias_table)
+    const ConvSrc& cs = L.vsrc[1];
+    ICS_TRY(launch_cond_bias_table(n.st, n.tp(L.t_w), bias, cs.p, L.vsrc[0].C, cs.bcast, L.Cin, L.Cout, B, L.cond_T));
+    ICS_TRY(launch_conv_fwd_thin_c(n.st, g, L.vsrc[0], L.vsrc[0].C, L.CinG, L.wp, nullptr, L.s, L.Cout, L.pre_act,
+                                   stats ? n.ws_stat : nullptr, &rpb, L.cond_T));
+  } else if (L.pad_in && L.nvsrc == 1 && conv_thin_c_ok(g, L.vsrc[0], 1, L.Cin) && L.Cout % 4 == 0) {
     // single-channel input (c1 at C = 1): the direct stencil reads the un-padded tensor; the packed weights keep the
     // padded layout (CinG channels per tap) the backward-weight kernel is built for
     ICS_TRY(launch_conv_fwd_thin_c(n.st, g, L.vsrc[0], L.Cin, L.CinG, L.wp, bias, L.s, L.Cout, L.pre_act,
@@ -683,6 +698,26 @@ static int conv_grads_from_dy(Net& n, ConvLayer& L, int B, bool need_dA, bool pa
     n.prof.begin(ws, "conv_wgrad:" + L.name + "|", 2.0 * M * L.taps * L.Cin * L.Cout,
                  4.0 * (M * L.Cin + M * L.Cout + (double)L.taps * L.Cin * L.Cout));
     float* dw = L.dw_phys ? L.dw_phys : n.tg(L.t_w);
+    // single-channel input (c1 at C = 1): direct stencil reduction on the un-padded tensor, straight into G
+    const bool thin1 = L.pad_in && L.nvsrc == 1 && L.Cin == 1 && conv_thin_c_ok(g, L.vsrc[0], 1, 1) && L.Cout % 4 == 0;
+    if (L.cond_fold) {
+      // rows of the x channel: stencil reduction; rows of the condition channels: region sums of dy x cond
+      const ConvSrc& cs = L.vsrc[1];
+      const int C0 = L.vsrc[0].C;
+      ICS_TRY(launch_conv_wgrad_thin_c(ws, g, L.vsrc[0], L.dy, L.Cout, n.tg(L.t_w), L.Cout, L.Cin, n.ws_wgrad,
+                                       n.ws_wgrad_n, 0));
+      ICS_TRY(launch_cond_wgrad(ws, L.dy, B, L.S, L.Cout, cs.p, C0, cs.C, cs.bcast, L.Cin, n.tg(L.t_w), n.ws_dbl,
+                                n.ws_dbl_n));
+      n.prof.end(ws);
+    } else if (thin1) {
+      ICS_TRY(launch_conv_wgrad_thin_c(ws, g, L.vsrc[0], L.dy, L.Cout, n.tg(L.t_w), L.Cout, L.Cin, n.ws_wgrad,
+                                       n.ws_wgrad_n, 1));
+      n.prof.end(ws);
+      n.prof.begin(ws, "wgrad_reduce_splits", 0, 0);
+      ICS_TRY(launch_conv_wgrad_thin_c(ws, g, L.vsrc[0], L.dy, L.Cout, n.tg(L.t_w), L.Cout, L.Cin, n.ws_wgrad,
+                                       n.ws_wgrad_n, 2));
+      n.prof.end(ws);
+    } else {
     ICS_TRY(launch_conv_wgrad(ws, g, L.src, L.nsrc, L.dy, L.Cout, dw, L.Cout, n.ws_wgrad, n.ws_wgrad_n, 0, 0, 0, 1));
     n.prof.end(ws);
     n.prof.begin(ws, "wgrad_reduce_splits", 0, 0);
@@ -694,6 +729,7 @@ static int conv_grads_from_dy(Net& n, ConvLayer& L, int B, bool need_dA, bool pa
       ICS_HIP(hipGetLastError());
     }
     n.prof.end(ws);
+    }
   }
   if (need_dA) {
     ConvGeom gb = geom_bwd(L, B);
@@ -1116,7 +1152,10 @@ static int vae_build(Net& n, const ics_vae_config& cfg, Net* pm) {
   int cin = C + C * cfg.cond_shape;   // K.tile quirk: cond channels = C*cond_shape
   int S = d;
   for (int i = 0; i < 4; ++i) {
-    add_conv(n, "e" + std::to_string(i), cin, cfg.filters[i], 27, S, ACT_NONE, 1, ACT_LRELU, false, true, i == 0);
+    ConvLayer* L = add_conv(n, "e" + std::to_string(i), cin, cfg.filters[i], 27, S, ACT_NONE, 1, ACT_LRELU, false, true, i == 0);
+    // e0 at C = 1: condition channels folded analytically (exact; needs the single-channel stencil kernels)
+    if (i == 0 && C == 1 && !(n.flags & (CF_NO_COND_FOLD | CF_NO_THIN_C)) && (cfg.filters[0] == 16 || cfg.filters[0] == 32))
+      L->cond_fold = true;
     cin = cfg.filters[i]; S /= 2;
   }
   add_conv(n, "e4", cin, 4, 27, S, ACT_LRELU, 0, ACT_NONE, false);        // S = d/16
