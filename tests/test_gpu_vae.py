@@ -61,10 +61,12 @@ def _pm_layer_shapes(B, d):
     return {n: (B, d // r, d // r, d // r, cout[n]) for n, r in res.items()}
 
 
-def test_vae_train_step_matches_oracle(relerr):
+@pytest.mark.parametrize("B", [2, 3, 5])
+def test_vae_train_step_matches_oracle(B, relerr):
     """One DFC-VAE train step: [Loss, PM, MSE, KLD], all gradients, BN statistics, frozen U-Net.
-    Activation kinks are pinned to the engine's stored activations (oracle.apply_kink)."""
-    B, d, C = 2, 16, 1
+    Activation kinks are pinned to the engine's stored activations (oracle.apply_kink).  Odd batch sizes: ragged
+    last tiles, split plans and block-to-sample mappings that do not divide evenly."""
+    d, C = 16, 1
     uo, vo, ue, ve, X, cond, eps = _setup(B, d, C)
     m = ve.train_step(X, cond, eps)
     kink = {n: ve.get_activation(n, s) for n, s in _vae_layer_shapes(B, d, C).items()}
