@@ -501,7 +501,9 @@ static int conv_forward(Net& n, ConvLayer& L, int B, bool training, bool update_
   const size_t M = n.rows(L, B);
   const bool stats = L.has_bn && training;
   int rpb = 128, par_blocks = 0;
-  if (L.pad_in) {
+  // single-channel input served by the direct stencils (forward AND backward-weight): the padded copy is never read
+  const bool thin1_all = L.pad_in && L.nvsrc == 1 && L.Cin == 1 && conv_thin_c_ok(g, L.vsrc[0], 1, 1) && L.Cout % 4 == 0;
+  if (L.pad_in && !thin1_all) {
     n.prof.begin(n.st, "materialize_input", 0, 4.0 * M * (L.Cin + L.CinG));
     ICS_TRY(launch_materialize_input(n.st, L.vsrc, L.nvsrc, L.Cin, L.CinG, B, L.S, L.pad_in));
     n.prof.end(n.st);
