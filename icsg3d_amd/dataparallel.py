@@ -49,3 +49,56 @@ def max_over_ranks(dist, value: float) -> float:
     t = torch.tensor([float(value)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+class DataParallelMixin:
+    """Data parallelism through the class API (AtomUnet / LatticeDFCVAE).  `enable_data_parallel` records the
+    process group; the communicator is attached whenever the model (re)creates its engine -- all ranks do that
+    at the same step because they see the same batch sizes.  Every rank runs the same number of steps (the
+    caller shards the id lists to equal lengths: `shard_ids`); the loss/metric values a step returns are
+    already reduced over the ranks, so every rank takes the same checkpoint decisions and only rank 0 writes."""
+
+    _dp = None
+
+    def enable_data_parallel(self, dist, rank: int, world: int, sync_bn: bool = False, force: bool = False):
+        self._dp = (dist, int(rank), int(world), bool(sync_bn), bool(force))
+        if getattr(self, "_eng", None) is not None:
+            self._dp_attach(self._eng)
+        return self
+
+    def _dp_attach(self, engine):
+        if self._dp is not None:
+            dist, rank, world, sync_bn, force = self._dp
+            init_engine_comm(engine, dist, rank, world, sync_bn=sync_bn, force=force)
+
+    def _dp_is_writer(self) -> bool:
+        return self._dp is None or self._dp[1] == 0
+
+    def _dp_barrier(self):
+        if self._dp is not None and self._dp[2] > 1:
+            self._dp[0].barrier()
+
+
+def shard_ids(ids, rank: int, world: int, batch_size: int):
+    """This rank's share of an id list: ids[rank::world], every rank cut to the same whole number of
+    batches (a rank with one batch more would wait for ever in the gradient all-reduce)."""
+    n_batches = len(ids) // (world * batch_size)
+    return list(ids[rank::world])[:n_batches * batch_size]
+
+
+def from_env():
+    """(dist, rank, world, local_rank) when launched under torch.distributed.run with WORLD_SIZE > 1 -- the
+    control plane is initialised over gloo -- else None.  ICSG3D_FORCE_DP=1 takes the data-parallel path with a
+    single rank too (a 1-GPU box can then exercise it end to end; pass force=True to enable_data_parallel)."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "RANK" not in os.environ or (world <= 1 and os.environ.get("ICSG3D_FORCE_DP") != "1"):
+        return None
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from . import _lib
+    _lib.check(_lib.load().ics_set_device(local_rank))       # one process per GPU
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        dist.init_process_group("gloo")
+    return dist, int(os.environ["RANK"]), world, local_rank

@@ -15,6 +15,7 @@ import numpy as np
 
 from ..checkpoint import load_weights as _load_weight_file
 from ..checkpoint import save_weights as _save_weight_file
+from ..dataparallel import DataParallelMixin
 from ..engine import UnetEngine
 from ..synthetic import bn_state_defaults, glorot_params, unet_param_shapes
 from .get_weights import get_weights
@@ -201,13 +202,15 @@ class _BestCheckpoint:
     def on_epoch_end(self, epoch, logs):
         v = logs.get("val_loss", logs.get("loss"))
         if v is not None and v < self.best:
-            print("Epoch %05d: val_loss improved from %.5f to %.5f, saving model to %s"
-                  % (epoch + 1, self.best, v, self.filepath))
+            if self.model._o._dp_is_writer():
+                print("Epoch %05d: val_loss improved from %.5f to %.5f, saving model to %s"
+                      % (epoch + 1, self.best, v, self.filepath))
             self.best = v
-            self.model.save_weights(self.filepath)
+            if self.model._o._dp_is_writer():        # data parallel: same decision on every rank, rank 0 writes
+                self.model.save_weights(self.filepath)
 
 
-class AtomUnet:
+class AtomUnet(DataParallelMixin):
     """U-Net for semantic segmentation of electron-density maps (unet/unet.py:224-391).
 
     num_classes, class_weights, weights, input_shape, lr: as the reference.  class_weights is
@@ -252,6 +255,7 @@ class AtomUnet:
                                    d=self.input_shape[0], max_batch=max(batch, self._max_batch or 0), lr=self.lr,
                                    pool_ties=self.pool_ties)
             self._eng.set_weights(carry)
+            self._dp_attach(self._eng)
         elif grow and batch > self._eng.max_batch:
             carry, opt = self._eng.get_weights(), self._eng.get_optimizer_state()
             self._eng.close()
@@ -259,6 +263,7 @@ class AtomUnet:
                                    d=self.input_shape[0], max_batch=batch, lr=self.lr, pool_ties=self.pool_ties)
             self._eng.set_weights(carry)
             self._eng.set_optimizer_state(*opt)
+            self._dp_attach(self._eng)
         return self._eng
 
     def _get_weights(self):
@@ -273,13 +278,18 @@ class AtomUnet:
     # ---- reference methods
     def train_generator(self, train_gen, val_gen, epochs=100, output_dir="output/unet/"):
         print("Training...")
-        callbacks = [_BestCheckpoint(self.model, self.filepath), TrainingPlot(val_gen, output_dir)]
+        callbacks = [_BestCheckpoint(self.model, self.filepath)]
+        if self._dp_is_writer():
+            callbacks.append(TrainingPlot(val_gen, output_dir))
         self.model.fit_generator(generator=train_gen, validation_data=val_gen, use_multiprocessing=False,
                                  workers=4, epochs=epochs, callbacks=callbacks)
+        self._dp_barrier()                               # rank 0 has finished writing the best checkpoint
         if os.path.exists(self.filepath):
             self.model.load_weights(self.filepath)
-        self.model.save(os.path.splitext(self.filepath)[0] + ".h5")
-        print("Model saved")
+        if self._dp_is_writer():
+            self.model.save(os.path.splitext(self.filepath)[0] + ".h5")
+            print("Model saved")
+        self._dp_barrier()
 
     def predict_generator(self, test_gen):
         return self.model.predict_generator(test_gen)

@@ -17,6 +17,7 @@ import numpy as np
 
 from ..checkpoint import load_weights as _load_weight_file
 from ..checkpoint import save_weights as _save_weight_file
+from ..dataparallel import DataParallelMixin
 from ..engine import UnetEngine, VaeEngine
 from ..synthetic import bn_state_defaults, glorot_params, unet_param_shapes, vae_param_shapes
 from ..unet.unet import custom_objects
@@ -98,7 +99,7 @@ class _VaeModel:
         _save_weight_file(path, self._o._get_weights(), "vae", full_model=True)
 
 
-class LatticeDFCVAE:
+class LatticeDFCVAE(DataParallelMixin):
     """Conditional VAE with a deep-feature-consistent (perceptual U-Net) loss; parameters as
     lattice_vae.py:89-105.  `perceptual_model` is a U-Net checkpoint written by
     `AtomUnet.model.save` (or an AtomUnet / dict of weights); its weights stay frozen and its
@@ -157,12 +158,14 @@ class LatticeDFCVAE:
             carry = dict(self._host_weights)
             self._build(max(batch, self.batch_size or 0))
             self._eng.set_weights(carry)
+            self._dp_attach(self._eng)
         elif grow and batch > self._eng.max_batch:
             carry, opt = self._eng.get_weights(), self._eng.get_optimizer_state()
             self._eng.close(); self._pm_eng.close()
             self._build(batch)
             self._eng.set_weights(carry)
             self._eng.set_optimizer_state(*opt)
+            self._dp_attach(self._eng)
         return self._eng
 
     def _get_weights(self):
@@ -215,12 +218,16 @@ class LatticeDFCVAE:
             self.losses[e] = [tm[0], vm[0]]
             if vm[0] < best_loss:
                 best_loss = vm[0]
-                print("Saving Model")
-                self.model.save_weights(self.filepath)
+                if self._dp_is_writer():                 # data parallel: vm is rank-reduced, rank 0 writes
+                    print("Saving Model")
+                    self.model.save_weights(self.filepath)
+        self._dp_barrier()
         if os.path.exists(self.filepath):
             self.model.load_weights(self.filepath)
-        self.model.save(os.path.splitext(self.filepath)[0] + ".h5")
-        print("Model saved")
+        if self._dp_is_writer():
+            self.model.save(os.path.splitext(self.filepath)[0] + ".h5")
+            print("Model saved")
+        self._dp_barrier()
 
     @staticmethod
     def _batches(gen, steps):

@@ -111,3 +111,49 @@ def test_bench_through_torchrun_single_rank():
     r = json.loads(lines[0])
     assert r["n_gpus"] == 1 and r["value"] > 0 and "RCCL buckets" in r["config"]["grad_allreduce"]
     assert r["secondary"]["value"] > 0 and r["roofline"]["frac"] > 0
+
+
+def test_class_api_data_parallel_single_rank(tmp_path):
+    """AtomUnet.enable_data_parallel: the communicator is attached when the engine is created (and again when a
+    larger training batch re-creates it); with one rank the losses equal the plain model's bit for bit."""
+    import torch.distributed as dist
+    from icsg3d_amd.synthetic import synthetic_batch
+    from icsg3d_amd.unet.unet import AtomUnet
+    X, lab, _ = synthetic_batch(4, 16, 1, seed=0, noise=1e-3)
+    y = [lab, (lab != 0).astype(np.float32)[..., None]]
+    np.random.seed(11); a = AtomUnet(input_shape=(16, 16, 16, 1), lr=1e-3, weights=str(tmp_path / "a.hdf5"))
+    np.random.seed(11); b = AtomUnet(input_shape=(16, 16, 16, 1), lr=1e-3, weights=str(tmp_path / "b.hdf5"))
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1)
+    try:
+        b.enable_data_parallel(dist, 0, 1, force=True)
+        for n in (2, 2, 4):                                   # the third step grows the engine: comm re-attached
+            ma = a.model.train_on_batch(X[:n], y[0][:n])
+            mb = b.model.train_on_batch(X[:n], y[0][:n])
+            assert ma == mb, (n, ma, mb)
+            assert b._eng.comm_info()["nranks"] == 1 and a._eng.comm_info()["nranks"] == 0
+        assert b._eng.max_batch == 4
+        assert b._dp_is_writer()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_train_scripts_through_torchrun_single_rank(tmp_path):
+    """train_unet.py then train_vae.py under the launcher, data-parallel path forced with one rank: sharded
+    synthetic ids, communicator through the class API, rank-0 checkpoints in Keras HDF5."""
+    env = dict(os.environ, ICSG3D_FORCE_DP="1", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
+    launch = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+              "127.0.0.1", "--master-port", "29541"]
+    common = ["--name", "dp", "--synthetic", "8", "--channels", "1", "--dim", "16", "--epochs", "1", "--batch_size", "2"]
+    p = subprocess.run(launch + [os.path.join(ROOT, "train_unet.py")] + common, capture_output=True, text=True,
+                       env=env, cwd=str(tmp_path), timeout=400)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert "val_loss improved" in p.stdout and "Model saved" in p.stdout, p.stdout[-2000:]
+    from icsg3d_amd.hdf5_min import is_hdf5
+    for f in ("unet_weights_dp.best.hdf5", "unet_weights_dp.best.h5"):
+        assert is_hdf5(str(tmp_path / "saved_models" / "unet" / "dp" / f)), f
+    p = subprocess.run(launch + [os.path.join(ROOT, "train_vae.py")] + common + ["--ncond", "10"],
+                       capture_output=True, text=True, env=env, cwd=str(tmp_path), timeout=400)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert "Saving Model" in p.stdout and "Model saved" in p.stdout, p.stdout[-2000:]
+    assert is_hdf5(str(tmp_path / "saved_models" / "vae" / "dp" / "vae_weights_dp.best.h5"))

@@ -126,3 +126,25 @@ def test_data_split_matches_reference_golden(tmp_path):
     sig = inspect.signature(data_split)
     assert [(k, v.default) for k, v in sig.parameters.items()][1:] == [
         ("n", None), ("frac", 0.8), ("n_rot", 10), ("shuffle", True), ("seed", 28)]
+
+
+def test_shard_ids_equal_whole_batches():
+    from icsg3d_amd.dataparallel import DataParallelMixin, from_env, shard_ids
+    ids = ["g%03d" % i for i in range(103)]
+    shards = [shard_ids(ids, r, 4, 5) for r in range(4)]
+    assert {len(s) for s in shards} == {25}                       # 103 // (4*5) = 5 batches of 5 on every rank
+    flat = [x for s in shards for x in s]
+    assert len(set(flat)) == 100 and set(flat) <= set(ids)        # disjoint
+    assert shards[1][:3] == ["g001", "g005", "g009"]              # dealt round-robin
+    assert shard_ids(ids, 0, 1, 10) == ids[:100]
+    assert shard_ids(ids[:7], 1, 4, 5) == []
+    # without a launcher there is no process group, and the mixin is inert: the single process writes
+    env = {k: os.environ.pop(k) for k in ("RANK", "WORLD_SIZE") if k in os.environ}
+    try:
+        assert from_env() is None
+    finally:
+        os.environ.update(env)
+    m = DataParallelMixin()
+    assert m._dp_is_writer() and m._dp_barrier() is None and m._dp_attach(object()) is None
+    m._dp = (None, 3, 8, False, False)
+    assert not m._dp_is_writer()
