@@ -78,6 +78,7 @@ enum ConvFlags : int {
   CF_NO_UPSPLIT = 32,     // ICSG3D_NO_UPSPLIT: direct 27-tap evaluation of upsampled inputs
   CF_NO_THIN_C = 64,      // ICSG3D_NO_THIN_C: single-channel-input layers through the MFMA kernels
   CF_NO_COND_FOLD = 128,  // ICSG3D_NO_COND_FOLD: the VAE encoder's K.tile'd condition as materialised input channels
+  CF_NO_WINO = 256,       // ICSG3D_NO_WINO: 3x3x3 layers through the 27-tap implicit GEMM instead of Winograd F(2,3)
 };
 int conv_flags_from_env();
 
@@ -140,6 +141,7 @@ int launch_conv_wgrad(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int
                       int phase = 0);   // 0: GEMM + split reduction; 1: GEMM only; 2: reduction only
 // exact template instantiation (as rocprofv3 names it) of the last conv GEMM kernel launched by this thread
 const char* conv_last_kernel_id();
+void conv_set_last_kernel_id(const char* id);
 int launch_pack_sub(hipStream_t st, const float* w, int taps, int Cin_total, int Cout, int c_off, int Csub,
                     int flip, float* dst, int Kpad, int Npad);
 size_t conv_wgrad_workspace_floats(const ConvGeom& g, const ConvSrc* src, int nsrc);
@@ -161,5 +163,18 @@ int launch_materialize_input(hipStream_t st, const ConvSrc* src, int nsrc, int C
                              float* out);
 int launch_pack_bwd(hipStream_t st, const float* w, int taps, int Cin, int Cout, float* dst,
                     int Kpad, int Npad, int cout_total, int co_off, int zero_first);
+
+// ---------------------------------------------------------------- Winograd F(2x2x2, 3x3x3) path (conv_wino.hip)
+// forward / backward-data of a 3x3x3 "same" convolution with one plain (optionally BatchNorm-affine) source,
+// Cin % 32 == 0, Cout % 32 == 0, S >= 8.  wt: weights transformed by launch_pack_wino.  stat_partial / accumulate:
+// as launch_conv_fwd; *rows_per_block = 256.
+bool conv_wino_ok(const ConvGeom& g, const ConvSrc* src, int nsrc);
+size_t conv_wino_weight_floats(int Cin, int Cout);
+int launch_conv_fwd_wino(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, const float* wt, const float* bias,
+                         float* out, int ldo, int pre_act, float* stat_partial, int* rows_per_block, int accumulate);
+// dst[Nn/32][K/4][64 f][2][32][2] = (G (x) G (x) G) applied to the 27 taps of
+//   bwd = 0: w[tap][c_off + k][n]          (forward: K = Csub input channels of Cin_total, Nn = Cout)
+//   bwd = 1: w[26 - tap][c_off + n][k]     (backward-data: K = Cout, Nn = Csub input channels)
+int launch_pack_wino(hipStream_t st, const float* w, int Cin_total, int Cout, int c_off, int Csub, int bwd, float* dst);
 
 }  // namespace ics

@@ -37,6 +37,7 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nblk) {
 // Exact template instantiation (the name rocprofv3 prints) of the last conv GEMM kernel this thread launched.
 static thread_local const char* g_last_kernel_id = "";
 const char* conv_last_kernel_id() { return g_last_kernel_id; }
+void conv_set_last_kernel_id(const char* id) { g_last_kernel_id = id; }
 static const char* tf(bool b) { return b ? "true" : "false"; }
 
 int conv_flags_from_env() {
@@ -49,6 +50,7 @@ int conv_flags_from_env() {
   if (getenv("ICSG3D_NO_UPSPLIT")) f |= CF_NO_UPSPLIT;
   if (getenv("ICSG3D_NO_THIN_C")) f |= CF_NO_THIN_C;
   if (getenv("ICSG3D_NO_COND_FOLD")) f |= CF_NO_COND_FOLD;
+  if (getenv("ICSG3D_NO_WINO")) f |= CF_NO_WINO;
   return f;
 }
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remember per (kernel instantiation, device)
@@ -1607,7 +1609,7 @@ int launch_conv_fwd_par(hipStream_t st, const ConvGeom& g, const ConvSrc& src, c
 // whatever their size.  The engine records the jobs once (the launch_pack_* calls below append to g_pack_rec
 // instead of launching) and replays them with ONE pack_table_kernel launch per step.
 struct PackJob {
-  int kind;                 // 0 fwd, 1 bwd, 2 sub, 3 fwd_sub, 4 par
+  int kind;                 // 0 fwd, 1 bwd, 2 sub, 3 fwd_sub, 4 par, 5 wino
   const float* w;
   float* dst;
   int a[9];
@@ -2781,6 +2783,48 @@ int launch_pack_bwd(hipStream_t st, const float* w, int taps, int Cin, int Cout,
   return 0;
 }
 
+// Winograd weight transform (conv_wino.hip's operand layout): element i of dst[Nn/32][K/4][64 f][2 h][32 n][2 j],
+// k = c4*4 + h*2 + j.  U = (G (x) G (x) G) g with G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1] per axis.
+__device__ __forceinline__ float pack_wino_value(size_t i, const float* __restrict__ w, int Cin_total, int Cout,
+                                                 int c_off, int Csub, int bwd) {
+  const int K = bwd ? Cout : Csub;
+  const int j = (int)(i & 1), n32 = (int)((i >> 1) & 31), h = (int)((i >> 6) & 1), f = (int)((i >> 7) & 63);
+  const size_t rest = i >> 13;
+  const int c4 = (int)(rest % (size_t)(K / 4)), nchunk = (int)(rest / (size_t)(K / 4));
+  const int k = c4 * 4 + h * 2 + j, n = nchunk * 32 + n32;
+  const int fz = f >> 4, fy = (f >> 2) & 3, fx = f & 3;
+  // rows of G: coefficients of taps 0,1,2
+  const float G[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, 1.f}};
+  float acc = 0.f;
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int bq = 0; bq < 3; ++bq)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float coef = G[fz][a] * G[fy][bq] * G[fx][c];
+        const int tap = (a * 3 + bq) * 3 + c;
+        const float wv = bwd ? w[((size_t)(26 - tap) * Cin_total + c_off + n) * Cout + k]
+                             : w[((size_t)tap * Cin_total + c_off + k) * Cout + n];
+        acc = fmaf(coef, wv, acc);
+      }
+  return acc;
+}
+__global__ void pack_wino_kernel(const float* __restrict__ w, int Cin_total, int Cout, int c_off, int Csub, int bwd,
+                                 float* __restrict__ dst, size_t total) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  dst[i] = pack_wino_value(i, w, Cin_total, Cout, c_off, Csub, bwd);
+}
+int launch_pack_wino(hipStream_t st, const float* w, int Cin_total, int Cout, int c_off, int Csub, int bwd, float* dst) {
+  const size_t total = (size_t)64 * Csub * Cout;
+  if (g_pack_rec) { g_pack_rec->push_back(PackJob{5, w, dst, {Cin_total, Cout, c_off, Csub, bwd, 0, 0, 0, 0}, (unsigned long long)total, 0}); return 0; }
+  hipLaunchKernelGGL(pack_wino_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, Cin_total, Cout,
+                     c_off, Csub, bwd, dst, total);
+  ICS_HIP(hipGetLastError());
+  return 0;
+}
+
 // One launch for a whole table of pack jobs.  Destination buffers are zero-initialised at allocation and the
 // padding of a packed image never changes, so jobs only write their valid elements (two jobs may share a
 // destination: the head packs soft | sig side by side) -- no ordering between jobs is needed.
@@ -2805,6 +2849,7 @@ __global__ __launch_bounds__(256) void pack_table_kernel(const PackJob* __restri
     case 1: if (pack_bwd_value(i, J.w, a[0], a[1], a[2], a[3], a[4], a[5], &v)) J.dst[i] = v; break;
     case 2: J.dst[i] = pack_sub_value(i, J.w, a[0], a[1], a[2], a[3], a[4], a[5], a[6]); break;
     case 3: J.dst[i] = pack_fwd_sub_value(i, J.w, a[0], a[1], a[2], a[3], a[4], a[5]); break;
+    case 5: J.dst[i] = pack_wino_value(i, J.w, a[0], a[1], a[2], a[3], a[4]); break;
     default: J.dst[i] = pack_par_value(i, J.w, a[0], a[1], a[2], a[3], a[4], a[5]); break;
   }
 }

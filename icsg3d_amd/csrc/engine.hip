@@ -113,6 +113,8 @@ struct ConvLayer {
   // BatchNorm state
   float *mm = nullptr, *mv = nullptr, *mean = nullptr, *rstd = nullptr, *scale = nullptr, *shift = nullptr;
   float *wp = nullptr, *wf = nullptr;   // packed forward / backward-data weights
+  float *ww = nullptr, *wwb = nullptr;  // Winograd-transformed forward / backward-data weights (conv_wino.hip); of the
+                                        // skip channels only in an up-split layer.  nullptr: layer not served
   float* s = nullptr;                   // stored output [M][Cout]
   float* dy = nullptr;                  // grad w.r.t. conv output [M][Cout]
   float* dA = nullptr;                  // grad w.r.t. virtual input [M][Cin]
@@ -385,6 +387,26 @@ static int enable_split_up(Net& n, ConvLayer& L) {
   return 0;
 }
 
+// Winograd F(2,3) forward / backward-data for the 3x3x3 layers conv_wino_ok accepts (in an up-split layer: the skip
+// channels; the upsampled channels keep their 8-tap parity GEMMs, which already do 8/27 of the work).
+static ConvGeom geom_wino_fwd(const ConvLayer& L, int B) { return L.split_up ? geom_skip_fwd(L, B) : geom_fwd(L, B); }
+static ConvGeom geom_wino_bwd(const ConvLayer& L, int B) {
+  if (L.split_up) return geom_skip_dgrad(L, B);
+  ConvGeom g = geom_bwd(L, B);
+  g.Cout = L.Cin;
+  return g;
+}
+static int enable_wino(Net& n, ConvLayer& L, bool need_bwd) {
+  if ((n.flags & CF_NO_WINO) || L.taps != 27 || L.pad_in || L.cond_fold || L.CinG != L.Cin) return 0;
+  if (L.split_up ? L.Cs == 0 : L.nsrc != 1) return 0;
+  const int K = L.split_up ? L.Cs : L.Cin;
+  if (conv_wino_ok(geom_wino_fwd(L, n.maxB), L.src, 1)) ICS_TRY(n.alloc(&L.ww, conv_wino_weight_floats(K, L.Cout)));
+  const ConvSrc sdy = src_plain(nullptr, L.Cout);
+  if (need_bwd && conv_wino_ok(geom_wino_bwd(L, n.maxB), &sdy, 1))
+    ICS_TRY(n.alloc(&L.wwb, conv_wino_weight_floats(K, L.Cout)));
+  return 0;
+}
+
 // workspace sizing over all layers (max batch)
 static int alloc_workspaces(Net& n, bool need_bwd) {
   size_t stat = 0, bwd = 0, wg = 0, fw = 0;
@@ -483,6 +505,9 @@ static int pack_layer(Net& n, ConvLayer& L, bool need_bwd) {
                                   round_up(L.taps * L.Cs, 32), L.Npad));
     ICS_TRY(launch_pack_par(n.st, n.tp(L.t_w), L.Cin, L.Cout, L.Cs, L.Cu, L.wp_par, 8 * L.Cu, L.Npad));
   }
+  if (L.ww) ICS_TRY(launch_pack_wino(n.st, n.tp(L.t_w), L.Cin, L.Cout, 0, L.split_up ? L.Cs : L.Cin, 0, L.ww));
+  if (need_bwd && L.wwb)
+    ICS_TRY(launch_pack_wino(n.st, n.tp(L.t_w), L.Cin, L.Cout, 0, L.split_up ? L.Cs : L.Cin, 1, L.wwb));
   if (need_bwd && L.split_up) {
     if (L.Cs)
       ICS_TRY(launch_pack_sub(n.st, n.tp(L.t_w), L.taps, L.Cin, L.Cout, 0, L.Cs, 1, L.wf_skip, L.Kpad_b,
@@ -523,6 +548,10 @@ static int conv_forward(Net& n, ConvLayer& L, int B, bool training, bool update_
     if (!only_up) {
       n.prof.begin(n.st, "conv_fwd:" + L.name + ".skip|", 2.0 * M * 27 * L.Cs * L.Cout,
                    4.0 * (M * L.Cs + 2 * M * L.Cout + 27.0 * L.Cs * L.Cout));
+      if (L.ww && conv_wino_ok(gs, L.src, 1))
+        ICS_TRY(launch_conv_fwd_wino(n.st, gs, L.src[0], L.ww, bias, L.s, L.Cout, L.pre_act,
+                                     stats ? n.ws_stat : nullptr, &rpb, 1));
+      else
       ICS_TRY(launch_conv_fwd(n.st, gs, L.src, 1, L.wp_skip, bias, L.s, L.Cout, L.pre_act, stats ? n.ws_stat : nullptr,
                               &rpb, 1));
       n.prof.end(n.st);
@@ -543,6 +572,9 @@ static int conv_forward(Net& n, ConvLayer& L, int B, bool training, bool update_
     // padded layout (CinG channels per tap) the backward-weight kernel is built for
     ICS_TRY(launch_conv_fwd_thin_c(n.st, g, L.vsrc[0], L.Cin, L.CinG, L.wp, bias, L.s, L.Cout, L.pre_act,
                                    stats ? n.ws_stat : nullptr, &rpb));
+  } else if (L.ww && conv_wino_ok(g, L.src, L.nsrc)) {
+    ICS_TRY(launch_conv_fwd_wino(n.st, g, L.src[0], L.ww, bias, L.s, L.Cout, L.pre_act, stats ? n.ws_stat : nullptr,
+                                 &rpb, 0));
   } else {
     ICS_TRY(launch_conv_fwd(n.st, g, L.src, L.nsrc, L.wp, bias, L.s, L.Cout, L.pre_act,
                             stats ? n.ws_stat : nullptr, &rpb, 0, n.fws(), n.ws_fwd_n));
@@ -669,6 +701,9 @@ static int conv_grads_split_up(Net& n, ConvLayer& L, int B, ConvLayer* next) {
     ConvSrc sdy = src_plain(L.dy, L.Cout);
     n.prof.begin(n.st, "conv_dgrad:" + L.name + ".skip|", fl_skip,
                  4.0 * (M * L.Cs + M * L.Cout + 27.0 * L.Cs * L.Cout));
+    if (L.wwb && conv_wino_ok(g, &sdy, 1))
+      ICS_TRY(launch_conv_fwd_wino(n.st, g, sdy, L.wwb, nullptr, L.dA_skip, L.Cs, ACT_NONE, nullptr, nullptr, 0));
+    else
     ICS_TRY(launch_conv_fwd(n.st, g, &sdy, 1, L.wf_skip, nullptr, L.dA_skip, L.Cs, ACT_NONE, nullptr, nullptr, 0,
                             n.fws(), n.ws_fwd_n));
     n.prof.end(n.st);
@@ -741,6 +776,9 @@ static int conv_grads_from_dy(Net& n, ConvLayer& L, int B, bool need_dA, bool pa
                  4.0 * (M * L.Cin + M * L.Cout + (double)L.taps * L.Cin * L.Cout));
     const BwdStat bs = bwd_stat_for(n, next, B);
     int blocks = 0;
+    if (L.wwb && !L.split_up && conv_wino_ok(gb, &sdy, 1))   // the producer's BN-backward sums: separate pass
+      ICS_TRY(launch_conv_fwd_wino(n.st, gb, sdy, L.wwb, nullptr, L.dA, L.CinG, ACT_NONE, nullptr, nullptr, 0));
+    else
     ICS_TRY(launch_conv_fwd(n.st, gb, &sdy, 1, L.wf, nullptr, L.dA, L.CinG, ACT_NONE, nullptr, nullptr, 0, n.fws(),
                             n.ws_fwd_n, &bs, &blocks));
     bwd_stat_done(next, bs, blocks, gb.Npad);
@@ -899,6 +937,7 @@ static int unet_build(Net& n, const ics_unet_config& cfg) {
   n.head->src[0] = src_layer(*r.c18, 0);
   use_padded_input(*r.c1);
   ICS_TRY(enable_split_up(n, *r.c13)); ICS_TRY(enable_split_up(n, *r.c15)); ICS_TRY(enable_split_up(n, *r.c17));
+  for (int i = 0; i < 14; ++i) ICS_TRY(enable_wino(n, *n.layers[i], true));
   ICS_TRY(alloc_workspaces(n, true));
   ICS_TRY(init_bn_defaults(n));
   return 0;
