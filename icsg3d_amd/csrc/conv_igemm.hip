@@ -2783,44 +2783,59 @@ int launch_pack_bwd(hipStream_t st, const float* w, int taps, int Cin, int Cout,
   return 0;
 }
 
-// Winograd weight transform (conv_wino.hip's operand layout): element i of dst[Nn/32][K/4][64 f][2 h][32 n][2 j],
-// k = c4*4 + h*2 + j.  U = (G (x) G (x) G) g with G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1] per axis.
-__device__ __forceinline__ float pack_wino_value(size_t i, const float* __restrict__ w, int Cin_total, int Cout,
-                                                 int c_off, int Csub, int bwd) {
+// Winograd weight transform (conv_wino.hip's operand layout dst[Nn/32][K/4][64 f][2 h][32 n][2 j], k = c4*4 + h*2 + j).
+// Thread t of a job = one (k, n) pair, t = (((nchunk * K/4 + c4) * 2 + h) * 32 + n32) * 2 + j: it reads the pair's 27 taps
+// once, applies U = (G (x) G (x) G) g with G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1] one axis at a time and writes the
+// 64 frequencies (a half-wave writes 128 contiguous floats per frequency).
+__device__ __forceinline__ void pack_wino_pair(size_t t, const float* __restrict__ w, int Cin_total, int Cout, int c_off,
+                                               int Csub, int bwd, float* __restrict__ dst) {
   const int K = bwd ? Cout : Csub;
-  const int j = (int)(i & 1), n32 = (int)((i >> 1) & 31), h = (int)((i >> 6) & 1), f = (int)((i >> 7) & 63);
-  const size_t rest = i >> 13;
+  const int j = (int)(t & 1), n32 = (int)((t >> 1) & 31), h = (int)((t >> 6) & 1);
+  const size_t rest = t >> 7;
   const int c4 = (int)(rest % (size_t)(K / 4)), nchunk = (int)(rest / (size_t)(K / 4));
   const int k = c4 * 4 + h * 2 + j, n = nchunk * 32 + n32;
-  const int fz = f >> 4, fy = (f >> 2) & 3, fx = f & 3;
-  // rows of G: coefficients of taps 0,1,2
-  const float G[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, 1.f}};
-  float acc = 0.f;
+  float g[27];
+#pragma unroll
+  for (int tap = 0; tap < 27; ++tap)
+    g[tap] = bwd ? w[((size_t)(26 - tap) * Cin_total + c_off + n) * Cout + k]
+                 : w[((size_t)tap * Cin_total + c_off + k) * Cout + n];
+  float gx[9][4];                                  // [(a, b)][fx]
+#pragma unroll
+  for (int ab = 0; ab < 9; ++ab) {
+    const float g0 = g[ab * 3], g1 = g[ab * 3 + 1], g2 = g[ab * 3 + 2];
+    gx[ab][0] = g0; gx[ab][1] = 0.5f * (g0 + g1 + g2); gx[ab][2] = 0.5f * (g0 - g1 + g2); gx[ab][3] = g2;
+  }
+  float gy[3][4][4];                               // [a][fy][fx]
 #pragma unroll
   for (int a = 0; a < 3; ++a)
 #pragma unroll
-    for (int bq = 0; bq < 3; ++bq)
+    for (int fx = 0; fx < 4; ++fx) {
+      const float g0 = gx[a * 3][fx], g1 = gx[a * 3 + 1][fx], g2 = gx[a * 3 + 2][fx];
+      gy[a][0][fx] = g0; gy[a][1][fx] = 0.5f * (g0 + g1 + g2); gy[a][2][fx] = 0.5f * (g0 - g1 + g2); gy[a][3][fx] = g2;
+    }
+  float* d = dst + ((size_t)rest * 64 * 2 + h) * 64 + n32 * 2 + j;        // + f * 128
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float coef = G[fz][a] * G[fy][bq] * G[fx][c];
-        const int tap = (a * 3 + bq) * 3 + c;
-        const float wv = bwd ? w[((size_t)(26 - tap) * Cin_total + c_off + n) * Cout + k]
-                             : w[((size_t)tap * Cin_total + c_off + k) * Cout + n];
-        acc = fmaf(coef, wv, acc);
-      }
-  return acc;
+  for (int fy = 0; fy < 4; ++fy)
+#pragma unroll
+    for (int fx = 0; fx < 4; ++fx) {
+      const float g0 = gy[0][fy][fx], g1 = gy[1][fy][fx], g2 = gy[2][fy][fx];
+      d[(0 * 16 + fy * 4 + fx) * 128] = g0;
+      d[(1 * 16 + fy * 4 + fx) * 128] = 0.5f * (g0 + g1 + g2);
+      d[(2 * 16 + fy * 4 + fx) * 128] = 0.5f * (g0 - g1 + g2);
+      d[(3 * 16 + fy * 4 + fx) * 128] = g2;
+    }
 }
 __global__ void pack_wino_kernel(const float* __restrict__ w, int Cin_total, int Cout, int c_off, int Csub, int bwd,
-                                 float* __restrict__ dst, size_t total) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  dst[i] = pack_wino_value(i, w, Cin_total, Cout, c_off, Csub, bwd);
+                                 float* __restrict__ dst, size_t pairs) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= pairs) return;
+  pack_wino_pair(t, w, Cin_total, Cout, c_off, Csub, bwd, dst);
 }
 int launch_pack_wino(hipStream_t st, const float* w, int Cin_total, int Cout, int c_off, int Csub, int bwd, float* dst) {
-  const size_t total = (size_t)64 * Csub * Cout;
-  if (g_pack_rec) { g_pack_rec->push_back(PackJob{5, w, dst, {Cin_total, Cout, c_off, Csub, bwd, 0, 0, 0, 0}, (unsigned long long)total, 0}); return 0; }
-  hipLaunchKernelGGL(pack_wino_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, Cin_total, Cout,
-                     c_off, Csub, bwd, dst, total);
+  const size_t pairs = (size_t)Csub * Cout;
+  if (g_pack_rec) { g_pack_rec->push_back(PackJob{5, w, dst, {Cin_total, Cout, c_off, Csub, bwd, 0, 0, 0, 0}, (unsigned long long)pairs, 0}); return 0; }
+  hipLaunchKernelGGL(pack_wino_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, w, Cin_total, Cout,
+                     c_off, Csub, bwd, dst, pairs);
   ICS_HIP(hipGetLastError());
   return 0;
 }
@@ -2849,7 +2864,7 @@ __global__ __launch_bounds__(256) void pack_table_kernel(const PackJob* __restri
     case 1: if (pack_bwd_value(i, J.w, a[0], a[1], a[2], a[3], a[4], a[5], &v)) J.dst[i] = v; break;
     case 2: J.dst[i] = pack_sub_value(i, J.w, a[0], a[1], a[2], a[3], a[4], a[5], a[6]); break;
     case 3: J.dst[i] = pack_fwd_sub_value(i, J.w, a[0], a[1], a[2], a[3], a[4], a[5]); break;
-    case 5: J.dst[i] = pack_wino_value(i, J.w, a[0], a[1], a[2], a[3], a[4]); break;
+    case 5: pack_wino_pair(i, J.w, a[0], a[1], a[2], a[3], a[4], J.dst); break;
     default: J.dst[i] = pack_par_value(i, J.w, a[0], a[1], a[2], a[3], a[4], a[5]); break;
   }
 }

@@ -495,21 +495,25 @@ static int init_bn_defaults(Net& n) {
 // weight packing (after every parameter change)
 // ------------------------------------------------------------------------------------------
 static int pack_layer(Net& n, ConvLayer& L, bool need_bwd) {
-  ICS_TRY(launch_pack_fwd(n.st, n.tp(L.t_w), L.taps * L.CinG, L.Cout, L.wp, L.Kpad, L.Npad, 0, 0, 1,
-                          L.CinG != L.Cin ? L.Cin : 0, L.CinG != L.Cin ? L.CinG : 0));
-  if (need_bwd && L.wf)
+  // a layer served by the Winograd kernels (decided once, at the maximum batch) never reads the direct-path image of
+  // the same weights: ww replaces wp (wp_skip in an up-split layer), wwb replaces wf (wf_skip)
+  const bool wino_f = L.ww != nullptr, wino_b = L.wwb != nullptr;
+  if (!(wino_f && !L.split_up))
+    ICS_TRY(launch_pack_fwd(n.st, n.tp(L.t_w), L.taps * L.CinG, L.Cout, L.wp, L.Kpad, L.Npad, 0, 0, 1,
+                            L.CinG != L.Cin ? L.Cin : 0, L.CinG != L.Cin ? L.CinG : 0));
+  if (need_bwd && L.wf && !(wino_b && !L.split_up))
     ICS_TRY(launch_pack_bwd(n.st, n.tp(L.t_w), L.taps, L.Cin, L.Cout, L.wf, L.Kpad_b, L.Npad_b, L.Cout, 0, 1));
   if (L.split_up) {
-    if (L.Cs)
+    if (L.Cs && !wino_f)
       ICS_TRY(launch_pack_fwd_sub(n.st, n.tp(L.t_w), L.taps, L.Cin, L.Cout, 0, L.Cs, L.wp_skip,
                                   round_up(L.taps * L.Cs, 32), L.Npad));
     ICS_TRY(launch_pack_par(n.st, n.tp(L.t_w), L.Cin, L.Cout, L.Cs, L.Cu, L.wp_par, 8 * L.Cu, L.Npad));
   }
-  if (L.ww) ICS_TRY(launch_pack_wino(n.st, n.tp(L.t_w), L.Cin, L.Cout, 0, L.split_up ? L.Cs : L.Cin, 0, L.ww));
-  if (need_bwd && L.wwb)
+  if (wino_f) ICS_TRY(launch_pack_wino(n.st, n.tp(L.t_w), L.Cin, L.Cout, 0, L.split_up ? L.Cs : L.Cin, 0, L.ww));
+  if (need_bwd && wino_b)
     ICS_TRY(launch_pack_wino(n.st, n.tp(L.t_w), L.Cin, L.Cout, 0, L.split_up ? L.Cs : L.Cin, 1, L.wwb));
   if (need_bwd && L.split_up) {
-    if (L.Cs)
+    if (L.Cs && !wino_b)
       ICS_TRY(launch_pack_sub(n.st, n.tp(L.t_w), L.taps, L.Cin, L.Cout, 0, L.Cs, 1, L.wf_skip, L.Kpad_b,
                               round_up(L.Cs, 32)));
     ICS_TRY(launch_pack_sub(n.st, n.tp(L.t_w), L.taps, L.Cin, L.Cout, L.Cs, L.Cu, 0, L.w_up, L.ldS, round_up(L.Cu, 32)));
