@@ -79,6 +79,7 @@ enum ConvFlags : int {
   CF_NO_THIN_C = 64,      // ICSG3D_NO_THIN_C: single-channel-input layers through the MFMA kernels
   CF_NO_COND_FOLD = 128,  // ICSG3D_NO_COND_FOLD: the VAE encoder's K.tile'd condition as materialised input channels
   CF_NO_WINO = 256,       // ICSG3D_NO_WINO: 3x3x3 layers through the 27-tap implicit GEMM instead of Winograd F(2,3)
+  CF_NO_WINO_WGRAD = 512, // ICSG3D_NO_WINO_WGRAD: backward-weight through the direct kernels, Winograd forward/backward-data kept
 };
 int conv_flags_from_env();
 
@@ -176,5 +177,15 @@ int launch_conv_fwd_wino(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, c
 //   bwd = 0: w[tap][c_off + k][n]          (forward: K = Csub input channels of Cin_total, Nn = Cout)
 //   bwd = 1: w[26 - tap][c_off + n][k]     (backward-data: K = Cout, Nn = Csub input channels)
 int launch_pack_wino(hipStream_t st, const float* w, int Cin_total, int Cout, int c_off, int Csub, int bwd, float* dst);
+// backward-weight in the Winograd domain; workspace / sub_rows / row_pitch / row_off / phase as launch_conv_wgrad;
+// zeros: >= 16 bytes of device zeros (halo voxels outside the grid are read from there)
+bool conv_wino_wgrad_ok(const ConvGeom& g, const ConvSrc* src, int nsrc);
+size_t conv_wino_wgrad_workspace_floats(const ConvGeom& g);
+int launch_conv_wgrad_wino(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, const float* dy, int ldy, float* dw,
+                           int ldw, float* ws, size_t ws_floats, int sub_rows, int row_pitch, int row_off, int phase,
+                           const float* zeros);
+// fixed-order reduction of split-K weight-gradient partials ws[split][k][n] into dw (conv_igemm.hip)
+int launch_wgrad_reduce_splits(hipStream_t st, const float* ws, int nsplit, size_t n_elems, int N, float* dw, int ldw,
+                               int sub_rows, int row_pitch, int row_off);
 
 }  // namespace ics

@@ -51,6 +51,7 @@ int conv_flags_from_env() {
   if (getenv("ICSG3D_NO_THIN_C")) f |= CF_NO_THIN_C;
   if (getenv("ICSG3D_NO_COND_FOLD")) f |= CF_NO_COND_FOLD;
   if (getenv("ICSG3D_NO_WINO")) f |= CF_NO_WINO;
+  if (getenv("ICSG3D_NO_WINO_WGRAD")) f |= CF_NO_WINO_WGRAD;
   return f;
 }
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remember per (kernel instantiation, device)
@@ -2222,6 +2223,11 @@ static int launch_reduce_splits(hipStream_t st, const float* ws, int nsplit, siz
                        n_elems, N, dw, ldw, sub_rows, row_pitch, row_off);
   ICS_HIP(hipGetLastError());
   return 0;
+}
+
+int launch_wgrad_reduce_splits(hipStream_t st, const float* ws, int nsplit, size_t n_elems, int N, float* dw, int ldw,
+                               int sub_rows, int row_pitch, int row_off) {
+  return launch_reduce_splits(st, ws, nsplit, n_elems, N, dw, ldw, sub_rows, row_pitch, row_off);
 }
 
 struct WgradPlan {

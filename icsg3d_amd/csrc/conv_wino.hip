@@ -319,6 +319,292 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const float* __restrict_
   }
 }
 
+// ================================================================================================================
+// Backward-weight in the Winograd domain.  From Y = A^T[(G g) .* (B^T d)]:
+//   dL/dg = G^T [ sum over tiles (A dY) .* (B^T d) ]     (per axis; dY = the 2x2x2 gradient tile, A = [1 0; 1 1; 1 -1; 0 -1])
+// i.e. 64 independent GEMMs  dW^_f[ci][co] = sum_t U_f[t][ci] V_f[t][co]  reduced over ALL tiles, then the 4 -> 3
+// contraction with G per axis.  One workgroup = 32 input channels x 32 output channels x 64 frequencies (same 256 + 256
+// register accumulator layout as the forward kernel: wave w owns fz = w) over a range of tile blocks (split-K over the
+// tiles); a block = 2x2x4 tiles (4x4x8 voxels): x halo [6][6][10] x 32 ci and dy [4][4][8] x 32 co staged in LDS,
+// double buffered.  MFMA k = 2 tiles: lanes 0-31 tile 2p, lanes 32-63 tile 2p+1, lane & 31 = channel -- every lane
+// transforms its own (tile, channel) pair from conflict-free ds_read_b32.  The transform of k-step p+1 is interleaved
+// with the 16 MFMAs of step p.  V is built without its negations (rows f = 3 of A); the epilogue puts the signs back
+// while contracting (fy, fx) -> (b, c) in registers and fz -> a across the waves, and writes ws[split][27*Cin][Cout],
+// the layout conv_igemm.hip's split reduction consumes.
+namespace {
+constexpr int GZ = 6, GY = 6, GX = 10, GNV = GZ * GY * GX;                 // x halo of a 4x4x8 block
+constexpr int GXF = GNV * 32, GYF = 128 * 32, GBUF = GXF + GYF;            // floats: x part, dy part, one buffer
+constexpr int GNX = (GNV * 8 + 255) / 256, GNY = 4;                        // float4 staging slots per thread
+}  // namespace
+
+template <bool AFF, bool NOACT>
+__global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(const float* __restrict__ x, int ldx,
+                                                              const float* __restrict__ in_scale,
+                                                              const float* __restrict__ in_shift, float in_slope,
+                                                              const float* __restrict__ dy, int ldy,
+                                                              float* __restrict__ ws, const float* __restrict__ zeros,
+                                                              int S, int Cin, int Cout, int nblocks, int per_split) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * GBUF];      // 124 928 B
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 31, hl = lane >> 5;
+  const int nco = Cout >> 5, nci = Cin >> 5;
+  const int cob = blockIdx.x % nco;
+  const int cib = (blockIdx.x / nco) % nci;
+  const int split = blockIdx.x / (nco * nci);
+  const int ci0 = cib * 32, co0 = cob * 32;
+  const int blk_lo = split * per_split, blk_hi = blk_lo + per_split;
+  const int nbx = S >> 3, nby = S >> 2, nbz = S >> 2;
+
+  // ---- staging slots
+  wf4 xs[GNX], ys[GNY];
+  int xrel[GNX], yrel[GNY];
+  unsigned xface = 0;                                  // 6 face bits per slot, 5 slots per word -> 3 words
+  unsigned xface1 = 0, xface2 = 0;
+  const int q4 = (tid & 7) * 4;
+#pragma unroll
+  for (int i = 0; i < GNX; ++i) {
+    int e = tid + i * 256;
+    if (e >= GNV * 8) e = GNV * 8 - 1;
+    const int v = e >> 3;
+    const int hx = v % GX, hy = (v / GX) % GY, hz = v / (GX * GY);
+    xrel[i] = (((hz - 1) * S + (hy - 1)) * S + (hx - 1)) * ldx + q4;
+    const unsigned f = (hz == 0) | ((hz == GZ - 1) << 1) | ((hy == 0) << 2) | ((hy == GY - 1) << 3) | ((hx == 0) << 4) |
+                       ((hx == GX - 1) << 5);
+    if (i < 5) xface |= f << (6 * i); else if (i < 10) xface1 |= f << (6 * (i - 5)); else xface2 |= f << (6 * (i - 10));
+  }
+#pragma unroll
+  for (int i = 0; i < GNY; ++i) {
+    const int v = (tid + i * 256) >> 3;
+    yrel[i] = (((v >> 5) * S + ((v >> 3) & 3)) * S + (v & 7)) * ldy + q4;
+  }
+  wf4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+  if (AFF) {
+    sc4 = *reinterpret_cast<const wf4*>(in_scale + ci0 + q4);
+    sh4 = *reinterpret_cast<const wf4*>(in_shift + ci0 + q4);
+  }
+  unsigned bface_cur = 0;
+  auto gload = [&](int blk) {
+    int t = blk;
+    const int bx = t % nbx; t /= nbx;
+    const int by = t % nby; t /= nby;
+    const int bz = t % nbz;
+    const int b = t / nbz;
+    const int org = ((b * S + 4 * bz) * S + 4 * by) * S + 8 * bx;          // voxel index of the block origin (uniform)
+    const unsigned bface = (bz == 0) | ((bz == nbz - 1) << 1) | ((by == 0) << 2) | ((by == nby - 1) << 3) |
+                           ((bx == 0) << 4) | ((bx == nbx - 1) << 5);
+    bface_cur = bface;
+    const float* xb = x + (size_t)org * ldx + ci0;
+    const float* yb = dy + (size_t)org * ldy + co0;
+    if (bface) {                                                           // halo outside the grid: read the zero page
+#pragma unroll
+      for (int i = 0; i < GNX; ++i) {
+        const unsigned f = ((i < 5 ? xface >> (6 * i) : (i < 10 ? xface1 >> (6 * (i - 5)) : xface2 >> (6 * (i - 10)))) & 63u);
+        const float* p = (f & bface) ? zeros : xb + xrel[i];
+        xs[i] = *reinterpret_cast<const wf4*>(p);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < GNX; ++i) xs[i] = *reinterpret_cast<const wf4*>(xb + xrel[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < GNY; ++i) ys[i] = *reinterpret_cast<const wf4*>(yb + yrel[i]);
+  };
+  auto sstore = [&](const int bo) {
+    if (AFF) {
+      const unsigned bface = bface_cur;
+#pragma unroll
+      for (int i = 0; i < GNX; ++i) {
+        wf4 t = xs[i];
+        t.x = fmaf(t.x, sc4.x, sh4.x); t.y = fmaf(t.y, sc4.y, sh4.y);
+        t.z = fmaf(t.z, sc4.z, sh4.z); t.w = fmaf(t.w, sc4.w, sh4.w);
+        if (!NOACT) { t.x = wact(t.x, in_slope); t.y = wact(t.y, in_slope); t.z = wact(t.z, in_slope); t.w = wact(t.w, in_slope); }
+        if (bface) {                                                       // padding zeros come AFTER the affine
+          const unsigned f = ((i < 5 ? xface >> (6 * i) : (i < 10 ? xface1 >> (6 * (i - 5)) : xface2 >> (6 * (i - 10)))) & 63u);
+          if (f & bface) t = wf4{0.f, 0.f, 0.f, 0.f};
+        }
+        xs[i] = t;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < GNX; ++i) {
+      int e = tid + i * 256;
+      if (e >= GNV * 8) e = GNV * 8 - 1;
+      *reinterpret_cast<wf4*>(&lds[bo + (e >> 3) * 32 + q4]) = xs[i];
+    }
+#pragma unroll
+    for (int i = 0; i < GNY; ++i) *reinterpret_cast<wf4*>(&lds[bo + GXF + ((tid + i * 256) >> 3) * 32 + q4]) = ys[i];
+  };
+
+  // ---- per-lane read bases: wave w = fz combines x planes (za, zb) with sign sg, dy planes with (ca, cb)
+  const int za = (w == 0) ? 0 : (w == 2 ? 2 : 1);
+  const int zb = (w == 0) ? 2 : (w == 1 ? 2 : (w == 2 ? 1 : 3));
+  const float sg = (w == 1) ? 1.f : -1.f;
+  const float ca = (w == 3) ? 0.f : 1.f, cb = (w == 0) ? 0.f : (w == 2 ? -1.f : 1.f);   // row fz of A (fz = 3 un-negated)
+  const int LXa = za * (GY * GX * 32) + hl * 64 + c, LXb = zb * (GY * GX * 32) + hl * 64 + c;
+  const int LY = GXF + hl * 64 + c;
+
+  wf16 acc[16];
+#pragma unroll
+  for (int f = 0; f < 16; ++f)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+
+  float u[16], vv[16];                 // operands of the current k-step
+  float xa[16], xb_[16], e0[4], e1[4]; // raw reads of the next k-step
+  auto rd = [&](const int bo, const int p) {
+    const int tz = p >> 2, ty = (p >> 1) & 1, txp = p & 1;
+#pragma unroll
+    for (int iy = 0; iy < 4; ++iy)
+#pragma unroll
+      for (int ix = 0; ix < 4; ++ix) {
+        const int off = bo + (((2 * tz) * GY + 2 * ty + iy) * GX + 4 * txp + ix) * 32;
+        xa[iy * 4 + ix] = lds[LXa + off];
+        xb_[iy * 4 + ix] = lds[LXb + off];
+      }
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {      // d = dyy*2 + dx
+      const int off = bo + (((2 * tz) * 4 + 2 * ty + (d >> 1)) * 8 + 4 * txp + (d & 1)) * 32;
+      e0[d] = lds[LY + off];
+      e1[d] = lds[LY + off + 4 * 8 * 32];
+    }
+  };
+  // the whole transform of one k-step (used in the prologue; the main loop interleaves the same steps with MFMAs)
+  float tz_[16], ty_[16], g_[4], r_[4][2];
+  auto tr_z = [&](int i0) {
+#pragma unroll
+    for (int i = i0; i < i0 + 4; ++i) tz_[i] = fmaf(sg, xb_[i], xa[i]);
+  };
+  auto tr_y = [&](int ix) {            // column ix: over iy
+    const float v0 = tz_[0 * 4 + ix], v1 = tz_[1 * 4 + ix], v2 = tz_[2 * 4 + ix], v3 = tz_[3 * 4 + ix];
+    ty_[0 * 4 + ix] = v0 - v2; ty_[1 * 4 + ix] = v1 + v2; ty_[2 * 4 + ix] = v2 - v1; ty_[3 * 4 + ix] = v1 - v3;
+  };
+  auto tr_x = [&](int fy, float* un) { // row fy: over ix
+    const float v0 = ty_[fy * 4 + 0], v1 = ty_[fy * 4 + 1], v2 = ty_[fy * 4 + 2], v3 = ty_[fy * 4 + 3];
+    un[fy * 4 + 0] = v0 - v2; un[fy * 4 + 1] = v1 + v2; un[fy * 4 + 2] = v2 - v1; un[fy * 4 + 3] = v1 - v3;
+  };
+  auto tr_dz = [&]() {
+#pragma unroll
+    for (int d = 0; d < 4; ++d) g_[d] = fmaf(cb, e1[d], ca * e0[d]);
+  };
+  auto tr_dy = [&]() {                 // over dyy -> fy (row 3 un-negated)
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      r_[0][dx] = g_[0 * 2 + dx]; r_[1][dx] = g_[dx] + g_[2 + dx]; r_[2][dx] = g_[dx] - g_[2 + dx]; r_[3][dx] = g_[2 + dx];
+    }
+  };
+  auto tr_dx = [&](int fy, float* vn) {
+    vn[fy * 4 + 0] = r_[fy][0]; vn[fy * 4 + 1] = r_[fy][0] + r_[fy][1]; vn[fy * 4 + 2] = r_[fy][0] - r_[fy][1];
+    vn[fy * 4 + 3] = r_[fy][1];
+  };
+
+  // per_split is even and every split is full (launcher): no conditional blocks -- a conditional one makes the
+  // register allocator spill the accumulators
+  gload(blk_lo);
+  sstore(0);
+  __syncthreads();
+  rd(0, 0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) tr_z(4 * i);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) tr_y(i);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) tr_x(i, u);
+  tr_dz(); tr_dy();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) tr_dx(i, vv);
+  rd(0, 1);
+  auto block = [&](const int blk, const int cur, const int nxt) {
+    gload(blk + 1 < blk_hi ? blk + 1 : blk);             // past the end: this block again (never consumed)
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      float un[16], vn[16];
+      // raw reads in xa/xb_/e0/e1 belong to step p+1 (step 0 of the next block when p == 7)
+#define ICS_GMF(F) acc[F] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[F], vv[F], acc[F], 0, 0, 0)
+#define ICS_GFN __builtin_amdgcn_sched_barrier(0)
+      ICS_GMF(0); tr_z(0); ICS_GFN;
+      ICS_GMF(1); tr_z(4); ICS_GFN;
+      ICS_GMF(2); tr_z(8); ICS_GFN;
+      ICS_GMF(3); tr_z(12); ICS_GFN;
+      ICS_GMF(4); tr_y(0); ICS_GFN;
+      ICS_GMF(5); tr_y(1); ICS_GFN;
+      ICS_GMF(6); tr_y(2); ICS_GFN;
+      ICS_GMF(7); tr_y(3); ICS_GFN;
+      ICS_GMF(8); tr_x(0, un); ICS_GFN;
+      ICS_GMF(9); tr_x(1, un); ICS_GFN;
+      ICS_GMF(10); tr_x(2, un); ICS_GFN;
+      ICS_GMF(11); tr_x(3, un); ICS_GFN;
+      ICS_GMF(12); tr_dz(); tr_dy(); ICS_GFN;
+      ICS_GMF(13); tr_dx(0, vn); tr_dx(1, vn); ICS_GFN;
+      ICS_GMF(14); tr_dx(2, vn); tr_dx(3, vn); ICS_GFN;
+      ICS_GMF(15); ICS_GFN;
+#undef ICS_GMF
+      // raw reads two steps ahead: step p+2 of this block, or step (p+2)-8 of the next one
+      if (p < 6) rd(cur, p + 2); else rd(nxt, p - 6);
+      if (p == 5) {                                      // every read of `cur` is issued: the next block becomes visible
+        sstore(nxt);                                     // before step 6 reads its step 0
+        __syncthreads();
+      }
+      ICS_GFN;
+#undef ICS_GFN
+#pragma unroll
+      for (int f = 0; f < 16; ++f) { u[f] = un[f]; vv[f] = vn[f]; }
+    }
+  };
+  for (int blk = blk_lo; blk < blk_hi; blk += 2) {
+    block(blk, 0, GBUF);
+    block(blk + 1, GBUF, 0);
+  }
+
+  // ---------------------------------------------------------------- epilogue: G^T contraction, signs of the f = 3 rows
+  float* part = lds;                                     // [4 w][9 (b,c)][8 r][64 lanes]   (73 728 B per pass)
+  float* wsp = ws + (size_t)split * 27 * Cin * Cout;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int r = pass * 8 + rr;
+      float yb[3][4];                                    // [b][fx]
+#pragma unroll
+      for (int fx = 0; fx < 4; ++fx) {
+        const float X0 = acc[0 * 4 + fx][r], X1 = acc[1 * 4 + fx][r], X2 = acc[2 * 4 + fx][r], X3 = acc[3 * 4 + fx][r];
+        const float h1 = 0.5f * (X1 + X2), h2 = 0.5f * (X1 - X2);
+        yb[0][fx] = X0 + h1; yb[1][fx] = h2; yb[2][fx] = h1 - X3;
+      }
+#pragma unroll
+      for (int bb = 0; bb < 3; ++bb) {
+        const float X0 = yb[bb][0], X1 = yb[bb][1], X2 = yb[bb][2], X3 = yb[bb][3];
+        const float h1 = 0.5f * (X1 + X2), h2 = 0.5f * (X1 - X2);
+        part[((w * 9 + bb * 3 + 0) * 8 + rr) * 64 + lane] = X0 + h1;
+        part[((w * 9 + bb * 3 + 1) * 8 + rr) * 64 + lane] = h2;
+        part[((w * 9 + bb * 3 + 2) * 8 + rr) * 64 + lane] = h1 - X3;
+      }
+    }
+    __syncthreads();
+    // task = ((bc * 8 + rr) * 2 + hh) * 8 + quad: 1152 per pass; each gives the three taps a = 0,1,2 as float4
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int task = tid + 256 * i;
+      if (task < 1152) {
+        const int quad = task & 7, hh = (task >> 3) & 1, rr = (task >> 4) & 7, bc = task >> 7;
+        const int r = pass * 8 + rr;
+        const int row = (r >> 2) * 8 + hh * 4 + (r & 3);
+        const int slot = (bc * 8 + rr) * 64 + hh * 32 + 4 * quad;
+        const wf4 p0 = *reinterpret_cast<const wf4*>(&part[0 * 4608 + slot]);
+        const wf4 p1 = *reinterpret_cast<const wf4*>(&part[1 * 4608 + slot]);
+        const wf4 p2 = *reinterpret_cast<const wf4*>(&part[2 * 4608 + slot]);
+        const wf4 p3 = *reinterpret_cast<const wf4*>(&part[3 * 4608 + slot]);
+        const wf4 h1 = 0.5f * (p1 + p2), h2 = 0.5f * (p1 - p2);
+        float* o = wsp + ((size_t)(bc)*Cin + ci0 + row) * Cout + co0 + 4 * quad;   // tap = a*9 + bc
+        *reinterpret_cast<wf4*>(o) = p0 + h1;
+        *reinterpret_cast<wf4*>(o + (size_t)9 * Cin * Cout) = h2;
+        *reinterpret_cast<wf4*>(o + (size_t)18 * Cin * Cout) = h1 - p3;
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------- host side
 bool conv_wino_ok(const ConvGeom& g, const ConvSrc* src, int nsrc) {
   if (g.flags & CF_NO_WINO) return false;
@@ -353,6 +639,63 @@ int launch_conv_fwd_wino(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, c
   else ICS_WINO_LAUNCH(true, false);
 #undef ICS_WINO_LAUNCH
   ICS_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------- backward-weight launcher
+// blocks per workgroup: a power of two >= 2 that divides the blocks of one sample (every split full, even count),
+// small enough for ~6 workgroups per CU, large enough for the workspace
+static int wino_wgrad_per_split(const ConvGeom& g, size_t ws_floats) {
+  const int bps = (g.S / 4) * (g.S / 4) * (g.S / 8);               // blocks per sample: a power of two >= 4
+  const int nblocks = g.B * bps;
+  const int pairs = (g.Cin / 32) * (g.Cout / 32);
+  const int want = std::max((1536 + pairs - 1) / pairs, 1);         // splits wanted
+  const size_t per = (size_t)27 * g.Cin * g.Cout;
+  int ps = 2;
+  while (ps < bps && ((nblocks / ps) > want || (size_t)(nblocks / ps) * per > ws_floats)) ps *= 2;
+  if ((size_t)(nblocks / ps) * per > ws_floats) return 0;
+  return ps;
+}
+size_t conv_wino_wgrad_workspace_floats(const ConvGeom& g) {
+  const int ps = wino_wgrad_per_split(g, ~(size_t)0);
+  return (size_t)(g.B * (g.S / 4) * (g.S / 4) * (g.S / 8) / ps) * 27 * g.Cin * g.Cout;
+}
+bool conv_wino_wgrad_ok(const ConvGeom& g, const ConvSrc* src, int nsrc) {
+  if (g.flags & (CF_NO_WINO | CF_NO_WINO_WGRAD)) return false;
+  if (g.taps != 27 || nsrc != 1 || g.S < 8) return false;
+  const ConvSrc& s = src[0];
+  if (s.up || s.bcast || s.C != g.Cin) return false;
+  if (g.Cin % 32 != 0 || g.Cout % 32 != 0) return false;
+  if ((long long)g.B * g.S * g.S * g.S * (long long)std::max(g.Cin, g.Cout) >= (1ll << 31)) return false;
+  return true;
+}
+int launch_conv_wgrad_wino(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, const float* dy, int ldy, float* dw,
+                           int ldw, float* ws, size_t ws_floats, int sub_rows, int row_pitch, int row_off, int phase,
+                           const float* zeros) {
+  ICS_CHECK(conv_wino_wgrad_ok(g, &s0, 1), "shape not served by the Winograd backward-weight kernel");
+  const int per_split = wino_wgrad_per_split(g, ws_floats);
+  ICS_CHECK(per_split >= 2, "wgrad workspace too small");
+  const int nblocks = g.B * (g.S / 4) * (g.S / 4) * (g.S / 8);
+  const int nsplit = nblocks / per_split;
+  if (phase != 2) {
+    const unsigned grid = (unsigned)(nsplit * (g.Cin / 32) * (g.Cout / 32));
+    const bool aff = s0.scale != nullptr, noact = s0.act == ACT_NONE;
+    const float in_slope = wslope(s0.act);
+#define ICS_WG_LAUNCH(AFFV, NOACTV)                                                                                   \
+  do {                                                                                                                \
+    hipLaunchKernelGGL((conv_wino_wgrad_kernel<AFFV, NOACTV>), dim3(grid), dim3(256), 0, st, s0.p, s0.C, s0.scale,    \
+                       s0.shift, in_slope, dy, ldy, ws, zeros, g.S, g.Cin, g.Cout, nblocks, per_split);               \
+    conv_set_last_kernel_id("conv_wino_wgrad_kernel<" #AFFV ", " #NOACTV ">");                                        \
+  } while (0)
+    if (!aff) ICS_WG_LAUNCH(false, true);
+    else if (noact) ICS_WG_LAUNCH(true, true);
+    else ICS_WG_LAUNCH(true, false);
+#undef ICS_WG_LAUNCH
+    ICS_HIP(hipGetLastError());
+  }
+  if (phase != 1)
+    ICS_TRY(launch_wgrad_reduce_splits(st, ws, nsplit, (size_t)27 * g.Cin * g.Cout, g.Cout, dw, ldw, sub_rows, row_pitch,
+                                       row_off));
   return 0;
 }
 

@@ -115,6 +115,7 @@ struct ConvLayer {
   float *wp = nullptr, *wf = nullptr;   // packed forward / backward-data weights
   float *ww = nullptr, *wwb = nullptr;  // Winograd-transformed forward / backward-data weights (conv_wino.hip); of the
                                         // skip channels only in an up-split layer.  nullptr: layer not served
+  bool wino_w = false;                  // backward-weight in the Winograd domain
   float* s = nullptr;                   // stored output [M][Cout]
   float* dy = nullptr;                  // grad w.r.t. conv output [M][Cout]
   float* dA = nullptr;                  // grad w.r.t. virtual input [M][Cin]
@@ -136,6 +137,7 @@ struct ConvLayer {
 };
 
 struct Net {
+  float* zero_page = nullptr;           // device zeros: out-of-grid halo reads of the Winograd backward-weight kernel
   int kind = 0;   // 0 U-Net, 1 VAE
   int device = 0;
   int flags = 0;  // ConvFlags, read from the environment when the handle is created
@@ -404,6 +406,8 @@ static int enable_wino(Net& n, ConvLayer& L, bool need_bwd) {
   const ConvSrc sdy = src_plain(nullptr, L.Cout);
   if (need_bwd && conv_wino_ok(geom_wino_bwd(L, n.maxB), &sdy, 1))
     ICS_TRY(n.alloc(&L.wwb, conv_wino_weight_floats(K, L.Cout)));
+  L.wino_w = need_bwd && conv_wino_wgrad_ok(L.split_up ? geom_skip_wgrad(L, n.maxB) : geom_fwd(L, n.maxB), L.src, 1);
+  if (L.wino_w && !n.zero_page) ICS_TRY(n.alloc(&n.zero_page, (size_t)256));
   return 0;
 }
 
@@ -431,6 +435,8 @@ static int alloc_workspaces(Net& n, bool need_bwd) {
       // Cout may be a non power of two only for the head, which never goes through layer_bwd
       if ((L.Cout & (L.Cout - 1)) == 0) bwd = std::max(bwd, layer_bwd_workspace_floats(lb));
       wg = std::max(wg, conv_wgrad_workspace_floats(g, L.src, L.nsrc));
+      if (L.wino_w)
+        wg = std::max(wg, conv_wino_wgrad_workspace_floats(L.split_up ? geom_skip_wgrad(L, n.maxB) : g));
       if ((L.Cin == 1 || L.cond_fold) && (L.Cout == 16 || L.Cout == 32))
         wg = std::max(wg, conv_thin_c_wgrad_workspace_floats(g));
       if (L.split_up) {
@@ -680,10 +686,19 @@ static int conv_grads_split_up(Net& n, ConvLayer& L, int B, ConvLayer* next) {
     const ConvGeom g = geom_skip_wgrad(L, B);
     n.prof.begin(ws, "conv_wgrad:" + L.name + ".skip|", fl_skip,
                  4.0 * (M * L.Cs + M * L.Cout + 27.0 * L.Cs * L.Cout));
+    const bool wino = L.wino_w && conv_wino_wgrad_ok(g, L.src, 1);
+    if (wino)
+      ICS_TRY(launch_conv_wgrad_wino(ws, g, L.src[0], L.dy, L.Cout, n.tg(L.t_w), L.Cout, n.ws_wgrad, n.ws_wgrad_n,
+                                     L.Cs, L.Cin, 0, 1, n.zero_page));
+    else
     ICS_TRY(launch_conv_wgrad(ws, g, L.src, 1, L.dy, L.Cout, n.tg(L.t_w), L.Cout, n.ws_wgrad, n.ws_wgrad_n, L.Cs,
                               L.Cin, 0, 1));
     n.prof.end(ws);
     n.prof.begin(ws, "wgrad_reduce_splits", 0, 0);
+    if (wino)
+      ICS_TRY(launch_conv_wgrad_wino(ws, g, L.src[0], L.dy, L.Cout, n.tg(L.t_w), L.Cout, n.ws_wgrad, n.ws_wgrad_n,
+                                     L.Cs, L.Cin, 0, 2, n.zero_page));
+    else
     ICS_TRY(launch_conv_wgrad(ws, g, L.src, 1, L.dy, L.Cout, n.tg(L.t_w), L.Cout, n.ws_wgrad, n.ws_wgrad_n, L.Cs,
                               L.Cin, 0, 2));
     n.prof.end(ws);
@@ -757,6 +772,14 @@ static int conv_grads_from_dy(Net& n, ConvLayer& L, int B, bool need_dA, bool pa
       n.prof.begin(ws, "wgrad_reduce_splits", 0, 0);
       ICS_TRY(launch_conv_wgrad_thin_c(ws, g, L.vsrc[0], L.dy, L.Cout, n.tg(L.t_w), L.Cout, L.Cin, n.ws_wgrad,
                                        n.ws_wgrad_n, 2));
+      n.prof.end(ws);
+    } else if (L.wino_w && !L.split_up && conv_wino_wgrad_ok(g, L.src, L.nsrc)) {
+      ICS_TRY(launch_conv_wgrad_wino(ws, g, L.src[0], L.dy, L.Cout, dw, L.Cout, n.ws_wgrad, n.ws_wgrad_n, 0, 0, 0, 1,
+                                     n.zero_page));
+      n.prof.end(ws);
+      n.prof.begin(ws, "wgrad_reduce_splits", 0, 0);
+      ICS_TRY(launch_conv_wgrad_wino(ws, g, L.src[0], L.dy, L.Cout, dw, L.Cout, n.ws_wgrad, n.ws_wgrad_n, 0, 0, 0, 2,
+                                     n.zero_page));
       n.prof.end(ws);
     } else {
     ICS_TRY(launch_conv_wgrad(ws, g, L.src, L.nsrc, L.dy, L.Cout, dw, L.Cout, n.ws_wgrad, n.ws_wgrad_n, 0, 0, 0, 1));
