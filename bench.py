@@ -27,6 +27,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: fp32 vector = fp32 MFMA peak
+WINO_EXEC = 64.0 / 216.0      # executed / algorithmic multiplies of the Winograd F(2x2x2, 3x3x3) kernels
+
+
+def wino(kernel_name):
+    """executed / algorithmic FLOPs of a kernel row: the Winograd kernels' rows carry the 27-tap count."""
+    return WINO_EXEC if "conv_wino" in kernel_name else 1.0
 PEAK_HBM_GBS = 8000.0         # HBM3E spec
 # SURVEY.md 8(d): algorithmic work of one U-Net train step per grid (C=1, d=32)
 UNET_FLOP_PER_GRID = 377.66e9          # fwd 125.886 GFLOP x 3
@@ -209,7 +215,9 @@ def main():
             traffic, traffic_note = pmc_traffic(dom_name, avg_ms)
             scale = (d / 32.0) ** 3
             step_flop = UNET_FLOP_PER_GRID * scale * B
-            exec_flop = sum(r["flop"] for r in rows) / args.steps
+            # the profile rows of the Winograd kernels carry the ALGORITHMIC (27-tap) FLOPs of the convolution they
+            # compute; the MFMAs they execute are 64/216 of that (F(2x2x2, 3x3x3))
+            exec_flop = sum(v["flop"] * wino(k) for k, v in kern.items()) / args.steps
             step_bytes = UNET_BYTES_PER_GRID * scale * B + UNET_PARAM_BYTES_PER_STEP
             out = {
                 "metric": "voxel-grids/s (fwd+bwd) for 32^3 U-Net at batch 32 per GPU",
@@ -229,6 +237,13 @@ def main():
                 "value_events_off": round(world * B * args.steps / elapsed_plain, 2),
                 "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 2),
                              "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_TFLOPS, 4),
+                             # achieved / frac: algorithmic FLOPs of the convolution (2*S^3*27*Cin*Cout) per
+                             # second; executed_*: the multiply-adds the kernel really issues to the matrix cores
+                             "executed_achieved": round(achieved * wino(dom_name), 2),
+                             "executed_frac": round(achieved * wino(dom_name) / PEAK_FP32_TFLOPS, 4),
+                             "note": ("Winograd F(2x2x2,3x3x3): 64 multiplies per 2x2x2 output tile instead of 216, so the "
+                                      "algorithmic rate can exceed the fp32 MFMA peak; executed_frac is the matrix-core "
+                                      "utilisation") if wino(dom_name) != 1.0 else None,
                              "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_note,
                              "algorithmic_bytes_per_launch": int(dom["bytes"] / max(dom["launches"], 1)),
                              "launches": dom["launches"], "avg_launch_ms": round(avg_ms, 4),
@@ -277,7 +292,7 @@ def main():
             gemms = {k: v for k, v in kern.items() if v["flop"] > 0}
             dom_name, dom = max(gemms.items(), key=lambda kv: kv[1]["ms"])
             ms_v = elapsed_v / args.steps * 1e3
-            exec_flop = sum(r["flop"] for r in rows_v) / args.steps
+            exec_flop = sum(v["flop"] * wino(k) for k, v in kern.items()) / args.steps
             blk = {"workload": ("U-Net step + DFC-VAE step per iteration" if args.workload == "joint" else
                                 "LatticeDFCVAE train step (encoder + decoder + frozen perceptual U-Net c1..c10 x2 fwd "
                                 "+ bwd-data, Adam), %d x %d^3 x 1 grids per GPU (BASELINE.json configs[2])" % (B, d)),

@@ -2046,7 +2046,14 @@ int ics_op_conv3d_forward(const float* x, const float* w, const float* bias, int
   ICS_TRY(launch_pack_fwd(n.st, dw, taps * Cin, Cout, dwp, Kpad, Npad, 0, 0, 1));
   ConvGeom g{B, S, ilog2(S), Cin, Cout, taps, Kpad, Npad, n.flags};
   ConvSrc s = src_plain(dx, Cin);
-  ICS_TRY(launch_conv_fwd(n.st, g, &s, 1, dwp, bias ? db : nullptr, dyv, Cout, pre_act, nullptr, nullptr));
+  if (conv_wino_ok(g, &s, 1)) {          // the path the engine takes for this shape (ICSG3D_NO_WINO: the direct kernels)
+    float* ww = nullptr;
+    ICS_TRY(n.alloc(&ww, conv_wino_weight_floats(Cin, Cout)));
+    ICS_TRY(launch_pack_wino(n.st, dw, Cin, Cout, 0, Cin, 0, ww));
+    ICS_TRY(launch_conv_fwd_wino(n.st, g, s, ww, bias ? db : nullptr, dyv, Cout, pre_act, nullptr, nullptr, 0));
+  } else {
+    ICS_TRY(launch_conv_fwd(n.st, g, &s, 1, dwp, bias ? db : nullptr, dyv, Cout, pre_act, nullptr, nullptr));
+  }
   ICS_HIP(hipMemcpyAsync(y, dyv, M * Cout * 4, hipMemcpyDeviceToHost, n.st));
   ICS_HIP(hipStreamSynchronize(n.st));
   return 0;
@@ -2115,9 +2122,15 @@ int ics_op_conv3d_backward(const float* x, const float* w, const float* dy, int 
   ICS_HIP(hipMemcpyAsync(ddy, dy, M * Cout * 4, hipMemcpyHostToDevice, n.st));
   ConvGeom g{B, S, ilog2(S), Cin, Cout, taps, Kpad, Npad, n.flags};
   ConvSrc s = src_plain(dx, Cin);
-  const size_t wsn = conv_wgrad_workspace_floats(g, &s, 1);
+  const bool wino_w = conv_wino_wgrad_ok(g, &s, 1);
+  const size_t wsn = wino_w ? conv_wino_wgrad_workspace_floats(g) : conv_wgrad_workspace_floats(g, &s, 1);
   ICS_TRY(n.alloc(&ws, wsn + 16));
   if (dwo) {
+    if (wino_w) {
+      float* zeros = nullptr;
+      ICS_TRY(n.alloc(&zeros, (size_t)256));
+      ICS_TRY(launch_conv_wgrad_wino(n.st, g, s, ddy, Cout, dgw, Cout, ws, wsn, 0, 0, 0, 0, zeros));
+    } else
     ICS_TRY(launch_conv_wgrad(n.st, g, &s, 1, ddy, Cout, dgw, Cout, ws, wsn));
     ICS_HIP(hipMemcpyAsync(dwo, dgw, (size_t)taps * Cin * Cout * 4, hipMemcpyDeviceToHost, n.st));
   }
@@ -2125,6 +2138,12 @@ int ics_op_conv3d_backward(const float* x, const float* w, const float* dy, int 
     ICS_TRY(launch_pack_bwd(n.st, dw, taps, Cin, Cout, dwf, Kpad_b, Npad_b, Cout, 0, 1));
     ConvGeom gb{B, S, ilog2(S), Cout, Cin, taps, Kpad_b, Npad_b, n.flags};
     ConvSrc sd = src_plain(ddy, Cout);
+    if (conv_wino_ok(gb, &sd, 1)) {
+      float* wwb = nullptr;
+      ICS_TRY(n.alloc(&wwb, conv_wino_weight_floats(Cin, Cout)));
+      ICS_TRY(launch_pack_wino(n.st, dw, Cin, Cout, 0, Cin, 1, wwb));
+      ICS_TRY(launch_conv_fwd_wino(n.st, gb, sd, wwb, nullptr, dgx, Cin, ACT_NONE, nullptr, nullptr, 0));
+    } else
     ICS_TRY(launch_conv_fwd(n.st, gb, &sd, 1, dwf, nullptr, dgx, Cin, ACT_NONE, nullptr, nullptr));
     ICS_HIP(hipMemcpyAsync(dxo, dgx, M * Cin * 4, hipMemcpyDeviceToHost, n.st));
   }

@@ -1,5 +1,8 @@
-"""Parity of the HIP implicit-GEMM Conv3D (fwd / bwd-data / bwd-weight) against the fp64 oracle,
-through the C ABI (ics_op_conv3d_*).  Tolerance: tensor-relative 1e-5."""
+"""Parity of the HIP Conv3D kernels (fwd / bwd-data / bwd-weight) against the fp64 oracle, through the C ABI
+(ics_op_conv3d_*).  Tolerance: tensor-relative 1e-5.  The ops take the path the engine takes
+for the shape: Winograd F(2x2x2, 3x3x3) where csrc/conv_wino.hip serves it (3x3x3, S >= 8, Cin and Cout multiples of
+32), the 27-tap implicit GEMM or a direct stencil otherwise; every Winograd-served case is ALSO run with
+ICSG3D_NO_WINO=1, which keeps the implicit-GEMM kernels covered at the same shapes."""
 import numpy as np
 import pytest
 
@@ -18,7 +21,14 @@ CASES = [
     # resolutions of the benchmark (S=32) and of the d=64 extension: the dx-reuse kernels' line padding
     (1, 32, 64, 128, 3), (1, 64, 32, 32, 3), (1, 32, 128, 128, 3),
     (1, 64, 64, 128, 3),   # S = 64 through the dx-reuse backward-weight kernel (half-line chunks with halo rows)
+    # Winograd edge cases: odd batch with every block on the border (S = 8), one block row per axis, wide Cout
+    (3, 8, 32, 32, 3), (5, 8, 64, 32, 3), (1, 16, 32, 96, 3), (2, 16, 96, 64, 3), (1, 8, 256, 512, 3),
 ]
+
+
+def _wino(case):
+    B, S, Cin, Cout, k = case
+    return k == 3 and S >= 8 and Cin % 32 == 0 and Cout % 32 == 0
 
 
 def _data(B, S, Cin, Cout, k, seed=0):
@@ -31,7 +41,7 @@ def _data(B, S, Cin, Cout, k, seed=0):
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "B%d_S%d_%dto%d_k%d" % c)
-def test_conv_forward(case, relerr):
+def test_conv_forward(case, relerr, monkeypatch):
     from icsg3d_amd import engine as E
     x, w, b, _ = _data(*case)
     ref = R.conv3d_fwd(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64))
@@ -39,13 +49,23 @@ def test_conv_forward(case, relerr):
     assert relerr(got, ref) <= TOL
     got_relu = E.conv3d_forward(x, w, b, pre_act=1)
     assert relerr(got_relu, np.maximum(ref, 0)) <= TOL
+    if _wino(case):
+        monkeypatch.setenv("ICSG3D_NO_WINO", "1")
+        direct = E.conv3d_forward(x, w, b, pre_act=0)
+        assert relerr(direct, ref) <= TOL
+        assert not np.array_equal(direct, got)           # really two different kernels
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "B%d_S%d_%dto%d_k%d" % c)
-def test_conv_backward(case, relerr):
+def test_conv_backward(case, relerr, monkeypatch):
     from icsg3d_amd import engine as E
     x, w, _, dy = _data(*case, seed=1)
     dx_ref, dw_ref, _ = R.conv3d_bwd(x.astype(np.float64), w.astype(np.float64), dy.astype(np.float64))
     dx, dw = E.conv3d_backward(x, w, dy)
     assert relerr(dx, dx_ref) <= TOL
     assert relerr(dw, dw_ref) <= TOL
+    if _wino(case):
+        monkeypatch.setenv("ICSG3D_NO_WINO", "1")
+        dx2, dw2 = E.conv3d_backward(x, w, dy)
+        assert relerr(dx2, dx_ref) <= TOL and relerr(dw2, dw_ref) <= TOL
+        assert not np.array_equal(dx2, dx) and not np.array_equal(dw2, dw)
