@@ -7,21 +7,24 @@
 // applied along z, y and x.  The products over input channels are 64 independent GEMMs (one per frequency
 // f = (fz, fy, fx)), tiles x Cin x Cout, which is where the MFMAs go.
 //
-// One workgroup (4 waves, one per SIMD, 256 + 256 registers) = 32 tiles (2x4x4 tiles = 4x8x8 voxels) x 32 output
-// channels x all 64 frequencies: wave w owns the 16 frequencies with fz = w, one 32x32 fp32 accumulator each
-// (v_mfma_f32_32x32x2_f32, all 256 AGPRs).  K loop over input channels in chunks of 16: the raw halo block
-// [6][10][10] voxels x 16 channels is staged in LDS (double buffered, BatchNorm affine of the producer applied on the
-// way in, zero padding after it); each wave reads the two z-planes its fz row of B^T combines and finishes the y / x
-// transforms in registers, directly in the MFMA A-operand layout (lane = tile, half-wave = channel pair); B operands
-// (the transformed weights, pre-arranged so that one sub-step of one wave is 8 KB contiguous) stream from L2 one
-// sub-step ahead.  The transform of sub-step g+1 is interleaved, instruction by instruction, with the 32 MFMAs of
-// sub-step g: this wave is alone on its SIMD, nothing else hides the LDS latency.  On this chip the fp32 MFMA shares
-// the SIMD's VALU issue (SQ_VALU_MFMA_COEXEC_CYCLES = 0, scripts/probes/mfma_filler.hip): every VALU instruction is
-// MFMA time lost, hence scalar-base addressing, immediates and no packed math in the main loop.
-// LDS layout: voxel pitch 18 floats, row pitch 10 voxels, plane pitch 104 voxels, the two channel pairs of each
-// 4-channel group swapped where (hy >> 1) is odd: the 32 tiles of a half-wave then hit 32 distinct bank pairs.
-// Epilogue: (fy, fx) -> (dy, dx) in registers, fz -> dz across the four waves through LDS, then bias / accumulate /
-// activation / store as float4 and the per-block BatchNorm partials (count, mean, M2) of conv_igemm.hip's layout.
+// One workgroup (8 waves, two per SIMD) = 32 tiles (2x4x4 tiles = 4x8x8 voxels) x 32 output channels x all 64
+// frequencies: wave w owns the 8 frequencies (fz = w >> 1, fy in {2 (w & 1), 2 (w & 1) + 1}, fx = 0..3), one 32x32 fp32
+// accumulator each (v_mfma_f32_32x32x2_f32).  K loop over input channels in chunks of 16: the halo block
+// [6][10][10] voxels x 16 channels is read once per chunk by 400 threads, each owning one (y, x, channel quad) column:
+// BatchNorm affine of the producer, zero padding after it, and the z rows of B^T are applied THERE, once per voxel, and
+// the eight z-combined planes (tile z, fz) go to LDS (double buffered).  Each wave then reads three rows of its plane
+// per column and finishes the y / x transforms in registers, directly in the MFMA A-operand layout (lane = tile,
+// half-wave = channel pair): 12 ds_read_b64 + 32 VALU per 16 MFMAs.  B operands (the transformed weights, pre-arranged
+// so that one sub-step of one wave is 4 KB contiguous) stream from L2 one sub-step ahead.  The transform of sub-step
+// g+1 is interleaved, instruction by instruction, with the MFMAs of sub-step g.  On this chip the fp32 MFMA shares the
+// SIMD's VALU issue (SQ_VALU_MFMA_COEXEC_CYCLES = 0; scripts/probes/mfma_filler.hip: a v_fma_f32 between MFMAs costs
+// 5.2 cycles with one wave per SIMD, 3.6 with two, and the bare MFMA issues every 75 / 69.5 cycles): every VALU
+// instruction is MFMA time lost, hence two waves per SIMD, scalar-base addressing, immediates and no packed math in
+// the main loop.  LDS layout: voxel pitch 18 floats, row pitch 10 voxels, plane pitch 100 voxels, the two channel pairs
+// of each 4-channel group swapped where (hy >> 1) is odd: the 32 tiles of a half-wave hit 32 distinct bank pairs.
+// Epilogue (two passes of 8 accumulator registers): fx -> dx and the wave's share of fy -> dy in registers, the sum
+// over the eight waves (fz -> dz) through LDS, then bias / accumulate / activation / store as float4 and the per-block
+// BatchNorm partials (count, mean, M2) of conv_igemm.hip's layout.
 #include "common.h"
 
 #include <algorithm>
@@ -35,8 +38,7 @@ typedef float wf16 __attribute__((ext_vector_type(16)));
 namespace {
 constexpr int KC = 16;                                   // input channels per LDS chunk
 constexpr int HZ = 6, HY = 10, HX = 10, NV = HZ * HY * HX;
-constexpr int P3 = 18, PY3 = 10, PZ3 = 104, BUF3 = HZ * PZ3 * P3;      // floats per buffer (44 928 B)
-constexpr int NLD = (NV * 4 + 255) / 256;                // float4 staging slots per thread per chunk
+constexpr int P3 = 18, PY3 = 10, PZ3 = 100, BUF3 = 8 * PZ3 * P3;       // floats per buffer (57 600 B): 8 z-combined planes
 constexpr int kRowsPerBlock = 256;                       // voxels per workgroup
 
 __device__ __forceinline__ float wact(float v, float slope) { return fmaxf(v, v * slope); }
@@ -46,16 +48,17 @@ __host__ __device__ __forceinline__ float wslope(int act) { return act == ACT_RE
 // wt layout: [Cout/32][Cin/4][64 f][2 h][32 n][2 j]   (input channel = c4*4 + h*2 + j)
 // AFF: the source carries a per-channel affine (+ activation of slope in_slope); NOACT: affine only.
 template <bool AFF, bool NOACT>
-__global__ __launch_bounds__(256) void conv_wino_kernel(const float* __restrict__ x, int ldx,
+__global__ __launch_bounds__(512) void conv_wino_kernel(const float* __restrict__ x, int ldx,
                                                         const float* __restrict__ in_scale,
                                                         const float* __restrict__ in_shift, float in_slope,
                                                         const float* __restrict__ wt, const float* __restrict__ bias,
                                                         float* __restrict__ y, int ldo, float pre_slope, int accumulate,
                                                         float* __restrict__ stat_partial, int Npad, int S, int Cin,
                                                         int Cout) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * BUF3];   // 89 856 B; the epilogue reuses it
+  __shared__ __attribute__((aligned(16))) float lds[2 * BUF3];   // 115 200 B; the epilogue reuses it
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fz = w >> 1, fyh = w & 1;            // this wave: frequencies (fz, 2 fyh + {0,1}, 0..3)
   const int m = lane & 31, h = lane >> 5;
   const int nchunks = Cout >> 5;
   const int nb = blockIdx.x % nchunks;           // the n-chunks of one tile block are neighbours in launch order:
@@ -69,40 +72,42 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const float* __restrict_
   const int oz = bz * 4, oy = by * 8, ox = bx * 8, n0 = nb * 32;
   const bool edge = bx == 0 || by == 0 || bz == 0 || bx == nbx - 1 || by == nby - 1 || bz == nbz - 1;   // uniform
 
-  wf4 stage[NLD];
-  int soff[NLD];                               // float offset into x of the (clamped) voxel + channel quad
-  int dlo[NLD], dhi[NLD];                      // LDS float offsets of the two channel pairs of the quad
+  // ---- staging: thread t < 400 owns one (hy, hx, channel quad) column of the halo block: six raw z values in,
+  // the eight z-combined planes (tz, fz) out -- the z rows of B^T are applied ONCE per voxel here instead of once per
+  // overlapping tile in the waves
+  const int cmb = tid < 400 ? tid : 399;
+  const int q = cmb & 3, hx = (cmb >> 2) % HX, hy = (cmb >> 2) / HX;
+  wf4 stage[6];
+  int soff[6];
   unsigned okmask = 0;
+  {
+    const int gy = oy - 1 + hy, gx = ox - 1 + hx;
+    const bool okyx = gy >= 0 && gy < S && gx >= 0 && gx < S;
+    const int cy = min(max(gy, 0), S - 1), cx = min(max(gx, 0), S - 1);
 #pragma unroll
-  for (int i = 0; i < NLD; ++i) {
-    int e = tid + i * 256;
-    if (e >= NV * 4) e = NV * 4 - 1;           // duplicates of the last slot: same value to the same place
-    const int v = e >> 2, q = e & 3;
-    const int hx = v % HX, hy = (v / HX) % HY, hz = v / (HX * HY);
-    int gz = oz - 1 + hz, gy = oy - 1 + hy, gx = ox - 1 + hx;
-    const bool ok = gz >= 0 && gz < S && gy >= 0 && gy < S && gx >= 0 && gx < S;
-    okmask |= ok ? (1u << i) : 0u;
-    gz = min(max(gz, 0), S - 1); gy = min(max(gy, 0), S - 1); gx = min(max(gx, 0), S - 1);
-    soff[i] = (((b * S + gz) * S + gy) * S + gx) * ldx + q * 4;
-    const int base = (hz * PZ3 + hy * PY3 + hx) * P3 + q * 4, sw = ((hy >> 1) & 1) * 2;
-    dlo[i] = base + sw;
-    dhi[i] = base + 2 - sw;
+    for (int hz = 0; hz < 6; ++hz) {
+      const int gz = oz - 1 + hz;
+      okmask |= (okyx && gz >= 0 && gz < S) ? (1u << hz) : 0u;
+      const int cz = min(max(gz, 0), S - 1);
+      soff[hz] = (((b * S + cz) * S + cy) * S + cx) * ldx + q * 4;
+    }
   }
+  const int sw = ((hy >> 1) & 1) * 2;
+  const int dbase = (hy * PY3 + hx) * P3 + q * 4;            // + plane * PZ3 * P3
   wf4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
-  const int q4 = (tid & 3) * 4;                // this thread's channel quad inside every chunk
   auto gload = [&](int c0) {
     const float* xc = x + c0;                  // uniform base
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) stage[i] = *reinterpret_cast<const wf4*>(xc + soff[i]);
+    for (int i = 0; i < 6; ++i) stage[i] = *reinterpret_cast<const wf4*>(xc + soff[i]);
     if (AFF) {
-      sc4 = *reinterpret_cast<const wf4*>(in_scale + c0 + q4);
-      sh4 = *reinterpret_cast<const wf4*>(in_shift + c0 + q4);
+      sc4 = *reinterpret_cast<const wf4*>(in_scale + c0 + q * 4);
+      sh4 = *reinterpret_cast<const wf4*>(in_shift + c0 + q * 4);
     }
   };
   auto sstore = [&](const int bo) {            // bo: a compile-time constant after unrolling
     if (AFF) {
 #pragma unroll
-      for (int i = 0; i < NLD; ++i) {
+      for (int i = 0; i < 6; ++i) {
         wf4 t = stage[i];
         t.x = fmaf(t.x, sc4.x, sh4.x); t.y = fmaf(t.y, sc4.y, sh4.y);
         t.z = fmaf(t.z, sc4.z, sh4.z); t.w = fmaf(t.w, sc4.w, sh4.w);
@@ -112,61 +117,59 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const float* __restrict_
     }
     if (edge) {                                // "same" padding: zeros AFTER the producer's affine / activation
 #pragma unroll
-      for (int i = 0; i < NLD; ++i)
+      for (int i = 0; i < 6; ++i)
         if (!((okmask >> i) & 1)) stage[i] = wf4{0.f, 0.f, 0.f, 0.f};
     }
+    if (tid < 400) {
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      const wf2 lo = {stage[i].x, stage[i].y}, hi = {stage[i].z, stage[i].w};
-      *reinterpret_cast<wf2*>(&lds[bo + dlo[i]]) = lo;
-      *reinterpret_cast<wf2*>(&lds[bo + dhi[i]]) = hi;
+      for (int tz = 0; tz < 2; ++tz) {
+        const wf4 d0 = stage[2 * tz], d1 = stage[2 * tz + 1], d2 = stage[2 * tz + 2], d3 = stage[2 * tz + 3];
+        const wf4 c[4] = {d0 - d2, d1 + d2, d2 - d1, d1 - d3};
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          const int o = bo + (tz * 4 + f) * (PZ3 * P3) + dbase;
+          *reinterpret_cast<wf2*>(&lds[o + sw]) = wf2{c[f].x, c[f].y};
+          *reinterpret_cast<wf2*>(&lds[o + 2 - sw]) = wf2{c[f].z, c[f].w};
+        }
+      }
     }
   };
 
-  // tile m = (tz, ty, tx); wave w = fz combines planes (za, zb) with sign sg
+  // ---- per-lane read geometry.  tile m = (tz, ty, tx).  The wave's two fy rows of B^T need rows (a, b, c) of the
+  // combined plane:  fy = 2 fyh:  R_a - R_b,   fy = 2 fyh + 1:  R_b + sg R_c   with (a,b,c,sg) = (0,2,1,+) / (2,1,3,-)
   const int tz = m >> 4, ty = (m >> 2) & 3, tx = m & 3;
-  const int za = (w == 0) ? 0 : (w == 2 ? 2 : 1);
-  const int zb = (w == 0) ? 2 : (w == 1 ? 2 : (w == 2 ? 1 : 3));
-  const float sg = (w == 1) ? 1.f : -1.f;
-  const int la = ((2 * tz + za) * PZ3 + 2 * ty * PY3 + 2 * tx) * P3;
-  const int lb = ((2 * tz + zb) * PZ3 + 2 * ty * PY3 + 2 * tx) * P3;
-  const int hs0 = 2 * (h ^ (ty & 1)), hs1 = 2 * (h ^ ((ty + 1) & 1));     // rows iy in {0,1} / {2,3}
-  const int A0 = la + hs0, A1 = la + hs1, B0 = lb + hs0, B1 = lb + hs1;
+  const float sg = fyh ? -1.f : 1.f;
+  auto rowbase = [&](int iy) {
+    const int hyy = 2 * ty + iy;
+    return ((tz * 4 + fz) * PZ3 + hyy * PY3 + 2 * tx) * P3 + 2 * (h ^ ((hyy >> 1) & 1));
+  };
+  const int Ra = rowbase(fyh ? 2 : 0), Rb = rowbase(fyh ? 1 : 2), Rc = rowbase(fyh ? 3 : 1);
 
   const int nsub = Cin >> 2;
   constexpr int wstride_f = 128;
   constexpr int wsub = 64 * 128;
-  const float* wu = wt + ((size_t)nb * nsub * 64 + w * 16) * 128;          // uniform
+  const float* wu = wt + ((size_t)nb * nsub * 64 + fz * 16 + fyh * 8) * 128;      // uniform
   const int wlane = h * 64 + m * 2;
-  wf2 wreg[16];
+  wf2 wreg[8];
 #pragma unroll
-  for (int f = 0; f < 16; ++f) wreg[f] = *reinterpret_cast<const wf2*>(wu + f * wstride_f + wlane);
+  for (int f = 0; f < 8; ++f) wreg[f] = *reinterpret_cast<const wf2*>(wu + f * wstride_f + wlane);
 
-  wf16 acc[16];
+  wf16 acc[8];                                   // frequency (fy local, fx) = acc[fyl * 4 + fx]
 #pragma unroll
-  for (int f = 0; f < 16; ++f)
+  for (int f = 0; f < 8; ++f)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
 
-  wf2 u[16], tn[4][4], ra[4], rb[4];
+  wf2 u[8], tn[2][4], qa, qb, qc;
   auto rd = [&](const int bo, const int sub, const int col) {
-#pragma unroll
-    for (int iy = 0; iy < 4; ++iy) {
-      const int off = (iy * PY3 + col) * P3 + 4 * sub + bo;
-      ra[iy] = *reinterpret_cast<const wf2*>(&lds[(iy < 2 ? A0 : A1) + off]);
-      rb[iy] = *reinterpret_cast<const wf2*>(&lds[(iy < 2 ? B0 : B1) + off]);
-    }
-  };
-  auto colmath = [&](int g) {
-    const wf2 v0 = ra[0] + sg * rb[0], v1 = ra[1] + sg * rb[1], v2 = ra[2] + sg * rb[2], v3 = ra[3] + sg * rb[3];
-    tn[0][g] = v0 - v2;
-    tn[1][g] = v1 + v2;
-    tn[2][g] = v2 - v1;
-    tn[3][g] = v1 - v3;
+    const int off = col * P3 + 4 * sub + bo;
+    qa = *reinterpret_cast<const wf2*>(&lds[Ra + off]);
+    qb = *reinterpret_cast<const wf2*>(&lds[Rb + off]);
+    qc = *reinterpret_cast<const wf2*>(&lds[Rc + off]);
   };
   auto xform = [&]() {
 #pragma unroll
-    for (int fy = 0; fy < 4; ++fy) {
+    for (int fy = 0; fy < 2; ++fy) {
       u[fy * 4 + 0] = tn[fy][0] - tn[fy][2];
       u[fy * 4 + 1] = tn[fy][1] + tn[fy][2];
       u[fy * 4 + 2] = tn[fy][2] - tn[fy][1];
@@ -180,7 +183,8 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const float* __restrict_
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     rd(0, 0, g);
-    colmath(g);
+    tn[0][g] = qa - qb;
+    tn[1][g] = qb + sg * qc;
   }
   xform();
   rd(0, 1, 0);                                   // column 0 of sub-step 1
@@ -195,8 +199,7 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const float* __restrict_
       const float* wn = wu + (size_t)gs * wsub;  // uniform
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        wf2 v0, v1, v2, v3;
-        const wf2 a0 = ra[0], a1 = ra[1], a2 = ra[2], a3 = ra[3], b0 = rb[0], b1 = rb[1], b2 = rb[2], b3 = rb[3];
+        const wf2 a = qa, bq = qb, c = qc;
         if (s == 2 && g == 3) {                  // the next chunk must be visible before its first column is read
           sstore(nxt);
           __syncthreads();
@@ -207,19 +210,14 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const float* __restrict_
         __builtin_amdgcn_sched_barrier(0);
 #define ICS_WMF(F, C) acc[F] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[F].C, wreg[F].C, acc[F], 0, 0, 0)
 #define ICS_WFN __builtin_amdgcn_sched_barrier(0)
-        // consecutive MFMAs on different accumulators; one step of the column math after each
-        ICS_WMF(g * 4 + 0, x); v0 = a0 + sg * b0; ICS_WFN;
-        ICS_WMF(g * 4 + 1, x); v1 = a1 + sg * b1; ICS_WFN;
-        ICS_WMF(g * 4 + 2, x); v2 = a2 + sg * b2; ICS_WFN;
-        ICS_WMF(g * 4 + 3, x); v3 = a3 + sg * b3; ICS_WFN;
-        ICS_WMF(g * 4 + 0, y); tn[0][g] = v0 - v2; ICS_WFN;
-        ICS_WMF(g * 4 + 1, y); tn[1][g] = v1 + v2; ICS_WFN;
-        ICS_WMF(g * 4 + 2, y); tn[2][g] = v2 - v1; ICS_WFN;
-        ICS_WMF(g * 4 + 3, y); tn[3][g] = v1 - v3; ICS_WFN;
+        // consecutive MFMAs on different accumulators; the column math of the next sub-step in between
+        ICS_WMF(g, x); tn[0][g] = a - bq; ICS_WFN;
+        ICS_WMF(4 + g, x); tn[1][g] = bq + sg * c; ICS_WFN;
+        ICS_WMF(g, y); ICS_WFN;
+        ICS_WMF(4 + g, y); ICS_WFN;
 #undef ICS_WMF
-#pragma unroll
-        for (int fx = 0; fx < 4; ++fx)
-          wreg[g * 4 + fx] = *reinterpret_cast<const wf2*>(wn + (g * 4 + fx) * wstride_f + wlane);
+        wreg[g] = *reinterpret_cast<const wf2*>(wn + g * wstride_f + wlane);
+        wreg[4 + g] = *reinterpret_cast<const wf2*>(wn + (4 + g) * wstride_f + wlane);
         ICS_WFN;
 #undef ICS_WFN
       }
@@ -231,47 +229,52 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const float* __restrict_
     chunk(ch + 1, BUF3, 0);
   }
 
-  // ---------------------------------------------------------------- epilogue
-  float* part = lds;                             // [4 w][64 slots = r*4 + dy*2 + dx][64 lanes]  (64 KB)
-  float* red = lds + 16384;                      // [4 w][32] + [32]
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    float q[2][4];
-#pragma unroll
-    for (int fx = 0; fx < 4; ++fx) {
-      q[0][fx] = acc[0 * 4 + fx][r] + acc[1 * 4 + fx][r] + acc[2 * 4 + fx][r];
-      q[1][fx] = acc[1 * 4 + fx][r] - acc[2 * 4 + fx][r] - acc[3 * 4 + fx][r];
-    }
-#pragma unroll
-    for (int dy = 0; dy < 2; ++dy) {
-      part[(w * 64 + r * 4 + dy * 2 + 0) * 64 + lane] = q[dy][0] + q[dy][1] + q[dy][2];
-      part[(w * 64 + r * 4 + dy * 2 + 1) * 64 + lane] = q[dy][1] - q[dy][2] - q[dy][3];
-    }
-  }
-  __syncthreads();
-  // thread task i = 0..3: output-channel quad k = tid & 7, q = (tid >> 3) + 32 i -> h = q & 1, o = (q >> 1) & 3,
-  // accumulator register r = q >> 3; tile = (r >> 2) * 8 + h * 4 + (r & 3)
-  const int k = tid & 7;
+  // ---------------------------------------------------------------- epilogue, two passes of 8 accumulator registers
+  float* part = lds;                             // [8 w][32 slots = rr*4 + dy*2 + dx][64 lanes]  (64 KB)
+  float* red = lds + 16384;                      // [8 w][32] + [32]
+  const int k = tid & 7;                         // this thread's output-channel quad in the final stage
   wf4 bv = {0.f, 0.f, 0.f, 0.f};
   if (bias != nullptr) bv = *reinterpret_cast<const wf4*>(bias + n0 + 4 * k);
-  wf4 val[8];
+  wf4 val[4];
   wf4 csum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int q = (tid >> 3) + 32 * i;
-    const int hh = q & 1, o = (q >> 1) & 3, r = q >> 3;
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int r = pass * 8 + rr;
+      float qv[2][2];                            // [fy local][dx]
+#pragma unroll
+      for (int fy = 0; fy < 2; ++fy) {
+        qv[fy][0] = acc[fy * 4 + 0][r] + acc[fy * 4 + 1][r] + acc[fy * 4 + 2][r];
+        qv[fy][1] = acc[fy * 4 + 1][r] - acc[fy * 4 + 2][r] - acc[fy * 4 + 3][r];
+      }
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        // rows of A^T: the wave with fy 0,1 gives dy0 += q0 + q1, dy1 += q1; the one with fy 2,3: dy0 += q0, dy1 -= q0 + q1
+        const float d0 = fyh ? qv[0][dx] : qv[0][dx] + qv[1][dx];
+        const float d1 = fyh ? -qv[0][dx] - qv[1][dx] : qv[1][dx];
+        part[(w * 32 + rr * 4 + 0 + dx) * 64 + lane] = d0;
+        part[(w * 32 + rr * 4 + 2 + dx) * 64 + lane] = d1;
+      }
+    }
+    __syncthreads();
+    // one task per thread: t = tid >> 3: hh = t & 1, o = (t >> 1) & 3 (= dy*2 + dx), rr = t >> 3; tile = (r>>2)*8 + hh*4 + (r&3)
+    const int t = tid >> 3;
+    const int hh = t & 1, o = (t >> 1) & 3, rr = t >> 3;
+    const int r = pass * 8 + rr;
     const int mt = (r >> 2) * 8 + hh * 4 + (r & 3);
     const int ttz = mt >> 4, tty = (mt >> 2) & 3, ttx = mt & 3;
-    const int slot = (r * 4 + o) * 64 + hh * 32 + 4 * k;
-    const wf4 p0 = *reinterpret_cast<const wf4*>(&part[0 * 4096 + slot]);
-    const wf4 p1 = *reinterpret_cast<const wf4*>(&part[1 * 4096 + slot]);
-    const wf4 p2 = *reinterpret_cast<const wf4*>(&part[2 * 4096 + slot]);
-    const wf4 p3 = *reinterpret_cast<const wf4*>(&part[3 * 4096 + slot]);
+    const int slot = (rr * 4 + o) * 64 + hh * 32 + 4 * k;
+    wf4 p[4];
+#pragma unroll
+    for (int z = 0; z < 4; ++z)
+      p[z] = *reinterpret_cast<const wf4*>(&part[(2 * z) * 2048 + slot]) +
+             *reinterpret_cast<const wf4*>(&part[(2 * z + 1) * 2048 + slot]);
     const int vy = oy + 2 * tty + (o >> 1), vx = ox + 2 * ttx + (o & 1), vz = oz + 2 * ttz;
     const size_t o0 = ((((size_t)b * S + vz) * S + vy) * S + vx) * ldo + n0 + 4 * k;
     const size_t o1 = o0 + (size_t)S * S * ldo;
-    wf4 e0 = p0 + p1 + p2 + bv, e1 = p1 - p2 - p3 + bv;
+    wf4 e0 = p[0] + p[1] + p[2] + bv, e1 = p[1] - p[2] - p[3] + bv;
     if (accumulate) {
       e0 += *reinterpret_cast<const wf4*>(y + o0);
       e1 += *reinterpret_cast<const wf4*>(y + o1);
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const float* __restrict_
     e1.x = wact(e1.x, pre_slope); e1.y = wact(e1.y, pre_slope); e1.z = wact(e1.z, pre_slope); e1.w = wact(e1.w, pre_slope);
     *reinterpret_cast<wf4*>(y + o0) = e0;
     *reinterpret_cast<wf4*>(y + o1) = e1;
-    val[2 * i] = e0; val[2 * i + 1] = e1;
+    val[2 * pass] = e0; val[2 * pass + 1] = e1;
     csum += e0 + e1;
   }
   if (stat_partial == nullptr) return;
@@ -294,15 +297,22 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const float* __restrict_
     }
     return v;
   };
+  auto sum8 = [&](int i) {
+    float s = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < 8; ++ww) s += red[ww * 32 + i];
+    return s;
+  };
   csum = colreduce(csum);
+  __syncthreads();
   if (lane < 8) *reinterpret_cast<wf4*>(&red[w * 32 + 4 * lane]) = csum;
   __syncthreads();
-  if (tid < 32) red[128 + tid] = (red[tid] + red[32 + tid] + red[64 + tid] + red[96 + tid]) * (1.f / kRowsPerBlock);
+  if (tid < 32) red[256 + tid] = sum8(tid) * (1.f / kRowsPerBlock);
   __syncthreads();
-  const wf4 mu = *reinterpret_cast<const wf4*>(&red[128 + 4 * k]);
+  const wf4 mu = *reinterpret_cast<const wf4*>(&red[256 + 4 * k]);
   wf4 qs = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
+  for (int i = 0; i < 4; ++i) {
     const wf4 d = val[i] - mu;
     qs += d * d;
   }
@@ -314,8 +324,8 @@ __global__ __launch_bounds__(256) void conv_wino_kernel(const float* __restrict_
     const size_t nstat = gridDim.x / nchunks;
     float* sp = stat_partial + (size_t)(n0 + tid) * nstat + tblk;
     sp[0] = (float)kRowsPerBlock;
-    sp[(size_t)Npad * nstat] = red[128 + tid];
-    sp[(size_t)2 * Npad * nstat] = red[tid] + red[32 + tid] + red[64 + tid] + red[96 + tid];
+    sp[(size_t)Npad * nstat] = red[256 + tid];
+    sp[(size_t)2 * Npad * nstat] = sum8(tid);
   }
 }
 
@@ -629,7 +639,7 @@ int launch_conv_fwd_wino(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, c
   const float in_slope = wslope(s0.act), pre_slope = wslope(pre_act);
 #define ICS_WINO_LAUNCH(AFFV, NOACTV)                                                                               \
   do {                                                                                                              \
-    hipLaunchKernelGGL((conv_wino_kernel<AFFV, NOACTV>), dim3(grid), dim3(256), 0, st, s0.p, s0.C, s0.scale,        \
+    hipLaunchKernelGGL((conv_wino_kernel<AFFV, NOACTV>), dim3(grid), dim3(512), 0, st, s0.p, s0.C, s0.scale,        \
                        s0.shift, in_slope, wt, bias, out, ldo, pre_slope, accumulate, stat_partial, g.Npad, g.S,    \
                        g.Cin, g.Cout);                                                                              \
     conv_set_last_kernel_id("conv_wino_kernel<" #AFFV ", " #NOACTV ">");                                            \

@@ -943,6 +943,215 @@ __global__ __launch_bounds__(256) void wino_fwd6(const float* __restrict__ x, co
   }
 }
 
+
+// ---------------------------------------------------------------- v7: 8 waves (2 per SIMD: VALU 3.6 instead of 5.2
+// cycles, MFMA 69.5 instead of 75), z-combination done ONCE at staging time (8 combined planes (tz, fz) in LDS instead
+// of 6 raw ones), wave w: fz = w >> 1, fy rows {2 (w&1), 2 (w&1) + 1}: 12 LDS reads + 32 VALU per 16 MFMAs.
+constexpr int P7 = 18, PY7 = 10, PZ7 = 100, BUF7 = 8 * PZ7 * P7;          // floats per buffer (57 600 B)
+template <int EXP>
+__global__ __launch_bounds__(512) void wino_fwd7(const float* __restrict__ x, const float* __restrict__ wt,
+                                                 float* __restrict__ y, int S, int Cin, int Cout) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * BUF7];   // 115 200 B
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fz = w >> 1, fyh = w & 1;
+  const int m = lane & 31, h = lane >> 5;
+  const int nchunks = Cout >> 5;
+  const int nb = blockIdx.x % nchunks;
+  int tb = blockIdx.x / nchunks;
+  const int nbx = S >> 3, nby = S >> 3, nbz = S >> 2;
+  const int bx = tb % nbx; tb /= nbx;
+  const int by = tb % nby; tb /= nby;
+  const int bz = tb % nbz;
+  const int b = tb / nbz;
+  const int oz = bz * 4, oy = by * 8, ox = bx * 8, n0 = nb * 32;
+  const bool edge = bx == 0 || by == 0 || bz == 0 || bx == nbx - 1 || by == nby - 1 || bz == nbz - 1;
+
+  // ---- staging: thread t < 400 owns (hy, hx, q): six raw z values -> eight combined planes
+  const int cmb = tid < 400 ? tid : 399;
+  const int q = cmb & 3, hx = (cmb >> 2) % HX, hy = (cmb >> 2) / HX;
+  f4 stage[6];
+  int soff[6];
+  unsigned okmask = 0;
+  {
+    const int gy = oy - 1 + hy, gx = ox - 1 + hx;
+    const bool okyx = gy >= 0 && gy < S && gx >= 0 && gx < S;
+    const int cy = min(max(gy, 0), S - 1), cx = min(max(gx, 0), S - 1);
+#pragma unroll
+    for (int hz = 0; hz < 6; ++hz) {
+      const int gz = oz - 1 + hz;
+      const bool ok = okyx && gz >= 0 && gz < S;
+      okmask |= ok ? (1u << hz) : 0u;
+      const int cz = min(max(gz, 0), S - 1);
+      soff[hz] = (((b * S + cz) * S + cy) * S + cx) * Cin + q * 4;
+    }
+  }
+  const int sw = ((hy >> 1) & 1) * 2;
+  const int dbase = (hy * PY7 + hx) * P7 + q * 4;           // + plane * PZ7 * P7
+  auto gload = [&](int c0) {
+    const float* xc = x + c0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) stage[i] = *reinterpret_cast<const f4*>(xc + soff[i]);
+  };
+  auto sstore = [&](const int bo) {
+    if (edge) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+        if (!((okmask >> i) & 1)) stage[i] = f4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (tid < 400) {
+#pragma unroll
+      for (int tz = 0; tz < 2; ++tz) {
+        const f4 d0 = stage[2 * tz], d1 = stage[2 * tz + 1], d2 = stage[2 * tz + 2], d3 = stage[2 * tz + 3];
+        const f4 c[4] = {d0 - d2, d1 + d2, d2 - d1, d1 - d3};
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          const int o = bo + (tz * 4 + f) * (PZ7 * P7) + dbase;
+          *reinterpret_cast<f2*>(&lds[o + sw]) = f2{c[f].x, c[f].y};
+          *reinterpret_cast<f2*>(&lds[o + 2 - sw]) = f2{c[f].z, c[f].w};
+        }
+      }
+    }
+  };
+
+  // ---- per-lane read geometry: rows (a, b, cc) of the y transform for this wave's two fy rows
+  const int tz = m >> 4, ty = (m >> 2) & 3, tx = m & 3;
+  const int ra_ = fyh ? 2 : 0, rb_ = fyh ? 1 : 2, rc_ = fyh ? 3 : 1;
+  const float sg = fyh ? -1.f : 1.f;                       // t1 = R_b + sg * R_c
+  auto rowbase = [&](int iy) {
+    const int hyy = 2 * ty + iy;
+    return ((tz * 4 + fz) * PZ7 + hyy * PY7 + 2 * tx) * P7 + 2 * (h ^ ((hyy >> 1) & 1));
+  };
+  const int Ra = rowbase(ra_), Rb = rowbase(rb_), Rc = rowbase(rc_);
+
+  const int nsub = Cin >> 2;
+  constexpr int wstride_f = 128;
+  constexpr int wsub = 64 * 128;
+  const float* wu = wt + ((size_t)nb * nsub * 64 + fz * 16 + fyh * 8) * 128;       // uniform
+  const int wlane = h * 64 + m * 2;
+  f2 wreg[8];
+#pragma unroll
+  for (int f = 0; f < 8; ++f) wreg[f] = *reinterpret_cast<const f2*>(wu + f * wstride_f + wlane);
+
+  f16v acc[8];
+#pragma unroll
+  for (int f = 0; f < 8; ++f)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+
+  f2 u[8], tn[2][4], qa, qb, qc;
+  auto rd = [&](const int bo, const int sub, const int col) {
+    const int off = col * P7 + 4 * sub + bo;
+    qa = *reinterpret_cast<const f2*>(&lds[Ra + off]);
+    qb = *reinterpret_cast<const f2*>(&lds[Rb + off]);
+    qc = *reinterpret_cast<const f2*>(&lds[Rc + off]);
+  };
+  auto colmath = [&](int g) {
+    tn[0][g] = qa - qb;
+    tn[1][g] = qb + sg * qc;
+  };
+  auto xform = [&]() {
+#pragma unroll
+    for (int fy = 0; fy < 2; ++fy) {
+      u[fy * 4 + 0] = tn[fy][0] - tn[fy][2];
+      u[fy * 4 + 1] = tn[fy][1] + tn[fy][2];
+      u[fy * 4 + 2] = tn[fy][2] - tn[fy][1];
+      u[fy * 4 + 3] = tn[fy][1] - tn[fy][3];
+    }
+  };
+
+  gload(0);
+  sstore(0);
+  __syncthreads();
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    rd(0, 0, g);
+    colmath(g);
+  }
+  xform();
+  rd(0, 1, 0);
+
+  const int nch = Cin / KC;
+  auto chunk = [&](const int ch, const int cur, const int nxt) {
+    gload((ch + 1 < nch ? ch + 1 : ch) * KC);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      int gs = ch * 4 + s + 1;
+      gs = gs < nsub ? gs : nsub - 1;
+      const float* wn = wu + (size_t)gs * wsub;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f2 a = qa, bq = qb, c = qc;
+        if (s == 2 && g == 3) {
+          sstore(nxt);
+          __syncthreads();
+        }
+        if (g < 3) rd(s == 3 ? nxt : cur, (s + 1) & 3, g + 1);
+        else rd(s >= 2 ? nxt : cur, (s + 2) & 3, 0);
+        if (!(EXP & 1)) __builtin_amdgcn_sched_barrier(0);
+#define MF7(F, C) acc[F] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[F].C, wreg[F].C, acc[F], 0, 0, 0)
+#define FN7 if (!(EXP & 1)) __builtin_amdgcn_sched_barrier(0)
+        MF7(g, x); tn[0][g] = a - bq; FN7;
+        MF7(4 + g, x); tn[1][g] = bq + sg * c; FN7;
+        MF7(g, y); FN7;
+        MF7(4 + g, y); FN7;
+        wreg[g] = *reinterpret_cast<const f2*>(wn + g * wstride_f + wlane);
+        wreg[4 + g] = *reinterpret_cast<const f2*>(wn + (4 + g) * wstride_f + wlane);
+        FN7;
+      }
+      xform();
+    }
+  };
+  for (int ch = 0; ch < nch; ch += 2) {
+    chunk(ch, 0, BUF7);
+    chunk(ch + 1, BUF7, 0);
+  }
+
+  // ---- epilogue, two passes of 8 accumulator registers
+  float* part = lds;                              // [8 w][32 = rr*4 + dy*2 + dx][64 lanes]  (64 KB)
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int r = pass * 8 + rr;
+      float qv[2][2];                             // [fy local][dx]
+#pragma unroll
+      for (int fy = 0; fy < 2; ++fy) {
+        qv[fy][0] = acc[fy * 4 + 0][r] + acc[fy * 4 + 1][r] + acc[fy * 4 + 2][r];
+        qv[fy][1] = acc[fy * 4 + 1][r] - acc[fy * 4 + 2][r] - acc[fy * 4 + 3][r];
+      }
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        // fyh = 0 holds fy 0,1: dy0 += q0 + q1, dy1 += q1;   fyh = 1 holds fy 2,3: dy0 += q0, dy1 += -q0 - q1
+        const float d0 = fyh ? qv[0][dx] : qv[0][dx] + qv[1][dx];
+        const float d1 = fyh ? -qv[0][dx] - qv[1][dx] : qv[1][dx];
+        part[(w * 32 + rr * 4 + 0 + dx) * 64 + lane] = d0;
+        part[(w * 32 + rr * 4 + 2 + dx) * 64 + lane] = d1;
+      }
+    }
+    __syncthreads();
+    // task: k = tid & 7 (channel quad), t = tid >> 3 (0..63): hh = t & 1, o = (t >> 1) & 3, rr = t >> 3
+    {
+      const int k = tid & 7, t = tid >> 3;
+      const int hh = t & 1, o = (t >> 1) & 3, rr = t >> 3;
+      const int r = pass * 8 + rr;
+      const int mt = (r >> 2) * 8 + hh * 4 + (r & 3);
+      const int ttz = mt >> 4, tty = (mt >> 2) & 3, ttx = mt & 3;
+      const int slot = (rr * 4 + o) * 64 + hh * 32 + 4 * k;
+      f4 p[4];
+#pragma unroll
+      for (int z = 0; z < 4; ++z)
+        p[z] = *reinterpret_cast<const f4*>(&part[(2 * z) * 2048 + slot]) +
+               *reinterpret_cast<const f4*>(&part[(2 * z + 1) * 2048 + slot]);
+      const int vy = oy + 2 * tty + (o >> 1), vx = ox + 2 * ttx + (o & 1), vz = oz + 2 * ttz;
+      const size_t o0 = ((((size_t)b * S + vz) * S + vy) * S + vx) * Cout + n0 + 4 * k;
+      *reinterpret_cast<f4*>(y + o0) = p[0] + p[1] + p[2];
+      *reinterpret_cast<f4*>(y + o0 + (size_t)S * S * Cout) = p[1] - p[2] - p[3];
+    }
+  }
+}
+
 // ---------------------------------------------------------------- host
 static void transform_weights(const std::vector<float>& w, int Cin, int Cout, std::vector<float>& wt, int cw, int lay) {
   // w: [3][3][3][Cin][Cout] -> wt: [64][Cin/8][2][Cout][4]
@@ -974,7 +1183,7 @@ static void transform_weights(const std::vector<float>& w, int Cin, int Cout, st
 int main(int argc, char** argv) {
   bool check = argc > 1 && !strcmp(argv[1], "check");
   int B = 32, S = 32, Cin = 128, Cout = 128;
-  if (check) { B = 2; S = 8; Cin = 16; Cout = 32; }
+  if (check) { B = 2; S = 8; Cin = 32; Cout = 32; }
   if (argc > 5) { B = atoi(argv[2]); S = atoi(argv[3]); Cin = atoi(argv[4]); Cout = atoi(argv[5]); }
   size_t nx = (size_t)B * S * S * S * Cin, ny = (size_t)B * S * S * S * Cout, nw = (size_t)27 * Cin * Cout;
   std::vector<float> hx(nx), hw(nw), hwt;
@@ -1000,6 +1209,7 @@ int main(int argc, char** argv) {
       if (ex == 0) L3(0); else if (ex == 1) L3(2); else if (ex == 2) L3(4); else if (ex == 3) L3(6); else if (ex == 4) L3(8);
       else if (ex == 5) L3(10); else if (ex == 6) L3(12); else L3(14);
     }
+    else if (variant == 7) { if (flags & 1) hipLaunchKernelGGL((wino_fwd7<1>), dim3(grid), dim3(512), 0, 0, dx, dwt, dy, S, Cin, Cout); else hipLaunchKernelGGL((wino_fwd7<0>), dim3(grid), dim3(512), 0, 0, dx, dwt, dy, S, Cin, Cout); }
     else if (variant == 6) hipLaunchKernelGGL((wino_fwd6<0>), dim3(grid), dim3(256), 0, 0, dx, dwt, dy, S, Cin, Cout);
     else if (variant == 4) hipLaunchKernelGGL((wino_fwd4<0, 0>), dim3(grid), dim3(256), 0, 0, dx, dwt, dz, dy, S, Cin, Cout);
     else if (variant == 5) {
