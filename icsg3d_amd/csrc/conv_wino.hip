@@ -78,7 +78,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const float* __restrict_
   const int cmb = tid < 400 ? tid : 399;
   const int q = cmb & 3, hx = (cmb >> 2) % HX, hy = (cmb >> 2) / HX;
   wf4 stage[6];
-  int soff[6];
+  unsigned soff[6];                              // unsigned: scalar base + 32-bit lane offset addressing
   unsigned okmask = 0;
   {
     const int gy = oy - 1 + hy, gx = ox - 1 + hx;
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const float* __restrict_
       const int gz = oz - 1 + hz;
       okmask |= (okyx && gz >= 0 && gz < S) ? (1u << hz) : 0u;
       const int cz = min(max(gz, 0), S - 1);
-      soff[hz] = (((b * S + cz) * S + cy) * S + cx) * ldx + q * 4;
+      soff[hz] = (unsigned)((((b * S + cz) * S + cy) * S + cx) * ldx + q * 4);
     }
   }
   const int sw = ((hy >> 1) & 1) * 2;
@@ -333,30 +333,34 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const float* __restrict_
 // Backward-weight in the Winograd domain.  From Y = A^T[(G g) .* (B^T d)]:
 //   dL/dg = G^T [ sum over tiles (A dY) .* (B^T d) ]     (per axis; dY = the 2x2x2 gradient tile, A = [1 0; 1 1; 1 -1; 0 -1])
 // i.e. 64 independent GEMMs  dW^_f[ci][co] = sum_t U_f[t][ci] V_f[t][co]  reduced over ALL tiles, then the 4 -> 3
-// contraction with G per axis.  One workgroup = 32 input channels x 32 output channels x 64 frequencies (same 256 + 256
-// register accumulator layout as the forward kernel: wave w owns fz = w) over a range of tile blocks (split-K over the
-// tiles); a block = 2x2x4 tiles (4x4x8 voxels): x halo [6][6][10] x 32 ci and dy [4][4][8] x 32 co staged in LDS,
-// double buffered.  MFMA k = 2 tiles: lanes 0-31 tile 2p, lanes 32-63 tile 2p+1, lane & 31 = channel -- every lane
-// transforms its own (tile, channel) pair from conflict-free ds_read_b32.  The transform of k-step p+1 is interleaved
-// with the 16 MFMAs of step p.  V is built without its negations (rows f = 3 of A); the epilogue puts the signs back
-// while contracting (fy, fx) -> (b, c) in registers and fz -> a across the waves, and writes ws[split][27*Cin][Cout],
-// the layout conv_igemm.hip's split reduction consumes.
+// contraction with G per axis.  One workgroup = 32 input channels x 32 output channels x 64 frequencies over a range
+// of tile blocks (split-K over the tiles); 8 waves, wave w owns (fz = w >> 1, fy in {2 (w&1), 2 (w&1) + 1}, fx = 0..3),
+// one 32x32 accumulator each.  A block = 2x2x4 tiles (4x4x8 voxels): the x halo [6][6][10] x 32 ci is read by 480
+// threads, each owning one (y, x, channel quad) column and writing the eight z-combined planes (tile z, fz) (BatchNorm
+// affine of the producer and zero padding applied first), dy [4][4][8] x 32 co is staged as is; both CHANNEL-major in
+// LDS (pitch 482 / 130 floats per channel), double buffered.  MFMA k = 2 tiles: lanes 0-31 tile 2p, lanes 32-63 tile
+// 2p+1, lane & 31 = channel -- every lane transforms its own (tile, channel) pair from conflict-free ds_read_b64
+// (two x-neighbours per read) at immediate offsets of one base register.  The transform of k-step p+1 is interleaved
+// with the 8 MFMAs of step p.  V is built without the negations of A's last row; the epilogue puts the signs back while
+// contracting fx -> c and the wave's share of fy -> b in registers and the rest (fy halves, fz -> a) across the waves,
+// and writes ws[split][27*Cin][Cout], the layout conv_igemm.hip's split reduction consumes.
 namespace {
-constexpr int GZ = 6, GY = 6, GX = 10, GNV = GZ * GY * GX;                 // x halo of a 4x4x8 block
-constexpr int GXF = GNV * 32, GYF = 128 * 32, GBUF = GXF + GYF;            // floats: x part, dy part, one buffer
-constexpr int GNX = (GNV * 8 + 255) / 256, GNY = 4;                        // float4 staging slots per thread
+constexpr int GZ = 6, GY = 6, GX = 10;
+constexpr int GXP = 482, GYP = 130;                                        // floats per channel: 8 planes x 60 (+2), 128 (+2)
+constexpr int GXF = 32 * GXP, GYF = 32 * GYP, GBUF = GXF + GYF;            // one buffer: 78 336 B
 }  // namespace
 
 template <bool AFF, bool NOACT>
-__global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(const float* __restrict__ x, int ldx,
+__global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(const float* __restrict__ x, int ldx,
                                                               const float* __restrict__ in_scale,
                                                               const float* __restrict__ in_shift, float in_slope,
                                                               const float* __restrict__ dy, int ldy,
-                                                              float* __restrict__ ws, const float* __restrict__ zeros,
-                                                              int S, int Cin, int Cout, int nblocks, int per_split) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * GBUF];      // 124 928 B
+                                                              float* __restrict__ ws, int S, int Cin, int Cout,
+                                                              int per_split) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * GBUF];      // 156 672 B
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fz = w >> 1, fyh = w & 1;
   const int c = lane & 31, hl = lane >> 5;
   const int nco = Cout >> 5, nci = Cin >> 5;
   const int cob = blockIdx.x % nco;
@@ -366,32 +370,25 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(const float* __res
   const int blk_lo = split * per_split, blk_hi = blk_lo + per_split;
   const int nbx = S >> 3, nby = S >> 2, nbz = S >> 2;
 
-  // ---- staging slots
-  wf4 xs[GNX], ys[GNY];
-  int xrel[GNX], yrel[GNY];
-  unsigned xface = 0;                                  // 6 face bits per slot, 5 slots per word -> 3 words
-  unsigned xface1 = 0, xface2 = 0;
-  const int q4 = (tid & 7) * 4;
+  // ---- staging.  x: thread t < 480 owns (hy, hx, channel quad q): six raw z values -> eight combined planes.
+  const int cmb = tid < 480 ? tid : 479;
+  const int q = cmb & 7, hx = (cmb >> 3) % GX, hy = (cmb >> 3) / GX;
+  wf4 xs[6], ys[2];
+  unsigned xrel[6], yrel[2];                       // relative to the halo corner (block origin - (1,1,1)): unsigned,
+#pragma unroll                                     // so that loads take a scalar base + 32-bit lane offset
+  for (int hz = 0; hz < 6; ++hz) xrel[hz] = (unsigned)(((hz * S + hy) * S + hx) * ldx + q * 4);
+  const unsigned xsafe = (unsigned)(((S + 1) * S + 1) * ldx + q * 4);   // the block's own first voxel
 #pragma unroll
-  for (int i = 0; i < GNX; ++i) {
-    int e = tid + i * 256;
-    if (e >= GNV * 8) e = GNV * 8 - 1;
-    const int v = e >> 3;
-    const int hx = v % GX, hy = (v / GX) % GY, hz = v / (GX * GY);
-    xrel[i] = (((hz - 1) * S + (hy - 1)) * S + (hx - 1)) * ldx + q4;
-    const unsigned f = (hz == 0) | ((hz == GZ - 1) << 1) | ((hy == 0) << 2) | ((hy == GY - 1) << 3) | ((hx == 0) << 4) |
-                       ((hx == GX - 1) << 5);
-    if (i < 5) xface |= f << (6 * i); else if (i < 10) xface1 |= f << (6 * (i - 5)); else xface2 |= f << (6 * (i - 10));
+  for (int i = 0; i < 2; ++i) {
+    const int v = (tid + i * 512) >> 3;                                    // 0..127 = (vz, vy, vx)
+    yrel[i] = (unsigned)((((v >> 5) * S + ((v >> 3) & 3)) * S + (v & 7)) * ldy + (tid & 7) * 4);
   }
-#pragma unroll
-  for (int i = 0; i < GNY; ++i) {
-    const int v = (tid + i * 256) >> 3;
-    yrel[i] = (((v >> 5) * S + ((v >> 3) & 3)) * S + (v & 7)) * ldy + q4;
-  }
+  const unsigned yxface = ((hy == 0) << 2) | ((hy == GY - 1) << 3) | ((hx == 0) << 4) | ((hx == GX - 1) << 5);
+  const int xw = (q * 4) * GXP + hy * GX + hx;                             // LDS write base (floats): + j*GXP + plane*60
   wf4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
   if (AFF) {
-    sc4 = *reinterpret_cast<const wf4*>(in_scale + ci0 + q4);
-    sh4 = *reinterpret_cast<const wf4*>(in_shift + ci0 + q4);
+    sc4 = *reinterpret_cast<const wf4*>(in_scale + ci0 + q * 4);
+    sh4 = *reinterpret_cast<const wf4*>(in_shift + ci0 + q * 4);
   }
   unsigned bface_cur = 0;
   auto gload = [&](int blk) {
@@ -404,109 +401,108 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(const float* __res
     const unsigned bface = (bz == 0) | ((bz == nbz - 1) << 1) | ((by == 0) << 2) | ((by == nby - 1) << 3) |
                            ((bx == 0) << 4) | ((bx == nbx - 1) << 5);
     bface_cur = bface;
-    const float* xb = x + (size_t)org * ldx + ci0;
+    const float* xb = x + ((ptrdiff_t)org - ((S + 1) * S + 1)) * ldx + ci0;    // halo corner (never dereferenced outside)
     const float* yb = dy + (size_t)org * ldy + co0;
-    if (bface) {                                                           // halo outside the grid: read the zero page
+    if (bface) {                                                           // halo outside the grid: read the block's
+      const bool yxbad = (yxface & bface) != 0;                            // own first voxel instead, zeroed below
 #pragma unroll
-      for (int i = 0; i < GNX; ++i) {
-        const unsigned f = ((i < 5 ? xface >> (6 * i) : (i < 10 ? xface1 >> (6 * (i - 5)) : xface2 >> (6 * (i - 10)))) & 63u);
-        const float* p = (f & bface) ? zeros : xb + xrel[i];
-        xs[i] = *reinterpret_cast<const wf4*>(p);
+      for (int hz = 0; hz < 6; ++hz) {
+        const bool bad = yxbad || (hz == 0 && (bface & 1)) || (hz == 5 && (bface & 2));
+        xs[hz] = *reinterpret_cast<const wf4*>(xb + (bad ? xsafe : xrel[hz]));
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < GNX; ++i) xs[i] = *reinterpret_cast<const wf4*>(xb + xrel[i]);
+      for (int hz = 0; hz < 6; ++hz) xs[hz] = *reinterpret_cast<const wf4*>(xb + xrel[hz]);
     }
 #pragma unroll
-    for (int i = 0; i < GNY; ++i) ys[i] = *reinterpret_cast<const wf4*>(yb + yrel[i]);
+    for (int i = 0; i < 2; ++i) ys[i] = *reinterpret_cast<const wf4*>(yb + yrel[i]);
   };
   auto sstore = [&](const int bo) {
+    const unsigned bface = bface_cur;
     if (AFF) {
-      const unsigned bface = bface_cur;
 #pragma unroll
-      for (int i = 0; i < GNX; ++i) {
+      for (int i = 0; i < 6; ++i) {
         wf4 t = xs[i];
         t.x = fmaf(t.x, sc4.x, sh4.x); t.y = fmaf(t.y, sc4.y, sh4.y);
         t.z = fmaf(t.z, sc4.z, sh4.z); t.w = fmaf(t.w, sc4.w, sh4.w);
         if (!NOACT) { t.x = wact(t.x, in_slope); t.y = wact(t.y, in_slope); t.z = wact(t.z, in_slope); t.w = wact(t.w, in_slope); }
-        if (bface) {                                                       // padding zeros come AFTER the affine
-          const unsigned f = ((i < 5 ? xface >> (6 * i) : (i < 10 ? xface1 >> (6 * (i - 5)) : xface2 >> (6 * (i - 10)))) & 63u);
-          if (f & bface) t = wf4{0.f, 0.f, 0.f, 0.f};
-        }
         xs[i] = t;
       }
     }
+    if (bface) {                                                           // padding zeros come AFTER the affine
+      const bool yxbad = (yxface & bface) != 0;
 #pragma unroll
-    for (int i = 0; i < GNX; ++i) {
-      int e = tid + i * 256;
-      if (e >= GNV * 8) e = GNV * 8 - 1;
-      *reinterpret_cast<wf4*>(&lds[bo + (e >> 3) * 32 + q4]) = xs[i];
+      for (int hz = 0; hz < 6; ++hz)
+        if (yxbad || (hz == 0 && (bface & 1)) || (hz == 5 && (bface & 2))) xs[hz] = wf4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (tid < 480) {
+#pragma unroll
+      for (int tz = 0; tz < 2; ++tz) {
+        const wf4 d0 = xs[2 * tz], d1 = xs[2 * tz + 1], d2 = xs[2 * tz + 2], d3 = xs[2 * tz + 3];
+        const wf4 cz[4] = {d0 - d2, d1 + d2, d2 - d1, d1 - d3};
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          const int o = bo + xw + (tz * 4 + f) * 60;
+          lds[o] = cz[f].x; lds[o + GXP] = cz[f].y; lds[o + 2 * GXP] = cz[f].z; lds[o + 3 * GXP] = cz[f].w;
+        }
+      }
     }
 #pragma unroll
-    for (int i = 0; i < GNY; ++i) *reinterpret_cast<wf4*>(&lds[bo + GXF + ((tid + i * 256) >> 3) * 32 + q4]) = ys[i];
+    for (int i = 0; i < 2; ++i) {
+      const int o = bo + GXF + ((tid & 7) * 4) * GYP + ((tid + i * 512) >> 3);
+      lds[o] = ys[i].x; lds[o + GYP] = ys[i].y; lds[o + 2 * GYP] = ys[i].z; lds[o + 3 * GYP] = ys[i].w;
+    }
   };
 
-  // ---- per-lane read bases: wave w = fz combines x planes (za, zb) with sign sg, dy planes with (ca, cb)
-  const int za = (w == 0) ? 0 : (w == 2 ? 2 : 1);
-  const int zb = (w == 0) ? 2 : (w == 1 ? 2 : (w == 2 ? 1 : 3));
-  const float sg = (w == 1) ? 1.f : -1.f;
-  const float ca = (w == 3) ? 0.f : 1.f, cb = (w == 0) ? 0.f : (w == 2 ? -1.f : 1.f);   // row fz of A (fz = 3 un-negated)
-  const int LXa = za * (GY * GX * 32) + hl * 64 + c, LXb = zb * (GY * GX * 32) + hl * 64 + c;
-  const int LY = GXF + hl * 64 + c;
+  // ---- per-lane read bases.  x rows (a, b, c) of the wave's two fy rows:  fy = 2 fyh: R_a - R_b,  fy = 2 fyh + 1:
+  // R_b + sg R_c  with (a, b, c, sg) = (0,2,1,+) / (2,1,3,-);  dy: rows fz of A as (ca, cb), rows fy as (a1, b0)
+  const float sg = fyh ? -1.f : 1.f;
+  const int xbase = c * GXP + fz * 60 + 2 * hl;
+  const int XA = xbase + (fyh ? 2 : 0) * GX, XB = xbase + (fyh ? 1 : 2) * GX, XC = xbase + (fyh ? 3 : 1) * GX;
+  const int YB = GXF + c * GYP + 2 * hl;
+  const float ca = (fz == 3) ? 0.f : 1.f, cb = (fz == 0) ? 0.f : (fz == 2 ? -1.f : 1.f);   // fz = 3 un-negated
+  const float a1 = fyh ? -1.f : 0.f, b0 = fyh ? 0.f : 1.f;   // rlo = g0 + a1 g1, rhi = b0 g0 + g1 (fy = 3 un-negated)
 
-  wf16 acc[16];
+  wf16 acc[8];
 #pragma unroll
-  for (int f = 0; f < 16; ++f)
+  for (int f = 0; f < 8; ++f)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
 
-  float u[16], vv[16];                 // operands of the current k-step
-  float xa[16], xb_[16], e0[4], e1[4]; // raw reads of the next k-step
+  float u[2][8], vv[2][8];             // operands of k-step p in [p & 1]: f = fy_local * 4 + fx
+  wf2 xa[2], xb2[2], xc[2];            // raw reads of a later k-step: rows a, b, c, x pairs (0,1) (2,3)
+  wf2 e0[2], e1[2];                    // dy: z = 2tz / 2tz+1, [dyy] = (dx0, dx1)
   auto rd = [&](const int bo, const int p) {
     const int tz = p >> 2, ty = (p >> 1) & 1, txp = p & 1;
+    const int ox = bo + tz * 240 + (2 * ty) * GX + 4 * txp;
 #pragma unroll
-    for (int iy = 0; iy < 4; ++iy)
+    for (int j = 0; j < 2; ++j) {
+      xa[j] = *reinterpret_cast<const wf2*>(&lds[XA + ox + 2 * j]);
+      xb2[j] = *reinterpret_cast<const wf2*>(&lds[XB + ox + 2 * j]);
+      xc[j] = *reinterpret_cast<const wf2*>(&lds[XC + ox + 2 * j]);
+    }
 #pragma unroll
-      for (int ix = 0; ix < 4; ++ix) {
-        const int off = bo + (((2 * tz) * GY + 2 * ty + iy) * GX + 4 * txp + ix) * 32;
-        xa[iy * 4 + ix] = lds[LXa + off];
-        xb_[iy * 4 + ix] = lds[LXb + off];
-      }
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {      // d = dyy*2 + dx
-      const int off = bo + (((2 * tz) * 4 + 2 * ty + (d >> 1)) * 8 + 4 * txp + (d & 1)) * 32;
-      e0[d] = lds[LY + off];
-      e1[d] = lds[LY + off + 4 * 8 * 32];
+    for (int d = 0; d < 2; ++d) {
+      const int oy = bo + ((2 * tz) * 4 + 2 * ty + d) * 8 + 4 * txp;
+      e0[d] = *reinterpret_cast<const wf2*>(&lds[YB + oy]);
+      e1[d] = *reinterpret_cast<const wf2*>(&lds[YB + oy + 32]);
     }
   };
-  // the whole transform of one k-step (used in the prologue; the main loop interleaves the same steps with MFMAs)
-  float tz_[16], ty_[16], g_[4], r_[4][2];
-  auto tr_z = [&](int i0) {
-#pragma unroll
-    for (int i = i0; i < i0 + 4; ++i) tz_[i] = fmaf(sg, xb_[i], xa[i]);
+  float t0[4], t1[4], rl[2], rh[2];
+  auto tr_y = [&](int j) {             // x pair j: columns 2j, 2j+1
+    t0[2 * j] = xa[j].x - xb2[j].x; t0[2 * j + 1] = xa[j].y - xb2[j].y;
+    t1[2 * j] = fmaf(sg, xc[j].x, xb2[j].x); t1[2 * j + 1] = fmaf(sg, xc[j].y, xb2[j].y);
   };
-  auto tr_y = [&](int ix) {            // column ix: over iy
-    const float v0 = tz_[0 * 4 + ix], v1 = tz_[1 * 4 + ix], v2 = tz_[2 * 4 + ix], v3 = tz_[3 * 4 + ix];
-    ty_[0 * 4 + ix] = v0 - v2; ty_[1 * 4 + ix] = v1 + v2; ty_[2 * 4 + ix] = v2 - v1; ty_[3 * 4 + ix] = v1 - v3;
+  auto tr_x = [&](const float* t, float* un) {
+    un[0] = t[0] - t[2]; un[1] = t[1] + t[2]; un[2] = t[2] - t[1]; un[3] = t[1] - t[3];
   };
-  auto tr_x = [&](int fy, float* un) { // row fy: over ix
-    const float v0 = ty_[fy * 4 + 0], v1 = ty_[fy * 4 + 1], v2 = ty_[fy * 4 + 2], v3 = ty_[fy * 4 + 3];
-    un[fy * 4 + 0] = v0 - v2; un[fy * 4 + 1] = v1 + v2; un[fy * 4 + 2] = v2 - v1; un[fy * 4 + 3] = v1 - v3;
+  auto tr_d = [&]() {                  // dy: z rows then the wave's two y rows
+    const float g00 = fmaf(cb, e1[0].x, ca * e0[0].x), g01 = fmaf(cb, e1[0].y, ca * e0[0].y);   // dyy = 0: dx 0, 1
+    const float g10 = fmaf(cb, e1[1].x, ca * e0[1].x), g11 = fmaf(cb, e1[1].y, ca * e0[1].y);   // dyy = 1
+    rl[0] = fmaf(a1, g10, g00); rl[1] = fmaf(a1, g11, g01);
+    rh[0] = fmaf(b0, g00, g10); rh[1] = fmaf(b0, g01, g11);
   };
-  auto tr_dz = [&]() {
-#pragma unroll
-    for (int d = 0; d < 4; ++d) g_[d] = fmaf(cb, e1[d], ca * e0[d]);
-  };
-  auto tr_dy = [&]() {                 // over dyy -> fy (row 3 un-negated)
-#pragma unroll
-    for (int dx = 0; dx < 2; ++dx) {
-      r_[0][dx] = g_[0 * 2 + dx]; r_[1][dx] = g_[dx] + g_[2 + dx]; r_[2][dx] = g_[dx] - g_[2 + dx]; r_[3][dx] = g_[2 + dx];
-    }
-  };
-  auto tr_dx = [&](int fy, float* vn) {
-    vn[fy * 4 + 0] = r_[fy][0]; vn[fy * 4 + 1] = r_[fy][0] + r_[fy][1]; vn[fy * 4 + 2] = r_[fy][0] - r_[fy][1];
-    vn[fy * 4 + 3] = r_[fy][1];
-  };
+  auto tr_v = [&](const float* r, float* vn) { vn[0] = r[0]; vn[1] = r[0] + r[1]; vn[2] = r[0] - r[1]; vn[3] = r[1]; };
 
   // per_split is even and every split is full (launcher): no conditional blocks -- a conditional one makes the
   // register allocator spill the accumulators
@@ -514,41 +510,30 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(const float* __res
   sstore(0);
   __syncthreads();
   rd(0, 0);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) tr_z(4 * i);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) tr_y(i);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) tr_x(i, u);
-  tr_dz(); tr_dy();
-#pragma unroll
-  for (int i = 0; i < 4; ++i) tr_dx(i, vv);
+  tr_y(0); tr_y(1); tr_x(t0, u[0]); tr_x(t1, u[0] + 4); tr_d(); tr_v(rl, vv[0]); tr_v(rh, vv[0] + 4);
   rd(0, 1);
   auto block = [&](const int blk, const int cur, const int nxt) {
     gload(blk + 1 < blk_hi ? blk + 1 : blk);             // past the end: this block again (never consumed)
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
-      float un[16], vn[16];
-      // raw reads in xa/xb_/e0/e1 belong to step p+1 (step 0 of the next block when p == 7)
-#define ICS_GMF(F) acc[F] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[F], vv[F], acc[F], 0, 0, 0)
+      float* uc = u[p & 1];  float* vc = vv[p & 1];      // this step's operands
+      float* un = u[(p + 1) & 1];  float* vn = vv[(p + 1) & 1];
+      // raw reads in xa/xb2/xc/e0/e1 belong to step p+1 (step 0 of the next block when p == 7); its transform is
+      // interleaved with this step's MFMAs (measured: doing it after them costs 15 %)
+#define ICS_GMF(F) acc[F] = __builtin_amdgcn_mfma_f32_32x32x2f32(uc[F], vc[F], acc[F], 0, 0, 0)
 #define ICS_GFN __builtin_amdgcn_sched_barrier(0)
-      ICS_GMF(0); tr_z(0); ICS_GFN;
-      ICS_GMF(1); tr_z(4); ICS_GFN;
-      ICS_GMF(2); tr_z(8); ICS_GFN;
-      ICS_GMF(3); tr_z(12); ICS_GFN;
-      ICS_GMF(4); tr_y(0); ICS_GFN;
-      ICS_GMF(5); tr_y(1); ICS_GFN;
-      ICS_GMF(6); tr_y(2); ICS_GFN;
-      ICS_GMF(7); tr_y(3); ICS_GFN;
-      ICS_GMF(8); tr_x(0, un); ICS_GFN;
-      ICS_GMF(9); tr_x(1, un); ICS_GFN;
-      ICS_GMF(10); tr_x(2, un); ICS_GFN;
-      ICS_GMF(11); tr_x(3, un); ICS_GFN;
-      ICS_GMF(12); tr_dz(); tr_dy(); ICS_GFN;
-      ICS_GMF(13); tr_dx(0, vn); tr_dx(1, vn); ICS_GFN;
-      ICS_GMF(14); tr_dx(2, vn); tr_dx(3, vn); ICS_GFN;
-      ICS_GMF(15); ICS_GFN;
+      ICS_GMF(0); tr_y(0); ICS_GFN;
+      ICS_GMF(4); tr_y(1); ICS_GFN;
+      ICS_GMF(1); tr_d(); ICS_GFN;
+      ICS_GMF(5); ICS_GFN;
+      ICS_GMF(2); ICS_GFN;
+      ICS_GMF(6); ICS_GFN;
+      ICS_GMF(3); ICS_GFN;
+      ICS_GMF(7); ICS_GFN;
 #undef ICS_GMF
+      // measured (ms of this kernel per U-Net step): these 24 ops interleaved with the MFMAs above 10.35, the whole
+      // transform as a burst here 10.34, this split 9.8: the burst runs under the other wave's MFMAs
+      tr_x(t0, un); tr_x(t1, un + 4); tr_v(rl, vn); tr_v(rh, vn + 4);
       // raw reads two steps ahead: step p+2 of this block, or step (p+2)-8 of the next one
       if (p < 6) rd(cur, p + 2); else rd(nxt, p - 6);
       if (p == 5) {                                      // every read of `cur` is issued: the next block becomes visible
@@ -557,8 +542,6 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(const float* __res
       }
       ICS_GFN;
 #undef ICS_GFN
-#pragma unroll
-      for (int f = 0; f < 16; ++f) { u[f] = un[f]; vv[f] = vn[f]; }
     }
   };
   for (int blk = blk_lo; blk < blk_hi; blk += 2) {
@@ -567,49 +550,54 @@ __global__ __launch_bounds__(256) void conv_wino_wgrad_kernel(const float* __res
   }
 
   // ---------------------------------------------------------------- epilogue: G^T contraction, signs of the f = 3 rows
-  float* part = lds;                                     // [4 w][9 (b,c)][8 r][64 lanes]   (73 728 B per pass)
+  // in registers: fx -> c and this wave's share of fy -> b;  part[w 8][9 (b,c)][4 rr][64 lanes]  (73 728 B per pass)
+  float* part = lds;
   float* wsp = ws + (size_t)split * 27 * Cin * Cout;
 #pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
+  for (int pass = 0; pass < 4; ++pass) {
     __syncthreads();
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-      const int r = pass * 8 + rr;
-      float yb[3][4];                                    // [b][fx]
+    for (int rr = 0; rr < 4; ++rr) {
+      const int r = pass * 4 + rr;
+      float yc[2][3];                                    // [fy local][c]
 #pragma unroll
-      for (int fx = 0; fx < 4; ++fx) {
-        const float X0 = acc[0 * 4 + fx][r], X1 = acc[1 * 4 + fx][r], X2 = acc[2 * 4 + fx][r], X3 = acc[3 * 4 + fx][r];
+      for (int fy = 0; fy < 2; ++fy) {
+        const float X0 = acc[fy * 4 + 0][r], X1 = acc[fy * 4 + 1][r], X2 = acc[fy * 4 + 2][r], X3 = acc[fy * 4 + 3][r];
         const float h1 = 0.5f * (X1 + X2), h2 = 0.5f * (X1 - X2);
-        yb[0][fx] = X0 + h1; yb[1][fx] = h2; yb[2][fx] = h1 - X3;
+        yc[fy][0] = X0 + h1; yc[fy][1] = h2; yc[fy][2] = h1 - X3;
       }
 #pragma unroll
-      for (int bb = 0; bb < 3; ++bb) {
-        const float X0 = yb[bb][0], X1 = yb[bb][1], X2 = yb[bb][2], X3 = yb[bb][3];
-        const float h1 = 0.5f * (X1 + X2), h2 = 0.5f * (X1 - X2);
-        part[((w * 9 + bb * 3 + 0) * 8 + rr) * 64 + lane] = X0 + h1;
-        part[((w * 9 + bb * 3 + 1) * 8 + rr) * 64 + lane] = h2;
-        part[((w * 9 + bb * 3 + 2) * 8 + rr) * 64 + lane] = h1 - X3;
+      for (int cc = 0; cc < 3; ++cc) {
+        // rows of G^T over fy: b0 = Y0 + (Y1 + Y2)/2, b1 = (Y1 - Y2)/2, b2 = (Y1 + Y2)/2 - Y3'
+        const float lo = yc[0][cc], hi = yc[1][cc];      // fyh = 0: (Y0, Y1); fyh = 1: (Y2, Y3')
+        const float v0 = fyh ? 0.5f * lo : lo + 0.5f * hi;
+        const float v1 = fyh ? -0.5f * lo : 0.5f * hi;
+        const float v2 = fyh ? 0.5f * lo - hi : 0.5f * hi;
+        part[((w * 9 + 0 * 3 + cc) * 4 + rr) * 64 + lane] = v0;
+        part[((w * 9 + 1 * 3 + cc) * 4 + rr) * 64 + lane] = v1;
+        part[((w * 9 + 2 * 3 + cc) * 4 + rr) * 64 + lane] = v2;
       }
     }
     __syncthreads();
-    // task = ((bc * 8 + rr) * 2 + hh) * 8 + quad: 1152 per pass; each gives the three taps a = 0,1,2 as float4
+    // task = ((bc * 4 + rr) * 2 + hh) * 8 + quad: 576 per pass; each gives the three taps a = 0,1,2 as float4
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const int task = tid + 256 * i;
-      if (task < 1152) {
-        const int quad = task & 7, hh = (task >> 3) & 1, rr = (task >> 4) & 7, bc = task >> 7;
-        const int r = pass * 8 + rr;
+    for (int i = 0; i < 2; ++i) {
+      const int task = tid + 512 * i;
+      if (task < 576) {
+        const int quad = task & 7, hh = (task >> 3) & 1, rr = (task >> 4) & 3, bc = task >> 6;
+        const int r = pass * 4 + rr;
         const int row = (r >> 2) * 8 + hh * 4 + (r & 3);
-        const int slot = (bc * 8 + rr) * 64 + hh * 32 + 4 * quad;
-        const wf4 p0 = *reinterpret_cast<const wf4*>(&part[0 * 4608 + slot]);
-        const wf4 p1 = *reinterpret_cast<const wf4*>(&part[1 * 4608 + slot]);
-        const wf4 p2 = *reinterpret_cast<const wf4*>(&part[2 * 4608 + slot]);
-        const wf4 p3 = *reinterpret_cast<const wf4*>(&part[3 * 4608 + slot]);
-        const wf4 h1 = 0.5f * (p1 + p2), h2 = 0.5f * (p1 - p2);
+        const int slot = (bc * 4 + rr) * 64 + hh * 32 + 4 * quad;
+        wf4 pz[4];
+#pragma unroll
+        for (int z = 0; z < 4; ++z)
+          pz[z] = *reinterpret_cast<const wf4*>(&part[(2 * z) * 2304 + slot]) +
+                  *reinterpret_cast<const wf4*>(&part[(2 * z + 1) * 2304 + slot]);
+        const wf4 h1 = 0.5f * (pz[1] + pz[2]), h2 = 0.5f * (pz[1] - pz[2]);
         float* o = wsp + ((size_t)(bc)*Cin + ci0 + row) * Cout + co0 + 4 * quad;   // tap = a*9 + bc
-        *reinterpret_cast<wf4*>(o) = p0 + h1;
+        *reinterpret_cast<wf4*>(o) = pz[0] + h1;
         *reinterpret_cast<wf4*>(o + (size_t)9 * Cin * Cout) = h2;
-        *reinterpret_cast<wf4*>(o + (size_t)18 * Cin * Cout) = h1 - p3;
+        *reinterpret_cast<wf4*>(o + (size_t)18 * Cin * Cout) = h1 - pz[3];
       }
     }
   }
@@ -693,8 +681,8 @@ int launch_conv_wgrad_wino(hipStream_t st, const ConvGeom& g, const ConvSrc& s0,
     const float in_slope = wslope(s0.act);
 #define ICS_WG_LAUNCH(AFFV, NOACTV)                                                                                   \
   do {                                                                                                                \
-    hipLaunchKernelGGL((conv_wino_wgrad_kernel<AFFV, NOACTV>), dim3(grid), dim3(256), 0, st, s0.p, s0.C, s0.scale,    \
-                       s0.shift, in_slope, dy, ldy, ws, zeros, g.S, g.Cin, g.Cout, nblocks, per_split);               \
+    hipLaunchKernelGGL((conv_wino_wgrad_kernel<AFFV, NOACTV>), dim3(grid), dim3(512), 0, st, s0.p, s0.C, s0.scale,    \
+                       s0.shift, in_slope, dy, ldy, ws, g.S, g.Cin, g.Cout, per_split);                               \
     conv_set_last_kernel_id("conv_wino_wgrad_kernel<" #AFFV ", " #NOACTV ">");                                        \
   } while (0)
     if (!aff) ICS_WG_LAUNCH(false, true);
