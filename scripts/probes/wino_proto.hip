@@ -1091,10 +1091,19 @@ __global__ __launch_bounds__(512) void wino_fwd7(const float* __restrict__ x, co
         if (!(EXP & 1)) __builtin_amdgcn_sched_barrier(0);
 #define MF7(F, C) acc[F] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[F].C, wreg[F].C, acc[F], 0, 0, 0)
 #define FN7 if (!(EXP & 1)) __builtin_amdgcn_sched_barrier(0)
-        MF7(g, x); tn[0][g] = a - bq; FN7;
-        MF7(4 + g, x); tn[1][g] = bq + sg * c; FN7;
-        MF7(g, y); FN7;
-        MF7(4 + g, y); FN7;
+        if (EXP & 2) {          // colmath as a burst after the group's MFMAs
+          MF7(g, x); FN7; MF7(4 + g, x); FN7; MF7(g, y); FN7; MF7(4 + g, y); FN7;
+          tn[0][g] = a - bq; tn[1][g] = bq + sg * c;
+        } else if (EXP & 4) {   // colmath after MFMAs 2 and 3
+          MF7(g, x); FN7; MF7(4 + g, x); FN7;
+          MF7(g, y); tn[0][g] = a - bq; FN7;
+          MF7(4 + g, y); tn[1][g] = bq + sg * c; FN7;
+        } else {
+          MF7(g, x); tn[0][g] = a - bq; FN7;
+          MF7(4 + g, x); tn[1][g] = bq + sg * c; FN7;
+          MF7(g, y); FN7;
+          MF7(4 + g, y); FN7;
+        }
         wreg[g] = *reinterpret_cast<const f2*>(wn + g * wstride_f + wlane);
         wreg[4 + g] = *reinterpret_cast<const f2*>(wn + (4 + g) * wstride_f + wlane);
         FN7;
@@ -1209,7 +1218,7 @@ int main(int argc, char** argv) {
       if (ex == 0) L3(0); else if (ex == 1) L3(2); else if (ex == 2) L3(4); else if (ex == 3) L3(6); else if (ex == 4) L3(8);
       else if (ex == 5) L3(10); else if (ex == 6) L3(12); else L3(14);
     }
-    else if (variant == 7) { if (flags & 1) hipLaunchKernelGGL((wino_fwd7<1>), dim3(grid), dim3(512), 0, 0, dx, dwt, dy, S, Cin, Cout); else hipLaunchKernelGGL((wino_fwd7<0>), dim3(grid), dim3(512), 0, 0, dx, dwt, dy, S, Cin, Cout); }
+    else if (variant == 7) { if (flags == 1) hipLaunchKernelGGL((wino_fwd7<1>), dim3(grid), dim3(512), 0, 0, dx, dwt, dy, S, Cin, Cout); else if (flags == 2) hipLaunchKernelGGL((wino_fwd7<2>), dim3(grid), dim3(512), 0, 0, dx, dwt, dy, S, Cin, Cout); else if (flags == 4) hipLaunchKernelGGL((wino_fwd7<4>), dim3(grid), dim3(512), 0, 0, dx, dwt, dy, S, Cin, Cout); else hipLaunchKernelGGL((wino_fwd7<0>), dim3(grid), dim3(512), 0, 0, dx, dwt, dy, S, Cin, Cout); }
     else if (variant == 6) hipLaunchKernelGGL((wino_fwd6<0>), dim3(grid), dim3(256), 0, 0, dx, dwt, dy, S, Cin, Cout);
     else if (variant == 4) hipLaunchKernelGGL((wino_fwd4<0, 0>), dim3(grid), dim3(256), 0, 0, dx, dwt, dz, dy, S, Cin, Cout);
     else if (variant == 5) {
