@@ -172,7 +172,8 @@ int launch_pack_bwd(hipStream_t st, const float* w, int taps, int Cin, int Cout,
 bool conv_wino_ok(const ConvGeom& g, const ConvSrc* src, int nsrc);
 size_t conv_wino_weight_floats(int Cin, int Cout);
 int launch_conv_fwd_wino(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, const float* wt, const float* bias,
-                         float* out, int ldo, int pre_act, float* stat_partial, int* rows_per_block, int accumulate);
+                         float* out, int ldo, int pre_act, float* stat_partial, int* rows_per_block, int accumulate,
+                         const BwdStat* bwd = nullptr, int* bwd_blocks = nullptr);   // bwd / bwd_blocks: as launch_conv_fwd
 // dst[Nn/32][K/4][64 f][2][32][2] = (G (x) G (x) G) applied to the 27 taps of
 //   bwd = 0: w[tap][c_off + k][n]          (forward: K = Csub input channels of Cin_total, Nn = Cout)
 //   bwd = 1: w[26 - tap][c_off + n][k]     (backward-data: K = Cout, Nn = Csub input channels)

@@ -47,14 +47,16 @@ __host__ __device__ __forceinline__ float wslope(int act) { return act == ACT_RE
 
 // wt layout: [Cout/32][Cin/4][64 f][2 h][32 n][2 j]   (input channel = c4*4 + h*2 + j)
 // AFF: the source carries a per-channel affine (+ activation of slope in_slope); NOACT: affine only.
-template <bool AFF, bool NOACT>
+// FOLD (backward-data launches): the tile just produced is dO of the producer layer P; the block also adds its share of
+// P's BatchNorm-backward sums (BwdStat, common.h) -- the pass bn_bwd_reduce_kernel would otherwise make over dO and s.
+template <bool AFF, bool NOACT, bool FOLD>
 __global__ __launch_bounds__(512) void conv_wino_kernel(const float* __restrict__ x, int ldx,
                                                         const float* __restrict__ in_scale,
                                                         const float* __restrict__ in_shift, float in_slope,
                                                         const float* __restrict__ wt, const float* __restrict__ bias,
                                                         float* __restrict__ y, int ldo, float pre_slope, int accumulate,
                                                         float* __restrict__ stat_partial, int Npad, int S, int Cin,
-                                                        int Cout) {
+                                                        int Cout, BwdStat bs) {
   __shared__ __attribute__((aligned(16))) float lds[2 * BUF3];   // 115 200 B; the epilogue reuses it
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -237,6 +239,16 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const float* __restrict_
   if (bias != nullptr) bv = *reinterpret_cast<const wf4*>(bias + n0 + 4 * k);
   wf4 val[4];
   wf4 csum = {0.f, 0.f, 0.f, 0.f};
+  wf4 f1 = {0.f, 0.f, 0.f, 0.f}, f2s = {0.f, 0.f, 0.f, 0.f};    // FOLD: sum d, sum d * xhat of this thread's 4 columns
+  wf4 b_mu = f1, b_rs = f1, b_sc = {1.f, 1.f, 1.f, 1.f}, b_sh = f1;
+  if (FOLD) {
+    b_mu = *reinterpret_cast<const wf4*>(bs.mean + n0 + 4 * k);
+    b_rs = *reinterpret_cast<const wf4*>(bs.rstd + n0 + 4 * k);
+    if (bs.post_act != ACT_NONE) {
+      b_sc = *reinterpret_cast<const wf4*>(bs.scale + n0 + 4 * k);
+      b_sh = *reinterpret_cast<const wf4*>(bs.shift + n0 + 4 * k);
+    }
+  }
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     __syncthreads();
@@ -285,12 +297,23 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const float* __restrict_
     *reinterpret_cast<wf4*>(y + o1) = e1;
     val[2 * pass] = e0; val[2 * pass + 1] = e1;
     csum += e0 + e1;
+    if (FOLD) {
+      const size_t s0 = ((((size_t)b * S + vz) * S + vy) * S + vx) * bs.ld + n0 + 4 * k;
+      const wf4 sv0 = *reinterpret_cast<const wf4*>(bs.s + s0);
+      const wf4 sv1 = *reinterpret_cast<const wf4*>(bs.s + s0 + (size_t)S * S * bs.ld);
+      wf4 d0 = e0, d1 = e1;
+      if (bs.post_act != ACT_NONE) {
+        const wf4 z0 = sv0 * b_sc + b_sh, z1 = sv1 * b_sc + b_sh;
+        d0.x *= act_grad(z0.x, bs.post_act); d0.y *= act_grad(z0.y, bs.post_act);
+        d0.z *= act_grad(z0.z, bs.post_act); d0.w *= act_grad(z0.w, bs.post_act);
+        d1.x *= act_grad(z1.x, bs.post_act); d1.y *= act_grad(z1.y, bs.post_act);
+        d1.z *= act_grad(z1.z, bs.post_act); d1.w *= act_grad(z1.w, bs.post_act);
+      }
+      f1 += d0 + d1;
+      f2s += d0 * ((sv0 - b_mu) * b_rs) + d1 * ((sv1 - b_mu) * b_rs);
+    }
   }
-  if (stat_partial == nullptr) return;
-
-  // block-level (count, mean, M2) per column, two passes inside the block (conv_igemm.hip's layout
-  // [3][Npad][nblocks], block index fastest).  Columns 4k..4k+3 live in the lanes with the same (tid & 7).
-  auto colreduce = [&](wf4 v) -> wf4 {
+  auto colreduce = [&](wf4 v) -> wf4 {             // columns 4k..4k+3 live in the lanes with the same (tid & 7)
 #pragma unroll
     for (int d = 8; d < 64; d <<= 1) {
       v.x += __shfl_xor(v.x, d); v.y += __shfl_xor(v.y, d); v.z += __shfl_xor(v.z, d); v.w += __shfl_xor(v.w, d);
@@ -298,11 +321,34 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const float* __restrict_
     return v;
   };
   auto sum8 = [&](int i) {
-    float s = 0.f;
+    float sacc = 0.f;
 #pragma unroll
-    for (int ww = 0; ww < 8; ++ww) s += red[ww * 32 + i];
-    return s;
+    for (int ww = 0; ww < 8; ++ww) sacc += red[ww * 32 + i];
+    return sacc;
   };
+  if (FOLD) {                                      // [2][Npad][blocks] (block index fastest), as conv_igemm.hip's FOLD
+    f1 = colreduce(f1); f2s = colreduce(f2s);
+    __syncthreads();
+    if (lane < 8) {
+      *reinterpret_cast<wf4*>(&red[w * 32 + 4 * lane]) = f1;
+      *reinterpret_cast<wf4*>(&red[512 + w * 32 + 4 * lane]) = f2s;
+    }
+    __syncthreads();
+    if (tid < 32) {
+      const size_t nstat = gridDim.x / nchunks;
+      float a2 = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < 8; ++ww) a2 += red[512 + ww * 32 + tid];
+      float* sp = bs.partial + (size_t)(n0 + tid) * nstat + tblk;
+      sp[0] = sum8(tid);
+      sp[(size_t)Npad * nstat] = a2;
+    }
+    return;
+  }
+  if (stat_partial == nullptr) return;
+
+  // block-level (count, mean, M2) per column, two passes inside the block (conv_igemm.hip's layout
+  // [3][Npad][nblocks], block index fastest)
   csum = colreduce(csum);
   __syncthreads();
   if (lane < 8) *reinterpret_cast<wf4*>(&red[w * 32 + 4 * lane]) = csum;
@@ -617,7 +663,8 @@ size_t conv_wino_weight_floats(int Cin, int Cout) { return (size_t)64 * Cin * Co
 int conv_wino_rows_per_block() { return kRowsPerBlock; }
 
 int launch_conv_fwd_wino(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, const float* wt, const float* bias,
-                         float* out, int ldo, int pre_act, float* stat_partial, int* rows_per_block, int accumulate) {
+                         float* out, int ldo, int pre_act, float* stat_partial, int* rows_per_block, int accumulate,
+                         const BwdStat* bwd, int* bwd_blocks) {
   ICS_CHECK(conv_wino_ok(g, &s0, 1), "shape not served by the Winograd kernel");
   ICS_CHECK(ldo % 4 == 0, "Winograd epilogue stores float4");
   const unsigned grid = (unsigned)(g.B * (g.S / 4) * (g.S / 8) * (g.S / 8) * (g.Cout / 32));
@@ -625,16 +672,23 @@ int launch_conv_fwd_wino(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, c
   const bool aff = s0.scale != nullptr;
   const bool noact = s0.act == ACT_NONE;
   const float in_slope = wslope(s0.act), pre_slope = wslope(pre_act);
-#define ICS_WINO_LAUNCH(AFFV, NOACTV)                                                                               \
+  // the folded BatchNorm-backward sums: plain backward-data launches only (no source affine, no statistics, no
+  // activation); the producer's tensors must be float4-addressable like the output
+  const bool fold = bwd != nullptr && bwd->partial != nullptr && !aff && stat_partial == nullptr && bias == nullptr &&
+                    pre_act == ACT_NONE && !accumulate && bwd->ld % 4 == 0;
+  if (bwd_blocks) *bwd_blocks = fold ? (int)(grid / (unsigned)(g.Cout / 32)) : 0;
+  const BwdStat bs = fold ? *bwd : BwdStat{};
+#define ICS_WINO_LAUNCH(AFFV, NOACTV, FOLDV)                                                                        \
   do {                                                                                                              \
-    hipLaunchKernelGGL((conv_wino_kernel<AFFV, NOACTV>), dim3(grid), dim3(512), 0, st, s0.p, s0.C, s0.scale,        \
+    hipLaunchKernelGGL((conv_wino_kernel<AFFV, NOACTV, FOLDV>), dim3(grid), dim3(512), 0, st, s0.p, s0.C, s0.scale, \
                        s0.shift, in_slope, wt, bias, out, ldo, pre_slope, accumulate, stat_partial, g.Npad, g.S,    \
-                       g.Cin, g.Cout);                                                                              \
-    conv_set_last_kernel_id("conv_wino_kernel<" #AFFV ", " #NOACTV ">");                                            \
+                       g.Cin, g.Cout, bs);                                                                          \
+    conv_set_last_kernel_id("conv_wino_kernel<" #AFFV ", " #NOACTV ", " #FOLDV ">");                                \
   } while (0)
-  if (!aff) ICS_WINO_LAUNCH(false, true);
-  else if (noact) ICS_WINO_LAUNCH(true, true);
-  else ICS_WINO_LAUNCH(true, false);
+  if (fold) ICS_WINO_LAUNCH(false, true, true);
+  else if (!aff) ICS_WINO_LAUNCH(false, true, false);
+  else if (noact) ICS_WINO_LAUNCH(true, true, false);
+  else ICS_WINO_LAUNCH(true, false, false);
 #undef ICS_WINO_LAUNCH
   ICS_HIP(hipGetLastError());
   return 0;

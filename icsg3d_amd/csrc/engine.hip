@@ -803,8 +803,9 @@ static int conv_grads_from_dy(Net& n, ConvLayer& L, int B, bool need_dA, bool pa
                  4.0 * (M * L.Cin + M * L.Cout + (double)L.taps * L.Cin * L.Cout));
     const BwdStat bs = bwd_stat_for(n, next, B);
     int blocks = 0;
-    if (L.wwb && !L.split_up && conv_wino_ok(gb, &sdy, 1))   // the producer's BN-backward sums: separate pass
-      ICS_TRY(launch_conv_fwd_wino(n.st, gb, sdy, L.wwb, nullptr, L.dA, L.CinG, ACT_NONE, nullptr, nullptr, 0));
+    if (L.wwb && !L.split_up && conv_wino_ok(gb, &sdy, 1))
+      ICS_TRY(launch_conv_fwd_wino(n.st, gb, sdy, L.wwb, nullptr, L.dA, L.CinG, ACT_NONE, nullptr, nullptr, 0, &bs,
+                                   &blocks));
     else
     ICS_TRY(launch_conv_fwd(n.st, gb, &sdy, 1, L.wf, nullptr, L.dA, L.CinG, ACT_NONE, nullptr, nullptr, 0, n.fws(),
                             n.ws_fwd_n, &bs, &blocks));
