@@ -393,7 +393,10 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const float* __restrict_
 namespace {
 constexpr int GZ = 6, GY = 6, GX = 10;
 constexpr int GXP = 482, GYP = 130;                                        // floats per channel: 8 planes x 60 (+2), 128 (+2)
-constexpr int GXF = 32 * GXP, GYF = 32 * GYP, GBUF = GXF + GYF;            // one buffer: 78 336 B
+constexpr int GXF = 32 * GXP, GYF = 32 * GYP;                              // floats: x part 61 696 B, dy part 16 640 B
+// LDS = [x buffer 0][x buffer 1][dy buffer 0][dy buffer 1]: the second buffer of each part is < 64 KB from the first,
+// so both are immediate offsets of ONE base register (a per-buffer base costs 4 more VGPRs, and spilled bases are
+// reloaded through scratch behind the HBM-latency staging loads: 43 % of the wave cycles were such waits)
 }  // namespace
 
 template <bool AFF, bool NOACT>
@@ -403,7 +406,7 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(const float* __res
                                                               const float* __restrict__ dy, int ldy,
                                                               float* __restrict__ ws, int S, int Cin, int Cout,
                                                               int per_split) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * GBUF];      // 156 672 B
+  __shared__ __attribute__((aligned(16))) float lds[2 * (GXF + GYF)];      // 156 672 B
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fz = w >> 1, fyh = w & 1;
@@ -431,11 +434,6 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(const float* __res
   }
   const unsigned yxface = ((hy == 0) << 2) | ((hy == GY - 1) << 3) | ((hx == 0) << 4) | ((hx == GX - 1) << 5);
   const int xw = (q * 4) * GXP + hy * GX + hx;                             // LDS write base (floats): + j*GXP + plane*60
-  wf4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
-  if (AFF) {
-    sc4 = *reinterpret_cast<const wf4*>(in_scale + ci0 + q * 4);
-    sh4 = *reinterpret_cast<const wf4*>(in_shift + ci0 + q * 4);
-  }
   unsigned bface_cur = 0;
   auto gload = [&](int blk) {
     int t = blk;
@@ -463,9 +461,12 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(const float* __res
 #pragma unroll
     for (int i = 0; i < 2; ++i) ys[i] = *reinterpret_cast<const wf4*>(yb + yrel[i]);
   };
-  auto sstore = [&](const int bo) {
+  auto sstore = [&](const int bo) {            // bo: buffer index 0 / 1
     const unsigned bface = bface_cur;
     if (AFF) {
+      // reloaded per block (L1 hits): 8 registers less to keep live through the main loop
+      const wf4 sc4 = *reinterpret_cast<const wf4*>(in_scale + ci0 + q * 4);
+      const wf4 sh4 = *reinterpret_cast<const wf4*>(in_shift + ci0 + q * 4);
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
         wf4 t = xs[i];
@@ -488,14 +489,14 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(const float* __res
         const wf4 cz[4] = {d0 - d2, d1 + d2, d2 - d1, d1 - d3};
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
-          const int o = bo + xw + (tz * 4 + f) * 60;
+          const int o = bo * GXF + xw + (tz * 4 + f) * 60;
           lds[o] = cz[f].x; lds[o + GXP] = cz[f].y; lds[o + 2 * GXP] = cz[f].z; lds[o + 3 * GXP] = cz[f].w;
         }
       }
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int o = bo + GXF + ((tid & 7) * 4) * GYP + ((tid + i * 512) >> 3);
+      const int o = 2 * GXF + bo * GYF + ((tid & 7) * 4) * GYP + ((tid + i * 512) >> 3);
       lds[o] = ys[i].x; lds[o + GYP] = ys[i].y; lds[o + 2 * GYP] = ys[i].z; lds[o + 3 * GYP] = ys[i].w;
     }
   };
@@ -505,7 +506,7 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(const float* __res
   const float sg = fyh ? -1.f : 1.f;
   const int xbase = c * GXP + fz * 60 + 2 * hl;
   const int XA = xbase + (fyh ? 2 : 0) * GX, XB = xbase + (fyh ? 1 : 2) * GX, XC = xbase + (fyh ? 3 : 1) * GX;
-  const int YB = GXF + c * GYP + 2 * hl;
+  const int YB = 2 * GXF + c * GYP + 2 * hl;
   const float ca = (fz == 3) ? 0.f : 1.f, cb = (fz == 0) ? 0.f : (fz == 2 ? -1.f : 1.f);   // fz = 3 un-negated
   const float a1 = fyh ? -1.f : 0.f, b0 = fyh ? 0.f : 1.f;   // rlo = g0 + a1 g1, rhi = b0 g0 + g1 (fy = 3 un-negated)
 
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(const float* __res
   wf2 e0[2], e1[2];                    // dy: z = 2tz / 2tz+1, [dyy] = (dx0, dx1)
   auto rd = [&](const int bo, const int p) {
     const int tz = p >> 2, ty = (p >> 1) & 1, txp = p & 1;
-    const int ox = bo + tz * 240 + (2 * ty) * GX + 4 * txp;
+    const int ox = bo * GXF + tz * 240 + (2 * ty) * GX + 4 * txp;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       xa[j] = *reinterpret_cast<const wf2*>(&lds[XA + ox + 2 * j]);
@@ -529,7 +530,7 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(const float* __res
     }
 #pragma unroll
     for (int d = 0; d < 2; ++d) {
-      const int oy = bo + ((2 * tz) * 4 + 2 * ty + d) * 8 + 4 * txp;
+      const int oy = bo * GYF + ((2 * tz) * 4 + 2 * ty + d) * 8 + 4 * txp;
       e0[d] = *reinterpret_cast<const wf2*>(&lds[YB + oy]);
       e1[d] = *reinterpret_cast<const wf2*>(&lds[YB + oy + 32]);
     }
@@ -580,19 +581,19 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(const float* __res
       // measured (ms of this kernel per U-Net step): these 24 ops interleaved with the MFMAs above 10.35, the whole
       // transform as a burst here 10.34, this split 9.8: the burst runs under the other wave's MFMAs
       tr_x(t0, un); tr_x(t1, un + 4); tr_v(rl, vn); tr_v(rh, vn + 4);
-      // raw reads two steps ahead: step p+2 of this block, or step (p+2)-8 of the next one
+      // raw reads two steps ahead: step p+2 of this block, or step (p+2)-8 of the next one.  At p == 5 the next block
+      // is stored first (its arithmetic then runs without the raw-read registers live), and the barrier after BOTH:
+      // every read of `cur` is issued before it, the next block is visible before step 6 reads its step 0
+      if (p == 5) sstore(nxt);
       if (p < 6) rd(cur, p + 2); else rd(nxt, p - 6);
-      if (p == 5) {                                      // every read of `cur` is issued: the next block becomes visible
-        sstore(nxt);                                     // before step 6 reads its step 0
-        __syncthreads();
-      }
+      if (p == 5) __syncthreads();
       ICS_GFN;
 #undef ICS_GFN
     }
   };
   for (int blk = blk_lo; blk < blk_hi; blk += 2) {
-    block(blk, 0, GBUF);
-    block(blk + 1, GBUF, 0);
+    block(blk, 0, 1);
+    block(blk + 1, 1, 0);
   }
 
   // ---------------------------------------------------------------- epilogue: G^T contraction, signs of the f = 3 rows
