@@ -227,6 +227,8 @@ def main():
                 "config": {"workload": "AtomUnet fwd+bwd+Adam train step, %d x %d^3 x 1 grids per GPU "
                                        "(BASELINE.json configs[1]), Glorot weights PCG64(1)" % (B, d),
                            "global_batch": world * B, "grid": d, "parallelism": "dp%d" % world,
+                           "conv": "3x3x3 layers: Winograd F(2x2x2,3x3x3) on fp32 MFMA (fwd, bwd-data, bwd-weight); "
+                                   "upsampled channels: 8-tap parity GEMMs on the coarse grid; rest: 27-tap implicit GEMM",
                            "bn": "sync (global-batch statistics)" if args.sync_bn and use_dist
                                  else "local per-replica batch statistics, moving statistics averaged over ranks",
                            "grad_allreduce": ("%d RCCL buckets per step on a second stream, overlapped with the "
