@@ -178,13 +178,11 @@ int launch_conv_fwd_wino(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, c
 //   bwd = 0: w[tap][c_off + k][n]          (forward: K = Csub input channels of Cin_total, Nn = Cout)
 //   bwd = 1: w[26 - tap][c_off + n][k]     (backward-data: K = Cout, Nn = Csub input channels)
 int launch_pack_wino(hipStream_t st, const float* w, int Cin_total, int Cout, int c_off, int Csub, int bwd, float* dst);
-// backward-weight in the Winograd domain; workspace / sub_rows / row_pitch / row_off / phase as launch_conv_wgrad;
-// zeros: >= 16 bytes of device zeros (halo voxels outside the grid are read from there)
+// backward-weight in the Winograd domain; workspace / sub_rows / row_pitch / row_off / phase as launch_conv_wgrad
 bool conv_wino_wgrad_ok(const ConvGeom& g, const ConvSrc* src, int nsrc);
 size_t conv_wino_wgrad_workspace_floats(const ConvGeom& g);
 int launch_conv_wgrad_wino(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, const float* dy, int ldy, float* dw,
-                           int ldw, float* ws, size_t ws_floats, int sub_rows, int row_pitch, int row_off, int phase,
-                           const float* zeros);
+                           int ldw, float* ws, size_t ws_floats, int sub_rows, int row_pitch, int row_off, int phase);
 // fixed-order reduction of split-K weight-gradient partials ws[split][k][n] into dw (conv_igemm.hip)
 int launch_wgrad_reduce_splits(hipStream_t st, const float* ws, int nsplit, size_t n_elems, int N, float* dw, int ldw,
                                int sub_rows, int row_pitch, int row_off);

@@ -661,7 +661,6 @@ bool conv_wino_ok(const ConvGeom& g, const ConvSrc* src, int nsrc) {
   return true;
 }
 size_t conv_wino_weight_floats(int Cin, int Cout) { return (size_t)64 * Cin * Cout; }
-int conv_wino_rows_per_block() { return kRowsPerBlock; }
 
 int launch_conv_fwd_wino(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, const float* wt, const float* bias,
                          float* out, int ldo, int pre_act, float* stat_partial, int* rows_per_block, int accumulate,
@@ -723,8 +722,7 @@ bool conv_wino_wgrad_ok(const ConvGeom& g, const ConvSrc* src, int nsrc) {
   return true;
 }
 int launch_conv_wgrad_wino(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, const float* dy, int ldy, float* dw,
-                           int ldw, float* ws, size_t ws_floats, int sub_rows, int row_pitch, int row_off, int phase,
-                           const float* zeros) {
+                           int ldw, float* ws, size_t ws_floats, int sub_rows, int row_pitch, int row_off, int phase) {
   ICS_CHECK(conv_wino_wgrad_ok(g, &s0, 1), "shape not served by the Winograd backward-weight kernel");
   const int per_split = wino_wgrad_per_split(g, ws_floats);
   ICS_CHECK(per_split >= 2, "wgrad workspace too small");

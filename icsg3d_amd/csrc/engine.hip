@@ -137,7 +137,6 @@ struct ConvLayer {
 };
 
 struct Net {
-  float* zero_page = nullptr;           // device zeros: out-of-grid halo reads of the Winograd backward-weight kernel
   int kind = 0;   // 0 U-Net, 1 VAE
   int device = 0;
   int flags = 0;  // ConvFlags, read from the environment when the handle is created
@@ -407,7 +406,6 @@ static int enable_wino(Net& n, ConvLayer& L, bool need_bwd) {
   if (need_bwd && conv_wino_ok(geom_wino_bwd(L, n.maxB), &sdy, 1))
     ICS_TRY(n.alloc(&L.wwb, conv_wino_weight_floats(K, L.Cout)));
   L.wino_w = need_bwd && conv_wino_wgrad_ok(L.split_up ? geom_skip_wgrad(L, n.maxB) : geom_fwd(L, n.maxB), L.src, 1);
-  if (L.wino_w && !n.zero_page) ICS_TRY(n.alloc(&n.zero_page, (size_t)256));
   return 0;
 }
 
@@ -689,7 +687,7 @@ static int conv_grads_split_up(Net& n, ConvLayer& L, int B, ConvLayer* next) {
     const bool wino = L.wino_w && conv_wino_wgrad_ok(g, L.src, 1);
     if (wino)
       ICS_TRY(launch_conv_wgrad_wino(ws, g, L.src[0], L.dy, L.Cout, n.tg(L.t_w), L.Cout, n.ws_wgrad, n.ws_wgrad_n,
-                                     L.Cs, L.Cin, 0, 1, n.zero_page));
+                                     L.Cs, L.Cin, 0, 1));
     else
     ICS_TRY(launch_conv_wgrad(ws, g, L.src, 1, L.dy, L.Cout, n.tg(L.t_w), L.Cout, n.ws_wgrad, n.ws_wgrad_n, L.Cs,
                               L.Cin, 0, 1));
@@ -697,7 +695,7 @@ static int conv_grads_split_up(Net& n, ConvLayer& L, int B, ConvLayer* next) {
     n.prof.begin(ws, "wgrad_reduce_splits", 0, 0);
     if (wino)
       ICS_TRY(launch_conv_wgrad_wino(ws, g, L.src[0], L.dy, L.Cout, n.tg(L.t_w), L.Cout, n.ws_wgrad, n.ws_wgrad_n,
-                                     L.Cs, L.Cin, 0, 2, n.zero_page));
+                                     L.Cs, L.Cin, 0, 2));
     else
     ICS_TRY(launch_conv_wgrad(ws, g, L.src, 1, L.dy, L.Cout, n.tg(L.t_w), L.Cout, n.ws_wgrad, n.ws_wgrad_n, L.Cs,
                               L.Cin, 0, 2));
@@ -774,12 +772,10 @@ static int conv_grads_from_dy(Net& n, ConvLayer& L, int B, bool need_dA, bool pa
                                        n.ws_wgrad_n, 2));
       n.prof.end(ws);
     } else if (L.wino_w && !L.split_up && conv_wino_wgrad_ok(g, L.src, L.nsrc)) {
-      ICS_TRY(launch_conv_wgrad_wino(ws, g, L.src[0], L.dy, L.Cout, dw, L.Cout, n.ws_wgrad, n.ws_wgrad_n, 0, 0, 0, 1,
-                                     n.zero_page));
+      ICS_TRY(launch_conv_wgrad_wino(ws, g, L.src[0], L.dy, L.Cout, dw, L.Cout, n.ws_wgrad, n.ws_wgrad_n, 0, 0, 0, 1));
       n.prof.end(ws);
       n.prof.begin(ws, "wgrad_reduce_splits", 0, 0);
-      ICS_TRY(launch_conv_wgrad_wino(ws, g, L.src[0], L.dy, L.Cout, dw, L.Cout, n.ws_wgrad, n.ws_wgrad_n, 0, 0, 0, 2,
-                                     n.zero_page));
+      ICS_TRY(launch_conv_wgrad_wino(ws, g, L.src[0], L.dy, L.Cout, dw, L.Cout, n.ws_wgrad, n.ws_wgrad_n, 0, 0, 0, 2));
       n.prof.end(ws);
     } else {
     ICS_TRY(launch_conv_wgrad(ws, g, L.src, L.nsrc, L.dy, L.Cout, dw, L.Cout, n.ws_wgrad, n.ws_wgrad_n, 0, 0, 0, 1));
@@ -2128,9 +2124,7 @@ int ics_op_conv3d_backward(const float* x, const float* w, const float* dy, int 
   ICS_TRY(n.alloc(&ws, wsn + 16));
   if (dwo) {
     if (wino_w) {
-      float* zeros = nullptr;
-      ICS_TRY(n.alloc(&zeros, (size_t)256));
-      ICS_TRY(launch_conv_wgrad_wino(n.st, g, s, ddy, Cout, dgw, Cout, ws, wsn, 0, 0, 0, 0, zeros));
+      ICS_TRY(launch_conv_wgrad_wino(n.st, g, s, ddy, Cout, dgw, Cout, ws, wsn, 0, 0, 0, 0));
     } else
     ICS_TRY(launch_conv_wgrad(n.st, g, &s, 1, ddy, Cout, dgw, Cout, ws, wsn));
     ICS_HIP(hipMemcpyAsync(dwo, dgw, (size_t)taps * Cin * Cout * 4, hipMemcpyDeviceToHost, n.st));
