@@ -666,7 +666,9 @@ int launch_conv_fwd_wino(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, c
                          float* out, int ldo, int pre_act, float* stat_partial, int* rows_per_block, int accumulate,
                          const BwdStat* bwd, int* bwd_blocks) {
   ICS_CHECK(conv_wino_ok(g, &s0, 1), "shape not served by the Winograd kernel");
-  ICS_CHECK(ldo % 4 == 0, "Winograd epilogue stores float4");
+  ICS_CHECK(ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
+                (reinterpret_cast<uintptr_t>(bias) & 15) == 0 && (reinterpret_cast<uintptr_t>(s0.p) & 15) == 0,
+            "Winograd kernel: float4 accesses need 16-byte aligned tensors");
   const unsigned grid = (unsigned)(g.B * (g.S / 4) * (g.S / 8) * (g.S / 8) * (g.Cout / 32));
   if (rows_per_block) *rows_per_block = kRowsPerBlock;
   const bool aff = s0.scale != nullptr;
