@@ -412,9 +412,14 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(const float* __res
   const int fz = w >> 1, fyh = w & 1;
   const int c = lane & 31, hl = lane >> 5;
   const int nco = Cout >> 5, nci = Cin >> 5;
-  const int cob = blockIdx.x % nco;
-  const int cib = (blockIdx.x / nco) % nci;
-  const int split = blockIdx.x / (nco * nci);
+  // workgroups are dispatched round-robin over the 8 XCDs: give every XCD whole splits, so that the nci x nco
+  // workgroups that read the same tiles (different channel chunks) share one L2
+  int lin = blockIdx.x;
+  const int npairs = nco * nci, nsplit = gridDim.x / npairs;
+  if ((nsplit & 7) == 0) lin = ((blockIdx.x >> 3) / npairs * 8 + (blockIdx.x & 7)) * npairs + (blockIdx.x >> 3) % npairs;
+  const int cob = lin % nco;
+  const int cib = (lin / nco) % nci;
+  const int split = lin / npairs;
   const int ci0 = cib * 32, co0 = cob * 32;
   const int blk_lo = split * per_split, blk_hi = blk_lo + per_split;
   const int nbx = S >> 3, nby = S >> 2, nbz = S >> 2;
