@@ -1116,6 +1116,27 @@ __global__ __launch_bounds__(512) void wino_fwd7(const float* __restrict__ x, co
     chunk(ch + 1, BUF7, 0);
   }
 
+  // EXP & 32: while the epilogue runs, pull the first chunk of the tile block this CU will most likely get next
+  // (blockIdx + 256: same XCD) into L2 with LDS-DMA loads into a dead LDS region
+  if (EXP & 32) {
+    const int tbn = (int)(blockIdx.x + 256) / nchunks;
+    const int total_tb = (int)gridDim.x / nchunks;
+    if (tbn < total_tb) {
+      int t2 = tbn;
+      const int bx2 = t2 % nbx; t2 /= nbx;
+      const int by2 = t2 % nby; t2 /= nby;
+      const int bz2 = t2 % nbz;
+      const int b2 = t2 / nbz;
+      const int gy = min(max(by2 * 8 - 1 + hy, 0), S - 1), gx = min(max(bx2 * 8 - 1 + hx, 0), S - 1);
+#pragma unroll
+      for (int hz = 0; hz < 6; ++hz) {
+        const int gz = min(max(bz2 * 4 - 1 + hz, 0), S - 1);
+        const float* p = x + ((((size_t)b2 * S + gz) * S + gy) * S + gx) * Cin + q * 4;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                         (__attribute__((address_space(3))) void*)(lds + 20480 + w * 256), 16, 0, 0);
+      }
+    }
+  }
   // ---- epilogue, two passes of 8 accumulator registers
   float* part = lds;                              // [8 w][32 = rr*4 + dy*2 + dx][64 lanes]  (64 KB)
 #pragma unroll
@@ -1220,7 +1241,7 @@ int main(int argc, char** argv) {
       if (ex == 0) L3(0); else if (ex == 1) L3(2); else if (ex == 2) L3(4); else if (ex == 3) L3(6); else if (ex == 4) L3(8);
       else if (ex == 5) L3(10); else if (ex == 6) L3(12); else L3(14);
     }
-    else if (variant == 7) { if (flags == 1) hipLaunchKernelGGL((wino_fwd7<1>), dim3(grid), dim3(512), 0, 0, dx, dwt, dy, S, Cin, Cout); else if (flags == 2) hipLaunchKernelGGL((wino_fwd7<2>), dim3(grid), dim3(512), 0, 0, dx, dwt, dy, S, Cin, Cout); else if (flags == 4) hipLaunchKernelGGL((wino_fwd7<4>), dim3(grid), dim3(512), 0, 0, dx, dwt, dy, S, Cin, Cout); else if (flags == 8) hipLaunchKernelGGL((wino_fwd7<8>), dim3(grid), dim3(512), 0, 0, dx, dwt, dy, S, Cin, Cout); else if (flags == 16) hipLaunchKernelGGL((wino_fwd7<16>), dim3(grid), dim3(512), 0, 0, dx, dwt, dy, S, Cin, Cout); else if (flags == 24) hipLaunchKernelGGL((wino_fwd7<24>), dim3(grid), dim3(512), 0, 0, dx, dwt, dy, S, Cin, Cout); else hipLaunchKernelGGL((wino_fwd7<0>), dim3(grid), dim3(512), 0, 0, dx, dwt, dy, S, Cin, Cout); }
+    else if (variant == 7) { if (flags == 1) hipLaunchKernelGGL((wino_fwd7<1>), dim3(grid), dim3(512), 0, 0, dx, dwt, dy, S, Cin, Cout); else if (flags == 2) hipLaunchKernelGGL((wino_fwd7<2>), dim3(grid), dim3(512), 0, 0, dx, dwt, dy, S, Cin, Cout); else if (flags == 4) hipLaunchKernelGGL((wino_fwd7<4>), dim3(grid), dim3(512), 0, 0, dx, dwt, dy, S, Cin, Cout); else if (flags == 8) hipLaunchKernelGGL((wino_fwd7<8>), dim3(grid), dim3(512), 0, 0, dx, dwt, dy, S, Cin, Cout); else if (flags == 16) hipLaunchKernelGGL((wino_fwd7<16>), dim3(grid), dim3(512), 0, 0, dx, dwt, dy, S, Cin, Cout); else if (flags == 24) hipLaunchKernelGGL((wino_fwd7<24>), dim3(grid), dim3(512), 0, 0, dx, dwt, dy, S, Cin, Cout); else if (flags == 32) hipLaunchKernelGGL((wino_fwd7<32>), dim3(grid), dim3(512), 0, 0, dx, dwt, dy, S, Cin, Cout); else hipLaunchKernelGGL((wino_fwd7<0>), dim3(grid), dim3(512), 0, 0, dx, dwt, dy, S, Cin, Cout); }
     else if (variant == 6) hipLaunchKernelGGL((wino_fwd6<0>), dim3(grid), dim3(256), 0, 0, dx, dwt, dy, S, Cin, Cout);
     else if (variant == 4) hipLaunchKernelGGL((wino_fwd4<0, 0>), dim3(grid), dim3(256), 0, 0, dx, dwt, dz, dy, S, Cin, Cout);
     else if (variant == 5) {
