@@ -703,12 +703,14 @@ int launch_conv_fwd_wino(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, c
 
 // ---------------------------------------------------------------- backward-weight launcher
 // blocks per workgroup: a power of two >= 2 that divides the blocks of one sample (every split full, even count),
-// small enough for ~6 workgroups per CU, large enough for the workspace
+// small enough for ~2 workgroups per CU, large enough for the workspace
 static int wino_wgrad_per_split(const ConvGeom& g, size_t ws_floats) {
   const int bps = (g.S / 4) * (g.S / 4) * (g.S / 8);               // blocks per sample: a power of two >= 4
   const int nblocks = g.B * bps;
   const int pairs = (g.Cin / 32) * (g.Cout / 32);
-  const int want = std::max((1536 + pairs - 1) / pairs, 1);         // splits wanted
+  // ~2 workgroups per CU (measured per U-Net step: 256 -> 36.96 ms, 512 -> 37.05, 1536 -> 37.15, 3072 -> 37.7; one
+  // round of workgroups would double the launch time whenever a communication kernel holds a few CUs)
+  const int want = std::max((512 + pairs - 1) / pairs, 1);          // splits wanted
   const size_t per = (size_t)27 * g.Cin * g.Cout;
   int ps = 2;
   while (ps < bps && ((nblocks / ps) > want || (size_t)(nblocks / ps) * per > ws_floats)) ps *= 2;
