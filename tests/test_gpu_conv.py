@@ -3,6 +3,8 @@
 for the shape: Winograd F(2x2x2, 3x3x3) where csrc/conv_wino.hip serves it (3x3x3, S >= 8, Cin and Cout multiples of
 32), the 27-tap implicit GEMM or a direct stencil otherwise; every Winograd-served case is ALSO run with
 ICSG3D_NO_WINO=1, which keeps the implicit-GEMM kernels covered at the same shapes."""
+import os
+
 import numpy as np
 import pytest
 
@@ -27,8 +29,10 @@ CASES = [
 
 
 def _wino(case):
+    """True when the default path of this shape is the Winograd kernel (and the suite is not itself run under
+    ICSG3D_NO_WINO, in which case there is nothing to A/B)."""
     B, S, Cin, Cout, k = case
-    return k == 3 and S >= 8 and Cin % 32 == 0 and Cout % 32 == 0
+    return k == 3 and S >= 8 and Cin % 32 == 0 and Cout % 32 == 0 and not os.environ.get("ICSG3D_NO_WINO")
 
 
 def _data(B, S, Cin, Cout, k, seed=0):
