@@ -9,6 +9,7 @@
 // two z-planes its fz row of B^T combines, finishes the y/x transforms in registers directly in the MFMA A-operand
 // layout (lane = tile, half-wave = channel group), and streams its B operands (pre-transformed weights) from L2.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -947,12 +948,15 @@ __global__ __launch_bounds__(256) void wino_fwd6(const float* __restrict__ x, co
 // ---------------------------------------------------------------- v7: 8 waves (2 per SIMD: VALU 3.6 instead of 5.2
 // cycles, MFMA 69.5 instead of 75), z-combination done ONCE at staging time (8 combined planes (tz, fz) in LDS instead
 // of 6 raw ones), wave w: fz = w >> 1, fy rows {2 (w&1), 2 (w&1) + 1}: 12 LDS reads + 32 VALU per 16 MFMAs.
+__device__ unsigned long long* g_tl;   // EXP & 64: per-wave wall-clock stamps (100 MHz)
 constexpr int P7 = 18, PY7 = 10, PZ7 = 100, BUF7 = 8 * PZ7 * P7;          // floats per buffer (57 600 B)
 template <int EXP>
 __global__ __launch_bounds__(512) void wino_fwd7(const float* __restrict__ x, const float* __restrict__ wt,
                                                  float* __restrict__ y, int S, int Cin, int Cout) {
   __shared__ __attribute__((aligned(16))) float lds[2 * BUF7];   // 115 200 B
   const int tid = threadIdx.x, lane = tid & 63;
+  unsigned long long tl0 = 0, tl1 = 0, tl2 = 0;
+  if (EXP & 64) tl0 = wall_clock64();
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fz = w >> 1, fyh = w & 1;
   const int m = lane & 31, h = lane >> 5;
@@ -1070,10 +1074,13 @@ __global__ __launch_bounds__(512) void wino_fwd7(const float* __restrict__ x, co
   }
   xform();
   rd(0, 1, 0);
+  if (EXP & 64) tl1 = wall_clock64();
 
   const int nch = Cin / KC;
+  // ablations (v7): 128 no weight reloads, 256 no LDS operand reads, 512 no transform VALU, 1024 no staging (global loads,
+  // LDS stores, barrier), 2048 no MFMAs
   auto chunk = [&](const int ch, const int cur, const int nxt) {
-    gload((ch + 1 < nch ? ch + 1 : ch) * KC);
+    if (!(EXP & 1024)) gload((ch + 1 < nch ? ch + 1 : ch) * KC);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       int gs = ch * 4 + s + 1;
@@ -1082,16 +1089,20 @@ __global__ __launch_bounds__(512) void wino_fwd7(const float* __restrict__ x, co
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const f2 a = qa, bq = qb, c = qc;
-        if (s == 2 && g == 3) {
+        if (s == 2 && g == 3 && !(EXP & 1024)) {
           sstore(nxt);
           __syncthreads();
         }
-        if (g < 3) rd(s == 3 ? nxt : cur, (s + 1) & 3, g + 1);
-        else rd(s >= 2 ? nxt : cur, (s + 2) & 3, 0);
+        if (!(EXP & 256)) {
+          if (g < 3) rd(s == 3 ? nxt : cur, (s + 1) & 3, g + 1);
+          else rd(s >= 2 ? nxt : cur, (s + 2) & 3, 0);
+        }
         if (!(EXP & 1)) __builtin_amdgcn_sched_barrier(0);
-#define MF7(F, C) acc[F] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[F].C, wreg[F].C, acc[F], 0, 0, 0)
+#define MF7(F, C) if (!(EXP & 2048)) acc[F] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[F].C, wreg[F].C, acc[F], 0, 0, 0)
 #define FN7 if (!(EXP & 1)) __builtin_amdgcn_sched_barrier(0)
-        if (EXP & 2) {          // colmath as a burst after the group's MFMAs
+        if (EXP & 512) {
+          MF7(g, x); FN7; MF7(4 + g, x); FN7; MF7(g, y); FN7; MF7(4 + g, y); FN7;
+        } else if (EXP & 2) {          // colmath as a burst after the group's MFMAs
           MF7(g, x); FN7; MF7(4 + g, x); FN7; MF7(g, y); FN7; MF7(4 + g, y); FN7;
           tn[0][g] = a - bq; tn[1][g] = bq + sg * c;
         } else if (EXP & 4) {   // colmath after MFMAs 2 and 3
@@ -1104,17 +1115,20 @@ __global__ __launch_bounds__(512) void wino_fwd7(const float* __restrict__ x, co
           MF7(g, y); FN7;
           MF7(4 + g, y); FN7;
         }
-        wreg[g] = *reinterpret_cast<const f2*>(wn + g * wstride_f + wlane);
-        wreg[4 + g] = *reinterpret_cast<const f2*>(wn + (4 + g) * wstride_f + wlane);
+        if (!(EXP & 128)) {
+          wreg[g] = *reinterpret_cast<const f2*>(wn + g * wstride_f + wlane);
+          wreg[4 + g] = *reinterpret_cast<const f2*>(wn + (4 + g) * wstride_f + wlane);
+        }
         FN7;
       }
-      xform();
+      if (!(EXP & 512)) xform();
     }
   };
   for (int ch = 0; ch < nch; ch += 2) {
     chunk(ch, 0, BUF7);
     chunk(ch + 1, BUF7, 0);
   }
+  if (EXP & 64) tl2 = wall_clock64();
 
   // EXP & 32: while the epilogue runs, pull the first chunk of the tile block this CU will most likely get next
   // (blockIdx + 256: same XCD) into L2 with LDS-DMA loads into a dead LDS region
@@ -1182,6 +1196,14 @@ __global__ __launch_bounds__(512) void wino_fwd7(const float* __restrict__ x, co
       }
     }
   }
+  if (EXP & 64) {                                   // one record per WAVE: start, prologue end, main-loop end, end, ids
+    if (lane == 0) {
+      unsigned long long* r = g_tl + ((size_t)blockIdx.x * 8 + w) * 6;
+      r[0] = tl0; r[1] = tl1; r[2] = tl2; r[3] = wall_clock64();
+      r[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID: wave[3:0] simd[5:4] pipe[7:6] cu[11:8] sh[12] se[15:13]
+      r[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
+    }
+  }
 }
 
 // ---------------------------------------------------------------- host
@@ -1241,7 +1263,12 @@ int main(int argc, char** argv) {
       if (ex == 0) L3(0); else if (ex == 1) L3(2); else if (ex == 2) L3(4); else if (ex == 3) L3(6); else if (ex == 4) L3(8);
       else if (ex == 5) L3(10); else if (ex == 6) L3(12); else L3(14);
     }
-    else if (variant == 7) { if (flags == 1) hipLaunchKernelGGL((wino_fwd7<1>), dim3(grid), dim3(512), 0, 0, dx, dwt, dy, S, Cin, Cout); else if (flags == 2) hipLaunchKernelGGL((wino_fwd7<2>), dim3(grid), dim3(512), 0, 0, dx, dwt, dy, S, Cin, Cout); else if (flags == 4) hipLaunchKernelGGL((wino_fwd7<4>), dim3(grid), dim3(512), 0, 0, dx, dwt, dy, S, Cin, Cout); else if (flags == 8) hipLaunchKernelGGL((wino_fwd7<8>), dim3(grid), dim3(512), 0, 0, dx, dwt, dy, S, Cin, Cout); else if (flags == 16) hipLaunchKernelGGL((wino_fwd7<16>), dim3(grid), dim3(512), 0, 0, dx, dwt, dy, S, Cin, Cout); else if (flags == 24) hipLaunchKernelGGL((wino_fwd7<24>), dim3(grid), dim3(512), 0, 0, dx, dwt, dy, S, Cin, Cout); else if (flags == 32) hipLaunchKernelGGL((wino_fwd7<32>), dim3(grid), dim3(512), 0, 0, dx, dwt, dy, S, Cin, Cout); else hipLaunchKernelGGL((wino_fwd7<0>), dim3(grid), dim3(512), 0, 0, dx, dwt, dy, S, Cin, Cout); }
+    else if (variant == 7) {
+#define L7(E) case E: hipLaunchKernelGGL((wino_fwd7<E>), dim3(grid), dim3(512), 0, 0, dx, dwt, dy, S, Cin, Cout); break
+      switch (flags) { L7(0); L7(1); L7(2); L7(4); L7(8); L7(16); L7(24); L7(32); L7(64); L7(128); L7(256); L7(512); L7(1024);
+        L7(2048); L7(384); L7(896); L7(1920); L7(1040); L7(1152); L7(2048 + 16); L7(640); L7(1536);
+        default: fprintf(stderr, "v7: flags %d not instantiated\n", flags); exit(2); }
+    }
     else if (variant == 6) hipLaunchKernelGGL((wino_fwd6<0>), dim3(grid), dim3(256), 0, 0, dx, dwt, dy, S, Cin, Cout);
     else if (variant == 4) hipLaunchKernelGGL((wino_fwd4<0, 0>), dim3(grid), dim3(256), 0, 0, dx, dwt, dz, dy, S, Cin, Cout);
     else if (variant == 5) {
@@ -1251,8 +1278,58 @@ int main(int argc, char** argv) {
     }
     else hipLaunchKernelGGL(wino_fwd8, dim3(grid), dim3(512), 0, 0, dx, dwt, dz, dy, S, Cin, Cout);
   };
+  unsigned long long* dtl = nullptr;
+  if (variant == 7 && flags == 64) {
+    HIPCHECK(hipMalloc(&dtl, (size_t)grid * 8 * 6 * 8));
+    HIPCHECK(hipMemset(dtl, 0, (size_t)grid * 8 * 6 * 8));
+    HIPCHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_tl), &dtl, sizeof(dtl)));
+    launch(); launch();                       // warm (clocks, L2)
+    HIPCHECK(hipDeviceSynchronize());
+  }
   launch();
   HIPCHECK(hipDeviceSynchronize());
+  if (dtl) {
+    // timeline analysis: per CU, workgroups in start order; all times in 10 ns ticks of the 100 MHz wall clock
+    std::vector<unsigned long long> tl((size_t)grid * 8 * 6);
+    HIPCHECK(hipMemcpy(tl.data(), dtl, tl.size() * 8, hipMemcpyDeviceToHost));
+    struct WG { unsigned long long s, p, m, e; int cu; int blk; };
+    std::vector<WG> wgs(grid);
+    unsigned long long t0 = ~0ull, t1 = 0;
+    for (int g = 0; g < grid; ++g) {
+      WG q{~0ull, 0, 0, 0, 0, g};
+      for (int w = 0; w < 8; ++w) {
+        const unsigned long long* r = &tl[((size_t)g * 8 + w) * 6];
+        q.s = r[0] < q.s ? r[0] : q.s; q.p = r[1] > q.p ? r[1] : q.p; q.m = r[2] > q.m ? r[2] : q.m; q.e = r[3] > q.e ? r[3] : q.e;
+        const unsigned hw = (unsigned)r[4], xcc = (unsigned)r[5] & 15;
+        q.cu = (int)((xcc << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15));
+      }
+      wgs[g] = q; t0 = q.s < t0 ? q.s : t0; t1 = q.e > t1 ? q.e : t1;
+    }
+    std::sort(wgs.begin(), wgs.end(), [](const WG& a, const WG& b) { return a.cu != b.cu ? a.cu < b.cu : a.s < b.s; });
+    double sp = 0, sm = 0, se = 0, sg = 0; long ng = 0; int ncu = 0, overlaps = 0;
+    for (int i = 0; i < grid; ++i) {
+      sp += wgs[i].p - wgs[i].s; sm += wgs[i].m - wgs[i].p; se += wgs[i].e - wgs[i].m;
+      if (i == 0 || wgs[i].cu != wgs[i - 1].cu) { ++ncu; continue; }
+      if (wgs[i].s < wgs[i - 1].e) ++overlaps;
+      sg += (double)wgs[i].s - (double)wgs[i - 1].e; ++ng;
+    }
+    printf("timeline: %d workgroups on %d CUs, kernel span %.1f us; per workgroup (us): prologue %.3f  main loop %.3f  epilogue %.3f  "
+           "gap to the next workgroup on the same CU %.3f (%d overlapping)\n", grid, ncu, (t1 - t0) * 0.01, sp / grid * 0.01,
+           sm / grid * 0.01, se / grid * 0.01, sg / ng * 0.01, overlaps);
+    for (int i = 0; i < 12 && i < grid; ++i)
+      printf("  cu %04x blk %5d: start %.2f  +pro %.2f  +main %.2f  +epi %.2f us\n", wgs[i].cu, wgs[i].blk, (wgs[i].s - t0) * 0.01,
+             (wgs[i].p - wgs[i].s) * 0.01, (wgs[i].m - wgs[i].p) * 0.01, (wgs[i].e - wgs[i].m) * 0.01);
+    double dm = 0, de = 0;                    // how far apart do the 8 waves of a workgroup leave the main loop / finish?
+    for (int g = 0; g < grid; ++g) {
+      unsigned long long mlo = ~0ull, mhi = 0, elo = ~0ull, ehi = 0;
+      for (int w = 0; w < 8; ++w) {
+        const unsigned long long* r = &tl[((size_t)g * 8 + w) * 6];
+        mlo = r[2] < mlo ? r[2] : mlo; mhi = r[2] > mhi ? r[2] : mhi; elo = r[3] < elo ? r[3] : elo; ehi = r[3] > ehi ? r[3] : ehi;
+      }
+      dm += mhi - mlo; de += ehi - elo;
+    }
+    printf("  wave spread: main-loop exit %.3f us, end %.3f us\n", dm / grid * 0.01, de / grid * 0.01);
+  }
   if (check || (size_t)B * S * S * S <= 4096) {
     std::vector<float> hy(ny);
     HIPCHECK(hipMemcpy(hy.data(), dy, ny * 4, hipMemcpyDeviceToHost));

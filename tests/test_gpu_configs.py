@@ -1,0 +1,156 @@
+"""BASELINE.json's configurations at their stated per-GPU sizes ("configs untested at their stated size"):
+
+  configs[0]  U-Net forward-only on exactly 16 grids
+  configs[2]  DFC-VAE train step at B = 32, d = 32
+  configs[4]  64^3 grids at B = 8 per GPU: U-Net step + DFC-VAE step
+  the conv launches bench.py times (B = 32: S = 32 128->128, S = 16 256->128) against the fp64 oracle
+
+Where the fp64 oracle finishes in seconds (the conv ops: BLAS-backed, ~1 TFLOP each) it is the checker; for whole
+networks at these sizes the checks are the size-independent properties test_gpu_fullsize.py uses: finite metrics,
+bit-identical reruns, training reduces the loss, eval-mode batch invariance, metrics equal to the reference formulas."""
+import numpy as np
+import pytest
+
+from oracle import numpy_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _reset_bn(eng, w):
+    for k in w:
+        if k.endswith("moving_mean"):
+            eng.set_tensor(k, np.zeros_like(w[k]))
+        if k.endswith("moving_var"):
+            eng.set_tensor(k, np.ones_like(w[k]))
+
+
+def _vae_pair(B, d, lr=5e-4):
+    from icsg3d_amd.engine import UnetEngine, VaeEngine
+    from icsg3d_amd.synthetic import glorot_params, unet_param_shapes, vae_param_shapes
+    PU = glorot_params(unet_param_shapes(1, 95), 1)
+    PV = glorot_params(vae_param_shapes(1, d=d), 3)
+    ue = UnetEngine(in_channels=1, d=d, max_batch=B, lr=1e-4)
+    ue.set_weights(PU)
+    ve = VaeEngine(ue, in_channels=1, d=d, max_batch=B, lr=lr)
+    ve.set_weights(PV)
+    return ue, ve, PU, PV
+
+
+def _vae_properties(B, d, steps=3):
+    """finite metrics, loss decreases, bit-identical rerun from the same state, frozen perceptual U-Net untouched,
+    Loss == MSE + alpha PM + beta KLD (vae/lattice_vae.py:241-255) on every step."""
+    from icsg3d_amd.synthetic import synthetic_batch
+    ue, ve, PU, PV = _vae_pair(B, d)
+    X, _, cond = synthetic_batch(B, d, 1, seed=0, noise=1e-3)
+    eps = np.random.default_rng(2).standard_normal((B, 256)).astype(np.float32)
+    pm_before = ue.get_weights()
+    ms = [ve.train_step(X, cond, eps) for _ in range(steps)]
+    assert np.all(np.isfinite(ms))
+    assert ms[-1][0] < ms[0][0]
+    for m in ms:
+        assert abs(m[0] - (m[2] + 0.5 * m[1] + 3e-4 * m[3])) <= 2e-5 * abs(m[0])
+    w1 = ve.get_weights()
+    pm_after = ue.get_weights()
+    assert all(np.array_equal(pm_before[k], pm_after[k]) for k in pm_before)      # frozen, BN moving stats included
+    ve.set_weights(PV); ve.reset_optimizer(); _reset_bn(ve, w1)
+    ms2 = [ve.train_step(X, cond, eps) for _ in range(steps)]
+    assert all(np.array_equal(a, b) for a, b in zip(ms, ms2))
+    w2 = ve.get_weights()
+    assert all(np.array_equal(w1[k], w2[k]) for k in w1)
+    # eval mode is batch-invariant: reconstructions of a sub-batch equal the rows of the full batch
+    zm, zlv, z = ve.encode(X, cond, eps)
+    rec = ve.decode(z, cond)
+    assert np.all(np.isfinite(rec)) and rec.min() >= 0          # decoder_output -> BN -> ReLU
+    zm2, _, z2 = ve.encode(X[1:3], cond[1:3], eps[1:3])
+    assert np.array_equal(zm2, zm[1:3])
+    assert np.array_equal(ve.decode(z2, cond[1:3]), rec[1:3])
+    return ue, ve, X, cond, eps
+
+
+def test_config2_dfc_vae_step_b32_d32():
+    """BASELINE configs[2]: DFC-VAE (encoder + decoder + frozen U-Net perceptual loss) fwd+bwd at batch 32."""
+    ue, ve, X, cond, eps = _vae_properties(32, 32)
+    # test_on_batch (eval-mode BN everywhere but the perceptual taps) equals the reference formulas on the
+    # engine's own predictions: MSE = mean((x - recon)^2), KLD = mean_b(-1/2 sum(1 + lv - mu^2 - e^lv))
+    m = ve.test_step(X, cond, eps)
+    zm, zlv, z = ve.encode(X, cond, eps)
+    rec = ve.decode(z, cond)
+    mse = float(np.mean((X.astype(np.float64) - rec) ** 2))
+    kld = float(np.mean(-0.5 * np.sum(1 + zlv.astype(np.float64) - zm.astype(np.float64) ** 2 - np.exp(zlv.astype(np.float64)), -1)))
+    assert abs(m[2] - mse) <= 2e-5 * mse and abs(m[3] - kld) <= 2e-5 * abs(kld)
+
+
+def test_config4_d64_b8_unet_and_vae_steps():
+    """BASELINE configs[4]: 64^3 grids, batch 8 per GPU, U-Net step + DFC-VAE step (the joint job's per-GPU shape)."""
+    from icsg3d_amd.synthetic import synthetic_batch
+    B, d = 8, 64
+    ue, ve, X, cond, eps = _vae_properties(B, d)
+    _, lab, _ = synthetic_batch(B, d, 1, seed=0, noise=1e-3)
+    # eval mode: the batch of 8 gives the per-sample results bit for bit, and test_step's losses are their means
+    m8 = ue.test_step(X, lab)
+    per = np.array([ue.test_step(X[i:i + 1], lab[i:i + 1]) for i in range(B)])
+    np.testing.assert_allclose(m8[:3], per[:, :3].mean(0), rtol=2e-6)
+    soft, sig = ue.predict(X[:2])
+    soft1, sig1 = ue.predict(X[1:2])
+    assert np.array_equal(soft[1:2], soft1) and np.array_equal(sig[1:2], sig1)
+    del soft, sig
+    # U-Net training at the same shape: finite, decreasing, bit-identical rerun
+    P0 = ue.get_weights()
+    losses = [ue.train_step(X, lab)[0] for _ in range(3)]
+    assert np.all(np.isfinite(losses)) and losses[-1] < losses[0]
+    w1 = ue.get_weights()
+    ue.set_weights(P0); ue.reset_optimizer()
+    losses2 = [ue.train_step(X, lab)[0] for _ in range(3)]
+    assert losses == losses2
+    w2 = ue.get_weights()
+    assert all(np.array_equal(w1[k], w2[k]) for k in w1)
+
+
+def test_config0_predict_on_exactly_16_grids():
+    """BASELINE configs[0]: U-Net forward-only on 16 synthetic 32^3 x 1 grids: one call, oracle-checked on the
+    first and last grid (eval-mode BN: every grid is independent of the rest of the batch)."""
+    from icsg3d_amd.engine import UnetEngine
+    from icsg3d_amd.synthetic import synthetic_batch
+    B, d = 16, 32
+    uo = R.UnetOracle(in_ch=1, seed=1)
+    eng = UnetEngine(in_channels=1, d=d, max_batch=B)
+    eng.set_weights(uo.P)
+    X, lab, _ = synthetic_batch(B, d, 1, seed=0, noise=1e-3)
+    soft, sig = eng.predict(X)
+    assert soft.shape == (16, d, d, d, 95) and sig.shape == (16, d, d, d, 1)
+    np.testing.assert_allclose(soft.sum(-1), 1.0, atol=2e-6)
+    for i in (0, 15):
+        sr, gr = uo.forward(X[i:i + 1].astype(np.float64), training=False)
+        assert np.abs(soft[i:i + 1] - sr).max() <= 1e-5 * np.abs(sr).max()
+        assert np.abs(sig[i:i + 1] - gr).max() <= 1e-5 * np.abs(gr).max()
+        # argmax labels bit-exact wherever the oracle's top-2 margin exceeds 1e-4
+        top2 = np.sort(sr, -1)[..., -2:]
+        sure = (top2[..., 1] - top2[..., 0]) > 1e-4
+        assert np.array_equal(soft[i:i + 1].argmax(-1)[sure], sr.argmax(-1)[sure])
+    sp, mk = eng.predict_labels(X, 0.8)
+    assert np.array_equal(sp, soft.argmax(-1)) and np.array_equal(mk, sig[..., 0] >= 0.8)
+
+
+# the convolution launches bench.py times at B = 32 (the split plans of the backward-weight kernels depend on B:
+# one split per sample at B = 32), against the fp64 oracle.  ~0.9 TFLOP of fp64 BLAS per direction and shape.
+BENCH_SHAPES = [(32, 32, 128, 128), (32, 16, 256, 128)]
+
+
+@pytest.mark.parametrize("case", BENCH_SHAPES, ids=lambda c: "B%d_S%d_%dto%d" % c)
+def test_conv_ops_at_bench_launch_shapes(case, relerr):
+    from icsg3d_amd import engine as E
+    B, S, Cin, Cout = case
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((B, S, S, S, Cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 3, Cin, Cout)) / np.sqrt(27 * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    dy = rng.standard_normal((B, S, S, S, Cout)).astype(np.float32)
+    got = E.conv3d_forward(x, w, b, pre_act=0)
+    dx, dw = E.conv3d_backward(x, w, dy)
+    x64, w64, dy64 = x.astype(np.float64), w.astype(np.float64), dy.astype(np.float64)
+    ref = R.conv3d_fwd(x64, w64, b.astype(np.float64))
+    assert relerr(got, ref) <= 1e-5
+    del ref, got
+    dx_ref, dw_ref, _ = R.conv3d_bwd(x64, w64, dy64)
+    assert relerr(dx, dx_ref) <= 1e-5
+    assert relerr(dw, dw_ref) <= 1e-5
