@@ -36,6 +36,7 @@ class VaeConfig(C.Structure):
 
 _F = C.POINTER(C.c_float)
 _U8 = C.POINTER(C.c_uint8)
+_I32 = C.POINTER(C.c_int32)
 _H = C.c_void_p
 
 # name -> (restype, argtypes); every symbol include/icsg3d.h declares
@@ -60,6 +61,9 @@ SIGNATURES = {
     "ics_vae_upload_batch": (C.c_int, [_H, _F, _F, _F, C.c_int]),
     "ics_vae_train_step_resident": (C.c_int, [_H, _F]),
     "ics_vae_decode_to_unet_labels": (C.c_int, [_H, _H, _F, _F, C.c_int, C.c_float, _U8, _U8, _F, _F]),
+    "ics_vae_decode_to_unet_atoms": (C.c_int, [_H, _H, _F, _F, C.c_int, C.c_float, C.c_int, C.c_int, _U8, _U8, _F, _F,
+                                               _I32, _I32, _I32]),
+    "ics_op_segment_atoms": (C.c_int, [_U8, _U8, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _I32, _I32, _I32]),
     "ics_net_destroy": (C.c_int, [_H]),
     "ics_net_sync": (C.c_int, [_H]),
     "ics_net_num_tensors": (C.c_int, [_H, C.POINTER(C.c_int)]),
@@ -129,6 +133,10 @@ def fptr(a):
 
 def u8ptr(a):
     return a.ctypes.data_as(_U8) if a is not None else None
+
+
+def i32ptr(a):
+    return a.ctypes.data_as(_I32) if a is not None else None
 
 
 def device_count():

@@ -6,6 +6,7 @@
 // step needs lives in HBM for the life of the handle (activations for B=32, d=32 are ~7 GB of 288).
 #include "common.h"
 #include "elementwise.h"
+#include "segment.h"
 #include "../../include/icsg3d.h"
 
 #include <rccl/rccl.h>
@@ -1887,13 +1888,11 @@ int ics_vae_test_step(ics_net* net, const float* x, const float* cond, const flo
 // argmax / threshold, all on the device.  The reconstruction never leaves HBM: the U-Net reads it where the
 // decoder wrote it (driven on the VAE's stream), and what comes back is 2 bytes per voxel plus, on request,
 // the density channel (watershed input) and the coordinate channels' min/max (to_lattice_params).
-int ics_vae_decode_to_unet_labels(ics_net* vae, ics_net* unet, const float* z, const float* cond, int batch,
-                                  float thresh, uint8_t* species, uint8_t* mask, float* density,
-                                  float* coord_minmax) {
-  ICS_TRY(require_kind(vae, 1));
-  ICS_TRY(require_kind(unet, 0));
-  Net& n = vae->n;
-  Net& u = unet->n;
+// device part of the tail: decoder -> U-Net -> labels; leaves species / mask (uint8 [M] each) and aux (density [M] |
+// minmax [B][3][2]) in the U-Net head's gradient buffer, which no inference path reads
+static int decode_to_labels_device(Net& n, Net& u, const float* z, const float* cond, int batch, float thresh,
+                                   bool want_density, bool want_minmax, unsigned char** d_species_out,
+                                   unsigned char** d_mask_out, float** d_aux_out) {
   ICS_CHECK(z && cond, "null argument");
   ICS_CHECK(u.d == n.d && u.C == n.C && u.device == n.device, "U-Net / VAE engines do not match (grid, channels, device)");
   ICS_CHECK(batch >= 1 && batch <= n.maxB && batch <= u.maxB, "batch exceeds max_batch");
@@ -1915,11 +1914,11 @@ int ics_vae_decode_to_unet_labels(ics_net* vae, ics_net* unet, const float* z, c
     if ((rc = unet_loss(u, batch, 0, 0))) break;
     hipLaunchKernelGGL(labels_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, n.st, u.head->s, u.ncls + 1,
                        u.ncls, M, thresh, d_species, d_mask);
-    if (density) {
+    if (want_density) {
       hipLaunchKernelGGL(gather_cols_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, n.st, n.recon, n.C, 0, 1,
                          M, d_aux);
     }
-    if (coord_minmax && n.C >= 4) {
+    if (want_minmax && n.C >= 4) {
       hipLaunchKernelGGL(chan_minmax_kernel, dim3(batch * 3), dim3(256), 0, n.st, n.recon, M / batch, n.C, 1, 3,
                          d_aux + M);
     }
@@ -1927,6 +1926,13 @@ int ics_vae_decode_to_unet_labels(ics_net* vae, ics_net* unet, const float* z, c
   } while (0);
   u.st = saved;
   ICS_TRY(rc);
+  *d_species_out = d_species; *d_mask_out = d_mask; *d_aux_out = d_aux;
+  return 0;
+}
+
+static int tail_copy_out(Net& n, int batch, const unsigned char* d_species, const unsigned char* d_mask,
+                         const float* d_aux, uint8_t* species, uint8_t* mask, float* density, float* coord_minmax) {
+  const size_t M = (size_t)batch * n.d * n.d * n.d;
   if (species) ICS_HIP(hipMemcpyAsync(species, d_species, M, hipMemcpyDeviceToHost, n.st));
   if (mask) ICS_HIP(hipMemcpyAsync(mask, d_mask, M, hipMemcpyDeviceToHost, n.st));
   if (density) ICS_HIP(hipMemcpyAsync(density, d_aux, M * 4, hipMemcpyDeviceToHost, n.st));
@@ -1934,8 +1940,85 @@ int ics_vae_decode_to_unet_labels(ics_net* vae, ics_net* unet, const float* z, c
     if (n.C >= 4) ICS_HIP(hipMemcpyAsync(coord_minmax, d_aux + M, (size_t)batch * 6 * 4, hipMemcpyDeviceToHost, n.st));
     else std::memset(coord_minmax, 0, (size_t)batch * 6 * 4);
   }
+  return 0;
+}
+
+int ics_vae_decode_to_unet_labels(ics_net* vae, ics_net* unet, const float* z, const float* cond, int batch,
+                                  float thresh, uint8_t* species, uint8_t* mask, float* density,
+                                  float* coord_minmax) {
+  ICS_TRY(require_kind(vae, 1));
+  ICS_TRY(require_kind(unet, 0));
+  Net& n = vae->n;
+  unsigned char *d_species, *d_mask;
+  float* d_aux;
+  ICS_TRY(decode_to_labels_device(n, unet->n, z, cond, batch, thresh, density != nullptr, coord_minmax != nullptr,
+                                  &d_species, &d_mask, &d_aux));
+  ICS_TRY(tail_copy_out(n, batch, d_species, d_mask, d_aux, species, mask, density, coord_minmax));
   ICS_HIP(hipStreamSynchronize(n.st));
   return 0;
+}
+
+// connected components + region statistics of device-resident mask / species volumes; results to the host
+static int segment_to_host(Net& n, const unsigned char* d_mask, const unsigned char* d_species, int batch, int d,
+                           int min_voxels, int max_atoms, int nbins, int32_t* regions, int32_t* counts,
+                           int32_t* atom_stats) {
+  ICS_CHECK(counts && atom_stats && max_atoms >= 1, "null argument");
+  const size_t M = (size_t)batch * d * d * d;
+  const size_t wsb = segment_workspace_bytes(batch, d, max_atoms, nbins);
+  unsigned char* ws = nullptr;
+  int* d_R = nullptr;
+  ICS_HIP(hipMalloc(reinterpret_cast<void**>(&ws), wsb + (regions ? M * 4 : 0)));
+  int rc = 0;
+  do {
+    if (regions) d_R = reinterpret_cast<int*>(ws + ((wsb + 15) & ~(size_t)15)) ;
+    int *d_counts = nullptr, *d_stats = nullptr;
+    if ((rc = launch_segment_atoms(n.st, d_mask, d_species, batch, d, min_voxels, max_atoms, nbins, ws, wsb, d_R,
+                                   &d_counts, &d_stats)))
+      break;
+    hipError_t e = hipSuccess;
+    if (regions) e = hipMemcpyAsync(regions, d_R, M * 4, hipMemcpyDeviceToHost, n.st);
+    if (e == hipSuccess) e = hipMemcpyAsync(counts, d_counts, (size_t)batch * 2 * 4, hipMemcpyDeviceToHost, n.st);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(atom_stats, d_stats, (size_t)batch * max_atoms * kSegStatInts * 4, hipMemcpyDeviceToHost, n.st);
+    if (e == hipSuccess) e = hipStreamSynchronize(n.st);
+    if (e != hipSuccess) { set_error(std::string("segmentation copy-out: ") + hipGetErrorString(e)); rc = -1; }
+  } while (0);
+  (void)hipFree(ws);
+  ICS_TRY(rc);
+  for (int b = 0; b < batch; ++b)
+    ICS_CHECK(counts[2 * b + 1] <= max_atoms, "more kept components than max_atoms in sample " + std::to_string(b) +
+                                              " (" + std::to_string(counts[2 * b + 1]) + ")");
+  return 0;
+}
+
+int ics_vae_decode_to_unet_atoms(ics_net* vae, ics_net* unet, const float* z, const float* cond, int batch,
+                                 float thresh, int min_voxels, int max_atoms, uint8_t* species, uint8_t* mask,
+                                 float* density, float* coord_minmax, int32_t* regions, int32_t* counts,
+                                 int32_t* atom_stats) {
+  ICS_TRY(require_kind(vae, 1));
+  ICS_TRY(require_kind(unet, 0));
+  Net& n = vae->n;
+  unsigned char *d_species, *d_mask;
+  float* d_aux;
+  ICS_TRY(decode_to_labels_device(n, unet->n, z, cond, batch, thresh, density != nullptr, coord_minmax != nullptr,
+                                  &d_species, &d_mask, &d_aux));
+  ICS_TRY(tail_copy_out(n, batch, d_species, d_mask, d_aux, species, mask, density, coord_minmax));
+  ICS_TRY(segment_to_host(n, d_mask, d_species, batch, n.d, min_voxels, max_atoms, unet->n.ncls, regions, counts,
+                          atom_stats));
+  return 0;
+}
+
+int ics_op_segment_atoms(const uint8_t* mask, const uint8_t* species, int batch, int d, int min_voxels, int max_atoms,
+                         int num_species, int32_t* regions, int32_t* counts, int32_t* atom_stats) {
+  ICS_CHECK(mask && species && batch >= 1, "bad segmentation arguments");
+  Net n;
+  ICS_TRY(net_common_init(n));
+  const size_t M = (size_t)batch * d * d * d;
+  unsigned char *dm, *ds;
+  ICS_TRY(n.alloc(&dm, M)); ICS_TRY(n.alloc(&ds, M));
+  ICS_HIP(hipMemcpyAsync(dm, mask, M, hipMemcpyHostToDevice, n.st));
+  ICS_HIP(hipMemcpyAsync(ds, species, M, hipMemcpyHostToDevice, n.st));
+  return segment_to_host(n, dm, ds, batch, d, min_voxels, max_atoms, num_species, regions, counts, atom_stats);
 }
 
 // ---------------------------------------------------------------- data parallel

@@ -294,6 +294,32 @@ class VaeEngine(_Net):
                 L.u8ptr(mk[s]), L.fptr(dens[s]) if want_density else None, L.fptr(mm[s])))
         return {"species": sp, "mask": mk, "density": dens, "coord_minmax": mm}
 
+    def decode_to_atoms(self, unet, z, cond, thresh=0.8, min_voxels=3, max_atoms=512, want_density=True,
+                        want_regions=False):
+        """decode_to_labels continued on the device through connected components + region statistics
+        (generate.py:204-236, watershed.py:52-56,153-187): dict(species, mask, density, coord_minmax, regions | None,
+        n_components (B,), n_atoms (B,), stats int32 (B,max_atoms,11), atoms [(species list, mean list)])."""
+        from .watershed import STAT_FIELDS, _atoms_from_stats
+        z, cond = _f32(z), _f32(cond)
+        B, d = z.shape[0], self.d
+        mb = min(self.max_batch, unet.max_batch)
+        sp = np.empty((B, d, d, d), np.uint8)
+        mk = np.empty((B, d, d, d), np.uint8)
+        dens = np.empty((B, d, d, d), np.float32) if want_density else None
+        reg = np.empty((B, d, d, d), np.int32) if want_regions else None
+        mm = np.zeros((B, 3, 2), np.float32)
+        counts = np.zeros((B, 2), np.int32)
+        stats = np.zeros((B, max_atoms, len(STAT_FIELDS)), np.int32)
+        for i in range(0, B, mb):
+            s = slice(i, i + mb)
+            L.check(self._lib.ics_vae_decode_to_unet_atoms(
+                self._h, unet._h, L.fptr(z[s]), L.fptr(cond[s]), z[s].shape[0], float(thresh), int(min_voxels),
+                int(max_atoms), L.u8ptr(sp[s]), L.u8ptr(mk[s]), L.fptr(dens[s]) if want_density else None,
+                L.fptr(mm[s]), L.i32ptr(reg[s]) if want_regions else None, L.i32ptr(counts[s]), L.i32ptr(stats[s])))
+        return {"species": sp, "mask": mk, "density": dens, "coord_minmax": mm, "regions": reg,
+                "n_components": counts[:, 0].copy(), "n_atoms": counts[:, 1].copy(), "stats": stats,
+                "atoms": _atoms_from_stats(counts, stats, d ** 3)}
+
     def train_step(self, x, cond, eps):
         x, cond, eps, B = self._args(x, cond, eps)
         m = np.zeros(4, np.float32)

@@ -117,6 +117,31 @@ int ics_vae_decode_to_unet_labels(ics_net* vae, ics_net* unet, const float* z, c
                                   float thresh, uint8_t* species, uint8_t* mask, float* density,
                                   float* coord_minmax);
 
+/* Connected-component post-processing on the device: the integer part of watershed_clustering
+ * (/root/reference/watershed.py:190-203) that follows the fused tail in generate.py:228-236 / eval.py.
+ *   - segment_nuclei step 1 (watershed.py:52-56): measure.label(binary, connectivity=1) = 6-connected components
+ *     numbered in raster order of their first voxel; components with <= min_voxels voxels are dropped (reference: 3);
+ *   - R as segment_nuclei returns it when every kept component passes `convexity >= min_convexity`
+ *     (watershed.py:85-92): kept components renumbered 1..n in ascending label order, 0 elsewhere;
+ *   - centroids / majority_vote (watershed.py:153-187) per region: the most frequent non-zero species (equal counts:
+ *     the larger id, as the reference's stable sort leaves it) and the integer coordinate sums of ALL its voxels.
+ * NOT implemented: the convex-hull test (watershed.py:80) and the marker watershed that splits non-convex
+ * components (watershed.py:96-150); the bounding boxes and voxel counts returned here are what a host-side
+ * implementation of those needs.
+ * Outputs: regions int32 (B,d,d,d) or NULL; counts int32 (B,2) = {components, kept components};
+ * atom_stats int32 (B,max_atoms,11) = {species, voxels, sum_z, sum_y, sum_x, z0, y0, x0, z1, y1, x1} (axes 0,1,2 of the
+ * volume -- the reference calls them x,y,z; bounding box half-open), rows >= kept components are empty.
+ * Fails if a sample has more than max_atoms kept components.  Integer atomics only: results are bit-exact. */
+int ics_op_segment_atoms(const uint8_t* mask, const uint8_t* species, int batch, int d, int min_voxels, int max_atoms,
+                         int num_species, int32_t* regions, int32_t* counts, int32_t* atom_stats);
+/* ics_vae_decode_to_unet_labels continued on the device through the component labelling above: the mask and species
+ * volumes never leave HBM between the U-Net and the region statistics.  species/mask/density/coord_minmax/regions
+ * are optional (NULL to skip). */
+int ics_vae_decode_to_unet_atoms(ics_net* vae, ics_net* unet, const float* z, const float* cond, int batch,
+                                 float thresh, int min_voxels, int max_atoms, uint8_t* species, uint8_t* mask,
+                                 float* density, float* coord_minmax, int32_t* regions, int32_t* counts,
+                                 int32_t* atom_stats);
+
 /* ---------------------------------------------------------------- common to both engines */
 int ics_net_destroy(ics_net* net);
 int ics_net_sync(ics_net* net);
