@@ -113,13 +113,17 @@ def _by_kind(entries):
         table[layer][var] = np.asarray(arr)
     kinds = {}
     for layer in order:
-        m = re.match(r"^(conv3d|batch_normalization|dense)(?:_(\d+))?$", layer)
+        # auto-numbered Keras layers; TF1 appends further "_<k>" suffixes to a variable scope whose name is already
+        # taken in the graph (the VAE's conv3d_1 after a load_model'ed U-Net owns conv3d_1: "conv3d_1_1")
+        m = re.match(r"^(conv3d|batch_normalization|dense)((?:_\d+)*)$", layer)
         if m:
-            kinds.setdefault(m.group(1), []).append((int(m.group(2) or 0), layer, table[layer]))
+            nums = tuple(int(v) for v in m.group(2).split("_")[1:])
+            kinds.setdefault(m.group(1), []).append((nums, layer, table[layer]))
         else:
             kinds.setdefault("named", {})[layer] = table[layer]
     for k in ("conv3d", "batch_normalization", "dense"):
-        # Keras numbers layers in creation order; the file lists them in that order too -- sort to be safe
+        # Keras numbers layers in creation order and the file lists them in that order; sorting by the numeric suffixes
+        # (first number first) is the same order and survives a writer that lists them differently
         kinds[k] = [t for _, _, t in sorted(kinds.get(k, []), key=lambda e: e[0])]
     kinds.setdefault("named", {})
     return kinds

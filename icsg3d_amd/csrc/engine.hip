@@ -1967,10 +1967,11 @@ static int segment_to_host(Net& n, const unsigned char* d_mask, const unsigned c
   const size_t wsb = segment_workspace_bytes(batch, d, max_atoms, nbins);
   unsigned char* ws = nullptr;
   int* d_R = nullptr;
-  ICS_HIP(hipMalloc(reinterpret_cast<void**>(&ws), wsb + (regions ? M * 4 : 0)));
+  const size_t wsb16 = (wsb + 15) & ~(size_t)15;
+  ICS_HIP(hipMalloc(reinterpret_cast<void**>(&ws), wsb16 + (regions ? M * 4 : 0)));
   int rc = 0;
   do {
-    if (regions) d_R = reinterpret_cast<int*>(ws + ((wsb + 15) & ~(size_t)15)) ;
+    if (regions) d_R = reinterpret_cast<int*>(ws + wsb16);
     int *d_counts = nullptr, *d_stats = nullptr;
     if ((rc = launch_segment_atoms(n.st, d_mask, d_species, batch, d, min_voxels, max_atoms, nbins, ws, wsb, d_R,
                                    &d_counts, &d_stats)))

@@ -38,6 +38,14 @@ def init_engine_comm(engine, dist, rank: int, world: int, sync_bn: bool = False,
     communicator: exercises the whole data-parallel path on a 1-GPU box)."""
     if world <= 1 and not force:
         return
+    info = engine.comm_info()
+    if info["nranks"] > 0:
+        # idempotent: a second enable_data_parallel / a re-enable after train() finds the communicator in place
+        if (info["nranks"], info["rank"]) != (world, rank):
+            raise RuntimeError("engine already holds a communicator for rank %d of %d, asked for rank %d of %d"
+                               % (info["rank"], info["nranks"], rank, world))
+        engine.set_sync_bn(sync_bn)
+        return
     from .engine import comm_unique_id
     engine.comm_init(rank, world, exchange_unique_id(dist, rank, comm_unique_id))
     engine.set_sync_bn(sync_bn)
@@ -69,6 +77,14 @@ class DataParallelMixin:
     def _dp_attach(self, engine):
         if self._dp is not None:
             dist, rank, world, sync_bn, force = self._dp
+            if world > 1:
+                # creating an engine is a collective (communicator + broadcast): a rank that grows alone -- its batch
+                # differs -- would hang the others in ncclCommInitRank.  Fail loudly instead.
+                sizes = [None] * world
+                dist.all_gather_object(sizes, int(engine.max_batch))
+                if len(set(sizes)) != 1:
+                    raise RuntimeError("data parallel: ranks built engines for different batch sizes %s; shard the "
+                                       "ids with shard_ids() so that every rank sees the same batches" % sizes)
             init_engine_comm(engine, dist, rank, world, sync_bn=sync_bn, force=force)
 
     def _dp_is_writer(self) -> bool:

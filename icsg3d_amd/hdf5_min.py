@@ -20,6 +20,7 @@ this reader.  New-style groups (object header v2 / fractal heaps, libver="latest
 """
 from __future__ import annotations
 
+import os
 import struct
 
 import numpy as np
@@ -555,8 +556,17 @@ class Hdf5Writer:
         sb += struct.pack("<QQII", 0, root_addr, 1, 0) + struct.pack("<QQ", bt, hp)
         assert len(sb) == 96
         out[0:96] = sb
-        with open(path, "wb") as fh:
-            fh.write(bytes(out))
+        # never truncate the target in place: a kill during the write would destroy the only copy of the best weights
+        tmp = "%s.tmp.%d" % (path, os.getpid())
+        try:
+            with open(tmp, "wb") as fh:
+                fh.write(bytes(out))
+                fh.flush()
+                os.fsync(fh.fileno())
+            os.replace(tmp, path)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
 
 
 def is_hdf5(path):

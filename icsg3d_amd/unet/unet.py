@@ -189,7 +189,10 @@ class _UnetModel:
         _save_weight_file(path, self._o._get_weights(), "unet")
 
     def save(self, path):
-        """model.save(.h5) (unet/unet.py:379,389): the weight tree under /model_weights."""
+        """model.save(.h5) (unet/unet.py:379,389): the weight tree under /model_weights, which is all that this
+        package's loaders and Keras' `load_weights` read.  LIMITATION: `model_config` is a stub without the layer graph,
+        so Keras' `load_model` (how the reference's LatticeDFCVAE opens its perceptual U-Net, vae/lattice_vae.py:120)
+        cannot rebuild the network from a file written here -- build AtomUnet() there and `load_weights` the file."""
         _save_weight_file(path, self._o._get_weights(), "unet", full_model=True)
 
 

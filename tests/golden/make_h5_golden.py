@@ -41,20 +41,23 @@ def tiny_weights(kind, seed):
     return w
 
 
-def keras_unet_layers(w, first=1, with_weightless=True):
+def keras_unet_layers(w, first=1, with_weightless=True, scope=""):
     """Keras' model.layers order for AtomUnet (unet/unet.py:272-355): conv, re_lu, batch_normalization per block,
     pools / upsampling / concatenate in between (weightless: empty weight_names), heads last.  `first` shifts the
-    auto-numbering, as happens when the saving process had built other layers before."""
+    auto-numbering, as happens when the saving process had built other layers before.  `scope`: suffix TF1 appends
+    to a VARIABLE scope whose name is already taken in the graph ("conv3d_1" -> "conv3d_1_1"): the layer (group) name
+    stays, the weight names carry the suffix."""
     layers = [("input_1", [])] if with_weightless else []
     for i, n in enumerate(UNET):
         k = first + i
         cv, bn = "conv3d_%d" % k, "batch_normalization_%d" % k
-        layers.append((cv, [(cv + "/kernel:0", w[n + "/kernel"]), (cv + "/bias:0", w[n + "/bias"])]))
+        cvs, bns = cv + scope, bn + scope
+        layers.append((cv, [(cvs + "/kernel:0", w[n + "/kernel"]), (cvs + "/bias:0", w[n + "/bias"])]))
         if with_weightless:
             layers.append(("re_lu_%d" % k, []))
-        layers.append((bn, [(bn + "/gamma:0", w[n + "/gamma"]), (bn + "/beta:0", w[n + "/beta"]),
-                            (bn + "/moving_mean:0", w[n + "/moving_mean"]),
-                            (bn + "/moving_variance:0", w[n + "/moving_var"])]))
+        layers.append((bn, [(bns + "/gamma:0", w[n + "/gamma"]), (bns + "/beta:0", w[n + "/beta"]),
+                            (bns + "/moving_mean:0", w[n + "/moving_mean"]),
+                            (bns + "/moving_variance:0", w[n + "/moving_var"])]))
         if with_weightless and n in ("c2", "c4", "c6"):
             layers.append(("max_pooling3d_%d" % (UNET.index(n) // 2 + 1), []))
         if with_weightless and n in ("c10", "c14", "c16"):
@@ -64,17 +67,23 @@ def keras_unet_layers(w, first=1, with_weightless=True):
     return layers
 
 
-def keras_vae_layers(w, conv0=1, bn0=1, dense0=1):
+def keras_vae_layers(w, conv0=1, bn0=1, dense0=1, scope=""):
     """outer model layers [input, input, encoder, decoder]; nested models list trainable weights, then BN
-    moving statistics (Keras 2.3.1 Network.weights)."""
+    moving statistics (Keras 2.3.1 Network.weights).  `scope`: the suffix the conv3d_* / batch_normalization_*
+    variable scopes get when the perceptual U-Net was rebuilt by load_model first (vae/lattice_vae.py:120): its
+    layers keep their SAVED names conv3d_1..14, Keras' own counter still starts the encoder at conv3d_1, and TF1
+    uniquifies the second scope of that name to conv3d_1_1."""
+    def sc(name):
+        return name + scope if name.startswith(("conv3d_", "batch_normalization_")) else name
+
     def kb(name, n):
-        return [(name + "/kernel:0", w[n + "/kernel"]), (name + "/bias:0", w[n + "/bias"])]
+        return [(sc(name) + "/kernel:0", w[n + "/kernel"]), (sc(name) + "/bias:0", w[n + "/bias"])]
 
     def gb(name, n):
-        return [(name + "/gamma:0", w[n + "/gamma"]), (name + "/beta:0", w[n + "/beta"])]
+        return [(sc(name) + "/gamma:0", w[n + "/gamma"]), (sc(name) + "/beta:0", w[n + "/beta"])]
 
     def mv(name, n):
-        return [(name + "/moving_mean:0", w[n + "/moving_mean"]), (name + "/moving_variance:0", w[n + "/moving_var"])]
+        return [(sc(name) + "/moving_mean:0", w[n + "/moving_mean"]), (sc(name) + "/moving_variance:0", w[n + "/moving_var"])]
 
     enc, enc_s = [], []
     for i in range(4):
@@ -102,6 +111,9 @@ def main():
                   full_model=True, chunked=True)
     # 3. the VAE's nested encoder / decoder models, numbering shifted by a perceptual U-Net built before
     h.write_keras(os.path.join(HERE, "keras_vae_weights.h5"), keras_vae_layers(wv, conv0=15, bn0=15, dense0=1))
+    # 4./5. TF1 scope reuse: weight names with a "_1" scope suffix (see keras_vae_layers)
+    h.write_keras(os.path.join(HERE, "keras_vae_weights_scoped.h5"), keras_vae_layers(wv, scope="_1"))
+    h.write_keras(os.path.join(HERE, "keras_unet_weights_scoped.h5"), keras_unet_layers(wu, 1, scope="_1"))
     for f in sorted(os.listdir(HERE)):
         if f.startswith("keras_"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

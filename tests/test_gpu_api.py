@@ -78,10 +78,16 @@ def test_training_scripts_run_on_synthetic_data(tmp_path):
     assert os.path.exists(tmp_path / "saved_models" / "unet" / "t" / "unet_weights_t.best.h5")
     subprocess.run([sys.executable, os.path.join(root, "train_vae.py")] + common, cwd=tmp_path, env=env, check=True)
     assert os.path.exists(tmp_path / "saved_models" / "vae" / "t" / "vae_weights_t.best.h5")
-    subprocess.run([sys.executable, os.path.join(root, "generate.py"), "--name", "t", "--channels", "1", "--d", "16",
-                    "--batch_size", "2", "--nsamples", "4"], cwd=tmp_path, env=env, check=True)
-    sp = np.load(tmp_path / "output" / "results" / "synthetic__v=0.5" / "species" / "3.npy")
+    # the reference's own flags (generate.py:52-102) are accepted; --synthetic stands in for the base compound
+    subprocess.run([sys.executable, os.path.join(root, "generate.py"), "--name", "t", "--synthetic", "--channels", "1",
+                    "--d", "16", "--batch_size", "2", "--nsamples", "4", "--eps_frac", "0.3", "--clus_iters", "3",
+                    "--alpha", "90", "--beta", "90", "--gamma", "120", "--target", "band_gap", "--ncond", "10"],
+                   cwd=tmp_path, env=env, check=True)
+    res = tmp_path / "output" / "results" / "synthetic__v=0.5"
+    sp = np.load(res / "species" / "3.npy")
     assert sp.shape == (16, 16, 16) and sp.dtype == np.uint8
+    co = np.load(res / "coords" / "3.npy")
+    assert co.ndim == 2 and co.shape[1] == 4
 
 
 def test_batches_below_max_batch_match_a_right_sized_engine():

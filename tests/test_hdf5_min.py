@@ -57,6 +57,13 @@ def test_writer_reader_round_trip_bit_equal(tmp_path, kind, seed):
         _eq(K.load_weights(p, kind), w)
 
 
+def test_tf1_scope_suffixed_weight_names():
+    """a VAE saved by a process that had load_model'ed the perceptual U-Net first carries variable scopes
+    conv3d_1_1 / batch_normalization_1_1 ... (libhdf5-written fixtures; the U-Net case for symmetry)."""
+    _eq(K.load_weights(os.path.join(HERE, "golden", "keras_vae_weights_scoped.h5"), "vae"), G.tiny_weights("vae", 12))
+    _eq(K.load_weights(os.path.join(HERE, "golden", "keras_unet_weights_scoped.h5"), "unet"), G.tiny_weights("unet", 11))
+
+
 def test_shape_validation_and_container_sniffing(tmp_path):
     w = G.tiny_weights("unet", 3)
     p = str(tmp_path / "u.hdf5")

@@ -16,6 +16,7 @@ averaged with RCCL inside the engine; --sync_bn 1 exchanges the BatchNorm batch 
 launcher spell --d as --dim: torch.distributed.run's own parser rejects `--d` as an ambiguous abbreviation.
 """
 import argparse
+import json
 import os
 
 import numpy as np
@@ -64,10 +65,13 @@ if __name__ == "__main__":
         class_weights = get_weights()
     else:
         training_ids, validation_ids = data_split(path, a.samples, frac=a.split, n_rot=a.nrot)
-        all_training_ids = training_ids
+        all_training_ids, all_validation_ids = training_ids, validation_ids
         if world > 1:
             training_ids = shard_ids(training_ids, rank, world, a.batch_size)
             validation_ids = shard_ids(validation_ids, rank, world, a.batch_size)
+        if rank == 0:                            # provenance: which files this run trained / validated on, in order
+            with open(os.path.join("output", "unet", mode, "split_ids.json"), "w") as f:
+                json.dump({"train": all_training_ids, "val": all_validation_ids}, f)
         training_generator = UnetDataGenerator(training_ids, data_path=path, batch_size=a.batch_size, dim=(d, d, d),
                                                n_channels=a.channels, shuffle=True)
         validation_generator = UnetDataGenerator(validation_ids, data_path=path, batch_size=a.batch_size, dim=(d, d, d),

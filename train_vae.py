@@ -9,6 +9,7 @@ saved_models/unet/<name>/unet_weights_<name>.best.h5 written by train_unet.py.  
 trains on its share of the ids at the PER-GPU --batch_size (train_unet.py explains the flags).
 """
 import argparse
+import json
 import os
 
 from icsg3d_amd.dataparallel import from_env, shard_ids
@@ -56,6 +57,9 @@ if __name__ == "__main__":
             training_ids = training_ids[:-1 * int(len(training_ids) % bs)]
         if len(validation_ids) % bs != 0:
             validation_ids = validation_ids[:-1 * int(len(validation_ids) % bs)]
+        if rank == 0:                            # provenance: which files this run trained / validated on, in order
+            with open(os.path.join("output", "vae", mode, "split_ids.json"), "w") as f:
+                json.dump({"train": training_ids, "val": validation_ids}, f)
         if world > 1:
             training_ids = shard_ids(training_ids, rank, world, bs)
             validation_ids = shard_ids(validation_ids, rank, world, bs)
