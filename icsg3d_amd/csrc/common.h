@@ -80,6 +80,7 @@ enum ConvFlags : int {
   CF_NO_COND_FOLD = 128,  // ICSG3D_NO_COND_FOLD: the VAE encoder's K.tile'd condition as materialised input channels
   CF_NO_WINO = 256,       // ICSG3D_NO_WINO: 3x3x3 layers through the 27-tap implicit GEMM instead of Winograd F(2,3)
   CF_NO_WINO_WGRAD = 512, // ICSG3D_NO_WINO_WGRAD: backward-weight through the direct kernels, Winograd forward/backward-data kept
+  CF_NO_WINO64 = 1024,    // ICSG3D_NO_WINO64: Winograd forward/backward-data through the 32-tile x 32-channel kernel only
 };
 int conv_flags_from_env();
 
@@ -177,7 +178,16 @@ int launch_conv_fwd_wino(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, c
 // dst[Nn/32][K/4][64 f][2][32][2] = (G (x) G (x) G) applied to the 27 taps of
 //   bwd = 0: w[tap][c_off + k][n]          (forward: K = Csub input channels of Cin_total, Nn = Cout)
 //   bwd = 1: w[26 - tap][c_off + n][k]     (backward-data: K = Cout, Nn = Csub input channels)
-int launch_pack_wino(hipStream_t st, const float* w, int Cin_total, int Cout, int c_off, int Csub, int bwd, float* dst);
+// layout 0: conv_wino.hip's operand; layout 1: conv_wino64.hip's dst[Nn/64][K/4][64 f][4 k][16 n][4 column blocks].
+// conv_wino_layout(g) is the layout launch_conv_fwd_wino will read for GEMM geometry g (g.Cin = K, g.Cout = Nn).
+int launch_pack_wino(hipStream_t st, const float* w, int Cin_total, int Cout, int c_off, int Csub, int bwd, float* dst,
+                     int layout = 0);
+int conv_wino_layout(const ConvGeom& g);
+// the 16-tile x 64-channel kernel shape (conv_wino64.hip): Cout % 64 == 0; launch_conv_fwd_wino dispatches to it
+bool conv_wino64_ok(const ConvGeom& g, const ConvSrc* src, int nsrc);
+int launch_conv_fwd_wino64(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, const float* wt, const float* bias,
+                           float* out, int ldo, int pre_act, float* stat_partial, int* rows_per_block, int accumulate,
+                           const BwdStat* bwd = nullptr, int* bwd_blocks = nullptr);
 // backward-weight in the Winograd domain; workspace / sub_rows / row_pitch / row_off / phase as launch_conv_wgrad
 bool conv_wino_wgrad_ok(const ConvGeom& g, const ConvSrc* src, int nsrc);
 size_t conv_wino_wgrad_workspace_floats(const ConvGeom& g);

@@ -52,6 +52,7 @@ int conv_flags_from_env() {
   if (getenv("ICSG3D_NO_COND_FOLD")) f |= CF_NO_COND_FOLD;
   if (getenv("ICSG3D_NO_WINO")) f |= CF_NO_WINO;
   if (getenv("ICSG3D_NO_WINO_WGRAD")) f |= CF_NO_WINO_WGRAD;
+  if (getenv("ICSG3D_NO_WINO64")) f |= CF_NO_WINO64;
   return f;
 }
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remember per (kernel instantiation, device)
@@ -2793,13 +2794,19 @@ int launch_pack_bwd(hipStream_t st, const float* w, int taps, int Cin, int Cout,
 // Thread t of a job = one (k, n) pair, t = (((nchunk * K/4 + c4) * 2 + h) * 32 + n32) * 2 + j: it reads the pair's 27 taps
 // once, applies U = (G (x) G (x) G) g with G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1] one axis at a time and writes the
 // 64 frequencies (a half-wave writes 128 contiguous floats per frequency).
+// layout 1 (conv_wino64.hip): dst[Nn/64][K/4][64 f][4 k][16 n][4 column blocks]; t = ((nchunk * K/4 + c4) * 256 +
+// (kk * 16 + n16) * 4 + nb: consecutive threads write consecutive floats of one frequency image.
 __device__ __forceinline__ void pack_wino_pair(size_t t, const float* __restrict__ w, int Cin_total, int Cout, int c_off,
-                                               int Csub, int bwd, float* __restrict__ dst) {
+                                               int Csub, int bwd, float* __restrict__ dst, int layout) {
   const int K = bwd ? Cout : Csub;
   const int j = (int)(t & 1), n32 = (int)((t >> 1) & 31), h = (int)((t >> 6) & 1);
-  const size_t rest = t >> 7;
+  const size_t rest = layout ? t >> 8 : t >> 7;
   const int c4 = (int)(rest % (size_t)(K / 4)), nchunk = (int)(rest / (size_t)(K / 4));
-  const int k = c4 * 4 + h * 2 + j, n = nchunk * 32 + n32;
+  int k = c4 * 4 + h * 2 + j, n = nchunk * 32 + n32;
+  if (layout) {
+    const int nbk = (int)(t & 3), n16 = (int)((t >> 2) & 15), kk = (int)((t >> 6) & 3);
+    k = c4 * 4 + kk; n = nchunk * 64 + nbk * 16 + n16;
+  }
   float g[27];
 #pragma unroll
   for (int tap = 0; tap < 27; ++tap)
@@ -2819,29 +2826,35 @@ __device__ __forceinline__ void pack_wino_pair(size_t t, const float* __restrict
       const float g0 = gx[a * 3][fx], g1 = gx[a * 3 + 1][fx], g2 = gx[a * 3 + 2][fx];
       gy[a][0][fx] = g0; gy[a][1][fx] = 0.5f * (g0 + g1 + g2); gy[a][2][fx] = 0.5f * (g0 - g1 + g2); gy[a][3][fx] = g2;
     }
-  float* d = dst + ((size_t)rest * 64 * 2 + h) * 64 + n32 * 2 + j;        // + f * 128
+  const int fs = layout ? 256 : 128;                                        // floats per frequency image
+  float* d = layout ? dst + (size_t)rest * 64 * 256 + (t & 255)
+                    : dst + ((size_t)rest * 64 * 2 + h) * 64 + n32 * 2 + j;    // + f * fs
 #pragma unroll
   for (int fy = 0; fy < 4; ++fy)
 #pragma unroll
     for (int fx = 0; fx < 4; ++fx) {
       const float g0 = gy[0][fy][fx], g1 = gy[1][fy][fx], g2 = gy[2][fy][fx];
-      d[(0 * 16 + fy * 4 + fx) * 128] = g0;
-      d[(1 * 16 + fy * 4 + fx) * 128] = 0.5f * (g0 + g1 + g2);
-      d[(2 * 16 + fy * 4 + fx) * 128] = 0.5f * (g0 - g1 + g2);
-      d[(3 * 16 + fy * 4 + fx) * 128] = g2;
+      d[(0 * 16 + fy * 4 + fx) * fs] = g0;
+      d[(1 * 16 + fy * 4 + fx) * fs] = 0.5f * (g0 + g1 + g2);
+      d[(2 * 16 + fy * 4 + fx) * fs] = 0.5f * (g0 - g1 + g2);
+      d[(3 * 16 + fy * 4 + fx) * fs] = g2;
     }
 }
 __global__ void pack_wino_kernel(const float* __restrict__ w, int Cin_total, int Cout, int c_off, int Csub, int bwd,
-                                 float* __restrict__ dst, size_t pairs) {
+                                 float* __restrict__ dst, size_t pairs, int layout) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= pairs) return;
-  pack_wino_pair(t, w, Cin_total, Cout, c_off, Csub, bwd, dst);
+  pack_wino_pair(t, w, Cin_total, Cout, c_off, Csub, bwd, dst, layout);
 }
-int launch_pack_wino(hipStream_t st, const float* w, int Cin_total, int Cout, int c_off, int Csub, int bwd, float* dst) {
+int conv_wino_layout(const ConvGeom& g) {
+  return (!(g.flags & CF_NO_WINO64) && g.Cout % 64 == 0 && g.Cin % 32 == 0) ? 1 : 0;
+}
+int launch_pack_wino(hipStream_t st, const float* w, int Cin_total, int Cout, int c_off, int Csub, int bwd, float* dst,
+                     int layout) {
   const size_t pairs = (size_t)Csub * Cout;
-  if (g_pack_rec) { g_pack_rec->push_back(PackJob{5, w, dst, {Cin_total, Cout, c_off, Csub, bwd, 0, 0, 0, 0}, (unsigned long long)pairs, 0}); return 0; }
+  if (g_pack_rec) { g_pack_rec->push_back(PackJob{5, w, dst, {Cin_total, Cout, c_off, Csub, bwd, layout, 0, 0, 0}, (unsigned long long)pairs, 0}); return 0; }
   hipLaunchKernelGGL(pack_wino_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, w, Cin_total, Cout,
-                     c_off, Csub, bwd, dst, pairs);
+                     c_off, Csub, bwd, dst, pairs, layout);
   ICS_HIP(hipGetLastError());
   return 0;
 }
@@ -2870,7 +2883,7 @@ __global__ __launch_bounds__(256) void pack_table_kernel(const PackJob* __restri
     case 1: if (pack_bwd_value(i, J.w, a[0], a[1], a[2], a[3], a[4], a[5], &v)) J.dst[i] = v; break;
     case 2: J.dst[i] = pack_sub_value(i, J.w, a[0], a[1], a[2], a[3], a[4], a[5], a[6]); break;
     case 3: J.dst[i] = pack_fwd_sub_value(i, J.w, a[0], a[1], a[2], a[3], a[4], a[5]); break;
-    case 5: pack_wino_pair(i, J.w, a[0], a[1], a[2], a[3], a[4], J.dst); break;
+    case 5: pack_wino_pair(i, J.w, a[0], a[1], a[2], a[3], a[4], J.dst, a[5]); break;
     default: J.dst[i] = pack_par_value(i, J.w, a[0], a[1], a[2], a[3], a[4], a[5]); break;
   }
 }

@@ -671,6 +671,9 @@ int launch_conv_fwd_wino(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, c
                          float* out, int ldo, int pre_act, float* stat_partial, int* rows_per_block, int accumulate,
                          const BwdStat* bwd, int* bwd_blocks) {
   ICS_CHECK(conv_wino_ok(g, &s0, 1), "shape not served by the Winograd kernel");
+  if (conv_wino64_ok(g, &s0, 1))                 // Cout % 64 == 0: the 16-tile x 64-channel shape (weights in layout 1)
+    return launch_conv_fwd_wino64(st, g, s0, wt, bias, out, ldo, pre_act, stat_partial, rows_per_block, accumulate, bwd,
+                                  bwd_blocks);
   ICS_CHECK(ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
                 (reinterpret_cast<uintptr_t>(bias) & 15) == 0 && (reinterpret_cast<uintptr_t>(s0.p) & 15) == 0,
             "Winograd kernel: float4 accesses need 16-byte aligned tensors");

@@ -1,0 +1,458 @@
+// Winograd F(2x2x2, 3x3x3) forward / backward-data, second kernel shape (gfx950 / MI355X only): one workgroup =
+// 16 tiles (2x2x4 tiles = 4x4x8 voxels) x 64 output channels x all 64 frequencies on v_mfma_f32_16x16x4_f32.
+//
+// Same operator and same algebra as conv_wino.hip (Keras Conv3D 3x3x3 "same", /root/reference/unet/unet.py:283-336);
+// what changes is the shape of the per-frequency GEMM tile, 16 tiles x 64 channels instead of 32 x 32:
+//   * the transformed input (the MFMA A operand) is built ONCE per (tile, input channel, frequency) and feeds FOUR
+//     16x16x4 MFMAs (four 16-channel column blocks) instead of one 32-wide tile: the transform's VALU instructions per
+//     MFMA cycle halve (fp32 VALU and fp32 MFMA share the issue port on this chip: every VALU instruction is MFMA
+//     time lost -- scripts/probes/mfma_filler.hip);
+//   * the halo block is [6][6][10] voxels for 128 outputs x 64 channels instead of [6][10][10] for 256 x 32: 0.6x the
+//     staging work and 0.6x the input re-reads per MFMA (Cout/64 instead of Cout/32 n-chunks);
+//   * a buffer of 32 input channels is 64 KB, so the K loop runs in chunks of 32 channels, double buffered: half the
+//     barriers per channel and twice the distance between a chunk's global loads and their first use.
+// 8 waves, two per SIMD: wave w owns the 8 frequencies (fz = w >> 1, fy in {2 (w & 1), 2 (w & 1) + 1}, fx = 0..3) x 4
+// column blocks = 32 accumulators of 4 registers.  MFMA lane l: A[tile = l & 15][k = l >> 4], B[k = l >> 4][n = l & 15],
+// D[tile = 4 (l >> 4) + reg][n = l & 15].  Staging as in conv_wino.hip: thread t < 480 owns one (y, x, channel quad)
+// column of the halo, applies the producer's BatchNorm affine, the zero padding after it and the z rows of B^T, and
+// writes the eight z-combined planes (tile z, fz).  LDS: voxel pitch 33 floats, row pitch 332, plane pitch 1996:
+// the 32 lanes of a ds_read_b32 group (16 tiles x 2 channels) hit 32 distinct banks for every (fz, row, column,
+// sub-step) -- checked exhaustively.  Weights: [Cout/64][Cin/4][64 f][4 k][16 n][4 column blocks],
+// one ds-free global_load_dwordx4 per frequency and sub-step, a wave's sub-step = 8 KB contiguous.
+#include "common.h"
+
+#include <algorithm>
+#include <type_traits>
+
+namespace ics {
+
+typedef float vf4 __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr int KC = 32;                                   // input channels per LDS chunk
+constexpr int VX = KC + 1, RP = 10 * VX + 2, PP = 6 * RP + 4, BUF = 8 * PP;   // floats: 33 / 332 / 1996 / 15 968 (63 872 B)
+constexpr int kRows = 128;                               // voxels per workgroup
+
+__device__ __forceinline__ float wact(float v, float slope) { return fmaxf(v, v * slope); }
+__host__ __device__ __forceinline__ float wslope(int act) { return act == ACT_RELU ? 0.f : (act == ACT_LRELU ? kLeaky : 1.f); }
+}  // namespace
+
+template <bool AFF, bool NOACT, bool FOLD>
+__global__ __launch_bounds__(512) void conv_wino64_kernel(const float* __restrict__ x, int ldx,
+                                                          const float* __restrict__ in_scale,
+                                                          const float* __restrict__ in_shift, float in_slope,
+                                                          const float* __restrict__ wt, const float* __restrict__ bias,
+                                                          float* __restrict__ y, int ldo, float pre_slope,
+                                                          int accumulate, float* __restrict__ stat_partial, int Npad,
+                                                          int S, int Cin, int Cout, BwdStat bs) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * BUF + (AFF ? 2048 : 0)];   // 127 744 B (+ 8 KB); the epilogue reuses it
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fz = w >> 1, fyh = w & 1;            // this wave: frequencies (fz, 2 fyh + {0,1}, 0..3)
+  const int m = lane & 15, kq = lane >> 4;
+  const int nchunks = Cout >> 6;
+  const int nb = blockIdx.x % nchunks;           // the n-chunks of one tile block are neighbours in launch order: an XCD
+  const int tblk = blockIdx.x / nchunks;         // (blockIdx mod 8) keeps ONE n-chunk's weights hot in its L2
+  int tb = tblk;
+  const int nbx = S >> 3, nby = S >> 2, nbz = S >> 2;
+  const int bx = tb % nbx; tb /= nbx;
+  const int by = tb % nby; tb /= nby;
+  const int bz = tb % nbz;
+  const int b = tb / nbz;
+  const int oz = bz * 4, oy = by * 4, ox = bx * 8, n0 = nb * 64;
+  const bool edge = bx == 0 || by == 0 || bz == 0 || bx == nbx - 1 || by == nby - 1 || bz == nbz - 1;   // uniform
+
+  // ---- staging: thread t < 480 owns one (hy, hx, channel quad) column of the halo block [6][6][10] x 32 channels
+  const int cmb = tid < 480 ? tid : 479;
+  const int q = cmb & 7, hx = (cmb >> 3) % 10, hy = (cmb >> 3) / 10;
+  // Buffer loads: ONE per-lane byte offset (the clamped (y, x) position and the channel quad) in a VGPR; the
+  // clamped z plane of each of the six loads and the channel chunk go into the scalar offset operand (six 64-bit
+  // per-lane pointers cost 12 VGPRs, which the allocator spilled).
+  vf4 stage[6];
+  unsigned zoff[6];                              // uniform: byte offset of sample b, plane clamp(oz - 1 + hz)
+  unsigned okmask = 0;
+  unsigned voff;
+  {
+    const int gy = oy - 1 + hy, gx = ox - 1 + hx;
+    const bool okyx = gy >= 0 && gy < S && gx >= 0 && gx < S;
+    const int cy = min(max(gy, 0), S - 1), cx = min(max(gx, 0), S - 1);
+    voff = (unsigned)((cy * S + cx) * ldx + q * 4) * 4u;
+#pragma unroll
+    for (int hz = 0; hz < 6; ++hz) {
+      const int gz = oz - 1 + hz;
+      okmask |= (okyx && gz >= 0 && gz < S) ? (1u << hz) : 0u;
+      const int cz = min(max(gz, 0), S - 1);
+      zoff[hz] = (unsigned)((b * S + cz) * S * S * ldx) * 4u;
+    }
+  }
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, 0x7fffffff, 0x00020000);
+  const int dbase = hy * RP + hx * VX + q * 4;   // + plane * PP + buffer
+  // AFF: the producer's per-channel scale / shift of ALL input channels sit in LDS behind the two buffers (Cin <= 1024:
+  // 8 KB), read back per chunk at store time -- eight registers less to keep live through the main loop
+  float* aff = lds + 2 * BUF;
+  if (AFF) {
+    for (int i = tid; i < Cin; i += 512) { aff[i] = in_scale[i]; aff[1024 + i] = in_shift[i]; }
+  }
+  auto gload = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      stage[i] = __builtin_bit_cast(vf4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)voff, (int)(zoff[i] + (unsigned)c0 * 4u), 0));
+  };
+  auto sstore = [&](const int bo, const int c0) {
+    if (AFF) {
+      const vf4 sc4 = *reinterpret_cast<const vf4*>(&aff[c0 + q * 4]);
+      const vf4 sh4 = *reinterpret_cast<const vf4*>(&aff[1024 + c0 + q * 4]);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        vf4 t = stage[i];
+        t.x = fmaf(t.x, sc4.x, sh4.x); t.y = fmaf(t.y, sc4.y, sh4.y);
+        t.z = fmaf(t.z, sc4.z, sh4.z); t.w = fmaf(t.w, sc4.w, sh4.w);
+        if (!NOACT) { t.x = wact(t.x, in_slope); t.y = wact(t.y, in_slope); t.z = wact(t.z, in_slope); t.w = wact(t.w, in_slope); }
+        stage[i] = t;
+      }
+    }
+    if (edge) {                                  // "same" padding: zeros AFTER the producer's affine / activation
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+        if (!((okmask >> i) & 1)) stage[i] = vf4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (tid < 480) {
+      float* o = &lds[bo + dbase];
+#pragma unroll
+      for (int tz = 0; tz < 2; ++tz) {
+        const vf4 d0 = stage[2 * tz], d1 = stage[2 * tz + 1], d2 = stage[2 * tz + 2], d3 = stage[2 * tz + 3];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {            // one plane at a time: four live temporaries, not sixteen
+          const vf4 c = f == 0 ? d0 - d2 : (f == 1 ? d1 + d2 : (f == 2 ? d2 - d1 : d1 - d3));
+          float* op = o + (tz * 4 + f) * PP;     // odd voxel pitch: four dword stores
+          op[0] = c.x; op[1] = c.y; op[2] = c.z; op[3] = c.w;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  };
+
+  // In the main loop the halo of the next chunk is staged in TWO phases of four z rows each -- rows 0..3 -> the planes of
+  // tile z 0, rows 2..5 -> tile z 1 (rows 2, 3 are read twice, from L1 / L2) -- so that 16 instead of 24 registers are in
+  // flight next to the accumulators; the prologue, where nothing else is live yet, uses the six-row form above.
+  vf4 hs[4];
+  auto hload = [&](const int tzh, int c0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      hs[i] = __builtin_bit_cast(vf4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)voff, (int)(zoff[2 * tzh + i] + (unsigned)c0 * 4u), 0));
+  };
+  auto hstore = [&](const int tzh, const int bo, const int c0) {
+    if (AFF) {
+      const vf4 sc4 = *reinterpret_cast<const vf4*>(&aff[c0 + q * 4]);
+      const vf4 sh4 = *reinterpret_cast<const vf4*>(&aff[1024 + c0 + q * 4]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        vf4 t = hs[i];
+        t.x = fmaf(t.x, sc4.x, sh4.x); t.y = fmaf(t.y, sc4.y, sh4.y);
+        t.z = fmaf(t.z, sc4.z, sh4.z); t.w = fmaf(t.w, sc4.w, sh4.w);
+        if (!NOACT) { t.x = wact(t.x, in_slope); t.y = wact(t.y, in_slope); t.z = wact(t.z, in_slope); t.w = wact(t.w, in_slope); }
+        hs[i] = t;
+      }
+    }
+    if (edge) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (!((okmask >> (2 * tzh + i)) & 1)) hs[i] = vf4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (tid < 480) {
+      float* o = &lds[bo + dbase + tzh * 4 * PP];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const vf4 c = f == 0 ? hs[0] - hs[2] : (f == 1 ? hs[1] + hs[2] : (f == 2 ? hs[2] - hs[1] : hs[1] - hs[3]));
+        float* op = o + f * PP;
+        op[0] = c.x; op[1] = c.y; op[2] = c.z; op[3] = c.w;
+      }
+    }
+  };
+
+  // ---- per-lane read geometry.  tile m = (tz, ty, tx).  The wave's two fy rows of B^T need rows (a, b, c) of the
+  // combined plane:  fy = 2 fyh:  R_a - R_b,   fy = 2 fyh + 1:  R_b + sg R_c   with (a,b,c,sg) = (0,2,1,+) / (2,1,3,-)
+  const int tz = m >> 3, ty = (m >> 2) & 1, tx = m & 3;
+  const float sg = fyh ? -1.f : 1.f;
+  auto rowbase = [&](int iy) { return (tz * 4 + fz) * PP + (2 * ty + iy) * RP + 2 * tx * VX + kq; };
+  const int Ra0 = rowbase(fyh ? 2 : 0), Rb0 = rowbase(fyh ? 1 : 2), Rc0 = rowbase(fyh ? 3 : 1);
+
+  const int nsub = Cin >> 2;
+  constexpr int wstride_f = 256;                 // floats per frequency of one sub-step: [4 k][16 n][4 column blocks]
+  constexpr int wsub = 64 * 256;
+  // buffer loads again: one per-lane byte offset, everything else (n-chunk, wave, sub-step, frequency) scalar
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(wt + ((size_t)nb * nsub * 64 + fz * 16 + fyh * 8) * 256), 0, 0x7fffffff, 0x00020000);
+  const int wlane = lane * 16;                   // bytes
+  auto wload = [&](int gs, int f) {              // sub-step gs, local frequency f
+    return __builtin_bit_cast(vf4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wlane, (gs * wsub + f * wstride_f) * 4, 0));
+  };
+  vf4 wreg[8];
+#pragma unroll
+  for (int f = 0; f < 8; ++f) wreg[f] = wload(0, f);
+
+  vf4 acc[8][4];                                 // [frequency fy_local * 4 + fx][column block]
+#pragma unroll
+  for (int f = 0; f < 8; ++f)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[f][j] = vf4{0.f, 0.f, 0.f, 0.f};
+
+  float u[8], tn[2][4], qa, qb, qc;
+  auto xform = [&]() {
+#pragma unroll
+    for (int fy = 0; fy < 2; ++fy) {
+      u[fy * 4 + 0] = tn[fy][0] - tn[fy][2];
+      u[fy * 4 + 1] = tn[fy][1] + tn[fy][2];
+      u[fy * 4 + 2] = tn[fy][2] - tn[fy][1];
+      u[fy * 4 + 3] = tn[fy][1] - tn[fy][3];
+    }
+  };
+
+  gload(0);
+  if (AFF) __syncthreads();                      // scale / shift visible
+  sstore(0, 0);
+  __syncthreads();
+
+  auto rd = [&](const int ra, const int rb, const int rc, const int sub, const int col) {
+    const int off = col * VX + 4 * sub;          // compile-time after unrolling
+    qa = lds[ra + off]; qb = lds[rb + off]; qc = lds[rc + off];
+  };
+  int Ra = Ra0, Rb = Rb0, Rc = Rc0;              // row bases of the buffer being read
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    rd(Ra, Rb, Rc, 0, g);
+    tn[0][g] = qa - qb;
+    tn[1][g] = fmaf(sg, qc, qb);
+  }
+  xform();
+  rd(Ra, Rb, Rc, 1, 0);                          // column 0 of sub-step 1
+
+  const int nch = Cin / KC;
+  int nxt = BUF;                                 // float offset of the buffer being filled (the other one is consumed)
+  for (int ch = 0; ch < nch; ++ch) {
+    const int cn = (ch + 1 < nch ? ch + 1 : ch) * KC;                   // past the end: the last chunk again (never consumed)
+    const int dlt = 2 * nxt - BUF;               // + BUF / - BUF: from the buffer being consumed to the other one
+    hload(0, cn);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      int gs = ch * 8 + s + 1;
+      gs = gs < nsub ? gs : nsub - 1;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float a = qa, bq = qb, c = qc;
+        if (s == 3 && g == 3) {                  // first half of the next chunk's planes; then the second half's rows
+          hstore(0, nxt, cn);
+          hload(1, cn);
+        }
+        if (s == 6 && g == 3) {                  // the next chunk must be visible before its first column is read
+          hstore(1, nxt, cn);
+          __syncthreads();
+          Ra += dlt; Rb += dlt; Rc += dlt;       // every read from here on is in the other buffer
+        }
+        // reads of the next column: column g+1 of sub-step s+1, or column 0 of sub-step s+2
+        if (g < 3) rd(Ra, Rb, Rc, (s + 1) & 7, g + 1);
+        else rd(Ra, Rb, Rc, (s + 2) & 7, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#define ICS_WMF(F, J) acc[F][J] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[F], wreg[F][J], acc[F][J], 0, 0, 0)
+#define ICS_WFN __builtin_amdgcn_sched_barrier(0)
+        // consecutive MFMAs on different accumulators; the column math of the next sub-step in between
+        ICS_WMF(g, 0); ICS_WMF(4 + g, 0); tn[0][g] = a - bq; ICS_WFN;
+        ICS_WMF(g, 1); ICS_WMF(4 + g, 1); tn[1][g] = fmaf(sg, c, bq); ICS_WFN;
+        ICS_WMF(g, 2); ICS_WMF(4 + g, 2); ICS_WFN;
+        ICS_WMF(g, 3); ICS_WMF(4 + g, 3); ICS_WFN;
+#undef ICS_WMF
+        wreg[g] = wload(gs, g);
+        wreg[4 + g] = wload(gs, 4 + g);
+        ICS_WFN;
+#undef ICS_WFN
+      }
+      xform();
+    }
+    nxt = BUF - nxt;
+  }
+
+  // ---------------------------------------------------------------- epilogue, two passes of two column blocks each
+  // lane l holds D[tile = 4 kq + i][n = l & 15]: tile = (tz, ty, tx) with (tz, ty) = kq, tx = i
+  float* part = lds;                             // [8 w][32 slots = (jl * 4 + i) * 4 + dy * 2 + dx][64 lanes]  (64 KB)
+  float* red = lds + 16384;                      // [8 w][64] + [64] + [8 w][64]
+  // final-stage task of this thread: cq = tid & 3 (channel quad of a column block), jl = (tid >> 2) & 1, o = (tid >> 3) & 3
+  // (= dy * 2 + dx), tile = tid >> 5
+  const int cq = tid & 3, jl = (tid >> 2) & 1, o = (tid >> 3) & 3, tile = tid >> 5;
+  const int ttz = tile >> 3, tty = (tile >> 2) & 1, ttx = tile & 3;
+  const int vz = oz + 2 * ttz, vy = oy + 2 * tty + (o >> 1), vx = ox + 2 * ttx + (o & 1);
+  const size_t vox0 = (((size_t)b * S + vz) * S + vy) * S + vx;
+  const int slot_rd = ((jl * 4 + ttx) * 4 + o) * 64 + (tile >> 2) * 16 + cq * 4;
+  vf4 val[2][2];
+  vf4 csum[2];
+  vf4 f1[2], f2s[2];
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int j = pass * 2 + jj;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float qv[2][2];                          // [fy local][dx]
+#pragma unroll
+        for (int fy = 0; fy < 2; ++fy) {
+          qv[fy][0] = acc[fy * 4 + 0][j][i] + acc[fy * 4 + 1][j][i] + acc[fy * 4 + 2][j][i];
+          qv[fy][1] = acc[fy * 4 + 1][j][i] - acc[fy * 4 + 2][j][i] - acc[fy * 4 + 3][j][i];
+        }
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          // rows of A^T: the wave with fy 0,1 gives dy0 += q0 + q1, dy1 += q1; the one with fy 2,3: dy0 += q0, dy1 -= q0 + q1
+          const float d0 = fyh ? qv[0][dx] : qv[0][dx] + qv[1][dx];
+          const float d1 = fyh ? -qv[0][dx] - qv[1][dx] : qv[1][dx];
+          part[(w * 32 + (jj * 4 + i) * 4 + 0 + dx) * 64 + lane] = d0;
+          part[(w * 32 + (jj * 4 + i) * 4 + 2 + dx) * 64 + lane] = d1;
+        }
+      }
+    }
+    __syncthreads();
+    const int nn = n0 + (pass * 2 + jl) * 16 + cq * 4;             // this thread's four output channels
+    vf4 p[4];
+#pragma unroll
+    for (int z = 0; z < 4; ++z)
+      p[z] = *reinterpret_cast<const vf4*>(&part[(2 * z) * 2048 + slot_rd]) +
+             *reinterpret_cast<const vf4*>(&part[(2 * z + 1) * 2048 + slot_rd]);
+    vf4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias != nullptr) bv = *reinterpret_cast<const vf4*>(bias + nn);
+    const size_t o0 = vox0 * ldo + nn;
+    const size_t o1 = o0 + (size_t)S * S * ldo;
+    vf4 e0 = p[0] + p[1] + p[2] + bv, e1 = p[1] - p[2] - p[3] + bv;
+    if (accumulate) {
+      e0 += *reinterpret_cast<const vf4*>(y + o0);
+      e1 += *reinterpret_cast<const vf4*>(y + o1);
+    }
+    e0.x = wact(e0.x, pre_slope); e0.y = wact(e0.y, pre_slope); e0.z = wact(e0.z, pre_slope); e0.w = wact(e0.w, pre_slope);
+    e1.x = wact(e1.x, pre_slope); e1.y = wact(e1.y, pre_slope); e1.z = wact(e1.z, pre_slope); e1.w = wact(e1.w, pre_slope);
+    *reinterpret_cast<vf4*>(y + o0) = e0;
+    *reinterpret_cast<vf4*>(y + o1) = e1;
+    val[pass][0] = e0; val[pass][1] = e1;
+    csum[pass] = e0 + e1;
+    if (FOLD) {
+      const vf4 b_mu = *reinterpret_cast<const vf4*>(bs.mean + nn), b_rs = *reinterpret_cast<const vf4*>(bs.rstd + nn);
+      const size_t s0 = vox0 * bs.ld + nn;
+      const vf4 sv0 = *reinterpret_cast<const vf4*>(bs.s + s0);
+      const vf4 sv1 = *reinterpret_cast<const vf4*>(bs.s + s0 + (size_t)S * S * bs.ld);
+      vf4 d0 = e0, d1 = e1;
+      if (bs.post_act != ACT_NONE) {
+        const vf4 b_sc = *reinterpret_cast<const vf4*>(bs.scale + nn), b_sh = *reinterpret_cast<const vf4*>(bs.shift + nn);
+        const vf4 z0 = sv0 * b_sc + b_sh, z1 = sv1 * b_sc + b_sh;
+        d0.x *= act_grad(z0.x, bs.post_act); d0.y *= act_grad(z0.y, bs.post_act);
+        d0.z *= act_grad(z0.z, bs.post_act); d0.w *= act_grad(z0.w, bs.post_act);
+        d1.x *= act_grad(z1.x, bs.post_act); d1.y *= act_grad(z1.y, bs.post_act);
+        d1.z *= act_grad(z1.z, bs.post_act); d1.w *= act_grad(z1.w, bs.post_act);
+      }
+      f1[pass] = d0 + d1;
+      f2s[pass] = d0 * ((sv0 - b_mu) * b_rs) + d1 * ((sv1 - b_mu) * b_rs);
+    }
+  }
+  // column sums over the block's 128 voxels: a column quad (pass, jl, cq) lives in the threads with the same (tid & 7)
+  auto colreduce = [&](vf4 v) -> vf4 {
+#pragma unroll
+    for (int d = 8; d < 64; d <<= 1) {
+      v.x += __shfl_xor(v.x, d); v.y += __shfl_xor(v.y, d); v.z += __shfl_xor(v.z, d); v.w += __shfl_xor(v.w, d);
+    }
+    return v;
+  };
+  // red[w][64]: channel index (pass * 2 + jl) * 16 + cq * 4 + e
+  const int cidx = jl * 16 + cq * 4;
+  auto put = [&](float* dst, const vf4 (&v)[2]) {
+    const vf4 r0 = colreduce(v[0]), r1 = colreduce(v[1]);
+    __syncthreads();
+    if (lane < 8) {
+      *reinterpret_cast<vf4*>(&dst[w * 64 + cidx]) = r0;
+      *reinterpret_cast<vf4*>(&dst[w * 64 + 32 + cidx]) = r1;
+    }
+    __syncthreads();
+  };
+  auto sum8 = [&](const float* src, int i) {
+    float sacc = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < 8; ++ww) sacc += src[ww * 64 + i];
+    return sacc;
+  };
+  const size_t nstat = gridDim.x / nchunks;
+  if (FOLD) {                                      // [2][Npad][blocks] (block index fastest), as conv_igemm.hip's FOLD
+    put(red, f1);
+    float a1 = 0.f;
+    if (tid < 64) a1 = sum8(red, tid);
+    put(red, f2s);
+    if (tid < 64) {
+      float* sp = bs.partial + (size_t)(n0 + tid) * nstat + tblk;
+      sp[0] = a1;
+      sp[(size_t)Npad * nstat] = sum8(red, tid);
+    }
+    return;
+  }
+  if (stat_partial == nullptr) return;
+
+  // block-level (count, mean, M2) per column, two passes inside the block (conv_igemm.hip's layout
+  // [3][Npad][nblocks], block index fastest)
+  put(red, csum);
+  if (tid < 64) red[512 + tid] = sum8(red, tid) * (1.f / kRows);
+  __syncthreads();
+  vf4 qs[2];
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const vf4 mu = *reinterpret_cast<const vf4*>(&red[512 + pass * 32 + cidx]);
+    const vf4 d0 = val[pass][0] - mu, d1 = val[pass][1] - mu;
+    qs[pass] = d0 * d0 + d1 * d1;
+  }
+  float mean_t = 0.f;
+  if (tid < 64) mean_t = red[512 + tid];
+  put(red, qs);
+  if (tid < 64) {
+    float* sp = stat_partial + (size_t)(n0 + tid) * nstat + tblk;
+    sp[0] = (float)kRows;
+    sp[(size_t)Npad * nstat] = mean_t;
+    sp[(size_t)2 * Npad * nstat] = sum8(red, tid);
+  }
+}
+
+// ---------------------------------------------------------------- host side
+bool conv_wino64_ok(const ConvGeom& g, const ConvSrc* src, int nsrc) {
+  if (g.flags & (CF_NO_WINO | CF_NO_WINO64)) return false;
+  if (g.taps != 27 || nsrc != 1 || g.S < 8 || g.lgS < 3) return false;
+  const ConvSrc& s = src[0];
+  if (s.up || s.bcast || s.C != g.Cin) return false;
+  if (g.Cin % KC != 0 || g.Cout % 64 != 0) return false;
+  if ((long long)g.B * g.S * g.S * g.S * (long long)std::max(g.Cin, g.Cout) >= (1ll << 29)) return false;  // 32-bit BYTE offsets
+  return true;
+}
+
+int launch_conv_fwd_wino64(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, const float* wt, const float* bias,
+                           float* out, int ldo, int pre_act, float* stat_partial, int* rows_per_block, int accumulate,
+                           const BwdStat* bwd, int* bwd_blocks) {
+  ICS_CHECK(conv_wino64_ok(g, &s0, 1), "shape not served by the 64-channel Winograd kernel");
+  ICS_CHECK(ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
+                (reinterpret_cast<uintptr_t>(bias) & 15) == 0 && (reinterpret_cast<uintptr_t>(s0.p) & 15) == 0,
+            "Winograd kernel: float4 accesses need 16-byte aligned tensors");
+  const unsigned grid = (unsigned)(g.B * (g.S / 4) * (g.S / 4) * (g.S / 8) * (g.Cout / 64));
+  if (rows_per_block) *rows_per_block = kRows;
+  const bool aff = s0.scale != nullptr;
+  const bool noact = s0.act == ACT_NONE;
+  const float in_slope = wslope(s0.act), pre_slope = wslope(pre_act);
+  const bool fold = bwd != nullptr && bwd->partial != nullptr && !aff && stat_partial == nullptr && bias == nullptr &&
+                    pre_act == ACT_NONE && !accumulate && bwd->ld % 4 == 0;
+  if (bwd_blocks) *bwd_blocks = fold ? (int)(grid / (unsigned)(g.Cout / 64)) : 0;
+  const BwdStat bs = fold ? *bwd : BwdStat{};
+#define ICS_WINO_LAUNCH(AFFV, NOACTV, FOLDV)                                                                          \
+  do {                                                                                                                \
+    hipLaunchKernelGGL((conv_wino64_kernel<AFFV, NOACTV, FOLDV>), dim3(grid), dim3(512), 0, st, s0.p, s0.C, s0.scale, \
+                       s0.shift, in_slope, wt, bias, out, ldo, pre_slope, accumulate, stat_partial, g.Npad, g.S,      \
+                       g.Cin, g.Cout, bs);                                                                            \
+    conv_set_last_kernel_id("conv_wino64_kernel<" #AFFV ", " #NOACTV ", " #FOLDV ">");                                \
+  } while (0)
+  if (fold) ICS_WINO_LAUNCH(false, true, true);
+  else if (!aff) ICS_WINO_LAUNCH(false, true, false);
+  else if (noact) ICS_WINO_LAUNCH(true, true, false);
+  else ICS_WINO_LAUNCH(true, false, false);
+#undef ICS_WINO_LAUNCH
+  ICS_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace ics

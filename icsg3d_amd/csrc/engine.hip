@@ -514,9 +514,12 @@ static int pack_layer(Net& n, ConvLayer& L, bool need_bwd) {
                                   round_up(L.taps * L.Cs, 32), L.Npad));
     ICS_TRY(launch_pack_par(n.st, n.tp(L.t_w), L.Cin, L.Cout, L.Cs, L.Cu, L.wp_par, 8 * L.Cu, L.Npad));
   }
-  if (wino_f) ICS_TRY(launch_pack_wino(n.st, n.tp(L.t_w), L.Cin, L.Cout, 0, L.split_up ? L.Cs : L.Cin, 0, L.ww));
+  if (wino_f)
+    ICS_TRY(launch_pack_wino(n.st, n.tp(L.t_w), L.Cin, L.Cout, 0, L.split_up ? L.Cs : L.Cin, 0, L.ww,
+                             conv_wino_layout(geom_wino_fwd(L, n.maxB))));
   if (need_bwd && wino_b)
-    ICS_TRY(launch_pack_wino(n.st, n.tp(L.t_w), L.Cin, L.Cout, 0, L.split_up ? L.Cs : L.Cin, 1, L.wwb));
+    ICS_TRY(launch_pack_wino(n.st, n.tp(L.t_w), L.Cin, L.Cout, 0, L.split_up ? L.Cs : L.Cin, 1, L.wwb,
+                             conv_wino_layout(geom_wino_bwd(L, n.maxB))));
   if (need_bwd && L.split_up) {
     if (L.Cs && !wino_b)
       ICS_TRY(launch_pack_sub(n.st, n.tp(L.t_w), L.taps, L.Cin, L.Cout, 0, L.Cs, 1, L.wf_skip, L.Kpad_b,
@@ -2130,7 +2133,7 @@ int ics_op_conv3d_forward(const float* x, const float* w, const float* bias, int
   if (conv_wino_ok(g, &s, 1)) {          // the path the engine takes for this shape (ICSG3D_NO_WINO: the direct kernels)
     float* ww = nullptr;
     ICS_TRY(n.alloc(&ww, conv_wino_weight_floats(Cin, Cout)));
-    ICS_TRY(launch_pack_wino(n.st, dw, Cin, Cout, 0, Cin, 0, ww));
+    ICS_TRY(launch_pack_wino(n.st, dw, Cin, Cout, 0, Cin, 0, ww, conv_wino_layout(g)));
     ICS_TRY(launch_conv_fwd_wino(n.st, g, s, ww, bias ? db : nullptr, dyv, Cout, pre_act, nullptr, nullptr, 0));
   } else {
     ICS_TRY(launch_conv_fwd(n.st, g, &s, 1, dwp, bias ? db : nullptr, dyv, Cout, pre_act, nullptr, nullptr));
@@ -2160,7 +2163,13 @@ int ics_op_conv3d_bench(int B, int S, int Cin, int Cout, int taps, int mode, int
   ConvGeom g{B, S, ilog2(S), Cin, Cout, taps, Kpad, Npad, n.flags};
   ConvGeom gb{B, S, ilog2(S), Cout, Cin, taps, Kpad_b, Npad_b, n.flags};
   ConvSrc sx = src_plain(dx, Cin), sd = src_plain(dyv, Cout);
-  const size_t wsn = conv_wgrad_workspace_floats(g, &sx, 1);
+  // the path the engine takes for this shape: Winograd where conv_wino_ok / conv_wino_wgrad_ok accept it
+  const bool wf = !ablate && conv_wino_ok(g, &sx, 1), wb = !ablate && conv_wino_ok(gb, &sd, 1);
+  const bool ww = !ablate && conv_wino_wgrad_ok(g, &sx, 1);
+  float *wwf = nullptr, *wwb = nullptr;
+  if (wf) { ICS_TRY(n.alloc(&wwf, conv_wino_weight_floats(Cin, Cout))); ICS_TRY(launch_pack_wino(n.st, dw, Cin, Cout, 0, Cin, 0, wwf, conv_wino_layout(g))); }
+  if (wb) { ICS_TRY(n.alloc(&wwb, conv_wino_weight_floats(Cin, Cout))); ICS_TRY(launch_pack_wino(n.st, dw, Cin, Cout, 0, Cin, 1, wwb, conv_wino_layout(gb))); }
+  const size_t wsn = ww ? conv_wino_wgrad_workspace_floats(g) : conv_wgrad_workspace_floats(g, &sx, 1);
   ICS_TRY(n.alloc(&ws, wsn + 16));
   hipEvent_t e0, e1;
   ICS_HIP(hipEventCreate(&e0)); ICS_HIP(hipEventCreate(&e1));
@@ -2168,11 +2177,15 @@ int ics_op_conv3d_bench(int B, int S, int Cin, int Cout, int taps, int mode, int
     if (it == 0) ICS_HIP(hipEventRecord(e0, n.st));
     if (mode == 0) {
       if (ablate) ICS_TRY(launch_conv_fwd_ablate(n.st, g, &sx, 1, dwp, dyv, Cout, ablate));
+      else if (wf) ICS_TRY(launch_conv_fwd_wino(n.st, g, sx, wwf, nullptr, dyv, Cout, ACT_RELU, nullptr, nullptr, 0));
       else ICS_TRY(launch_conv_fwd(n.st, g, &sx, 1, dwp, nullptr, dyv, Cout, ACT_RELU, nullptr, nullptr));
     } else if (mode == 1) {
-      ICS_TRY(launch_conv_fwd(n.st, gb, &sd, 1, dwf, nullptr, dgx, Cin, ACT_NONE, nullptr, nullptr));
+      if (wb) ICS_TRY(launch_conv_fwd_wino(n.st, gb, sd, wwb, nullptr, dgx, Cin, ACT_NONE, nullptr, nullptr, 0));
+      else ICS_TRY(launch_conv_fwd(n.st, gb, &sd, 1, dwf, nullptr, dgx, Cin, ACT_NONE, nullptr, nullptr));
     } else if (ablate) {
       ICS_TRY(launch_conv_wgrad_ablate(n.st, g, &sx, dyv, Cout, ws, ablate));
+    } else if (ww) {
+      ICS_TRY(launch_conv_wgrad_wino(n.st, g, sx, dyv, Cout, dgw, Cout, ws, wsn, 0, 0, 0, 0));
     } else {
       ICS_TRY(launch_conv_wgrad(n.st, g, &sx, 1, dyv, Cout, dgw, Cout, ws, wsn));
     }
@@ -2220,7 +2233,7 @@ int ics_op_conv3d_backward(const float* x, const float* w, const float* dy, int 
     if (conv_wino_ok(gb, &sd, 1)) {
       float* wwb = nullptr;
       ICS_TRY(n.alloc(&wwb, conv_wino_weight_floats(Cin, Cout)));
-      ICS_TRY(launch_pack_wino(n.st, dw, Cin, Cout, 0, Cin, 1, wwb));
+      ICS_TRY(launch_pack_wino(n.st, dw, Cin, Cout, 0, Cin, 1, wwb, conv_wino_layout(gb)));
       ICS_TRY(launch_conv_fwd_wino(n.st, gb, sd, wwb, nullptr, dgx, Cin, ACT_NONE, nullptr, nullptr, 0));
     } else
     ICS_TRY(launch_conv_fwd(n.st, gb, &sd, 1, dwf, nullptr, dgx, Cin, ACT_NONE, nullptr, nullptr));
