@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libicsg3d_hip.so")
+# ICSG3D_LIB_PATH: another build of the same library (kernel A/B experiments: scripts/variants.sh)
+LIB_PATH = os.environ.get("ICSG3D_LIB_PATH") or os.path.join(_HERE, "libicsg3d_hip.so")
 
 
 class IcsLibraryError(RuntimeError):

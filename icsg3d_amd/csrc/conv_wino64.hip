@@ -24,6 +24,18 @@
 #include <algorithm>
 #include <type_traits>
 
+#ifndef ICS_W64_FENCE
+#define ICS_W64_FENCE 1      // 2: a scheduling fence after every MFMA pair; 1: one per column; 0: none.  Measured, c18
+                             // forward: 2.59 / 2.53 / 2.72 ms (with ICS_W64_COLTOP: 2.51 / 2.51 / 2.77)
+#endif
+#ifndef ICS_W64_COLTOP
+#define ICS_W64_COLTOP 1     // 1: the two column-math instructions ahead of a column's MFMAs instead of between them
+                             // (no copies of the three operands, one MFMA -> VALU -> MFMA switch per column less)
+#endif
+#ifndef ICS_W64_PRIO
+#define ICS_W64_PRIO 0       // 1: s_setprio(1) around a column's MFMAs (measured: +1 % time)
+#endif
+
 namespace ics {
 
 typedef float vf4 __attribute__((ext_vector_type(4)));
@@ -239,7 +251,12 @@ __global__ __launch_bounds__(512) void conv_wino64_kernel(const float* __restric
       gs = gs < nsub ? gs : nsub - 1;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
+#if ICS_W64_COLTOP
+        tn[0][g] = qa - qb;                      // column g of sub-step s+1, read one column ago
+        tn[1][g] = fmaf(sg, qc, qb);
+#else
         const float a = qa, bq = qb, c = qc;
+#endif
         if (s == 3 && g == 3) {                  // first half of the next chunk's planes; then the second half's rows
           hstore(0, nxt, cn);
           hload(1, cn);
@@ -252,19 +269,42 @@ __global__ __launch_bounds__(512) void conv_wino64_kernel(const float* __restric
         // reads of the next column: column g+1 of sub-step s+1, or column 0 of sub-step s+2
         if (g < 3) rd(Ra, Rb, Rc, (s + 1) & 7, g + 1);
         else rd(Ra, Rb, Rc, (s + 2) & 7, 0);
+#if ICS_W64_FENCE != 0
         __builtin_amdgcn_sched_barrier(0);
+#endif
 #define ICS_WMF(F, J) acc[F][J] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[F], wreg[F][J], acc[F][J], 0, 0, 0)
+#if ICS_W64_FENCE == 2
 #define ICS_WFN __builtin_amdgcn_sched_barrier(0)
+#define ICS_WFC __builtin_amdgcn_sched_barrier(0)
+#elif ICS_W64_FENCE == 1
+#define ICS_WFN
+#define ICS_WFC __builtin_amdgcn_sched_barrier(0)
+#else
+#define ICS_WFN
+#define ICS_WFC
+#endif
         // consecutive MFMAs on different accumulators; the column math of the next sub-step in between
+#if ICS_W64_PRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
+#if ICS_W64_COLTOP
+        ICS_WMF(g, 0); ICS_WMF(4 + g, 0); ICS_WFN;
+        ICS_WMF(g, 1); ICS_WMF(4 + g, 1); ICS_WFN;
+#else
         ICS_WMF(g, 0); ICS_WMF(4 + g, 0); tn[0][g] = a - bq; ICS_WFN;
         ICS_WMF(g, 1); ICS_WMF(4 + g, 1); tn[1][g] = fmaf(sg, c, bq); ICS_WFN;
+#endif
         ICS_WMF(g, 2); ICS_WMF(4 + g, 2); ICS_WFN;
-        ICS_WMF(g, 3); ICS_WMF(4 + g, 3); ICS_WFN;
+        ICS_WMF(g, 3); ICS_WMF(4 + g, 3); ICS_WFC;
+#if ICS_W64_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
 #undef ICS_WMF
         wreg[g] = wload(gs, g);
         wreg[4 + g] = wload(gs, 4 + g);
-        ICS_WFN;
+        ICS_WFC;
 #undef ICS_WFN
+#undef ICS_WFC
       }
       xform();
     }
