@@ -574,6 +574,10 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(const float* __res
       // interleaved with this step's MFMAs (measured: doing it after them costs 15 %)
 #define ICS_GMF(F) acc[F] = __builtin_amdgcn_mfma_f32_32x32x2f32(uc[F], vc[F], acc[F], 0, 0, 0)
 #define ICS_GFN __builtin_amdgcn_sched_barrier(0)
+#ifndef ICS_WG_SCHED
+#define ICS_WG_SCHED 0
+#endif
+#if ICS_WG_SCHED == 0       // one fence per MFMA, the y / dy math behind the first three
       ICS_GMF(0); tr_y(0); ICS_GFN;
       ICS_GMF(4); tr_y(1); ICS_GFN;
       ICS_GMF(1); tr_d(); ICS_GFN;
@@ -582,6 +586,20 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(const float* __res
       ICS_GMF(6); ICS_GFN;
       ICS_GMF(3); ICS_GFN;
       ICS_GMF(7); ICS_GFN;
+#elif ICS_WG_SCHED == 1     // all transform math first, then the eight MFMAs back to back
+      tr_y(0); tr_y(1); tr_d(); ICS_GFN;
+      ICS_GMF(0); ICS_GMF(4); ICS_GMF(1); ICS_GMF(5); ICS_GMF(2); ICS_GMF(6); ICS_GMF(3); ICS_GMF(7); ICS_GFN;
+#elif ICS_WG_SCHED == 2     // math first, fences every two MFMAs
+      tr_y(0); tr_y(1); tr_d(); ICS_GFN;
+      ICS_GMF(0); ICS_GMF(4); ICS_GFN; ICS_GMF(1); ICS_GMF(5); ICS_GFN; ICS_GMF(2); ICS_GMF(6); ICS_GFN; ICS_GMF(3); ICS_GMF(7); ICS_GFN;
+#elif ICS_WG_SCHED == 3     // math in two bursts between MFMA groups of four
+      tr_y(0); tr_y(1); ICS_GFN;
+      ICS_GMF(0); ICS_GMF(4); ICS_GMF(1); ICS_GMF(5); ICS_GFN;
+      tr_d(); ICS_GFN;
+      ICS_GMF(2); ICS_GMF(6); ICS_GMF(3); ICS_GMF(7); ICS_GFN;
+#else                       // no fences inside the step
+      ICS_GMF(0); tr_y(0); ICS_GMF(4); tr_y(1); ICS_GMF(1); tr_d(); ICS_GMF(5); ICS_GMF(2); ICS_GMF(6); ICS_GMF(3); ICS_GMF(7); ICS_GFN;
+#endif
 #undef ICS_GMF
       // measured (ms of this kernel per U-Net step): these 24 ops interleaved with the MFMAs above 10.35, the whole
       // transform as a burst here 10.34, this split 9.8: the burst runs under the other wave's MFMAs

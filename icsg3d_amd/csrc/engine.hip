@@ -2164,8 +2164,18 @@ int ics_op_conv3d_bench(int B, int S, int Cin, int Cout, int taps, int mode, int
   ConvGeom gb{B, S, ilog2(S), Cout, Cin, taps, Kpad_b, Npad_b, n.flags};
   ConvSrc sx = src_plain(dx, Cin), sd = src_plain(dyv, Cout);
   // the path the engine takes for this shape: Winograd where conv_wino_ok / conv_wino_wgrad_ok accept it
+  // ablate >= 8 (Winograd paths only): feature bits of the launch the engine makes -- 8: BatchNorm-affine source,
+  // 16: per-block BatchNorm statistics, 32: bias
+  const int feat = ablate >= 8 ? ablate : 0;
+  if (feat) ablate = 0;
   const bool wf = !ablate && conv_wino_ok(g, &sx, 1), wb = !ablate && conv_wino_ok(gb, &sd, 1);
   const bool ww = !ablate && conv_wino_wgrad_ok(g, &sx, 1);
+  float *f_aff = nullptr, *f_stat = nullptr, *f_bias = nullptr;
+  if (feat) {
+    ICS_TRY(n.alloc(&f_aff, (size_t)2 * std::max(Cin, Cout))); ICS_TRY(fill(n, f_aff, (size_t)2 * std::max(Cin, Cout), 0.9f));
+    ICS_TRY(n.alloc(&f_stat, (M / 64 + 1) * 3 * (size_t)Npad)); ICS_TRY(n.alloc(&f_bias, (size_t)Cout));
+    if (feat & 8) { sx.scale = f_aff; sx.shift = f_aff + Cin; }
+  }
   float *wwf = nullptr, *wwb = nullptr;
   if (wf) { ICS_TRY(n.alloc(&wwf, conv_wino_weight_floats(Cin, Cout))); ICS_TRY(launch_pack_wino(n.st, dw, Cin, Cout, 0, Cin, 0, wwf, conv_wino_layout(g))); }
   if (wb) { ICS_TRY(n.alloc(&wwb, conv_wino_weight_floats(Cin, Cout))); ICS_TRY(launch_pack_wino(n.st, dw, Cin, Cout, 0, Cin, 1, wwb, conv_wino_layout(gb))); }
@@ -2177,7 +2187,8 @@ int ics_op_conv3d_bench(int B, int S, int Cin, int Cout, int taps, int mode, int
     if (it == 0) ICS_HIP(hipEventRecord(e0, n.st));
     if (mode == 0) {
       if (ablate) ICS_TRY(launch_conv_fwd_ablate(n.st, g, &sx, 1, dwp, dyv, Cout, ablate));
-      else if (wf) ICS_TRY(launch_conv_fwd_wino(n.st, g, sx, wwf, nullptr, dyv, Cout, ACT_RELU, nullptr, nullptr, 0));
+      else if (wf) ICS_TRY(launch_conv_fwd_wino(n.st, g, sx, wwf, (feat & 32) ? f_bias : nullptr, dyv, Cout, ACT_RELU,
+                                                (feat & 16) ? f_stat : nullptr, nullptr, 0));
       else ICS_TRY(launch_conv_fwd(n.st, g, &sx, 1, dwp, nullptr, dyv, Cout, ACT_RELU, nullptr, nullptr));
     } else if (mode == 1) {
       if (wb) ICS_TRY(launch_conv_fwd_wino(n.st, gb, sd, wwb, nullptr, dgx, Cin, ACT_NONE, nullptr, nullptr, 0));
