@@ -81,6 +81,8 @@ enum ConvFlags : int {
   CF_NO_WINO = 256,       // ICSG3D_NO_WINO: 3x3x3 layers through the 27-tap implicit GEMM instead of Winograd F(2,3)
   CF_NO_WINO_WGRAD = 512, // ICSG3D_NO_WINO_WGRAD: backward-weight through the direct kernels, Winograd forward/backward-data kept
   CF_NO_WINO64 = 1024,    // ICSG3D_NO_WINO64: Winograd forward/backward-data through the 32-tile x 32-channel kernel only
+  CF_NO_UP3 = 2048,       // ICSG3D_NO_UP3: upsampled channels forward through the 8 parity-class GEMMs (64 products per low-res
+                          // voxel) instead of the 27-product kernel
 };
 int conv_flags_from_env();
 
@@ -193,6 +195,14 @@ bool conv_wino_wgrad_ok(const ConvGeom& g, const ConvSrc* src, int nsrc);
 size_t conv_wino_wgrad_workspace_floats(const ConvGeom& g);
 int launch_conv_wgrad_wino(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, const float* dy, int ldy, float* dw,
                            int ldw, float* ws, size_t ws_floats, int sub_rows, int row_pitch, int row_off, int phase);
+// ---------------------------------------------------------------- upsampled input, 27 products per low-res voxel (conv_up3.hip)
+// g = the LOW-RES geometry (geom_par_fwd: S = low-res extent, Cin = Cu upsampled channels, Cout); s0 = the low-res source.
+// *stat_blocks = row blocks (128 fine voxels each) written to stat_partial.
+bool conv_up3_ok(const ConvGeom& g, const ConvSrc& s0);
+size_t conv_up3_weight_floats(int Cu, int Cout);
+int launch_pack_up3(hipStream_t st, const float* w, int Cin_total, int Cout, int c_off, int Cu, float* dst);
+int launch_conv_fwd_up3(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, const float* wt, const float* bias,
+                        float* out, int ldo, int pre_act, float* stat_partial, int* stat_blocks, int accumulate);
 // fixed-order reduction of split-K weight-gradient partials ws[split][k][n] into dw (conv_igemm.hip)
 int launch_wgrad_reduce_splits(hipStream_t st, const float* ws, int nsplit, size_t n_elems, int N, float* dw, int ldw,
                                int sub_rows, int row_pitch, int row_off);

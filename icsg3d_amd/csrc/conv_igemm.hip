@@ -53,6 +53,7 @@ int conv_flags_from_env() {
   if (getenv("ICSG3D_NO_WINO")) f |= CF_NO_WINO;
   if (getenv("ICSG3D_NO_WINO_WGRAD")) f |= CF_NO_WINO_WGRAD;
   if (getenv("ICSG3D_NO_WINO64")) f |= CF_NO_WINO64;
+  if (getenv("ICSG3D_NO_UP3")) f |= CF_NO_UP3;
   return f;
 }
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remember per (kernel instantiation, device)
@@ -1611,7 +1612,7 @@ int launch_conv_fwd_par(hipStream_t st, const ConvGeom& g, const ConvSrc& src, c
 // whatever their size.  The engine records the jobs once (the launch_pack_* calls below append to g_pack_rec
 // instead of launching) and replays them with ONE pack_table_kernel launch per step.
 struct PackJob {
-  int kind;                 // 0 fwd, 1 bwd, 2 sub, 3 fwd_sub, 4 par, 5 wino
+  int kind;                 // 0 fwd, 1 bwd, 2 sub, 3 fwd_sub, 4 par, 5 wino, 6 up3
   const float* w;
   float* dst;
   int a[9];
@@ -2859,6 +2860,56 @@ int launch_pack_wino(hipStream_t st, const float* w, int Cin_total, int Cout, in
   return 0;
 }
 
+// Weights of the 27-product upsampled-input kernel (conv_up3.hip): dst[Cout/64][Cu/4][27 f][4 k][16 n][4 column blocks] =
+// (g (x) g (x) g) applied to w[tap][c_off + k][n] along z, y, x with g = [1 0 0; 1 1 1; 0 0 1].
+// Thread t = (nchunk * Cu/4 + c4) * 256 + (kk * 16 + n16) * 4 + nb: one (k, n) pair.
+__device__ __forceinline__ void pack_up3_pair(size_t t, const float* __restrict__ w, int Cin_total, int Cout, int c_off,
+                                              int Cu, float* __restrict__ dst) {
+  const size_t rest = t >> 8;
+  const int c4 = (int)(rest % (size_t)(Cu / 4)), nchunk = (int)(rest / (size_t)(Cu / 4));
+  const int nbk = (int)(t & 3), n16 = (int)((t >> 2) & 15), kk = (int)((t >> 6) & 3);
+  const int k = c4 * 4 + kk, n = nchunk * 64 + nbk * 16 + n16;
+  float g[27];
+#pragma unroll
+  for (int tap = 0; tap < 27; ++tap) g[tap] = w[((size_t)tap * Cin_total + c_off + k) * Cout + n];
+  float gx[9][3];
+#pragma unroll
+  for (int ab = 0; ab < 9; ++ab) {
+    gx[ab][0] = g[ab * 3]; gx[ab][1] = g[ab * 3] + g[ab * 3 + 1] + g[ab * 3 + 2]; gx[ab][2] = g[ab * 3 + 2];
+  }
+  float gy[3][3][3];                               // [a][fy][fx]
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int fx = 0; fx < 3; ++fx) {
+      gy[a][0][fx] = gx[a * 3][fx]; gy[a][1][fx] = gx[a * 3][fx] + gx[a * 3 + 1][fx] + gx[a * 3 + 2][fx];
+      gy[a][2][fx] = gx[a * 3 + 2][fx];
+    }
+  float* d = dst + (size_t)rest * 27 * 256 + (t & 255);
+#pragma unroll
+  for (int fy = 0; fy < 3; ++fy)
+#pragma unroll
+    for (int fx = 0; fx < 3; ++fx) {
+      d[(0 * 9 + fy * 3 + fx) * 256] = gy[0][fy][fx];
+      d[(1 * 9 + fy * 3 + fx) * 256] = gy[0][fy][fx] + gy[1][fy][fx] + gy[2][fy][fx];
+      d[(2 * 9 + fy * 3 + fx) * 256] = gy[2][fy][fx];
+    }
+}
+__global__ void pack_up3_kernel(const float* __restrict__ w, int Cin_total, int Cout, int c_off, int Cu,
+                                float* __restrict__ dst, size_t pairs) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < pairs) pack_up3_pair(t, w, Cin_total, Cout, c_off, Cu, dst);
+}
+size_t conv_up3_weight_floats(int Cu, int Cout) { return (size_t)27 * Cu * Cout; }
+int launch_pack_up3(hipStream_t st, const float* w, int Cin_total, int Cout, int c_off, int Cu, float* dst) {
+  const size_t pairs = (size_t)Cu * Cout;
+  if (g_pack_rec) { g_pack_rec->push_back(PackJob{6, w, dst, {Cin_total, Cout, c_off, Cu, 0, 0, 0, 0, 0}, (unsigned long long)pairs, 0}); return 0; }
+  hipLaunchKernelGGL(pack_up3_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, w, Cin_total, Cout, c_off,
+                     Cu, dst, pairs);
+  ICS_HIP(hipGetLastError());
+  return 0;
+}
+
 // One launch for a whole table of pack jobs.  Destination buffers are zero-initialised at allocation and the
 // padding of a packed image never changes, so jobs only write their valid elements (two jobs may share a
 // destination: the head packs soft | sig side by side) -- no ordering between jobs is needed.
@@ -2884,6 +2935,7 @@ __global__ __launch_bounds__(256) void pack_table_kernel(const PackJob* __restri
     case 2: J.dst[i] = pack_sub_value(i, J.w, a[0], a[1], a[2], a[3], a[4], a[5], a[6]); break;
     case 3: J.dst[i] = pack_fwd_sub_value(i, J.w, a[0], a[1], a[2], a[3], a[4], a[5]); break;
     case 5: pack_wino_pair(i, J.w, a[0], a[1], a[2], a[3], a[4], J.dst, a[5]); break;
+    case 6: pack_up3_pair(i, J.w, a[0], a[1], a[2], a[3], J.dst); break;
     default: J.dst[i] = pack_par_value(i, J.w, a[0], a[1], a[2], a[3], a[4], a[5]); break;
   }
 }

@@ -1,0 +1,355 @@
+// 3x3x3 "same" convolution over a nearest-upsampled input with 27 instead of 64 multiplies per low-res voxel
+// (gfx950 / MI355X only) -- the upsampled channels of the U-Net's [skip | UpSampling3D(x)] convolutions
+// (/root/reference/unet/unet.py:309-336) and the VAE decoder's upsampled layers (vae/lattice_vae.py:211-217).
+//
+// Along one axis the fine outputs 2a, 2a+1 of low-res position a see x[a-1], x[a], x[a+1]:
+//   y[2a]   = W-1 x[a-1] + (W0 + W+1) x[a]   = P0 + P1        P0 = W-1 (x[a-1] - x[a])
+//   y[2a+1] = (W-1 + W0) x[a] + W+1 x[a+1]   = P1 + P2        P1 = (W-1 + W0 + W+1) x[a]      P2 = W+1 (x[a+1] - x[a])
+// three products instead of the four of the parity-class form (conv_igemm.hip's PAR kernels: 8 GEMMs with K = 8 Cu).
+// In three dimensions: 27 "frequencies" (fz, fy, fx), a transformed input D = (B (x) B (x) B) x over the 3x3x3 low-res
+// neighbourhood with B = [1 -1 0; 0 1 0; 0 -1 1], weights G = (g (x) g (x) g) w with g = [1 0 0; 1 1 1; 0 0 1], 27 GEMMs
+// voxels x Cu x Cout, and Y = (A (x) A (x) A) P with A = [1 1 0; 0 1 1] -- exact in exact arithmetic, the same
+// structure as the Winograd kernels (conv_wino64.hip) with 3 instead of 4 points per axis and tiles one low-res voxel
+// apart.  Zero padding of the fine grid is zero padding of the low-res grid.
+//
+// One workgroup = 16 low-res voxels (2x2x4: the same 4x4x8 block of fine outputs as conv_wino64.hip) x 64 output
+// channels x 27 frequencies, 9 waves: wave w owns (fz, fy) = (w / 3, w % 3), fx = 0..2, four 16-channel column blocks
+// each: 12 accumulators of 4 registers (v_mfma_f32_16x16x4_f32; lane l: A[voxel l & 15][k = l >> 4]).  With 48
+// accumulator registers a wave needs < 102 VGPRs, so TWO workgroups share a CU (18 waves on 4 SIMDs) and cover each
+// other's prologue, epilogue and barrier.  Staging: thread t < 384 owns (tile z, y, x, channel quad) of the halo
+// [4][4][6] x 32 channels: three z rows in, the producer's BatchNorm affine + activation, zero padding, the z rows of
+// B, three planes out.  LDS: voxel pitch 34 floats, row pitch 208, plane pitch 840 (conflict-free ds_read_b32 for every
+// (fz, row, column, sub-step): checked exhaustively).  Weights [Cout/64][Cu/4][27 f][4 k][16 n][4 column blocks].
+#include "common.h"
+
+#include <algorithm>
+
+namespace ics {
+
+typedef float uf4 __attribute__((ext_vector_type(4)));
+typedef float uf2 __attribute__((ext_vector_type(2)));
+
+namespace {
+constexpr int KC = 32;                                   // input channels per LDS chunk
+constexpr int VX = 34, RP = 208, PP = 840, BUF = 6 * PP; // floats; one buffer = 20 160 B
+constexpr int kRows = 128;                               // fine voxels per workgroup
+
+__device__ __forceinline__ float uact(float v, float slope) { return fmaxf(v, v * slope); }
+__host__ __device__ __forceinline__ float uslope(int act) { return act == ACT_RELU ? 0.f : (act == ACT_LRELU ? kLeaky : 1.f); }
+}  // namespace
+
+// x: low-res source [B][Sl][Sl][Sl][ldx]; y: fine output [B][2 Sl]^3 [ldo].  AFF / NOACT as in conv_wino64.hip.
+template <bool AFF, bool NOACT>
+__global__ __launch_bounds__(576, 4) void conv_up3_kernel(const float* __restrict__ x, int ldx,
+                                                          const float* __restrict__ in_scale,
+                                                          const float* __restrict__ in_shift, float in_slope,
+                                                          const float* __restrict__ wt, const float* __restrict__ bias,
+                                                          float* __restrict__ y, int ldo, float pre_slope, int accumulate,
+                                                          float* __restrict__ stat_partial, int Npad, int Sl, int Cin,
+                                                          int Cout) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * BUF];    // 40 320 B; the epilogue reuses it (36 KB per pass)
+  __shared__ unsigned park[3 * 576];
+  __shared__ __attribute__((aligned(16))) float aff[AFF ? 2048 : 4];
+  __shared__ float red[9 * 64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fz = w / 3, fy = w - 3 * fz;         // this wave: frequencies (fz, fy, 0..2)
+  const int m = lane & 15, kq = lane >> 4;
+  const int nchunks = Cout >> 6;
+  const int nb = blockIdx.x % nchunks;
+  const int tblk = blockIdx.x / nchunks;
+  int tb = tblk;
+  const int nbx = Sl >> 2, nby = Sl >> 1, nbz = Sl >> 1;
+  const int bx = tb % nbx; tb /= nbx;
+  const int by = tb % nby; tb /= nby;
+  const int bz = tb % nbz;
+  const int b = tb / nbz;
+  const int oz = bz * 2, oy = by * 2, ox = bx * 4, n0 = nb * 64;      // low-res origin of the block
+  const bool edge = bx == 0 || by == 0 || bz == 0 || bx == nbx - 1 || by == nby - 1 || bz == nbz - 1;   // uniform
+  const int S = 2 * Sl;
+
+  // ---- staging: thread t < 384 owns (tile z tzh, hy, hx, channel quad): z rows tzh, tzh+1, tzh+2 of the halo
+  const int cmb = tid < 384 ? tid : 383;
+  const int tzh = cmb / 192, rem = cmb - 192 * tzh;
+  const int q = rem & 7, hx = (rem >> 3) % 6, hy = (rem >> 3) / 6;
+  const int tzw = __builtin_amdgcn_readfirstlane(tzh);   // 192 threads = 3 whole waves per tile z: wave-uniform
+  uf4 hs[3];
+  unsigned zoff[4];                              // uniform: byte offset of sample b, low-res plane clamp(oz - 1 + hz)
+  unsigned okz = 0;                              // uniform: bit hz = plane inside the grid
+  bool okyx;
+  {
+    const int gy = oy - 1 + hy, gx = ox - 1 + hx;
+    const int cy = min(max(gy, 0), Sl - 1), cx = min(max(gx, 0), Sl - 1);
+    okyx = gy == cy && gx == cx;
+    park[tid] = (unsigned)((cy * Sl + cx) * ldx + q * 4) * 4u;
+    park[576 + tid] = (unsigned)(tzh * 3 * PP + hy * RP + hx * VX + q * 4);
+    park[1152 + tid] = (unsigned)(q * 4);
+#pragma unroll
+    for (int hz = 0; hz < 4; ++hz) {
+      const int gz = oz - 1 + hz, cz = min(max(gz, 0), Sl - 1);
+      okz |= gz == cz ? (1u << hz) : 0u;
+      zoff[hz] = (unsigned)((b * Sl + cz) * Sl * Sl * ldx) * 4u;
+    }
+  }
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, 0x7fffffff, 0x00020000);
+  // per-thread staging constants parked in LDS (conv_wino64.hip explains why)
+  const unsigned park_addr = (unsigned)(uintptr_t)&park[tid];
+  auto unpark = [&](const int which) -> int {
+    int v;
+    asm volatile("ds_read_b32 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(park_addr), "i"(which * 2304) : "memory");
+    return v;
+  };
+  if (AFF) {
+    for (int i = tid; i < Cin; i += 576) { aff[i] = in_scale[i]; aff[1024 + i] = in_shift[i]; }
+  }
+  auto hload = [&](int c0) {
+    const int vo = unpark(0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const unsigned zo = tzw ? zoff[1 + i] : zoff[i];
+      hs[i] = __builtin_bit_cast(uf4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vo, (int)(zo + (unsigned)c0 * 4u), 0));
+    }
+  };
+  auto hstore = [&](const int bo, const int c0) {
+    uf4 r[3] = {hs[0], hs[1], hs[2]};            // local copies: updating hs in place sends it to scratch (compiler)
+    if (AFF) {
+      const int q4 = unpark(2);
+      const uf4 sc4 = *reinterpret_cast<const uf4*>(&aff[c0 + q4]);
+      const uf4 sh4 = *reinterpret_cast<const uf4*>(&aff[1024 + c0 + q4]);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        uf4 t = r[i];
+        t.x = fmaf(t.x, sc4.x, sh4.x); t.y = fmaf(t.y, sc4.y, sh4.y);
+        t.z = fmaf(t.z, sc4.z, sh4.z); t.w = fmaf(t.w, sc4.w, sh4.w);
+        if (!NOACT) { t.x = uact(t.x, in_slope); t.y = uact(t.y, in_slope); t.z = uact(t.z, in_slope); t.w = uact(t.w, in_slope); }
+        r[i] = t;
+      }
+    }
+    if (edge) {                                  // zero padding AFTER the producer's affine / activation
+      const unsigned okzz = tzw ? okz >> 1 : okz;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        if (!(okyx && ((okzz >> i) & 1))) r[i] = uf4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (tid < 384) {
+      float* o = &lds[bo + unpark(1)];
+      const uf4 c0v = r[0] - r[1], c2v = r[2] - r[1];
+      *reinterpret_cast<uf2*>(o) = uf2{c0v.x, c0v.y}; *reinterpret_cast<uf2*>(o + 2) = uf2{c0v.z, c0v.w};
+      *reinterpret_cast<uf2*>(o + PP) = uf2{r[1].x, r[1].y}; *reinterpret_cast<uf2*>(o + PP + 2) = uf2{r[1].z, r[1].w};
+      *reinterpret_cast<uf2*>(o + 2 * PP) = uf2{c2v.x, c2v.y}; *reinterpret_cast<uf2*>(o + 2 * PP + 2) = uf2{c2v.z, c2v.w};
+    }
+  };
+
+  // ---- per-lane read geometry: voxel m = (tz, ty, tx); rows of the wave's fy: D0 = r0 - r1, D1 = r1, D2 = r2 - r1
+  const int tz = m >> 3, ty = (m >> 2) & 1, tx = m & 3;
+  const float sa = fy == 1 ? 0.f : 1.f, sb = fy == 1 ? 1.f : -1.f;        // t = sa * qa + sb * qb
+  const int R0 = (tz * 3 + fz) * PP + ty * RP + tx * VX + kq;
+  int Ra = R0 + (fy == 2 ? 2 : 0) * RP, Rb = R0 + RP;
+
+  const int nsub = Cin >> 2;
+  constexpr int wstride_f = 256;                 // floats per frequency of one sub-step: [4 k][16 n][4 column blocks]
+  constexpr int wsub = 27 * 256;
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(wt + ((size_t)nb * nsub * 27 + (fz * 3 + fy) * 3) * 256), 0, 0x7fffffff, 0x00020000);
+  const int wlane = lane * 16;                   // bytes
+  auto wload = [&](int gs, int f) {
+    return __builtin_bit_cast(uf4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wlane, (gs * wsub + f * wstride_f) * 4, 0));
+  };
+  uf4 wreg[3];
+#pragma unroll
+  for (int f = 0; f < 3; ++f) wreg[f] = wload(0, f);
+
+  uf4 acc[3][4];                                 // [fx][column block]
+#pragma unroll
+  for (int f = 0; f < 3; ++f)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[f][j] = uf4{0.f, 0.f, 0.f, 0.f};
+
+  float u[3], tn[3], qa, qb;
+  auto rd = [&](const int sub, const int col) {
+    const int off = col * VX + 4 * sub;          // compile-time after unrolling
+    qa = lds[Ra + off]; qb = lds[Rb + off];
+  };
+  auto xform = [&]() { u[0] = tn[0] - tn[1]; u[1] = tn[1]; u[2] = tn[2] - tn[1]; };
+
+  hload(0);
+  if (AFF) __syncthreads();                      // scale / shift visible
+  hstore(0, 0);
+  __syncthreads();
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    rd(0, g);
+    tn[g] = fmaf(sa, qa, sb * qb);
+  }
+  xform();
+  rd(1, 0);                                      // column 0 of sub-step 1
+
+  const int nch = Cin / KC;
+  int nxt = BUF;                                 // float offset of the buffer being filled
+  for (int ch = 0; ch < nch; ++ch) {
+    const int cn = (ch + 1 < nch ? ch + 1 : ch) * KC;                   // past the end: the last chunk again (never consumed)
+    const int dlt = 2 * nxt - BUF;
+    hload(cn);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      int gs = ch * 8 + s + 1;
+      gs = gs < nsub ? gs : nsub - 1;
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        tn[g] = fmaf(sa, qa, sb * qb);           // column g of sub-step s+1, read one column ago
+        if (s == 6 && g == 2) {                  // the next chunk must be visible before its first column is read
+          hstore(nxt, cn);
+          __syncthreads();
+          Ra += dlt; Rb += dlt;
+        }
+        if (g < 2) rd((s + 1) & 7, g + 1);
+        else rd((s + 2) & 7, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[g], wreg[g][j], acc[g][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        wreg[g] = wload(gs, g);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      xform();
+    }
+    nxt = BUF - nxt;
+  }
+
+  // ---------------------------------------------------------------- epilogue, two passes of two column blocks each
+  // lane l holds P[voxel = 4 kq + i][n = l & 15] for its (fz, fy) and fx = 0..2.  fx -> dx in registers (dx0 = P0 + P1,
+  // dx1 = P1 + P2); fy -> dy and fz -> dz across the waves through LDS: output (dz, dy, dx) = sum over fz in {dz, dz+1},
+  // fy in {dy, dy+1}.
+  float* part = lds;                             // [9 w][16 slots = (jl * 4 + i) * 2 + dx][64 lanes]  (36 KB)
+  const int cq = tid & 3, jl = (tid >> 2) & 1, o = (tid >> 3) & 3, tile = (tid >> 5) & 15;
+  const int dyo = o >> 1, dxo = o & 1;
+  const int ttz = tile >> 3, tty = (tile >> 2) & 1, ttx = tile & 3;
+  const int vz = 2 * (oz + ttz), vy = 2 * (oy + tty) + dyo, vx = 2 * (ox + ttx) + dxo;
+  const size_t vox0 = (((size_t)b * S + vz) * S + vy) * S + vx;
+  const int slot_rd = ((jl * 4 + ttx) * 2 + dxo) * 64 + (tile >> 2) * 16 + cq * 4;
+  uf4 val[2][2];
+  uf4 csum[2];
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int j = pass * 2 + jj;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        part[(w * 16 + (jj * 4 + i) * 2 + 0) * 64 + lane] = acc[0][j][i] + acc[1][j][i];
+        part[(w * 16 + (jj * 4 + i) * 2 + 1) * 64 + lane] = acc[1][j][i] + acc[2][j][i];
+      }
+    }
+    __syncthreads();
+    if (tid < 512) {
+      const int nn = n0 + (pass * 2 + jl) * 16 + cq * 4;           // this thread's four output channels
+      uf4 r[3];                                  // sum over fy in {dy, dy+1} for fz = 0, 1, 2
+#pragma unroll
+      for (int z = 0; z < 3; ++z)
+        r[z] = *reinterpret_cast<const uf4*>(&part[(z * 3 + dyo) * 1024 + slot_rd]) +
+               *reinterpret_cast<const uf4*>(&part[(z * 3 + dyo + 1) * 1024 + slot_rd]);
+      uf4 bv = {0.f, 0.f, 0.f, 0.f};
+      if (bias != nullptr) bv = *reinterpret_cast<const uf4*>(bias + nn);
+      const size_t o0 = vox0 * ldo + nn;
+      const size_t o1 = o0 + (size_t)S * S * ldo;
+      uf4 e0 = r[0] + r[1] + bv, e1 = r[1] + r[2] + bv;
+      if (accumulate) {
+        e0 += *reinterpret_cast<const uf4*>(y + o0);
+        e1 += *reinterpret_cast<const uf4*>(y + o1);
+      }
+      e0.x = uact(e0.x, pre_slope); e0.y = uact(e0.y, pre_slope); e0.z = uact(e0.z, pre_slope); e0.w = uact(e0.w, pre_slope);
+      e1.x = uact(e1.x, pre_slope); e1.y = uact(e1.y, pre_slope); e1.z = uact(e1.z, pre_slope); e1.w = uact(e1.w, pre_slope);
+      *reinterpret_cast<uf4*>(y + o0) = e0;
+      *reinterpret_cast<uf4*>(y + o1) = e1;
+      val[pass][0] = e0; val[pass][1] = e1;
+      csum[pass] = e0 + e1;
+    }
+  }
+  if (stat_partial == nullptr) return;
+
+  // block-level (count, mean, M2) per column over the block's 128 fine voxels (conv_igemm.hip's layout
+  // [3][Npad][nblocks], block index fastest); the 512 reader threads are waves 0..7
+  auto colreduce = [&](uf4 v) -> uf4 {
+#pragma unroll
+    for (int d = 8; d < 64; d <<= 1) {
+      v.x += __shfl_xor(v.x, d); v.y += __shfl_xor(v.y, d); v.z += __shfl_xor(v.z, d); v.w += __shfl_xor(v.w, d);
+    }
+    return v;
+  };
+  const int cidx = jl * 16 + cq * 4;
+  auto put = [&](const uf4 (&v)[2]) {
+    uf4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0;
+    if (w < 8) { r0 = colreduce(v[0]); r1 = colreduce(v[1]); }
+    __syncthreads();
+    if (w < 8 && lane < 8) {
+      *reinterpret_cast<uf4*>(&red[w * 64 + cidx]) = r0;
+      *reinterpret_cast<uf4*>(&red[w * 64 + 32 + cidx]) = r1;
+    }
+    __syncthreads();
+  };
+  auto sum8 = [&](int i) {
+    float sacc = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < 8; ++ww) sacc += red[ww * 64 + i];
+    return sacc;
+  };
+  const size_t nstat = gridDim.x / nchunks;
+  put(csum);
+  if (tid < 64) red[512 + tid] = sum8(tid) * (1.f / kRows);
+  __syncthreads();
+  uf4 qs[2];
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const uf4 mu = *reinterpret_cast<const uf4*>(&red[512 + pass * 32 + cidx]);
+    const uf4 d0 = val[pass][0] - mu, d1 = val[pass][1] - mu;
+    qs[pass] = d0 * d0 + d1 * d1;
+  }
+  float mean_t = 0.f;
+  if (tid < 64) mean_t = red[512 + tid];
+  put(qs);
+  if (tid < 64) {
+    float* sp = stat_partial + (size_t)(n0 + tid) * nstat + tblk;
+    sp[0] = (float)kRows;
+    sp[(size_t)Npad * nstat] = mean_t;
+    sp[(size_t)2 * Npad * nstat] = sum8(tid);
+  }
+}
+
+// ---------------------------------------------------------------- host side
+// g: geometry of the LOW-RES problem as geom_par_fwd gives it (S = low-res extent, Cin = Cu, Cout)
+bool conv_up3_ok(const ConvGeom& g, const ConvSrc& s) {
+  if (g.flags & (CF_NO_UPSPLIT | CF_NO_UP3)) return false;
+  if (g.S < 4 || s.up || s.bcast || s.C != g.Cin) return false;
+  if (g.Cin % KC != 0 || g.Cin > 1024 || g.Cout % 64 != 0) return false;
+  if ((long long)g.B * g.S * g.S * g.S * 8ll * (long long)std::max(g.Cin, g.Cout) >= (1ll << 29)) return false;   // byte offsets
+  return true;
+}
+
+int launch_conv_fwd_up3(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, const float* wt, const float* bias,
+                        float* out, int ldo, int pre_act, float* stat_partial, int* stat_blocks, int accumulate) {
+  ICS_CHECK(conv_up3_ok(g, s0), "shape not served by the 27-product upsampled-input kernel");
+  ICS_CHECK(ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (reinterpret_cast<uintptr_t>(bias) & 15) == 0 &&
+                (reinterpret_cast<uintptr_t>(s0.p) & 15) == 0,
+            "upsampled-input kernel: float4 accesses need 16-byte aligned tensors");
+  const unsigned grid = (unsigned)(g.B * (g.S / 2) * (g.S / 2) * (g.S / 4) * (g.Cout / 64));
+  if (stat_blocks) *stat_blocks = (int)(grid / (unsigned)(g.Cout / 64));
+  const bool aff = s0.scale != nullptr, noact = s0.act == ACT_NONE;
+  const float in_slope = uslope(s0.act), pre_slope = uslope(pre_act);
+#define ICS_UP3_LAUNCH(AFFV, NOACTV)                                                                              \
+  do {                                                                                                            \
+    hipLaunchKernelGGL((conv_up3_kernel<AFFV, NOACTV>), dim3(grid), dim3(576), 0, st, s0.p, s0.C, s0.scale,        \
+                       s0.shift, in_slope, wt, bias, out, ldo, pre_slope, accumulate, stat_partial, g.Npad, g.S,  \
+                       g.Cin, g.Cout);                                                                            \
+    conv_set_last_kernel_id("conv_up3_kernel<" #AFFV ", " #NOACTV ">");                                           \
+  } while (0)
+  if (!aff) ICS_UP3_LAUNCH(false, true);
+  else if (noact) ICS_UP3_LAUNCH(true, true);
+  else ICS_UP3_LAUNCH(true, false);
+#undef ICS_UP3_LAUNCH
+  ICS_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace ics

@@ -428,46 +428,45 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(const float* __res
   const int cmb = tid < 480 ? tid : 479;
   const int q = cmb & 7, hx = (cmb >> 3) % GX, hy = (cmb >> 3) / GX;
   wf4 xs[6], ys[2];
-  unsigned xrel[6], yrel[2];                       // relative to the halo corner (block origin - (1,1,1)): unsigned,
-#pragma unroll                                     // so that loads take a scalar base + 32-bit lane offset
-  for (int hz = 0; hz < 6; ++hz) xrel[hz] = (unsigned)(((hz * S + hy) * S + hx) * ldx + q * 4);
-  const unsigned xsafe = (unsigned)(((S + 1) * S + 1) * ldx + q * 4);   // the block's own first voxel
+  // Buffer loads (one 32-bit per-lane byte offset, everything block-dependent in the scalar offset operand): the halo
+  // positions are CLAMPED into the grid per block -- a handful of VALU per block -- and zeroed at store time.  The
+  // earlier form kept six per-lane offsets plus a "safe" one, selected per block through a scratch-resident table: two
+  // scratch round trips ahead of every block's loads.
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), 0, 0x7fffffff, 0x00020000);
+  unsigned yrel[2];                                // bytes, relative to the block origin
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int v = (tid + i * 512) >> 3;                                    // 0..127 = (vz, vy, vx)
-    yrel[i] = (unsigned)((((v >> 5) * S + ((v >> 3) & 3)) * S + (v & 7)) * ldy + (tid & 7) * 4);
+    yrel[i] = (unsigned)((((v >> 5) * S + ((v >> 3) & 3)) * S + (v & 7)) * ldy + co0 + (tid & 7) * 4) * 4u;
   }
-  const unsigned yxface = ((hy == 0) << 2) | ((hy == GY - 1) << 3) | ((hx == 0) << 4) | ((hx == GX - 1) << 5);
   const int xw = (q * 4) * GXP + hy * GX + hx;                             // LDS write base (floats): + j*GXP + plane*60
-  unsigned bface_cur = 0;
+  bool okyx_cur = true;                            // this lane's (y, x) halo position lies inside the grid (current block)
+  unsigned okz_cur = 0x3f;                         // uniform: bit hz set = plane oz - 1 + hz inside the grid
   auto gload = [&](int blk) {
     int t = blk;
     const int bx = t % nbx; t /= nbx;
     const int by = t % nby; t /= nby;
     const int bz = t % nbz;
     const int b = t / nbz;
-    const int org = ((b * S + 4 * bz) * S + 4 * by) * S + 8 * bx;          // voxel index of the block origin (uniform)
-    const unsigned bface = (bz == 0) | ((bz == nbz - 1) << 1) | ((by == 0) << 2) | ((by == nby - 1) << 3) |
-                           ((bx == 0) << 4) | ((bx == nbx - 1) << 5);
-    bface_cur = bface;
-    const float* xb = x + ((ptrdiff_t)org - ((S + 1) * S + 1)) * ldx + ci0;    // halo corner (never dereferenced outside)
-    const float* yb = dy + (size_t)org * ldy + co0;
-    if (bface) {                                                           // halo outside the grid: read the block's
-      const bool yxbad = (yxface & bface) != 0;                            // own first voxel instead, zeroed below
+    const int gy = 4 * by - 1 + hy, gx = 8 * bx - 1 + hx;
+    const int cy = min(max(gy, 0), S - 1), cx = min(max(gx, 0), S - 1);
+    okyx_cur = gy == cy && gx == cx;
+    const unsigned voff = (unsigned)((cy * S + cx) * ldx + ci0 + q * 4) * 4u;
+    unsigned okz = 0;
 #pragma unroll
-      for (int hz = 0; hz < 6; ++hz) {
-        const bool bad = yxbad || (hz == 0 && (bface & 1)) || (hz == 5 && (bface & 2));
-        xs[hz] = *reinterpret_cast<const wf4*>(xb + (bad ? xsafe : xrel[hz]));
-      }
-    } else {
-#pragma unroll
-      for (int hz = 0; hz < 6; ++hz) xs[hz] = *reinterpret_cast<const wf4*>(xb + xrel[hz]);
+    for (int hz = 0; hz < 6; ++hz) {
+      const int gz = 4 * bz - 1 + hz, cz = min(max(gz, 0), S - 1);
+      okz |= (gz == cz) ? (1u << hz) : 0u;
+      xs[hz] = __builtin_bit_cast(wf4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)voff, (int)((unsigned)((b * S + cz) * S * S * ldx) * 4u), 0));
     }
+    okz_cur = okz;
+    const unsigned org = (unsigned)((((b * S + 4 * bz) * S + 4 * by) * S + 8 * bx) * ldy) * 4u;   // block origin (uniform)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) ys[i] = *reinterpret_cast<const wf4*>(yb + yrel[i]);
+    for (int i = 0; i < 2; ++i)
+      ys[i] = __builtin_bit_cast(wf4, __builtin_amdgcn_raw_buffer_load_b128(yrs, (int)yrel[i], (int)org, 0));
   };
   auto sstore = [&](const int bo) {            // bo: buffer index 0 / 1
-    const unsigned bface = bface_cur;
     if (AFF) {
       // reloaded per block (L1 hits): 8 registers less to keep live through the main loop
       const wf4 sc4 = *reinterpret_cast<const wf4*>(in_scale + ci0 + q * 4);
@@ -481,11 +480,11 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(const float* __res
         xs[i] = t;
       }
     }
-    if (bface) {                                                           // padding zeros come AFTER the affine
-      const bool yxbad = (yxface & bface) != 0;
+    {                                                                      // padding zeros come AFTER the affine
+      const unsigned okz = okz_cur;
 #pragma unroll
       for (int hz = 0; hz < 6; ++hz)
-        if (yxbad || (hz == 0 && (bface & 1)) || (hz == 5 && (bface & 2))) xs[hz] = wf4{0.f, 0.f, 0.f, 0.f};
+        if (!(okyx_cur && ((okz >> hz) & 1))) xs[hz] = wf4{0.f, 0.f, 0.f, 0.f};
     }
     if (tid < 480) {
 #pragma unroll
@@ -748,7 +747,7 @@ bool conv_wino_wgrad_ok(const ConvGeom& g, const ConvSrc* src, int nsrc) {
   const ConvSrc& s = src[0];
   if (s.up || s.bcast || s.C != g.Cin) return false;
   if (g.Cin % 32 != 0 || g.Cout % 32 != 0) return false;
-  if ((long long)g.B * g.S * g.S * g.S * (long long)std::max(g.Cin, g.Cout) >= (1ll << 31)) return false;
+  if ((long long)g.B * g.S * g.S * g.S * (long long)std::max(g.Cin, g.Cout) >= (1ll << 29)) return false;   // 32-bit BYTE offsets
   return true;
 }
 int launch_conv_wgrad_wino(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, const float* dy, int ldy, float* dw,

@@ -131,6 +131,7 @@ struct ConvLayer {
   int Cs = 0, Cu = 0;
   float *wf_skip = nullptr, *w_up = nullptr;   // packed: dgrad of the skip channels; dxl = dyS x W_up
   float *wp_skip = nullptr, *wp_par = nullptr; // packed forward: skip channels (27 taps); 8 parity classes x 8 taps
+  float* w_up3 = nullptr;                      // upsampled channels, 27-product form (conv_up3.hip): replaces wp_par
   float *dyS = nullptr;                        // [M/8][ldS] tap-pooled dy, ldS = 27*Cout rounded up to 32 (pad = 0)
   int ldS = 0;
   float *dA_skip = nullptr, *dxl = nullptr;    // [M][Cs] grad of the skip input; [M/8][Cu] grad of the low-res input
@@ -380,7 +381,10 @@ static int enable_split_up(Net& n, ConvLayer& L) {
   ICS_HIP(hipMemsetAsync(L.dyS, 0, M / 8 * L.ldS * sizeof(float), n.st));   // pad columns stay zero
   ICS_TRY(n.alloc(&L.dxl, M / 8 * L.Cu));
   ICS_TRY(n.alloc(&L.dw_up, (size_t)L.Cu * 27 * L.Cout));
-  ICS_TRY(n.alloc(&L.wp_par, (size_t)8 * 8 * L.Cu * L.Npad));
+  if (conv_up3_ok(geom_par_fwd(L, n.maxB), src_lowres(L)))
+    ICS_TRY(n.alloc(&L.w_up3, conv_up3_weight_floats(L.Cu, L.Cout)));
+  else
+    ICS_TRY(n.alloc(&L.wp_par, (size_t)8 * 8 * L.Cu * L.Npad));
   if (L.Cs) {
     ICS_TRY(n.alloc(&L.wf_skip, (size_t)L.Kpad_b * round_up(L.Cs, 32)));
     ICS_TRY(n.alloc(&L.dA_skip, M * L.Cs));
@@ -512,7 +516,8 @@ static int pack_layer(Net& n, ConvLayer& L, bool need_bwd) {
     if (L.Cs && !wino_f)
       ICS_TRY(launch_pack_fwd_sub(n.st, n.tp(L.t_w), L.taps, L.Cin, L.Cout, 0, L.Cs, L.wp_skip,
                                   round_up(L.taps * L.Cs, 32), L.Npad));
-    ICS_TRY(launch_pack_par(n.st, n.tp(L.t_w), L.Cin, L.Cout, L.Cs, L.Cu, L.wp_par, 8 * L.Cu, L.Npad));
+    if (L.w_up3) ICS_TRY(launch_pack_up3(n.st, n.tp(L.t_w), L.Cin, L.Cout, L.Cs, L.Cu, L.w_up3));
+    else ICS_TRY(launch_pack_par(n.st, n.tp(L.t_w), L.Cin, L.Cout, L.Cs, L.Cu, L.wp_par, 8 * L.Cu, L.Npad));
   }
   if (wino_f)
     ICS_TRY(launch_pack_wino(n.st, n.tp(L.t_w), L.Cin, L.Cout, 0, L.split_up ? L.Cs : L.Cin, 0, L.ww,
@@ -552,10 +557,15 @@ static int conv_forward(Net& n, ConvLayer& L, int B, bool training, bool update_
     const ConvGeom gp = geom_par_fwd(L, B), gs = geom_skip_fwd(L, B);
     const ConvSrc lo = src_lowres(L);
     const bool only_up = L.Cs == 0;   // no skip part: the parity launch carries bias, activation and statistics
-    n.prof.begin(n.st, "conv_fwd:" + L.name + ".up|", 2.0 * M * 8 * L.Cu * L.Cout,
-                 4.0 * (M / 8 * L.Cu + M * L.Cout + 64.0 * L.Cu * L.Cout));
-    ICS_TRY(launch_conv_fwd_par(n.st, gp, lo, L.wp_par, L.s, L.Cout, only_up ? bias : nullptr,
-                                only_up ? L.pre_act : ACT_NONE, (only_up && stats) ? n.ws_stat : nullptr, &par_blocks));
+    // profile rows carry the MFMA work executed: 27 products per low-res voxel (conv_up3.hip) or 64 (8 parity GEMMs)
+    n.prof.begin(n.st, "conv_fwd:" + L.name + ".up|", 2.0 * M / 8 * (L.w_up3 ? 27 : 64) * L.Cu * L.Cout,
+                 4.0 * (M / 8 * L.Cu + M * L.Cout + (L.w_up3 ? 27.0 : 64.0) * L.Cu * L.Cout));
+    if (L.w_up3)
+      ICS_TRY(launch_conv_fwd_up3(n.st, gp, lo, L.w_up3, only_up ? bias : nullptr, L.s, L.Cout,
+                                  only_up ? L.pre_act : ACT_NONE, (only_up && stats) ? n.ws_stat : nullptr, &par_blocks, 0));
+    else
+      ICS_TRY(launch_conv_fwd_par(n.st, gp, lo, L.wp_par, L.s, L.Cout, only_up ? bias : nullptr,
+                                  only_up ? L.pre_act : ACT_NONE, (only_up && stats) ? n.ws_stat : nullptr, &par_blocks));
     n.prof.end(n.st);
     if (!only_up) {
       n.prof.begin(n.st, "conv_fwd:" + L.name + ".skip|", 2.0 * M * 27 * L.Cs * L.Cout,
