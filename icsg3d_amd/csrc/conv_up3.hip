@@ -39,7 +39,13 @@ __host__ __device__ __forceinline__ float uslope(int act) { return act == ACT_RE
 }  // namespace
 
 // x: low-res source [B][Sl][Sl][Sl][ldx]; y: fine output [B][2 Sl]^3 [ldo].  AFF / NOACT as in conv_wino64.hip.
-template <bool AFF, bool NOACT>
+// STATS: per-block BatchNorm statistics of the stored values (the VAE decoder's layers; the U-Net's launches leave bias,
+// activation and statistics to the skip-channel pass that accumulates on top).
+// Registers: 112-117 VGPRs = four waves per SIMD = ONE nine-wave workgroup per CU (3 + 2 + 2 + 2 waves on the four
+// SIMDs: the matrix pipe of the fullest SIMD bounds the kernel at 75 %).  Two workgroups per CU (5 + 5 + 4 + 4) need
+// <= 96 VGPRs; capped there the allocator spills 16-28 registers inside the main loop (measured, also with the halo
+// staged in two 8-byte phases), so that stays open.
+template <bool AFF, bool NOACT, bool STATS>
 __global__ __launch_bounds__(576, 4) void conv_up3_kernel(const float* __restrict__ x, int ldx,
                                                           const float* __restrict__ in_scale,
                                                           const float* __restrict__ in_shift, float in_slope,
@@ -263,11 +269,13 @@ __global__ __launch_bounds__(576, 4) void conv_up3_kernel(const float* __restric
       e1.x = uact(e1.x, pre_slope); e1.y = uact(e1.y, pre_slope); e1.z = uact(e1.z, pre_slope); e1.w = uact(e1.w, pre_slope);
       *reinterpret_cast<uf4*>(y + o0) = e0;
       *reinterpret_cast<uf4*>(y + o1) = e1;
-      val[pass][0] = e0; val[pass][1] = e1;
-      csum[pass] = e0 + e1;
+      if (STATS) {
+        val[pass][0] = e0; val[pass][1] = e1;
+        csum[pass] = e0 + e1;
+      }
     }
   }
-  if (stat_partial == nullptr) return;
+  if (!STATS) return;
 
   // block-level (count, mean, M2) per column over the block's 128 fine voxels (conv_igemm.hip's layout
   // [3][Npad][nblocks], block index fastest); the 512 reader threads are waves 0..7
@@ -337,16 +345,22 @@ int launch_conv_fwd_up3(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, co
   if (stat_blocks) *stat_blocks = (int)(grid / (unsigned)(g.Cout / 64));
   const bool aff = s0.scale != nullptr, noact = s0.act == ACT_NONE;
   const float in_slope = uslope(s0.act), pre_slope = uslope(pre_act);
-#define ICS_UP3_LAUNCH(AFFV, NOACTV)                                                                              \
+#define ICS_UP3_LAUNCH(AFFV, NOACTV, STATSV)                                                                      \
   do {                                                                                                            \
-    hipLaunchKernelGGL((conv_up3_kernel<AFFV, NOACTV>), dim3(grid), dim3(576), 0, st, s0.p, s0.C, s0.scale,        \
-                       s0.shift, in_slope, wt, bias, out, ldo, pre_slope, accumulate, stat_partial, g.Npad, g.S,  \
-                       g.Cin, g.Cout);                                                                            \
-    conv_set_last_kernel_id("conv_up3_kernel<" #AFFV ", " #NOACTV ">");                                           \
+    hipLaunchKernelGGL((conv_up3_kernel<AFFV, NOACTV, STATSV>), dim3(grid), dim3(576), 0, st, s0.p, s0.C,          \
+                       s0.scale, s0.shift, in_slope, wt, bias, out, ldo, pre_slope, accumulate, stat_partial,     \
+                       g.Npad, g.S, g.Cin, g.Cout);                                                               \
+    conv_set_last_kernel_id("conv_up3_kernel<" #AFFV ", " #NOACTV ", " #STATSV ">");                              \
   } while (0)
-  if (!aff) ICS_UP3_LAUNCH(false, true);
-  else if (noact) ICS_UP3_LAUNCH(true, true);
-  else ICS_UP3_LAUNCH(true, false);
+  if (stat_partial) {
+    if (!aff) ICS_UP3_LAUNCH(false, true, true);
+    else if (noact) ICS_UP3_LAUNCH(true, true, true);
+    else ICS_UP3_LAUNCH(true, false, true);
+  } else {
+    if (!aff) ICS_UP3_LAUNCH(false, true, false);
+    else if (noact) ICS_UP3_LAUNCH(true, true, false);
+    else ICS_UP3_LAUNCH(true, false, false);
+  }
 #undef ICS_UP3_LAUNCH
   ICS_HIP(hipGetLastError());
   return 0;

@@ -169,6 +169,7 @@ __global__ __launch_bounds__(512) void conv_wino64_kernel(const float* __restric
       hs[i] = __builtin_bit_cast(vf4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vo, (int)(zoff[2 * tzh + i] + (unsigned)c0 * 4u), 0));
   };
   auto hstore = [&](const int tzh, const int bo, const int c0) {
+    vf4 r[4] = {hs[0], hs[1], hs[2], hs[3]};     // local copies: updating hs in place can send it to scratch (compiler)
     if (AFF) {
       const int q4 = unpark(2);
       typedef float vf2 __attribute__((ext_vector_type(2)));
@@ -178,22 +179,22 @@ __global__ __launch_bounds__(512) void conv_wino64_kernel(const float* __restric
         const vf2 sh2 = *reinterpret_cast<const vf2*>(&aff[1024 + c0 + q4 + 2 * hh]);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          float t0 = fmaf(hs[i][2 * hh], sc2.x, sh2.x), t1 = fmaf(hs[i][2 * hh + 1], sc2.y, sh2.y);
+          float t0 = fmaf(r[i][2 * hh], sc2.x, sh2.x), t1 = fmaf(r[i][2 * hh + 1], sc2.y, sh2.y);
           if (!NOACT) { t0 = wact(t0, in_slope); t1 = wact(t1, in_slope); }
-          hs[i][2 * hh] = t0; hs[i][2 * hh + 1] = t1;
+          r[i][2 * hh] = t0; r[i][2 * hh + 1] = t1;
         }
       }
     }
     if (edge) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        if (!((okmask >> (2 * tzh + i)) & 1)) hs[i] = vf4{0.f, 0.f, 0.f, 0.f};
+        if (!((okmask >> (2 * tzh + i)) & 1)) r[i] = vf4{0.f, 0.f, 0.f, 0.f};
     }
     if (tid < 480) {
       float* o = &lds[bo + unpark(1) + tzh * 4 * PP];
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
-        const vf4 c = f == 0 ? hs[0] - hs[2] : (f == 1 ? hs[1] + hs[2] : (f == 2 ? hs[2] - hs[1] : hs[1] - hs[3]));
+        const vf4 c = f == 0 ? r[0] - r[2] : (f == 1 ? r[1] + r[2] : (f == 2 ? r[2] - r[1] : r[1] - r[3]));
         float* op = o + f * PP;
         op[0] = c.x; op[1] = c.y; op[2] = c.z; op[3] = c.w;
       }

@@ -58,6 +58,11 @@ def test_conv_forward(case, relerr, monkeypatch):
         direct = E.conv3d_forward(x, w, b, pre_act=0)
         assert relerr(direct, ref) <= TOL
         assert not np.array_equal(direct, got)           # really two different kernels
+        monkeypatch.delenv("ICSG3D_NO_WINO")
+        if case[3] % 64 == 0:                            # the 16-tile x 64-channel Winograd shape is the default there:
+            monkeypatch.setenv("ICSG3D_NO_WINO64", "1")  # keep the 32 x 32 kernel covered at the same shapes
+            w32 = E.conv3d_forward(x, w, b, pre_act=0)
+            assert relerr(w32, ref) <= TOL and not np.array_equal(w32, got)
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "B%d_S%d_%dto%d_k%d" % c)
@@ -73,3 +78,8 @@ def test_conv_backward(case, relerr, monkeypatch):
         dx2, dw2 = E.conv3d_backward(x, w, dy)
         assert relerr(dx2, dx_ref) <= TOL and relerr(dw2, dw_ref) <= TOL
         assert not np.array_equal(dx2, dx) and not np.array_equal(dw2, dw)
+        monkeypatch.delenv("ICSG3D_NO_WINO")
+        if case[2] % 64 == 0:                            # backward-data: N = Cin
+            monkeypatch.setenv("ICSG3D_NO_WINO64", "1")
+            dx3, _ = E.conv3d_backward(x, w, dy)
+            assert relerr(dx3, dx_ref) <= TOL and not np.array_equal(dx3, dx)
