@@ -564,7 +564,9 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(const float* __res
   tr_y(0); tr_y(1); tr_x(t0, u[0]); tr_x(t1, u[0] + 4); tr_d(); tr_v(rl, vv[0]); tr_v(rh, vv[0] + 4);
   rd(0, 1);
   auto block = [&](const int blk, const int cur, const int nxt) {
+#if !(ICS_WG_ABL & 4)
     gload(blk + 1 < blk_hi ? blk + 1 : blk);             // past the end: this block again (never consumed)
+#endif
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
       float* uc = u[p & 1];  float* vc = vv[p & 1];      // this step's operands
@@ -573,10 +575,17 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(const float* __res
       // interleaved with this step's MFMAs (measured: doing it after them costs 15 %)
 #define ICS_GMF(F) acc[F] = __builtin_amdgcn_mfma_f32_32x32x2f32(uc[F], vc[F], acc[F], 0, 0, 0)
 #define ICS_GFN __builtin_amdgcn_sched_barrier(0)
-#ifndef ICS_WG_SCHED
-#define ICS_WG_SCHED 0
+#ifndef ICS_WG_ABL
+#define ICS_WG_ABL 0        // ablation (scripts/variants.sh): 1 no transform VALU, 2 no LDS operand reads, 4 no staging, 8 no MFMA
 #endif
-#if ICS_WG_SCHED == 0       // one fence per MFMA, the y / dy math behind the first three
+#if ICS_WG_ABL & 8
+#undef ICS_GMF
+#define ICS_GMF(F)
+#endif
+#if ICS_WG_ABL & 1
+      ICS_GMF(0); ICS_GMF(4); ICS_GMF(1); ICS_GMF(5); ICS_GMF(2); ICS_GMF(6); ICS_GMF(3); ICS_GMF(7); ICS_GFN;
+#else
+      // one fence per MFMA, the y / dy math behind the first three (fence variants measured within 1 %)
       ICS_GMF(0); tr_y(0); ICS_GFN;
       ICS_GMF(4); tr_y(1); ICS_GFN;
       ICS_GMF(1); tr_d(); ICS_GFN;
@@ -585,30 +594,25 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(const float* __res
       ICS_GMF(6); ICS_GFN;
       ICS_GMF(3); ICS_GFN;
       ICS_GMF(7); ICS_GFN;
-#elif ICS_WG_SCHED == 1     // all transform math first, then the eight MFMAs back to back
-      tr_y(0); tr_y(1); tr_d(); ICS_GFN;
-      ICS_GMF(0); ICS_GMF(4); ICS_GMF(1); ICS_GMF(5); ICS_GMF(2); ICS_GMF(6); ICS_GMF(3); ICS_GMF(7); ICS_GFN;
-#elif ICS_WG_SCHED == 2     // math first, fences every two MFMAs
-      tr_y(0); tr_y(1); tr_d(); ICS_GFN;
-      ICS_GMF(0); ICS_GMF(4); ICS_GFN; ICS_GMF(1); ICS_GMF(5); ICS_GFN; ICS_GMF(2); ICS_GMF(6); ICS_GFN; ICS_GMF(3); ICS_GMF(7); ICS_GFN;
-#elif ICS_WG_SCHED == 3     // math in two bursts between MFMA groups of four
-      tr_y(0); tr_y(1); ICS_GFN;
-      ICS_GMF(0); ICS_GMF(4); ICS_GMF(1); ICS_GMF(5); ICS_GFN;
-      tr_d(); ICS_GFN;
-      ICS_GMF(2); ICS_GMF(6); ICS_GMF(3); ICS_GMF(7); ICS_GFN;
-#else                       // no fences inside the step
-      ICS_GMF(0); tr_y(0); ICS_GMF(4); tr_y(1); ICS_GMF(1); tr_d(); ICS_GMF(5); ICS_GMF(2); ICS_GMF(6); ICS_GMF(3); ICS_GMF(7); ICS_GFN;
 #endif
 #undef ICS_GMF
       // measured (ms of this kernel per U-Net step): these 24 ops interleaved with the MFMAs above 10.35, the whole
       // transform as a burst here 10.34, this split 9.8: the burst runs under the other wave's MFMAs
+#if !(ICS_WG_ABL & 1)
       tr_x(t0, un); tr_x(t1, un + 4); tr_v(rl, vn); tr_v(rh, vn + 4);
+#endif
       // raw reads two steps ahead: step p+2 of this block, or step (p+2)-8 of the next one.  At p == 5 the next block
       // is stored first (its arithmetic then runs without the raw-read registers live), and the barrier after BOTH:
       // every read of `cur` is issued before it, the next block is visible before step 6 reads its step 0
+#if !(ICS_WG_ABL & 4)
       if (p == 5) sstore(nxt);
+#endif
+#if !(ICS_WG_ABL & 2)
       if (p < 6) rd(cur, p + 2); else rd(nxt, p - 6);
+#endif
+#if !(ICS_WG_ABL & 4)
       if (p == 5) __syncthreads();
+#endif
       ICS_GFN;
 #undef ICS_GFN
     }
@@ -722,19 +726,20 @@ int launch_conv_fwd_wino(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, c
 }
 
 // ---------------------------------------------------------------- backward-weight launcher
-// blocks per workgroup: a power of two >= 2 that divides the blocks of one sample (every split full, even count),
-// small enough for ~2 workgroups per CU, large enough for the workspace
+// blocks per workgroup: a power of two >= 2 that divides the number of blocks (every split full, even count), small
+// enough for ~2 workgroups per CU, large enough for the workspace.  A split is a contiguous range of the linear block
+// index (b, bz, by, bx) and may span samples: capping it at one sample's blocks (round 2) left the S = 8 layers with 32
+// splits of 4 blocks where 4 splits of 32 were wanted -- 8x the fixed cost and 8x the partial sums (c14: 0.62 ms).
 static int wino_wgrad_per_split(const ConvGeom& g, size_t ws_floats) {
-  const int bps = (g.S / 4) * (g.S / 4) * (g.S / 8);               // blocks per sample: a power of two >= 4
-  const int nblocks = g.B * bps;
+  const int nblocks = g.B * (g.S / 4) * (g.S / 4) * (g.S / 8);
   const int pairs = (g.Cin / 32) * (g.Cout / 32);
   // ~2 workgroups per CU (measured per U-Net step: 256 -> 36.96 ms, 512 -> 37.05, 1536 -> 37.15, 3072 -> 37.7; one
   // round of workgroups would double the launch time whenever a communication kernel holds a few CUs)
   const int want = std::max((512 + pairs - 1) / pairs, 1);          // splits wanted
   const size_t per = (size_t)27 * g.Cin * g.Cout;
   int ps = 2;
-  while (ps < bps && ((nblocks / ps) > want || (size_t)(nblocks / ps) * per > ws_floats)) ps *= 2;
-  if ((size_t)(nblocks / ps) * per > ws_floats) return 0;
+  while (nblocks % (2 * ps) == 0 && ((nblocks / ps) > want || (size_t)(nblocks / ps) * per > ws_floats)) ps *= 2;
+  if (nblocks % ps != 0 || (size_t)(nblocks / ps) * per > ws_floats) return 0;
   return ps;
 }
 size_t conv_wino_wgrad_workspace_floats(const ConvGeom& g) {
