@@ -41,10 +41,11 @@ __host__ __device__ __forceinline__ float uslope(int act) { return act == ACT_RE
 // x: low-res source [B][Sl][Sl][Sl][ldx]; y: fine output [B][2 Sl]^3 [ldo].  AFF / NOACT as in conv_wino64.hip.
 // STATS: per-block BatchNorm statistics of the stored values (the VAE decoder's layers; the U-Net's launches leave bias,
 // activation and statistics to the skip-channel pass that accumulates on top).
-// Registers: 112-117 VGPRs = four waves per SIMD = ONE nine-wave workgroup per CU (3 + 2 + 2 + 2 waves on the four
-// SIMDs: the matrix pipe of the fullest SIMD bounds the kernel at 75 %).  Two workgroups per CU (5 + 5 + 4 + 4) need
-// <= 96 VGPRs; capped there the allocator spills 16-28 registers inside the main loop (measured, also with the halo
-// staged in two 8-byte phases), so that stays open.
+// Registers: 112 VGPRs = four waves per SIMD = ONE nine-wave workgroup per CU (3 + 2 + 2 + 2 waves on the four SIMDs).
+// A 96-register build (halo staged in two 8-byte phases, no statistics, one register spilled per chunk) puts TWO
+// workgroups on a CU (5 + 5 + 4 + 4): measured SLOWER, 2.53 vs 2.41 ms per U-Net step -- the matrix pipe is not what
+// bounds this kernel.  Every MFMA takes a fresh 256-byte B operand from L2 (16 voxels per weight load): ~70 GB/s per CU,
+// ~18 TB/s over the chip, half of the L2's 34.5 TB/s, the same rate conv_wino64.hip runs at.
 template <bool AFF, bool NOACT, bool STATS>
 __global__ __launch_bounds__(576, 4) void conv_up3_kernel(const float* __restrict__ x, int ldx,
                                                           const float* __restrict__ in_scale,
