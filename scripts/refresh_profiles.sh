@@ -2,7 +2,7 @@
 # On the GPU box, from the repo root: full GPU test suite, the contract bench line, the rocprofv3 kernel statistics
 # of the same workloads (U-Net step; DFC-VAE step), and the PMC passes.  Outputs land in gpurun_out/refresh_<tag>/;
 # copy what is to be judged into profiles/ (scripts/collect_profiles.py).
-TAG=${1:-r2}
+TAG=${1:-r3}
 ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out/refresh_$TAG
 mkdir -p $OUT

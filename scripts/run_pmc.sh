@@ -9,12 +9,13 @@ P1="SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST
 P2="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_LDS_UNALIGNED_STALL SQ_WAVES"
 P3="FETCH_SIZE"
 P4="WRITE_SIZE"
+P5="TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"   # L2 / vector-L1 request counts
 i=0
-for P in "$P1" "$P2" "$P3" "$P4"; do
+for P in "$P1" "$P2" "$P3" "$P4" "$P5"; do
   i=$((i+1))
   timeout 600 rocprofv3 --kernel-trace --pmc $P -f csv -d $OUT/p$i -o p$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary "$@" > $OUT/p$i.log 2>&1
   rm -f $OUT/p$i/*kernel_trace.csv $OUT/p$i/*.db
 done
-KSTATS=${KSTATS:-} python3 $GRAFT_REPO_ROOT/scripts/pmc_summary.py $OUT conv_wino_kernel conv_wino_wgrad_kernel conv_fwd_kernel conv_wgrad_kernel conv_wgrad3_kernel conv_wgrad3s_kernel conv_thin_n bn_bwd pool27 head_kernel adam > $OUT/summary.txt 2>&1
+KSTATS=${KSTATS:-} python3 $GRAFT_REPO_ROOT/scripts/pmc_summary.py $OUT conv_wino64_kernel conv_up3_kernel conv_wino_kernel conv_wino_wgrad_kernel conv_fwd_kernel conv_wgrad_kernel conv_wgrad3_kernel conv_wgrad3s_kernel conv_thin_n bn_bwd pool27 head_kernel adam > $OUT/summary.txt 2>&1
 find $OUT -name "*counter_collection.csv" -size +8M -delete
 head -60 $OUT/summary.txt
