@@ -100,12 +100,10 @@ __global__ __launch_bounds__(576, 4) void conv_up3_kernel(const float* __restric
   }
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, 0x7fffffff, 0x00020000);
   // per-thread staging constants parked in LDS (conv_wino64.hip explains why)
-  const unsigned park_base = (unsigned)(uintptr_t)&park[0] + (unsigned)w * 256u;     // this wave's slice (LDS byte address)
-  auto unpark = [&](const int which) -> int {    // lane id rebuilt inside the statement: no VGPR stays live for the address
+  const unsigned park_addr = (unsigned)(uintptr_t)&park[tid];
+  auto unpark = [&](const int which) -> int {
     int v;
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshl_add_u32 %0, %0, 2, %1\n\t"
-                 "ds_read_b32 %0, %0 offset:%2\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(v) : "s"(park_base), "i"(which * 2304) : "memory");
+    asm volatile("ds_read_b32 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(park_addr), "i"(which * 2304) : "memory");
     return v;
   };
   if (AFF) {

@@ -108,14 +108,10 @@ __global__ __launch_bounds__(512) void conv_wino64_kernel(const float* __restric
   park[tid] = voff;
   park[512 + tid] = (unsigned)dbase;
   park[1024 + tid] = (unsigned)(q * 4);
-  // read back with the lane id rebuilt inside the asm statement (v_mbcnt) and a wave-uniform base: no VGPR stays live
-  // for it (a parked ADDRESS in a register was itself spilled once the epilogue grew)
-  const unsigned park_base = (unsigned)(uintptr_t)&park[0] + (unsigned)w * 256u;     // LDS byte address of this wave's slice
+  const unsigned park_addr = (unsigned)(uintptr_t)&park[tid];     // LDS byte address (low half of the generic pointer)
   auto unpark = [&](const int which) -> int {    // an LDS read the compiler can neither hoist nor keep in a register
     int v;
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshl_add_u32 %0, %0, 2, %1\n\t"
-                 "ds_read_b32 %0, %0 offset:%2\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(v) : "s"(park_base), "i"(which * 2048) : "memory");
+    asm volatile("ds_read_b32 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(park_addr), "i"(which * 2048) : "memory");
     return v;
   };
   // AFF: the producer's per-channel scale / shift of ALL input channels sit in LDS behind the two buffers (Cin <= 1024:
@@ -350,22 +346,6 @@ __global__ __launch_bounds__(512) void conv_wino64_kernel(const float* __restric
   vf4 f1[2], f2s[2];
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
-    // the pass's global reads (accumulate: the values already in y; FOLD: the producer's stored activations; bias) are
-    // issued HERE, ahead of the LDS round trip of the partial sums, instead of where they are consumed
-    const int nn = n0 + (pass * 2 + jl) * 16 + cq * 4;             // this thread's four output channels
-    const size_t o0 = vox0 * ldo + nn;
-    const size_t o1 = o0 + (size_t)S * S * ldo;
-    vf4 ya0 = {0.f, 0.f, 0.f, 0.f}, ya1 = ya0, bv = ya0, sv0 = ya0, sv1 = ya0;
-    if (accumulate) {
-      ya0 = *reinterpret_cast<const vf4*>(y + o0);
-      ya1 = *reinterpret_cast<const vf4*>(y + o1);
-    }
-    if (bias != nullptr) bv = *reinterpret_cast<const vf4*>(bias + nn);
-    if (FOLD) {
-      const size_t s0 = vox0 * bs.ld + nn;
-      sv0 = *reinterpret_cast<const vf4*>(bs.s + s0);
-      sv1 = *reinterpret_cast<const vf4*>(bs.s + s0 + (size_t)S * S * bs.ld);
-    }
     __syncthreads();
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
@@ -389,12 +369,21 @@ __global__ __launch_bounds__(512) void conv_wino64_kernel(const float* __restric
       }
     }
     __syncthreads();
+    const int nn = n0 + (pass * 2 + jl) * 16 + cq * 4;             // this thread's four output channels
     vf4 p[4];
 #pragma unroll
     for (int z = 0; z < 4; ++z)
       p[z] = *reinterpret_cast<const vf4*>(&part[(2 * z) * 2048 + slot_rd]) +
              *reinterpret_cast<const vf4*>(&part[(2 * z + 1) * 2048 + slot_rd]);
-    vf4 e0 = p[0] + p[1] + p[2] + bv + ya0, e1 = p[1] - p[2] - p[3] + bv + ya1;
+    vf4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias != nullptr) bv = *reinterpret_cast<const vf4*>(bias + nn);
+    const size_t o0 = vox0 * ldo + nn;
+    const size_t o1 = o0 + (size_t)S * S * ldo;
+    vf4 e0 = p[0] + p[1] + p[2] + bv, e1 = p[1] - p[2] - p[3] + bv;
+    if (accumulate) {
+      e0 += *reinterpret_cast<const vf4*>(y + o0);
+      e1 += *reinterpret_cast<const vf4*>(y + o1);
+    }
     e0.x = wact(e0.x, pre_slope); e0.y = wact(e0.y, pre_slope); e0.z = wact(e0.z, pre_slope); e0.w = wact(e0.w, pre_slope);
     e1.x = wact(e1.x, pre_slope); e1.y = wact(e1.y, pre_slope); e1.z = wact(e1.z, pre_slope); e1.w = wact(e1.w, pre_slope);
     *reinterpret_cast<vf4*>(y + o0) = e0;
@@ -403,6 +392,9 @@ __global__ __launch_bounds__(512) void conv_wino64_kernel(const float* __restric
     csum[pass] = e0 + e1;
     if (FOLD) {
       const vf4 b_mu = *reinterpret_cast<const vf4*>(bs.mean + nn), b_rs = *reinterpret_cast<const vf4*>(bs.rstd + nn);
+      const size_t s0 = vox0 * bs.ld + nn;
+      const vf4 sv0 = *reinterpret_cast<const vf4*>(bs.s + s0);
+      const vf4 sv1 = *reinterpret_cast<const vf4*>(bs.s + s0 + (size_t)S * S * bs.ld);
       vf4 d0 = e0, d1 = e1;
       if (bs.post_act != ACT_NONE) {
         const vf4 b_sc = *reinterpret_cast<const vf4*>(bs.scale + nn), b_sh = *reinterpret_cast<const vf4*>(bs.shift + nn);
