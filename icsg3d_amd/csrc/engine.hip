@@ -2024,7 +2024,8 @@ int ics_vae_decode_to_unet_atoms(ics_net* vae, ics_net* unet, const float* z, co
 
 int ics_op_segment_atoms(const uint8_t* mask, const uint8_t* species, int batch, int d, int min_voxels, int max_atoms,
                          int num_species, int32_t* regions, int32_t* counts, int32_t* atom_stats) {
-  ICS_CHECK(mask && species && batch >= 1, "bad segmentation arguments");
+  ICS_CHECK(mask && species && batch >= 1 && max_atoms >= 1 && min_voxels >= 0, "bad segmentation arguments");
+  ICS_CHECK(d >= 16 && d <= 256 && (d & (d - 1)) == 0, "grid must be a power of two in [16, 256]");
   Net n;
   ICS_TRY(net_common_init(n));
   const size_t M = (size_t)batch * d * d * d;

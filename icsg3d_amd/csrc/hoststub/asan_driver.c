@@ -80,6 +80,14 @@ static int run(int d, int C, int B, int with_comm) {
     OK(ics_vae_encode(vae, x, cond, eps, b, z, z + (size_t)B * 256, z + (size_t)B * 512));
     OK(ics_vae_decode(vae, z, cond, b, rec));
     OK(ics_vae_decode_to_unet_labels(vae, unet, z, cond, b, 0.8f, sp, mk, rec, minmax));
+    {   /* ... continued through connected components / region statistics */
+      int32_t* regions = (int32_t*)malloc(M * sizeof(int32_t));
+      int32_t counts[2 * 8];
+      int32_t* stats = (int32_t*)malloc((size_t)b * 64 * 11 * sizeof(int32_t));
+      OK(ics_vae_decode_to_unet_atoms(vae, unet, z, cond, b, 0.8f, 3, 64, sp, mk, rec, minmax, regions, counts, stats));
+      OK(ics_vae_decode_to_unet_atoms(vae, unet, z, cond, b, 0.8f, 3, 64, NULL, NULL, NULL, NULL, NULL, counts, stats));
+      free(regions); free(stats);
+    }
   }
   OK(ics_unet_upload_batch(unet, x, lab, B));
   OK(ics_unet_train_step_resident(unet, NULL));
@@ -132,6 +140,17 @@ int main(void) {
     OK(ics_op_conv3d_forward(x, w, NULL, B, S, Cin, Cout, 27, 1, y));
     OK(ics_op_conv3d_backward(x, w, y, B, S, Cin, Cout, 27, dx, dw));
     free(x); free(y); free(w); free(dx); free(dw);
+  }
+  {   /* connected components on host arrays */
+    const int B = 2, d = 16;
+    const size_t M = (size_t)B * d * d * d;
+    uint8_t *mask = calloc(M, 1), *species = calloc(M, 1);
+    int32_t* regions = malloc(M * sizeof(int32_t));
+    int32_t counts[4];
+    int32_t* stats = malloc((size_t)B * 32 * 11 * sizeof(int32_t));
+    OK(ics_op_segment_atoms(mask, species, B, d, 3, 32, 95, regions, counts, stats));
+    if (ics_op_segment_atoms(mask, species, B, 24, 3, 32, 95, regions, counts, stats) == 0) { fprintf(stderr, "grid check missing\n"); return 1; }
+    free(mask); free(species); free(regions); free(stats);
   }
   printf("asan driver: all entry points walked, no sanitizer report\n");
   return 0;

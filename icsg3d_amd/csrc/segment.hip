@@ -168,6 +168,7 @@ int launch_segment_atoms(hipStream_t st, const unsigned char* mask, const unsign
   const unsigned gv = (unsigned)((n + 255) / 256), ga = (unsigned)((natoms + 255) / 256);
   ICS_HIP(hipMemsetAsync(size, 0, n * 4, st));
   ICS_HIP(hipMemsetAsync(hist, 0, natoms * nbins * 4, st));
+  ICS_HIP(hipMemsetAsync(counts, 0, (size_t)B * 2 * 4, st));
   hipLaunchKernelGGL(seg_init_kernel, dim3(gv), dim3(256), 0, st, mask, lab, n);
   hipLaunchKernelGGL(seg_stats_init_kernel, dim3(ga), dim3(256), 0, st, stats, natoms, d);
   hipLaunchKernelGGL(seg_merge_kernel, dim3(gv), dim3(256), 0, st, mask, lab, lgd, n);
