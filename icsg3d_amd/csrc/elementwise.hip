@@ -463,6 +463,195 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(LayerBwd L, int rows_
   }
 }
 
+// Fast path of the apply pass (VW = 4, BatchNorm present, no extra tap gradient, consumers at the same resolution
+// and/or behind the max-pool -- every U-Net layer and the plain VAE layers): the generic kernel above keeps ONE
+// float4 pair per thread in flight at 4 waves/SIMD (126 VGPRs of run-time source dispatch), 32 KB per CU, and gives
+// each block its own 256 KB region: 3.3 TB/s.  Here the source kinds are compile-time, the per-channel constants
+// live in registers, UNR rows per thread are loaded before the first is used, and the blocks walk the tensor
+// interleaved (pass p of block b = rows (b + p*gridDim)*RPP ...), so all resident blocks read one compact window.
+// Element arithmetic is the generic kernel's (up to fma contraction); only the order of the per-block bias-gradient
+// and tap-loss partial sums differs.
+__device__ __forceinline__ float4 ldf4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+template <int G0, int G1, bool TIES, int UNR, bool TAP = false>
+__global__ __launch_bounds__(256) void bn_bwd_apply_fast_kernel(LayerBwd L, const float* __restrict__ c1,
+                                                                 const float* __restrict__ c2, float* __restrict__ dy,
+                                                                 float* __restrict__ db_partial) {
+  __shared__ float sh1[1024];
+  __shared__ double shd[4];
+  double tap_sq = 0.0;
+  const int C = L.C, CB = C >> 2, RPP = 256 / CB;
+  const int t = threadIdx.x, tc = t % CB, tr = t / CB, c = tc * 4;
+  const size_t M = (size_t)L.B << (3 * L.lgS);
+  const size_t npass = M / RPP, stride = gridDim.x;
+  const float4 sc = ldf4(L.scale + c), shf = ldf4(L.shift + c), mu = ldf4(L.mean + c), rs = ldf4(L.rstd + c);
+  const float4 k1 = ldf4(c1 + c), k2 = ldf4(c2 + c);
+  const int post = L.post_act, pre = L.pre_act;
+  const int lg = L.lgS, Sm = L.S - 1, Sh = L.S >> 1;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+
+  auto body = [&](size_t p0, auto unr_tag) {
+    constexpr int U = decltype(unr_tag)::value;
+    float4 sv[U], d0[U], d1[U], ym[U], rf[U];
+    unsigned pi[U];
+    size_t row[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      row[u] = (p0 + (size_t)u * stride) * RPP + tr;
+      sv[u] = ldf4(L.s + row[u] * C + c);
+      if (G0 == GS_DIRECT) {
+        d0[u] = ldf4(L.g0.p + row[u] * L.g0.ld + L.g0.off + c);
+      } else {   // GS_POOL
+        const size_t r = row[u];
+        const int x = (int)(r & Sm), y = (int)((r >> lg) & Sm), z = (int)((r >> (2 * lg)) & Sm);
+        const size_t b = r >> (3 * lg);
+        const size_t prow = ((b * Sh + (z >> 1)) * Sh + (y >> 1)) * Sh + (x >> 1);
+        d0[u] = ldf4(L.g0.p + prow * L.g0.ld + L.g0.off + c);
+        if (TIES) ym[u] = ldf4(L.g0.pooled + prow * C + c);
+        else {
+          pi[u] = *reinterpret_cast<const unsigned*>(L.g0.pool_idx + prow * C + c);
+          const unsigned k = (unsigned)(((z & 1) << 2) | ((y & 1) << 1) | (x & 1));
+          pi[u] ^= k * 0x01010101u;          // byte j == 0  <=>  this voxel is channel c+j's (first) maximum
+        }
+      }
+      if (G1 == GS_DIRECT) d1[u] = ldf4(L.g1.p + row[u] * L.g1.ld + L.g1.off + c);
+      if (TAP) rf[u] = ldf4(L.tap_ref + row[u] * C + c);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float s4[4] = {sv[u].x, sv[u].y, sv[u].z, sv[u].w};
+      const float a4[4] = {sc.x, sc.y, sc.z, sc.w}, b4[4] = {shf.x, shf.y, shf.z, shf.w};
+      const float m4[4] = {mu.x, mu.y, mu.z, mu.w}, r4[4] = {rs.x, rs.y, rs.z, rs.w};
+      const float k14[4] = {k1.x, k1.y, k1.z, k1.w}, k24[4] = {k2.x, k2.y, k2.z, k2.w};
+      const float g04[4] = {d0[u].x, d0[u].y, d0[u].z, d0[u].w};
+      float g[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float bnout = fmaf(s4[j], a4[j], b4[j]);
+        const float xh = (s4[j] - m4[j]) * r4[j];
+        float d;
+        if (G0 == GS_DIRECT) d = g04[j];
+        else if (TIES) {
+          const float y4[4] = {ym[u].x, ym[u].y, ym[u].z, ym[u].w};
+          d = fabsf(act_fwd(bnout, post) - y4[j]) < kPoolTieTol ? g04[j] : 0.f;
+        } else d = ((pi[u] >> (8 * j)) & 0xffu) == 0u ? g04[j] : 0.f;
+        if (G1 == GS_DIRECT) {
+          const float g14[4] = {d1[u].x, d1[u].y, d1[u].z, d1[u].w};
+          d += g14[j];
+        }
+        d *= act_grad(bnout, post);
+        float ds = a4[j] * (d - k14[j] - xh * k24[j]);
+        if (TAP) {   // perceptual tap: see bn_bwd_apply_kernel<VW, true>
+          const float r4f[4] = {rf[u].x, rf[u].y, rf[u].z, rf[u].w};
+          const float df = s4[j] - r4f[j];
+          ds += L.tap_coef * df;
+          tap_sq += (double)df * (double)df;
+        }
+        g[j] = ds * act_grad(s4[j], pre);
+        acc[j] += g[j];
+      }
+      *reinterpret_cast<float4*>(dy + row[u] * C + c) = make_float4(g[0], g[1], g[2], g[3]);
+    }
+  };
+  size_t p = blockIdx.x;
+  for (; p + (size_t)(UNR - 1) * stride < npass; p += (size_t)UNR * stride) body(p, std::integral_constant<int, UNR>{});
+  for (; p < npass; p += stride) body(p, std::integral_constant<int, 1>{});
+
+  if (db_partial) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sh1[t * 4 + j] = acc[j];
+    __syncthreads();
+    for (int col = t; col < C; col += 256) {
+      const int tcc = col >> 2, jj = col & 3;
+      float sacc = 0.f;
+      for (int r = 0; r < RPP; ++r) sacc += sh1[(r * CB + tcc) * 4 + jj];
+      db_partial[(size_t)blockIdx.x * C + col] = sacc;
+    }
+  }
+  if (TAP) {
+    const double tot = block_sum_d(tap_sq, shd);
+    if (threadIdx.x == 0) L.tap_partial[blockIdx.x] = tot;
+  }
+}
+
+// the reduce pass in the same shape (layers whose dO has two sources or sits behind the max-pool keep this pass;
+// everywhere else the backward-data epilogue already summed these)
+template <int G0, int G1, bool TIES, int UNR>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_fast_kernel(LayerBwd L, float* __restrict__ partial) {
+  __shared__ float sh1[1024], sh2[1024];
+  const int C = L.C, CB = C >> 2, RPP = 256 / CB;
+  const int t = threadIdx.x, tc = t % CB, tr = t / CB, c = tc * 4;
+  const size_t M = (size_t)L.B << (3 * L.lgS);
+  const size_t npass = M / RPP, stride = gridDim.x;
+  const float4 sc = ldf4(L.scale + c), shf = ldf4(L.shift + c), mu = ldf4(L.mean + c), rs = ldf4(L.rstd + c);
+  const int post = L.post_act;
+  const int lg = L.lgS, Sm = L.S - 1, Sh = L.S >> 1;
+  float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+
+  auto body = [&](size_t p0, auto unr_tag) {
+    constexpr int U = decltype(unr_tag)::value;
+    float4 sv[U], d0[U], d1[U], ym[U];
+    unsigned pi[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t r = (p0 + (size_t)u * stride) * RPP + tr;
+      sv[u] = ldf4(L.s + r * C + c);
+      if (G0 == GS_DIRECT) {
+        d0[u] = ldf4(L.g0.p + r * L.g0.ld + L.g0.off + c);
+      } else {
+        const int x = (int)(r & Sm), y = (int)((r >> lg) & Sm), z = (int)((r >> (2 * lg)) & Sm);
+        const size_t b = r >> (3 * lg);
+        const size_t prow = ((b * Sh + (z >> 1)) * Sh + (y >> 1)) * Sh + (x >> 1);
+        d0[u] = ldf4(L.g0.p + prow * L.g0.ld + L.g0.off + c);
+        if (TIES) ym[u] = ldf4(L.g0.pooled + prow * C + c);
+        else {
+          pi[u] = *reinterpret_cast<const unsigned*>(L.g0.pool_idx + prow * C + c);
+          pi[u] ^= (unsigned)(((z & 1) << 2) | ((y & 1) << 1) | (x & 1)) * 0x01010101u;
+        }
+      }
+      if (G1 == GS_DIRECT) d1[u] = ldf4(L.g1.p + r * L.g1.ld + L.g1.off + c);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float s4[4] = {sv[u].x, sv[u].y, sv[u].z, sv[u].w};
+      const float a4[4] = {sc.x, sc.y, sc.z, sc.w}, b4[4] = {shf.x, shf.y, shf.z, shf.w};
+      const float m4[4] = {mu.x, mu.y, mu.z, mu.w}, r4[4] = {rs.x, rs.y, rs.z, rs.w};
+      const float g04[4] = {d0[u].x, d0[u].y, d0[u].z, d0[u].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float bnout = fmaf(s4[j], a4[j], b4[j]);
+        const float xh = (s4[j] - m4[j]) * r4[j];
+        float d;
+        if (G0 == GS_DIRECT) d = g04[j];
+        else if (TIES) {
+          const float y4[4] = {ym[u].x, ym[u].y, ym[u].z, ym[u].w};
+          d = fabsf(act_fwd(bnout, post) - y4[j]) < kPoolTieTol ? g04[j] : 0.f;
+        } else d = ((pi[u] >> (8 * j)) & 0xffu) == 0u ? g04[j] : 0.f;
+        if (G1 == GS_DIRECT) {
+          const float g14[4] = {d1[u].x, d1[u].y, d1[u].z, d1[u].w};
+          d += g14[j];
+        }
+        d *= act_grad(bnout, post);
+        a1[j] += d;
+        a2[j] += d * xh;
+      }
+    }
+  };
+  size_t p = blockIdx.x;
+  for (; p + (size_t)(UNR - 1) * stride < npass; p += (size_t)UNR * stride) body(p, std::integral_constant<int, UNR>{});
+  for (; p < npass; p += stride) body(p, std::integral_constant<int, 1>{});
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { sh1[t * 4 + j] = a1[j]; sh2[t * 4 + j] = a2[j]; }
+  __syncthreads();
+  for (int col = t; col < C; col += 256) {
+    const int tcc = col >> 2, jj = col & 3;
+    float s1 = 0.f, s2 = 0.f;
+    for (int r = 0; r < RPP; ++r) { s1 += sh1[(r * CB + tcc) * 4 + jj]; s2 += sh2[(r * CB + tcc) * 4 + jj]; }
+    partial[((size_t)0 * C + col) * gridDim.x + blockIdx.x] = s1;
+    partial[((size_t)1 * C + col) * gridDim.x + blockIdx.x] = s2;
+  }
+}
+
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partial,
                                                                int nblk, int C, float* __restrict__ out) {
   __shared__ double sh[4];
@@ -477,7 +666,8 @@ int bn_bwd_num_blocks(const LayerBwd& L, int* rows_per_block) {
   const size_t M = (size_t)L.B << (3 * L.lgS);
   // aim for ~2048 blocks, at least 64 rows each
   size_t rpb = (M + 2047) / 2048;
-  if (rpb < 64) rpb = 64;
+  const size_t lo = M / 256 < 8 ? 8 : (M / 256 > 64 ? 64 : M / 256);   // S = 4 layers: 256 blocks, not 32
+  if (rpb < lo) rpb = lo;
   const int VW = (L.C % 4 == 0) ? 4 : 1;
   const int CV = L.C / VW, CB = CV < 256 ? CV : 256, RPP = 256 / CB;
   rpb = (rpb + RPP - 1) / RPP * RPP;
@@ -493,12 +683,26 @@ int launch_layer_bwd(hipStream_t st, const LayerBwd& L, float* dy, float* ws_par
   float* c1 = c1c2;
   float* c2 = c1c2 + L.C;
   const bool v4 = (L.C % 4 == 0);
+  const int cb = L.C >> 2;
+  const bool fast = v4 && L.has_bn && !L.dtap && (!L.tap_ref || (L.g0.kind == GS_DIRECT && L.g1.kind == GS_NONE)) && cb <= 256 && (cb & (cb - 1)) == 0 &&
+                    ((size_t)n % (size_t)(256 / (cb ? cb : 1))) == 0 &&
+                    (L.g0.kind == GS_DIRECT || L.g0.kind == GS_POOL) &&
+                    (L.g1.kind == GS_NONE || L.g1.kind == GS_DIRECT) && std::getenv("ICSG3D_NO_FAST_BNBWD") == nullptr;
   if (L.has_bn) {
     const float* red = ws_partial;
     int red_n = nblk, red_ld = L.C;
     if (pre != nullptr && pre->nblk > 0) {
       // the backward-data launch that produced dO already summed d and d*xhat per block (BwdStat)
       red = pre->partial; red_n = pre->nblk; red_ld = pre->ld;
+    } else if (fast) {
+#define ICS_BNR(G0_, G1_, T_, U_) \
+      hipLaunchKernelGGL((bn_bwd_reduce_fast_kernel<G0_, G1_, T_, U_>), dim3(nblk), dim3(256), 0, st, L, ws_partial)
+      const bool g1 = L.g1.kind == GS_DIRECT, ties = L.pool_ties_all != 0;
+      if (L.g0.kind == GS_DIRECT) { if (g1) ICS_BNR(GS_DIRECT, GS_DIRECT, false, 4); else ICS_BNR(GS_DIRECT, GS_NONE, false, 4); }
+      else if (ties) { if (g1) ICS_BNR(GS_POOL, GS_DIRECT, true, 2); else ICS_BNR(GS_POOL, GS_NONE, true, 2); }
+      else { if (g1) ICS_BNR(GS_POOL, GS_DIRECT, false, 2); else ICS_BNR(GS_POOL, GS_NONE, false, 2); }
+#undef ICS_BNR
+      ICS_HIP(hipGetLastError());
     } else {
       if (v4) hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, dim3(nblk), dim3(256), 0, st, L, rpb, ws_partial);
       else hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(nblk), dim3(256), 0, st, L, rpb, ws_partial);
@@ -516,7 +720,17 @@ int launch_layer_bwd(hipStream_t st, const LayerBwd& L, float* dy, float* ws_par
     }
   }
   float* dbp = dbias ? ws_partial : nullptr;
-  if (L.tap_ref) {
+  if (fast) {
+    // M = B * S^3 with S >= 4 a power of two and RPP <= 64 rows per pass: whole passes
+#define ICS_BNF(G0_, G1_, T_, U_) \
+    hipLaunchKernelGGL((bn_bwd_apply_fast_kernel<G0_, G1_, T_, U_>), dim3(nblk), dim3(256), 0, st, L, c1, c2, dy, dbp)
+    const bool g1 = L.g1.kind == GS_DIRECT, ties = L.pool_ties_all != 0;
+    if (L.tap_ref) hipLaunchKernelGGL((bn_bwd_apply_fast_kernel<GS_DIRECT, GS_NONE, false, 4, true>), dim3(nblk), dim3(256), 0, st, L, c1, c2, dy, dbp);
+    else if (L.g0.kind == GS_DIRECT) { if (g1) ICS_BNF(GS_DIRECT, GS_DIRECT, false, 4); else ICS_BNF(GS_DIRECT, GS_NONE, false, 4); }
+    else if (ties) { if (g1) ICS_BNF(GS_POOL, GS_DIRECT, true, 2); else ICS_BNF(GS_POOL, GS_NONE, true, 2); }
+    else { if (g1) ICS_BNF(GS_POOL, GS_DIRECT, false, 2); else ICS_BNF(GS_POOL, GS_NONE, false, 2); }
+#undef ICS_BNF
+  } else if (L.tap_ref) {
     if (v4) hipLaunchKernelGGL((bn_bwd_apply_kernel<4, true>), dim3(nblk), dim3(256), 0, st, L, rpb, c1, c2, dy, dbp);
     else hipLaunchKernelGGL((bn_bwd_apply_kernel<1, true>), dim3(nblk), dim3(256), 0, st, L, rpb, c1, c2, dy, dbp);
   } else {

@@ -1,6 +1,6 @@
 """Per-layer conv micro-benchmark (HIP events): python scripts/conv_bench.py [B]"""
 import ctypes as C, sys
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from icsg3d_amd import _lib
 lib = _lib.load()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32

@@ -1,7 +1,7 @@
 """Developer timing helper (not the contract bench): U-Net train step at B=32,d=32 with per-kernel rows."""
 import sys, time
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from oracle import numpy_ref as R
 from icsg3d_amd.engine import UnetEngine
 

@@ -1,5 +1,5 @@
 import sys, time, numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from icsg3d_amd.engine import UnetEngine, VaeEngine
 from icsg3d_amd.synthetic import glorot_params, synthetic_batch, unet_param_shapes, vae_param_shapes
 B, d = 8, 64

@@ -1,7 +1,7 @@
 """Winograd kernel A/B on the bench shapes (HIP events, ics_op_conv3d_bench takes the engine's path for the shape):
 python scripts/wino_bench.py   -- run once plain, once with ICSG3D_NO_WINO64=1 to compare the two kernel shapes."""
 import ctypes as C, os, sys
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from icsg3d_amd import _lib
 lib = _lib.load()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
