@@ -36,6 +36,18 @@
 #define ICS_W64_PRIO 0       // 1: s_setprio(1) around a column's MFMAs (measured: +1 % time)
 #endif
 
+#ifdef ICS_W64_TIMELINE
+// variant builds only (scripts/variants.sh conv_wino64 "tl:-DICS_W64_TIMELINE"): per workgroup {entry, first chunk staged,
+// main loop done, exit; 4..: inside the epilogue} wall-clock stamps + HW_ID / XCC_ID, fetched with ics_debug_w64_timeline (scripts/w64_timeline.py)
+__device__ unsigned long long ics_w64_tl[16 * 32768];
+extern "C" int ics_debug_w64_timeline(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ics_w64_tl), (size_t)n * 8);
+}
+#define ICS_TL(i) do { if (threadIdx.x == 0 && blockIdx.x < 32768) ics_w64_tl[(size_t)blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define ICS_TL(i)
+#endif
+
 namespace ics {
 
 typedef float vf4 __attribute__((ext_vector_type(4)));
@@ -61,6 +73,7 @@ __global__ __launch_bounds__(512) void conv_wino64_kernel(const float* __restric
   __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
   __shared__ unsigned park[1536];
   __shared__ __attribute__((aligned(16))) float aff[AFF ? 2048 : 4];
+  ICS_TL(0);
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fz = w >> 1, fyh = w & 1;            // this wave: frequencies (fz, 2 fyh + {0,1}, 0..3)
@@ -108,10 +121,14 @@ __global__ __launch_bounds__(512) void conv_wino64_kernel(const float* __restric
   park[tid] = voff;
   park[512 + tid] = (unsigned)dbase;
   park[1024 + tid] = (unsigned)(q * 4);
-  const unsigned park_addr = (unsigned)(uintptr_t)&park[tid];     // LDS byte address (low half of the generic pointer)
+  // LDS byte address of the wave's 64 entries (scalar); the lane part is rebuilt from v_mbcnt at every read: a per-lane
+  // address register is itself one more value for the allocator to spill (it did, with a vmcnt(0) reload per read)
+  const unsigned park_wave = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)&park[0] + (unsigned)w * 256u);
   auto unpark = [&](const int which) -> int {    // an LDS read the compiler can neither hoist nor keep in a register
     int v;
-    asm volatile("ds_read_b32 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(park_addr), "i"(which * 2048) : "memory");
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshl_add_u32 %0, %0, 2, %1\n\t"
+                 "ds_read_b32 %0, %0 offset:%2\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v) : "s"(park_wave), "i"(which * 2048) : "memory");
     return v;
   };
   // AFF: the producer's per-channel scale / shift of ALL input channels sit in LDS behind the two buffers (Cin <= 1024:
@@ -243,6 +260,7 @@ __global__ __launch_bounds__(512) void conv_wino64_kernel(const float* __restric
   if (AFF) __syncthreads();                      // scale / shift visible
   sstore(0, 0);
   __syncthreads();
+  ICS_TL(1);
 
   auto rd = [&](const int ra, const int rb, const int rc, const int sub, const int col) {
     const int off = col * VX + 4 * sub;          // compile-time after unrolling
@@ -260,10 +278,20 @@ __global__ __launch_bounds__(512) void conv_wino64_kernel(const float* __restric
 
   const int nch = Cin / KC;
   int nxt = BUF;                                 // float offset of the buffer being filled (the other one is consumed)
-  for (int ch = 0; ch < nch; ++ch) {
+#ifndef ICS_W64_PEEL
+#define ICS_W64_PEEL 1       // 1: the last chunk is a second copy of the loop body without the staging of a next chunk
+#endif
+  // ST = false: nothing is staged (the last chunk; its read-ahead columns wrap around inside the buffer being consumed
+  // and are never used)
+  auto chunk = [&](const int ch, auto stage_tag) {
+    constexpr bool ST = decltype(stage_tag)::value;
+#if ICS_W64_PEEL
+    const int cn = (ch + 1) * KC;
+#else
     const int cn = (ch + 1 < nch ? ch + 1 : ch) * KC;                   // past the end: the last chunk again (never consumed)
+#endif
     const int dlt = 2 * nxt - BUF;               // + BUF / - BUF: from the buffer being consumed to the other one
-    hload(0, cn);
+    if (ST) hload(0, cn);
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       int gs = ch * 8 + s + 1;
@@ -276,11 +304,11 @@ __global__ __launch_bounds__(512) void conv_wino64_kernel(const float* __restric
 #else
         const float a = qa, bq = qb, c = qc;
 #endif
-        if (s == 3 && g == 3) {                  // first half of the next chunk's planes; then the second half's rows
+        if (ST && s == 3 && g == 3) {            // first half of the next chunk's planes; then the second half's rows
           hstore(0, nxt, cn);
           hload(1, cn);
         }
-        if (s == 6 && g == 3) {                  // the next chunk must be visible before its first column is read
+        if (ST && s == 6 && g == 3) {            // the next chunk must be visible before its first column is read
           hstore(1, nxt, cn);
           __syncthreads();
           Ra += dlt; Rb += dlt; Rc += dlt;       // every read from here on is in the other buffer
@@ -328,12 +356,32 @@ __global__ __launch_bounds__(512) void conv_wino64_kernel(const float* __restric
       xform();
     }
     nxt = BUF - nxt;
-  }
+  };
+#if ICS_W64_PEEL
+  for (int ch = 0; ch < nch - 1; ++ch) chunk(ch, std::true_type{});
+  chunk(nch - 1, std::false_type{});
+#else
+  for (int ch = 0; ch < nch; ++ch) chunk(ch, std::true_type{});
+#endif
 
+  ICS_TL(2);
+#ifdef ICS_W64_TIMELINE
+  auto tl_flush = [&]() {
+    if (threadIdx.x == 0 && blockIdx.x < 32768) {
+      unsigned long long* r = ics_w64_tl + (size_t)blockIdx.x * 16;
+      r[3] = wall_clock64();
+      r[14] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID: wave[3:0] simd[5:4] pipe[7:6] cu[11:8] sh[12] se[15:13]
+      r[15] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
+    }
+  };
+#define ICS_TL_FLUSH() tl_flush()
+#else
+#define ICS_TL_FLUSH()
+#endif
   // ---------------------------------------------------------------- epilogue, two passes of two column blocks each
   // lane l holds D[tile = 4 kq + i][n = l & 15]: tile = (tz, ty, tx) with (tz, ty) = kq, tx = i
   float* part = lds;                             // [8 w][32 slots = (jl * 4 + i) * 4 + dy * 2 + dx][64 lanes]  (64 KB)
-  float* red = lds + 16384;                      // [8 w][64] + [64] + [8 w][64]
+  float* red = lds + 16384;                      // 2 x [8 w][64]
   // final-stage task of this thread: cq = tid & 3 (channel quad of a column block), jl = (tid >> 2) & 1, o = (tid >> 3) & 3
   // (= dy * 2 + dx), tile = tid >> 5
   const int cq = tid & 3, jl = (tid >> 2) & 1, o = (tid >> 3) & 3, tile = tid >> 5;
@@ -342,11 +390,35 @@ __global__ __launch_bounds__(512) void conv_wino64_kernel(const float* __restric
   const size_t vox0 = (((size_t)b * S + vz) * S + vy) * S + vx;
   const int slot_rd = ((jl * 4 + ttx) * 4 + o) * 64 + (tile >> 2) * 16 + cq * 4;
   vf4 val[2][2];
-  vf4 csum[2];
   vf4 f1[2], f2s[2];
+#ifndef ICS_W64_EPI_PREFETCH
+#define ICS_W64_EPI_PREFETCH 1   // 1: everything the final stage reads from global memory is requested before the first
+#endif                           //    pass, under the output transform, instead of after each pass' second barrier
+#if ICS_W64_EPI_PREFETCH
+  vf4 pbias[2], pacc[2][2], psv[2][2], pmu[2], prs[2];
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int nn = n0 + (pass * 2 + jl) * 16 + cq * 4;
+    pbias[pass] = vf4{0.f, 0.f, 0.f, 0.f};
+    if (bias != nullptr) pbias[pass] = *reinterpret_cast<const vf4*>(bias + nn);
+    if (accumulate) {
+      const size_t o0 = vox0 * ldo + nn;
+      pacc[pass][0] = *reinterpret_cast<const vf4*>(y + o0);
+      pacc[pass][1] = *reinterpret_cast<const vf4*>(y + o0 + (size_t)S * S * ldo);
+    }
+    if (FOLD) {
+      pmu[pass] = *reinterpret_cast<const vf4*>(bs.mean + nn);
+      prs[pass] = *reinterpret_cast<const vf4*>(bs.rstd + nn);
+      const size_t s0 = vox0 * bs.ld + nn;
+      psv[pass][0] = *reinterpret_cast<const vf4*>(bs.s + s0);
+      psv[pass][1] = *reinterpret_cast<const vf4*>(bs.s + s0 + (size_t)S * S * bs.ld);
+    }
+  }
+#endif
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     __syncthreads();
+    ICS_TL(4 + pass * 3);
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
       const int j = pass * 2 + jj;
@@ -369,32 +441,43 @@ __global__ __launch_bounds__(512) void conv_wino64_kernel(const float* __restric
       }
     }
     __syncthreads();
+    ICS_TL(5 + pass * 3);
     const int nn = n0 + (pass * 2 + jl) * 16 + cq * 4;             // this thread's four output channels
     vf4 p[4];
 #pragma unroll
     for (int z = 0; z < 4; ++z)
       p[z] = *reinterpret_cast<const vf4*>(&part[(2 * z) * 2048 + slot_rd]) +
              *reinterpret_cast<const vf4*>(&part[(2 * z + 1) * 2048 + slot_rd]);
-    vf4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (bias != nullptr) bv = *reinterpret_cast<const vf4*>(bias + nn);
     const size_t o0 = vox0 * ldo + nn;
     const size_t o1 = o0 + (size_t)S * S * ldo;
+#if ICS_W64_EPI_PREFETCH
+    const vf4 bv = pbias[pass];
+    vf4 e0 = p[0] + p[1] + p[2] + bv, e1 = p[1] - p[2] - p[3] + bv;
+    if (accumulate) { e0 += pacc[pass][0]; e1 += pacc[pass][1]; }
+#else
+    vf4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias != nullptr) bv = *reinterpret_cast<const vf4*>(bias + nn);
     vf4 e0 = p[0] + p[1] + p[2] + bv, e1 = p[1] - p[2] - p[3] + bv;
     if (accumulate) {
       e0 += *reinterpret_cast<const vf4*>(y + o0);
       e1 += *reinterpret_cast<const vf4*>(y + o1);
     }
+#endif
     e0.x = wact(e0.x, pre_slope); e0.y = wact(e0.y, pre_slope); e0.z = wact(e0.z, pre_slope); e0.w = wact(e0.w, pre_slope);
     e1.x = wact(e1.x, pre_slope); e1.y = wact(e1.y, pre_slope); e1.z = wact(e1.z, pre_slope); e1.w = wact(e1.w, pre_slope);
     *reinterpret_cast<vf4*>(y + o0) = e0;
     *reinterpret_cast<vf4*>(y + o1) = e1;
     val[pass][0] = e0; val[pass][1] = e1;
-    csum[pass] = e0 + e1;
+    ICS_TL(6 + pass * 3);
     if (FOLD) {
+#if ICS_W64_EPI_PREFETCH
+      const vf4 b_mu = pmu[pass], b_rs = prs[pass], sv0 = psv[pass][0], sv1 = psv[pass][1];
+#else
       const vf4 b_mu = *reinterpret_cast<const vf4*>(bs.mean + nn), b_rs = *reinterpret_cast<const vf4*>(bs.rstd + nn);
       const size_t s0 = vox0 * bs.ld + nn;
       const vf4 sv0 = *reinterpret_cast<const vf4*>(bs.s + s0);
       const vf4 sv1 = *reinterpret_cast<const vf4*>(bs.s + s0 + (size_t)S * S * bs.ld);
+#endif
       vf4 d0 = e0, d1 = e1;
       if (bs.post_act != ACT_NONE) {
         const vf4 b_sc = *reinterpret_cast<const vf4*>(bs.scale + nn), b_sh = *reinterpret_cast<const vf4*>(bs.shift + nn);
@@ -408,67 +491,86 @@ __global__ __launch_bounds__(512) void conv_wino64_kernel(const float* __restric
       f2s[pass] = d0 * ((sv0 - b_mu) * b_rs) + d1 * ((sv1 - b_mu) * b_rs);
     }
   }
-  // column sums over the block's 128 voxels: a column quad (pass, jl, cq) lives in the threads with the same (tid & 7)
-  auto colreduce = [&](vf4 v) -> vf4 {
-#pragma unroll
-    for (int d = 8; d < 64; d <<= 1) {
-      v.x += __shfl_xor(v.x, d); v.y += __shfl_xor(v.y, d); v.z += __shfl_xor(v.z, d); v.w += __shfl_xor(v.w, d);
-    }
-    return v;
-  };
-  // red[w][64]: channel index (pass * 2 + jl) * 16 + cq * 4 + e
+  // column reductions over the block's 128 voxels: a column quad (pass, jl, cq) lives in the threads with the same
+  // (tid & 7): three xor-shuffle steps inside the wave (16 voxels), then the eight waves through LDS.
+  // red[0..512) / red[512..1024): [w][64], channel index (pass * 2 + jl) * 16 + cq * 4 + e
   const int cidx = jl * 16 + cq * 4;
-  auto put = [&](float* dst, const vf4 (&v)[2]) {
-    const vf4 r0 = colreduce(v[0]), r1 = colreduce(v[1]);
-    __syncthreads();
-    if (lane < 8) {
-      *reinterpret_cast<vf4*>(&dst[w * 64 + cidx]) = r0;
-      *reinterpret_cast<vf4*>(&dst[w * 64 + 32 + cidx]) = r1;
-    }
-    __syncthreads();
-  };
-  auto sum8 = [&](const float* src, int i) {
-    float sacc = 0.f;
-#pragma unroll
-    for (int ww = 0; ww < 8; ++ww) sacc += src[ww * 64 + i];
-    return sacc;
-  };
   const size_t nstat = gridDim.x / nchunks;
   if (FOLD) {                                      // [2][Npad][blocks] (block index fastest), as conv_igemm.hip's FOLD
-    put(red, f1);
-    float a1 = 0.f;
-    if (tid < 64) a1 = sum8(red, tid);
-    put(red, f2s);
-    if (tid < 64) {
-      float* sp = bs.partial + (size_t)(n0 + tid) * nstat + tblk;
-      sp[0] = a1;
-      sp[(size_t)Npad * nstat] = sum8(red, tid);
+#pragma unroll
+    for (int d = 8; d < 64; d <<= 1)
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          f1[pass][e] += __shfl_xor(f1[pass][e], d);
+          f2s[pass][e] += __shfl_xor(f2s[pass][e], d);
+        }
+    if (lane < 8) {
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        *reinterpret_cast<vf4*>(&red[w * 64 + pass * 32 + cidx]) = f1[pass];
+        *reinterpret_cast<vf4*>(&red[512 + w * 64 + pass * 32 + cidx]) = f2s[pass];
+      }
     }
+    __syncthreads();
+    if (tid < 128) {
+      const int c = tid & 63, which = tid >> 6;
+      float sacc = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < 8; ++ww) sacc += red[which * 512 + ww * 64 + c];
+      bs.partial[((size_t)which * Npad + n0 + c) * nstat + tblk] = sacc;
+    }
+    ICS_TL_FLUSH();
     return;
   }
-  if (stat_partial == nullptr) return;
+  if (stat_partial == nullptr) { ICS_TL_FLUSH(); return; }
 
-  // block-level (count, mean, M2) per column, two passes inside the block (conv_igemm.hip's layout
-  // [3][Npad][nblocks], block index fastest)
-  put(red, csum);
-  if (tid < 64) red[512 + tid] = sum8(red, tid) * (1.f / kRows);
-  __syncthreads();
-  vf4 qs[2];
+  // block-level (count, mean, M2) per column (conv_igemm.hip's layout [3][Npad][nblocks], block index fastest) as a
+  // tree of equal-count Chan merges: thread (2 voxels) -> wave (16) -> block (128); one trip through LDS
+  vf4 mn[2], m2[2];
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
-    const vf4 mu = *reinterpret_cast<const vf4*>(&red[512 + pass * 32 + cidx]);
-    const vf4 d0 = val[pass][0] - mu, d1 = val[pass][1] - mu;
-    qs[pass] = d0 * d0 + d1 * d1;
+    const vf4 dlt = val[pass][1] - val[pass][0];
+    mn[pass] = val[pass][0] + 0.5f * dlt;
+    m2[pass] = 0.5f * dlt * dlt;
   }
-  float mean_t = 0.f;
-  if (tid < 64) mean_t = red[512 + tid];
-  put(red, qs);
+  float nh = 1.f;                                  // half the element count of the groups being merged
+#pragma unroll
+  for (int d = 8; d < 64; d <<= 1) {
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float mo = __shfl_xor(mn[pass][e], d), qo = __shfl_xor(m2[pass][e], d);
+        const float dl = mo - mn[pass][e];
+        m2[pass][e] = m2[pass][e] + qo + dl * dl * nh;
+        mn[pass][e] = mn[pass][e] + 0.5f * dl;
+      }
+    nh *= 2.f;
+  }
+  if (lane < 8) {
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      *reinterpret_cast<vf4*>(&red[w * 64 + pass * 32 + cidx]) = mn[pass];
+      *reinterpret_cast<vf4*>(&red[512 + w * 64 + pass * 32 + cidx]) = m2[pass];
+    }
+  }
+  __syncthreads();
   if (tid < 64) {
+    float mw[8], msum = 0.f, q = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < 8; ++ww) { mw[ww] = red[ww * 64 + tid]; msum += mw[ww]; q += red[512 + ww * 64 + tid]; }
+    const float mean_t = msum * 0.125f;
+    float dev = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < 8; ++ww) dev += (mw[ww] - mean_t) * (mw[ww] - mean_t);
     float* sp = stat_partial + (size_t)(n0 + tid) * nstat + tblk;
     sp[0] = (float)kRows;
     sp[(size_t)Npad * nstat] = mean_t;
-    sp[(size_t)2 * Npad * nstat] = sum8(red, tid);
+    sp[(size_t)2 * Npad * nstat] = q + dev * (float)(kRows / 8);
   }
+  ICS_TL_FLUSH();
 }
 
 // ---------------------------------------------------------------- host side
