@@ -1,0 +1,685 @@
+// EXPERIMENT, not built (round 3): conv_wino64.hip with PIPELINED tile blocks -- a workgroup walks ipw consecutive tile
+// blocks and the last channel chunk of one stages the first chunk of the next under its MFMAs (no prologue, no launch gap;
+// the epilogue works in the complement of the staged LDS buffer).  Correct (tests/test_gpu_conv.py passes), measured on
+// MI355X against the shipped kernel (one tile block per workgroup, last chunk without staging):
+//   c18 forward: ipw 1/2/4/8 = 2.792 / 2.702 / 2.659 / 2.639 ms vs 2.591 ms shipped; backward-data 2.479 vs 2.463 ms;
+//   9-layer sums forward 6.93 vs 6.78 ms, backward-data 6.32 vs 6.22 ms.
+// Pipelining is worth 5.5 % (2.3 us per tile block), but it replaces the unstaged last chunk of the shipped kernel (worth
+// 4.2 %: staging a chunk costs 1.7 us of a chunk's 8 us) and the item loop costs ~3 % in code quality (every per-thread
+// constant has to be parked in LDS or rebuilt per phase to keep the main loop at 256 VGPRs without scratch; the kernel
+// arguments have to be re-read through a laundered kernarg pointer to stay under 102 SGPRs).  See DESIGN.md section 4.
+// Winograd F(2x2x2, 3x3x3) forward / backward-data, second kernel shape (gfx950 / MI355X only): one workgroup =
+// 16 tiles (2x2x4 tiles = 4x4x8 voxels) x 64 output channels x all 64 frequencies on v_mfma_f32_16x16x4_f32.
+//
+// Same operator and same algebra as conv_wino.hip (Keras Conv3D 3x3x3 "same", /root/reference/unet/unet.py:283-336);
+// what changes is the shape of the per-frequency GEMM tile, 16 tiles x 64 channels instead of 32 x 32:
+//   * the transformed input (the MFMA A operand) is built ONCE per (tile, input channel, frequency) and feeds FOUR
+//     16x16x4 MFMAs (four 16-channel column blocks) instead of one 32-wide tile: the transform's VALU instructions per
+//     MFMA cycle halve (fp32 VALU and fp32 MFMA share the issue port on this chip: every VALU instruction is MFMA
+//     time lost -- scripts/probes/mfma_filler.hip);
+//   * the halo block is [6][6][10] voxels for 128 outputs x 64 channels instead of [6][10][10] for 256 x 32: 0.6x the
+//     staging work and 0.6x the input re-reads per MFMA (Cout/64 instead of Cout/32 n-chunks);
+//   * a buffer of 32 input channels is 64 KB, so the K loop runs in chunks of 32 channels, double buffered: half the
+//     barriers per channel and twice the distance between a chunk's global loads and their first use.
+// 8 waves, two per SIMD: wave w owns the 8 frequencies (fz = w >> 1, fy in {2 (w & 1), 2 (w & 1) + 1}, fx = 0..3) x 4
+// column blocks = 32 accumulators of 4 registers.  MFMA lane l: A[tile = l & 15][k = l >> 4], B[k = l >> 4][n = l & 15],
+// D[tile = 4 (l >> 4) + reg][n = l & 15].  Staging as in conv_wino.hip: thread t < 480 owns one (y, x, channel quad)
+// column of the halo, applies the producer's BatchNorm affine, the zero padding after it and the z rows of B^T, and
+// writes the eight z-combined planes (tile z, fz).  LDS: voxel pitch 33 floats, row pitch 332, plane pitch 1996:
+// the 32 lanes of a ds_read_b32 group (16 tiles x 2 channels) hit 32 distinct banks for every (fz, row, column,
+// sub-step) -- checked exhaustively.  Weights: [Cout/64][Cin/4][64 f][4 k][16 n][4 column blocks],
+// one ds-free global_load_dwordx4 per frequency and sub-step, a wave's sub-step = 8 KB contiguous.
+#include "common.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+
+#ifndef ICS_W64_FENCE
+#define ICS_W64_FENCE 1      // 2: a scheduling fence after every MFMA pair; 1: one per column; 0: none.  Measured, c18
+                             // forward: 2.59 / 2.53 / 2.72 ms (with ICS_W64_COLTOP: 2.51 / 2.51 / 2.77)
+#endif
+#ifndef ICS_W64_COLTOP
+#define ICS_W64_COLTOP 1     // 1: the two column-math instructions ahead of a column's MFMAs instead of between them
+                             // (no copies of the three operands, one MFMA -> VALU -> MFMA switch per column less)
+#endif
+#ifndef ICS_W64_PRIO
+#define ICS_W64_PRIO 0       // 1: s_setprio(1) around a column's MFMAs (measured: +1 % time)
+#endif
+
+#ifdef ICS_W64_TIMELINE
+// variant builds only (scripts/variants.sh conv_wino64 "tl:-DICS_W64_TIMELINE"): per workgroup {entry, first chunk staged,
+// main loop done, exit; 4..: inside the epilogue} wall-clock stamps + HW_ID / XCC_ID, fetched with ics_debug_w64_timeline (scripts/w64_timeline.py)
+__device__ unsigned long long ics_w64_tl[16 * 32768];
+extern "C" int ics_debug_w64_timeline(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ics_w64_tl), (size_t)n * 8);
+}
+#define ICS_TL(i) do { if (threadIdx.x == 0 && tl_item < 32768) ics_w64_tl[(size_t)tl_item * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define ICS_TL(i)
+#endif
+
+namespace ics {
+
+typedef float vf4 __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr int KC = 32;                                   // input channels per LDS chunk
+constexpr int VX = KC + 1, RP = 10 * VX + 2, PP = 6 * RP + 4, BUF = 8 * PP;   // floats: 33 / 332 / 1996 / 15 968 (63 872 B)
+constexpr int kRows = 128;                               // voxels per workgroup
+// LDS: buffer 0 = [0, BUF), buffer 1 = [EB, EB + BUF).  The epilogue needs EP floats (the partial output transforms of
+// the eight waves + the column reductions) and runs while ONE buffer already holds the next tile block's first chunk:
+// it takes the complement of that buffer, [0, EB) or [BUF, EB + BUF), both EB >= EP floats long.
+constexpr int EP = 16384 + 1024, EB = EP;                // 17 408 floats; EB + BUF = 33 376 floats = 133 504 B
+
+__device__ __forceinline__ float wact(float v, float slope) { return fmaxf(v, v * slope); }
+__host__ __device__ __forceinline__ float wslope(int act) { return act == ACT_RELU ? 0.f : (act == ACT_LRELU ? kLeaky : 1.f); }
+}  // namespace
+
+// One by-value argument = the kernarg segment.  Only what the main loop needs is read from it at entry; the set-up of a
+// tile block and the epilogue RE-READ their scalars through a laundered kernarg pointer (s_load at the point of use):
+// with every argument live across the item loop the kernel needs ~125 SGPRs, the file has 102, and the overflow is
+// spilled into vector registers the main loop does not have.
+struct W64Args {
+  const float* x; const float* in_scale; const float* in_shift; const float* wt; const float* bias;
+  float* y; float* stat_partial;
+  int ldx, ldo, accumulate, Npad, S, lgS, Cin, Cout, ntb, ipw;
+  float in_slope, pre_slope;
+  BwdStat bs;
+};
+
+template <bool AFF, bool NOACT, bool FOLD>
+__global__ __launch_bounds__(512) void conv_wino64_kernel(const W64Args A) {
+  typedef const __attribute__((address_space(4))) W64Args* KargPtr;
+  auto karg = [&]() -> KargPtr {
+    KargPtr kp = (KargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    return kp;
+  };
+  const float in_slope = A.in_slope;
+  const int Cin = A.Cin, Cout = A.Cout, ipw = A.ipw;
+  // 2 buffers + the epilogue's extra 133 504 B + per-thread constants 8 KB + AFF: scale / shift 8 KB
+  __shared__ __attribute__((aligned(16))) float lds[EB + BUF];
+  __shared__ unsigned park[2560];
+  __shared__ __attribute__((aligned(16))) float aff[AFF ? 2048 : 4];
+#ifdef ICS_W64_TIMELINE
+  int tl_item = (blockIdx.x / (A.Cout >> 6)) * A.ipw * (A.Cout >> 6) + blockIdx.x % (A.Cout >> 6);
+#endif
+  ICS_TL(0);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fz = w >> 1, fyh = w & 1;            // this wave: frequencies (fz, 2 fyh + {0,1}, 0..3)
+  // Per-thread constants of the set-up and of the epilogue are REBUILT from a fresh lane id where they are needed (an
+  // asm the compiler cannot merge with earlier copies): kept in registers across the item loop they would all be live
+  // through the main loop, which has no register to spare.
+  auto flane = [&]() -> int {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+  };
+  const int nchunks = Cout >> 6;
+  // A workgroup walks ipw CONSECUTIVE tile blocks of one n-chunk (ntb tile blocks in all; the host picks ipw <= 8 so
+  // that at least four rounds of workgroups remain for load balance): the first chunk and the first weights of the
+  // next tile block are requested in the epilogue of the current one, as soon as the accumulators are dead.  Per tile
+  // block that hides the launch gap, the constants' set-up and most of the first chunk's memory latency (2.5 of ~8 us
+  // fixed cost -- scripts/w64_timeline.py).  The n-chunks of one tile-block group are neighbours in launch order: an
+  // XCD (blockIdx mod 8) keeps ONE n-chunk's weights hot in its L2.
+  const int nb = blockIdx.x % nchunks;
+  const int n0 = nb * 64;
+
+  // ---- staging: thread t < 480 owns one (hy, hx, channel quad) column of the halo block [6][6][10] x 32 channels
+  // Buffer loads: ONE per-lane byte offset (the clamped (y, x) position and the channel quad) in a VGPR; the
+  // clamped z plane of each of the six loads and the channel chunk go into the scalar offset operand (six 64-bit
+  // per-lane pointers cost 12 VGPRs, which the allocator spilled).
+  vf4 stage[6];
+  unsigned zoff[6];                              // uniform: byte offset of sample b, plane clamp(oz - 1 + hz)
+  unsigned voff;
+  int tblk, b, oz, oy, ox;
+  bool edge;
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.x), 0, 0x7fffffff, 0x00020000);
+  {
+    const int cmb = tid < 480 ? tid : 479;
+    const int q = cmb & 7, hx = (cmb >> 3) % 10, hy = (cmb >> 3) / 10;
+    park[512 + tid] = (unsigned)(hy * RP + hx * VX + q * 4);      // + plane * PP + buffer
+    park[1024 + tid] = (unsigned)(q * 4);
+    park[1536 + tid] = (unsigned)(hy | (hx << 8) | ((q * 4) << 16));
+  }
+  // The two per-thread staging constants are PARKED in LDS and read back where a chunk is loaded / stored: kept in
+  // registers they are what the allocator spills, and a scratch reload is a vector-memory load whose s_waitcnt
+  // vmcnt(0) drains the whole weight prefetch at every chunk (measured: +9 % on the BatchNorm-affine variant).
+  // LDS byte address of the wave's 64 entries (scalar); the lane part is rebuilt from v_mbcnt at every read: a per-lane
+  // address register is itself one more value for the allocator to spill (it did, with a vmcnt(0) reload per read)
+  const unsigned park_wave = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)&park[0] + (unsigned)w * 256u);
+  auto unpark = [&](const int which) -> int {    // an LDS read the compiler can neither hoist nor keep in a register
+    int v;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshl_add_u32 %0, %0, 2, %1\n\t"
+                 "ds_read_b32 %0, %0 offset:%2\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v) : "s"(park_wave), "i"(which * 2048) : "memory");
+    return v;
+  };
+  auto park_store = [&](const int which, const unsigned v) {
+    unsigned a_;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshl_add_u32 %0, %0, 2, %1\n\t"
+                 "ds_write_b32 %0, %2 offset:%3"
+                 : "=&v"(a_) : "s"(park_wave), "v"(v), "i"(which * 2048) : "memory");
+  };
+  auto geom = [&](const int tb, const int S, const int ldx, const int lgS) {   // everything that depends on the tile block
+    tblk = tb;
+    const int lgx = lgS - 3, lgy = lgS - 2;      // tile blocks per axis: S/8, S/4, S/4 (S is a power of two)
+    const int pk = unpark(3);                    // hy | hx << 8 | 4 q << 16
+    const int hy = pk & 255, hx = (pk >> 8) & 255, q4 = pk >> 16;
+    const int bx = tblk & ((1 << lgx) - 1), by = (tblk >> lgx) & ((1 << lgy) - 1), bz = (tblk >> (lgx + lgy)) & ((1 << lgy) - 1);
+    b = tblk >> (lgx + 2 * lgy);
+    oz = bz * 4; oy = by * 4; ox = bx * 8;
+    edge = bx == 0 || by == 0 || bz == 0 || bx == (1 << lgx) - 1 || by == (1 << lgy) - 1 || bz == (1 << lgy) - 1;   // uniform
+    const int gy = oy - 1 + hy, gx = ox - 1 + hx;
+    const bool okyx = gy >= 0 && gy < S && gx >= 0 && gx < S;
+    const int cy = min(max(gy, 0), S - 1), cx = min(max(gx, 0), S - 1);
+    voff = (unsigned)((cy * S + cx) * ldx + q4) * 4u;
+    unsigned okmask = 0;
+#pragma unroll
+    for (int hz = 0; hz < 6; ++hz) {
+      const int gz = oz - 1 + hz;
+      okmask |= (okyx && gz >= 0 && gz < S) ? (1u << hz) : 0u;
+      const int cz = min(max(gz, 0), S - 1);
+      zoff[hz] = (unsigned)((b * S + cz) * S * S * ldx) * 4u;
+    }
+    park_store(0, voff);                         // read back by the same thread only
+    park_store(4, okmask);
+  };
+  // AFF: the producer's per-channel scale / shift of ALL input channels sit in LDS behind the two buffers (Cin <= 1024:
+  // 8 KB), read back per chunk at store time -- eight registers less to keep live through the main loop
+  if (AFF) {
+    for (int i = tid; i < Cin; i += 512) { aff[i] = A.in_scale[i]; aff[1024 + i] = A.in_shift[i]; }
+  }
+  auto gload = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      stage[i] = __builtin_bit_cast(vf4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)voff, (int)(zoff[i] + (unsigned)c0 * 4u), 0));
+  };
+  auto sstore = [&](const int bo, const int c0) {
+    if (AFF) {
+      const int q4 = unpark(2);
+      const vf4 sc4 = *reinterpret_cast<const vf4*>(&aff[c0 + q4]);
+      const vf4 sh4 = *reinterpret_cast<const vf4*>(&aff[1024 + c0 + q4]);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        vf4 t = stage[i];
+        t.x = fmaf(t.x, sc4.x, sh4.x); t.y = fmaf(t.y, sc4.y, sh4.y);
+        t.z = fmaf(t.z, sc4.z, sh4.z); t.w = fmaf(t.w, sc4.w, sh4.w);
+        if (!NOACT) { t.x = wact(t.x, in_slope); t.y = wact(t.y, in_slope); t.z = wact(t.z, in_slope); t.w = wact(t.w, in_slope); }
+        stage[i] = t;
+      }
+    }
+    if (edge) {                                  // "same" padding: zeros AFTER the producer's affine / activation
+      const unsigned okmask = (unsigned)unpark(4);
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+        if (!((okmask >> i) & 1)) stage[i] = vf4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (tid < 480) {
+      float* o = &lds[bo + unpark(1)];
+#pragma unroll
+      for (int tz = 0; tz < 2; ++tz) {
+        const vf4 d0 = stage[2 * tz], d1 = stage[2 * tz + 1], d2 = stage[2 * tz + 2], d3 = stage[2 * tz + 3];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {            // one plane at a time: four live temporaries, not sixteen
+          const vf4 c = f == 0 ? d0 - d2 : (f == 1 ? d1 + d2 : (f == 2 ? d2 - d1 : d1 - d3));
+          float* op = o + (tz * 4 + f) * PP;     // odd voxel pitch: four dword stores
+          op[0] = c.x; op[1] = c.y; op[2] = c.z; op[3] = c.w;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  };
+
+  // In the main loop the halo of the next chunk is staged in TWO phases of four z rows each -- rows 0..3 -> the planes of
+  // tile z 0, rows 2..5 -> tile z 1 (rows 2, 3 are read twice, from L1 / L2) -- so that 16 instead of 24 registers are in
+  // flight next to the accumulators; the prologue, where nothing else is live yet, uses the six-row form above.
+  vf4 hs[4];
+  auto hload = [&](const int tzh, int c0) {
+    const int vo = unpark(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      hs[i] = __builtin_bit_cast(vf4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vo, (int)(zoff[2 * tzh + i] + (unsigned)c0 * 4u), 0));
+  };
+  auto hstore = [&](const int tzh, const int bo, const int c0) {
+    vf4 r[4] = {hs[0], hs[1], hs[2], hs[3]};     // local copies: updating hs in place can send it to scratch (compiler)
+    if (AFF) {
+      const int q4 = unpark(2);
+      typedef float vf2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {           // two channels at a time: four instead of eight live scale / shift registers
+        const vf2 sc2 = *reinterpret_cast<const vf2*>(&aff[c0 + q4 + 2 * hh]);
+        const vf2 sh2 = *reinterpret_cast<const vf2*>(&aff[1024 + c0 + q4 + 2 * hh]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float t0 = fmaf(r[i][2 * hh], sc2.x, sh2.x), t1 = fmaf(r[i][2 * hh + 1], sc2.y, sh2.y);
+          if (!NOACT) { t0 = wact(t0, in_slope); t1 = wact(t1, in_slope); }
+          r[i][2 * hh] = t0; r[i][2 * hh + 1] = t1;
+        }
+      }
+    }
+    if (edge) {
+      const unsigned okmask = (unsigned)unpark(4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (!((okmask >> (2 * tzh + i)) & 1)) r[i] = vf4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (tid < 480) {
+      float* o = &lds[bo + unpark(1) + tzh * 4 * PP];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const vf4 c = f == 0 ? r[0] - r[2] : (f == 1 ? r[1] + r[2] : (f == 2 ? r[2] - r[1] : r[1] - r[3]));
+        float* op = o + f * PP;
+        op[0] = c.x; op[1] = c.y; op[2] = c.z; op[3] = c.w;
+      }
+    }
+  };
+
+  // ---- per-lane read geometry.  tile m = (tz, ty, tx).  The wave's two fy rows of B^T need rows (a, b, c) of the
+  // combined plane:  fy = 2 fyh:  R_a - R_b,   fy = 2 fyh + 1:  R_b + sg R_c   with (a,b,c,sg) = (0,2,1,+) / (2,1,3,-)
+  const float sg = fyh ? -1.f : 1.f;
+
+  const int nsub = Cin >> 2;
+  constexpr int wstride_f = 256;                 // floats per frequency of one sub-step: [4 k][16 n][4 column blocks]
+  constexpr int wsub = 64 * 256;
+  // buffer loads again: one per-lane byte offset, everything else (n-chunk, wave, sub-step, frequency) scalar
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(A.wt + ((size_t)nb * nsub * 64 + fz * 16 + fyh * 8) * 256), 0, 0x7fffffff, 0x00020000);
+  const int wlane = lane * 16;                   // bytes
+  auto wload = [&](int gs, int f) {              // sub-step gs, local frequency f
+    return __builtin_bit_cast(vf4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wlane, (gs * wsub + f * wstride_f) * 4, 0));
+  };
+  vf4 wreg[8];
+  vf4 acc[8][4];                                 // [frequency fy_local * 4 + fx][column block]
+
+  float u[8], tn[2][4], qa, qb, qc;
+  auto xform = [&]() {
+#pragma unroll
+    for (int fy = 0; fy < 2; ++fy) {
+      u[fy * 4 + 0] = tn[fy][0] - tn[fy][2];
+      u[fy * 4 + 1] = tn[fy][1] + tn[fy][2];
+      u[fy * 4 + 2] = tn[fy][2] - tn[fy][1];
+      u[fy * 4 + 3] = tn[fy][1] - tn[fy][3];
+    }
+  };
+
+  auto rd = [&](const int ra, const int rb, const int rc, const int sub, const int col) {
+    const int off = col * VX + 4 * sub;          // compile-time after unrolling
+    qa = lds[ra + off]; qb = lds[rb + off]; qc = lds[rc + off];
+  };
+  const int nch = Cin / KC;
+  int item = (blockIdx.x / nchunks) * ipw;       // tile block
+  const int item_end = item + ipw;
+  geom(item, A.S, A.ldx, A.lgS);
+  gload(0);
+#pragma unroll
+  for (int f = 0; f < 8; ++f) wreg[f] = wload(0, f);
+
+  if (AFF) __syncthreads();                      // scale / shift visible
+  sstore(0, 0);                                  // the first tile block's first chunk; every later one is staged by the
+  __syncthreads();                               // last chunk of its predecessor
+  int nxt = EB;                                  // float offset of the buffer being filled (the other one is consumed)
+
+  for (;;) {                                     // ---------------------------------------------------------- items
+#pragma unroll
+  for (int f = 0; f < 8; ++f)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[f][j] = vf4{0.f, 0.f, 0.f, 0.f};
+  ICS_TL(1);
+  int Ra, Rb, Rc;                                // row bases of the buffer being read
+  {
+    const int l_ = flane(), m = l_ & 15, kq = l_ >> 4;
+    const int tz = m >> 3, ty = (m >> 2) & 1, tx = m & 3;
+    auto rowbase = [&](int iy) { return (tz * 4 + fz) * PP + (2 * ty + iy) * RP + 2 * tx * VX + kq; };
+    const int cur = EB - nxt;                    // the buffer holding this tile block's first chunk
+    Ra = rowbase(fyh ? 2 : 0) + cur; Rb = rowbase(fyh ? 1 : 2) + cur; Rc = rowbase(fyh ? 3 : 1) + cur;
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    rd(Ra, Rb, Rc, 0, g);
+    tn[0][g] = qa - qb;
+    tn[1][g] = fmaf(sg, qc, qb);
+  }
+  xform();
+  rd(Ra, Rb, Rc, 1, 0);                          // column 0 of sub-step 1
+
+  // Every chunk stages the next one under its MFMAs: the next 32 channels of this tile block, or (last chunk) the
+  // FIRST chunk of the next tile block -- geom() switches the staging geometry before it; the weights' read-ahead
+  // wraps around to sub-step 0 the same way (same n-chunk).  Nothing of a tile block's set-up is left outside the
+  // matrix-core work of its predecessor.
+  auto chunk = [&](const int ch, const int cn) {
+    const int dlt = 2 * nxt - EB;                // + EB / - EB: from the buffer being consumed to the other one
+    hload(0, cn);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      int gs = ch * 8 + s + 1;
+      gs = gs < nsub ? gs : 0;                   // past the end: the next tile block's first sub-step
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+#if ICS_W64_COLTOP
+        tn[0][g] = qa - qb;                      // column g of sub-step s+1, read one column ago
+        tn[1][g] = fmaf(sg, qc, qb);
+#else
+        const float a = qa, bq = qb, c = qc;
+#endif
+        if (s == 3 && g == 3) {                  // first half of the next chunk's planes; then the second half's rows
+          hstore(0, nxt, cn);
+          hload(1, cn);
+        }
+        if (s == 6 && g == 3) {                  // the next chunk must be visible before its first column is read
+          hstore(1, nxt, cn);
+          __syncthreads();
+          Ra += dlt; Rb += dlt; Rc += dlt;       // every read from here on is in the other buffer
+        }
+        // reads of the next column: column g+1 of sub-step s+1, or column 0 of sub-step s+2
+        if (g < 3) rd(Ra, Rb, Rc, (s + 1) & 7, g + 1);
+        else rd(Ra, Rb, Rc, (s + 2) & 7, 0);
+#if ICS_W64_FENCE != 0
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#define ICS_WMF(F, J) acc[F][J] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[F], wreg[F][J], acc[F][J], 0, 0, 0)
+#if ICS_W64_FENCE == 2
+#define ICS_WFN __builtin_amdgcn_sched_barrier(0)
+#define ICS_WFC __builtin_amdgcn_sched_barrier(0)
+#elif ICS_W64_FENCE == 1
+#define ICS_WFN
+#define ICS_WFC __builtin_amdgcn_sched_barrier(0)
+#else
+#define ICS_WFN
+#define ICS_WFC
+#endif
+        // consecutive MFMAs on different accumulators; the column math of the next sub-step in between
+#if ICS_W64_PRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
+#if ICS_W64_COLTOP
+        ICS_WMF(g, 0); ICS_WMF(4 + g, 0); ICS_WFN;
+        ICS_WMF(g, 1); ICS_WMF(4 + g, 1); ICS_WFN;
+#else
+        ICS_WMF(g, 0); ICS_WMF(4 + g, 0); tn[0][g] = a - bq; ICS_WFN;
+        ICS_WMF(g, 1); ICS_WMF(4 + g, 1); tn[1][g] = fmaf(sg, c, bq); ICS_WFN;
+#endif
+        ICS_WMF(g, 2); ICS_WMF(4 + g, 2); ICS_WFN;
+        ICS_WMF(g, 3); ICS_WMF(4 + g, 3); ICS_WFC;
+#if ICS_W64_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+#undef ICS_WMF
+        wreg[g] = wload(gs, g);
+        wreg[4 + g] = wload(gs, 4 + g);
+        ICS_WFC;
+#undef ICS_WFN
+#undef ICS_WFC
+      }
+      xform();
+    }
+    nxt = EB - nxt;
+  };
+  const int cur_tblk = tblk;
+  const bool more = item + 1 < item_end;         // uniform
+#ifndef ICS_W64_ONELOOP
+#define ICS_W64_ONELOOP 1
+#endif
+#if ICS_W64_ONELOOP
+  for (int ch = 0; ch < nch; ++ch) {
+    int cn = (ch + 1) * KC;
+    if (ch == nch - 1) {                         // after the last tile block the same one again (never consumed)
+      KargPtr ga = karg();
+      geom(more ? item + 1 : item, ga->S, ga->ldx, ga->lgS);
+      cn = 0;
+    }
+    chunk(ch, cn);
+  }
+#else
+  for (int ch = 0; ch < nch - 1; ++ch) chunk(ch, (ch + 1) * KC);
+  {                                              // after the last tile block the same one again (never consumed)
+    KargPtr ga = karg();
+    geom(more ? item + 1 : item, ga->S, ga->ldx, ga->lgS);
+  }
+  chunk(nch - 1, 0);
+#endif
+
+  ICS_TL(2);
+#ifdef ICS_W64_TIMELINE
+  auto tl_flush = [&]() {
+    if (threadIdx.x == 0 && tl_item < 32768) {
+      unsigned long long* r = ics_w64_tl + (size_t)tl_item * 16;
+      r[3] = wall_clock64();
+      r[14] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID: wave[3:0] simd[5:4] pipe[7:6] cu[11:8] sh[12] se[15:13]
+      r[15] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
+    }
+  };
+#define ICS_TL_FLUSH() tl_flush()
+#else
+#define ICS_TL_FLUSH()
+#endif
+  // ---------------------------------------------------------------- epilogue, two passes of two column blocks each
+  // lane l holds D[tile = 4 kq + i][n = l & 15]: tile = (tz, ty, tx) with (tz, ty) = kq, tx = i
+  // the complement of the buffer that holds the next tile block's first chunk (EB - nxt after the last chunk's flip)
+  float* part = lds + (nxt == 0 ? 0 : BUF);      // [8 w][32 slots = (jl * 4 + i) * 4 + dy * 2 + dx][64 lanes]  (64 KB)
+  float* red = part + 16384;                     // 2 x [8 w][64]
+  // final-stage task of this thread: cq = tid & 3 (channel quad of a column block), jl = (tid >> 2) & 1, o = (tid >> 3) & 3
+  // (= dy * 2 + dx), tile = tid >> 5
+  KargPtr ea = karg();
+  const int S = ea->S, ldo = ea->ldo, accumulate = ea->accumulate, Npad = ea->Npad;
+  const float pre_slope = ea->pre_slope;
+  const float* bias = ea->bias;
+  float* y = ea->y;
+  float* stat_partial = ea->stat_partial;
+  const size_t nstat = (size_t)ea->ntb;
+  const int elane = flane(), etid = w * 64 + elane;
+  const int cq = etid & 3, jl = (etid >> 2) & 1, o = (etid >> 3) & 3, tile = etid >> 5;
+  const int ttz = tile >> 3, tty = (tile >> 2) & 1, ttx = tile & 3;
+  const int elgS = ea->lgS, elgx = elgS - 3, elgy = elgS - 2;
+  const int eox = (cur_tblk & ((1 << elgx) - 1)) * 8, eoy = ((cur_tblk >> elgx) & ((1 << elgy) - 1)) * 4;
+  const int eoz = ((cur_tblk >> (elgx + elgy)) & ((1 << elgy) - 1)) * 4, eb = cur_tblk >> (elgx + 2 * elgy);
+  const int vz = eoz + 2 * ttz, vy = eoy + 2 * tty + (o >> 1), vx = eox + 2 * ttx + (o & 1);
+  const size_t vox0 = (((size_t)eb * S + vz) * S + vy) * S + vx;
+  const int slot_rd = ((jl * 4 + ttx) * 4 + o) * 64 + (tile >> 2) * 16 + cq * 4;
+  vf4 val[2][2];
+  vf4 f1[2], f2s[2];
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();
+    ICS_TL(4 + pass * 3);
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int j = pass * 2 + jj;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float qv[2][2];                          // [fy local][dx]
+#pragma unroll
+        for (int fy = 0; fy < 2; ++fy) {
+          qv[fy][0] = acc[fy * 4 + 0][j][i] + acc[fy * 4 + 1][j][i] + acc[fy * 4 + 2][j][i];
+          qv[fy][1] = acc[fy * 4 + 1][j][i] - acc[fy * 4 + 2][j][i] - acc[fy * 4 + 3][j][i];
+        }
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          // rows of A^T: the wave with fy 0,1 gives dy0 += q0 + q1, dy1 += q1; the one with fy 2,3: dy0 += q0, dy1 -= q0 + q1
+          const float d0 = fyh ? qv[0][dx] : qv[0][dx] + qv[1][dx];
+          const float d1 = fyh ? -qv[0][dx] - qv[1][dx] : qv[1][dx];
+          part[(w * 32 + (jj * 4 + i) * 4 + 0 + dx) * 64 + elane] = d0;
+          part[(w * 32 + (jj * 4 + i) * 4 + 2 + dx) * 64 + elane] = d1;
+        }
+      }
+    }
+    __syncthreads();
+    ICS_TL(5 + pass * 3);
+    const int nn = n0 + (pass * 2 + jl) * 16 + cq * 4;             // this thread's four output channels
+    vf4 p[4];
+#pragma unroll
+    for (int z = 0; z < 4; ++z)
+      p[z] = *reinterpret_cast<const vf4*>(&part[(2 * z) * 2048 + slot_rd]) +
+             *reinterpret_cast<const vf4*>(&part[(2 * z + 1) * 2048 + slot_rd]);
+    const size_t o0 = vox0 * ldo + nn;
+    const size_t o1 = o0 + (size_t)S * S * ldo;
+    vf4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (bias != nullptr) bv = *reinterpret_cast<const vf4*>(bias + nn);
+    vf4 e0 = p[0] + p[1] + p[2] + bv, e1 = p[1] - p[2] - p[3] + bv;
+    if (accumulate) {
+      e0 += *reinterpret_cast<const vf4*>(y + o0);
+      e1 += *reinterpret_cast<const vf4*>(y + o1);
+    }
+    e0.x = wact(e0.x, pre_slope); e0.y = wact(e0.y, pre_slope); e0.z = wact(e0.z, pre_slope); e0.w = wact(e0.w, pre_slope);
+    e1.x = wact(e1.x, pre_slope); e1.y = wact(e1.y, pre_slope); e1.z = wact(e1.z, pre_slope); e1.w = wact(e1.w, pre_slope);
+    *reinterpret_cast<vf4*>(y + o0) = e0;
+    *reinterpret_cast<vf4*>(y + o1) = e1;
+    val[pass][0] = e0; val[pass][1] = e1;
+    ICS_TL(6 + pass * 3);
+    if (FOLD) {
+      const vf4 b_mu = *reinterpret_cast<const vf4*>(ea->bs.mean + nn), b_rs = *reinterpret_cast<const vf4*>(ea->bs.rstd + nn);
+      const size_t s0 = vox0 * ea->bs.ld + nn;
+      const vf4 sv0 = *reinterpret_cast<const vf4*>(ea->bs.s + s0);
+      const vf4 sv1 = *reinterpret_cast<const vf4*>(ea->bs.s + s0 + (size_t)S * S * ea->bs.ld);
+      vf4 d0 = e0, d1 = e1;
+      if (ea->bs.post_act != ACT_NONE) {
+        const vf4 b_sc = *reinterpret_cast<const vf4*>(ea->bs.scale + nn), b_sh = *reinterpret_cast<const vf4*>(ea->bs.shift + nn);
+        const vf4 z0 = sv0 * b_sc + b_sh, z1 = sv1 * b_sc + b_sh;
+        d0.x *= act_grad(z0.x, ea->bs.post_act); d0.y *= act_grad(z0.y, ea->bs.post_act);
+        d0.z *= act_grad(z0.z, ea->bs.post_act); d0.w *= act_grad(z0.w, ea->bs.post_act);
+        d1.x *= act_grad(z1.x, ea->bs.post_act); d1.y *= act_grad(z1.y, ea->bs.post_act);
+        d1.z *= act_grad(z1.z, ea->bs.post_act); d1.w *= act_grad(z1.w, ea->bs.post_act);
+      }
+      f1[pass] = d0 + d1;
+      f2s[pass] = d0 * ((sv0 - b_mu) * b_rs) + d1 * ((sv1 - b_mu) * b_rs);
+    }
+  }
+  // column reductions over the block's 128 voxels: a column quad (pass, jl, cq) lives in the threads with the same
+  // (tid & 7): three xor-shuffle steps inside the wave (16 voxels), then the eight waves through LDS.
+  // red[0..512) / red[512..1024): [w][64], channel index (pass * 2 + jl) * 16 + cq * 4 + e
+  const int cidx = jl * 16 + cq * 4;
+  if (FOLD) {                                      // [2][Npad][blocks] (block index fastest), as conv_igemm.hip's FOLD
+#pragma unroll
+    for (int d = 8; d < 64; d <<= 1)
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          f1[pass][e] += __shfl_xor(f1[pass][e], d);
+          f2s[pass][e] += __shfl_xor(f2s[pass][e], d);
+        }
+    if (elane < 8) {
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        *reinterpret_cast<vf4*>(&red[w * 64 + pass * 32 + cidx]) = f1[pass];
+        *reinterpret_cast<vf4*>(&red[512 + w * 64 + pass * 32 + cidx]) = f2s[pass];
+      }
+    }
+    __syncthreads();
+    if (etid < 128) {
+      const int c = etid & 63, which = etid >> 6;
+      float sacc = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < 8; ++ww) sacc += red[which * 512 + ww * 64 + c];
+      ea->bs.partial[((size_t)which * Npad + n0 + c) * nstat + cur_tblk] = sacc;
+    }
+  } else if (stat_partial != nullptr) {
+
+  // block-level (count, mean, M2) per column (conv_igemm.hip's layout [3][Npad][nblocks], block index fastest) as a
+  // tree of equal-count Chan merges: thread (2 voxels) -> wave (16) -> block (128); one trip through LDS
+  vf4 mn[2], m2[2];
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const vf4 dlt = val[pass][1] - val[pass][0];
+    mn[pass] = val[pass][0] + 0.5f * dlt;
+    m2[pass] = 0.5f * dlt * dlt;
+  }
+  float nh = 1.f;                                  // half the element count of the groups being merged
+#pragma unroll
+  for (int d = 8; d < 64; d <<= 1) {
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float mo = __shfl_xor(mn[pass][e], d), qo = __shfl_xor(m2[pass][e], d);
+        const float dl = mo - mn[pass][e];
+        m2[pass][e] = m2[pass][e] + qo + dl * dl * nh;
+        mn[pass][e] = mn[pass][e] + 0.5f * dl;
+      }
+    nh *= 2.f;
+  }
+  if (elane < 8) {
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      *reinterpret_cast<vf4*>(&red[w * 64 + pass * 32 + cidx]) = mn[pass];
+      *reinterpret_cast<vf4*>(&red[512 + w * 64 + pass * 32 + cidx]) = m2[pass];
+    }
+  }
+  __syncthreads();
+  if (etid < 64) {
+    float mw[8], msum = 0.f, q = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < 8; ++ww) { mw[ww] = red[ww * 64 + etid]; msum += mw[ww]; q += red[512 + ww * 64 + etid]; }
+    const float mean_t = msum * 0.125f;
+    float dev = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < 8; ++ww) dev += (mw[ww] - mean_t) * (mw[ww] - mean_t);
+    float* sp = stat_partial + (size_t)(n0 + etid) * nstat + cur_tblk;
+    sp[0] = (float)kRows;
+    sp[(size_t)Npad * nstat] = mean_t;
+    sp[(size_t)2 * Npad * nstat] = q + dev * (float)(kRows / 8);
+  }
+  }
+  ICS_TL_FLUSH();
+  if (!more) break;
+  __syncthreads();                               // the epilogue is out of LDS before the next first chunk's successor is staged
+  item += 1;
+#ifdef ICS_W64_TIMELINE
+  tl_item = item * nchunks + nb;
+  ICS_TL(0);
+#endif
+  }                                              // items
+}
+
+// ---------------------------------------------------------------- host side
+bool conv_wino64_ok(const ConvGeom& g, const ConvSrc* src, int nsrc) {
+  if (g.flags & (CF_NO_WINO | CF_NO_WINO64)) return false;
+  if (g.taps != 27 || nsrc != 1 || g.S < 8 || g.lgS < 3) return false;
+  const ConvSrc& s = src[0];
+  if (s.up || s.bcast || s.C != g.Cin) return false;
+  if (g.Cin % KC != 0 || g.Cout % 64 != 0) return false;
+  if ((long long)g.B * g.S * g.S * g.S * (long long)std::max(g.Cin, g.Cout) >= (1ll << 29)) return false;  // 32-bit BYTE offsets
+  return true;
+}
+
+int launch_conv_fwd_wino64(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, const float* wt, const float* bias,
+                           float* out, int ldo, int pre_act, float* stat_partial, int* rows_per_block, int accumulate,
+                           const BwdStat* bwd, int* bwd_blocks) {
+  ICS_CHECK(conv_wino64_ok(g, &s0, 1), "shape not served by the 64-channel Winograd kernel");
+  ICS_CHECK(ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
+                (reinterpret_cast<uintptr_t>(bias) & 15) == 0 && (reinterpret_cast<uintptr_t>(s0.p) & 15) == 0,
+            "Winograd kernel: float4 accesses need 16-byte aligned tensors");
+  const int ntb = g.B * (g.S / 4) * (g.S / 4) * (g.S / 8), nchunks = g.Cout / 64;
+  int ipw = 1;                                   // tile blocks per workgroup: as many as leave >= 4 rounds of workgroups
+  while (ipw < 8 && ntb % (2 * ipw) == 0 && (long long)(ntb / (2 * ipw)) * nchunks >= 4ll * conv_num_cus()) ipw *= 2;
+  if (const char* e = std::getenv("ICSG3D_W64_IPW")) { const int v = std::atoi(e); if (v >= 1 && ntb % v == 0) ipw = v; }
+  const unsigned grid = (unsigned)((ntb / ipw) * nchunks);
+  if (rows_per_block) *rows_per_block = kRows;
+  const bool aff = s0.scale != nullptr;
+  const bool noact = s0.act == ACT_NONE;
+  const float in_slope = wslope(s0.act), pre_slope = wslope(pre_act);
+  const bool fold = bwd != nullptr && bwd->partial != nullptr && !aff && stat_partial == nullptr && bias == nullptr &&
+                    pre_act == ACT_NONE && !accumulate && bwd->ld % 4 == 0;
+  if (bwd_blocks) *bwd_blocks = fold ? ntb : 0;
+  const BwdStat bs = fold ? *bwd : BwdStat{};
+  W64Args a;
+  a.x = s0.p; a.in_scale = s0.scale; a.in_shift = s0.shift; a.wt = wt; a.bias = bias; a.y = out; a.stat_partial = stat_partial;
+  a.ldx = s0.C; a.ldo = ldo; a.accumulate = accumulate; a.Npad = g.Npad; a.S = g.S; a.lgS = g.lgS; a.Cin = g.Cin;
+  a.Cout = g.Cout; a.ntb = ntb; a.ipw = ipw; a.in_slope = in_slope; a.pre_slope = pre_slope; a.bs = bs;
+#define ICS_WINO_LAUNCH(AFFV, NOACTV, FOLDV)                                                                  \
+  do {                                                                                                        \
+    hipLaunchKernelGGL((conv_wino64_kernel<AFFV, NOACTV, FOLDV>), dim3(grid), dim3(512), 0, st, a);           \
+    conv_set_last_kernel_id("conv_wino64_kernel<" #AFFV ", " #NOACTV ", " #FOLDV ">");                        \
+  } while (0)
+  if (fold) ICS_WINO_LAUNCH(false, true, true);
+  else if (!aff) ICS_WINO_LAUNCH(false, true, false);
+  else if (noact) ICS_WINO_LAUNCH(true, true, false);
+  else ICS_WINO_LAUNCH(true, false, false);
+#undef ICS_WINO_LAUNCH
+  ICS_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace ics
