@@ -128,6 +128,7 @@ struct ConvLayer {
   // "up-split" backward for [skip | nearest-upsampled] concat inputs (c13/c15/c17): the up channels'
   // gradients are GEMMs over the LOW-RES grid against dy pooled per tap (27 -> 27/8 of the FLOPs).
   bool split_up = false;
+  bool wf_stale = false;                       // up-split layer: wf not rebuilt since the last parameter change
   int Cs = 0, Cu = 0;
   float *wf_skip = nullptr, *w_up = nullptr;   // packed: dgrad of the skip channels; dxl = dyS x W_up
   float *wp_skip = nullptr, *wp_par = nullptr; // packed forward: skip channels (27 taps); 8 parity classes x 8 taps
@@ -506,11 +507,14 @@ static int init_bn_defaults(Net& n) {
 static int pack_layer(Net& n, ConvLayer& L, bool need_bwd) {
   // a layer served by the Winograd kernels (decided once, at the maximum batch) never reads the direct-path image of
   // the same weights: ww replaces wp (wp_skip in an up-split layer), wwb replaces wf (wf_skip)
+  // An up-split layer never reads the full images either: its forward always takes the [skip | up] pair, and the only
+  // reader of wf is the direct backward-data path (input gradient WITHOUT parameter gradients), which no engine runs on
+  // these layers today -- it re-packs on demand (wf_stale).  c13 / c15 / c17: 111 MB per step not written.
   const bool wino_f = L.ww != nullptr, wino_b = L.wwb != nullptr;
-  if (!(wino_f && !L.split_up))
+  if (!wino_f && !L.split_up)
     ICS_TRY(launch_pack_fwd(n.st, n.tp(L.t_w), L.taps * L.CinG, L.Cout, L.wp, L.Kpad, L.Npad, 0, 0, 1,
                             L.CinG != L.Cin ? L.Cin : 0, L.CinG != L.Cin ? L.CinG : 0));
-  if (need_bwd && L.wf && !(wino_b && !L.split_up))
+  if (need_bwd && L.wf && !wino_b && !L.split_up)
     ICS_TRY(launch_pack_bwd(n.st, n.tp(L.t_w), L.taps, L.Cin, L.Cout, L.wf, L.Kpad_b, L.Npad_b, L.Cout, 0, 1));
   if (L.split_up) {
     if (L.Cs && !wino_f)
@@ -816,9 +820,14 @@ static int conv_grads_from_dy(Net& n, ConvLayer& L, int B, bool need_dA, bool pa
     if (L.wwb && !L.split_up && conv_wino_ok(gb, &sdy, 1))
       ICS_TRY(launch_conv_fwd_wino(n.st, gb, sdy, L.wwb, nullptr, L.dA, L.CinG, ACT_NONE, nullptr, nullptr, 0, &bs,
                                    &blocks));
-    else
-    ICS_TRY(launch_conv_fwd(n.st, gb, &sdy, 1, L.wf, nullptr, L.dA, L.CinG, ACT_NONE, nullptr, nullptr, 0, n.fws(),
-                            n.ws_fwd_n, &bs, &blocks));
+    else {
+      if (L.split_up && L.wf_stale) {              // see pack_layer
+        ICS_TRY(launch_pack_bwd(n.st, n.tp(L.t_w), L.taps, L.Cin, L.Cout, L.wf, L.Kpad_b, L.Npad_b, L.Cout, 0, 1));
+        L.wf_stale = false;
+      }
+      ICS_TRY(launch_conv_fwd(n.st, gb, &sdy, 1, L.wf, nullptr, L.dA, L.CinG, ACT_NONE, nullptr, nullptr, 0, n.fws(),
+                              n.ws_fwd_n, &bs, &blocks));
+    }
     bwd_stat_done(next, bs, blocks, gb.Npad);
     n.prof.end(n.st);
   }
@@ -1014,6 +1023,7 @@ static int run_pack_table(Net& n, int (*jobs)(Net&)) {
   ICS_TRY(launch_pack_table(n.st, n.d_pack_jobs, n.pack_njobs, n.pack_nblocks));
   n.prof.end(n.st);
   n.packed_valid = true;
+  for (auto& L : n.layers) if (L->split_up) L->wf_stale = true;   // the table skips their full backward image
   return 0;
 }
 static int unet_pack(Net& n) { return run_pack_table(n, unet_pack_jobs); }
