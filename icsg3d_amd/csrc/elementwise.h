@@ -75,6 +75,11 @@ struct PmSums {
   double per[4];
   float w[4];
 };
+bool head_fused_ok(int ncls, int cin, size_t M, int act);
+int launch_head_fused(hipStream_t st, const float* x, int ldx, const float* scale, const float* shift, const float* wsoft_k,
+                      const float* wsig_k, const float* bsoft, const float* bsig, float* z, const unsigned char* labels,
+                      size_t M, int mode, int want_grad, float wsoft, double* partial, int partial_blocks, float* metrics,
+                      int* nblk_out = nullptr, float* dz_colsum = nullptr);
 int launch_head(hipStream_t st, float* z, int ldz, int ncls, const unsigned char* labels, size_t M,
                 int mode, int want_grad, float wsoft, double* partial, int partial_blocks,
                 float* metrics, int* nblk_out = nullptr, float* dz_colsum = nullptr);

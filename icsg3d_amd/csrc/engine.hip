@@ -1065,6 +1065,33 @@ static int unet_loss(Net& n, int B, int mode, int want_grad, bool want_metrics =
   return 0;
 }
 
+// head GEMM + loss: one fused pass over the trunk output where the shape allows it (elementwise.hip head_fused_kernel:
+// the logits never go to memory), else the 1x1x1 GEMM followed by head_kernel.  H.s receives what head_kernel would
+// have left there: probabilities (mode 0) or dLoss/dz (mode 1 with want_grad).
+static int unet_head_loss(Net& n, int B, int mode, int want_grad, bool want_metrics = true) {
+  ConvLayer& H = *n.head;
+  const size_t M = n.rows(H, B);
+  const ConvSrc& s0 = H.src[0];
+  if (H.nsrc != 1 || s0.up || s0.bcast || !head_fused_ok(n.ncls, s0.C, M, s0.act)) {
+    ICS_TRY(unet_head_forward(n, B));
+    return unet_loss(n, B, mode, want_grad, want_metrics);
+  }
+  ICS_TRY(unet_pack(n));
+  n.last_batch = B;
+  n.prof.begin(n.st, "head_fused", 2.0 * M * 128 * (n.ncls + 1), 4.0 * M * (128 + (mode == 1 && !want_grad ? 0 : n.ncls + 1)));
+  ICS_TRY(launch_head_fused(n.st, s0.p, s0.C, s0.scale, s0.shift, n.tp(H.t_w), n.tp(H.t_gamma), n.tp(H.t_b),
+                            n.tp(H.t_b) + n.ncls, H.s, n.labels, M, mode, want_grad, n.loss_weight, n.ws_dbl, 2048,
+                            n.comm ? nullptr : n.d_metrics, &n.head_nblk, want_grad ? n.ws_bwd : nullptr));
+  n.prof.end(n.st);
+  if (mode != 0 && n.comm && want_metrics) {
+    ICS_TRY(launch_head_metrics(n.st, n.ws_dbl, n.head_nblk, (double)M, n.d_metrics, n.d_red, 1));
+    ncclResult_t r = ncclAllReduce(n.d_red, n.d_red, 7, ncclDouble, ncclSum, n.comm, n.st);
+    ICS_CHECK(r == ncclSuccess, std::string("ncclAllReduce(metrics): ") + ncclGetErrorString(r));
+    ICS_TRY(launch_head_metrics(n.st, n.ws_dbl, n.head_nblk, (double)M, n.d_metrics, n.d_red, 2));
+  }
+  return 0;
+}
+
 // merges per-block column partials [nblk][C] (head bias gradients; partials come from head_kernel)
 __global__ __launch_bounds__(256) void colsum_merge_kernel(const float* __restrict__ partial, int nblk, int C,
                                                             float* __restrict__ out) {
@@ -1185,8 +1212,7 @@ static int unet_train_resident_impl(Net& n, int B, float* metrics) {
   {
     Range r("icsg3d.unet.forward");
     ICS_TRY(unet_forward_trunk(n, B, true, true, false, n.x_in));
-    ICS_TRY(unet_head_forward(n, B));
-    ICS_TRY(unet_loss(n, B, 1, 1, metrics != nullptr));
+    ICS_TRY(unet_head_loss(n, B, 1, 1, metrics != nullptr));
   }
   {
     Range r("icsg3d.unet.backward");
@@ -1780,8 +1806,7 @@ int ics_unet_predict(ics_net* net, const float* x, int batch, float* soft, float
   Net& n = net->n;
   ICS_TRY(unet_upload(n, x, nullptr, batch));
   ICS_TRY(unet_forward_trunk(n, batch, false, false, false, n.x_in));
-  ICS_TRY(unet_head_forward(n, batch));
-  ICS_TRY(unet_loss(n, batch, 0, 0));
+  ICS_TRY(unet_head_loss(n, batch, 0, 0));
   const size_t M = n.rows(*n.head, batch);
   const int ld = n.ncls + 1;
   float* stage = n.head->dy;   // [M][ncls+1] scratch: soft packed first, sig after it
@@ -1808,8 +1833,7 @@ int ics_unet_predict_labels(ics_net* net, const float* x, int batch, float thres
   Net& n = net->n;
   ICS_TRY(unet_upload(n, x, nullptr, batch));
   ICS_TRY(unet_forward_trunk(n, batch, false, false, false, n.x_in));
-  ICS_TRY(unet_head_forward(n, batch));
-  ICS_TRY(unet_loss(n, batch, 0, 0));
+  ICS_TRY(unet_head_loss(n, batch, 0, 0));
   const size_t M = n.rows(*n.head, batch);
   unsigned char* d_species = reinterpret_cast<unsigned char*>(n.head->dy);   // [M][ncls+1] float scratch
   unsigned char* d_mask = d_species + M;
@@ -1845,8 +1869,7 @@ int ics_unet_test_step(ics_net* net, const float* x, const uint8_t* labels, int 
   Net& n = net->n;
   ICS_TRY(unet_upload(n, x, labels, batch));
   ICS_TRY(unet_forward_trunk(n, batch, false, false, false, n.x_in));
-  ICS_TRY(unet_head_forward(n, batch));
-  ICS_TRY(unet_loss(n, batch, 1, 0));
+  ICS_TRY(unet_head_loss(n, batch, 1, 0));
   ICS_HIP(hipMemcpyAsync(metrics, n.d_metrics, 5 * sizeof(float), hipMemcpyDeviceToHost, n.st));
   ICS_HIP(hipStreamSynchronize(n.st));
   return 0;
@@ -1933,8 +1956,7 @@ static int decode_to_labels_device(Net& n, Net& u, const float* z, const float* 
   float* d_aux = reinterpret_cast<float*>(d_mask + M);                       // density [M] | minmax [B][3][2]
   do {
     if ((rc = unet_forward_trunk(u, batch, false, false, false, n.recon))) break;
-    if ((rc = unet_head_forward(u, batch))) break;
-    if ((rc = unet_loss(u, batch, 0, 0))) break;
+    if ((rc = unet_head_loss(u, batch, 0, 0))) break;
     hipLaunchKernelGGL(labels_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, n.st, u.head->s, u.ncls + 1,
                        u.ncls, M, thresh, d_species, d_mask);
     if (want_density) {
