@@ -1000,11 +1000,12 @@ __global__ __launch_bounds__(256, 2) void head_fused_kernel(const float* __restr
         sl_sum += p[t][r];
       }
     const float sum = xsum(sl_sum);
+    const float rsum = 1.f / sum;                            // one division per voxel (head_kernel divides per class)
     float psl = 0.f;
 #pragma unroll
     for (int t = 0; t < 6; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { p[t][r] = p[t][r] / sum; psl += p[t][r]; }
+      for (int r = 0; r < 4; ++r) { p[t][r] = p[t][r] * rsum; psl += p[t][r]; }
     const float ps = 1.f / (1.f + expf(-zsig));
     float* zr = z + row * NZ + 4 * g;
     if (mode == 0) {
