@@ -76,6 +76,9 @@ struct PmSums {
   float w[4];
 };
 bool head_fused_ok(int ncls, int cin, size_t M, int act);
+bool head_dgrad_ok(int ncls, int cin, size_t M, const BwdStat* bs);
+int launch_head_dgrad(hipStream_t st, const float* dz, const float* wsoft_k, const float* wsig_k, float* dx, int ldo, size_t M,
+                      const BwdStat* bs, int Npad, int* blocks);
 int launch_head_fused(hipStream_t st, const float* x, int ldx, const float* scale, const float* shift, const float* wsoft_k,
                       const float* wsig_k, const float* bsoft, const float* bsig, float* z, const unsigned char* labels,
                       size_t M, int mode, int want_grad, float wsoft, double* partial, int partial_blocks, float* metrics,

@@ -34,34 +34,49 @@ __device__ __forceinline__ double block_sum_d(double v, double* sh /*[4]*/) {
   __syncthreads();
   return sh[0] + sh[1] + sh[2] + sh[3];
 }
+// any block size up to 1024 threads (sh[16]); the waves' sums are added in wave order
+__device__ __forceinline__ double block_sum_dn(double v, double* sh /*[16]*/) {
+  v = wave_sum_d(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double r = sh[0];
+  for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r += sh[w];
+  return r;
+}
 
 // ------------------------------------------------------------------------------------------
 // BatchNorm forward statistics: merge per-block (count, mean, M2) -> mean/var -> scale/shift,
 // moving-average update.  One block per channel, fp64 merge (Chan et al.).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int nblk,
-                                                           int Npad, BnParams bn, int update_moving,
-                                                           float momentum, int unbias) {
-  __shared__ double sh[4];
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ partial, int nblk,
+                                                            int Npad, BnParams bn, int update_moving,
+                                                            float momentum, int unbias) {
+  __shared__ double sh[16];
   const int c = blockIdx.x;
-  double n = 0.0, s = 0.0;
-  // partial layout [3][Npad][nblk]: this channel's (count, mean, M2) rows are contiguous
+  // partial layout [3][Npad][nblk]: this channel's (count, mean, M2) rows are contiguous.  ONE pass in fp64:
+  // M2 = sum (M2_b + n_b m_b^2) - N mean^2 (the inputs are fp32: 29 spare bits for the cancellation), one trip
+  // through the block reduction for the three sums -- the kernel sits between every convolution and its consumer.
   const float* pn = partial + (size_t)c * nblk;
   const float* pm = partial + ((size_t)Npad + c) * nblk;
   const float* pq = partial + ((size_t)2 * Npad + c) * nblk;
-  for (int b = threadIdx.x; b < nblk; b += 256) {
-    n += (double)pn[b];
-    s += (double)pn[b] * (double)pm[b];
+  double n = 0.0, s = 0.0, q = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += blockDim.x) {
+    const double nb = (double)pn[b], mb = (double)pm[b];
+    n += nb;
+    s += nb * mb;
+    q += (double)pq[b] + nb * mb * mb;
   }
-  n = block_sum_d(n, sh);
-  s = block_sum_d(s, sh);
+  n = wave_sum_d(n); s = wave_sum_d(s); q = wave_sum_d(q);
+  __shared__ double sh3[3][16];
+  if ((threadIdx.x & 63) == 0) { sh3[0][threadIdx.x >> 6] = n; sh3[1][threadIdx.x >> 6] = s; sh3[2][threadIdx.x >> 6] = q; }
+  __syncthreads();
+  n = sh3[0][0]; s = sh3[1][0]; q = sh3[2][0];
+  for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { n += sh3[0][w]; s += sh3[1][w]; q += sh3[2][w]; }
   const double mean = s / n;
-  double m2 = 0.0;
-  for (int b = threadIdx.x; b < nblk; b += 256) {
-    const double d = (double)pm[b] - mean;
-    m2 += (double)pq[b] + (double)pn[b] * d * d;
-  }
-  m2 = block_sum_d(m2, sh);
+  double m2 = q - n * mean * mean;
+  if (m2 < 0.0) m2 = 0.0;
+  (void)sh;
   if (threadIdx.x == 0) {
     const double var = m2 / n;   // biased, as tf.nn.moments
     const float rstd = (float)(1.0 / sqrt(var + (double)kBnEps));
@@ -158,7 +173,7 @@ int launch_bn_finalize(hipStream_t st, const float* partial, int nblk, int Npad,
     ICS_HIP(hipGetLastError());
     return 0;
   }
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, st, partial, nblk, Npad, bn,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(nblk >= 2048 ? 1024 : 256), 0, st, partial, nblk, Npad, bn,
                      update_moving, 0.99f, unbias);
   ICS_HIP(hipGetLastError());
   return 0;
@@ -358,24 +373,24 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(LayerBwd L, int rows
 // sums != nullptr (SyncBN): the raw fp64 sums go to sums[0..C) / sums[C..2C) instead of c1/c2; after
 // the all-reduce over ranks bn_bwd_sync_c_kernel divides by the GLOBAL element count.  dgamma/dbeta
 // stay the local sums (the gradient all-reduce adds the ranks later).
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial,
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial,
                                                                int nblk, int C, int ld, double n,
                                                                float* __restrict__ c1,
                                                                float* __restrict__ c2,
                                                                float* __restrict__ dgamma,
                                                                float* __restrict__ dbeta,
                                                                double* __restrict__ sums) {
-  __shared__ double sh[4];
+  __shared__ double sh[16];
   const int c = blockIdx.x;
   double s1 = 0.0, s2 = 0.0;
   const float* p1 = partial + (size_t)c * nblk;                 // [2][ld][nblk]
   const float* p2 = partial + ((size_t)ld + c) * nblk;
-  for (int b = threadIdx.x; b < nblk; b += 256) {
+  for (int b = threadIdx.x; b < nblk; b += blockDim.x) {
     s1 += (double)p1[b];
     s2 += (double)p2[b];
   }
-  s1 = block_sum_d(s1, sh);
-  s2 = block_sum_d(s2, sh);
+  s1 = block_sum_dn(s1, sh);
+  s2 = block_sum_dn(s2, sh);
   if (threadIdx.x == 0) {
     if (sums) { sums[c] = s1; sums[C + c] = s2; }
     else { c1[c] = (float)(s1 / n); c2[c] = (float)(s2 / n); }
@@ -708,7 +723,7 @@ int launch_layer_bwd(hipStream_t st, const LayerBwd& L, float* dy, float* ws_par
       else hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(nblk), dim3(256), 0, st, L, rpb, ws_partial);
       ICS_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(L.C), dim3(256), 0, st, red, red_n, L.C, red_ld, n, c1,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(L.C), dim3(red_n >= 2048 ? 1024 : 256), 0, st, red, red_n, L.C, red_ld, n, c1,
                        c2, dgamma, dbeta, sync ? sync->local : nullptr);
     ICS_HIP(hipGetLastError());
     if (sync) {   // every rank holds the same number of rows (equal shards): n_global = n * nranks
@@ -1104,6 +1119,115 @@ int launch_head_fused(hipStream_t st, const float* x, int ldx, const float* scal
   ICS_HIP(hipGetLastError());
   if (nblk_out) *nblk_out = nblk;
   if (mode != 0 && metrics != nullptr) ICS_TRY(launch_head_metrics(st, partial, nblk, (double)M, metrics, nullptr, 0));
+  return 0;
+}
+
+// Backward-data of the same head in the same transposed shape: dX^T[ch][voxel] = sum_cls W[ch][cls] dZ^T[cls][voxel].
+// The B operand is the voxel's own dz row from global memory (six 16-byte loads = 24 k-steps), the weights sit in LDS
+// channel-major (pitch 100), a lane ends with the channels 16 c + 4 g + r of its voxel (eight float4 stores), and the
+// producer's BatchNorm-backward sums (sum d, sum d * xhat per channel -- what bn_bwd_reduce would compute) are
+// accumulated per lane over the wave's voxels and reduced once at the end: [2][Npad][blocks], block index fastest.
+constexpr int kHeadDP = 100;
+__global__ __launch_bounds__(256, 2) void head_dgrad_kernel(const float* __restrict__ dz, const float* __restrict__ wsoft_k,
+                                                            const float* __restrict__ wsig_k, float* __restrict__ dx,
+                                                            int ldo, int ntiles, BwdStat bs, int Npad) {
+  constexpr int NC = 95, NZ = 96, CH = 128;
+  __shared__ __attribute__((aligned(16))) float Wc[CH * kHeadDP];
+  __shared__ __attribute__((aligned(16))) float mu_s[CH], rs_s[CH];
+  __shared__ float fold[4][2][CH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool stat = bs.partial != nullptr;
+  for (int i = tid; i < CH * NZ; i += 256) {
+    const int ch = i / NZ, cls = i - ch * NZ;
+    Wc[ch * kHeadDP + cls] = cls < NC ? wsoft_k[ch * NC + cls] : wsig_k[ch];
+  }
+  if (stat && tid < CH) { mu_s[tid] = bs.mean[tid]; rs_s[tid] = bs.rstd[tid]; }
+  __syncthreads();
+  const int n = lane & 15, g = lane >> 4;
+  const int nwaves = gridDim.x * 4;
+  int tile = blockIdx.x * 4 + wave;
+  hv4 f1[8], f2[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) { f1[c] = hv4{0.f, 0.f, 0.f, 0.f}; f2[c] = hv4{0.f, 0.f, 0.f, 0.f}; }
+  hv4 db[6];
+  auto dload = [&](int tl) {
+    const float* zr = dz + ((size_t)tl * 16 + n) * NZ + 4 * g;
+#pragma unroll
+    for (int t = 0; t < 6; ++t) db[t] = *reinterpret_cast<const hv4*>(zr + 16 * t);
+  };
+  if (tile < ntiles) dload(tile);
+  for (; tile < ntiles; tile += nwaves) {
+    const size_t row = (size_t)tile * 16 + n;
+    hv4 dc[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) dc[t] = db[t];
+    if (tile + nwaves < ntiles) dload(tile + nwaves);
+    hv4 sv[8];
+    if (stat) {
+      const float* sr = bs.s + row * bs.ld + 4 * g;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) sv[c] = *reinterpret_cast<const hv4*>(sr + 16 * c);
+    }
+    hv4 acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = hv4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const hv4 a4 = *reinterpret_cast<const hv4*>(&Wc[(16 * c + n) * kHeadDP + 16 * t + 4 * g]);
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx)
+          acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[sidx], dc[t][sidx], acc[c], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    float* xr = dx + row * ldo + 4 * g;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) *reinterpret_cast<hv4*>(xr + 16 * c) = acc[c];
+    if (stat) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const hv4 mu = *reinterpret_cast<const hv4*>(&mu_s[16 * c + 4 * g]);
+        const hv4 rs = *reinterpret_cast<const hv4*>(&rs_s[16 * c + 4 * g]);
+        f1[c] += acc[c];
+        f2[c] += acc[c] * ((sv[c] - mu) * rs);
+      }
+    }
+  }
+  if (!stat) return;
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float a = f1[c][r], b = f2[c][r];
+      a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 4); a += __shfl_xor(a, 8);
+      b += __shfl_xor(b, 1); b += __shfl_xor(b, 2); b += __shfl_xor(b, 4); b += __shfl_xor(b, 8);
+      if (n == 0) { fold[wave][0][16 * c + 4 * g + r] = a; fold[wave][1][16 * c + 4 * g + r] = b; }
+    }
+  __syncthreads();
+  {
+    const int which = tid >> 7, ch = tid & 127;
+    const float v = fold[0][which][ch] + fold[1][which][ch] + fold[2][which][ch] + fold[3][which][ch];
+    bs.partial[((size_t)which * Npad + ch) * gridDim.x + blockIdx.x] = v;
+  }
+}
+
+bool head_dgrad_ok(int ncls, int cin, size_t M, const BwdStat* bs) {
+  return ncls == 95 && cin == 128 && M % 16 == 0 && (bs == nullptr || bs->partial == nullptr || bs->post_act == ACT_NONE) &&
+         std::getenv("ICSG3D_NO_FUSED_HEAD") == nullptr;
+}
+int launch_head_dgrad(hipStream_t st, const float* dz, const float* wsoft_k, const float* wsig_k, float* dx, int ldo, size_t M,
+                      const BwdStat* bs, int Npad, int* blocks) {
+  ICS_CHECK(M % 16 == 0 && ldo % 4 == 0, "head backward-data: rows must come in sixteens, float4-aligned");
+  const int ntiles = (int)(M / 16);
+  int nblk = (ntiles + 3) / 4;
+  if (nblk > 512) nblk = 512;
+  const BwdStat b = bs ? *bs : BwdStat{};
+  hipLaunchKernelGGL(head_dgrad_kernel, dim3(nblk), dim3(256), 0, st, dz, wsoft_k, wsig_k, dx, ldo, ntiles, b, Npad);
+  ICS_HIP(hipGetLastError());
+  conv_set_last_kernel_id("head_dgrad_kernel");
+  if (blocks) *blocks = b.partial ? nblk : 0;
   return 0;
 }
 

@@ -1145,8 +1145,11 @@ static int unet_backward(Net& n, int B) {
     n.prof.begin(n.st, "conv_dgrad:head|", 2.0 * M * 128 * nc1, 4.0 * M * (128 + nc1));
     const BwdStat bs = bwd_stat_for(n, r.c18, B);
     int blocks = 0;
-    ICS_TRY(launch_conv_fwd(n.st, gb, &sdz, 1, H.wf, nullptr, H.dA, 128, ACT_NONE, nullptr, nullptr, 0, nullptr, 0, &bs,
-                            &blocks));
+    if (head_dgrad_ok(n.ncls, 128, M, &bs))
+      ICS_TRY(launch_head_dgrad(n.st, H.s, n.tp(H.t_w), n.tp(H.t_gamma), H.dA, 128, M, &bs, gb.Npad, &blocks));
+    else
+      ICS_TRY(launch_conv_fwd(n.st, gb, &sdz, 1, H.wf, nullptr, H.dA, 128, ACT_NONE, nullptr, nullptr, 0, nullptr, 0, &bs,
+                              &blocks));
     bwd_stat_done(r.c18, bs, blocks, gb.Npad);
     n.prof.end(n.st);
   }
