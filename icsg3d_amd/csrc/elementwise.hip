@@ -213,8 +213,51 @@ __global__ void pool_fwd_kernel(const float* __restrict__ s, const float* __rest
   idx[i] = (unsigned char)bi;
 }
 
+// four channels per thread (C % 4 == 0): eight 16-byte loads in flight, one 16-byte and one 4-byte store
+__global__ __launch_bounds__(256) void pool_fwd4_kernel(const float* __restrict__ s, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, int act, int B, int S, int C,
+                                                         float* __restrict__ out, unsigned char* __restrict__ idx) {
+  typedef float qv4 __attribute__((ext_vector_type(4)));
+  const int Sh = S >> 1, C4 = C >> 2;
+  const size_t total = (size_t)B * Sh * Sh * Sh * C4;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % C4) * 4;
+  size_t v = i / C4;
+  const int x = v % Sh; v /= Sh;
+  const int y = v % Sh; v /= Sh;
+  const int z = v % Sh;
+  const int b = (int)(v / Sh);
+  qv4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+  if (scale) { sc = *reinterpret_cast<const qv4*>(scale + c); sh = *reinterpret_cast<const qv4*>(shift + c); }
+  qv4 q[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int zz = 2 * z + (k >> 2), yy = 2 * y + ((k >> 1) & 1), xx = 2 * x + (k & 1);
+    q[k] = *reinterpret_cast<const qv4*>(s + ((((size_t)b * S + zz) * S + yy) * S + xx) * C + c);
+  }
+  float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  unsigned bi[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float o = act_fwd(fmaf(q[k][j], sc[j], sh[j]), act);
+      if (o > best[j]) { best[j] = o; bi[j] = (unsigned)k; }   // first maximum in (dz,dy,dx) scan order
+    }
+  *reinterpret_cast<qv4*>(out + i * 4) = qv4{best[0], best[1], best[2], best[3]};
+  *reinterpret_cast<unsigned*>(idx + i * 4) = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+}
+
 int launch_pool_fwd(hipStream_t st, const float* s, const float* scale, const float* shift, int act,
                     int B, int S, int C, float* out, unsigned char* idx) {
+  if (C % 4 == 0 && ((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(idx)) & 15) == 0) {
+    const size_t total4 = (size_t)B * (S / 2) * (S / 2) * (S / 2) * (C / 4);
+    hipLaunchKernelGGL(pool_fwd4_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, s, scale, shift, act, B,
+                       S, C, out, idx);
+    ICS_HIP(hipGetLastError());
+    return 0;
+  }
   const size_t total = (size_t)B * (S / 2) * (S / 2) * (S / 2) * C;
   hipLaunchKernelGGL(pool_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, s, scale,
                      shift, act, B, S, C, out, idx);
