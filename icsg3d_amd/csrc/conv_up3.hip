@@ -22,6 +22,8 @@
 // (fz, row, column, sub-step): checked exhaustively).  Weights [Cout/64][Cu/4][27 f][4 k][16 n][4 column blocks].
 #include "common.h"
 
+#include <type_traits>
+
 #include <algorithm>
 
 namespace ics {
@@ -193,10 +195,13 @@ __global__ __launch_bounds__(576, 4) void conv_up3_kernel(const float* __restric
 
   const int nch = Cin / KC;
   int nxt = BUF;                                 // float offset of the buffer being filled
-  for (int ch = 0; ch < nch; ++ch) {
-    const int cn = (ch + 1 < nch ? ch + 1 : ch) * KC;                   // past the end: the last chunk again (never consumed)
+  // ST = false: the last chunk, a second copy of the loop body that stages nothing (its read-ahead columns wrap around
+  // inside the buffer being consumed and are never used) -- as in conv_wino64.hip
+  auto chunk = [&](const int ch, auto stage_tag) {
+    constexpr bool ST = decltype(stage_tag)::value;
+    const int cn = (ch + 1) * KC;
     const int dlt = 2 * nxt - BUF;
-    hload(cn);
+    if (ST) hload(cn);
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       int gs = ch * 8 + s + 1;
@@ -204,7 +209,7 @@ __global__ __launch_bounds__(576, 4) void conv_up3_kernel(const float* __restric
 #pragma unroll
       for (int g = 0; g < 3; ++g) {
         tn[g] = fmaf(sa, qa, sb * qb);           // column g of sub-step s+1, read one column ago
-        if (s == 6 && g == 2) {                  // the next chunk must be visible before its first column is read
+        if (ST && s == 6 && g == 2) {            // the next chunk must be visible before its first column is read
           hstore(nxt, cn);
           __syncthreads();
           Ra += dlt; Rb += dlt;
@@ -222,7 +227,9 @@ __global__ __launch_bounds__(576, 4) void conv_up3_kernel(const float* __restric
       xform();
     }
     nxt = BUF - nxt;
-  }
+  };
+  for (int ch = 0; ch < nch - 1; ++ch) chunk(ch, std::true_type{});
+  chunk(nch - 1, std::false_type{});
 
   // ---------------------------------------------------------------- epilogue, two passes of two column blocks each
   // lane l holds P[voxel = 4 kq + i][n = l & 15] for its (fz, fy) and fx = 0..2.  fx -> dx in registers (dx0 = P0 + P1,
