@@ -1294,11 +1294,103 @@ __global__ __launch_bounds__(256) void conv_thin_n_fwd_kernel(ConvGeom g, ConvSr
   }
 }
 
+// Cout == 1 in two stages (the stencil above moves 27 x Cin floats per output voxel through L1: c1's backward-data,
+// Cin = 32, 0.23 ms at 0.6 TB/s):
+//   A. T[tap][m] = sum_c x[m][c] w[tap][c] for all 27 taps at once -- a [M x Cin] x [Cin x 27] product, so it runs on
+//      v_mfma_f32_16x16x4_f32 transposed (D[tap][voxel]): the B operand is the voxel's own row from global memory, the
+//      27 x Cin weights live in registers; one pass over x, 27 planes out;
+//   B. out[m] = act(sum_tap T[tap][m + off(tap)] + b): 27 coalesced plane reads per voxel, zero padding by predicate.
+// Traffic (M = 1 M voxels, Cin = 32): 134 MB in + 113 MB out, then 113 MB in: ~0.08 ms.  Same sums, other order.
+typedef float tv4 __attribute__((ext_vector_type(4)));
+template <int CK>                                  // CK = Cin / 16
+__global__ __launch_bounds__(256) void thin1_taps_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ wp,
+                                                         int Npad, int M, float* __restrict__ T) {
+  const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+  constexpr int C = CK * 16;
+  tv4 wa[2][CK];                                   // A operand: w[tap = 16 tt + n][c = 16 kk + 4 g + s]
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int kk = 0; kk < CK; ++kk) {
+      const int tap = 16 * tt + n;
+      const int k4 = (tap * C + 16 * kk + 4 * g) >> 2;       // packed [K/4][Npad][4], column 0
+      wa[tt][kk] = tap < 27 ? *reinterpret_cast<const tv4*>(wp + (size_t)k4 * Npad * 4) : tv4{0.f, 0.f, 0.f, 0.f};
+    }
+  const int ntiles = M >> 4, nw = gridDim.x * 4;
+  for (int tile = blockIdx.x * 4 + (threadIdx.x >> 6); tile < ntiles; tile += nw) {
+    const size_t m = (size_t)tile * 16 + n;
+    tv4 xb[CK];
+#pragma unroll
+    for (int kk = 0; kk < CK; ++kk) xb[kk] = *reinterpret_cast<const tv4*>(x + m * ldx + 16 * kk + 4 * g);
+    tv4 acc[2] = {tv4{0.f, 0.f, 0.f, 0.f}, tv4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int kk = 0; kk < CK; ++kk)
+#pragma unroll
+      for (int sidx = 0; sidx < 4; ++sidx) {
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[0][kk][sidx], xb[kk][sidx], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[1][kk][sidx], xb[kk][sidx], acc[1], 0, 0, 0);
+      }
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int tap = 16 * tt + 4 * g + r;                 // D[tap local = 4 g + r][voxel n]
+        if (tap < 27) T[(size_t)tap * M + m] = acc[tt][r];
+      }
+  }
+}
+__global__ __launch_bounds__(256) void thin1_gather_kernel(const float* __restrict__ T, int B, int S, int lg, int M,
+                                                           const float* __restrict__ bias, float slope,
+                                                           float* __restrict__ out, int ldo) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  const RowPos rp = decode_row(m, S, lg);
+  float a = 0.f;
+#pragma unroll
+  for (int tap = 0; tap < 27; ++tap) {
+    const int dz = tap / 9 - 1, dy = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
+    const bool inb = (unsigned)(rp.z + dz) < (unsigned)S && (unsigned)(rp.y + dy) < (unsigned)S &&
+                     (unsigned)(rp.x + dx) < (unsigned)S;
+    const float v = T[(size_t)tap * M + (inb ? m + (dz * S + dy) * S + dx : m)];
+    a += inb ? v : 0.f;
+  }
+  if (bias != nullptr) a += bias[0];
+  out[(size_t)m * ldo] = act_apply(a, slope);
+}
+static bool thin1_two_stage_ok(const ConvGeom& g, const ConvSrc& s0) {
+  const int M = g.B << (3 * g.lgS);
+  return g.Cin % 16 == 0 && g.Cin <= 64 && M % 16 == 0 && s0.scale == nullptr && s0.act == ACT_NONE &&
+         std::getenv("ICSG3D_NO_THIN1_2STAGE") == nullptr;
+}
+static int launch_thin1_two_stage(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, const float* wp, const float* bias,
+                                  float* out, int ldo, int pre_act, float* ws) {
+  const int M = g.B << (3 * g.lgS);
+  int nblk = (M / 16 + 3) / 4;
+  if (nblk > 1024) nblk = 1024;
+  switch (g.Cin / 16) {
+    case 1: hipLaunchKernelGGL(thin1_taps_kernel<1>, dim3(nblk), dim3(256), 0, st, s0.p, s0.C, wp, g.Npad, M, ws); break;
+    case 2: hipLaunchKernelGGL(thin1_taps_kernel<2>, dim3(nblk), dim3(256), 0, st, s0.p, s0.C, wp, g.Npad, M, ws); break;
+    case 3: hipLaunchKernelGGL(thin1_taps_kernel<3>, dim3(nblk), dim3(256), 0, st, s0.p, s0.C, wp, g.Npad, M, ws); break;
+    default: hipLaunchKernelGGL(thin1_taps_kernel<4>, dim3(nblk), dim3(256), 0, st, s0.p, s0.C, wp, g.Npad, M, ws); break;
+  }
+  ICS_HIP(hipGetLastError());
+  hipLaunchKernelGGL(thin1_gather_kernel, dim3((M + 255) / 256), dim3(256), 0, st, ws, g.B, g.S, g.lgS, M, bias,
+                     act_slope_of(pre_act), out, ldo);
+  ICS_HIP(hipGetLastError());
+  g_last_kernel_id = "thin1_taps_kernel + thin1_gather_kernel";
+  return 0;
+}
+
 static int thin_n_lg_lpv(const ConvGeom& g) { return g.Cin <= 16 ? 0 : 2; }
 static int launch_thin_n_fwd(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, const float* wp, const float* bias,
                              float* out, int ldo, int pre_act, float* stat_partial, int* rows_per_block,
-                             int accumulate) {
+                             int accumulate, float* ws = nullptr, size_t ws_floats = 0) {
   const int M = g.B << (3 * g.lgS);
+  if (g.Cout == 1 && stat_partial == nullptr && !accumulate && ws != nullptr && ws_floats >= (size_t)27 * M &&
+      thin1_two_stage_ok(g, s0)) {
+    if (rows_per_block) *rows_per_block = 256;
+    return launch_thin1_two_stage(st, g, s0, wp, bias, out, ldo, pre_act, ws);
+  }
   const int lgv = thin_n_lg_lpv(g), vpb = 256 >> lgv;
   const dim3 grid((M + vpb - 1) / vpb);
   const size_t lds = (size_t)std::max(27 * g.Cin * 4, 64) * sizeof(float);
@@ -1413,7 +1505,9 @@ size_t conv_fwd_workspace_floats(const ConvGeom& g, const ConvSrc* src, int nsrc
   ConvSrc s0 = src[0], s1 = src[nsrc > 1 ? 1 : 0];
   if (nsrc == 1) s1.C = 0;
   const int ks = fwd_splitk_plan(g, s0, s1, nsrc);
-  return ks > 1 ? (size_t)ks * ((size_t)g.B << (3 * g.lgS)) * g.Npad : 0;
+  size_t need = ks > 1 ? (size_t)ks * ((size_t)g.B << (3 * g.lgS)) * g.Npad : 0;
+  if (thin_n_ok(g, s0, nsrc) && g.Cin % 16 == 0) need = std::max(need, (size_t)27 * ((size_t)g.B << (3 * g.lgS)));   // thin1 two-stage planes
+  return need;
 }
 
 __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ ws, int nsplit, int M, int N,
@@ -1471,7 +1565,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
 static int launch_conv_fwd_inner(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int nsrc,
                                  const float* wp, const float* bias, float* out, int ldo, int pre_act,
                                  float* stat_partial, int* rows_per_block, int accumulate, int ksplit,
-                                 const BwdStat* bwd = nullptr);
+                                 const BwdStat* bwd = nullptr, float* ws = nullptr, size_t ws_floats = 0);
 
 int launch_conv_fwd(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int nsrc,
                     const float* wp, const float* bias, float* out, int ldo, int pre_act,
@@ -1490,7 +1584,7 @@ int launch_conv_fwd(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int n
                       !accumulate;
     int rpb = 0;
     ICS_TRY(launch_conv_fwd_inner(st, g, src, nsrc, wp, bias, out, ldo, pre_act, stat_partial, &rpb, accumulate, 1,
-                                  fold ? bwd : nullptr));
+                                  fold ? bwd : nullptr, ws, ws_floats));
     if (rows_per_block) *rows_per_block = rpb;
     if (fold && bwd_blocks) *bwd_blocks = (int)((((size_t)g.B << (3 * g.lgS)) + rpb - 1) / rpb);
     return 0;
@@ -1508,9 +1602,10 @@ int launch_conv_fwd(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int n
 static int launch_conv_fwd_inner(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int nsrc,
                                  const float* wp, const float* bias, float* out, int ldo, int pre_act,
                                  float* stat_partial, int* rows_per_block, int accumulate, int ksplit,
-                                 const BwdStat* bwd) {
+                                 const BwdStat* bwd, float* ws, size_t ws_floats) {
   if (ksplit == 1 && thin_n_ok(g, src[0], nsrc))
-    return launch_thin_n_fwd(st, g, src[0], wp, bias, out, ldo, pre_act, stat_partial, rows_per_block, accumulate);
+    return launch_thin_n_fwd(st, g, src[0], wp, bias, out, ldo, pre_act, stat_partial, rows_per_block, accumulate, ws,
+                             ws_floats);
   if (ksplit == 1 && !accumulate && bwd == nullptr && conv_thin_c_ok(g, src[0], nsrc, g.Cin) && ldo % 4 == 0)
     return launch_conv_fwd_thin_c(st, g, src[0], g.Cin, g.Cin, wp, bias, out, ldo, pre_act, stat_partial,
                                   rows_per_block);

@@ -742,7 +742,7 @@ int launch_layer_bwd(hipStream_t st, const LayerBwd& L, float* dy, float* ws_par
   float* c2 = c1c2 + L.C;
   const bool v4 = (L.C % 4 == 0);
   const int cb = L.C >> 2;
-  const bool fast = v4 && L.has_bn && !L.dtap && (!L.tap_ref || (L.g0.kind == GS_DIRECT && L.g1.kind == GS_NONE)) && cb <= 256 && (cb & (cb - 1)) == 0 &&
+  const bool fast = v4 && L.has_bn && !L.dtap && (!L.tap_ref || L.g1.kind == GS_NONE) && cb <= 256 && (cb & (cb - 1)) == 0 &&
                     ((size_t)n % (size_t)(256 / (cb ? cb : 1))) == 0 &&
                     (L.g0.kind == GS_DIRECT || L.g0.kind == GS_POOL) &&
                     (L.g1.kind == GS_NONE || L.g1.kind == GS_DIRECT) && std::getenv("ICSG3D_NO_FAST_BNBWD") == nullptr;
@@ -783,7 +783,11 @@ int launch_layer_bwd(hipStream_t st, const LayerBwd& L, float* dy, float* ws_par
 #define ICS_BNF(G0_, G1_, T_, U_) \
     hipLaunchKernelGGL((bn_bwd_apply_fast_kernel<G0_, G1_, T_, U_>), dim3(nblk), dim3(256), 0, st, L, c1, c2, dy, dbp)
     const bool g1 = L.g1.kind == GS_DIRECT, ties = L.pool_ties_all != 0;
-    if (L.tap_ref) hipLaunchKernelGGL((bn_bwd_apply_fast_kernel<GS_DIRECT, GS_NONE, false, 4, true>), dim3(nblk), dim3(256), 0, st, L, c1, c2, dy, dbp);
+    if (L.tap_ref) {                               // perceptual tap layers: behind the max-pool, or straight from a consumer
+      if (L.g0.kind == GS_DIRECT) hipLaunchKernelGGL((bn_bwd_apply_fast_kernel<GS_DIRECT, GS_NONE, false, 4, true>), dim3(nblk), dim3(256), 0, st, L, c1, c2, dy, dbp);
+      else if (ties) hipLaunchKernelGGL((bn_bwd_apply_fast_kernel<GS_POOL, GS_NONE, true, 2, true>), dim3(nblk), dim3(256), 0, st, L, c1, c2, dy, dbp);
+      else hipLaunchKernelGGL((bn_bwd_apply_fast_kernel<GS_POOL, GS_NONE, false, 2, true>), dim3(nblk), dim3(256), 0, st, L, c1, c2, dy, dbp);
+    }
     else if (L.g0.kind == GS_DIRECT) { if (g1) ICS_BNF(GS_DIRECT, GS_DIRECT, false, 4); else ICS_BNF(GS_DIRECT, GS_NONE, false, 4); }
     else if (ties) { if (g1) ICS_BNF(GS_POOL, GS_DIRECT, true, 2); else ICS_BNF(GS_POOL, GS_NONE, true, 2); }
     else { if (g1) ICS_BNF(GS_POOL, GS_DIRECT, false, 2); else ICS_BNF(GS_POOL, GS_NONE, false, 2); }

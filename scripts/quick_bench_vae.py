@@ -17,10 +17,10 @@ ve.sync(); t0 = time.perf_counter()
 for _ in range(steps): ve.train_step_resident(False)
 ve.sync(); dt = (time.perf_counter() - t0) / steps
 print("ms/step %.3f  grids/s %.1f" % (dt * 1e3, B / dt))
-ve.profile_enable(True)
+ve.profile_enable(True); ue.profile_enable(True)
 for _ in range(2): ve.train_step_resident(False)
 ve.sync()
-rows = sorted(ve.profile_rows(), key=lambda r: -r["ms"])
+rows = sorted(list(ve.profile_rows()) + [dict(r, label="pm:" + r["label"]) for r in ue.profile_rows()], key=lambda r: -r["ms"])
 print("total profiled ms/step %.2f  launches/step %d" % (sum(r["ms"] for r in rows) / 2, sum(r["launches"] for r in rows) / 2))
 for r in rows:
     tf = r["flop"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0
