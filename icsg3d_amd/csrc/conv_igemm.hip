@@ -1302,9 +1302,11 @@ __global__ __launch_bounds__(256) void conv_thin_n_fwd_kernel(ConvGeom g, ConvSr
 //   B. out[m] = act(sum_tap T[tap][m + off(tap)] + b): 27 coalesced plane reads per voxel, zero padding by predicate.
 // Traffic (M = 1 M voxels, Cin = 32): 134 MB in + 113 MB out, then 113 MB in: ~0.08 ms.  Same sums, other order.
 typedef float tv4 __attribute__((ext_vector_type(4)));
-template <int CK>                                  // CK = Cin / 16
+template <int CK, bool AFF>                        // CK = Cin / 16; AFF: producer's BatchNorm affine + activation on load
 __global__ __launch_bounds__(256) void thin1_taps_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ wp,
-                                                         int Npad, int M, float* __restrict__ T) {
+                                                         int Npad, int M, float* __restrict__ T,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         float slope) {
   const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
   constexpr int C = CK * 16;
   tv4 wa[2][CK];                                   // A operand: w[tap = 16 tt + n][c = 16 kk + 4 g + s]
@@ -1316,12 +1318,24 @@ __global__ __launch_bounds__(256) void thin1_taps_kernel(const float* __restrict
       const int k4 = (tap * C + 16 * kk + 4 * g) >> 2;       // packed [K/4][Npad][4], column 0
       wa[tt][kk] = tap < 27 ? *reinterpret_cast<const tv4*>(wp + (size_t)k4 * Npad * 4) : tv4{0.f, 0.f, 0.f, 0.f};
     }
+  tv4 asc[CK], ash[CK];
+#pragma unroll
+  for (int kk = 0; kk < CK; ++kk) {
+    asc[kk] = AFF ? *reinterpret_cast<const tv4*>(scale + 16 * kk + 4 * g) : tv4{1.f, 1.f, 1.f, 1.f};
+    ash[kk] = AFF ? *reinterpret_cast<const tv4*>(shift + 16 * kk + 4 * g) : tv4{0.f, 0.f, 0.f, 0.f};
+  }
   const int ntiles = M >> 4, nw = gridDim.x * 4;
   for (int tile = blockIdx.x * 4 + (threadIdx.x >> 6); tile < ntiles; tile += nw) {
     const size_t m = (size_t)tile * 16 + n;
     tv4 xb[CK];
 #pragma unroll
-    for (int kk = 0; kk < CK; ++kk) xb[kk] = *reinterpret_cast<const tv4*>(x + m * ldx + 16 * kk + 4 * g);
+    for (int kk = 0; kk < CK; ++kk) {
+      xb[kk] = *reinterpret_cast<const tv4*>(x + m * ldx + 16 * kk + 4 * g);
+      if (AFF) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xb[kk][e] = act_apply(fmaf(xb[kk][e], asc[kk][e], ash[kk][e]), slope);
+      }
+    }
     tv4 acc[2] = {tv4{0.f, 0.f, 0.f, 0.f}, tv4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int kk = 0; kk < CK; ++kk)
@@ -1341,41 +1355,71 @@ __global__ __launch_bounds__(256) void thin1_taps_kernel(const float* __restrict
 }
 __global__ __launch_bounds__(256) void thin1_gather_kernel(const float* __restrict__ T, int B, int S, int lg, int M,
                                                            const float* __restrict__ bias, float slope,
-                                                           float* __restrict__ out, int ldo) {
+                                                           float* __restrict__ out, int ldo,
+                                                           float* __restrict__ stat_partial, int Npad) {
+  __shared__ float red[4];
   const int m = blockIdx.x * 256 + threadIdx.x;
-  if (m >= M) return;
-  const RowPos rp = decode_row(m, S, lg);
+  const bool mv = m < M;
+  const RowPos rp = decode_row(mv ? m : 0, S, lg);
   float a = 0.f;
 #pragma unroll
   for (int tap = 0; tap < 27; ++tap) {
     const int dz = tap / 9 - 1, dy = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
-    const bool inb = (unsigned)(rp.z + dz) < (unsigned)S && (unsigned)(rp.y + dy) < (unsigned)S &&
+    const bool inb = mv && (unsigned)(rp.z + dz) < (unsigned)S && (unsigned)(rp.y + dy) < (unsigned)S &&
                      (unsigned)(rp.x + dx) < (unsigned)S;
-    const float v = T[(size_t)tap * M + (inb ? m + (dz * S + dy) * S + dx : m)];
+    const float v = T[(size_t)tap * M + (inb ? m + (dz * S + dy) * S + dx : 0)];
     a += inb ? v : 0.f;
   }
   if (bias != nullptr) a += bias[0];
-  out[(size_t)m * ldo] = act_apply(a, slope);
+  a = mv ? act_apply(a, slope) : 0.f;
+  if (mv) out[(size_t)m * ldo] = a;
+  if (stat_partial == nullptr) return;
+  // block (count, mean, M2) of column 0: two passes inside the block, as conv_thin_n_fwd_kernel does
+  const int nvalid = min(256, M - (int)blockIdx.x * 256);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float v = a;
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  const float mu = (red[0] + red[1] + red[2] + red[3]) / (float)nvalid;
+  __syncthreads();
+  const float d = a - mu;
+  float q = mv ? d * d : 0.f;
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+  if (lane == 0) red[wave] = q;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const size_t nstat = gridDim.x;
+    float* sp = stat_partial + blockIdx.x;
+    sp[0] = (float)nvalid;
+    sp[(size_t)Npad * nstat] = mu;
+    sp[(size_t)2 * Npad * nstat] = red[0] + red[1] + red[2] + red[3];
+  }
 }
 static bool thin1_two_stage_ok(const ConvGeom& g, const ConvSrc& s0) {
   const int M = g.B << (3 * g.lgS);
-  return g.Cin % 16 == 0 && g.Cin <= 64 && M % 16 == 0 && s0.scale == nullptr && s0.act == ACT_NONE &&
+  return g.Cin % 16 == 0 && g.Cin <= 64 && M % 16 == 0 && (s0.scale != nullptr || s0.act == ACT_NONE) &&
          std::getenv("ICSG3D_NO_THIN1_2STAGE") == nullptr;
 }
 static int launch_thin1_two_stage(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, const float* wp, const float* bias,
-                                  float* out, int ldo, int pre_act, float* ws) {
+                                  float* out, int ldo, int pre_act, float* ws, float* stat_partial) {
   const int M = g.B << (3 * g.lgS);
   int nblk = (M / 16 + 3) / 4;
   if (nblk > 1024) nblk = 1024;
-  switch (g.Cin / 16) {
-    case 1: hipLaunchKernelGGL(thin1_taps_kernel<1>, dim3(nblk), dim3(256), 0, st, s0.p, s0.C, wp, g.Npad, M, ws); break;
-    case 2: hipLaunchKernelGGL(thin1_taps_kernel<2>, dim3(nblk), dim3(256), 0, st, s0.p, s0.C, wp, g.Npad, M, ws); break;
-    case 3: hipLaunchKernelGGL(thin1_taps_kernel<3>, dim3(nblk), dim3(256), 0, st, s0.p, s0.C, wp, g.Npad, M, ws); break;
-    default: hipLaunchKernelGGL(thin1_taps_kernel<4>, dim3(nblk), dim3(256), 0, st, s0.p, s0.C, wp, g.Npad, M, ws); break;
-  }
+  const bool aff = s0.scale != nullptr;
+  const float in_slope = act_slope_of(s0.act);
+#define ICS_T1T(CKV)                                                                                                   \
+  do {                                                                                                                 \
+    if (aff) hipLaunchKernelGGL((thin1_taps_kernel<CKV, true>), dim3(nblk), dim3(256), 0, st, s0.p, s0.C, wp, g.Npad, M, ws, \
+                                s0.scale, s0.shift, in_slope);                                                         \
+    else hipLaunchKernelGGL((thin1_taps_kernel<CKV, false>), dim3(nblk), dim3(256), 0, st, s0.p, s0.C, wp, g.Npad, M, ws,    \
+                            nullptr, nullptr, 1.f);                                                                    \
+  } while (0)
+  switch (g.Cin / 16) { case 1: ICS_T1T(1); break; case 2: ICS_T1T(2); break; case 3: ICS_T1T(3); break; default: ICS_T1T(4); break; }
+#undef ICS_T1T
   ICS_HIP(hipGetLastError());
   hipLaunchKernelGGL(thin1_gather_kernel, dim3((M + 255) / 256), dim3(256), 0, st, ws, g.B, g.S, g.lgS, M, bias,
-                     act_slope_of(pre_act), out, ldo);
+                     act_slope_of(pre_act), out, ldo, stat_partial, g.Npad);
   ICS_HIP(hipGetLastError());
   g_last_kernel_id = "thin1_taps_kernel + thin1_gather_kernel";
   return 0;
@@ -1386,10 +1430,9 @@ static int launch_thin_n_fwd(hipStream_t st, const ConvGeom& g, const ConvSrc& s
                              float* out, int ldo, int pre_act, float* stat_partial, int* rows_per_block,
                              int accumulate, float* ws = nullptr, size_t ws_floats = 0) {
   const int M = g.B << (3 * g.lgS);
-  if (g.Cout == 1 && stat_partial == nullptr && !accumulate && ws != nullptr && ws_floats >= (size_t)27 * M &&
-      thin1_two_stage_ok(g, s0)) {
+  if (g.Cout == 1 && !accumulate && ws != nullptr && ws_floats >= (size_t)27 * M && thin1_two_stage_ok(g, s0)) {
     if (rows_per_block) *rows_per_block = 256;
-    return launch_thin1_two_stage(st, g, s0, wp, bias, out, ldo, pre_act, ws);
+    return launch_thin1_two_stage(st, g, s0, wp, bias, out, ldo, pre_act, ws, stat_partial);
   }
   const int lgv = thin_n_lg_lpv(g), vpb = 256 >> lgv;
   const dim3 grid((M + vpb - 1) / vpb);
@@ -1473,7 +1516,83 @@ __global__ __launch_bounds__(256) void conv_thin_n_wgrad_kernel(ConvGeom g, Conv
   }
 }
 
+// Cout == 1 backward-weight on the matrix cores: dW[tap][c] = sum_w x'[w][c] dy[w - off(tap)] is a [Cin x M] x [M x 27]
+// product with K = all voxels.  v_mfma_f32_16x16x4_f32: A[c][k = voxel] = the (BatchNorm + activation applied) input, a
+// 64-byte row piece per lane group; B[k = voxel][tap] = the output gradient GATHERED at the tap's offset (dy is one float
+// per voxel: 4 MB, cache resident; out-of-grid positions are zero).  A wave keeps its [Cin x 27] accumulators over all its
+// 16-voxel tiles and writes one split.  (The stencil above, a thread per weight row looping over voxels: 0.23 ms for the
+// decoder_output layer at 0.3 TB/s.)
+template <int CK, bool AFF>
+__global__ __launch_bounds__(256) void thin1_wgrad_kernel(ConvGeom g, ConvSrc s0, const float* __restrict__ dy, int ldy,
+                                                          float* __restrict__ ws) {
+  const int lane = threadIdx.x & 63, n = lane & 15, gq = lane >> 4;
+  const int S = g.S, lg = g.lgS, M = g.B << (3 * lg);
+  constexpr int C = CK * 16;
+  const float slope = act_slope_of(s0.act);
+  float sc[CK], sh[CK];
+#pragma unroll
+  for (int ct = 0; ct < CK; ++ct) { sc[ct] = AFF ? s0.scale[16 * ct + n] : 1.f; sh[ct] = AFF ? s0.shift[16 * ct + n] : 0.f; }
+  int tdz[2], tdy[2], tdx[2], toff[2];
+  bool tv[2];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+    const int tap = 16 * tt + n;
+    tv[tt] = tap < 27;
+    const int tp = tv[tt] ? tap : 13;
+    tdz[tt] = tp / 9 - 1; tdy[tt] = (tp / 3) % 3 - 1; tdx[tt] = tp % 3 - 1;
+    toff[tt] = (tdz[tt] * S + tdy[tt]) * S + tdx[tt];
+  }
+  tv4 acc[CK][2];
+#pragma unroll
+  for (int ct = 0; ct < CK; ++ct) { acc[ct][0] = tv4{0.f, 0.f, 0.f, 0.f}; acc[ct][1] = tv4{0.f, 0.f, 0.f, 0.f}; }
+  const int ntiles = M >> 4, wave_g = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+  for (int tile = wave_g; tile < ntiles; tile += nw) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int w = tile * 16 + 4 * j + gq;                  // this lane group's voxel of the k-step
+      const int x = w & (S - 1), y = (w >> lg) & (S - 1), z = (w >> (2 * lg)) & (S - 1);
+      float bv[2];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const bool inb = tv[tt] && (unsigned)(z - tdz[tt]) < (unsigned)S && (unsigned)(y - tdy[tt]) < (unsigned)S &&
+                         (unsigned)(x - tdx[tt]) < (unsigned)S;
+        const float v = dy[(size_t)(inb ? w - toff[tt] : w) * ldy];
+        bv[tt] = inb ? v : 0.f;
+      }
+#pragma unroll
+      for (int ct = 0; ct < CK; ++ct) {
+        float a = s0.p[(size_t)w * s0.C + 16 * ct + n];
+        if (AFF) a = act_apply(fmaf(a, sc[ct], sh[ct]), slope);
+        acc[ct][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[0], acc[ct][0], 0, 0, 0);
+        acc[ct][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[1], acc[ct][1], 0, 0, 0);
+      }
+    }
+  }
+  // D[c local = 4 gq + r][tap local = n]  ->  ws[split][k = tap * C + c]
+  float* wsp = ws + (size_t)wave_g * 27 * C;
+#pragma unroll
+  for (int ct = 0; ct < CK; ++ct)
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int tap = 16 * tt + n;
+        if (tap < 27) wsp[tap * C + 16 * ct + 4 * gq + r] = acc[ct][tt][r];
+      }
+}
+static bool thin1_wgrad_ok(const ConvGeom& g, const ConvSrc& s0) {
+  const int M = g.B << (3 * g.lgS);
+  return g.Cout == 1 && g.Cin % 16 == 0 && g.Cin <= 64 && M % 16 == 0 && std::getenv("ICSG3D_NO_THIN1_2STAGE") == nullptr;
+}
+static int thin1_wgrad_blocks(const ConvGeom& g) {
+  const int M = g.B << (3 * g.lgS);
+  return std::max(1, std::min(512, (M / 16 + 3) / 4));     // x 4 waves = splits
+}
+
 static int thin_n_wgrad_splits(const ConvGeom& g) {
+  if (g.Cout == 1 && g.Cin % 16 == 0 && g.Cin <= 64 && ((g.B << (3 * g.lgS)) % 16) == 0)
+    return std::max(4 * thin1_wgrad_blocks(g), (int)std::max(1L, std::min(4096L, ((long)g.B << (3 * g.lgS)) / 128)));
+
   const long M = (long)g.B << (3 * g.lgS);
   // >= 4 resident blocks per CU, but at least 256 voxels per block
   return (int)std::max(1L, std::min(4096L, M / 128));
@@ -2651,6 +2770,22 @@ int launch_conv_wgrad(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int
     const int rows = (M + ns - 1) / ns;
     const int K = 27 * g.Cin;
     const bool aff = src[0].scale != nullptr;
+    if (thin1_wgrad_ok(g, src[0])) {
+      const int nb = thin1_wgrad_blocks(g);
+      if (phase != 2) {
+#define ICS_T1W(CKV)                                                                                                 \
+  do {                                                                                                               \
+    if (aff) hipLaunchKernelGGL((thin1_wgrad_kernel<CKV, true>), dim3(nb), dim3(256), 0, st, g, src[0], dy, ldy, workspace); \
+    else hipLaunchKernelGGL((thin1_wgrad_kernel<CKV, false>), dim3(nb), dim3(256), 0, st, g, src[0], dy, ldy, workspace);    \
+  } while (0)
+        switch (g.Cin / 16) { case 1: ICS_T1W(1); break; case 2: ICS_T1W(2); break; case 3: ICS_T1W(3); break; default: ICS_T1W(4); break; }
+#undef ICS_T1W
+        ICS_HIP(hipGetLastError());
+        g_last_kernel_id = "thin1_wgrad_kernel";
+      }
+      if (phase != 1) ICS_TRY(launch_reduce_splits(st, workspace, 4 * nb, n_el, g.Cout, dw, ldw, sub_rows, row_pitch, row_off));
+      return 0;
+    }
     if (phase != 2) {
 #define ICS_TNW(NOUT, AFFV, KPT, NAME)                                                                         \
   do {                                                                                                         \
