@@ -81,6 +81,7 @@ SIGNATURES = {
     "ics_net_get_optimizer_state": (C.c_int, [_H, _F, _F, C.c_size_t, C.POINTER(C.c_int)]),
     "ics_net_set_optimizer_state": (C.c_int, [_H, _F, _F, C.c_size_t, C.c_int]),
     "ics_net_profile_enable": (C.c_int, [_H, C.c_int]),
+    "ics_net_profile_filter": (C.c_int, [_H, C.c_char_p]),
     "ics_net_profile_count": (C.c_int, [_H, C.POINTER(C.c_int)]),
     "ics_net_profile_row": (C.c_int, [_H, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64),
                                       C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

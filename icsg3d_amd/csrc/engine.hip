@@ -51,6 +51,8 @@ struct Profiler {
   struct Row { std::string label; int64_t launches = 0; double ms = 0, flop = 0, bytes = 0; };
   struct Pending { int row; hipEvent_t a, b; std::string label; double flop, bytes; };
   bool on = false;
+  bool active = false;                  // the bracket being measured passed the filter
+  std::string filter;                   // non-empty: only launch sites whose label starts with it get events
   std::vector<Row> rows;
   std::map<std::string, int> index;
   std::vector<Pending> pending;
@@ -63,12 +65,15 @@ struct Profiler {
   // bracket appended at end() (conv_last_kernel_id(): the name rocprofv3 prints for the same launch).
   void begin(hipStream_t st, const std::string& label, double flop, double bytes) {
     if (!on) return;
+    active = filter.empty() || label.compare(0, filter.size(), filter) == 0;
+    if (!active) return;
     Pending p{-1, get(), get(), label, flop, bytes};
     (void)hipEventRecord(p.a, st);
     pending.push_back(p);
   }
   void end(hipStream_t st) {
-    if (!on) return;
+    if (!on || !active) return;
+    active = false;
     Pending& p = pending.back();
     (void)hipEventRecord(p.b, st);
     if (!p.label.empty() && p.label.back() == '|') p.label += conv_last_kernel_id();
@@ -1775,6 +1780,11 @@ int ics_net_profile_enable(ics_net* net, int on) {
   ICS_HIP(hipStreamSynchronize(net->n.st));
   net->n.prof.reset();
   net->n.prof.on = on != 0;
+  return 0;
+}
+int ics_net_profile_filter(ics_net* net, const char* prefix) {
+  ICS_CHECK(net, "null handle");
+  net->n.prof.filter = prefix ? prefix : "";
   return 0;
 }
 int ics_net_profile_count(ics_net* net, int* rows) {

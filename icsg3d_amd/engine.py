@@ -116,6 +116,10 @@ class _Net:
     def profile_enable(self, on=True):
         L.check(self._lib.ics_net_profile_enable(self._h, 1 if on else 0))
 
+    def profile_filter(self, prefix=""):
+        """events only around launch sites whose label starts with `prefix` ("" = all)"""
+        L.check(self._lib.ics_net_profile_filter(self._h, prefix.encode() if prefix else None))
+
     def profile_rows(self):
         n = C.c_int(0)
         L.check(self._lib.ics_net_profile_count(self._h, C.byref(n)))
