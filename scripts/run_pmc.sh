@@ -16,6 +16,6 @@ for P in "$P1" "$P2" "$P3" "$P4" "$P5"; do
   timeout 600 rocprofv3 --kernel-trace --pmc $P -f csv -d $OUT/p$i -o p$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary "$@" > $OUT/p$i.log 2>&1
   rm -f $OUT/p$i/*kernel_trace.csv $OUT/p$i/*.db
 done
-KSTATS=${KSTATS:-} python3 $GRAFT_REPO_ROOT/scripts/pmc_summary.py $OUT conv_wino64_kernel conv_up3_kernel conv_wino_kernel conv_wino_wgrad_kernel conv_fwd_kernel conv_wgrad_kernel conv_wgrad3_kernel conv_wgrad3s_kernel conv_thin_n bn_bwd pool27 head_kernel adam > $OUT/summary.txt 2>&1
+KSTATS=${KSTATS:-} python3 $GRAFT_REPO_ROOT/scripts/pmc_summary.py $OUT conv_wino64_kernel conv_up3_kernel conv_wino_kernel conv_wino_wgrad_kernel conv_fwd_kernel conv_wgrad_kernel conv_wgrad3_kernel conv_wgrad3s_kernel conv_thin_n thin1_ bn_bwd pool27 pool_fwd head_fused_kernel head_dgrad_kernel reduce_splits adam > $OUT/summary.txt 2>&1
 find $OUT -name "*counter_collection.csv" -size +8M -delete
 head -60 $OUT/summary.txt
