@@ -55,7 +55,8 @@ def default_run():
 @pytest.mark.parametrize("switch", ["ICSG3D_NO_REUSE", "ICSG3D_NO_WGRAD3", "ICSG3D_NO_FWD_SPLITK",
                                     "ICSG3D_NO_THIN_N", "ICSG3D_NO_UPSPLIT", "ICSG3D_NO_THIN_C", "ICSG3D_NO_BWD_FOLD",
                                     "ICSG3D_NO_WGRAD3S", "ICSG3D_SIDE_STREAM", "ICSG3D_NO_COND_FOLD", "ICSG3D_NO_WINO",
-                                    "ICSG3D_NO_WINO64", "ICSG3D_NO_UP3", "ICSG3D_NO_WINO_WGRAD"])
+                                    "ICSG3D_NO_WINO64", "ICSG3D_NO_UP3", "ICSG3D_NO_WINO_WGRAD", "ICSG3D_NO_FUSED_HEAD",
+                                    "ICSG3D_NO_FAST_BNBWD", "ICSG3D_NO_THIN1_2STAGE"])
 def test_fallback_path_matches_default(default_run, switch):
     alt = _run({switch: "1"})
     for k, ref in default_run.items():
