@@ -56,7 +56,7 @@ __global__ __launch_bounds__(576, 4) void conv_up3_kernel(const float* __restric
                                                           float* __restrict__ y, int ldo, float pre_slope, int accumulate,
                                                           float* __restrict__ stat_partial, int Npad, int Sl, int Cin,
                                                           int Cout) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * BUF];    // 40 320 B; the epilogue reuses it (36 KB per pass)
+  __shared__ __attribute__((aligned(16))) float lds[9 * 16 * 80];   // 46 080 B: two buffers (40 320 B); the epilogue's [9][16][80]
   __shared__ unsigned park[3 * 576];
   __shared__ __attribute__((aligned(16))) float aff[AFF ? 2048 : 4];
   __shared__ float red[9 * 64];
@@ -235,13 +235,16 @@ __global__ __launch_bounds__(576, 4) void conv_up3_kernel(const float* __restric
   // lane l holds P[voxel = 4 kq + i][n = l & 15] for its (fz, fy) and fx = 0..2.  fx -> dx in registers (dx0 = P0 + P1,
   // dx1 = P1 + P2); fy -> dy and fz -> dz across the waves through LDS: output (dz, dy, dx) = sum over fz in {dz, dz+1},
   // fy in {dy, dy+1}.
-  float* part = lds;                             // [9 w][16 slots = (jl * 4 + i) * 2 + dx][64 lanes]  (36 KB)
+  // [9 w][16 slots = (i * 2 + dx) * 2 + jl][64 lanes + 16]: slot pitch 80 with jl as the lowest slot bit, so that the
+  // eight lanes of a 16-byte read group (cq, jl) hit eight different bank groups (conv_wino64.hip has the arithmetic)
+  constexpr int PS = 80, PW = 16 * PS;
+  float* part = lds;
   const int cq = tid & 3, jl = (tid >> 2) & 1, o = (tid >> 3) & 3, tile = (tid >> 5) & 15;
   const int dyo = o >> 1, dxo = o & 1;
   const int ttz = tile >> 3, tty = (tile >> 2) & 1, ttx = tile & 3;
   const int vz = 2 * (oz + ttz), vy = 2 * (oy + tty) + dyo, vx = 2 * (ox + ttx) + dxo;
   const size_t vox0 = (((size_t)b * S + vz) * S + vy) * S + vx;
-  const int slot_rd = ((jl * 4 + ttx) * 2 + dxo) * 64 + (tile >> 2) * 16 + cq * 4;
+  const int slot_rd = ((ttx * 2 + dxo) * 2 + jl) * PS + (tile >> 2) * 16 + cq * 4;
   uf4 val[2][2];
   uf4 csum[2];
 #pragma unroll
@@ -252,8 +255,8 @@ __global__ __launch_bounds__(576, 4) void conv_up3_kernel(const float* __restric
       const int j = pass * 2 + jj;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        part[(w * 16 + (jj * 4 + i) * 2 + 0) * 64 + lane] = acc[0][j][i] + acc[1][j][i];
-        part[(w * 16 + (jj * 4 + i) * 2 + 1) * 64 + lane] = acc[1][j][i] + acc[2][j][i];
+        part[w * PW + ((i * 2 + 0) * 2 + jj) * PS + lane] = acc[0][j][i] + acc[1][j][i];
+        part[w * PW + ((i * 2 + 1) * 2 + jj) * PS + lane] = acc[1][j][i] + acc[2][j][i];
       }
     }
     __syncthreads();
@@ -262,8 +265,8 @@ __global__ __launch_bounds__(576, 4) void conv_up3_kernel(const float* __restric
       uf4 r[3];                                  // sum over fy in {dy, dy+1} for fz = 0, 1, 2
 #pragma unroll
       for (int z = 0; z < 3; ++z)
-        r[z] = *reinterpret_cast<const uf4*>(&part[(z * 3 + dyo) * 1024 + slot_rd]) +
-               *reinterpret_cast<const uf4*>(&part[(z * 3 + dyo + 1) * 1024 + slot_rd]);
+        r[z] = *reinterpret_cast<const uf4*>(&part[(z * 3 + dyo) * PW + slot_rd]) +
+               *reinterpret_cast<const uf4*>(&part[(z * 3 + dyo + 1) * PW + slot_rd]);
       uf4 bv = {0.f, 0.f, 0.f, 0.f};
       if (bias != nullptr) bv = *reinterpret_cast<const uf4*>(bias + nn);
       const size_t o0 = vox0 * ldo + nn;

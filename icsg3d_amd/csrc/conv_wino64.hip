@@ -380,15 +380,20 @@ __global__ __launch_bounds__(512) void conv_wino64_kernel(const float* __restric
 #endif
   // ---------------------------------------------------------------- epilogue, two passes of two column blocks each
   // lane l holds D[tile = 4 kq + i][n = l & 15]: tile = (tz, ty, tx) with (tz, ty) = kq, tx = i
-  float* part = lds;                             // [8 w][32 slots = (jl * 4 + i) * 4 + dy * 2 + dx][64 lanes]  (64 KB)
-  float* red = lds + 16384;                      // 2 x [8 w][64]
+  // [8 w][32 slots = ((i * 4 + dy * 2 + dx) * 2 + jl)][64 lanes + 16]: the final stage reads 16 bytes per lane with
+  // lane bits (cq, jl | o | tile) -- with a 64-float slot pitch and jl in a high slot bit every lane of a wave landed in
+  // the same four 16-byte bank groups (half the LDS bandwidth); pitch 80 with jl as the lowest slot bit gives the eight
+  // lanes of a group eight different ones
+  constexpr int PS = 80, PW = 32 * PS;           // floats per slot / per wave: 8 x 2560 x 4 B = 80 KB
+  float* part = lds;
+  float* red = lds + 8 * PW;                     // 2 x [8 w][64]
   // final-stage task of this thread: cq = tid & 3 (channel quad of a column block), jl = (tid >> 2) & 1, o = (tid >> 3) & 3
   // (= dy * 2 + dx), tile = tid >> 5
   const int cq = tid & 3, jl = (tid >> 2) & 1, o = (tid >> 3) & 3, tile = tid >> 5;
   const int ttz = tile >> 3, tty = (tile >> 2) & 1, ttx = tile & 3;
   const int vz = oz + 2 * ttz, vy = oy + 2 * tty + (o >> 1), vx = ox + 2 * ttx + (o & 1);
   const size_t vox0 = (((size_t)b * S + vz) * S + vy) * S + vx;
-  const int slot_rd = ((jl * 4 + ttx) * 4 + o) * 64 + (tile >> 2) * 16 + cq * 4;
+  const int slot_rd = ((ttx * 4 + o) * 2 + jl) * PS + (tile >> 2) * 16 + cq * 4;
   vf4 val[2][2];
   vf4 f1[2], f2s[2];
 #ifndef ICS_W64_EPI_PREFETCH
@@ -435,8 +440,8 @@ __global__ __launch_bounds__(512) void conv_wino64_kernel(const float* __restric
           // rows of A^T: the wave with fy 0,1 gives dy0 += q0 + q1, dy1 += q1; the one with fy 2,3: dy0 += q0, dy1 -= q0 + q1
           const float d0 = fyh ? qv[0][dx] : qv[0][dx] + qv[1][dx];
           const float d1 = fyh ? -qv[0][dx] - qv[1][dx] : qv[1][dx];
-          part[(w * 32 + (jj * 4 + i) * 4 + 0 + dx) * 64 + lane] = d0;
-          part[(w * 32 + (jj * 4 + i) * 4 + 2 + dx) * 64 + lane] = d1;
+          part[w * PW + ((i * 4 + 0 + dx) * 2 + jj) * PS + lane] = d0;
+          part[w * PW + ((i * 4 + 2 + dx) * 2 + jj) * PS + lane] = d1;
         }
       }
     }
@@ -446,8 +451,8 @@ __global__ __launch_bounds__(512) void conv_wino64_kernel(const float* __restric
     vf4 p[4];
 #pragma unroll
     for (int z = 0; z < 4; ++z)
-      p[z] = *reinterpret_cast<const vf4*>(&part[(2 * z) * 2048 + slot_rd]) +
-             *reinterpret_cast<const vf4*>(&part[(2 * z + 1) * 2048 + slot_rd]);
+      p[z] = *reinterpret_cast<const vf4*>(&part[(2 * z) * PW + slot_rd]) +
+             *reinterpret_cast<const vf4*>(&part[(2 * z + 1) * PW + slot_rd]);
     const size_t o0 = vox0 * ldo + nn;
     const size_t o1 = o0 + (size_t)S * S * ldo;
 #if ICS_W64_EPI_PREFETCH
