@@ -441,8 +441,14 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(const float* __res
   const int nbx = S >> 3, nby = S >> 2, nbz = S >> 2;
 
   // ---- staging.  x: thread t < 480 owns (hy, hx, channel quad q): six raw z values -> eight combined planes.
-  const int cmb = tid < 480 ? tid : 479;
-  const int q = cmb & 7, hx = (cmb >> 3) % GX, hy = (cmb >> 3) / GX;
+  // thread -> (position, channel quad): a 32-lane store group holds FOUR quads x eight positions.  The channel pitch is
+  // = 2 mod 32 floats, so quad q lands on bank 8 q + position: with eight quads per group (q = lane & 7, the first
+  // version) q and q + 4 collided on every staging store -- 16 % of the kernel's LDS cycles were bank conflicts (PMC).
+  const int sq = (tid & 3) | (((tid >> 5) & 1) << 2);                    // channel quad 0..7
+  const int spos = (tid >> 6) * 8 + ((tid >> 2) & 7);                    // 0..63; the halo has 60 positions
+  const bool sact = spos < GY * GX;
+  const int cmb = sact ? spos : GY * GX - 1;
+  const int q = sq, hx = cmb % GX, hy = cmb / GX;
   wf4 xs[6], ys[2];
   // Buffer loads (one 32-bit per-lane byte offset, everything block-dependent in the scalar offset operand): the halo
   // positions are CLAMPED into the grid per block -- a handful of VALU per block -- and zeroed at store time.  The
@@ -453,8 +459,8 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(const float* __res
   unsigned yrel[2];                                // bytes, relative to the block origin
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int v = (tid + i * 512) >> 3;                                    // 0..127 = (vz, vy, vx)
-    yrel[i] = (unsigned)((((v >> 5) * S + ((v >> 3) & 3)) * S + (v & 7)) * ldy + co0 + (tid & 7) * 4) * 4u;
+    const int v = spos + i * 64;                                           // 0..127 = (vz, vy, vx)
+    yrel[i] = (unsigned)((((v >> 5) * S + ((v >> 3) & 3)) * S + (v & 7)) * ldy + co0 + sq * 4) * 4u;
   }
   const int xw = (q * 4) * GXP + hy * GX + hx;                             // LDS write base (floats): + j*GXP + plane*60
   bool okyx_cur = true;                            // this lane's (y, x) halo position lies inside the grid (current block)
@@ -502,7 +508,7 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(const float* __res
       for (int hz = 0; hz < 6; ++hz)
         if (!(okyx_cur && ((okz >> hz) & 1))) xs[hz] = wf4{0.f, 0.f, 0.f, 0.f};
     }
-    if (tid < 480) {
+    if (sact) {
 #pragma unroll
       for (int tz = 0; tz < 2; ++tz) {
         const wf4 d0 = xs[2 * tz], d1 = xs[2 * tz + 1], d2 = xs[2 * tz + 2], d3 = xs[2 * tz + 3];
@@ -516,7 +522,7 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(const float* __res
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int o = 2 * GXF + bo * GYF + ((tid & 7) * 4) * GYP + ((tid + i * 512) >> 3);
+      const int o = 2 * GXF + bo * GYF + (sq * 4) * GYP + spos + i * 64;
       lds[o] = ys[i].x; lds[o + GYP] = ys[i].y; lds[o + 2 * GYP] = ys[i].z; lds[o + 3 * GYP] = ys[i].w;
     }
   };
