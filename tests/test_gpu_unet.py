@@ -110,3 +110,22 @@ def test_unet_step_is_deterministic():
     assert np.array_equal(m1, m2)
     for k in p1:
         assert np.array_equal(p1[k], p2[k]), k
+
+
+def test_profile_filter_restricts_launch_sites():
+    """ics_net_profile_filter (bench.py's timed region): events only around the launch sites whose label starts with the
+    prefix; an empty prefix brackets every launch again."""
+    orc, eng, X, lab = _setup(2, 16, 1, "tf_cpu")
+    eng.train_step(X, lab)
+    eng.profile_filter("conv_wgrad:")
+    eng.profile_enable(True)
+    eng.train_step(X, lab)
+    rows = eng.profile_rows()
+    assert rows and all(r["label"].startswith("conv_wgrad:") for r in rows)
+    assert sum(r["launches"] for r in rows) >= 14          # one per conv layer at least
+    eng.profile_filter("")
+    eng.profile_enable(True)
+    eng.train_step(X, lab)
+    labels = {r["label"].split("|")[0].split(":")[0] for r in eng.profile_rows()}
+    eng.profile_enable(False)
+    assert {"conv_fwd", "conv_wgrad", "conv_dgrad", "bn_act_bwd", "adam"} <= labels
