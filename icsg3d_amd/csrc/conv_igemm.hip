@@ -11,6 +11,10 @@
 // k group (lane half h supplies k = 4h..4h+3), which only reorders the fp32 summation.
 #include "common.h"
 
+#ifndef ICS_GEMM_DEEP
+#define ICS_GEMM_DEEP 1      // 1: chunks are requested TWO ahead (a second register set): these GEMMs stream both operands
+#endif                       //    from HBM with no reuse in L2, one chunk of prefetch left the loads exposed
+
 #include <algorithm>
 #include <type_traits>
 #include <cstdlib>
@@ -634,6 +638,38 @@ __global__ __launch_bounds__(256, FOLD ? 2 : ((REUSE && PAR) ? 3 : 1)) void conv
     store_b(cb & 1);
     store_a_chunk();
     __syncthreads();
+#if ICS_GEMM_DEEP
+    if (!AFF && TM * TN >= 4) {                  // 128-row tiles only: on the 64 x 64 tiles the registers cost an occupancy step (+4 %)
+      // second register set; chunk c + 1 is in (ra4, rb) when iteration c starts, chunk c + 2 is requested into (ra4b, rbb)
+      v4f ra4b[RA], rbb[NB];
+      auto loadb_set = [&](int c) {
+        const char* wrow = reinterpret_cast<const char*>(wp) + (size_t)(c * 8) * (size_t)g.Npad * 16;
+#pragma unroll
+        for (int r = 0; r < NB; ++r) rbb[r] = *reinterpret_cast<const v4f*>(wrow + bofs[r]);
+        const int ci0 = c << 5;
+        const bool first = ci0 < s0.C;
+        const char* sp = reinterpret_cast<const char*>(first ? s0.p : s1.p) + (size_t)(first ? ci0 : ci0 - s0.C) * 4;
+#pragma unroll
+        for (int r = 0; r < RA; ++r) ra4b[r] = *reinterpret_cast<const v4f*>(sp + (first ? rowG0[r] : rowG1[r]));
+      };
+      if (cb + 1 < ce) load_chunk_gemm(cb + 1);
+      for (int c = cb; c + 1 < ce; ++c) {
+        if (c + 2 < ce) loadb_set(c + 2);
+        compute_g(c & 1);
+        store_b((c + 1) & 1);
+        __syncthreads();
+        store_a_chunk();
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < RA; ++r) ra4[r] = ra4b[r];
+#pragma unroll
+        for (int r = 0; r < NB; ++r) rb[r] = rbb[r];
+      }
+      compute_g((ce - 1) & 1);
+      __syncthreads();
+    } else
+#endif
+    {
     for (int c = cb; c + 1 < ce; ++c) {
       load_chunk_gemm(c + 1);
       compute_g(c & 1);
@@ -644,6 +680,7 @@ __global__ __launch_bounds__(256, FOLD ? 2 : ((REUSE && PAR) ? 3 : 1)) void conv
     }
     compute_g((ce - 1) & 1);
     __syncthreads();
+    }
   } else if (cb < ce) {
   load_chunk(cb);
   store_b(cb & 1);
@@ -2165,6 +2202,40 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvGeom g, ConvSrc s0,
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
   };
+#if ICS_GEMM_DEEP
+  if (gemm && VEC && TM * TN >= 4) {
+    // two chunks ahead (a second, raw register set; the affine is applied when a set rotates into (ra, rd)): both
+    // operands stream from HBM with no reuse, one chunk of prefetch left the loads exposed (see conv_fwd_kernel)
+    v4f ra2[APASS], rd2[DPASS];
+    auto load2 = [&](int c) {
+      const int mbase = m_begin + (c << 5);
+      const char* abase = reinterpret_cast<const char*>(sp) + (size_t)mbase * (size_t)sC * 4;
+      const char* dbase = reinterpret_cast<const char*>(dy) + (size_t)mbase * (size_t)ldy * 4;
+#pragma unroll
+      for (int p = 0; p < APASS; ++p) ra2[p] = *reinterpret_cast<const v4f*>(abase + aoffg[p]);
+#pragma unroll
+      for (int p = 0; p < DPASS; ++p) rd2[p] = *reinterpret_cast<const v4f*>(dbase + doffg[p]);
+    };
+    auto rotate = [&]() {
+#pragma unroll
+      for (int p = 0; p < APASS; ++p) {
+        v4f v = ra2[p];
+        if (AFF) v = noact_g ? affine_only_or_act4<true>(v, sc, sh, slope) : affine_only_or_act4<false>(v, sc, sh, slope);
+        ra[p] = v;
+      }
+#pragma unroll
+      for (int p = 0; p < DPASS; ++p) rd[p] = rd2[p];
+    };
+    if (nchunks > 1) { load2(1); }
+    for (int c = 0; c + 1 < nchunks; ++c) {
+      rotate();                                  // chunk c + 1
+      if (c + 2 < nchunks) load2(c + 2);
+      compute(c & 1);
+      store_chunk((c + 1) & 1);
+      __syncthreads();
+    }
+  } else
+#endif
   if (gemm) {
     for (int c = 0; c + 1 < nchunks; ++c) {
       if (noact_g) load_chunk_gemm(c + 1, std::true_type{}); else load_chunk_gemm(c + 1, std::false_type{});
