@@ -83,3 +83,25 @@ def test_conv_backward(case, relerr, monkeypatch):
             monkeypatch.setenv("ICSG3D_NO_WINO64", "1")
             dx3, _ = E.conv3d_backward(x, w, dy)
             assert relerr(dx3, dx_ref) <= TOL and not np.array_equal(dx3, dx)
+
+
+def test_pointwise_gemm_large_m_matches_numpy():
+    """taps = 1 over 65 536 rows: the plain-GEMM loaders with 128 x 128 tiles and operands requested two chunks ahead
+    (the coarse-grid GEMMs of the up-split backward at the bench's batch; smaller problems pick 64 x 64 tiles and never
+    reach that loop).  Forward, backward-data and backward-weight against fp64 numpy."""
+    from icsg3d_amd import engine as E
+    rng = np.random.default_rng(11)
+    B, S, Cin, Cout = 2, 32, 128, 256                       # forward K = 128 (4 chunks), backward-data K = 256 (8), both 128-wide N tiles
+    x = rng.standard_normal((B, S, S, S, Cin)).astype(np.float32)
+    w = (rng.standard_normal((1, 1, 1, Cin, Cout)) / np.sqrt(Cin)).astype(np.float32)
+    dy = rng.standard_normal((B, S, S, S, Cout)).astype(np.float32)
+    y = E.conv3d_forward(x, w)
+    X = x.reshape(-1, Cin).astype(np.float64)
+    W = w.reshape(Cin, Cout).astype(np.float64)
+    DY = dy.reshape(-1, Cout).astype(np.float64)
+    ref = X @ W
+    assert np.abs(y.reshape(-1, Cout) - ref).max() <= 1e-5 * np.abs(ref).max()
+    dx, dw = E.conv3d_backward(x, w, dy)
+    rdx, rdw = DY @ W.T, X.T @ DY
+    assert np.abs(dx.reshape(-1, Cin) - rdx).max() <= 1e-5 * np.abs(rdx).max()
+    assert np.abs(dw.reshape(Cin, Cout) - rdw).max() <= 2e-5 * np.abs(rdw).max()
