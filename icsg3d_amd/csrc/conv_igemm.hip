@@ -11,6 +11,9 @@
 // k group (lane half h supplies k = 4h..4h+3), which only reorders the fp32 summation.
 #include "common.h"
 
+#ifndef ICS_GEMM_DEEP_MIN
+#define ICS_GEMM_DEEP_MIN 3  // accumulator tiles per wave from which the backward-weight GEMM prefetches two chunks ahead
+#endif
 #ifndef ICS_GEMM_DEEP
 #define ICS_GEMM_DEEP 1      // 1: chunks are requested TWO ahead (a second register set): these GEMMs stream both operands
 #endif                       //    from HBM with no reuse in L2, one chunk of prefetch left the loads exposed
@@ -2203,7 +2206,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvGeom g, ConvSrc s0,
     }
   };
 #if ICS_GEMM_DEEP
-  if (gemm && VEC && TM * TN >= 4) {
+  if (gemm && VEC && TM * TN >= ICS_GEMM_DEEP_MIN) {
     // two chunks ahead (a second, raw register set; the affine is applied when a set rotates into (ra, rd)): both
     // operands stream from HBM with no reuse, one chunk of prefetch left the loads exposed (see conv_fwd_kernel)
     v4f ra2[APASS], rd2[DPASS];
