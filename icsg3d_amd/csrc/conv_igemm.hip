@@ -3215,9 +3215,10 @@ __device__ __forceinline__ void pack_up3_pair(size_t t, const float* __restrict_
   for (int fy = 0; fy < 3; ++fy)
 #pragma unroll
     for (int fx = 0; fx < 3; ++fx) {
-      d[(0 * 9 + fy * 3 + fx) * 256] = gy[0][fy][fx];
-      d[(1 * 9 + fy * 3 + fx) * 256] = gy[0][fy][fx] + gy[1][fy][fx] + gy[2][fy][fx];
-      d[(2 * 9 + fy * 3 + fx) * 256] = gy[2][fy][fx];
+      const float sgn = fy == 1 ? -1.f : 1.f;      // conv_up3.hip builds -r1 for the fy = 1 frequencies (one fma per column)
+      d[(0 * 9 + fy * 3 + fx) * 256] = sgn * gy[0][fy][fx];
+      d[(1 * 9 + fy * 3 + fx) * 256] = sgn * (gy[0][fy][fx] + gy[1][fy][fx] + gy[2][fy][fx]);
+      d[(2 * 9 + fy * 3 + fx) * 256] = sgn * gy[2][fy][fx];
     }
 }
 __global__ void pack_up3_kernel(const float* __restrict__ w, int Cin_total, int Cout, int c_off, int Cu,

@@ -151,7 +151,9 @@ __global__ __launch_bounds__(576, 4) void conv_up3_kernel(const float* __restric
 
   // ---- per-lane read geometry: voxel m = (tz, ty, tx); rows of the wave's fy: D0 = r0 - r1, D1 = r1, D2 = r2 - r1
   const int tz = m >> 3, ty = (m >> 2) & 1, tx = m & 3;
-  const float sa = fy == 1 ? 0.f : 1.f, sb = fy == 1 ? 1.f : -1.f;        // t = sa * qa + sb * qb
+  // t = sa * qa - qb: ONE fma per column.  For fy = 1 that is -r1 instead of r1: the packed weights of the fy = 1
+  // frequencies carry the opposite sign (pack_up3_pair), the products are unchanged
+  const float sa = fy == 1 ? 0.f : 1.f;
   const int R0 = (tz * 3 + fz) * PP + ty * RP + tx * VX + kq;
   int Ra = R0 + (fy == 2 ? 2 : 0) * RP, Rb = R0 + RP;
 
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(576, 4) void conv_up3_kernel(const float* __restric
 #pragma unroll
   for (int g = 0; g < 3; ++g) {
     rd(0, g);
-    tn[g] = fmaf(sa, qa, sb * qb);
+    tn[g] = fmaf(sa, qa, -qb);
   }
   xform();
   rd(1, 0);                                      // column 0 of sub-step 1
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(576, 4) void conv_up3_kernel(const float* __restric
       gs = gs < nsub ? gs : nsub - 1;
 #pragma unroll
       for (int g = 0; g < 3; ++g) {
-        tn[g] = fmaf(sa, qa, sb * qb);           // column g of sub-step s+1, read one column ago
+        tn[g] = fmaf(sa, qa, -qb);           // column g of sub-step s+1, read one column ago
         if (ST && s == 6 && g == 2) {            // the next chunk must be visible before its first column is read
           hstore(nxt, cn);
           __syncthreads();
