@@ -1,11 +1,11 @@
-// EXPERIMENT, not built (round 3): conv_up3.hip as TWELVE waves (three per SIMD), each owning three "triples"
-// ((fz, fy) pair, column block) of three fx, with the weights re-laid out as [36 triples][3 fx][4 k][16 n] (the matching
-// change of pack_up3_pair is in the commit message of this file).  Motivation: the shipped kernel's nine waves sit
-// 3 + 2 + 2 + 2 on the SIMDs; a variant in which the three waves of SIMD 0 skipped one column block ran 15 % faster.
-// Result on MI355X (ms per U-Net step, c17.up / c15.up / c13.up): shipped 1.402 / 0.653 / 0.327, this file 1.361 / 0.628 /
-// 0.314 (-3 %): the balanced MFMA load is paid for with two operand sets per wave and three MFMAs per column instead of
-// four.  A third variant (eight waves owning a pair each, the ninth pair's four column blocks given to waves 0..3 under
-// wave-uniform branches) measured 1.387 / 0.656 / 0.359.  Neither adopted.
+// EXPERIMENT, not built (round 3): conv_up3.hip as twelve waves (three per SIMD) x 32 low-res voxels per workgroup:
+// every wave owns two column blocks of one (fz, fy) pair and one of another, for both 16-voxel halves (18 accumulators),
+// original weight layout.  Correct (tests/test_gpu_conv.py, test_gpu_switches.py).  ms per U-Net step, c17.up / c15.up /
+// c13.up: shipped nine-wave kernel 1.362 / 0.634 / 0.318, this file 1.377 / 0.645 / 0.338.  Three more layouts measured the
+// same +-1 %: twelve waves x 16 voxels with re-laid-out weights (1.361), nine waves x 32 voxels (1.394), eight waves +
+// the ninth pair split over four of them (1.387) -- although scripts/up3_timeline.py shows the shipped main loop running
+// at the pace of the three waves that share SIMD 0.  The in-loop spills of this file (168 registers at three waves per
+// SIMD: the staged rows go through scratch) are part of the reason; the rest is not understood.
 // 3x3x3 "same" convolution over a nearest-upsampled input with 27 instead of 64 multiplies per low-res voxel
 // (gfx950 / MI355X only) -- the upsampled channels of the U-Net's [skip | UpSampling3D(x)] convolutions
 // (/root/reference/unet/unet.py:309-336) and the VAE decoder's upsampled layers (vae/lattice_vae.py:211-217).
@@ -20,18 +20,16 @@
 // structure as the Winograd kernels (conv_wino64.hip) with 3 instead of 4 points per axis and tiles one low-res voxel
 // apart.  Zero padding of the fine grid is zero padding of the low-res grid.
 //
-// One workgroup = 16 low-res voxels (2x2x4: the same 4x4x8 block of fine outputs as conv_wino64.hip) x 64 output
-// channels x 27 frequencies on v_mfma_f32_16x16x4_f32 (lane l: A[voxel l & 15][k = l >> 4]).  TWELVE waves, three per
-// SIMD: the 27 frequencies x 4 column blocks are 36 "triples" (fz, fy, column block) of three fx each, and wave w owns
-// the triples 3 w, 3 w + 1, 3 w + 2 -- nine accumulators of 4 registers.  (The first version gave each of nine waves one
-// (fz, fy) with all four column blocks: 3 + 2 + 2 + 2 waves on the four SIMDs, i.e. 36 MFMAs per sub-step on SIMD 0
-// against 24 on the others -- a variant in which those three waves skipped a column block ran 15 % faster, which is what
-// this layout collects: 27 per SIMD.)  A wave's triples span at most two (fz, fy) pairs, so it builds two operand sets
-// (A = the pair of its first triple, B = of its last; equal for every fourth wave) and the middle triple selects one.
-// Staging: thread t < 384 owns (tile z, y, x, channel quad) of the halo [4][4][6] x 32 channels: three z rows in, the
-// producer's BatchNorm affine + activation, zero padding, the z rows of B, three planes out.  LDS: voxel pitch 34
-// floats, row pitch 208, plane pitch 840 (conflict-free ds_read_b32 for every (fz, row, column, sub-step): checked
-// exhaustively).  Weights [Cout/64][Cu/4][36 triples][3 fx][4 k][16 n]: a wave's sub-step is 2304 contiguous bytes.
+// One workgroup = 32 low-res voxels (2x4x4: a 4x8x8 block of fine outputs) x 64 output channels x 27 frequencies on
+// v_mfma_f32_16x16x4_f32 (lane l: A[voxel l & 15][k = l >> 4]), TWELVE waves, three per SIMD.  The 27 frequencies x 4
+// column blocks are 36 triples ((fz, fy) pair, column block) of three fx; every wave owns three triples -- two column
+// blocks of one pair and one of another -- for both 16-voxel halves of the block: 18 accumulators of 4 registers, each
+// weight load feeding two MFMAs per half.  The first version (nine waves, one pair x four column blocks x 16 voxels each)
+// sat 3 + 2 + 2 + 2 on the SIMDs: its main loop ran at the pace of SIMD 0's 36 MFMAs per sub-step (scripts/up3_timeline.py).
+// Staging: thread t < 576 owns (hy, hx, tile z, channel quad) of the halo [4][6][6] x 32 channels: three z rows in, the
+// producer's BatchNorm affine + activation, zero padding, the z rows of B, three planes out.  LDS: voxel pitch 34 floats,
+// row pitch 208, plane pitch 1256 (conflict-free ds_read_b32 for every (fz, row, column, sub-step): the pattern of the
+// 16-voxel layout, the second half is a constant offset of two rows).  Weights [Cout/64][Cu/4][27 f][4 k][16 n][4 column blocks].
 #include "common.h"
 
 #include <type_traits>
@@ -45,8 +43,8 @@ typedef float uf2 __attribute__((ext_vector_type(2)));
 
 namespace {
 constexpr int KC = 32;                                   // input channels per LDS chunk
-constexpr int VX = 34, RP = 208, PP = 840, BUF = 6 * PP; // floats; one buffer = 20 160 B
-constexpr int kRows = 128;                               // fine voxels per workgroup
+constexpr int VX = 34, RP = 208, PP = 1256, BUF = 6 * PP; // floats; one buffer = 30 144 B
+constexpr int kRows = 256;                               // fine voxels per workgroup
 
 __device__ __forceinline__ float uact(float v, float slope) { return fmaxf(v, v * slope); }
 __host__ __device__ __forceinline__ float uslope(int act) { return act == ACT_RELU ? 0.f : (act == ACT_LRELU ? kLeaky : 1.f); }
@@ -65,46 +63,45 @@ __global__ __launch_bounds__(768) void conv_up3_kernel(const float* __restrict__
                                                           float* __restrict__ y, int ldo, float pre_slope, int accumulate,
                                                           float* __restrict__ stat_partial, int Npad, int Sl, int Cin,
                                                           int Cout) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * BUF];    // 40 320 B; the epilogue reuses it (36 KB per pass)
+  __shared__ __attribute__((aligned(16))) float lds[9 * 32 * 80];   // 92 160 B: two buffers (60 288 B); the epilogue's [9][32][80]
   __shared__ unsigned park[3 * 768];
   __shared__ __attribute__((aligned(16))) float aff[AFF ? 2048 : 4];
   __shared__ float red[9 * 64];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // this wave: triples T = 3 w + i, i = 0..2; triple T = ((fz, fy) pair T >> 2, column block T & 3), all three fx
-  const int cA = (3 * w) >> 2, cB = (3 * w + 2) >> 2;            // (fz, fy) pairs of the first / last triple
-  const bool mid_is_b = ((3 * w + 1) >> 2) == cB;                // the middle triple's pair (uniform)
-  const int fzA = cA / 3, fyA = cA - 3 * fzA, fzB = cB / 3, fyB = cB - 3 * fzB;
+  // this wave: two column blocks (cbA, cbA + 1) of the (fz, fy) pair pA and one column block cbB of the pair pB, all
+  // three fx each -- 36 (pair, column block) triples over 12 waves.  Pairs 0..5 give column blocks 0, 1 to wave p and
+  // 2 / 3 as the single block of waves (p + 5) % 6 / p + 6; pairs 6..8 give (0, 1) and (2, 3) to waves 6 + 2 j, 7 + 2 j.
+  const int pA = w < 6 ? w : 6 + ((w - 6) >> 1), cbA = w < 6 ? 0 : 2 * ((w - 6) & 1);
+  const int pB = w < 6 ? (w + 1) % 6 : w - 6, cbB = w < 6 ? 2 : 3;
+  const int fzA = pA / 3, fyA = pA - 3 * fzA, fzB = pB / 3, fyB = pB - 3 * fzB;
   const int m = lane & 15, kq = lane >> 4;
   const int nchunks = Cout >> 6;
   const int nb = blockIdx.x % nchunks;
   const int tblk = blockIdx.x / nchunks;
   int tb = tblk;
-  const int nbx = Sl >> 2, nby = Sl >> 1, nbz = Sl >> 1;
+  const int nbx = Sl >> 2, nby = Sl >> 2, nbz = Sl >> 1;
   const int bx = tb % nbx; tb /= nbx;
   const int by = tb % nby; tb /= nby;
   const int bz = tb % nbz;
   const int b = tb / nbz;
-  const int oz = bz * 2, oy = by * 2, ox = bx * 4, n0 = nb * 64;      // low-res origin of the block
+  const int oz = bz * 2, oy = by * 4, ox = bx * 4, n0 = nb * 64;      // low-res origin of the block
   const bool edge = bx == 0 || by == 0 || bz == 0 || bx == nbx - 1 || by == nby - 1 || bz == nbz - 1;   // uniform
   const int S = 2 * Sl;
 
-  // ---- staging: thread t < 384 owns (tile z tzh, hy, hx, channel quad): z rows tzh, tzh+1, tzh+2 of the halo
-  const int cmb = tid < 384 ? tid : 383;
-  const int tzh = cmb / 192, rem = cmb - 192 * tzh;
-  const int q = rem & 7, hx = (rem >> 3) % 6, hy = (rem >> 3) / 6;
-  const int tzw = __builtin_amdgcn_readfirstlane(tzh);   // 192 threads = 3 whole waves per tile z: wave-uniform
+  // ---- staging: thread t < 576 owns (hy, hx, tile z tzh, channel quad): z rows tzh, tzh+1, tzh+2 of the halo [4][6][6]
+  const int scol = tid < 576 ? tid : 575;
+  const int q = scol & 7, tzh = (scol >> 3) & 1, hx = (scol >> 4) % 6, hy = (scol >> 4) / 6;
   uf4 hs[3];
   unsigned zoff[4];                              // uniform: byte offset of sample b, low-res plane clamp(oz - 1 + hz)
   unsigned okz = 0;                              // uniform: bit hz = plane inside the grid
-  bool okyx;
   {
     const int gy = oy - 1 + hy, gx = ox - 1 + hx;
     const int cy = min(max(gy, 0), Sl - 1), cx = min(max(gx, 0), Sl - 1);
-    okyx = gy == cy && gx == cx;
+    const bool okyx = gy == cy && gx == cx;
     park[tid] = (unsigned)((cy * Sl + cx) * ldx + q * 4) * 4u;
     park[768 + tid] = (unsigned)(tzh * 3 * PP + hy * RP + hx * VX + q * 4);
-    park[1536 + tid] = (unsigned)(q * 4);
+    park[1536 + tid] = (unsigned)(q * 4) | ((unsigned)tzh << 8) | ((okyx ? 1u : 0u) << 9);
 #pragma unroll
     for (int hz = 0; hz < 4; ++hz) {
       const int gz = oz - 1 + hz, cz = min(max(gz, 0), Sl - 1);
@@ -114,10 +111,12 @@ __global__ __launch_bounds__(768) void conv_up3_kernel(const float* __restrict__
   }
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, 0x7fffffff, 0x00020000);
   // per-thread staging constants parked in LDS (conv_wino64.hip explains why)
-  const unsigned park_addr = (unsigned)(uintptr_t)&park[tid];
+  const unsigned park_wave = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)&park[0] + (unsigned)w * 256u);
   auto unpark = [&](const int which) -> int {
     int v;
-    asm volatile("ds_read_b32 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(park_addr), "i"(which * 3072) : "memory");
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshl_add_u32 %0, %0, 2, %1\n\t"
+                 "ds_read_b32 %0, %0 offset:%2\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v) : "s"(park_wave), "i"(which * 3072) : "memory");
     return v;
   };
   if (AFF) {
@@ -125,79 +124,103 @@ __global__ __launch_bounds__(768) void conv_up3_kernel(const float* __restrict__
   }
   auto hload = [&](int c0) {
     const int vo = unpark(0);
+    const bool tz1 = ((unpark(2) >> 8) & 1) != 0; // per lane: the tile z of this column
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      const unsigned zo = tzw ? zoff[1 + i] : zoff[i];
-      hs[i] = __builtin_bit_cast(uf4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vo, (int)(zo + (unsigned)c0 * 4u), 0));
+      const unsigned zo = tz1 ? zoff[1 + i] : zoff[i];
+      hs[i] = __builtin_bit_cast(uf4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)((unsigned)vo + zo), (int)((unsigned)c0 * 4u), 0));
     }
   };
   auto hstore = [&](const int bo, const int c0) {
-    uf4 r[3] = {hs[0], hs[1], hs[2]};            // local copies: updating hs in place sends it to scratch (compiler)
-    if (AFF) {
-      const int q4 = unpark(2);
-      const uf4 sc4 = *reinterpret_cast<const uf4*>(&aff[c0 + q4]);
-      const uf4 sh4 = *reinterpret_cast<const uf4*>(&aff[1024 + c0 + q4]);
+    // two channels at a time: 14 instead of 28 temporaries (the kernel runs three waves per SIMD: 168 registers)
+    const int pk2 = unpark(2);
+    const int q4 = pk2 & 255;
+    const unsigned okzz = ((pk2 >> 8) & 1) ? okz >> 1 : okz;
+    const bool okyx = ((pk2 >> 9) & 1) != 0;
+    float* o = &lds[bo + unpark(1)];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        uf4 t = r[i];
-        t.x = fmaf(t.x, sc4.x, sh4.x); t.y = fmaf(t.y, sc4.y, sh4.y);
-        t.z = fmaf(t.z, sc4.z, sh4.z); t.w = fmaf(t.w, sc4.w, sh4.w);
-        if (!NOACT) { t.x = uact(t.x, in_slope); t.y = uact(t.y, in_slope); t.z = uact(t.z, in_slope); t.w = uact(t.w, in_slope); }
-        r[i] = t;
+    for (int hh = 0; hh < 2; ++hh) {
+      uf2 r[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) r[i] = uf2{hs[i][2 * hh], hs[i][2 * hh + 1]};
+      if (AFF) {
+        const uf2 sc2 = *reinterpret_cast<const uf2*>(&aff[c0 + q4 + 2 * hh]);
+        const uf2 sh2 = *reinterpret_cast<const uf2*>(&aff[1024 + c0 + q4 + 2 * hh]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          float t0 = fmaf(r[i].x, sc2.x, sh2.x), t1 = fmaf(r[i].y, sc2.y, sh2.y);
+          if (!NOACT) { t0 = uact(t0, in_slope); t1 = uact(t1, in_slope); }
+          r[i] = uf2{t0, t1};
+        }
       }
-    }
-    if (edge) {                                  // zero padding AFTER the producer's affine / activation
-      const unsigned okzz = tzw ? okz >> 1 : okz;
+      if (edge) {                                // zero padding AFTER the producer's affine / activation
 #pragma unroll
-      for (int i = 0; i < 3; ++i)
-        if (!(okyx && ((okzz >> i) & 1))) r[i] = uf4{0.f, 0.f, 0.f, 0.f};
-    }
-    if (tid < 384) {
-      float* o = &lds[bo + unpark(1)];
-      const uf4 c0v = r[0] - r[1], c2v = r[2] - r[1];
-      *reinterpret_cast<uf2*>(o) = uf2{c0v.x, c0v.y}; *reinterpret_cast<uf2*>(o + 2) = uf2{c0v.z, c0v.w};
-      *reinterpret_cast<uf2*>(o + PP) = uf2{r[1].x, r[1].y}; *reinterpret_cast<uf2*>(o + PP + 2) = uf2{r[1].z, r[1].w};
-      *reinterpret_cast<uf2*>(o + 2 * PP) = uf2{c2v.x, c2v.y}; *reinterpret_cast<uf2*>(o + 2 * PP + 2) = uf2{c2v.z, c2v.w};
+        for (int i = 0; i < 3; ++i)
+          if (!(okyx && ((okzz >> i) & 1))) r[i] = uf2{0.f, 0.f};
+      }
+      if (tid < 576) {
+        *reinterpret_cast<uf2*>(o + 2 * hh) = r[0] - r[1];
+        *reinterpret_cast<uf2*>(o + PP + 2 * hh) = r[1];
+        *reinterpret_cast<uf2*>(o + 2 * PP + 2 * hh) = r[2] - r[1];
+      }
     }
   };
 
   // ---- per-lane read geometry: voxel m = (tz, ty, tx); rows of a pair's fy: D0 = r0 - r1, D1 = r1, D2 = r2 - r1
   const int tz = m >> 3, ty = (m >> 2) & 1, tx = m & 3;
-  const float saA = fyA == 1 ? 0.f : 1.f, sbA = fyA == 1 ? 1.f : -1.f;    // t = sa * qa + sb * qb
-  const float saB = fyB == 1 ? 0.f : 1.f, sbB = fyB == 1 ? 1.f : -1.f;
+  const float saA = fyA == 1 ? 0.f : 1.f, saB = fyB == 1 ? 0.f : 1.f;    // t = sa * qa - qb (fy = 1: sign folded into the weights)
   const int R0A = (tz * 3 + fzA) * PP + ty * RP + tx * VX + kq, R0B = (tz * 3 + fzB) * PP + ty * RP + tx * VX + kq;
   int RaA = R0A + (fyA == 2 ? 2 : 0) * RP, RbA = R0A + RP, RaB = R0B + (fyB == 2 ? 2 : 0) * RP, RbB = R0B + RP;
 
   const int nsub = Cin >> 2;
-  constexpr int wsub = 108 * 64;                 // floats per sub-step: [36 triples][3 fx][64 lanes]
-  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(wt + ((size_t)nb * nsub * 108 + 9 * w) * 64), 0, 0x7fffffff, 0x00020000);
-  const int wlane = lane * 4;                    // bytes
-  auto wload = [&](int gs, int i, int g) {       // sub-step gs, triple i, fx g
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrs, wlane, (gs * wsub + (i * 3 + g) * 64) * 4, 0));
+  constexpr int wstride_f = 256;                 // floats per frequency of one sub-step: [4 k][16 n][4 column blocks]
+  constexpr int wsub = 27 * 256;
+  const __amdgpu_buffer_rsrc_t wrsA = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(wt + ((size_t)nb * nsub * 27 + pA * 3) * 256 + cbA), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrsB = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(wt + ((size_t)nb * nsub * 27 + pB * 3) * 256 + cbB), 0, 0x7fffffff, 0x00020000);
+  const int wlane = lane * 16;                   // bytes
+  auto wloadA = [&](int gs, int g) {             // sub-step gs, fx g: column blocks cbA, cbA + 1
+    return __builtin_bit_cast(uf2, __builtin_amdgcn_raw_buffer_load_b64(wrsA, wlane, (gs * wsub + g * wstride_f) * 4, 0));
   };
-  float wreg[3][3];
+  auto wloadB = [&](int gs, int g) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrsB, wlane, (gs * wsub + g * wstride_f) * 4, 0));
+  };
+  uf2 wA[3];
+  float wB[3];
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int g = 0; g < 3; ++g) wreg[i][g] = wload(0, i, g);
+  for (int g = 0; g < 3; ++g) { wA[g] = wloadA(0, g); wB[g] = wloadB(0, g); }
 
-  uf4 acc[3][3];                                 // [triple][fx]
+  uf4 acc[2][3][3];                              // [voxel half][triple][fx]
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
+  for (int h = 0; h < 2; ++h)
 #pragma unroll
-    for (int g = 0; g < 3; ++g) acc[i][g] = uf4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int g = 0; g < 3; ++g) acc[h][i][g] = uf4{0.f, 0.f, 0.f, 0.f};
 
-  float uA[3], uB[3], uM[3], tnA[3], tnB[3], qaA, qbA, qaB, qbB;
+  float uA[2][3], uB[2][3], tnA[2][3], tnB[2][3], qaA[2], qbA[2], qaB[2], qbB[2];
   auto rd = [&](const int sub, const int col) {
     const int off = col * VX + 4 * sub;          // compile-time after unrolling
-    qaA = lds[RaA + off]; qbA = lds[RbA + off]; qaB = lds[RaB + off]; qbB = lds[RbB + off];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                // second half: two low-res rows further
+      qaA[h] = lds[RaA + off + h * 2 * RP]; qbA[h] = lds[RbA + off + h * 2 * RP];
+      qaB[h] = lds[RaB + off + h * 2 * RP]; qbB[h] = lds[RbB + off + h * 2 * RP];
+    }
+  };
+  auto tstep = [&](const int g) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      tnA[h][g] = fmaf(saA, qaA[h], -qbA[h]);
+      tnB[h][g] = fmaf(saB, qaB[h], -qbB[h]);
+    }
   };
   auto xform = [&]() {
-    uA[0] = tnA[0] - tnA[1]; uA[1] = tnA[1]; uA[2] = tnA[2] - tnA[1];
-    uB[0] = tnB[0] - tnB[1]; uB[1] = tnB[1]; uB[2] = tnB[2] - tnB[1];
 #pragma unroll
-    for (int g = 0; g < 3; ++g) uM[g] = mid_is_b ? uB[g] : uA[g];
+    for (int h = 0; h < 2; ++h) {
+      uA[h][0] = tnA[h][0] - tnA[h][1]; uA[h][1] = tnA[h][1]; uA[h][2] = tnA[h][2] - tnA[h][1];
+      uB[h][0] = tnB[h][0] - tnB[h][1]; uB[h][1] = tnB[h][1]; uB[h][2] = tnB[h][2] - tnB[h][1];
+    }
   };
 
   hload(0);
@@ -207,8 +230,7 @@ __global__ __launch_bounds__(768) void conv_up3_kernel(const float* __restrict__
 #pragma unroll
   for (int g = 0; g < 3; ++g) {
     rd(0, g);
-    tnA[g] = fmaf(saA, qaA, sbA * qbA);
-    tnB[g] = fmaf(saB, qaB, sbB * qbB);
+    tstep(g);
   }
   xform();
   rd(1, 0);                                      // column 0 of sub-step 1
@@ -228,8 +250,7 @@ __global__ __launch_bounds__(768) void conv_up3_kernel(const float* __restrict__
       gs = gs < nsub ? gs : nsub - 1;
 #pragma unroll
       for (int g = 0; g < 3; ++g) {
-        tnA[g] = fmaf(saA, qaA, sbA * qbA);      // column g of sub-step s+1, read one column ago
-        tnB[g] = fmaf(saB, qaB, sbB * qbB);
+        tstep(g);                                // column g of sub-step s+1, read one column ago
         if (ST && s == 6 && g == 2) {            // the next chunk must be visible before its first column is read
           hstore(nxt, cn);
           __syncthreads();
@@ -238,12 +259,15 @@ __global__ __launch_bounds__(768) void conv_up3_kernel(const float* __restrict__
         if (g < 2) rd((s + 1) & 7, g + 1);
         else rd((s + 2) & 7, 0);
         __builtin_amdgcn_sched_barrier(0);
-        acc[0][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(uA[g], wreg[0][g], acc[0][g], 0, 0, 0);
-        acc[1][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(uM[g], wreg[1][g], acc[1][g], 0, 0, 0);
-        acc[2][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(uB[g], wreg[2][g], acc[2][g], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) wreg[i][g] = wload(gs, i, g);
+        for (int h = 0; h < 2; ++h) {
+          acc[h][0][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(uA[h][g], wA[g].x, acc[h][0][g], 0, 0, 0);
+          acc[h][1][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(uA[h][g], wA[g].y, acc[h][1][g], 0, 0, 0);
+          acc[h][2][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(uB[h][g], wB[g], acc[h][2][g], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        wA[g] = wloadA(gs, g);
+        wB[g] = wloadB(gs, g);
         __builtin_amdgcn_sched_barrier(0);
       }
       xform();
@@ -254,64 +278,68 @@ __global__ __launch_bounds__(768) void conv_up3_kernel(const float* __restrict__
   chunk(nch - 1, std::false_type{});
 
   // ---------------------------------------------------------------- epilogue, two passes of two column blocks each
-  // lane l holds P[voxel = 4 kq + r][n = l & 15] of each of its triples for fx = 0..2.  fx -> dx in registers (dx0 = P0 +
-  // P1, dx1 = P1 + P2); fy -> dy and fz -> dz across the waves through LDS: output (dz, dy, dx) = sum over fz in
-  // {dz, dz+1}, fy in {dy, dy+1}.
-  float* part = lds;                             // [9 (fz, fy)][16 slots = (jl * 4 + r) * 2 + dx][64 lanes]  (36 KB)
+  // lane l holds P[voxel = 16 h + 4 kq + i][n = l & 15] for its (fz, fy) and fx = 0..2.  fx -> dx in registers (dx0 = P0 + P1,
+  // dx1 = P1 + P2); fy -> dy and fz -> dz across the waves through LDS: output (dz, dy, dx) = sum over fz in {dz, dz+1},
+  // fy in {dy, dy+1}.
+  // [9 w][32 slots = ((h * 4 + i) * 2 + dx) * 2 + jl][64 lanes + 16]: slot pitch 80 with jl as the lowest slot bit, so that the
+  // eight lanes of a 16-byte read group (cq, jl) hit eight different bank groups (conv_wino64.hip has the arithmetic)
+  constexpr int PS = 80, PW = 32 * PS;
+  float* part = lds;
   const int cq = tid & 3, jl = (tid >> 2) & 1, o = (tid >> 3) & 3, tile = (tid >> 5) & 15;
   const int dyo = o >> 1, dxo = o & 1;
   const int ttz = tile >> 3, tty = (tile >> 2) & 1, ttx = tile & 3;
   const int vz = 2 * (oz + ttz), vy = 2 * (oy + tty) + dyo, vx = 2 * (ox + ttx) + dxo;
-  const size_t vox0 = (((size_t)b * S + vz) * S + vy) * S + vx;
-  const int slot_rd = ((jl * 4 + ttx) * 2 + dxo) * 64 + (tile >> 2) * 16 + cq * 4;
-  uf4 val[2][2];
-  uf4 csum[2];
+  const size_t vox0 = (((size_t)b * S + vz) * S + vy) * S + vx;         // half h: + 4 fine rows
+  const int slot_rd = ((ttx * 2 + dxo) * 2 + jl) * PS + (tile >> 2) * 16 + cq * 4;
+  uf4 val[2][2][2];                              // [pass][half][dz]
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      const int T = 3 * w + i, cmb = T >> 2, cbk = T & 3;            // uniform
+      const int cmb = i < 2 ? pA : pB, cbk = i < 2 ? cbA + i : cbB;  // uniform
       if ((cbk >> 1) == pass) {
         const int jj = cbk & 1;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          part[(cmb * 16 + (jj * 4 + r) * 2 + 0) * 64 + lane] = acc[i][0][r] + acc[i][1][r];
-          part[(cmb * 16 + (jj * 4 + r) * 2 + 1) * 64 + lane] = acc[i][1][r] + acc[i][2][r];
-        }
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            part[cmb * PW + (((h * 4 + r) * 2 + 0) * 2 + jj) * PS + lane] = acc[h][i][0][r] + acc[h][i][1][r];
+            part[cmb * PW + (((h * 4 + r) * 2 + 1) * 2 + jj) * PS + lane] = acc[h][i][1][r] + acc[h][i][2][r];
+          }
       }
     }
     __syncthreads();
     if (tid < 512) {
       const int nn = n0 + (pass * 2 + jl) * 16 + cq * 4;           // this thread's four output channels
-      uf4 r[3];                                  // sum over fy in {dy, dy+1} for fz = 0, 1, 2
-#pragma unroll
-      for (int z = 0; z < 3; ++z)
-        r[z] = *reinterpret_cast<const uf4*>(&part[(z * 3 + dyo) * 1024 + slot_rd]) +
-               *reinterpret_cast<const uf4*>(&part[(z * 3 + dyo + 1) * 1024 + slot_rd]);
       uf4 bv = {0.f, 0.f, 0.f, 0.f};
       if (bias != nullptr) bv = *reinterpret_cast<const uf4*>(bias + nn);
-      const size_t o0 = vox0 * ldo + nn;
-      const size_t o1 = o0 + (size_t)S * S * ldo;
-      uf4 e0 = r[0] + r[1] + bv, e1 = r[1] + r[2] + bv;
-      if (accumulate) {
-        e0 += *reinterpret_cast<const uf4*>(y + o0);
-        e1 += *reinterpret_cast<const uf4*>(y + o1);
-      }
-      e0.x = uact(e0.x, pre_slope); e0.y = uact(e0.y, pre_slope); e0.z = uact(e0.z, pre_slope); e0.w = uact(e0.w, pre_slope);
-      e1.x = uact(e1.x, pre_slope); e1.y = uact(e1.y, pre_slope); e1.z = uact(e1.z, pre_slope); e1.w = uact(e1.w, pre_slope);
-      *reinterpret_cast<uf4*>(y + o0) = e0;
-      *reinterpret_cast<uf4*>(y + o1) = e1;
-      if (STATS) {
-        val[pass][0] = e0; val[pass][1] = e1;
-        csum[pass] = e0 + e1;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        uf4 r[3];                                // sum over fy in {dy, dy+1} for fz = 0, 1, 2
+#pragma unroll
+        for (int z = 0; z < 3; ++z)
+          r[z] = *reinterpret_cast<const uf4*>(&part[(z * 3 + dyo) * PW + h * 16 * PS + slot_rd]) +
+                 *reinterpret_cast<const uf4*>(&part[(z * 3 + dyo + 1) * PW + h * 16 * PS + slot_rd]);
+        const size_t o0 = (vox0 + (size_t)h * 4 * S) * ldo + nn;
+        const size_t o1 = o0 + (size_t)S * S * ldo;
+        uf4 e0 = r[0] + r[1] + bv, e1 = r[1] + r[2] + bv;
+        if (accumulate) {
+          e0 += *reinterpret_cast<const uf4*>(y + o0);
+          e1 += *reinterpret_cast<const uf4*>(y + o1);
+        }
+        e0.x = uact(e0.x, pre_slope); e0.y = uact(e0.y, pre_slope); e0.z = uact(e0.z, pre_slope); e0.w = uact(e0.w, pre_slope);
+        e1.x = uact(e1.x, pre_slope); e1.y = uact(e1.y, pre_slope); e1.z = uact(e1.z, pre_slope); e1.w = uact(e1.w, pre_slope);
+        *reinterpret_cast<uf4*>(y + o0) = e0;
+        *reinterpret_cast<uf4*>(y + o1) = e1;
+        if (STATS) { val[pass][h][0] = e0; val[pass][h][1] = e1; }
       }
     }
   }
   if (!STATS) return;
 
-  // block-level (count, mean, M2) per column over the block's 128 fine voxels (conv_igemm.hip's layout
-  // [3][Npad][nblocks], block index fastest); the 512 reader threads are waves 0..7
+  // block-level (count, mean, M2) per column over the block's 256 fine voxels (conv_igemm.hip's layout
+  // [3][Npad][nblocks], block index fastest); the 512 reader threads are waves 0..7, four voxels each per pass
   auto colreduce = [&](uf4 v) -> uf4 {
 #pragma unroll
     for (int d = 8; d < 64; d <<= 1) {
@@ -337,6 +365,9 @@ __global__ __launch_bounds__(768) void conv_up3_kernel(const float* __restrict__
     return sacc;
   };
   const size_t nstat = gridDim.x / nchunks;
+  uf4 csum[2];
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) csum[pass] = (val[pass][0][0] + val[pass][0][1]) + (val[pass][1][0] + val[pass][1][1]);
   put(csum);
   if (tid < 64) red[512 + tid] = sum8(tid) * (1.f / kRows);
   __syncthreads();
@@ -344,8 +375,12 @@ __global__ __launch_bounds__(768) void conv_up3_kernel(const float* __restrict__
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     const uf4 mu = *reinterpret_cast<const uf4*>(&red[512 + pass * 32 + cidx]);
-    const uf4 d0 = val[pass][0] - mu, d1 = val[pass][1] - mu;
-    qs[pass] = d0 * d0 + d1 * d1;
+    uf4 qacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int dzz = 0; dzz < 2; ++dzz) { const uf4 dd = val[pass][h][dzz] - mu; qacc += dd * dd; }
+    qs[pass] = qacc;
   }
   float mean_t = 0.f;
   if (tid < 64) mean_t = red[512 + tid];
@@ -374,7 +409,7 @@ int launch_conv_fwd_up3(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, co
   ICS_CHECK(ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (reinterpret_cast<uintptr_t>(bias) & 15) == 0 &&
                 (reinterpret_cast<uintptr_t>(s0.p) & 15) == 0,
             "upsampled-input kernel: float4 accesses need 16-byte aligned tensors");
-  const unsigned grid = (unsigned)(g.B * (g.S / 2) * (g.S / 2) * (g.S / 4) * (g.Cout / 64));
+  const unsigned grid = (unsigned)(g.B * (g.S / 2) * (g.S / 4) * (g.S / 4) * (g.Cout / 64));
   if (stat_blocks) *stat_blocks = (int)(grid / (unsigned)(g.Cout / 64));
   const bool aff = s0.scale != nullptr, noact = s0.act == ACT_NONE;
   const float in_slope = uslope(s0.act), pre_slope = uslope(pre_act);
