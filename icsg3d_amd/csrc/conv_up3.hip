@@ -13,13 +13,14 @@
 // apart.  Zero padding of the fine grid is zero padding of the low-res grid.
 //
 // One workgroup = 16 low-res voxels (2x2x4: the same 4x4x8 block of fine outputs as conv_wino64.hip) x 64 output
-// channels x 27 frequencies, 9 waves: wave w owns (fz, fy) = (w / 3, w % 3), fx = 0..2, four 16-channel column blocks
-// each: 12 accumulators of 4 registers (v_mfma_f32_16x16x4_f32; lane l: A[voxel l & 15][k = l >> 4]).  With 48
-// accumulator registers a wave needs < 102 VGPRs, so TWO workgroups share a CU (18 waves on 4 SIMDs) and cover each
-// other's prologue, epilogue and barrier.  Staging: thread t < 384 owns (tile z, y, x, channel quad) of the halo
-// [4][4][6] x 32 channels: three z rows in, the producer's BatchNorm affine + activation, zero padding, the z rows of
-// B, three planes out.  LDS: voxel pitch 34 floats, row pitch 208, plane pitch 840 (conflict-free ds_read_b32 for every
-// (fz, row, column, sub-step): checked exhaustively).  Weights [Cout/64][Cu/4][27 f][4 k][16 n][4 column blocks].
+// channels x 27 frequencies on v_mfma_f32_16x16x4_f32 (lane l: A[voxel l & 15][k = l >> 4]), EIGHT waves, two per SIMD:
+// wave w owns the (fz, fy) pair w with fx = 0..2 and all four 16-channel column blocks (12 accumulators of 4 registers),
+// and the waves 0..3 -- one per SIMD -- also take one column block each of the ninth pair (2, 2): 15 + 12 = 27 MFMAs per
+// sub-step on every SIMD (the kernel header below has the history).  Staging: thread t < 384 owns (tile z, y, x,
+// channel quad) of the halo [4][4][6] x 32 channels: three z rows in, the producer's BatchNorm affine + activation, zero
+// padding, the z rows of B, three planes out.  LDS: voxel pitch 34 floats, row pitch 208, plane pitch 840 (conflict-free
+// ds_read_b32 for every (fz, row, column, sub-step): checked exhaustively).  Weights [Cout/64][Cu/4][27 f][4 k][16 n][4
+// column blocks]; the fy = 1 frequencies carry the opposite sign (one fma per column in the y transform).
 #include "common.h"
 
 #include <type_traits>
@@ -43,13 +44,13 @@ __host__ __device__ __forceinline__ float uslope(int act) { return act == ACT_RE
 // x: low-res source [B][Sl][Sl][Sl][ldx]; y: fine output [B][2 Sl]^3 [ldo].  AFF / NOACT as in conv_wino64.hip.
 // STATS: per-block BatchNorm statistics of the stored values (the VAE decoder's layers; the U-Net's launches leave bias,
 // activation and statistics to the skip-channel pass that accumulates on top).
-// Registers: 112 VGPRs = four waves per SIMD = ONE nine-wave workgroup per CU (3 + 2 + 2 + 2 waves on the four SIMDs).
-// A 96-register build (halo staged in two 8-byte phases, no statistics, one register spilled per chunk) puts TWO
-// workgroups on a CU (5 + 5 + 4 + 4): measured SLOWER, 2.53 vs 2.41 ms per U-Net step -- the matrix pipe is not what
-// bounds this kernel.  Every MFMA takes a fresh 256-byte B operand from L2 (16 voxels per weight load): ~70 GB/s per CU,
-// ~18 TB/s over the chip, half of the L2's 34.5 TB/s, the same rate conv_wino64.hip runs at.
+// History of the wave layout (c17.up, ms per U-Net step): nine waves, one pair each, sat 3 + 2 + 2 + 2 on the SIMDs and
+// the main loop ran at the pace of SIMD 0's 36 MFMAs per sub-step (1.36; scripts/up3_timeline.py, and an ablation without
+// weight loads and operand reads still took 1.24); twelve waves x three triples 1.36 (two operand sets per wave); the
+// layout below with the extra work under wave-uniform branches INSIDE the loop 1.39 (conservative waits at every join);
+// with the two roles as two straight-line copies of the loop behind one branch: 1.24.
 template <bool AFF, bool NOACT, bool STATS>
-__global__ __launch_bounds__(576, 4) void conv_up3_kernel(const float* __restrict__ x, int ldx,
+__global__ __launch_bounds__(512) void conv_up3_kernel(const float* __restrict__ x, int ldx,
                                                           const float* __restrict__ in_scale,
                                                           const float* __restrict__ in_shift, float in_slope,
                                                           const float* __restrict__ wt, const float* __restrict__ bias,
@@ -57,12 +58,18 @@ __global__ __launch_bounds__(576, 4) void conv_up3_kernel(const float* __restric
                                                           float* __restrict__ stat_partial, int Npad, int Sl, int Cin,
                                                           int Cout) {
   __shared__ __attribute__((aligned(16))) float lds[9 * 16 * 80];   // 46 080 B: two buffers (40 320 B); the epilogue's [9][16][80]
-  __shared__ unsigned park[3 * 576];
+  __shared__ unsigned park[3 * 512];
   __shared__ __attribute__((aligned(16))) float aff[AFF ? 2048 : 4];
   __shared__ float red[9 * 64];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int fz = w / 3, fy = w - 3 * fz;         // this wave: frequencies (fz, fy, 0..2)
+  // EIGHT waves, two per SIMD.  Wave w owns the (fz, fy) pair w (fx = 0..2, four column blocks); the ninth pair (2, 2)
+  // is split by column block over the waves 0..3 (each on a different SIMD): 15 + 12 = 27 MFMAs per sub-step on every
+  // SIMD.  (Nine waves sat 3 + 2 + 2 + 2: the main loop ran at the pace of SIMD 0's 36, scripts/up3_timeline.py.)  The
+  // two roles are two straight-line copies of the main loop behind ONE wave-uniform branch: branches around the extra
+  // MFMAs inside the loop cost all of the gain (conservative waits at every join).
+  const int fz = w / 3, fy = w - 3 * fz;
+  const bool extra = w < 4;
   const int m = lane & 15, kq = lane >> 4;
   const int nchunks = Cout >> 6;
   const int nb = blockIdx.x % nchunks;
@@ -91,8 +98,8 @@ __global__ __launch_bounds__(576, 4) void conv_up3_kernel(const float* __restric
     const int cy = min(max(gy, 0), Sl - 1), cx = min(max(gx, 0), Sl - 1);
     okyx = gy == cy && gx == cx;
     park[tid] = (unsigned)((cy * Sl + cx) * ldx + q * 4) * 4u;
-    park[576 + tid] = (unsigned)(tzh * 3 * PP + hy * RP + hx * VX + q * 4);
-    park[1152 + tid] = (unsigned)(q * 4);
+    park[512 + tid] = (unsigned)(tzh * 3 * PP + hy * RP + hx * VX + q * 4);
+    park[1024 + tid] = (unsigned)(q * 4);
 #pragma unroll
     for (int hz = 0; hz < 4; ++hz) {
       const int gz = oz - 1 + hz, cz = min(max(gz, 0), Sl - 1);
@@ -105,11 +112,11 @@ __global__ __launch_bounds__(576, 4) void conv_up3_kernel(const float* __restric
   const unsigned park_addr = (unsigned)(uintptr_t)&park[tid];
   auto unpark = [&](const int which) -> int {
     int v;
-    asm volatile("ds_read_b32 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(park_addr), "i"(which * 2304) : "memory");
+    asm volatile("ds_read_b32 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(park_addr), "i"(which * 2048) : "memory");
     return v;
   };
   if (AFF) {
-    for (int i = tid; i < Cin; i += 576) { aff[i] = in_scale[i]; aff[1024 + i] = in_shift[i]; }
+    for (int i = tid; i < Cin; i += 512) { aff[i] = in_scale[i]; aff[1024 + i] = in_shift[i]; }
   }
   auto hload = [&](int c0) {
     const int vo = unpark(0);
@@ -156,6 +163,7 @@ __global__ __launch_bounds__(576, 4) void conv_up3_kernel(const float* __restric
   const float sa = fy == 1 ? 0.f : 1.f;
   const int R0 = (tz * 3 + fz) * PP + ty * RP + tx * VX + kq;
   int Ra = R0 + (fy == 2 ? 2 : 0) * RP, Rb = R0 + RP;
+  int Rxa = (tz * 3 + 2) * PP + ty * RP + tx * VX + kq + 2 * RP, Rxb = Rxa - RP;      // pair (2, 2): rows 2 and 1
 
   const int nsub = Cin >> 2;
   constexpr int wstride_f = 256;                 // floats per frequency of one sub-step: [4 k][16 n][4 column blocks]
@@ -169,6 +177,19 @@ __global__ __launch_bounds__(576, 4) void conv_up3_kernel(const float* __restric
   uf4 wreg[3];
 #pragma unroll
   for (int f = 0; f < 3; ++f) wreg[f] = wload(0, f);
+  // the extra triple's weights: frequency (2, 2, fx) = 24 + fx relative to frequency 0, column block w: one dword per lane
+  const __amdgpu_buffer_rsrc_t wrx = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(wt + ((size_t)nb * nsub * 27 + 24) * 256 + (w & 3)), 0, 0x7fffffff, 0x00020000);
+  auto wloadx = [&](int gs, int f) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrx, wlane, (gs * wsub + f * wstride_f) * 4, 0));
+  };
+  float wx[3];
+#pragma unroll
+  for (int f = 0; f < 3; ++f) wx[f] = wloadx(0, f);
+  uf4 accx[3];
+#pragma unroll
+  for (int f = 0; f < 3; ++f) accx[f] = uf4{0.f, 0.f, 0.f, 0.f};
+  float ux[3], tx3[3], qxa, qxb;
 
   uf4 acc[3][4];                                 // [fx][column block]
 #pragma unroll
@@ -177,11 +198,15 @@ __global__ __launch_bounds__(576, 4) void conv_up3_kernel(const float* __restric
     for (int j = 0; j < 4; ++j) acc[f][j] = uf4{0.f, 0.f, 0.f, 0.f};
 
   float u[3], tn[3], qa, qb;
-  auto rd = [&](const int sub, const int col) {
+  auto rd = [&](const int sub, const int col, auto xt) {
     const int off = col * VX + 4 * sub;          // compile-time after unrolling
     qa = lds[Ra + off]; qb = lds[Rb + off];
+    if (decltype(xt)::value) { qxa = lds[Rxa + off]; qxb = lds[Rxb + off]; }
   };
-  auto xform = [&]() { u[0] = tn[0] - tn[1]; u[1] = tn[1]; u[2] = tn[2] - tn[1]; };
+  auto xform = [&](auto xt) {
+    u[0] = tn[0] - tn[1]; u[1] = tn[1]; u[2] = tn[2] - tn[1];
+    if (decltype(xt)::value) { ux[0] = tx3[0] - tx3[1]; ux[1] = tx3[1]; ux[2] = tx3[2] - tx3[1]; }
+  };
 
   hload(0);
   if (AFF) __syncthreads();                      // scale / shift visible
@@ -189,18 +214,20 @@ __global__ __launch_bounds__(576, 4) void conv_up3_kernel(const float* __restric
   __syncthreads();
 #pragma unroll
   for (int g = 0; g < 3; ++g) {
-    rd(0, g);
+    rd(0, g, std::true_type{});
     tn[g] = fmaf(sa, qa, -qb);
+    tx3[g] = qxa - qxb;                          // fy = 2: r2 - r1
   }
-  xform();
-  rd(1, 0);                                      // column 0 of sub-step 1
+  xform(std::true_type{});
+  rd(1, 0, std::true_type{});                    // column 0 of sub-step 1
 
   const int nch = Cin / KC;
   int nxt = BUF;                                 // float offset of the buffer being filled
   // ST = false: the last chunk, a second copy of the loop body that stages nothing (its read-ahead columns wrap around
   // inside the buffer being consumed and are never used) -- as in conv_wino64.hip
-  auto chunk = [&](const int ch, auto stage_tag) {
+  auto chunk = [&](const int ch, auto stage_tag, auto xt) {
     constexpr bool ST = decltype(stage_tag)::value;
+    constexpr bool XT = decltype(xt)::value;
     const int cn = (ch + 1) * KC;
     const int dlt = 2 * nxt - BUF;
     if (ST) hload(cn);
@@ -210,28 +237,36 @@ __global__ __launch_bounds__(576, 4) void conv_up3_kernel(const float* __restric
       gs = gs < nsub ? gs : nsub - 1;
 #pragma unroll
       for (int g = 0; g < 3; ++g) {
-        tn[g] = fmaf(sa, qa, -qb);           // column g of sub-step s+1, read one column ago
+        tn[g] = fmaf(sa, qa, -qb);               // column g of sub-step s+1, read one column ago
+        if (XT) tx3[g] = qxa - qxb;
         if (ST && s == 6 && g == 2) {            // the next chunk must be visible before its first column is read
           hstore(nxt, cn);
           __syncthreads();
-          Ra += dlt; Rb += dlt;
+          Ra += dlt; Rb += dlt; Rxa += dlt; Rxb += dlt;
         }
-        if (g < 2) rd((s + 1) & 7, g + 1);
-        else rd((s + 2) & 7, 0);
+        if (g < 2) rd((s + 1) & 7, g + 1, xt);
+        else rd((s + 2) & 7, 0, xt);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[g], wreg[g][j], acc[g][j], 0, 0, 0);
+        if (XT) accx[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ux[g], wx[g], accx[g], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         wreg[g] = wload(gs, g);
+        if (XT) wx[g] = wloadx(gs, g);
         __builtin_amdgcn_sched_barrier(0);
       }
-      xform();
+      xform(xt);
     }
     nxt = BUF - nxt;
   };
-  for (int ch = 0; ch < nch - 1; ++ch) chunk(ch, std::true_type{});
-  chunk(nch - 1, std::false_type{});
+  if (extra) {
+    for (int ch = 0; ch < nch - 1; ++ch) chunk(ch, std::true_type{}, std::true_type{});
+    chunk(nch - 1, std::false_type{}, std::true_type{});
+  } else {
+    for (int ch = 0; ch < nch - 1; ++ch) chunk(ch, std::true_type{}, std::false_type{});
+    chunk(nch - 1, std::false_type{}, std::false_type{});
+  }
 
   // ---------------------------------------------------------------- epilogue, two passes of two column blocks each
   // lane l holds P[voxel = 4 kq + i][n = l & 15] for its (fz, fy) and fx = 0..2.  fx -> dx in registers (dx0 = P0 + P1,
@@ -261,8 +296,16 @@ __global__ __launch_bounds__(576, 4) void conv_up3_kernel(const float* __restric
         part[w * PW + ((i * 2 + 1) * 2 + jj) * PS + lane] = acc[1][j][i] + acc[2][j][i];
       }
     }
+    if (extra && (w >> 1) == pass) {             // pair (2, 2), column block w
+      const int jj = w & 1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        part[8 * PW + ((i * 2 + 0) * 2 + jj) * PS + lane] = accx[0][i] + accx[1][i];
+        part[8 * PW + ((i * 2 + 1) * 2 + jj) * PS + lane] = accx[1][i] + accx[2][i];
+      }
+    }
     __syncthreads();
-    if (tid < 512) {
+    {
       const int nn = n0 + (pass * 2 + jl) * 16 + cq * 4;           // this thread's four output channels
       uf4 r[3];                                  // sum over fy in {dy, dy+1} for fz = 0, 1, 2
 #pragma unroll
@@ -302,9 +345,9 @@ __global__ __launch_bounds__(576, 4) void conv_up3_kernel(const float* __restric
   const int cidx = jl * 16 + cq * 4;
   auto put = [&](const uf4 (&v)[2]) {
     uf4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0;
-    if (w < 8) { r0 = colreduce(v[0]); r1 = colreduce(v[1]); }
+    r0 = colreduce(v[0]); r1 = colreduce(v[1]);
     __syncthreads();
-    if (w < 8 && lane < 8) {
+    if (lane < 8) {
       *reinterpret_cast<uf4*>(&red[w * 64 + cidx]) = r0;
       *reinterpret_cast<uf4*>(&red[w * 64 + 32 + cidx]) = r1;
     }
@@ -360,7 +403,7 @@ int launch_conv_fwd_up3(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, co
   const float in_slope = uslope(s0.act), pre_slope = uslope(pre_act);
 #define ICS_UP3_LAUNCH(AFFV, NOACTV, STATSV)                                                                      \
   do {                                                                                                            \
-    hipLaunchKernelGGL((conv_up3_kernel<AFFV, NOACTV, STATSV>), dim3(grid), dim3(576), 0, st, s0.p, s0.C,          \
+    hipLaunchKernelGGL((conv_up3_kernel<AFFV, NOACTV, STATSV>), dim3(grid), dim3(512), 0, st, s0.p, s0.C,          \
                        s0.scale, s0.shift, in_slope, wt, bias, out, ldo, pre_slope, accumulate, stat_partial,     \
                        g.Npad, g.S, g.Cin, g.Cout);                                                               \
     conv_set_last_kernel_id("conv_up3_kernel<" #AFFV ", " #NOACTV ", " #STATSV ">");                              \
