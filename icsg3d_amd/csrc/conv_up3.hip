@@ -12,15 +12,17 @@
 // structure as the Winograd kernels (conv_wino64.hip) with 3 instead of 4 points per axis and tiles one low-res voxel
 // apart.  Zero padding of the fine grid is zero padding of the low-res grid.
 //
-// One workgroup = 16 low-res voxels (2x2x4: the same 4x4x8 block of fine outputs as conv_wino64.hip) x 64 output
-// channels x 27 frequencies on v_mfma_f32_16x16x4_f32 (lane l: A[voxel l & 15][k = l >> 4]), EIGHT waves, two per SIMD:
-// wave w owns the (fz, fy) pair w with fx = 0..2 and all four 16-channel column blocks (12 accumulators of 4 registers),
-// and the waves 0..3 -- one per SIMD -- also take one column block each of the ninth pair (2, 2): 15 + 12 = 27 MFMAs per
-// sub-step on every SIMD (the kernel header below has the history).  Staging: thread t < 384 owns (tile z, y, x,
-// channel quad) of the halo [4][4][6] x 32 channels: three z rows in, the producer's BatchNorm affine + activation, zero
-// padding, the z rows of B, three planes out.  LDS: voxel pitch 34 floats, row pitch 208, plane pitch 840 (conflict-free
-// ds_read_b32 for every (fz, row, column, sub-step): checked exhaustively).  Weights [Cout/64][Cu/4][27 f][4 k][16 n][4
-// column blocks]; the fy = 1 frequencies carry the opposite sign (one fma per column in the y transform).
+// One workgroup = 32 low-res voxels (2x4x4: an 4x8x8 block of fine outputs) x 64 output channels x 27 frequencies on
+// v_mfma_f32_16x16x4_f32 (lane l: A[voxel l & 15][k = l >> 4]; the two 16-voxel halves are two y rows apart and share
+// every B operand), EIGHT waves, two per SIMD: wave w owns the (fz, fy) pair w with fx = 0..2 and all four 16-channel
+// column blocks (2 x 12 accumulators of 4 registers), and the waves 0..3 -- one per SIMD -- also take one column block
+// each of the ninth pair (2, 2): 2 x (15 + 12) = 54 MFMAs per sub-step on every SIMD (the kernel header below has the
+// history).  Staging: thread t < 288 owns (y, x, channel quad) of the halo [4][6][6] x 32 channels: four z rows in, the
+// producer's BatchNorm affine + activation once per row, zero padding, the z rows of B for both tile z, six planes
+// out.  LDS: voxel pitch 34 floats, row pitch 208, plane pitch 1256 (3 x 1256 = 24 mod 32 as with the 16-voxel tile's
+// 840: conflict-free ds_read_b32 for every (fz, row, column, sub-step), checked exhaustively).  Weights [Cout/64][Cu/4]
+// [27 f][4 k][16 n][4 column blocks]; the fy = 1 frequencies carry the opposite sign (one fma per column in the y
+// transform).
 #include "common.h"
 
 #include <type_traits>
@@ -34,8 +36,8 @@ typedef float uf2 __attribute__((ext_vector_type(2)));
 
 namespace {
 constexpr int KC = 32;                                   // input channels per LDS chunk
-constexpr int VX = 34, RP = 208, PP = 840, BUF = 6 * PP; // floats; one buffer = 20 160 B
-constexpr int kRows = 128;                               // fine voxels per workgroup
+constexpr int VX = 34, RP = 208, PP = 1256, BUF = 6 * PP; // floats; one buffer = 30 144 B
+constexpr int kRows = 256;                               // fine voxels per workgroup
 
 __device__ __forceinline__ float uact(float v, float slope) { return fmaxf(v, v * slope); }
 __host__ __device__ __forceinline__ float uslope(int act) { return act == ACT_RELU ? 0.f : (act == ACT_LRELU ? kLeaky : 1.f); }
@@ -48,7 +50,8 @@ __host__ __device__ __forceinline__ float uslope(int act) { return act == ACT_RE
 // the main loop ran at the pace of SIMD 0's 36 MFMAs per sub-step (1.36; scripts/up3_timeline.py, and an ablation without
 // weight loads and operand reads still took 1.24); twelve waves x three triples 1.36 (two operand sets per wave); the
 // layout below with the extra work under wave-uniform branches INSIDE the loop 1.39 (conservative waits at every join);
-// with the two roles as two straight-line copies of the loop behind one branch: 1.24.
+// with the two roles as two straight-line copies of the loop behind one branch: 1.24; 32 instead of 16 voxels per
+// workgroup on top (half the weight traffic, halo 4.5 instead of 6 positions per voxel, one epilogue per 32): 1.15.
 template <bool AFF, bool NOACT, bool STATS>
 __global__ __launch_bounds__(512) void conv_up3_kernel(const float* __restrict__ x, int ldx,
                                                           const float* __restrict__ in_scale,
@@ -57,7 +60,7 @@ __global__ __launch_bounds__(512) void conv_up3_kernel(const float* __restrict__
                                                           float* __restrict__ y, int ldo, float pre_slope, int accumulate,
                                                           float* __restrict__ stat_partial, int Npad, int Sl, int Cin,
                                                           int Cout) {
-  __shared__ __attribute__((aligned(16))) float lds[9 * 16 * 80];   // 46 080 B: two buffers (40 320 B); the epilogue's [9][16][80]
+  __shared__ __attribute__((aligned(16))) float lds[9 * 32 * 80];   // 92 160 B: two buffers (60 288 B); the epilogue's [9][32][80]
   __shared__ unsigned park[3 * 512];
   __shared__ __attribute__((aligned(16))) float aff[AFF ? 2048 : 4];
   __shared__ float red[9 * 64];
@@ -75,31 +78,28 @@ __global__ __launch_bounds__(512) void conv_up3_kernel(const float* __restrict__
   const int nb = blockIdx.x % nchunks;
   const int tblk = blockIdx.x / nchunks;
   int tb = tblk;
-  const int nbx = Sl >> 2, nby = Sl >> 1, nbz = Sl >> 1;
+  const int nbx = Sl >> 2, nby = Sl >> 2, nbz = Sl >> 1;
   const int bx = tb % nbx; tb /= nbx;
   const int by = tb % nby; tb /= nby;
   const int bz = tb % nbz;
   const int b = tb / nbz;
-  const int oz = bz * 2, oy = by * 2, ox = bx * 4, n0 = nb * 64;      // low-res origin of the block
+  const int oz = bz * 2, oy = by * 4, ox = bx * 4, n0 = nb * 64;      // low-res origin of the block (2 x 4 x 4 voxels)
   const bool edge = bx == 0 || by == 0 || bz == 0 || bx == nbx - 1 || by == nby - 1 || bz == nbz - 1;   // uniform
   const int S = 2 * Sl;
 
-  // ---- staging: thread t < 384 owns (tile z tzh, hy, hx, channel quad): z rows tzh, tzh+1, tzh+2 of the halo
-  const int cmb = tid < 384 ? tid : 383;
-  const int tzh = cmb / 192, rem = cmb - 192 * tzh;
-  const int q = rem & 7, hx = (rem >> 3) % 6, hy = (rem >> 3) / 6;
-  const int tzw = __builtin_amdgcn_readfirstlane(tzh);   // 192 threads = 3 whole waves per tile z: wave-uniform
-  uf4 hs[3];
+  // ---- staging: thread t < 288 owns (hy, hx, channel quad) of the halo [4][6][6]: four z rows in, six planes out
+  const int cmb = tid < 288 ? tid : 287;
+  const int q = cmb & 7, hx = (cmb >> 3) % 6, hy = (cmb >> 3) / 6;
+  uf4 hs[4];
   unsigned zoff[4];                              // uniform: byte offset of sample b, low-res plane clamp(oz - 1 + hz)
   unsigned okz = 0;                              // uniform: bit hz = plane inside the grid
-  bool okyx;
   {
     const int gy = oy - 1 + hy, gx = ox - 1 + hx;
     const int cy = min(max(gy, 0), Sl - 1), cx = min(max(gx, 0), Sl - 1);
-    okyx = gy == cy && gx == cx;
+    const bool okyx = gy == cy && gx == cx;
     park[tid] = (unsigned)((cy * Sl + cx) * ldx + q * 4) * 4u;
-    park[512 + tid] = (unsigned)(tzh * 3 * PP + hy * RP + hx * VX + q * 4);
-    park[1024 + tid] = (unsigned)(q * 4);
+    park[512 + tid] = (unsigned)(hy * RP + hx * VX + q * 4);
+    park[1024 + tid] = (unsigned)(q * 4) | ((okyx ? 1u : 0u) << 8);
 #pragma unroll
     for (int hz = 0; hz < 4; ++hz) {
       const int gz = oz - 1 + hz, cz = min(max(gz, 0), Sl - 1);
@@ -121,38 +121,43 @@ __global__ __launch_bounds__(512) void conv_up3_kernel(const float* __restrict__
   auto hload = [&](int c0) {
     const int vo = unpark(0);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const unsigned zo = tzw ? zoff[1 + i] : zoff[i];
-      hs[i] = __builtin_bit_cast(uf4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vo, (int)(zo + (unsigned)c0 * 4u), 0));
-    }
+    for (int i = 0; i < 4; ++i)
+      hs[i] = __builtin_bit_cast(uf4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vo, (int)(zoff[i] + (unsigned)c0 * 4u), 0));
   };
   auto hstore = [&](const int bo, const int c0) {
-    uf4 r[3] = {hs[0], hs[1], hs[2]};            // local copies: updating hs in place sends it to scratch (compiler)
-    if (AFF) {
-      const int q4 = unpark(2);
-      const uf4 sc4 = *reinterpret_cast<const uf4*>(&aff[c0 + q4]);
-      const uf4 sh4 = *reinterpret_cast<const uf4*>(&aff[1024 + c0 + q4]);
+    // two channels at a time (few temporaries); every z row gets the affine ONCE although rows 1, 2 feed both tile z
+    const int pk2 = unpark(2);
+    const int q4 = pk2 & 255;
+    const bool okyx = ((pk2 >> 8) & 1) != 0;
+    float* o = &lds[bo + unpark(1)];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        uf4 t = r[i];
-        t.x = fmaf(t.x, sc4.x, sh4.x); t.y = fmaf(t.y, sc4.y, sh4.y);
-        t.z = fmaf(t.z, sc4.z, sh4.z); t.w = fmaf(t.w, sc4.w, sh4.w);
-        if (!NOACT) { t.x = uact(t.x, in_slope); t.y = uact(t.y, in_slope); t.z = uact(t.z, in_slope); t.w = uact(t.w, in_slope); }
-        r[i] = t;
+    for (int hh = 0; hh < 2; ++hh) {
+      uf2 r[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) r[i] = uf2{hs[i][2 * hh], hs[i][2 * hh + 1]};
+      if (AFF) {
+        const uf2 sc2 = *reinterpret_cast<const uf2*>(&aff[c0 + q4 + 2 * hh]);
+        const uf2 sh2 = *reinterpret_cast<const uf2*>(&aff[1024 + c0 + q4 + 2 * hh]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float t0 = fmaf(r[i].x, sc2.x, sh2.x), t1 = fmaf(r[i].y, sc2.y, sh2.y);
+          if (!NOACT) { t0 = uact(t0, in_slope); t1 = uact(t1, in_slope); }
+          r[i] = uf2{t0, t1};
+        }
       }
-    }
-    if (edge) {                                  // zero padding AFTER the producer's affine / activation
-      const unsigned okzz = tzw ? okz >> 1 : okz;
+      if (edge) {                                // zero padding AFTER the producer's affine / activation
 #pragma unroll
-      for (int i = 0; i < 3; ++i)
-        if (!(okyx && ((okzz >> i) & 1))) r[i] = uf4{0.f, 0.f, 0.f, 0.f};
-    }
-    if (tid < 384) {
-      float* o = &lds[bo + unpark(1)];
-      const uf4 c0v = r[0] - r[1], c2v = r[2] - r[1];
-      *reinterpret_cast<uf2*>(o) = uf2{c0v.x, c0v.y}; *reinterpret_cast<uf2*>(o + 2) = uf2{c0v.z, c0v.w};
-      *reinterpret_cast<uf2*>(o + PP) = uf2{r[1].x, r[1].y}; *reinterpret_cast<uf2*>(o + PP + 2) = uf2{r[1].z, r[1].w};
-      *reinterpret_cast<uf2*>(o + 2 * PP) = uf2{c2v.x, c2v.y}; *reinterpret_cast<uf2*>(o + 2 * PP + 2) = uf2{c2v.z, c2v.w};
+        for (int i = 0; i < 4; ++i)
+          if (!(okyx && ((okz >> i) & 1))) r[i] = uf2{0.f, 0.f};
+      }
+      if (tid < 288) {
+#pragma unroll
+        for (int tzq = 0; tzq < 2; ++tzq) {       // tile z: rows tzq, tzq + 1, tzq + 2
+          *reinterpret_cast<uf2*>(o + (tzq * 3 + 0) * PP + 2 * hh) = r[tzq] - r[tzq + 1];
+          *reinterpret_cast<uf2*>(o + (tzq * 3 + 1) * PP + 2 * hh) = r[tzq + 1];
+          *reinterpret_cast<uf2*>(o + (tzq * 3 + 2) * PP + 2 * hh) = r[tzq + 2] - r[tzq + 1];
+        }
+      }
     }
   };
 
@@ -186,26 +191,43 @@ __global__ __launch_bounds__(512) void conv_up3_kernel(const float* __restrict__
   float wx[3];
 #pragma unroll
   for (int f = 0; f < 3; ++f) wx[f] = wloadx(0, f);
-  uf4 accx[3];
+  uf4 accx[2][3];
 #pragma unroll
-  for (int f = 0; f < 3; ++f) accx[f] = uf4{0.f, 0.f, 0.f, 0.f};
-  float ux[3], tx3[3], qxa, qxb;
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int f = 0; f < 3; ++f) accx[h][f] = uf4{0.f, 0.f, 0.f, 0.f};
+  float ux[2][3], tx3[2][3], qxa[2], qxb[2];
 
-  uf4 acc[3][4];                                 // [fx][column block]
+  uf4 acc[2][3][4];                              // [voxel half][fx][column block]
 #pragma unroll
-  for (int f = 0; f < 3; ++f)
+  for (int h = 0; h < 2; ++h)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[f][j] = uf4{0.f, 0.f, 0.f, 0.f};
+    for (int f = 0; f < 3; ++f)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[h][f][j] = uf4{0.f, 0.f, 0.f, 0.f};
 
-  float u[3], tn[3], qa, qb;
+  float u[2][3], tn[2][3], qa[2], qb[2];
   auto rd = [&](const int sub, const int col, auto xt) {
     const int off = col * VX + 4 * sub;          // compile-time after unrolling
-    qa = lds[Ra + off]; qb = lds[Rb + off];
-    if (decltype(xt)::value) { qxa = lds[Rxa + off]; qxb = lds[Rxb + off]; }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                // second half: two low-res rows further
+      qa[h] = lds[Ra + off + h * 2 * RP]; qb[h] = lds[Rb + off + h * 2 * RP];
+      if (decltype(xt)::value) { qxa[h] = lds[Rxa + off + h * 2 * RP]; qxb[h] = lds[Rxb + off + h * 2 * RP]; }
+    }
+  };
+  auto tstep = [&](const int g, auto xt) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      tn[h][g] = fmaf(sa, qa[h], -qb[h]);
+      if (decltype(xt)::value) tx3[h][g] = qxa[h] - qxb[h];     // fy = 2: r2 - r1
+    }
   };
   auto xform = [&](auto xt) {
-    u[0] = tn[0] - tn[1]; u[1] = tn[1]; u[2] = tn[2] - tn[1];
-    if (decltype(xt)::value) { ux[0] = tx3[0] - tx3[1]; ux[1] = tx3[1]; ux[2] = tx3[2] - tx3[1]; }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      u[h][0] = tn[h][0] - tn[h][1]; u[h][1] = tn[h][1]; u[h][2] = tn[h][2] - tn[h][1];
+      if (decltype(xt)::value) { ux[h][0] = tx3[h][0] - tx3[h][1]; ux[h][1] = tx3[h][1]; ux[h][2] = tx3[h][2] - tx3[h][1]; }
+    }
   };
 
   hload(0);
@@ -215,8 +237,7 @@ __global__ __launch_bounds__(512) void conv_up3_kernel(const float* __restrict__
 #pragma unroll
   for (int g = 0; g < 3; ++g) {
     rd(0, g, std::true_type{});
-    tn[g] = fmaf(sa, qa, -qb);
-    tx3[g] = qxa - qxb;                          // fy = 2: r2 - r1
+    tstep(g, std::true_type{});
   }
   xform(std::true_type{});
   rd(1, 0, std::true_type{});                    // column 0 of sub-step 1
@@ -237,8 +258,7 @@ __global__ __launch_bounds__(512) void conv_up3_kernel(const float* __restrict__
       gs = gs < nsub ? gs : nsub - 1;
 #pragma unroll
       for (int g = 0; g < 3; ++g) {
-        tn[g] = fmaf(sa, qa, -qb);               // column g of sub-step s+1, read one column ago
-        if (XT) tx3[g] = qxa - qxb;
+        tstep(g, xt);                            // column g of sub-step s+1, read one column ago
         if (ST && s == 6 && g == 2) {            // the next chunk must be visible before its first column is read
           hstore(nxt, cn);
           __syncthreads();
@@ -248,9 +268,14 @@ __global__ __launch_bounds__(512) void conv_up3_kernel(const float* __restrict__
         else rd((s + 2) & 7, 0, xt);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[g], wreg[g][j], acc[g][j], 0, 0, 0);
-        if (XT) accx[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ux[g], wx[g], accx[g], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) {
+          acc[0][g][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[0][g], wreg[g][j], acc[0][g][j], 0, 0, 0);
+          acc[1][g][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[1][g], wreg[g][j], acc[1][g][j], 0, 0, 0);
+        }
+        if (XT) {
+          accx[0][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ux[0][g], wx[g], accx[0][g], 0, 0, 0);
+          accx[1][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ux[1][g], wx[g], accx[1][g], 0, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
         wreg[g] = wload(gs, g);
         if (XT) wx[g] = wloadx(gs, g);
@@ -269,72 +294,75 @@ __global__ __launch_bounds__(512) void conv_up3_kernel(const float* __restrict__
   }
 
   // ---------------------------------------------------------------- epilogue, two passes of two column blocks each
-  // lane l holds P[voxel = 4 kq + i][n = l & 15] for its (fz, fy) and fx = 0..2.  fx -> dx in registers (dx0 = P0 + P1,
+  // lane l holds P[voxel = 16 h + 4 kq + i][n = l & 15] for its (fz, fy) and fx = 0..2.  fx -> dx in registers (dx0 = P0 + P1,
   // dx1 = P1 + P2); fy -> dy and fz -> dz across the waves through LDS: output (dz, dy, dx) = sum over fz in {dz, dz+1},
   // fy in {dy, dy+1}.
-  // [9 w][16 slots = (i * 2 + dx) * 2 + jl][64 lanes + 16]: slot pitch 80 with jl as the lowest slot bit, so that the
+  // [9 w][32 slots = ((h * 4 + i) * 2 + dx) * 2 + jl][64 lanes + 16]: slot pitch 80 with jl as the lowest slot bit, so that the
   // eight lanes of a 16-byte read group (cq, jl) hit eight different bank groups (conv_wino64.hip has the arithmetic)
-  constexpr int PS = 80, PW = 16 * PS;
+  constexpr int PS = 80, PW = 32 * PS;
   float* part = lds;
   const int cq = tid & 3, jl = (tid >> 2) & 1, o = (tid >> 3) & 3, tile = (tid >> 5) & 15;
   const int dyo = o >> 1, dxo = o & 1;
   const int ttz = tile >> 3, tty = (tile >> 2) & 1, ttx = tile & 3;
   const int vz = 2 * (oz + ttz), vy = 2 * (oy + tty) + dyo, vx = 2 * (ox + ttx) + dxo;
-  const size_t vox0 = (((size_t)b * S + vz) * S + vy) * S + vx;
+  const size_t vox0 = (((size_t)b * S + vz) * S + vy) * S + vx;         // half h: + 4 fine rows
   const int slot_rd = ((ttx * 2 + dxo) * 2 + jl) * PS + (tile >> 2) * 16 + cq * 4;
-  uf4 val[2][2];
-  uf4 csum[2];
+  uf4 val[2][2][2];                              // [pass][half][dz]
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     __syncthreads();
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-      const int j = pass * 2 + jj;
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        part[w * PW + ((i * 2 + 0) * 2 + jj) * PS + lane] = acc[0][j][i] + acc[1][j][i];
-        part[w * PW + ((i * 2 + 1) * 2 + jj) * PS + lane] = acc[1][j][i] + acc[2][j][i];
+      for (int jj = 0; jj < 2; ++jj) {
+        const int j = pass * 2 + jj;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          part[w * PW + (((h * 4 + i) * 2 + 0) * 2 + jj) * PS + lane] = acc[h][0][j][i] + acc[h][1][j][i];
+          part[w * PW + (((h * 4 + i) * 2 + 1) * 2 + jj) * PS + lane] = acc[h][1][j][i] + acc[h][2][j][i];
+        }
       }
-    }
     if (extra && (w >> 1) == pass) {             // pair (2, 2), column block w
       const int jj = w & 1;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        part[8 * PW + ((i * 2 + 0) * 2 + jj) * PS + lane] = accx[0][i] + accx[1][i];
-        part[8 * PW + ((i * 2 + 1) * 2 + jj) * PS + lane] = accx[1][i] + accx[2][i];
-      }
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          part[8 * PW + (((h * 4 + i) * 2 + 0) * 2 + jj) * PS + lane] = accx[h][0][i] + accx[h][1][i];
+          part[8 * PW + (((h * 4 + i) * 2 + 1) * 2 + jj) * PS + lane] = accx[h][1][i] + accx[h][2][i];
+        }
     }
     __syncthreads();
     {
       const int nn = n0 + (pass * 2 + jl) * 16 + cq * 4;           // this thread's four output channels
-      uf4 r[3];                                  // sum over fy in {dy, dy+1} for fz = 0, 1, 2
-#pragma unroll
-      for (int z = 0; z < 3; ++z)
-        r[z] = *reinterpret_cast<const uf4*>(&part[(z * 3 + dyo) * PW + slot_rd]) +
-               *reinterpret_cast<const uf4*>(&part[(z * 3 + dyo + 1) * PW + slot_rd]);
       uf4 bv = {0.f, 0.f, 0.f, 0.f};
       if (bias != nullptr) bv = *reinterpret_cast<const uf4*>(bias + nn);
-      const size_t o0 = vox0 * ldo + nn;
-      const size_t o1 = o0 + (size_t)S * S * ldo;
-      uf4 e0 = r[0] + r[1] + bv, e1 = r[1] + r[2] + bv;
-      if (accumulate) {
-        e0 += *reinterpret_cast<const uf4*>(y + o0);
-        e1 += *reinterpret_cast<const uf4*>(y + o1);
-      }
-      e0.x = uact(e0.x, pre_slope); e0.y = uact(e0.y, pre_slope); e0.z = uact(e0.z, pre_slope); e0.w = uact(e0.w, pre_slope);
-      e1.x = uact(e1.x, pre_slope); e1.y = uact(e1.y, pre_slope); e1.z = uact(e1.z, pre_slope); e1.w = uact(e1.w, pre_slope);
-      *reinterpret_cast<uf4*>(y + o0) = e0;
-      *reinterpret_cast<uf4*>(y + o1) = e1;
-      if (STATS) {
-        val[pass][0] = e0; val[pass][1] = e1;
-        csum[pass] = e0 + e1;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        uf4 r[3];                                // sum over fy in {dy, dy+1} for fz = 0, 1, 2
+#pragma unroll
+        for (int z = 0; z < 3; ++z)
+          r[z] = *reinterpret_cast<const uf4*>(&part[(z * 3 + dyo) * PW + h * 16 * PS + slot_rd]) +
+                 *reinterpret_cast<const uf4*>(&part[(z * 3 + dyo + 1) * PW + h * 16 * PS + slot_rd]);
+        const size_t o0 = (vox0 + (size_t)h * 4 * S) * ldo + nn;
+        const size_t o1 = o0 + (size_t)S * S * ldo;
+        uf4 e0 = r[0] + r[1] + bv, e1 = r[1] + r[2] + bv;
+        if (accumulate) {
+          e0 += *reinterpret_cast<const uf4*>(y + o0);
+          e1 += *reinterpret_cast<const uf4*>(y + o1);
+        }
+        e0.x = uact(e0.x, pre_slope); e0.y = uact(e0.y, pre_slope); e0.z = uact(e0.z, pre_slope); e0.w = uact(e0.w, pre_slope);
+        e1.x = uact(e1.x, pre_slope); e1.y = uact(e1.y, pre_slope); e1.z = uact(e1.z, pre_slope); e1.w = uact(e1.w, pre_slope);
+        *reinterpret_cast<uf4*>(y + o0) = e0;
+        *reinterpret_cast<uf4*>(y + o1) = e1;
+        if (STATS) { val[pass][h][0] = e0; val[pass][h][1] = e1; }
       }
     }
   }
   if (!STATS) return;
 
-  // block-level (count, mean, M2) per column over the block's 128 fine voxels (conv_igemm.hip's layout
-  // [3][Npad][nblocks], block index fastest); the 512 reader threads are waves 0..7
+  // block-level (count, mean, M2) per column over the block's 256 fine voxels (conv_igemm.hip's layout
+  // [3][Npad][nblocks], block index fastest); the 512 reader threads are waves 0..7, four voxels each per pass
   auto colreduce = [&](uf4 v) -> uf4 {
 #pragma unroll
     for (int d = 8; d < 64; d <<= 1) {
@@ -360,6 +388,9 @@ __global__ __launch_bounds__(512) void conv_up3_kernel(const float* __restrict__
     return sacc;
   };
   const size_t nstat = gridDim.x / nchunks;
+  uf4 csum[2];
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) csum[pass] = (val[pass][0][0] + val[pass][0][1]) + (val[pass][1][0] + val[pass][1][1]);
   put(csum);
   if (tid < 64) red[512 + tid] = sum8(tid) * (1.f / kRows);
   __syncthreads();
@@ -367,8 +398,12 @@ __global__ __launch_bounds__(512) void conv_up3_kernel(const float* __restrict__
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     const uf4 mu = *reinterpret_cast<const uf4*>(&red[512 + pass * 32 + cidx]);
-    const uf4 d0 = val[pass][0] - mu, d1 = val[pass][1] - mu;
-    qs[pass] = d0 * d0 + d1 * d1;
+    uf4 qacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int dzz = 0; dzz < 2; ++dzz) { const uf4 dd = val[pass][h][dzz] - mu; qacc += dd * dd; }
+    qs[pass] = qacc;
   }
   float mean_t = 0.f;
   if (tid < 64) mean_t = red[512 + tid];
@@ -385,7 +420,7 @@ __global__ __launch_bounds__(512) void conv_up3_kernel(const float* __restrict__
 // g: geometry of the LOW-RES problem as geom_par_fwd gives it (S = low-res extent, Cin = Cu, Cout)
 bool conv_up3_ok(const ConvGeom& g, const ConvSrc& s) {
   if (g.flags & (CF_NO_UPSPLIT | CF_NO_UP3)) return false;
-  if (g.S < 4 || s.up || s.bcast || s.C != g.Cin) return false;
+  if (g.S < 4 || g.S % 4 != 0 || s.up || s.bcast || s.C != g.Cin) return false;     // g.S: the LOW-RES side
   if (g.Cin % KC != 0 || g.Cin > 1024 || g.Cout % 64 != 0) return false;
   if ((long long)g.B * g.S * g.S * g.S * 8ll * (long long)std::max(g.Cin, g.Cout) >= (1ll << 29)) return false;   // byte offsets
   return true;
@@ -397,7 +432,7 @@ int launch_conv_fwd_up3(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, co
   ICS_CHECK(ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (reinterpret_cast<uintptr_t>(bias) & 15) == 0 &&
                 (reinterpret_cast<uintptr_t>(s0.p) & 15) == 0,
             "upsampled-input kernel: float4 accesses need 16-byte aligned tensors");
-  const unsigned grid = (unsigned)(g.B * (g.S / 2) * (g.S / 2) * (g.S / 4) * (g.Cout / 64));
+  const unsigned grid = (unsigned)(g.B * (g.S / 2) * (g.S / 4) * (g.S / 4) * (g.Cout / 64));
   if (stat_blocks) *stat_blocks = (int)(grid / (unsigned)(g.Cout / 64));
   const bool aff = s0.scale != nullptr, noact = s0.act == ACT_NONE;
   const float in_slope = uslope(s0.act), pre_slope = uslope(pre_act);
