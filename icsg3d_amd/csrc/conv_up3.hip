@@ -36,8 +36,10 @@ typedef float uf2 __attribute__((ext_vector_type(2)));
 
 namespace {
 constexpr int KC = 32;                                   // input channels per LDS chunk
-constexpr int VX = 34, RP = 208, PP = 1256, BUF = 6 * PP; // floats; one buffer = 30 144 B
-constexpr int kRows = 256;                               // fine voxels per workgroup
+#ifndef ICS_UP3_BIG_MIN_WG
+#define ICS_UP3_BIG_MIN_WG 256                           // workgroups of the 32-voxel tile below which the 16-voxel one runs
+#endif
+constexpr int VX = 34, RP = 208;                         // floats; plane pitch and buffer size depend on the tile (kernel)
 
 __device__ __forceinline__ float uact(float v, float slope) { return fmaxf(v, v * slope); }
 __host__ __device__ __forceinline__ float uslope(int act) { return act == ACT_RELU ? 0.f : (act == ACT_LRELU ? kLeaky : 1.f); }
@@ -52,7 +54,9 @@ __host__ __device__ __forceinline__ float uslope(int act) { return act == ACT_RE
 // layout below with the extra work under wave-uniform branches INSIDE the loop 1.39 (conservative waits at every join);
 // with the two roles as two straight-line copies of the loop behind one branch: 1.24; 32 instead of 16 voxels per
 // workgroup on top (half the weight traffic, halo 4.5 instead of 6 positions per voxel, one epilogue per 32): 1.15.
-template <bool AFF, bool NOACT, bool STATS>
+// NH: 16-voxel halves per workgroup -- 2 (2x4x4 low-res voxels) or 1 (2x2x4, for launches that would not fill the chip
+// with the large tile: the S = 4 layers and the VAE decoder).
+template <bool AFF, bool NOACT, bool STATS, int NH>
 __global__ __launch_bounds__(512) void conv_up3_kernel(const float* __restrict__ x, int ldx,
                                                           const float* __restrict__ in_scale,
                                                           const float* __restrict__ in_shift, float in_slope,
@@ -60,7 +64,12 @@ __global__ __launch_bounds__(512) void conv_up3_kernel(const float* __restrict__
                                                           float* __restrict__ y, int ldo, float pre_slope, int accumulate,
                                                           float* __restrict__ stat_partial, int Npad, int Sl, int Cin,
                                                           int Cout) {
-  __shared__ __attribute__((aligned(16))) float lds[9 * 32 * 80];   // 92 160 B: two buffers (60 288 B); the epilogue's [9][32][80]
+  constexpr int HY = 2 + 2 * NH;                 // halo rows in y
+  constexpr int PP = HY * RP + 8, BUF = 6 * PP;  // plane pitch 1256 / 840: 3 PP = 24 mod 32 either way
+  constexpr int NST = HY * 6 * 8;                // staging threads: 288 / 192
+  constexpr int kRows = 128 * NH;                // fine voxels per workgroup
+  // NH = 2: 92 160 B -- two buffers (60 288 B), the epilogue's [9][32][80]; NH = 1: 46 080 B
+  __shared__ __attribute__((aligned(16))) float lds[9 * 16 * NH * 80];
   __shared__ unsigned park[3 * 512];
   __shared__ __attribute__((aligned(16))) float aff[AFF ? 2048 : 4];
   __shared__ float red[9 * 64];
@@ -78,17 +87,17 @@ __global__ __launch_bounds__(512) void conv_up3_kernel(const float* __restrict__
   const int nb = blockIdx.x % nchunks;
   const int tblk = blockIdx.x / nchunks;
   int tb = tblk;
-  const int nbx = Sl >> 2, nby = Sl >> 2, nbz = Sl >> 1;
+  const int nbx = Sl >> 2, nby = Sl >> NH, nbz = Sl >> 1;
   const int bx = tb % nbx; tb /= nbx;
   const int by = tb % nby; tb /= nby;
   const int bz = tb % nbz;
   const int b = tb / nbz;
-  const int oz = bz * 2, oy = by * 4, ox = bx * 4, n0 = nb * 64;      // low-res origin of the block (2 x 4 x 4 voxels)
+  const int oz = bz * 2, oy = by * 2 * NH, ox = bx * 4, n0 = nb * 64; // low-res origin of the block (2 x 2 NH x 4 voxels)
   const bool edge = bx == 0 || by == 0 || bz == 0 || bx == nbx - 1 || by == nby - 1 || bz == nbz - 1;   // uniform
   const int S = 2 * Sl;
 
-  // ---- staging: thread t < 288 owns (hy, hx, channel quad) of the halo [4][6][6]: four z rows in, six planes out
-  const int cmb = tid < 288 ? tid : 287;
+  // ---- staging: thread t < NST owns (hy, hx, channel quad) of the halo [4][HY][6]: four z rows in, six planes out
+  const int cmb = tid < NST ? tid : NST - 1;
   const int q = cmb & 7, hx = (cmb >> 3) % 6, hy = (cmb >> 3) / 6;
   uf4 hs[4];
   unsigned zoff[4];                              // uniform: byte offset of sample b, low-res plane clamp(oz - 1 + hz)
@@ -150,7 +159,7 @@ __global__ __launch_bounds__(512) void conv_up3_kernel(const float* __restrict__
         for (int i = 0; i < 4; ++i)
           if (!(okyx && ((okz >> i) & 1))) r[i] = uf2{0.f, 0.f};
       }
-      if (tid < 288) {
+      if (tid < NST) {
 #pragma unroll
         for (int tzq = 0; tzq < 2; ++tzq) {       // tile z: rows tzq, tzq + 1, tzq + 2
           *reinterpret_cast<uf2*>(o + (tzq * 3 + 0) * PP + 2 * hh) = r[tzq] - r[tzq + 1];
@@ -191,40 +200,40 @@ __global__ __launch_bounds__(512) void conv_up3_kernel(const float* __restrict__
   float wx[3];
 #pragma unroll
   for (int f = 0; f < 3; ++f) wx[f] = wloadx(0, f);
-  uf4 accx[2][3];
+  uf4 accx[NH][3];
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+  for (int h = 0; h < NH; ++h)
 #pragma unroll
     for (int f = 0; f < 3; ++f) accx[h][f] = uf4{0.f, 0.f, 0.f, 0.f};
-  float ux[2][3], tx3[2][3], qxa[2], qxb[2];
+  float ux[NH][3], tx3[NH][3], qxa[NH], qxb[NH];
 
-  uf4 acc[2][3][4];                              // [voxel half][fx][column block]
+  uf4 acc[NH][3][4];                             // [voxel half][fx][column block]
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+  for (int h = 0; h < NH; ++h)
 #pragma unroll
     for (int f = 0; f < 3; ++f)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[h][f][j] = uf4{0.f, 0.f, 0.f, 0.f};
 
-  float u[2][3], tn[2][3], qa[2], qb[2];
+  float u[NH][3], tn[NH][3], qa[NH], qb[NH];
   auto rd = [&](const int sub, const int col, auto xt) {
     const int off = col * VX + 4 * sub;          // compile-time after unrolling
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {                // second half: two low-res rows further
+    for (int h = 0; h < NH; ++h) {                // second half: two low-res rows further
       qa[h] = lds[Ra + off + h * 2 * RP]; qb[h] = lds[Rb + off + h * 2 * RP];
       if (decltype(xt)::value) { qxa[h] = lds[Rxa + off + h * 2 * RP]; qxb[h] = lds[Rxb + off + h * 2 * RP]; }
     }
   };
   auto tstep = [&](const int g, auto xt) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NH; ++h) {
       tn[h][g] = fmaf(sa, qa[h], -qb[h]);
       if (decltype(xt)::value) tx3[h][g] = qxa[h] - qxb[h];     // fy = 2: r2 - r1
     }
   };
   auto xform = [&](auto xt) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NH; ++h) {
       u[h][0] = tn[h][0] - tn[h][1]; u[h][1] = tn[h][1]; u[h][2] = tn[h][2] - tn[h][1];
       if (decltype(xt)::value) { ux[h][0] = tx3[h][0] - tx3[h][1]; ux[h][1] = tx3[h][1]; ux[h][2] = tx3[h][2] - tx3[h][1]; }
     }
@@ -269,12 +278,14 @@ __global__ __launch_bounds__(512) void conv_up3_kernel(const float* __restrict__
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          acc[0][g][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[0][g], wreg[g][j], acc[0][g][j], 0, 0, 0);
-          acc[1][g][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[1][g], wreg[g][j], acc[1][g][j], 0, 0, 0);
+#pragma unroll
+          for (int h = 0; h < NH; ++h)
+            acc[h][g][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[h][g], wreg[g][j], acc[h][g][j], 0, 0, 0);
         }
         if (XT) {
-          accx[0][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ux[0][g], wx[g], accx[0][g], 0, 0, 0);
-          accx[1][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ux[1][g], wx[g], accx[1][g], 0, 0, 0);
+#pragma unroll
+          for (int h = 0; h < NH; ++h)
+            accx[h][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ux[h][g], wx[g], accx[h][g], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         wreg[g] = wload(gs, g);
@@ -299,7 +310,7 @@ __global__ __launch_bounds__(512) void conv_up3_kernel(const float* __restrict__
   // fy in {dy, dy+1}.
   // [9 w][32 slots = ((h * 4 + i) * 2 + dx) * 2 + jl][64 lanes + 16]: slot pitch 80 with jl as the lowest slot bit, so that the
   // eight lanes of a 16-byte read group (cq, jl) hit eight different bank groups (conv_wino64.hip has the arithmetic)
-  constexpr int PS = 80, PW = 32 * PS;
+  constexpr int PS = 80, PW = 16 * NH * PS;
   float* part = lds;
   const int cq = tid & 3, jl = (tid >> 2) & 1, o = (tid >> 3) & 3, tile = (tid >> 5) & 15;
   const int dyo = o >> 1, dxo = o & 1;
@@ -307,12 +318,12 @@ __global__ __launch_bounds__(512) void conv_up3_kernel(const float* __restrict__
   const int vz = 2 * (oz + ttz), vy = 2 * (oy + tty) + dyo, vx = 2 * (ox + ttx) + dxo;
   const size_t vox0 = (((size_t)b * S + vz) * S + vy) * S + vx;         // half h: + 4 fine rows
   const int slot_rd = ((ttx * 2 + dxo) * 2 + jl) * PS + (tile >> 2) * 16 + cq * 4;
-  uf4 val[2][2][2];                              // [pass][half][dz]
+  uf4 val[2][NH][2];                             // [pass][half][dz]
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     __syncthreads();
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < NH; ++h)
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
         const int j = pass * 2 + jj;
@@ -325,7 +336,7 @@ __global__ __launch_bounds__(512) void conv_up3_kernel(const float* __restrict__
     if (extra && (w >> 1) == pass) {             // pair (2, 2), column block w
       const int jj = w & 1;
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+      for (int h = 0; h < NH; ++h)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           part[8 * PW + (((h * 4 + i) * 2 + 0) * 2 + jj) * PS + lane] = accx[h][0][i] + accx[h][1][i];
@@ -338,7 +349,7 @@ __global__ __launch_bounds__(512) void conv_up3_kernel(const float* __restrict__
       uf4 bv = {0.f, 0.f, 0.f, 0.f};
       if (bias != nullptr) bv = *reinterpret_cast<const uf4*>(bias + nn);
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
+      for (int h = 0; h < NH; ++h) {
         uf4 r[3];                                // sum over fy in {dy, dy+1} for fz = 0, 1, 2
 #pragma unroll
         for (int z = 0; z < 3; ++z)
@@ -390,7 +401,10 @@ __global__ __launch_bounds__(512) void conv_up3_kernel(const float* __restrict__
   const size_t nstat = gridDim.x / nchunks;
   uf4 csum[2];
 #pragma unroll
-  for (int pass = 0; pass < 2; ++pass) csum[pass] = (val[pass][0][0] + val[pass][0][1]) + (val[pass][1][0] + val[pass][1][1]);
+  for (int pass = 0; pass < 2; ++pass) {
+    csum[pass] = val[pass][0][0] + val[pass][0][1];
+    if (NH == 2) csum[pass] += val[pass][NH - 1][0] + val[pass][NH - 1][1];
+  }
   put(csum);
   if (tid < 64) red[512 + tid] = sum8(tid) * (1.f / kRows);
   __syncthreads();
@@ -400,7 +414,7 @@ __global__ __launch_bounds__(512) void conv_up3_kernel(const float* __restrict__
     const uf4 mu = *reinterpret_cast<const uf4*>(&red[512 + pass * 32 + cidx]);
     uf4 qacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < NH; ++h)
 #pragma unroll
       for (int dzz = 0; dzz < 2; ++dzz) { const uf4 dd = val[pass][h][dzz] - mu; qacc += dd * dd; }
     qs[pass] = qacc;
@@ -432,16 +446,25 @@ int launch_conv_fwd_up3(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, co
   ICS_CHECK(ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (reinterpret_cast<uintptr_t>(bias) & 15) == 0 &&
                 (reinterpret_cast<uintptr_t>(s0.p) & 15) == 0,
             "upsampled-input kernel: float4 accesses need 16-byte aligned tensors");
-  const unsigned grid = (unsigned)(g.B * (g.S / 2) * (g.S / 4) * (g.S / 4) * (g.Cout / 64));
+  // 32-voxel workgroups when they still give every CU several (c17.up 4096, c15.up 1024); 16-voxel ones below that
+  const unsigned grid32 = (unsigned)(g.B * (g.S / 2) * (g.S / 4) * (g.S / 4) * (g.Cout / 64));
+  const bool big = grid32 >= (unsigned)ICS_UP3_BIG_MIN_WG;
+  const unsigned grid = big ? grid32 : 2u * grid32;
   if (stat_blocks) *stat_blocks = (int)(grid / (unsigned)(g.Cout / 64));
   const bool aff = s0.scale != nullptr, noact = s0.act == ACT_NONE;
   const float in_slope = uslope(s0.act), pre_slope = uslope(pre_act);
 #define ICS_UP3_LAUNCH(AFFV, NOACTV, STATSV)                                                                      \
   do {                                                                                                            \
-    hipLaunchKernelGGL((conv_up3_kernel<AFFV, NOACTV, STATSV>), dim3(grid), dim3(512), 0, st, s0.p, s0.C,          \
-                       s0.scale, s0.shift, in_slope, wt, bias, out, ldo, pre_slope, accumulate, stat_partial,     \
-                       g.Npad, g.S, g.Cin, g.Cout);                                                               \
-    conv_set_last_kernel_id("conv_up3_kernel<" #AFFV ", " #NOACTV ", " #STATSV ">");                              \
+    if (big)                                                                                                      \
+      hipLaunchKernelGGL((conv_up3_kernel<AFFV, NOACTV, STATSV, 2>), dim3(grid), dim3(512), 0, st, s0.p, s0.C,     \
+                         s0.scale, s0.shift, in_slope, wt, bias, out, ldo, pre_slope, accumulate, stat_partial,   \
+                         g.Npad, g.S, g.Cin, g.Cout);                                                             \
+    else                                                                                                          \
+      hipLaunchKernelGGL((conv_up3_kernel<AFFV, NOACTV, STATSV, 1>), dim3(grid), dim3(512), 0, st, s0.p, s0.C,     \
+                         s0.scale, s0.shift, in_slope, wt, bias, out, ldo, pre_slope, accumulate, stat_partial,   \
+                         g.Npad, g.S, g.Cin, g.Cout);                                                             \
+    conv_set_last_kernel_id(big ? "conv_up3_kernel<" #AFFV ", " #NOACTV ", " #STATSV ", 2>"                         \
+                                : "conv_up3_kernel<" #AFFV ", " #NOACTV ", " #STATSV ", 1>");                       \
   } while (0)
   if (stat_partial) {
     if (!aff) ICS_UP3_LAUNCH(false, true, true);
