@@ -561,21 +561,37 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(const float* __res
       e1[d] = *reinterpret_cast<const wf2*>(&lds[YB + oy + 32]);
     }
   };
-  float t0[4], t1[4], rl[2], rh[2];
+  // The transforms run on PACKED fp32 (v_pk_add_f32 / v_pk_fma_f32: two values per lane and instruction at the scalar
+  // rate -- fp32 VALU shares the issue port with the MFMAs, so every instruction saved is matrix time): the x pairs as
+  // read, op_sel / neg modifiers for the butterflies, 16 instead of 32 instructions per k-step.  The fx = 3 row of B^T
+  // comes out negated (t3 - t1) -- which cancels the missing negation of A's last row on the dy side.
+  wf2 t0p[2], t1p[2], rlp, rhp;
+  const wf2 sg2 = {sg, sg}, ca2 = {ca, ca}, cb2 = {cb, cb}, a12 = {a1, a1}, b02 = {b0, b0};   // wave-uniform: SGPR pairs
+  // (hipcc scalarises most of the same expressions written on float2 values: 767 VALU per 128 MFMAs instead of 688)
+#define ICS_PK2(out, text, A, B) asm(text : "=v"(out) : "v"(A), "v"(B))
+  auto pk_fma_s = [&](wf2 sc, wf2 x, wf2 y) { wf2 r; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "s"(sc), "v"(x), "v"(y)); return r; };
+  auto pk_mul_s = [&](wf2 sc, wf2 x) { wf2 r; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "s"(sc), "v"(x)); return r; };
   auto tr_y = [&](int j) {             // x pair j: columns 2j, 2j+1
-    t0[2 * j] = xa[j].x - xb2[j].x; t0[2 * j + 1] = xa[j].y - xb2[j].y;
-    t1[2 * j] = fmaf(sg, xc[j].x, xb2[j].x); t1[2 * j + 1] = fmaf(sg, xc[j].y, xb2[j].y);
+    ICS_PK2(t0p[j], "v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]", xa[j], xb2[j]);          // a - b
+    t1p[j] = pk_fma_s(sg2, xc[j], xb2[j]);                                                         // b + sg c
   };
-  auto tr_x = [&](const float* t, float* un) {
-    un[0] = t[0] - t[2]; un[1] = t[1] + t[2]; un[2] = t[2] - t[1]; un[3] = t[1] - t[3];
+  auto tr_x = [&](const wf2* t, float* un) {
+    wf2 lo, hi;
+    ICS_PK2(lo, "v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1]", t[0], t[1]);               // (t0 - t2, t1 + t2)
+    ICS_PK2(hi, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]", t[1], t[0]);  // (t2 - t1, t3 - t1)
+    un[0] = lo.x; un[1] = lo.y; un[2] = hi.x; un[3] = hi.y;                                        // un[3] = -(B^T d)_3
   };
   auto tr_d = [&]() {                  // dy: z rows then the wave's two y rows
-    const float g00 = fmaf(cb, e1[0].x, ca * e0[0].x), g01 = fmaf(cb, e1[0].y, ca * e0[0].y);   // dyy = 0: dx 0, 1
-    const float g10 = fmaf(cb, e1[1].x, ca * e0[1].x), g11 = fmaf(cb, e1[1].y, ca * e0[1].y);   // dyy = 1
-    rl[0] = fmaf(a1, g10, g00); rl[1] = fmaf(a1, g11, g01);
-    rh[0] = fmaf(b0, g00, g10); rh[1] = fmaf(b0, g01, g11);
+    const wf2 g0 = pk_fma_s(cb2, e1[0], pk_mul_s(ca2, e0[0]));             // dyy = 0: dx 0, 1
+    const wf2 g1 = pk_fma_s(cb2, e1[1], pk_mul_s(ca2, e0[1]));             // dyy = 1
+    rlp = pk_fma_s(a12, g1, g0);
+    rhp = pk_fma_s(b02, g0, g1);
   };
-  auto tr_v = [&](const float* r, float* vn) { vn[0] = r[0]; vn[1] = r[0] + r[1]; vn[2] = r[0] - r[1]; vn[3] = r[1]; };
+  auto tr_v = [&](const wf2 r, float* vn) {
+    wf2 m;
+    ICS_PK2(m, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]", r, r);        // (r0 + r1, r0 - r1)
+    vn[0] = r.x; vn[1] = m.x; vn[2] = m.y; vn[3] = r.y;
+  };
 
   // per_split is even and every split is full (launcher): no conditional blocks -- a conditional one makes the
   // register allocator spill the accumulators
@@ -583,7 +599,7 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(const float* __res
   sstore(0);
   __syncthreads();
   rd(0, 0);
-  tr_y(0); tr_y(1); tr_x(t0, u[0]); tr_x(t1, u[0] + 4); tr_d(); tr_v(rl, vv[0]); tr_v(rh, vv[0] + 4);
+  tr_y(0); tr_y(1); tr_x(t0p, u[0]); tr_x(t1p, u[0] + 4); tr_d(); tr_v(rlp, vv[0]); tr_v(rhp, vv[0] + 4);
   rd(0, 1);
   auto block = [&](const int blk, const int cur, const int nxt) {
 #if !(ICS_WG_ABL & 4)
@@ -621,7 +637,7 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(const float* __res
       // measured (ms of this kernel per U-Net step): these 24 ops interleaved with the MFMAs above 10.35, the whole
       // transform as a burst here 10.34, this split 9.8: the burst runs under the other wave's MFMAs
 #if !(ICS_WG_ABL & 1)
-      tr_x(t0, un); tr_x(t1, un + 4); tr_v(rl, vn); tr_v(rh, vn + 4);
+      tr_x(t0p, un); tr_x(t1p, un + 4); tr_v(rlp, vn); tr_v(rhp, vn + 4);
 #endif
       // raw reads two steps ahead: step p+2 of this block, or step (p+2)-8 of the next one.  At p == 5 the next block
       // is stored first (its arithmetic then runs without the raw-read registers live), and the barrier after BOTH:
@@ -659,7 +675,7 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(const float* __res
       for (int fy = 0; fy < 2; ++fy) {
         const float X0 = acc[fy * 4 + 0][r], X1 = acc[fy * 4 + 1][r], X2 = acc[fy * 4 + 2][r], X3 = acc[fy * 4 + 3][r];
         const float h1 = 0.5f * (X1 + X2), h2 = 0.5f * (X1 - X2);
-        yc[fy][0] = X0 + h1; yc[fy][1] = h2; yc[fy][2] = h1 - X3;
+        yc[fy][0] = X0 + h1; yc[fy][1] = h2; yc[fy][2] = h1 + X3;      // X3 carries its true sign (packed transform)
       }
 #pragma unroll
       for (int cc = 0; cc < 3; ++cc) {
