@@ -853,7 +853,7 @@ static int conv_backward(Net& n, ConvLayer& L, int B, GradSrc g0, GradSrc g1, co
   const size_t M = n.rows(L, B);
   const BwdPre pre{n.ws_bwd2, L.bwd_pre_nblk, L.bwd_pre_ld};
   L.bwd_pre_nblk = 0;
-  n.prof.begin(n.st, "bn_act_bwd", 0, 4.0 * M * L.Cout * (L.has_bn ? (pre.nblk ? 3.0 : 5.0) : 3.0));
+  n.prof.begin(n.st, "bn_act_bwd:" + L.name, 0, 4.0 * M * L.Cout * (L.has_bn ? (pre.nblk ? 3.0 : 5.0) : 3.0));
   ICS_TRY(launch_layer_bwd(n.st, lb, L.dy, n.ws_bwd, L.c1c2,
                            (param_grads && L.has_bn) ? n.tg(L.t_gamma) : nullptr,
                            (param_grads && L.has_bn) ? n.tg(L.t_beta) : nullptr,
