@@ -863,12 +863,17 @@ int launch_conv_fwd_wino(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, c
 // enough for ~2 workgroups per CU, large enough for the workspace.  A split is a contiguous range of the linear block
 // index (b, bz, by, bx) and may span samples: capping it at one sample's blocks (round 2) left the S = 8 layers with 32
 // splits of 4 blocks where 4 splits of 32 were wanted -- 8x the fixed cost and 8x the partial sums (c14: 0.62 ms).
+#ifndef ICS_WG_WANT
+#define ICS_WG_WANT 512
+#endif
 static int wino_wgrad_per_split(const ConvGeom& g, size_t ws_floats) {
   const int nblocks = g.B * (g.S / 4) * (g.S / 4) * (g.S / 8);
   const int pairs = (g.Cin / 32) * (g.Cout / 32);
-  // ~2 workgroups per CU (measured per U-Net step: 256 -> 36.96 ms, 512 -> 37.05, 1536 -> 37.15, 3072 -> 37.7; one
-  // round of workgroups would double the launch time whenever a communication kernel holds a few CUs)
-  const int want = std::max((512 + pairs - 1) / pairs, 1);          // splits wanted
+  // ~2 workgroups per CU (measured per U-Net step: 256 -> 36.96 ms, 512 -> 37.05, 1536 -> 37.15, 3072 -> 37.7 in round 2;
+  // 256 -> 30.5, 384 -> 30.5, 512 -> 30.66 at the end of round 3: one round is 0.5 % faster on an otherwise idle chip, but
+  // would double the launch time whenever a communication kernel holds a few CUs, and the split count fixes the
+  // summation order -- it must not depend on whether a communicator is attached, tests/test_gpu_dp.py compares bit for bit)
+  const int want = std::max((ICS_WG_WANT + pairs - 1) / pairs, 1);  // splits wanted
   const size_t per = (size_t)27 * g.Cin * g.Cout;
   int ps = 2;
   while (nblocks % (2 * ps) == 0 && ((nblocks / ps) > want || (size_t)(nblocks / ps) * per > ws_floats)) ps *= 2;
