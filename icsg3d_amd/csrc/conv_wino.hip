@@ -527,7 +527,7 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(const float* __res
     }
   };
 
-  // The same store in pieces, for the main loop: spread over the MFMA slots of k-steps 3..5 so that it runs under the
+  // The same store in pieces, for the main loop: spread over the MFMA slots of k-steps 2..5 so that it runs under the
   // matrix pipe instead of in front of the block's barrier
   wf4 sc4v = {1.f, 1.f, 1.f, 1.f}, sh4v = {0.f, 0.f, 0.f, 0.f};
   auto ss_pre = [&]() {
@@ -558,33 +558,15 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(const float* __res
     const int o = 2 * GXF + bo * GYF + (sq * 4) * GYP + spos + i * 64;
     lds[o] = ys[i].x; lds[o + GYP] = ys[i].y; lds[o + 2 * GYP] = ys[i].z; lds[o + 3 * GYP] = ys[i].w;
   };
-#ifndef ICS_WG_SS
-#define ICS_WG_SS 1
-#endif
-#ifndef ICS_WG_SY
-#define ICS_WG_SY 1
-#endif
-#ifndef ICS_WG_GL
-#define ICS_WG_GL 0
-#endif
-#ifndef ICS_WG_TRX
-#define ICS_WG_TRX 0
-#endif
+  // slot = the MFMA of k-step pp after which the piece is issued (slots 0..2 carry the y / dy transforms, slot 3 the
+  // operand reads).  Measured on top of this: everything one or two k-steps earlier +-0, the staging loads in a slot +-0
   auto ss_slot = [&](const int pp, const int slot, const int nxt) {
-#if ICS_WG_SS
-#ifndef ICS_WG_SHIFT
-#define ICS_WG_SHIFT 0
-#endif
-    constexpr int SH = ICS_WG_SHIFT;
-    if (pp == 2 - SH && slot == 7) ss_pre();
-    if (pp == 3 - SH && slot >= 4 && slot <= 6) { ss_aff(2 * (slot - 4)); ss_aff(2 * (slot - 4) + 1); }
-    if (pp == 4 - SH && slot >= 4) ss_x(nxt, 0, slot - 4);
-    if (pp == 5 - SH && slot >= 4) ss_x(nxt, 1, slot - 4);
-#if ICS_WG_SY
-    if (pp == 2 - SH && slot == 5) ss_y(nxt, 0);
-    if (pp == 2 - SH && slot == 6) ss_y(nxt, 1);
-#endif
-#endif
+    if (pp == 2 && slot == 5) ss_y(nxt, 0);
+    if (pp == 2 && slot == 6) ss_y(nxt, 1);
+    if (pp == 2 && slot == 7) ss_pre();
+    if (pp == 3 && slot >= 4 && slot <= 6) { ss_aff(2 * (slot - 4)); ss_aff(2 * (slot - 4) + 1); }
+    if (pp == 4 && slot >= 4) ss_x(nxt, 0, slot - 4);
+    if (pp == 5 && slot >= 4) ss_x(nxt, 1, slot - 4);
   };
 
   // ---- per-lane read bases.  x rows (a, b, c) of the wave's two fy rows:  fy = 2 fyh: R_a - R_b,  fy = 2 fyh + 1:
@@ -655,20 +637,18 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(const float* __res
 
   // per_split is even and every split is full (launcher): no conditional blocks -- a conditional one makes the
   // register allocator spill the accumulators
-#ifndef ICS_WG_PRIO
-#define ICS_WG_PRIO 0
-#endif
-#if ICS_WG_PRIO & 1
-  if (w < 4) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
-#endif
   gload(blk_lo);
   sstore(0);
   __syncthreads();
   rd(0, 0);
   tr_y(0); tr_y(1); tr_x(t0p, u[0]); tr_x(t1p, u[0] + 4); tr_d(); tr_v(rlp, vv[0]); tr_v(rhp, vv[0] + 4);
   rd(0, 1);
+#ifndef ICS_WG_ABL
+#define ICS_WG_ABL 0        // ablation (scripts/variants.sh): 1 no transforms / operand reads / staging stores, 4 no staging,
+                            // 8 no MFMA, 16 no barrier, 64 no staging loads
+#endif
   auto block = [&](const int blk, const int cur, const int nxt) {
-#if !(ICS_WG_ABL & (4 | 64)) && !ICS_WG_GL
+#if !(ICS_WG_ABL & (4 | 64))
     gload(blk + 1 < blk_hi ? blk + 1 : blk);             // past the end: this block again (never consumed)
 #endif
 #pragma unroll
@@ -679,10 +659,6 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(const float* __res
       // interleaved with this step's MFMAs (measured: doing it after them costs 15 %)
 #define ICS_GMF(F) acc[F] = __builtin_amdgcn_mfma_f32_32x32x2f32(uc[F], vc[F], acc[F], 0, 0, 0)
 #define ICS_GFN __builtin_amdgcn_sched_barrier(0)
-#ifndef ICS_WG_ABL
-#define ICS_WG_ABL 0        // ablation (scripts/variants.sh): 1 no transform VALU, 2 no LDS operand reads, 4 no staging, 8 no MFMA,
-                            // 16 no barrier, 32 no staging stores, 64 no staging loads
-#endif
 #if ICS_WG_ABL & 8
 #undef ICS_GMF
 #define ICS_GMF(F)
@@ -690,59 +666,28 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(const float* __res
 #if ICS_WG_ABL & 1
       ICS_GMF(0); ICS_GMF(4); ICS_GMF(1); ICS_GMF(5); ICS_GMF(2); ICS_GMF(6); ICS_GMF(3); ICS_GMF(7); ICS_GFN;
 #else
-      // one fence per MFMA, the y / dy math behind the first three (fence variants measured within 1 %)
-#if ICS_WG_PRIO & 2
-      __builtin_amdgcn_s_setprio(2);
-#endif
+      // One fence per MFMA.  Slots 0..2: the y / dy math of step p+1.  Slot 3: the raw reads of step p+2 (of this block,
+      // or step (p+2)-8 of the next one) -- the raw registers are free from here on, and the reads (ds_read2_b64, 8 LDS
+      // cycles each) complete under five MFMAs; at the end of the k-step, where they sat first, the next step's first
+      // transform waited for them (-3.2 %).  Slots 4..7: a piece of the next block's staging store (k-steps 2..5; as one
+      // burst in front of the barrier: +3.3 %).  s_setprio per wave or around the MFMAs: +-0.
       ICS_GMF(0); tr_y(0); ICS_GFN;
       ICS_GMF(4); tr_y(1); ICS_GFN;
-#if ICS_WG_TRX
-      ICS_GMF(1); tr_d(); tr_x(t0p, un); ICS_GFN;
-#else
       ICS_GMF(1); tr_d(); ICS_GFN;
-#endif
-#ifndef ICS_WG_RD
-#define ICS_WG_RD 1
-#endif
-#if ICS_WG_RD == 1 && ICS_WG_TRX
-      ICS_GMF(5); tr_x(t1p, un + 4); tr_v(rlp, vn); tr_v(rhp, vn + 4); if (p < 6) rd(cur, p + 2); else rd(nxt, p - 6); ICS_GFN;
-#elif ICS_WG_RD == 1
       ICS_GMF(5); if (p < 6) rd(cur, p + 2); else rd(nxt, p - 6); ICS_GFN;
-#else
-      ICS_GMF(5); ICS_GFN;
-#endif
-#if ICS_WG_GL
-      ICS_GMF(2); if (p == 0) gload(blk + 1 < blk_hi ? blk + 1 : blk); ss_slot(p, 4, nxt); ICS_GFN;
-#else
       ICS_GMF(2); ss_slot(p, 4, nxt); ICS_GFN;
-#endif
       ICS_GMF(6); ss_slot(p, 5, nxt); ICS_GFN;
       ICS_GMF(3); ss_slot(p, 6, nxt); ICS_GFN;
       ICS_GMF(7); ss_slot(p, 7, nxt); ICS_GFN;
-#if ICS_WG_PRIO & 2
-      __builtin_amdgcn_s_setprio(0);
-#endif
 #endif
 #undef ICS_GMF
-      // measured (ms of this kernel per U-Net step): these 24 ops interleaved with the MFMAs above 10.35, the whole
-      // transform as a burst here 10.34, this split 9.8: the burst runs under the other wave's MFMAs
-#if !(ICS_WG_ABL & 1) && !ICS_WG_TRX
+      // the x transform of step p+1 as a burst here: it runs under the other wave's MFMAs (in the slots above: +1.5 %)
+#if !(ICS_WG_ABL & 1)
       tr_x(t0p, un); tr_x(t1p, un + 4); tr_v(rlp, vn); tr_v(rhp, vn + 4);
 #endif
-      // raw reads two steps ahead: step p+2 of this block, or step (p+2)-8 of the next one.  At p == 5 the next block
-      // is stored first (its arithmetic then runs without the raw-read registers live), and the barrier after BOTH:
-      // every read of `cur` is issued before it, the next block is visible before step 6 reads its step 0
-#if !(ICS_WG_ABL & (4 | 32))
-#if ICS_WG_SS && ICS_WG_SY
-#elif ICS_WG_SS
-      if (p == 5) { ss_y(nxt, 0); ss_y(nxt, 1); }
-#else
-      if (p == 5) sstore(nxt);
-#endif
-#endif
-#if !(ICS_WG_ABL & 2) && ICS_WG_RD != 1
-      if (p < 6) rd(cur, p + 2); else rd(nxt, p - 6);
-#endif
+      // the barrier of the block: every read of `cur` is issued (slot 3 of step 5 was the last), the next block's last
+      // store (slot 7 of step 5) is behind us, and step 6 reads the next block's step 0.  No wave waits here any more
+      // (a build without the barrier: +-0)
 #if !(ICS_WG_ABL & (4 | 16))
       if (p == 5) __syncthreads();
 #endif
