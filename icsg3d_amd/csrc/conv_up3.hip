@@ -25,6 +25,7 @@
 // transform).
 #include "common.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 #include <algorithm>
@@ -448,7 +449,12 @@ int launch_conv_fwd_up3(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, co
             "upsampled-input kernel: float4 accesses need 16-byte aligned tensors");
   // 32-voxel workgroups when they still give every CU several (c17.up 4096, c15.up 1024); 16-voxel ones below that
   const unsigned grid32 = (unsigned)(g.B * (g.S / 2) * (g.S / 4) * (g.S / 4) * (g.Cout / 64));
-  const bool big = grid32 >= (unsigned)ICS_UP3_BIG_MIN_WG;
+  // ICSG3D_UP3_BIG_MIN_WG overrides the threshold (tests: 1 = the 32-voxel tile wherever the shape allows it)
+  static const unsigned big_min = [] {
+    const char* e = getenv("ICSG3D_UP3_BIG_MIN_WG");
+    return e && *e ? (unsigned)strtoul(e, nullptr, 10) : (unsigned)ICS_UP3_BIG_MIN_WG;
+  }();
+  const bool big = grid32 >= big_min;
   const unsigned grid = big ? grid32 : 2u * grid32;
   if (stat_blocks) *stat_blocks = (int)(grid / (unsigned)(g.Cout / 64));
   const bool aff = s0.scale != nullptr, noact = s0.act == ACT_NONE;
