@@ -805,19 +805,22 @@ int launch_conv_fwd_wino(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, c
 
 // ---------------------------------------------------------------- backward-weight launcher
 // blocks per workgroup: a power of two >= 2 that divides the number of blocks (every split full, even count), small
-// enough for ~2 workgroups per CU, large enough for the workspace.  A split is a contiguous range of the linear block
+// enough for ~1 workgroup per CU, large enough for the workspace.  A split is a contiguous range of the linear block
 // index (b, bz, by, bx) and may span samples: capping it at one sample's blocks (round 2) left the S = 8 layers with 32
 // splits of 4 blocks where 4 splits of 32 were wanted -- 8x the fixed cost and 8x the partial sums (c14: 0.62 ms).
 #ifndef ICS_WG_WANT
-#define ICS_WG_WANT 512
+#define ICS_WG_WANT 256
 #endif
 static int wino_wgrad_per_split(const ConvGeom& g, size_t ws_floats) {
   const int nblocks = g.B * (g.S / 4) * (g.S / 4) * (g.S / 8);
   const int pairs = (g.Cin / 32) * (g.Cout / 32);
-  // ~2 workgroups per CU (measured per U-Net step: 256 -> 36.96 ms, 512 -> 37.05, 1536 -> 37.15, 3072 -> 37.7 in round 2;
-  // 256 -> 30.5, 384 -> 30.5, 512 -> 30.66 at the end of round 3: one round is 0.5 % faster on an otherwise idle chip, but
-  // would double the launch time whenever a communication kernel holds a few CUs, and the split count fixes the
-  // summation order -- it must not depend on whether a communicator is attached, tests/test_gpu_dp.py compares bit for bit)
+  // Workgroups wanted per launch (one per CU; the kernel takes a whole CU).  Per U-Net step, round 2: 256 -> 36.96 ms,
+  // 512 -> 37.05, 1536 -> 37.15, 3072 -> 37.7; end of round 3: 256 -> 30.5, 384 -> 30.5, 512 -> 30.66 (half the
+  // epilogues and half the partial sums for reduce_splits: 0.32 -> 0.28 ms).  Round 2 kept 512 so that a communication
+  // kernel holding a few CUs costs a third round instead of a second; the gradient buckets (125 MB per step) are
+  // estimated to keep RCCL kernels live for a few per cent of a step, so that insurance buys less than the 0.15 ms it
+  // costs (single-rank communicator forced on: scripts/forcedist_bench.sh).  The split count fixes the
+  // summation order: it must not depend on whether a communicator is attached (tests/test_gpu_dp.py compares bit for bit).
   const int want = std::max((ICS_WG_WANT + pairs - 1) / pairs, 1);  // splits wanted
   const size_t per = (size_t)27 * g.Cin * g.Cout;
   int ps = 2;
