@@ -2207,34 +2207,51 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvGeom g, ConvSrc s0,
   };
 #if ICS_GEMM_DEEP
   if (gemm && VEC && TM * TN >= ICS_GEMM_DEEP_MIN) {
-    // two chunks ahead (a second, raw register set; the affine is applied when a set rotates into (ra, rd)): both
-    // operands stream from HBM with no reuse, one chunk of prefetch left the loads exposed (see conv_fwd_kernel)
-    v4f ra2[APASS], rd2[DPASS];
-    auto load2 = [&](int c) {
+    // two chunks ahead through TWO raw register sets that swap roles (the loop is unrolled by two; the affine is applied
+    // when a set is stored): both operands stream from HBM with no reuse, one chunk of prefetch left the loads exposed
+    // (see conv_fwd_kernel).  The first version rotated one set into the other: 24 register moves per 64 MFMAs.
+    v4f raA[APASS], rdA[DPASS], raB[APASS], rdB[DPASS];
+    auto loadS = [&](int c, v4f (&xa)[APASS], v4f (&xd)[DPASS]) {
       const int mbase = m_begin + (c << 5);
       const char* abase = reinterpret_cast<const char*>(sp) + (size_t)mbase * (size_t)sC * 4;
       const char* dbase = reinterpret_cast<const char*>(dy) + (size_t)mbase * (size_t)ldy * 4;
 #pragma unroll
-      for (int p = 0; p < APASS; ++p) ra2[p] = *reinterpret_cast<const v4f*>(abase + aoffg[p]);
+      for (int p = 0; p < APASS; ++p) xa[p] = *reinterpret_cast<const v4f*>(abase + aoffg[p]);
 #pragma unroll
-      for (int p = 0; p < DPASS; ++p) rd2[p] = *reinterpret_cast<const v4f*>(dbase + doffg[p]);
+      for (int p = 0; p < DPASS; ++p) xd[p] = *reinterpret_cast<const v4f*>(dbase + doffg[p]);
     };
-    auto rotate = [&]() {
+    auto storeS = [&](int buf, const v4f (&xa)[APASS], const v4f (&xd)[DPASS]) {
+      float* A = As + buf * A_FLOATS;
+      float* D = Ds + buf * D_FLOATS;
 #pragma unroll
       for (int p = 0; p < APASS; ++p) {
-        v4f v = ra2[p];
+        const int idx = t + 256 * p;
+        v4f v = xa[p];
         if (AFF) v = noact_g ? affine_only_or_act4<true>(v, sc, sh, slope) : affine_only_or_act4<false>(v, sc, sh, slope);
-        ra[p] = v;
+        *reinterpret_cast<v4f*>(A + (idx / AF4) * KT + (idx % AF4) * 4) = v;
       }
 #pragma unroll
-      for (int p = 0; p < DPASS; ++p) rd[p] = rd2[p];
+      for (int p = 0; p < DPASS; ++p) {
+        const int idx = t + 256 * p;
+        *reinterpret_cast<v4f*>(D + (idx / DF4) * NT + (idx % DF4) * 4) = xd[p];
+      }
     };
-    if (nchunks > 1) { load2(1); }
-    for (int c = 0; c + 1 < nchunks; ++c) {
-      rotate();                                  // chunk c + 1
-      if (c + 2 < nchunks) load2(c + 2);
+    const int last = nchunks - 1;
+    if (nchunks > 1) loadS(1, raA, rdA);
+    int c = 0;
+    for (; c + 2 < nchunks; c += 2) {                      // set A holds chunk c + 1
+      loadS(c + 2, raB, rdB);
       compute(c & 1);
-      store_chunk((c + 1) & 1);
+      storeS((c + 1) & 1, raA, rdA);
+      __syncthreads();
+      loadS(c + 3 < nchunks ? c + 3 : last, raA, rdA);     // past the end: the last chunk again (never stored)
+      compute((c + 1) & 1);
+      storeS(c & 1, raB, rdB);                             // chunk c + 2
+      __syncthreads();
+    }
+    if (c + 1 < nchunks) {                                 // an even number of chunks: chunk c + 1 is still in set A
+      compute(c & 1);
+      storeS((c + 1) & 1, raA, rdA);
       __syncthreads();
     }
   } else
