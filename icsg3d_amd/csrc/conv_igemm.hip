@@ -643,30 +643,42 @@ __global__ __launch_bounds__(256, FOLD ? 2 : ((REUSE && PAR) ? 3 : 1)) void conv
     __syncthreads();
 #if ICS_GEMM_DEEP
     if (!AFF && TM * TN >= 4) {                  // 128-row tiles only: on the 64 x 64 tiles the registers cost an occupancy step (+4 %)
-      // second register set; chunk c + 1 is in (ra4, rb) when iteration c starts, chunk c + 2 is requested into (ra4b, rbb)
-      v4f ra4b[RA], rbb[NB];
-      auto loadb_set = [&](int c) {
+      // two register sets that swap roles (loop unrolled by two): chunk c + 1 is in set A when an iteration starts,
+      // chunk c + 2 is requested into set B.  (First version: one set copied into the other, 16 64-bit moves per chunk.)
+      v4f raA[RA], rbA[NB], raB[RA], rbB[NB];
+      auto load_set = [&](int c, v4f (&xa)[RA], v4f (&xb)[NB]) {
         const char* wrow = reinterpret_cast<const char*>(wp) + (size_t)(c * 8) * (size_t)g.Npad * 16;
 #pragma unroll
-        for (int r = 0; r < NB; ++r) rbb[r] = *reinterpret_cast<const v4f*>(wrow + bofs[r]);
+        for (int r = 0; r < NB; ++r) xb[r] = *reinterpret_cast<const v4f*>(wrow + bofs[r]);
         const int ci0 = c << 5;
         const bool first = ci0 < s0.C;
         const char* sp = reinterpret_cast<const char*>(first ? s0.p : s1.p) + (size_t)(first ? ci0 : ci0 - s0.C) * 4;
 #pragma unroll
-        for (int r = 0; r < RA; ++r) ra4b[r] = *reinterpret_cast<const v4f*>(sp + (first ? rowG0[r] : rowG1[r]));
+        for (int r = 0; r < RA; ++r) xa[r] = *reinterpret_cast<const v4f*>(sp + (first ? rowG0[r] : rowG1[r]));
       };
-      if (cb + 1 < ce) load_chunk_gemm(cb + 1);
-      for (int c = cb; c + 1 < ce; ++c) {
-        if (c + 2 < ce) loadb_set(c + 2);
+      auto store_set = [&](int buf, const v4f (&xa)[RA], const v4f (&xb)[NB]) {   // B now, A behind the barrier
+        float* Bw = Bs + buf * B_FLOATS;
+#pragma unroll
+        for (int r = 0; r < NB; ++r) *reinterpret_cast<v4f*>(Bw + (t + 256 * r) * 4) = xb[r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < RA; ++r) *reinterpret_cast<v4f*>(As + ((t >> 3) + 32 * r) * kLDA + (t & 7) * 4) = xa[r];
+        __syncthreads();
+      };
+      const int lastc = ce - 1;
+      if (cb + 1 < ce) load_set(cb + 1, raA, rbA);
+      int c = cb;
+      for (; c + 2 < ce; c += 2) {
+        load_set(c + 2, raB, rbB);
         compute_g(c & 1);
-        store_b((c + 1) & 1);
-        __syncthreads();
-        store_a_chunk();
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < RA; ++r) ra4[r] = ra4b[r];
-#pragma unroll
-        for (int r = 0; r < NB; ++r) rb[r] = rbb[r];
+        store_set((c + 1) & 1, raA, rbA);
+        load_set(c + 3 < ce ? c + 3 : lastc, raA, rbA);    // past the end: the last chunk again (never stored)
+        compute_g((c + 1) & 1);
+        store_set(c & 1, raB, rbB);                        // chunk c + 2
+      }
+      if (c + 1 < ce) {                                    // chunk c + 1 is still in set A
+        compute_g(c & 1);
+        store_set((c + 1) & 1, raA, rbA);
       }
       compute_g((ce - 1) & 1);
       __syncthreads();
