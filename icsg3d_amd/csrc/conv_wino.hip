@@ -543,16 +543,19 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(const float* __res
       t.z = fmaf(t.z, sc4v.z, sh4v.z); t.w = fmaf(t.w, sc4v.w, sh4v.w);
       if (!NOACT) { t.x = wact(t.x, in_slope); t.y = wact(t.y, in_slope); t.z = wact(t.z, in_slope); t.w = wact(t.w, in_slope); }
     }
-    if (!(okyx_cur && ((okz_cur >> i) & 1))) t = wf4{0.f, 0.f, 0.f, 0.f};
+    // zero padding as a bit mask (a select per component compiled to a branch per piece: 12 divergent regions per block)
+    const unsigned msk = (okyx_cur ? ~0u : 0u) & (((okz_cur >> i) & 1) ? ~0u : 0u);
+    t.x = __uint_as_float(__float_as_uint(t.x) & msk); t.y = __uint_as_float(__float_as_uint(t.y) & msk);
+    t.z = __uint_as_float(__float_as_uint(t.z) & msk); t.w = __uint_as_float(__float_as_uint(t.w) & msk);
     xs[i] = t;
   };
   auto ss_x = [&](const int bo, const int tz, const int f) {
-    if (sact) {
-      const wf4 d0 = xs[2 * tz], d1 = xs[2 * tz + 1], d2 = xs[2 * tz + 2], d3 = xs[2 * tz + 3];
-      const wf4 czf = f == 0 ? d0 - d2 : (f == 1 ? d1 + d2 : (f == 2 ? d2 - d1 : d1 - d3));
-      const int o = bo * GXF + xw + (tz * 4 + f) * 60;
-      lds[o] = czf.x; lds[o + GXP] = czf.y; lds[o + 2 * GXP] = czf.z; lds[o + 3 * GXP] = czf.w;
-    }
+    // no `if (sact)`: the 32 threads past the halo's 60 positions were clamped to position 59 and hold the same values
+    // as its owner -- a duplicate store of identical data instead of an exec-masked region per piece
+    const wf4 d0 = xs[2 * tz], d1 = xs[2 * tz + 1], d2 = xs[2 * tz + 2], d3 = xs[2 * tz + 3];
+    const wf4 czf = f == 0 ? d0 - d2 : (f == 1 ? d1 + d2 : (f == 2 ? d2 - d1 : d1 - d3));
+    const int o = bo * GXF + xw + (tz * 4 + f) * 60;
+    lds[o] = czf.x; lds[o + GXP] = czf.y; lds[o + 2 * GXP] = czf.z; lds[o + 3 * GXP] = czf.w;
   };
   auto ss_y = [&](const int bo, const int i) {
     const int o = 2 * GXF + bo * GYF + (sq * 4) * GYP + spos + i * 64;
