@@ -207,7 +207,10 @@ __global__ __launch_bounds__(512) void conv_wino64_kernel(const float* __restric
       for (int i = 0; i < 4; ++i)
         if (!((okmask >> (2 * tzh + i)) & 1)) r[i] = vf4{0.f, 0.f, 0.f, 0.f};
     }
-    if (tid < 480) {
+    // !AFF: threads 480..511 (clamped to thread 479's column: same data) store too -- a duplicate store of identical values
+    // instead of an exec-masked region in the main loop (backward-data -0.9 %).  The AFF variants keep the predicate: without
+    // it they spill four more registers (forward +3 %).
+    if (!AFF || tid < 480) {
       float* o = &lds[bo + unpark(1) + tzh * 4 * PP];
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
