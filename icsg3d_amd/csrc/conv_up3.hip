@@ -15,14 +15,15 @@
 // One workgroup = 32 low-res voxels (2x4x4: an 4x8x8 block of fine outputs) x 64 output channels x 27 frequencies on
 // v_mfma_f32_16x16x4_f32 (lane l: A[voxel l & 15][k = l >> 4]; the two 16-voxel halves are two y rows apart and share
 // every B operand), EIGHT waves, two per SIMD: wave w owns the (fz, fy) pair w with fx = 0..2 and all four 16-channel
-// column blocks (2 x 12 accumulators of 4 registers), and the waves 0..3 -- one per SIMD -- also take one column block
-// each of the ninth pair (2, 2): 2 x (15 + 12) = 54 MFMAs per sub-step on every SIMD (the kernel header below has the
-// history).  Staging: thread t < 288 owns (y, x, channel quad) of the halo [4][6][6] x 32 channels: four z rows in, the
-// producer's BatchNorm affine + activation once per row, zero padding, the z rows of B for both tile z, six planes
-// out.  LDS: voxel pitch 34 floats, row pitch 208, plane pitch 1256 (3 x 1256 = 24 mod 32 as with the 16-voxel tile's
-// 840: conflict-free ds_read_b32 for every (fz, row, column, sub-step), checked exhaustively).  Weights [Cout/64][Cu/4]
-// [27 f][4 k][16 n][4 column blocks]; the fy = 1 frequencies carry the opposite sign (one fma per column in the y
-// transform).
+// column blocks (2 x 12 accumulators of 4 registers), and the 24 tiles of the ninth pair (2, 2) are dealt over all eight
+// waves -- column block w & 3 of voxel half w >> 2, fx = 0..2: 24 + 3 = 27 MFMAs per wave and sub-step, 54 on every SIMD
+// (the kernel header below has the history).  Staging: thread t < 288 owns (y, x, channel quad) of the halo [4][6][6] x
+// 32 channels, in two phases of three z rows (12 registers in flight): the producer's BatchNorm affine + activation,
+// zero padding, the z rows of B, three planes out per phase.  LDS: voxel pitch 34 floats, row pitch 208, plane pitch
+// 1256 (3 x 1256 = 24 mod 32 as with the 16-voxel tile's 840: conflict-free ds_read_b32 for every (fz, row, column,
+// sub-step), checked exhaustively).  Weights [Cout/64][Cu/4][27 f][4 k][16 n][4 column blocks]; the fy = 1 frequencies
+// carry the opposite sign (one fma per column in the y transform).  The 16-voxel tile (NH = 1, small launches) keeps the
+// ninth pair on the waves 0..3 (column block w) and the four-row staging.
 #include "common.h"
 
 #include <cstdlib>
@@ -54,7 +55,10 @@ __host__ __device__ __forceinline__ float uslope(int act) { return act == ACT_RE
 // weight loads and operand reads still took 1.24); twelve waves x three triples 1.36 (two operand sets per wave); the
 // layout below with the extra work under wave-uniform branches INSIDE the loop 1.39 (conservative waits at every join);
 // with the two roles as two straight-line copies of the loop behind one branch: 1.24; 32 instead of 16 voxels per
-// workgroup on top (half the weight traffic, halo 4.5 instead of 6 positions per voxel, one epilogue per 32): 1.15.
+// workgroup on top (half the weight traffic, halo 4.5 instead of 6 positions per voxel, one epilogue per 32): 1.15 --
+// but the four waves with the whole ninth pair (24 more accumulator registers) spilled the four staged rows right behind
+// their loads and waited for HBM four times per chunk; the ninth pair dealt over ALL eight waves (one loop, one role) and
+// the staging in two three-row phases: no spill, 1.06.
 // NH: 16-voxel halves per workgroup -- 2 (2x4x4 low-res voxels) or 1 (2x2x4, for launches that would not fill the chip
 // with the large tile: the S = 4 layers and the VAE decoder).
 template <bool AFF, bool NOACT, bool STATS, int NH>
@@ -77,12 +81,15 @@ __global__ __launch_bounds__(512) void conv_up3_kernel(const float* __restrict__
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   // EIGHT waves, two per SIMD.  Wave w owns the (fz, fy) pair w (fx = 0..2, four column blocks); the ninth pair (2, 2)
-  // is split by column block over the waves 0..3 (each on a different SIMD): 15 + 12 = 27 MFMAs per sub-step on every
-  // SIMD.  (Nine waves sat 3 + 2 + 2 + 2: the main loop ran at the pace of SIMD 0's 36, scripts/up3_timeline.py.)  The
-  // two roles are two straight-line copies of the main loop behind ONE wave-uniform branch: branches around the extra
-  // MFMAs inside the loop cost all of the gain (conservative waits at every join).
+  // is split over the waves so that every SIMD issues the same number of MFMAs per sub-step.  (Nine waves sat 3 + 2 + 2
+  // + 2: the main loop ran at the pace of SIMD 0's 36, scripts/up3_timeline.py.)  Where only some waves carry extra tiles
+  // (NH = 1) the two roles are two straight-line copies of the main loop behind ONE wave-uniform branch: branches around
+  // the extra MFMAs inside the loop cost all of the gain (conservative waits at every join).
   const int fz = w / 3, fy = w - 3 * fz;
-  const bool extra = w < 4;
+  // NH = 2: EVERY wave takes three tiles of the ninth pair -- column block w & 3 of voxel half w >> 2 (the 24 tiles of the
+  // pair over eight waves); NH = 1: the waves 0..3, column block w
+  const bool extra = NH == 2 || w < 4;
+  const int xh = NH == 2 ? (w >> 2) : 0;         // voxel half of this wave's extra tiles
   const int m = lane & 15, kq = lane >> 4;
   const int nchunks = Cout >> 6;
   const int nb = blockIdx.x % nchunks;
@@ -171,6 +178,49 @@ __global__ __launch_bounds__(512) void conv_up3_kernel(const float* __restrict__
     }
   };
 
+  // NH = 2, main loop: the same staging in TWO phases of three z rows -- rows 0..2 -> the planes of tile z 0, rows 1..3 ->
+  // tile z 1 (rows 1, 2 come a second time, from L1 / L2) -- so that 12 instead of 16 registers are in flight next to the
+  // 132 accumulator registers: with four rows the allocator spilled one right behind its load, i.e. every wave waited for
+  // HBM once per chunk (and the four waves that carried the whole ninth pair in the first version: four times)
+  auto hloadP = [&](const int tzq, int c0) {
+    const int vo = unpark(0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      hs[i] = __builtin_bit_cast(uf4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vo, (int)(zoff[tzq + i] + (unsigned)c0 * 4u), 0));
+  };
+  auto hstoreP = [&](const int tzq, const int bo, const int c0) {
+    const int pk2 = unpark(2);
+    const int q4 = pk2 & 255;
+    const bool okyx = ((pk2 >> 8) & 1) != 0;
+    float* o = &lds[bo + unpark(1)];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      uf2 r[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) r[i] = uf2{hs[i][2 * hh], hs[i][2 * hh + 1]};
+      if (AFF) {
+        const uf2 sc2 = *reinterpret_cast<const uf2*>(&aff[c0 + q4 + 2 * hh]);
+        const uf2 sh2 = *reinterpret_cast<const uf2*>(&aff[1024 + c0 + q4 + 2 * hh]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          float t0 = fmaf(r[i].x, sc2.x, sh2.x), t1 = fmaf(r[i].y, sc2.y, sh2.y);
+          if (!NOACT) { t0 = uact(t0, in_slope); t1 = uact(t1, in_slope); }
+          r[i] = uf2{t0, t1};
+        }
+      }
+      if (edge) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+          if (!(okyx && ((okz >> (tzq + i)) & 1))) r[i] = uf2{0.f, 0.f};
+      }
+      if (tid < NST) {
+        *reinterpret_cast<uf2*>(o + (tzq * 3 + 0) * PP + 2 * hh) = r[0] - r[1];
+        *reinterpret_cast<uf2*>(o + (tzq * 3 + 1) * PP + 2 * hh) = r[1];
+        *reinterpret_cast<uf2*>(o + (tzq * 3 + 2) * PP + 2 * hh) = r[2] - r[1];
+      }
+    }
+  };
+
   // ---- per-lane read geometry: voxel m = (tz, ty, tx); rows of the wave's fy: D0 = r0 - r1, D1 = r1, D2 = r2 - r1
   const int tz = m >> 3, ty = (m >> 2) & 1, tx = m & 3;
   // t = sa * qa - qb: ONE fma per column.  For fy = 1 that is -r1 instead of r1: the packed weights of the fy = 1
@@ -178,7 +228,7 @@ __global__ __launch_bounds__(512) void conv_up3_kernel(const float* __restrict__
   const float sa = fy == 1 ? 0.f : 1.f;
   const int R0 = (tz * 3 + fz) * PP + ty * RP + tx * VX + kq;
   int Ra = R0 + (fy == 2 ? 2 : 0) * RP, Rb = R0 + RP;
-  int Rxa = (tz * 3 + 2) * PP + ty * RP + tx * VX + kq + 2 * RP, Rxb = Rxa - RP;      // pair (2, 2): rows 2 and 1
+  int Rxa = (tz * 3 + 2) * PP + ty * RP + tx * VX + kq + 2 * RP + xh * 2 * RP, Rxb = Rxa - RP;   // pair (2, 2): rows 2 and 1 (of half xh)
 
   const int nsub = Cin >> 2;
   constexpr int wstride_f = 256;                 // floats per frequency of one sub-step: [4 k][16 n][4 column blocks]
@@ -201,12 +251,10 @@ __global__ __launch_bounds__(512) void conv_up3_kernel(const float* __restrict__
   float wx[3];
 #pragma unroll
   for (int f = 0; f < 3; ++f) wx[f] = wloadx(0, f);
-  uf4 accx[NH][3];
+  uf4 accx[3];
 #pragma unroll
-  for (int h = 0; h < NH; ++h)
-#pragma unroll
-    for (int f = 0; f < 3; ++f) accx[h][f] = uf4{0.f, 0.f, 0.f, 0.f};
-  float ux[NH][3], tx3[NH][3], qxa[NH], qxb[NH];
+  for (int f = 0; f < 3; ++f) accx[f] = uf4{0.f, 0.f, 0.f, 0.f};
+  float ux[3], tx3[3], qxa, qxb;
 
   uf4 acc[NH][3][4];                             // [voxel half][fx][column block]
 #pragma unroll
@@ -222,22 +270,22 @@ __global__ __launch_bounds__(512) void conv_up3_kernel(const float* __restrict__
 #pragma unroll
     for (int h = 0; h < NH; ++h) {                // second half: two low-res rows further
       qa[h] = lds[Ra + off + h * 2 * RP]; qb[h] = lds[Rb + off + h * 2 * RP];
-      if (decltype(xt)::value) { qxa[h] = lds[Rxa + off + h * 2 * RP]; qxb[h] = lds[Rxb + off + h * 2 * RP]; }
     }
+    if (decltype(xt)::value) { qxa = lds[Rxa + off]; qxb = lds[Rxb + off]; }
   };
   auto tstep = [&](const int g, auto xt) {
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       tn[h][g] = fmaf(sa, qa[h], -qb[h]);
-      if (decltype(xt)::value) tx3[h][g] = qxa[h] - qxb[h];     // fy = 2: r2 - r1
     }
+    if (decltype(xt)::value) tx3[g] = qxa - qxb;              // fy = 2: r2 - r1
   };
   auto xform = [&](auto xt) {
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       u[h][0] = tn[h][0] - tn[h][1]; u[h][1] = tn[h][1]; u[h][2] = tn[h][2] - tn[h][1];
-      if (decltype(xt)::value) { ux[h][0] = tx3[h][0] - tx3[h][1]; ux[h][1] = tx3[h][1]; ux[h][2] = tx3[h][2] - tx3[h][1]; }
     }
+    if (decltype(xt)::value) { ux[0] = tx3[0] - tx3[1]; ux[1] = tx3[1]; ux[2] = tx3[2] - tx3[1]; }
   };
 
   hload(0);
@@ -261,7 +309,7 @@ __global__ __launch_bounds__(512) void conv_up3_kernel(const float* __restrict__
     constexpr bool XT = decltype(xt)::value;
     const int cn = (ch + 1) * KC;
     const int dlt = 2 * nxt - BUF;
-    if (ST) hload(cn);
+    if (ST) { if (NH == 2) hloadP(0, cn); else hload(cn); }
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       int gs = ch * 8 + s + 1;
@@ -269,8 +317,9 @@ __global__ __launch_bounds__(512) void conv_up3_kernel(const float* __restrict__
 #pragma unroll
       for (int g = 0; g < 3; ++g) {
         tstep(g, xt);                            // column g of sub-step s+1, read one column ago
+        if (ST && NH == 2 && s == 3 && g == 2) { hstoreP(0, nxt, cn); hloadP(1, cn); }
         if (ST && s == 6 && g == 2) {            // the next chunk must be visible before its first column is read
-          hstore(nxt, cn);
+          if (NH == 2) hstoreP(1, nxt, cn); else hstore(nxt, cn);
           __syncthreads();
           Ra += dlt; Rb += dlt; Rxa += dlt; Rxb += dlt;
         }
@@ -283,11 +332,7 @@ __global__ __launch_bounds__(512) void conv_up3_kernel(const float* __restrict__
           for (int h = 0; h < NH; ++h)
             acc[h][g][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[h][g], wreg[g][j], acc[h][g][j], 0, 0, 0);
         }
-        if (XT) {
-#pragma unroll
-          for (int h = 0; h < NH; ++h)
-            accx[h][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ux[h][g], wx[g], accx[h][g], 0, 0, 0);
-        }
+        if (XT) accx[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ux[g], wx[g], accx[g], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         wreg[g] = wload(gs, g);
         if (XT) wx[g] = wloadx(gs, g);
@@ -297,7 +342,7 @@ __global__ __launch_bounds__(512) void conv_up3_kernel(const float* __restrict__
     }
     nxt = BUF - nxt;
   };
-  if (extra) {
+  if (NH == 2 || extra) {                        // NH = 2: one role, one copy of the loop
     for (int ch = 0; ch < nch - 1; ++ch) chunk(ch, std::true_type{}, std::true_type{});
     chunk(nch - 1, std::false_type{}, std::true_type{});
   } else {
@@ -334,15 +379,13 @@ __global__ __launch_bounds__(512) void conv_up3_kernel(const float* __restrict__
           part[w * PW + (((h * 4 + i) * 2 + 1) * 2 + jj) * PS + lane] = acc[h][1][j][i] + acc[h][2][j][i];
         }
       }
-    if (extra && (w >> 1) == pass) {             // pair (2, 2), column block w
+    if (extra && ((w & 3) >> 1) == pass) {       // pair (2, 2), column block w & 3, voxel half xh
       const int jj = w & 1;
 #pragma unroll
-      for (int h = 0; h < NH; ++h)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          part[8 * PW + (((h * 4 + i) * 2 + 0) * 2 + jj) * PS + lane] = accx[h][0][i] + accx[h][1][i];
-          part[8 * PW + (((h * 4 + i) * 2 + 1) * 2 + jj) * PS + lane] = accx[h][1][i] + accx[h][2][i];
-        }
+      for (int i = 0; i < 4; ++i) {
+        part[8 * PW + (((xh * 4 + i) * 2 + 0) * 2 + jj) * PS + lane] = accx[0][i] + accx[1][i];
+        part[8 * PW + (((xh * 4 + i) * 2 + 1) * 2 + jj) * PS + lane] = accx[1][i] + accx[2][i];
+      }
     }
     __syncthreads();
     {
