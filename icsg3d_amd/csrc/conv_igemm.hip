@@ -3280,9 +3280,17 @@ __global__ __launch_bounds__(256) void pack_table_kernel(const PackJob* __restri
   }
   __syncthreads();
   const PackJob J = jobs[sj];
-  const size_t i = (size_t)(blockIdx.x - J.blk0) * 256 + threadIdx.x;
-  if (i >= J.total) return;
   const int* a = J.a;
+  size_t i = (size_t)(blockIdx.x - J.blk0) * 256 + threadIdx.x;
+  if (a[8] > 0) {
+    // Winograd / 27-product jobs: blocks are dispatched round-robin over the 8 XCDs, and in the backward images the eight
+    // launch-order neighbours (k quads c4 .. c4 + 7 of the same n rows) read different 16-byte pieces of the SAME 128-byte
+    // lines of w -- through eight different L2s.  Give every XCD a contiguous range of the job's groups instead (blk0 and
+    // the block count a[8] are multiples of 8): the neighbours in k then follow each other on one XCD
+    const unsigned bj = blockIdx.x - J.blk0, per = (unsigned)a[8] >> 3;
+    i = ((size_t)(bj & 7u) * per + (bj >> 3)) * 256 + threadIdx.x;
+  }
+  if (i >= J.total) return;
   float v;
   switch (J.kind) {
     case 0: if (pack_fwd_value(i, J.w, a[0], a[1], a[2], a[3], a[4], a[5], a[6], &v)) J.dst[i] = v; break;
@@ -3309,8 +3317,12 @@ int pack_table_record_end(void* handle, std::vector<unsigned char>* bytes, int* 
   auto* t = static_cast<PackTableHost*>(handle);
   unsigned blk = 0;
   for (auto& j : t->jobs) {
+    const bool xcd = (j.kind == 5 && j.a[5] == 1) || j.kind == 6;     // see pack_table_kernel
+    if (xcd) blk = (blk + 7u) & ~7u;
     j.blk0 = blk;
-    blk += (unsigned)((j.total + 255) / 256);
+    const unsigned nb = (unsigned)((j.total + 255) / 256);
+    j.a[8] = xcd ? (int)((nb + 7u) & ~7u) : 0;
+    blk += xcd ? (unsigned)j.a[8] : nb;
   }
   bytes->resize(t->jobs.size() * sizeof(PackJob));
   if (!t->jobs.empty()) std::memcpy(bytes->data(), t->jobs.data(), bytes->size());
