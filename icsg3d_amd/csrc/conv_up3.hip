@@ -132,9 +132,8 @@ __global__ __launch_bounds__(512) void conv_up3_kernel(const float* __restrict__
     asm volatile("ds_read_b32 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(park_addr), "i"(which * 2048) : "memory");
     return v;
   };
-  if (AFF) {
-    for (int i = tid; i < Cin; i += 512) { aff[i] = in_scale[i]; aff[1024 + i] = in_shift[i]; }
-  }
+  // (the producer's scale / shift table is requested together with the first halo rows, below: as a load -> wait -> store
+  // loop up here it put a full memory round trip in front of every other load of the prologue)
   auto hload = [&](int c0) {
     const int vo = unpark(0);
 #pragma unroll
@@ -288,8 +287,19 @@ __global__ __launch_bounds__(512) void conv_up3_kernel(const float* __restrict__
     if (decltype(xt)::value) { ux[0] = tx3[0] - tx3[1]; ux[1] = tx3[1]; ux[2] = tx3[2] - tx3[1]; }
   };
 
+  float a_sc[2] = {0.f, 0.f}, a_sh[2] = {0.f, 0.f};
+  if (AFF) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      if (tid + 512 * k < Cin) { a_sc[k] = in_scale[tid + 512 * k]; a_sh[k] = in_shift[tid + 512 * k]; }
+  }
   hload(0);
-  if (AFF) __syncthreads();                      // scale / shift visible
+  if (AFF) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      if (tid + 512 * k < Cin) { aff[tid + 512 * k] = a_sc[k]; aff[1024 + tid + 512 * k] = a_sh[k]; }
+    __syncthreads();                             // scale / shift visible
+  }
   hstore(0, 0);
   __syncthreads();
 #pragma unroll

@@ -133,9 +133,8 @@ __global__ __launch_bounds__(512) void conv_wino64_kernel(const float* __restric
   };
   // AFF: the producer's per-channel scale / shift of ALL input channels sit in LDS behind the two buffers (Cin <= 1024:
   // 8 KB), read back per chunk at store time -- eight registers less to keep live through the main loop
-  if (AFF) {
-    for (int i = tid; i < Cin; i += 512) { aff[i] = in_scale[i]; aff[1024 + i] = in_shift[i]; }
-  }
+  // (requested together with the first halo block and the first weights, below: as a load -> wait -> store loop up here
+  // it put a full memory round trip in front of every other load of the prologue)
   auto gload = [&](int c0) {
 #pragma unroll
     for (int i = 0; i < 6; ++i)
@@ -259,8 +258,19 @@ __global__ __launch_bounds__(512) void conv_wino64_kernel(const float* __restric
     }
   };
 
+  float a_sc[2] = {0.f, 0.f}, a_sh[2] = {0.f, 0.f};
+  if (AFF) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      if (tid + 512 * k < Cin) { a_sc[k] = in_scale[tid + 512 * k]; a_sh[k] = in_shift[tid + 512 * k]; }
+  }
   gload(0);
-  if (AFF) __syncthreads();                      // scale / shift visible
+  if (AFF) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      if (tid + 512 * k < Cin) { aff[tid + 512 * k] = a_sc[k]; aff[1024 + tid + 512 * k] = a_sh[k]; }
+    __syncthreads();                             // scale / shift visible
+  }
   sstore(0, 0);
   __syncthreads();
   ICS_TL(1);
