@@ -51,7 +51,7 @@ __host__ __device__ __forceinline__ float uslope(int act) { return act == ACT_RE
 // STATS: per-block BatchNorm statistics of the stored values (the VAE decoder's layers; the U-Net's launches leave bias,
 // activation and statistics to the skip-channel pass that accumulates on top).
 // History of the wave layout (c17.up, ms per U-Net step): nine waves, one pair each, sat 3 + 2 + 2 + 2 on the SIMDs and
-// the main loop ran at the pace of SIMD 0's 36 MFMAs per sub-step (1.36; scripts/up3_timeline.py, and an ablation without
+// the main loop ran at the pace of SIMD 0's 36 MFMAs per sub-step (1.36; per-wave time stamps in an instrumented build, and an ablation without
 // weight loads and operand reads still took 1.24); twelve waves x three triples 1.36 (two operand sets per wave); the
 // layout below with the extra work under wave-uniform branches INSIDE the loop 1.39 (conservative waits at every join);
 // with the two roles as two straight-line copies of the loop behind one branch: 1.24; 32 instead of 16 voxels per
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(512) void conv_up3_kernel(const float* __restrict__
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   // EIGHT waves, two per SIMD.  Wave w owns the (fz, fy) pair w (fx = 0..2, four column blocks); the ninth pair (2, 2)
   // is split over the waves so that every SIMD issues the same number of MFMAs per sub-step.  (Nine waves sat 3 + 2 + 2
-  // + 2: the main loop ran at the pace of SIMD 0's 36, scripts/up3_timeline.py.)  Where only some waves carry extra tiles
+  // + 2: the main loop ran at the pace of SIMD 0's 36: per-wave time stamps.)  Where only some waves carry extra tiles
   // (NH = 1) the two roles are two straight-line copies of the main loop behind ONE wave-uniform branch: branches around
   // the extra MFMAs inside the loop cost all of the gain (conservative waits at every join).
   const int fz = w / 3, fy = w - 3 * fz;
