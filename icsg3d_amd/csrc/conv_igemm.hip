@@ -11,6 +11,10 @@
 // k group (lane half h supplies k = 4h..4h+3), which only reorders the fp32 summation.
 #include "common.h"
 
+#ifndef ICS_GEMM_DEEP_FWD_MIN
+#define ICS_GEMM_DEEP_FWD_MIN 1  // accumulator tiles per wave from which the forward / backward-data GEMM path prefetches two chunks ahead
+                                 // (with the copying form the 64 x 64 tiles lost 4 %; with swapping sets: c15.up / c13.up dgrad -6 / -7 %)
+#endif
 #ifndef ICS_GEMM_DEEP_MIN
 #define ICS_GEMM_DEEP_MIN 3  // accumulator tiles per wave from which the backward-weight GEMM prefetches two chunks ahead
 #endif
@@ -642,7 +646,7 @@ __global__ __launch_bounds__(256, FOLD ? 2 : ((REUSE && PAR) ? 3 : 1)) void conv
     store_a_chunk();
     __syncthreads();
 #if ICS_GEMM_DEEP
-    if (!AFF && TM * TN >= 4) {                  // 128-row tiles only: on the 64 x 64 tiles the registers cost an occupancy step (+4 %)
+    if (!AFF && TM * TN >= ICS_GEMM_DEEP_FWD_MIN) {
       // two register sets that swap roles (loop unrolled by two): chunk c + 1 is in set A when an iteration starts,
       // chunk c + 2 is requested into set B.  (First version: one set copied into the other, 16 64-bit moves per chunk.)
       v4f raA[RA], rbA[NB], raB[RA], rbB[NB];
