@@ -260,7 +260,7 @@ def main():
                                        "per batch), Glorot weights PCG64(1)" % (B, d),
                            "global_batch": world * B, "grid": d, "parallelism": "dp%d" % world,
                            "conv": "3x3x3 layers: Winograd F(2x2x2,3x3x3) on fp32 MFMA (fwd, bwd-data, bwd-weight); "
-                                   "upsampled channels: 8-tap parity GEMMs on the coarse grid; rest: 27-tap implicit GEMM",
+                                   "upsampled channels: 27 three-point-transform products per low-res voxel forward, tap-pooled GEMMs on the coarse grid backward; rest: 27-tap implicit GEMM",
                            "bn": "sync (global-batch statistics)" if args.sync_bn and use_dist
                                  else "local per-replica batch statistics, moving statistics averaged over ranks",
                            "grad_allreduce": ("%d RCCL buckets per step on a second stream, overlapped with the "
