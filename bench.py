@@ -39,22 +39,30 @@ UNET_FLOP_PER_GRID = 377.66e9          # fwd 125.886 GFLOP x 3
 UNET_BYTES_PER_GRID = 499.6e6          # fused-minimum activation traffic
 UNET_PARAM_BYTES_PER_STEP = 1.25e9     # 124.6 MB x (1 fwd + 2 bwd + 7 Adam)
 VAE_FLOP_PER_GRID = 33.73e9            # VAE 3 x 2.126 + perceptual 3 x 9.116 GFLOP
-PMC_TRAFFIC_FILES = ("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json")
+PMC_TRAFFIC_FILES = ("r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json")
 
 
-def cpu_baseline(sample_grids=4):
+def cpu_baseline():
     """oracle/torch_ref.py (fp32 torch-CPU restatement of the same train step, all host cores) in a
-    subprocess -- the checker timed as a baseline, never the product path."""
+    subprocess -- the checker timed as a baseline, never the product path.  The GPU number is quoted at 32 grids per
+    step; a 32-grid CPU step takes ~40 s, so the sample is bounded: one warm-up + one timed step at 4 grids and one
+    timed step at 8 grids.  Both per-grid rates are reported: the CPU step is a chain of compute-bound convolutions
+    whose cost is linear in the batch, so the per-grid rate does not depend on it (the two figures agree to a few %)."""
     code = ("import json,sys; sys.path.insert(0, %r); from oracle import torch_ref as T; "
-            "v,c,s = T.time_unet_train_step(B=%d, d=32, in_ch=1, steps=2, warmup=1); "
-            "print(json.dumps({'value': v, 'cores': c, 'sec_per_step': s}))" % (ROOT, sample_grids))
+            "v4,c,s4 = T.time_unet_train_step(B=4, d=32, in_ch=1, steps=1, warmup=1); "
+            "v8,c,s8 = T.time_unet_train_step(B=8, d=32, in_ch=1, steps=1, warmup=0); "
+            "print(json.dumps({'v4': v4, 'v8': v8, 'cores': c, 's4': s4, 's8': s8}))" % ROOT)
     try:
         out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
         r = json.loads(out.stdout.strip().splitlines()[-1])
-        return {"value": round(r["value"], 4), "unit": "voxel-grids/s", "cores": int(r["cores"]), "kind": "port",
-                "sample": "oracle/torch_ref.py fp32 U-Net fwd+bwd+Adam on %d synthetic 32^3 grids/step, "
-                          "1 warm-up + 2 timed steps (%.1f s/step), torch-CPU channels_last_3d; the reference's "
-                          "Keras/TF path is not installable here" % (sample_grids, r["sec_per_step"])}
+        return {"value": round(r["v8"], 4), "unit": "voxel-grids/s", "cores": int(r["cores"]), "kind": "port",
+                "value_at_4_grids_per_step": round(r["v4"], 4),
+                "sample": "oracle/torch_ref.py fp32 U-Net fwd+bwd+Adam, torch-CPU channels_last_3d, all host cores: "
+                          "one warm-up + one timed step on 4 synthetic 32^3 grids (%.1f s/step), then one timed step on "
+                          "8 grids (%.1f s/step; `value`).  The GPU figure is quoted at 32 grids per step; a 32-grid CPU "
+                          "step (~%.0f s) is outside the bounded sample, and the per-grid CPU rate does not depend on the "
+                          "batch (compare value_at_4_grids_per_step: every layer's cost is linear in the batch).  The "
+                          "reference's Keras/TF path is not installable here" % (r["s4"], r["s8"], 4 * r["s8"])}
     except Exception as e:  # pragma: no cover
         return {"value": None, "unit": "voxel-grids/s", "cores": os.cpu_count(), "kind": "port",
                 "sample": "cpu baseline failed: %s" % e}
@@ -176,7 +184,7 @@ def main():
         barrier()
         rows_all = [r for e in profiled for r in e.profile_rows()]
         for r in rows_all:
-            r["ms"] /= 2.0; r["flop"] /= 2.0; r["bytes"] /= 2.0; r["launches"] /= 2.0     # per step
+            r["ms"] /= 2.0; r["flop"] /= 2.0; r["bytes"] /= 2.0; r["launches"] //= 2     # per step
         gem = {}
         for r in rows_all:
             if r["flop"] > 0 and "|" in r["label"]:
@@ -206,13 +214,16 @@ def main():
         if args.dump_rows and rank == 0:
             with open(args.dump_rows, "a") as f:
                 f.write(json.dumps({"steps": args.steps, "rows": rows}) + "\n")
-        # the same K steps without the per-launch events (what a training job sees)
+        # the same K steps without the per-launch events (what a training job sees); the library counts every kernel
+        # it enqueues (ics_kernel_launches): the per-step difference is the number rocprofv3 --kernel-trace shows
         barrier()
+        n0 = lib.ics_kernel_launches()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
         barrier()
         elapsed_plain = max_over_ranks(time.perf_counter() - t0)
+        timed.kernel_launches_per_step = (lib.ics_kernel_launches() - n0) / float(args.steps)
         return elapsed, elapsed_plain, rows, rows_all
 
     out = None
@@ -226,6 +237,7 @@ def main():
 
     if args.workload == "unet":
         elapsed, elapsed_plain, rows_live, rows = timed(lambda: unet.train_step_resident(False), [unet], [unet])
+        unet_launches = timed.kernel_launches_per_step
         metrics = unet.train_step_resident(True)   # untimed: sanity that the job is still finite
         if not np.all(np.isfinite(metrics)):
             raise SystemExit("non-finite training metrics: %s" % metrics)
@@ -270,6 +282,11 @@ def main():
                 # untimed pass with events around every launch); the same K steps with no events at all:
                 "ms_per_step_events_off": round(elapsed_plain / args.steps * 1e3, 3),
                 "value_events_off": round(world * B * args.steps / elapsed_plain, 2),
+                # device kernels the library enqueues per step (counted at every launch site; = the ics:: rows of
+                # rocprofv3 --kernel-trace for the same command); profiler_brackets = timed launch SITES, several
+                # kernels can sit inside one
+                "kernel_launches_per_step": round(unet_launches, 1),
+                "profiler_brackets_per_step": round(sum(v["launches"] for v in kern.values()) / args.steps, 1),
                 # achieved / frac: the multiply-adds the kernel ISSUES to the matrix cores per second over the fp32 MFMA
                 # peak (<= 1 by construction: the matrix-core utilisation).  The Winograd kernels' profile rows carry
                 # the 27-tap count of the convolution they compute (2*S^3*27*Cin*Cout); they execute 64/216
@@ -341,8 +358,12 @@ def main():
                    "executed_tflop_per_step": round(exec_flop / 1e12, 3),
                    "compute_frac": round(exec_flop / (ms_v * 1e-3) / (PEAK_FP32_TFLOPS * 1e12), 4),
                    "algorithmic_tflop_per_step": round(VAE_FLOP_PER_GRID * (d / 32.0) ** 3 * B / 1e12, 3),
-                   "launches_per_step": round(sum(v["launches"] for v in kern.values()) / args.steps, 1),
-                   "dominant_kernel": {"kernel": dom_name, "tflops": round(dom["flop"] / (dom["ms"] * 1e-3) / 1e12, 2),
+                   "kernel_launches_per_step": round(timed.kernel_launches_per_step, 1),
+                   "profiler_brackets_per_step": round(sum(v["launches"] for v in kern.values()) / args.steps, 1),
+                   # tflops = MFMA work executed per second (Winograd rows x 64/216), as roofline.achieved
+                   "dominant_kernel": {"kernel": dom_name,
+                                       "tflops": round(dom["flop"] * wino(dom_name) / (dom["ms"] * 1e-3) / 1e12, 2),
+                                       "algorithmic_equivalent_tflops": round(dom["flop"] / (dom["ms"] * 1e-3) / 1e12, 2),
                                        "ms_per_step": round(dom["ms"] / args.steps, 3)},
                    "kernels": {k: {"ms_per_step": round(v["ms"] / args.steps, 3),
                                    "tflops": round(v["flop"] * wino(k) / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 and v["flop"] > 0 else None}
@@ -353,16 +374,19 @@ def main():
                 out["unet_plus_vae"] = {"ms_per_batch": round(out["ms_per_step"] + ms_v, 3),
                                         "value": round(world * B / ((out["ms_per_step"] + ms_v) * 1e-3), 2),
                                         "unit": "voxel-grids/s"}
+                # a reader of `metric` + `value` alone must not take `value` for the U-Net+VAE pair
+                out["metric"] += " (= %.1f voxel-grids/s, U-Net step + DFC-VAE step per batch)" % out["unet_plus_vae"]["value"]
             else:
                 out = {"metric": "voxel-grids/s (fwd+bwd) for %d^3 %s at batch %d per GPU" % (d, args.workload, B),
                        "n_gpus": world, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                        "data": "synthetic", "config": {"workload": blk["workload"], "global_batch": world * B, "grid": d,
                                                        "parallelism": "dp%d" % world}}
                 out.update({k: blk[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup")})
-                ex = blk["dominant_kernel"]["tflops"] * wino(dom_name)
+                ex = blk["dominant_kernel"]["tflops"]
                 out["roofline"] = {"bound": "mfma", "kernel": dom_name, "achieved": round(ex, 2),
                                    "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(ex / PEAK_FP32_TFLOPS, 4),
-                                   "algorithmic_equivalent_tflops": blk["dominant_kernel"]["tflops"], "traffic": None}
+                                   "algorithmic_equivalent_tflops": blk["dominant_kernel"]["algorithmic_equivalent_tflops"],
+                                   "traffic": None}
                 out["detail"] = blk
                 out["cpu_baseline"] = None
 

@@ -44,6 +44,7 @@ _H = C.c_void_p
 SIGNATURES = {
     "ics_last_error": (C.c_char_p, []),
     "ics_version": (C.c_char_p, []),
+    "ics_kernel_launches": (C.c_longlong, []),
     "ics_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "ics_set_device": (C.c_int, [C.c_int]),
     "ics_device_info": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),

@@ -1,12 +1,23 @@
 // Shared declarations for the icsg3d_amd HIP library (gfx950 / MI355X only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <string>
 #include <vector>
 
 namespace ics {
+
+// Every kernel launch of the library goes through ICS_LAUNCH: a process-wide count of device kernels enqueued, the
+// number rocprofv3 --kernel-trace reports for the same run minus the runtime's own copy / fill kernels and RCCL's
+// (ics_kernel_launches; bench.py's kernel_launches_per_step).
+extern std::atomic<long long> g_kernel_launches;
+#define ICS_LAUNCH(...)                                      \
+  do {                                                       \
+    ::ics::g_kernel_launches.fetch_add(1, std::memory_order_relaxed); \
+    hipLaunchKernelGGL(__VA_ARGS__);                         \
+  } while (0)
 
 // ---------------------------------------------------------------- error plumbing
 void set_error(const std::string& msg);
@@ -83,6 +94,13 @@ enum ConvFlags : int {
   CF_NO_WINO64 = 1024,    // ICSG3D_NO_WINO64: Winograd forward/backward-data through the 32-tile x 32-channel kernel only
   CF_NO_UP3 = 2048,       // ICSG3D_NO_UP3: upsampled channels forward through the 8 parity-class GEMMs (64 products per low-res
                           // voxel) instead of the 27-product kernel
+  CF_NO_THIN1_2STAGE = 4096,   // ICSG3D_NO_THIN1_2STAGE: Cout = 1 layers through the direct stencils
+  CF_NO_FAST_BNBWD = 8192,     // ICSG3D_NO_FAST_BNBWD: BatchNorm backward through the generic (run-time source) kernels
+  CF_NO_FUSED_HEAD = 16384,    // ICSG3D_NO_FUSED_HEAD: 1x1x1 head GEMM + loss kernel / implicit-GEMM head backward-data
+  CF_NO_BWD_FOLD = 32768,      // ICSG3D_NO_BWD_FOLD: BatchNorm-backward sums in their own pass, not in the consumer's dgrad
+  CF_UP3_BIG_ALWAYS = 65536,   // ICSG3D_UP3_BIG_MIN_WG=1: 32-voxel conv_up3 workgroups wherever the shape allows (tests)
+  CF_NO_TICKET = 131072,       // ICSG3D_NO_TICKET: finalize / split reductions as their own launches instead of in the
+                               // last workgroup of the producer (round 4)
 };
 int conv_flags_from_env();
 
@@ -176,12 +194,15 @@ bool conv_wino_ok(const ConvGeom& g, const ConvSrc* src, int nsrc);
 size_t conv_wino_weight_floats(int Cin, int Cout);
 int launch_conv_fwd_wino(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, const float* wt, const float* bias,
                          float* out, int ldo, int pre_act, float* stat_partial, int* rows_per_block, int accumulate,
-                         const BwdStat* bwd = nullptr, int* bwd_blocks = nullptr);   // bwd / bwd_blocks: as launch_conv_fwd
+                         int layout, const BwdStat* bwd = nullptr, int* bwd_blocks = nullptr);   // bwd / bwd_blocks: as launch_conv_fwd
+// layout: the layout `wt` was packed in (conv_wino_layout at the geometry the weights were packed for, i.e. the
+// maximum batch); 1 selects conv_wino64.hip's kernel, 0 conv_wino.hip's.
 // dst[Nn/32][K/4][64 f][2][32][2] = (G (x) G (x) G) applied to the 27 taps of
 //   bwd = 0: w[tap][c_off + k][n]          (forward: K = Csub input channels of Cin_total, Nn = Cout)
 //   bwd = 1: w[26 - tap][c_off + n][k]     (backward-data: K = Cout, Nn = Csub input channels)
 // layout 0: conv_wino.hip's operand; layout 1: conv_wino64.hip's dst[Nn/64][K/4][64 f][4 k][16 n][4 column blocks].
-// conv_wino_layout(g) is the layout launch_conv_fwd_wino will read for GEMM geometry g (g.Cin = K, g.Cout = Nn).
+// conv_wino_layout(g): the layout to pack for GEMM geometry g (g.Cin = K, g.Cout = Nn, g.B = the LARGEST batch the
+// weights will serve): 1 iff conv_wino64_ok holds there (it then holds at every smaller batch).
 int launch_pack_wino(hipStream_t st, const float* w, int Cin_total, int Cout, int c_off, int Csub, int bwd, float* dst,
                      int layout = 0);
 int conv_wino_layout(const ConvGeom& g);

@@ -65,6 +65,12 @@ int conv_flags_from_env() {
   if (getenv("ICSG3D_NO_WINO_WGRAD")) f |= CF_NO_WINO_WGRAD;
   if (getenv("ICSG3D_NO_WINO64")) f |= CF_NO_WINO64;
   if (getenv("ICSG3D_NO_UP3")) f |= CF_NO_UP3;
+  if (getenv("ICSG3D_NO_THIN1_2STAGE")) f |= CF_NO_THIN1_2STAGE;
+  if (getenv("ICSG3D_NO_FAST_BNBWD")) f |= CF_NO_FAST_BNBWD;
+  if (getenv("ICSG3D_NO_FUSED_HEAD")) f |= CF_NO_FUSED_HEAD;
+  if (getenv("ICSG3D_NO_BWD_FOLD")) f |= CF_NO_BWD_FOLD;
+  if (getenv("ICSG3D_NO_TICKET")) f |= CF_NO_TICKET;
+  { const char* e = getenv("ICSG3D_UP3_BIG_MIN_WG"); if (e && *e && strtoul(e, nullptr, 10) <= 1) f |= CF_UP3_BIG_ALWAYS; }
   return f;
 }
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remember per (kernel instantiation, device)
@@ -909,7 +915,7 @@ static int launch_fwd_cfg(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, 
   g_last_kernel_id = id.c_str();
   BwdStat bs_arg;
   if (FOLD) bs_arg = *bwd;
-  hipLaunchKernelGGL(kern, dim3(gridM * gridN, PAR ? 8 : 1, ksplit), dim3(256), lds, st, g, s0, s1, wp, bias, out, ldo,
+  ICS_LAUNCH(kern, dim3(gridM * gridN, PAR ? 8 : 1, ksplit), dim3(256), lds, st, g, s0, s1, wp, bias, out, ldo,
                      pre_act, stat_partial, gridM, gridN, accumulate, bs_arg);
   ICS_HIP(hipGetLastError());
   return 0;
@@ -1190,10 +1196,10 @@ int launch_conv_wgrad_thin_c(hipStream_t st, const ConvGeom& g, const ConvSrc& s
   if (phase != 2) {
     if (g.Cout == 32) {
       g_last_kernel_id = "conv_thin_c_wgrad_kernel<32>";
-      hipLaunchKernelGGL(conv_thin_c_wgrad_kernel<32>, dim3(nb), dim3(256), 0, st, g, s0.p, dy, ldy, ws, gpb);
+      ICS_LAUNCH(conv_thin_c_wgrad_kernel<32>, dim3(nb), dim3(256), 0, st, g, s0.p, dy, ldy, ws, gpb);
     } else {
       g_last_kernel_id = "conv_thin_c_wgrad_kernel<16>";
-      hipLaunchKernelGGL(conv_thin_c_wgrad_kernel<16>, dim3(nb), dim3(256), 0, st, g, s0.p, dy, ldy, ws, gpb);
+      ICS_LAUNCH(conv_thin_c_wgrad_kernel<16>, dim3(nb), dim3(256), 0, st, g, s0.p, dy, ldy, ws, gpb);
     }
     ICS_HIP(hipGetLastError());
   }
@@ -1232,7 +1238,7 @@ int launch_conv_fwd_thin_c(hipStream_t st, const ConvGeom& g, const ConvSrc& s0,
       attr.mark(dev);                                                                                                \
     }                                                                                                                \
     g_last_kernel_id = "conv_thin_c_fwd_kernel<" #CINV ", " #COUTV ">";                                              \
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, g, s0.p, wstride, wp, bias, out, ldo, pre_act, stat_partial, \
+    ICS_LAUNCH(kern, grid, dim3(256), lds, st, g, s0.p, wstride, wp, bias, out, ldo, pre_act, stat_partial, \
                        pos_bias);                                                                                     \
   } while (0)
   if (g.Cout == 32) ICS_TC(1, 32); else ICS_TC(1, 16);
@@ -1455,7 +1461,7 @@ __global__ __launch_bounds__(256) void thin1_gather_kernel(const float* __restri
 static bool thin1_two_stage_ok(const ConvGeom& g, const ConvSrc& s0) {
   const int M = g.B << (3 * g.lgS);
   return g.Cin % 16 == 0 && g.Cin <= 64 && M % 16 == 0 && (s0.scale != nullptr || s0.act == ACT_NONE) &&
-         std::getenv("ICSG3D_NO_THIN1_2STAGE") == nullptr;
+         !(g.flags & CF_NO_THIN1_2STAGE);
 }
 static int launch_thin1_two_stage(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, const float* wp, const float* bias,
                                   float* out, int ldo, int pre_act, float* ws, float* stat_partial) {
@@ -1466,15 +1472,15 @@ static int launch_thin1_two_stage(hipStream_t st, const ConvGeom& g, const ConvS
   const float in_slope = act_slope_of(s0.act);
 #define ICS_T1T(CKV)                                                                                                   \
   do {                                                                                                                 \
-    if (aff) hipLaunchKernelGGL((thin1_taps_kernel<CKV, true>), dim3(nblk), dim3(256), 0, st, s0.p, s0.C, wp, g.Npad, M, ws, \
+    if (aff) ICS_LAUNCH((thin1_taps_kernel<CKV, true>), dim3(nblk), dim3(256), 0, st, s0.p, s0.C, wp, g.Npad, M, ws, \
                                 s0.scale, s0.shift, in_slope);                                                         \
-    else hipLaunchKernelGGL((thin1_taps_kernel<CKV, false>), dim3(nblk), dim3(256), 0, st, s0.p, s0.C, wp, g.Npad, M, ws,    \
+    else ICS_LAUNCH((thin1_taps_kernel<CKV, false>), dim3(nblk), dim3(256), 0, st, s0.p, s0.C, wp, g.Npad, M, ws,    \
                             nullptr, nullptr, 1.f);                                                                    \
   } while (0)
   switch (g.Cin / 16) { case 1: ICS_T1T(1); break; case 2: ICS_T1T(2); break; case 3: ICS_T1T(3); break; default: ICS_T1T(4); break; }
 #undef ICS_T1T
   ICS_HIP(hipGetLastError());
-  hipLaunchKernelGGL(thin1_gather_kernel, dim3((M + 255) / 256), dim3(256), 0, st, ws, g.B, g.S, g.lgS, M, bias,
+  ICS_LAUNCH(thin1_gather_kernel, dim3((M + 255) / 256), dim3(256), 0, st, ws, g.B, g.S, g.lgS, M, bias,
                      act_slope_of(pre_act), out, ldo, stat_partial, g.Npad);
   ICS_HIP(hipGetLastError());
   g_last_kernel_id = "thin1_taps_kernel + thin1_gather_kernel";
@@ -1499,7 +1505,7 @@ static int launch_thin_n_fwd(hipStream_t st, const ConvGeom& g, const ConvSrc& s
 #define ICS_TN(NOUT, AFFV, LGV)                                                                                   \
   do {                                                                                                            \
     g_last_kernel_id = "conv_thin_n_fwd_kernel<" #NOUT ", " #AFFV ", " #LGV ">";                                  \
-    hipLaunchKernelGGL((conv_thin_n_fwd_kernel<NOUT, AFFV, LGV>), grid, dim3(256), lds, st, g, s, wp, bias, out,   \
+    ICS_LAUNCH((conv_thin_n_fwd_kernel<NOUT, AFFV, LGV>), grid, dim3(256), lds, st, g, s, wp, bias, out,   \
                        ldo, pre_act, stat_partial, accumulate);                                                   \
   } while (0)
 #define ICS_TN_L(NOUT, AFFV)                                          \
@@ -1638,7 +1644,7 @@ __global__ __launch_bounds__(256) void thin1_wgrad_kernel(ConvGeom g, ConvSrc s0
 }
 static bool thin1_wgrad_ok(const ConvGeom& g, const ConvSrc& s0) {
   const int M = g.B << (3 * g.lgS);
-  return g.Cout == 1 && g.Cin % 16 == 0 && g.Cin <= 64 && M % 16 == 0 && std::getenv("ICSG3D_NO_THIN1_2STAGE") == nullptr;
+  return g.Cout == 1 && g.Cin % 16 == 0 && g.Cin <= 64 && M % 16 == 0 && !(g.flags & CF_NO_THIN1_2STAGE);
 }
 static int thin1_wgrad_blocks(const ConvGeom& g) {
   const int M = g.B << (3 * g.lgS);
@@ -1767,7 +1773,7 @@ int launch_conv_fwd(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int n
   const int M = g.B << (3 * g.lgS);
   ICS_CHECK((size_t)ks * M * g.Npad <= ws_floats, "forward split-K workspace too small");
   ICS_TRY(launch_conv_fwd_inner(st, g, src, nsrc, wp, nullptr, ws, g.Npad, ACT_NONE, nullptr, nullptr, 0, ks));
-  hipLaunchKernelGGL(splitk_finish_kernel, dim3((M + 63) / 64, (g.Npad + 63) / 64), dim3(256), 0, st, ws, ks, M, g.Cout,
+  ICS_LAUNCH(splitk_finish_kernel, dim3((M + 63) / 64, (g.Npad + 63) / 64), dim3(256), 0, st, ws, ks, M, g.Cout,
                      g.Npad, bias, act_slope_of(pre_act), out, ldo, accumulate, stat_partial);
   ICS_HIP(hipGetLastError());
   if (rows_per_block) *rows_per_block = 64;
@@ -1930,7 +1936,7 @@ int launch_pack_par(hipStream_t st, const float* w, int Cin_total, int Cout, int
                     int Kpad, int Npad) {
   if (g_pack_rec) { g_pack_rec->push_back(PackJob{4, w, dst, {Cin_total, Cout, c_off, Cu, Kpad, Npad, 0, 0, 0}, 8ull * Kpad * Npad, 0}); return 0; }
   const size_t total = (size_t)8 * Kpad * Npad;
-  hipLaunchKernelGGL(pack_par_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, Cin_total, Cout,
+  ICS_LAUNCH(pack_par_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, Cin_total, Cout,
                      c_off, Cu, dst, Kpad, Npad);
   ICS_HIP(hipGetLastError());
   return 0;
@@ -1955,7 +1961,7 @@ int launch_pack_fwd_sub(hipStream_t st, const float* w, int taps, int Cin_total,
                         float* dst, int Kpad, int Npad) {
   if (g_pack_rec) { g_pack_rec->push_back(PackJob{3, w, dst, {taps, Cin_total, Cout, c_off, Csub, Npad, 0, 0, 0}, (unsigned long long)Kpad * Npad, 0}); return 0; }
   const size_t total = (size_t)Kpad * Npad;
-  hipLaunchKernelGGL(pack_fwd_sub_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, taps,
+  ICS_LAUNCH(pack_fwd_sub_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, taps,
                      Cin_total, Cout, c_off, Csub, dst, Kpad, Npad);
   ICS_HIP(hipGetLastError());
   return 0;
@@ -2557,13 +2563,13 @@ static int launch_reduce_splits(hipStream_t st, const float* ws, int nsplit, siz
   const bool v4 = N % 4 == 0 && ldw % 4 == 0 && n_elems % 4 == 0 && (reinterpret_cast<uintptr_t>(ws) & 15) == 0 &&
                   (reinterpret_cast<uintptr_t>(dw) & 15) == 0;
   if (v4 && !(nsplit >= 16 && n_elems * 4 < (size_t)1 << 20))
-    hipLaunchKernelGGL(reduce_splits4_kernel, dim3((unsigned)((n_elems / 4 + 255) / 256)), dim3(256), 0, st, ws, nsplit,
+    ICS_LAUNCH(reduce_splits4_kernel, dim3((unsigned)((n_elems / 4 + 255) / 256)), dim3(256), 0, st, ws, nsplit,
                        n_elems, N, dw, ldw, sub_rows, row_pitch, row_off);
   else if (nsplit >= 16 && n_elems * 4 < (size_t)1 << 20)
-    hipLaunchKernelGGL(reduce_splits_wide_kernel, dim3((unsigned)((n_elems + 31) / 32)), dim3(256), 0, st, ws, nsplit,
+    ICS_LAUNCH(reduce_splits_wide_kernel, dim3((unsigned)((n_elems + 31) / 32)), dim3(256), 0, st, ws, nsplit,
                        n_elems, N, dw, ldw, sub_rows, row_pitch, row_off);
   else
-    hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((n_elems + 255) / 256)), dim3(256), 0, st, ws, nsplit,
+    ICS_LAUNCH(reduce_splits_kernel, dim3((unsigned)((n_elems + 255) / 256)), dim3(256), 0, st, ws, nsplit,
                        n_elems, N, dw, ldw, sub_rows, row_pitch, row_off);
   ICS_HIP(hipGetLastError());
   return 0;
@@ -2847,7 +2853,7 @@ static int launch_wgrad_cfg(hipStream_t st, const ConvGeom& g, const ConvSrc& s0
                                 tf(DYVEC) + ", " + tf(AFF) + ", " + tf(UP) + ", " + tf(THIN) + ", " +
                                 std::to_string(ABL) + ">";
   g_last_kernel_id = id.c_str();
-  hipLaunchKernelGGL(kern, dim3(p.ktiles * p.ntiles * p.ksplit), dim3(256), lds, st, g, s0, s1, dy,
+  ICS_LAUNCH(kern, dim3(p.ktiles * p.ntiles * p.ksplit), dim3(256), lds, st, g, s0, s1, dy,
                      ldy, n_load, ws, p.ktiles, p.ntiles, p.rows_per_split);
   ICS_HIP(hipGetLastError());
   return 0;
@@ -2882,8 +2888,8 @@ int launch_conv_wgrad(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int
       if (phase != 2) {
 #define ICS_T1W(CKV)                                                                                                 \
   do {                                                                                                               \
-    if (aff) hipLaunchKernelGGL((thin1_wgrad_kernel<CKV, true>), dim3(nb), dim3(256), 0, st, g, src[0], dy, ldy, workspace); \
-    else hipLaunchKernelGGL((thin1_wgrad_kernel<CKV, false>), dim3(nb), dim3(256), 0, st, g, src[0], dy, ldy, workspace);    \
+    if (aff) ICS_LAUNCH((thin1_wgrad_kernel<CKV, true>), dim3(nb), dim3(256), 0, st, g, src[0], dy, ldy, workspace); \
+    else ICS_LAUNCH((thin1_wgrad_kernel<CKV, false>), dim3(nb), dim3(256), 0, st, g, src[0], dy, ldy, workspace);    \
   } while (0)
         switch (g.Cin / 16) { case 1: ICS_T1W(1); break; case 2: ICS_T1W(2); break; case 3: ICS_T1W(3); break; default: ICS_T1W(4); break; }
 #undef ICS_T1W
@@ -2897,7 +2903,7 @@ int launch_conv_wgrad(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int
 #define ICS_TNW(NOUT, AFFV, KPT, NAME)                                                                         \
   do {                                                                                                         \
     g_last_kernel_id = NAME;                                                                                   \
-    hipLaunchKernelGGL((conv_thin_n_wgrad_kernel<NOUT, AFFV, KPT>), dim3((M + rows - 1) / rows), dim3(256), 0,  \
+    ICS_LAUNCH((conv_thin_n_wgrad_kernel<NOUT, AFFV, KPT>), dim3((M + rows - 1) / rows), dim3(256), 0,  \
                        st, g, src[0], dy, ldy, workspace, rows);                                               \
   } while (0)
 #define ICS_TNW_K(NOUT, AFFV, TAG)                                                                  \
@@ -2951,7 +2957,7 @@ int launch_conv_wgrad(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int
 #define ICS_W3S(AFFV, NOACTV, LGV)                                                                              \
   do {                                                                                                          \
     g_last_kernel_id = "conv_wgrad3s_kernel<" #AFFV ", " #NOACTV ", " #LGV ">";                                 \
-    hipLaunchKernelGGL((conv_wgrad3s_kernel<AFFV, NOACTV, LGV>), grid, dim3(256), lds3, st, g, s0, s1, dy, ldy,  \
+    ICS_LAUNCH((conv_wgrad3s_kernel<AFFV, NOACTV, LGV>), grid, dim3(256), lds3, st, g, s0, s1, dy, ldy,  \
                        workspace, q.cgroups, q.ntiles, q.rows_per_split);                                       \
   } while (0)
 #define ICS_W3S_L(AFFV, NOACTV)                                                       \
@@ -2970,7 +2976,7 @@ int launch_conv_wgrad(hipStream_t st, const ConvGeom& g, const ConvSrc* src, int
 #define ICS_W3(AFFV, UPV, HALOV)                                                                                 \
   do {                                                                                                           \
     g_last_kernel_id = "conv_wgrad3_kernel<" #AFFV ", " #UPV ", " #HALOV ">";                                    \
-    hipLaunchKernelGGL((conv_wgrad3_kernel<AFFV, UPV, HALOV>), grid, dim3(256), lds, st, g, s0, s1, dy, ldy,      \
+    ICS_LAUNCH((conv_wgrad3_kernel<AFFV, UPV, HALOV>), grid, dim3(256), lds, st, g, s0, s1, dy, ldy,      \
                        n_load, workspace, q.cgroups, q.ntiles, q.rows_per_split);                                \
   } while (0)
       if (g.lgS > 5) {
@@ -3071,7 +3077,7 @@ int launch_materialize_input(hipStream_t st, const ConvSrc* src, int nsrc, int C
   int lg = 0;
   while ((1 << lg) < S) ++lg;
   const size_t total = (size_t)B * S * S * S * CinG;
-  hipLaunchKernelGGL(materialize_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, s0, s1, Cin,
+  ICS_LAUNCH(materialize_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, s0, s1, Cin,
                      CinG, S, lg, total, out);
   ICS_HIP(hipGetLastError());
   return 0;
@@ -3124,7 +3130,7 @@ int launch_pack_sub(hipStream_t st, const float* w, int taps, int Cin_total, int
                     int flip, float* dst, int Kpad, int Npad) {
   if (g_pack_rec) { g_pack_rec->push_back(PackJob{2, w, dst, {taps, Cin_total, Cout, c_off, Csub, flip, Npad, 0, 0}, (unsigned long long)Kpad * Npad, 0}); return 0; }
   const size_t total = (size_t)Kpad * Npad;
-  hipLaunchKernelGGL(pack_sub_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, taps, Cin_total,
+  ICS_LAUNCH(pack_sub_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, taps, Cin_total,
                      Cout, c_off, Csub, flip, dst, Kpad, Npad);
   ICS_HIP(hipGetLastError());
   return 0;
@@ -3134,7 +3140,7 @@ int launch_pack_fwd(hipStream_t st, const float* w, int K, int N, float* dst, in
                     int k_off, int n_off, int zero_first, int cin_log, int cin_phys) {
   if (g_pack_rec) { g_pack_rec->push_back(PackJob{0, w, dst, {K, N, Npad, k_off, n_off, cin_log, cin_phys, 0, 0}, (unsigned long long)Kpad * Npad, 0}); return 0; }
   const size_t total = (size_t)Kpad * Npad;
-  hipLaunchKernelGGL(pack_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, K, N,
+  ICS_LAUNCH(pack_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, K, N,
                      dst, Kpad, Npad, k_off, n_off, zero_first, cin_log, cin_phys);
   ICS_HIP(hipGetLastError());
   return 0;
@@ -3143,7 +3149,7 @@ int launch_pack_bwd(hipStream_t st, const float* w, int taps, int Cin, int Cout,
                     int Kpad, int Npad, int cout_total, int co_off, int zero_first) {
   if (g_pack_rec) { g_pack_rec->push_back(PackJob{1, w, dst, {taps, Cin, Cout, Npad, cout_total, co_off, 0, 0, 0}, (unsigned long long)Kpad * Npad, 0}); return 0; }
   const size_t total = (size_t)Kpad * Npad;
-  hipLaunchKernelGGL(pack_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, taps,
+  ICS_LAUNCH(pack_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, taps,
                      Cin, Cout, dst, Kpad, Npad, cout_total, co_off, zero_first);
   ICS_HIP(hipGetLastError());
   return 0;
@@ -3205,14 +3211,19 @@ __global__ void pack_wino_kernel(const float* __restrict__ w, int Cin_total, int
   if (t >= pairs) return;
   pack_wino_pair(t, w, Cin_total, Cout, c_off, Csub, bwd, dst, layout);
 }
+// The FULL predicate of the 64-channel kernel, size bound included: a layer whose geometry at the maximum batch fails
+// it keeps layout 0 and the 32 x 32 kernel at EVERY batch size (the caller stores the answer and hands it to
+// launch_conv_fwd_wino; deciding it again from the launch geometry once read layout-1 weights with the layout-0 kernel
+// in the window 2^29 <= B*S^3*C < 2^31).
 int conv_wino_layout(const ConvGeom& g) {
-  return (!(g.flags & CF_NO_WINO64) && g.Cout % 64 == 0 && g.Cin % 32 == 0) ? 1 : 0;
+  const ConvSrc s{nullptr, nullptr, nullptr, g.Cin, 0, ACT_NONE, 0};
+  return conv_wino64_ok(g, &s, 1) ? 1 : 0;
 }
 int launch_pack_wino(hipStream_t st, const float* w, int Cin_total, int Cout, int c_off, int Csub, int bwd, float* dst,
                      int layout) {
   const size_t pairs = (size_t)Csub * Cout;
   if (g_pack_rec) { g_pack_rec->push_back(PackJob{5, w, dst, {Cin_total, Cout, c_off, Csub, bwd, layout, 0, 0, 0}, (unsigned long long)pairs, 0}); return 0; }
-  hipLaunchKernelGGL(pack_wino_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, w, Cin_total, Cout,
+  ICS_LAUNCH(pack_wino_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, w, Cin_total, Cout,
                      c_off, Csub, bwd, dst, pairs, layout);
   ICS_HIP(hipGetLastError());
   return 0;
@@ -3263,7 +3274,7 @@ size_t conv_up3_weight_floats(int Cu, int Cout) { return (size_t)27 * Cu * Cout;
 int launch_pack_up3(hipStream_t st, const float* w, int Cin_total, int Cout, int c_off, int Cu, float* dst) {
   const size_t pairs = (size_t)Cu * Cout;
   if (g_pack_rec) { g_pack_rec->push_back(PackJob{6, w, dst, {Cin_total, Cout, c_off, Cu, 0, 0, 0, 0, 0}, (unsigned long long)pairs, 0}); return 0; }
-  hipLaunchKernelGGL(pack_up3_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, w, Cin_total, Cout, c_off,
+  ICS_LAUNCH(pack_up3_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, w, Cin_total, Cout, c_off,
                      Cu, dst, pairs);
   ICS_HIP(hipGetLastError());
   return 0;
@@ -3337,7 +3348,7 @@ int pack_table_record_end(void* handle, std::vector<unsigned char>* bytes, int* 
 }
 int launch_pack_table(hipStream_t st, const void* d_jobs, int njobs, unsigned nblocks) {
   if (njobs == 0) return 0;
-  hipLaunchKernelGGL(pack_table_kernel, dim3(nblocks), dim3(256), 0, st, static_cast<const PackJob*>(d_jobs), njobs);
+  ICS_LAUNCH(pack_table_kernel, dim3(nblocks), dim3(256), 0, st, static_cast<const PackJob*>(d_jobs), njobs);
   ICS_HIP(hipGetLastError());
   return 0;
 }

@@ -503,10 +503,7 @@ int launch_conv_fwd_up3(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, co
   // 32-voxel workgroups when they still give every CU several (c17.up 4096, c15.up 1024); 16-voxel ones below that
   const unsigned grid32 = (unsigned)(g.B * (g.S / 2) * (g.S / 4) * (g.S / 4) * (g.Cout / 64));
   // ICSG3D_UP3_BIG_MIN_WG overrides the threshold (tests: 1 = the 32-voxel tile wherever the shape allows it)
-  static const unsigned big_min = [] {
-    const char* e = getenv("ICSG3D_UP3_BIG_MIN_WG");
-    return e && *e ? (unsigned)strtoul(e, nullptr, 10) : (unsigned)ICS_UP3_BIG_MIN_WG;
-  }();
+  const unsigned big_min = (g.flags & CF_UP3_BIG_ALWAYS) ? 1u : (unsigned)ICS_UP3_BIG_MIN_WG;
   const bool big = grid32 >= big_min;
   const unsigned grid = big ? grid32 : 2u * grid32;
   if (stat_blocks) *stat_blocks = (int)(grid / (unsigned)(g.Cout / 64));
@@ -515,11 +512,11 @@ int launch_conv_fwd_up3(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, co
 #define ICS_UP3_LAUNCH(AFFV, NOACTV, STATSV)                                                                      \
   do {                                                                                                            \
     if (big)                                                                                                      \
-      hipLaunchKernelGGL((conv_up3_kernel<AFFV, NOACTV, STATSV, 2>), dim3(grid), dim3(512), 0, st, s0.p, s0.C,     \
+      ICS_LAUNCH((conv_up3_kernel<AFFV, NOACTV, STATSV, 2>), dim3(grid), dim3(512), 0, st, s0.p, s0.C,     \
                          s0.scale, s0.shift, in_slope, wt, bias, out, ldo, pre_slope, accumulate, stat_partial,   \
                          g.Npad, g.S, g.Cin, g.Cout);                                                             \
     else                                                                                                          \
-      hipLaunchKernelGGL((conv_up3_kernel<AFFV, NOACTV, STATSV, 1>), dim3(grid), dim3(512), 0, st, s0.p, s0.C,     \
+      ICS_LAUNCH((conv_up3_kernel<AFFV, NOACTV, STATSV, 1>), dim3(grid), dim3(512), 0, st, s0.p, s0.C,     \
                          s0.scale, s0.shift, in_slope, wt, bias, out, ldo, pre_slope, accumulate, stat_partial,   \
                          g.Npad, g.S, g.Cin, g.Cout);                                                             \
     conv_set_last_kernel_id(big ? "conv_up3_kernel<" #AFFV ", " #NOACTV ", " #STATSV ", 2>"                         \

@@ -771,9 +771,10 @@ size_t conv_wino_weight_floats(int Cin, int Cout) { return (size_t)64 * Cin * Co
 
 int launch_conv_fwd_wino(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, const float* wt, const float* bias,
                          float* out, int ldo, int pre_act, float* stat_partial, int* rows_per_block, int accumulate,
-                         const BwdStat* bwd, int* bwd_blocks) {
+                         int layout, const BwdStat* bwd, int* bwd_blocks) {
   ICS_CHECK(conv_wino_ok(g, &s0, 1), "shape not served by the Winograd kernel");
-  if (conv_wino64_ok(g, &s0, 1))                 // Cout % 64 == 0: the 16-tile x 64-channel shape (weights in layout 1)
+  ICS_CHECK(layout == 0 || layout == 1, "unknown Winograd weight layout");
+  if (layout == 1)       // the 16-tile x 64-channel shape: the layout the weights were packed in decides, not this launch
     return launch_conv_fwd_wino64(st, g, s0, wt, bias, out, ldo, pre_act, stat_partial, rows_per_block, accumulate, bwd,
                                   bwd_blocks);
   ICS_CHECK(ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
@@ -792,7 +793,7 @@ int launch_conv_fwd_wino(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, c
   const BwdStat bs = fold ? *bwd : BwdStat{};
 #define ICS_WINO_LAUNCH(AFFV, NOACTV, FOLDV)                                                                        \
   do {                                                                                                              \
-    hipLaunchKernelGGL((conv_wino_kernel<AFFV, NOACTV, FOLDV>), dim3(grid), dim3(512), 0, st, s0.p, s0.C, s0.scale, \
+    ICS_LAUNCH((conv_wino_kernel<AFFV, NOACTV, FOLDV>), dim3(grid), dim3(512), 0, st, s0.p, s0.C, s0.scale, \
                        s0.shift, in_slope, wt, bias, out, ldo, pre_slope, accumulate, stat_partial, g.Npad, g.S,    \
                        g.Cin, g.Cout, bs);                                                                          \
     conv_set_last_kernel_id("conv_wino_kernel<" #AFFV ", " #NOACTV ", " #FOLDV ">");                                \
@@ -857,7 +858,7 @@ int launch_conv_wgrad_wino(hipStream_t st, const ConvGeom& g, const ConvSrc& s0,
     const float in_slope = wslope(s0.act);
 #define ICS_WG_LAUNCH(AFFV, NOACTV)                                                                                   \
   do {                                                                                                                \
-    hipLaunchKernelGGL((conv_wino_wgrad_kernel<AFFV, NOACTV>), dim3(grid), dim3(512), 0, st, s0.p, s0.C, s0.scale,    \
+    ICS_LAUNCH((conv_wino_wgrad_kernel<AFFV, NOACTV>), dim3(grid), dim3(512), 0, st, s0.p, s0.C, s0.scale,    \
                        s0.shift, in_slope, dy, ldy, ws, g.S, g.Cin, g.Cout, per_split);                               \
     conv_set_last_kernel_id("conv_wino_wgrad_kernel<" #AFFV ", " #NOACTV ">");                                        \
   } while (0)

@@ -620,7 +620,7 @@ int launch_conv_fwd_wino64(hipStream_t st, const ConvGeom& g, const ConvSrc& s0,
   const BwdStat bs = fold ? *bwd : BwdStat{};
 #define ICS_WINO_LAUNCH(AFFV, NOACTV, FOLDV)                                                                          \
   do {                                                                                                                \
-    hipLaunchKernelGGL((conv_wino64_kernel<AFFV, NOACTV, FOLDV>), dim3(grid), dim3(512), 0, st, s0.p, s0.C, s0.scale, \
+    ICS_LAUNCH((conv_wino64_kernel<AFFV, NOACTV, FOLDV>), dim3(grid), dim3(512), 0, st, s0.p, s0.C, s0.scale, \
                        s0.shift, in_slope, wt, bias, out, ldo, pre_slope, accumulate, stat_partial, g.Npad, g.S,      \
                        g.Cin, g.Cout, bs);                                                                            \
     conv_set_last_kernel_id("conv_wino64_kernel<" #AFFV ", " #NOACTV ", " #FOLDV ">");                                \

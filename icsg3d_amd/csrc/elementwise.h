@@ -50,6 +50,7 @@ struct LayerBwd {
   int B, S, lgS, C;
   int has_bn, pre_act, post_act;
   int pool_ties_all;              // 1: TF-CPU MaxPool3DGrad tie rule, 0: first max only
+  int flags;                      // ConvFlags of the owning handle
 };
 
 int launch_bn_finalize(hipStream_t st, const float* partial, int nblk, int Npad, const BnParams& bn,
@@ -75,8 +76,8 @@ struct PmSums {
   double per[4];
   float w[4];
 };
-bool head_fused_ok(int ncls, int cin, size_t M, int act);
-bool head_dgrad_ok(int ncls, int cin, size_t M, const BwdStat* bs);
+bool head_fused_ok(int ncls, int cin, size_t M, int act, int flags);     // flags: the handle's ConvFlags
+bool head_dgrad_ok(int ncls, int cin, size_t M, const BwdStat* bs, int flags);
 int launch_head_dgrad(hipStream_t st, const float* dz, const float* wsoft_k, const float* wsig_k, float* dx, int ldo, size_t M,
                       const BwdStat* bs, int Npad, int* blocks);
 int launch_head_fused(hipStream_t st, const float* x, int ldx, const float* scale, const float* shift, const float* wsoft_k,

@@ -164,22 +164,22 @@ __global__ void bn_sync_finalize_kernel(const double* __restrict__ gathered, int
 int launch_bn_finalize(hipStream_t st, const float* partial, int nblk, int Npad, const BnParams& bn,
                        int C, int update_moving, int unbias, const BnSync* sync) {
   if (sync != nullptr) {
-    hipLaunchKernelGGL(bn_local_merge_kernel, dim3(C), dim3(256), 0, st, partial, nblk, Npad, C, sync->local);
+    ICS_LAUNCH(bn_local_merge_kernel, dim3(C), dim3(256), 0, st, partial, nblk, Npad, C, sync->local);
     ICS_HIP(hipGetLastError());
     ncclResult_t r = ncclAllGather(sync->local, sync->gathered, (size_t)3 * C, ncclDouble, sync->comm, st);
     ICS_CHECK(r == ncclSuccess, std::string("ncclAllGather(SyncBN): ") + ncclGetErrorString(r));
-    hipLaunchKernelGGL(bn_sync_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, sync->gathered, sync->nranks, C,
+    ICS_LAUNCH(bn_sync_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, sync->gathered, sync->nranks, C,
                        bn, update_moving, 0.99f, unbias);
     ICS_HIP(hipGetLastError());
     return 0;
   }
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(nblk >= 2048 ? 1024 : 256), 0, st, partial, nblk, Npad, bn,
+  ICS_LAUNCH(bn_finalize_kernel, dim3(C), dim3(nblk >= 2048 ? 1024 : 256), 0, st, partial, nblk, Npad, bn,
                      update_moving, 0.99f, unbias);
   ICS_HIP(hipGetLastError());
   return 0;
 }
 int launch_bn_eval_prepare(hipStream_t st, const BnParams& bn, int C) {
-  hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3((C + 255) / 256), dim3(256), 0, st, bn, C);
+  ICS_LAUNCH(bn_eval_prepare_kernel, dim3((C + 255) / 256), dim3(256), 0, st, bn, C);
   ICS_HIP(hipGetLastError());
   return 0;
 }
@@ -253,13 +253,13 @@ int launch_pool_fwd(hipStream_t st, const float* s, const float* scale, const fl
                     int B, int S, int C, float* out, unsigned char* idx) {
   if (C % 4 == 0 && ((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(idx)) & 15) == 0) {
     const size_t total4 = (size_t)B * (S / 2) * (S / 2) * (S / 2) * (C / 4);
-    hipLaunchKernelGGL(pool_fwd4_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, s, scale, shift, act, B,
+    ICS_LAUNCH(pool_fwd4_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, s, scale, shift, act, B,
                        S, C, out, idx);
     ICS_HIP(hipGetLastError());
     return 0;
   }
   const size_t total = (size_t)B * (S / 2) * (S / 2) * (S / 2) * C;
-  hipLaunchKernelGGL(pool_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, s, scale,
+  ICS_LAUNCH(pool_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, s, scale,
                      shift, act, B, S, C, out, idx);
   ICS_HIP(hipGetLastError());
   return 0;
@@ -745,7 +745,7 @@ int launch_layer_bwd(hipStream_t st, const LayerBwd& L, float* dy, float* ws_par
   const bool fast = v4 && L.has_bn && !L.dtap && (!L.tap_ref || L.g1.kind == GS_NONE) && cb <= 256 && (cb & (cb - 1)) == 0 &&
                     ((size_t)n % (size_t)(256 / (cb ? cb : 1))) == 0 &&
                     (L.g0.kind == GS_DIRECT || L.g0.kind == GS_POOL) &&
-                    (L.g1.kind == GS_NONE || L.g1.kind == GS_DIRECT) && std::getenv("ICSG3D_NO_FAST_BNBWD") == nullptr;
+                    (L.g1.kind == GS_NONE || L.g1.kind == GS_DIRECT) && !(L.flags & CF_NO_FAST_BNBWD);
   if (L.has_bn) {
     const float* red = ws_partial;
     int red_n = nblk, red_ld = L.C;
@@ -754,7 +754,7 @@ int launch_layer_bwd(hipStream_t st, const LayerBwd& L, float* dy, float* ws_par
       red = pre->partial; red_n = pre->nblk; red_ld = pre->ld;
     } else if (fast) {
 #define ICS_BNR(G0_, G1_, T_, U_) \
-      hipLaunchKernelGGL((bn_bwd_reduce_fast_kernel<G0_, G1_, T_, U_>), dim3(nblk), dim3(256), 0, st, L, ws_partial)
+      ICS_LAUNCH((bn_bwd_reduce_fast_kernel<G0_, G1_, T_, U_>), dim3(nblk), dim3(256), 0, st, L, ws_partial)
       const bool g1 = L.g1.kind == GS_DIRECT, ties = L.pool_ties_all != 0;
       if (L.g0.kind == GS_DIRECT) { if (g1) ICS_BNR(GS_DIRECT, GS_DIRECT, false, 4); else ICS_BNR(GS_DIRECT, GS_NONE, false, 4); }
       else if (ties) { if (g1) ICS_BNR(GS_POOL, GS_DIRECT, true, 2); else ICS_BNR(GS_POOL, GS_NONE, true, 2); }
@@ -762,17 +762,17 @@ int launch_layer_bwd(hipStream_t st, const LayerBwd& L, float* dy, float* ws_par
 #undef ICS_BNR
       ICS_HIP(hipGetLastError());
     } else {
-      if (v4) hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, dim3(nblk), dim3(256), 0, st, L, rpb, ws_partial);
-      else hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(nblk), dim3(256), 0, st, L, rpb, ws_partial);
+      if (v4) ICS_LAUNCH(bn_bwd_reduce_kernel<4>, dim3(nblk), dim3(256), 0, st, L, rpb, ws_partial);
+      else ICS_LAUNCH(bn_bwd_reduce_kernel<1>, dim3(nblk), dim3(256), 0, st, L, rpb, ws_partial);
       ICS_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(L.C), dim3(red_n >= 2048 ? 1024 : 256), 0, st, red, red_n, L.C, red_ld, n, c1,
+    ICS_LAUNCH(bn_bwd_finalize_kernel, dim3(L.C), dim3(red_n >= 2048 ? 1024 : 256), 0, st, red, red_n, L.C, red_ld, n, c1,
                        c2, dgamma, dbeta, sync ? sync->local : nullptr);
     ICS_HIP(hipGetLastError());
     if (sync) {   // every rank holds the same number of rows (equal shards): n_global = n * nranks
       ncclResult_t r = ncclAllReduce(sync->local, sync->local, (size_t)2 * L.C, ncclDouble, ncclSum, sync->comm, st);
       ICS_CHECK(r == ncclSuccess, std::string("ncclAllReduce(SyncBN bwd): ") + ncclGetErrorString(r));
-      hipLaunchKernelGGL(bn_bwd_sync_c_kernel, dim3((L.C + 63) / 64), dim3(64), 0, st, sync->local, L.C,
+      ICS_LAUNCH(bn_bwd_sync_c_kernel, dim3((L.C + 63) / 64), dim3(64), 0, st, sync->local, L.C,
                          n * (double)sync->nranks, c1, c2);
       ICS_HIP(hipGetLastError());
     }
@@ -781,27 +781,27 @@ int launch_layer_bwd(hipStream_t st, const LayerBwd& L, float* dy, float* ws_par
   if (fast) {
     // M = B * S^3 with S >= 4 a power of two and RPP <= 64 rows per pass: whole passes
 #define ICS_BNF(G0_, G1_, T_, U_) \
-    hipLaunchKernelGGL((bn_bwd_apply_fast_kernel<G0_, G1_, T_, U_>), dim3(nblk), dim3(256), 0, st, L, c1, c2, dy, dbp)
+    ICS_LAUNCH((bn_bwd_apply_fast_kernel<G0_, G1_, T_, U_>), dim3(nblk), dim3(256), 0, st, L, c1, c2, dy, dbp)
     const bool g1 = L.g1.kind == GS_DIRECT, ties = L.pool_ties_all != 0;
     if (L.tap_ref) {                               // perceptual tap layers: behind the max-pool, or straight from a consumer
-      if (L.g0.kind == GS_DIRECT) hipLaunchKernelGGL((bn_bwd_apply_fast_kernel<GS_DIRECT, GS_NONE, false, 4, true>), dim3(nblk), dim3(256), 0, st, L, c1, c2, dy, dbp);
-      else if (ties) hipLaunchKernelGGL((bn_bwd_apply_fast_kernel<GS_POOL, GS_NONE, true, 2, true>), dim3(nblk), dim3(256), 0, st, L, c1, c2, dy, dbp);
-      else hipLaunchKernelGGL((bn_bwd_apply_fast_kernel<GS_POOL, GS_NONE, false, 2, true>), dim3(nblk), dim3(256), 0, st, L, c1, c2, dy, dbp);
+      if (L.g0.kind == GS_DIRECT) ICS_LAUNCH((bn_bwd_apply_fast_kernel<GS_DIRECT, GS_NONE, false, 4, true>), dim3(nblk), dim3(256), 0, st, L, c1, c2, dy, dbp);
+      else if (ties) ICS_LAUNCH((bn_bwd_apply_fast_kernel<GS_POOL, GS_NONE, true, 2, true>), dim3(nblk), dim3(256), 0, st, L, c1, c2, dy, dbp);
+      else ICS_LAUNCH((bn_bwd_apply_fast_kernel<GS_POOL, GS_NONE, false, 2, true>), dim3(nblk), dim3(256), 0, st, L, c1, c2, dy, dbp);
     }
     else if (L.g0.kind == GS_DIRECT) { if (g1) ICS_BNF(GS_DIRECT, GS_DIRECT, false, 4); else ICS_BNF(GS_DIRECT, GS_NONE, false, 4); }
     else if (ties) { if (g1) ICS_BNF(GS_POOL, GS_DIRECT, true, 2); else ICS_BNF(GS_POOL, GS_NONE, true, 2); }
     else { if (g1) ICS_BNF(GS_POOL, GS_DIRECT, false, 2); else ICS_BNF(GS_POOL, GS_NONE, false, 2); }
 #undef ICS_BNF
   } else if (L.tap_ref) {
-    if (v4) hipLaunchKernelGGL((bn_bwd_apply_kernel<4, true>), dim3(nblk), dim3(256), 0, st, L, rpb, c1, c2, dy, dbp);
-    else hipLaunchKernelGGL((bn_bwd_apply_kernel<1, true>), dim3(nblk), dim3(256), 0, st, L, rpb, c1, c2, dy, dbp);
+    if (v4) ICS_LAUNCH((bn_bwd_apply_kernel<4, true>), dim3(nblk), dim3(256), 0, st, L, rpb, c1, c2, dy, dbp);
+    else ICS_LAUNCH((bn_bwd_apply_kernel<1, true>), dim3(nblk), dim3(256), 0, st, L, rpb, c1, c2, dy, dbp);
   } else {
-    if (v4) hipLaunchKernelGGL((bn_bwd_apply_kernel<4, false>), dim3(nblk), dim3(256), 0, st, L, rpb, c1, c2, dy, dbp);
-    else hipLaunchKernelGGL((bn_bwd_apply_kernel<1, false>), dim3(nblk), dim3(256), 0, st, L, rpb, c1, c2, dy, dbp);
+    if (v4) ICS_LAUNCH((bn_bwd_apply_kernel<4, false>), dim3(nblk), dim3(256), 0, st, L, rpb, c1, c2, dy, dbp);
+    else ICS_LAUNCH((bn_bwd_apply_kernel<1, false>), dim3(nblk), dim3(256), 0, st, L, rpb, c1, c2, dy, dbp);
   }
   ICS_HIP(hipGetLastError());
   if (dbias) {
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(L.C), dim3(256), 0, st, ws_partial, nblk, L.C, dbias);
+    ICS_LAUNCH(colsum_finalize_kernel, dim3(L.C), dim3(256), 0, st, ws_partial, nblk, L.C, dbias);
     ICS_HIP(hipGetLastError());
   }
   return 0;
@@ -1149,8 +1149,8 @@ __global__ __launch_bounds__(256, 2) void head_fused_kernel(const float* __restr
   if (tid < 6) partial[(size_t)blockIdx.x * 6 + tid] = shd[0][tid] + shd[1][tid] + shd[2][tid] + shd[3][tid];
 }
 
-bool head_fused_ok(int ncls, int cin, size_t M, int act) {
-  return ncls == 95 && cin == 128 && M % 16 == 0 && act == ACT_NONE && std::getenv("ICSG3D_NO_FUSED_HEAD") == nullptr;
+bool head_fused_ok(int ncls, int cin, size_t M, int act, int flags) {
+  return ncls == 95 && cin == 128 && M % 16 == 0 && act == ACT_NONE && !(flags & CF_NO_FUSED_HEAD);
 }
 int launch_head_fused(hipStream_t st, const float* x, int ldx, const float* scale, const float* shift, const float* wsoft_k,
                       const float* wsig_k, const float* bsoft, const float* bsig, float* z, const unsigned char* labels,
@@ -1161,7 +1161,7 @@ int launch_head_fused(hipStream_t st, const float* x, int ldx, const float* scal
   int nblk = (ntiles + 3) / 4;
   const int cap = partial_blocks < 512 ? partial_blocks : 512;   // 2 workgroups per CU, whole rounds of tiles at B = 32
   if (nblk > cap) nblk = cap;
-  hipLaunchKernelGGL(head_fused_kernel, dim3(nblk), dim3(256), 0, st, x, ldx, scale, shift, wsoft_k, wsig_k, bsoft, bsig, z,
+  ICS_LAUNCH(head_fused_kernel, dim3(nblk), dim3(256), 0, st, x, ldx, scale, shift, wsoft_k, wsig_k, bsoft, bsig, z,
                      labels, ntiles, mode, want_grad, wsoft, (float)(1.0 / (double)M), partial, dz_colsum);
   ICS_HIP(hipGetLastError());
   if (nblk_out) *nblk_out = nblk;
@@ -1260,9 +1260,9 @@ __global__ __launch_bounds__(256, 2) void head_dgrad_kernel(const float* __restr
   }
 }
 
-bool head_dgrad_ok(int ncls, int cin, size_t M, const BwdStat* bs) {
+bool head_dgrad_ok(int ncls, int cin, size_t M, const BwdStat* bs, int flags) {
   return ncls == 95 && cin == 128 && M % 16 == 0 && (bs == nullptr || bs->partial == nullptr || bs->post_act == ACT_NONE) &&
-         std::getenv("ICSG3D_NO_FUSED_HEAD") == nullptr;
+         !(flags & CF_NO_FUSED_HEAD);
 }
 int launch_head_dgrad(hipStream_t st, const float* dz, const float* wsoft_k, const float* wsig_k, float* dx, int ldo, size_t M,
                       const BwdStat* bs, int Npad, int* blocks) {
@@ -1271,7 +1271,7 @@ int launch_head_dgrad(hipStream_t st, const float* dz, const float* wsoft_k, con
   int nblk = (ntiles + 3) / 4;
   if (nblk > 512) nblk = 512;
   const BwdStat b = bs ? *bs : BwdStat{};
-  hipLaunchKernelGGL(head_dgrad_kernel, dim3(nblk), dim3(256), 0, st, dz, wsoft_k, wsig_k, dx, ldo, ntiles, b, Npad);
+  ICS_LAUNCH(head_dgrad_kernel, dim3(nblk), dim3(256), 0, st, dz, wsoft_k, wsig_k, dx, ldo, ntiles, b, Npad);
   ICS_HIP(hipGetLastError());
   conv_set_last_kernel_id("head_dgrad_kernel");
   if (blocks) *blocks = b.partial ? nblk : 0;
@@ -1320,7 +1320,7 @@ __global__ __launch_bounds__(256) void head_finalize_kernel(const double* __rest
 }
 int launch_head_metrics(hipStream_t st, const double* partial, int nblk, double M, float* metrics, double* sums,
                         int phase) {
-  hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(256), 0, st, partial, nblk, M, metrics, sums, phase);
+  ICS_LAUNCH(head_finalize_kernel, dim3(1), dim3(256), 0, st, partial, nblk, M, metrics, sums, phase);
   ICS_HIP(hipGetLastError());
   return 0;
 }
@@ -1332,7 +1332,7 @@ int launch_head(hipStream_t st, float* z, int ldz, int ncls, const unsigned char
   int rpb = (int)((M + partial_blocks - 1) / partial_blocks);
   rpb = (rpb + 15) / 16 * 16;
   const int nblk = (int)((M + rpb - 1) / rpb);
-  hipLaunchKernelGGL(head_kernel, dim3(nblk), dim3(256), 0, st, z, ldz, ncls, labels, M, rpb, mode,
+  ICS_LAUNCH(head_kernel, dim3(nblk), dim3(256), 0, st, z, ldz, ncls, labels, M, rpb, mode,
                      want_grad, wsoft, (float)(1.0 / (double)M), partial, dz_colsum);
   ICS_HIP(hipGetLastError());
   if (nblk_out) *nblk_out = nblk;
@@ -1405,7 +1405,7 @@ __global__ __launch_bounds__(256) void pool27_kernel(const float* __restrict__ d
 int launch_pool27(hipStream_t st, const float* dy, int B, int S, int N, float* out, int ldo) {
   ICS_CHECK(N % 4 == 0 && ldo % 4 == 0, "pool27: channel counts must be multiples of 4");
   const size_t total = (size_t)B * (S / 2) * (S / 2) * (S / 2) * (N / 4);
-  hipLaunchKernelGGL(pool27_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dy, B, S, N, total, out, ldo);
+  ICS_LAUNCH(pool27_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dy, B, S, N, total, out, ldo);
   ICS_HIP(hipGetLastError());
   return 0;
 }
@@ -1422,7 +1422,7 @@ __global__ void permute_up_dw_kernel(const float* __restrict__ tmp, int Cu, int 
 }
 int launch_permute_up_dw(hipStream_t st, const float* tmp, int Cu, int N, int Cin, int c_off, float* dw) {
   const size_t total = (size_t)27 * Cu * N;
-  hipLaunchKernelGGL(permute_up_dw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, tmp, Cu, N, Cin,
+  ICS_LAUNCH(permute_up_dw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, tmp, Cu, N, Cin,
                      c_off, total, dw);
   ICS_HIP(hipGetLastError());
   return 0;
@@ -1445,7 +1445,7 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 }
 int launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v, size_t n, float lr_t,
                 float gscale) {
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, g, m, v, n,
+  ICS_LAUNCH(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, g, m, v, n,
                      lr_t, 0.9f, 0.999f, (float)(1.0 - 0.9), (float)(1.0 - 0.999), 1e-7f, gscale);
   ICS_HIP(hipGetLastError());
   return 0;
@@ -1465,7 +1465,7 @@ __global__ void bn_apply_kernel(const float* __restrict__ s, const float* __rest
 }
 int launch_bn_apply(hipStream_t st, const float* s, const float* scale, const float* shift, int act,
                     size_t n, int C, float* out) {
-  hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s, scale, shift,
+  ICS_LAUNCH(bn_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s, scale, shift,
                      act, n, C, out);
   ICS_HIP(hipGetLastError());
   return 0;
@@ -1507,7 +1507,7 @@ __global__ __launch_bounds__(256) void sqdiff_kernel(const float* __restrict__ a
 }
 int launch_sqdiff(hipStream_t st, const float* a, const float* b, int B, size_t per_sample,
                   int blocks_per_sample, double* partial, float* grad, float coef, int accumulate) {
-  hipLaunchKernelGGL(sqdiff_kernel, dim3(B * blocks_per_sample), dim3(256), 0, st, a, b, per_sample,
+  ICS_LAUNCH(sqdiff_kernel, dim3(B * blocks_per_sample), dim3(256), 0, st, a, b, per_sample,
                      blocks_per_sample, partial, grad, coef, accumulate);
   ICS_HIP(hipGetLastError());
   return 0;
@@ -1533,7 +1533,7 @@ __global__ void sampling_kernel(const float* __restrict__ mulv, int ld, int late
 int launch_sampling(hipStream_t st, const float* mulv, int ld, int latent, const float* eps,
                     const float* cond, int ncond, int B, float* z, float* zc) {
   const int n = B * (latent + ncond);
-  hipLaunchKernelGGL(sampling_kernel, dim3((n + 255) / 256), dim3(256), 0, st, mulv, ld, latent, eps, cond,
+  ICS_LAUNCH(sampling_kernel, dim3((n + 255) / 256), dim3(256), 0, st, mulv, ld, latent, eps, cond,
                      ncond, B, z, zc);
   ICS_HIP(hipGetLastError());
   return 0;
@@ -1601,7 +1601,7 @@ __global__ void vae_dz_kernel(const float* __restrict__ mulv, int ld, int latent
 int launch_vae_loss(hipStream_t st, const float* mulv, int ld, int latent, int B, const double* mse_partial,
                     int n_mse, double n_elems, const double* pm_partial, const PmSums& pmc, float alpha, float beta,
                     float* metrics, double* sums, int phase) {
-  hipLaunchKernelGGL(vae_loss_kernel, dim3(1), dim3(256), 0, st, mulv, ld, latent, B, mse_partial, n_mse,
+  ICS_LAUNCH(vae_loss_kernel, dim3(1), dim3(256), 0, st, mulv, ld, latent, B, mse_partial, n_mse,
                      n_elems, pm_partial, pmc, alpha, beta, metrics, sums, phase);
   ICS_HIP(hipGetLastError());
   return 0;
@@ -1609,7 +1609,7 @@ int launch_vae_loss(hipStream_t st, const float* mulv, int ld, int latent, int B
 int launch_vae_dz(hipStream_t st, const float* mulv, int ld, int latent, int B, const float* eps,
                   const float* dzc, int ldzc, float beta, float* dmulv) {
   const int n = B * latent;
-  hipLaunchKernelGGL(vae_dz_kernel, dim3((n + 255) / 256), dim3(256), 0, st, mulv, ld, latent, B, eps, dzc,
+  ICS_LAUNCH(vae_dz_kernel, dim3((n + 255) / 256), dim3(256), 0, st, mulv, ld, latent, B, eps, dzc,
                      ldzc, beta, dmulv);
   ICS_HIP(hipGetLastError());
   return 0;
@@ -1647,7 +1647,7 @@ __global__ void cond_bias_table_kernel(const float* __restrict__ w, const float*
 int launch_cond_bias_table(hipStream_t st, const float* w, const float* bias, const float* cond, int C, int ncond,
                            int Cin_tot, int Cout, int B, float* T) {
   const int n = B * 27 * Cout;
-  hipLaunchKernelGGL(cond_bias_table_kernel, dim3((n + 255) / 256), dim3(256), 0, st, w, bias, cond, C, ncond, Cin_tot,
+  ICS_LAUNCH(cond_bias_table_kernel, dim3((n + 255) / 256), dim3(256), 0, st, w, bias, cond, C, ncond, Cin_tot,
                      Cout, B, T);
   ICS_HIP(hipGetLastError());
   return 0;
@@ -1738,9 +1738,9 @@ int launch_cond_wgrad(hipStream_t st, const float* dy, int B, int S, int Cout, c
   double* tot_partial = ws;                                  // [B][64][Cout]
   double* R = ws + (size_t)B * bps * Cout;                   // [B][27][Cout]
   const size_t per = (size_t)S * S * S;
-  hipLaunchKernelGGL(sample_colsum_kernel, dim3(B * bps), dim3(256), 0, st, dy, per, Cout, bps, tot_partial);
-  hipLaunchKernelGGL(border_region_sums_kernel, dim3(B * 27), dim3(256), 0, st, dy, S, Cout, R);
-  hipLaunchKernelGGL(cond_wgrad_kernel, dim3(27), dim3(256), (size_t)B * Cout * sizeof(double), st, R, tot_partial, bps,
+  ICS_LAUNCH(sample_colsum_kernel, dim3(B * bps), dim3(256), 0, st, dy, per, Cout, bps, tot_partial);
+  ICS_LAUNCH(border_region_sums_kernel, dim3(B * 27), dim3(256), 0, st, dy, S, Cout, R);
+  ICS_LAUNCH(cond_wgrad_kernel, dim3(27), dim3(256), (size_t)B * Cout * sizeof(double), st, R, tot_partial, bps,
                      cond, B, C0, nfold, ncond, Cin_tot, Cout, dw);
   ICS_HIP(hipGetLastError());
   return 0;
@@ -1752,7 +1752,7 @@ __global__ void relu_bwd_kernel(const float* __restrict__ a, float* __restrict__
   if (i < n && !(a[i] > 0.f)) g[i] = 0.f;
 }
 int launch_relu_bwd(hipStream_t st, const float* a, float* g, size_t n) {
-  hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, g, n);
+  ICS_LAUNCH(relu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, g, n);
   ICS_HIP(hipGetLastError());
   return 0;
 }
@@ -1766,7 +1766,7 @@ __global__ void colsum_small_kernel(const float* __restrict__ a, int rows, int c
   out[c] = s;
 }
 int launch_colsum_small(hipStream_t st, const float* a, int rows, int cols, int ld, float* out) {
-  hipLaunchKernelGGL(colsum_small_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, a, rows, cols, ld, out);
+  ICS_LAUNCH(colsum_small_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, a, rows, cols, ld, out);
   ICS_HIP(hipGetLastError());
   return 0;
 }
@@ -1775,7 +1775,7 @@ __global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, 
   if (i < n) y[i] += a * x[i];
 }
 int launch_axpy(hipStream_t st, float* y, const float* x, size_t n, float a) {
-  hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, y, x, n, a);
+  ICS_LAUNCH(axpy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, y, x, n, a);
   ICS_HIP(hipGetLastError());
   return 0;
 }

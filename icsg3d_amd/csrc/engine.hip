@@ -27,6 +27,7 @@ struct Range {
   ~Range() { roctxRangePop(); }
 };
 
+std::atomic<long long> g_kernel_launches{0};
 static thread_local std::string g_err;
 void set_error(const std::string& msg) { g_err = msg; }
 
@@ -121,6 +122,7 @@ struct ConvLayer {
   float *wp = nullptr, *wf = nullptr;   // packed forward / backward-data weights
   float *ww = nullptr, *wwb = nullptr;  // Winograd-transformed forward / backward-data weights (conv_wino.hip); of the
                                         // skip channels only in an up-split layer.  nullptr: layer not served
+  int ww_layout = 0, wwb_layout = 0;    // decided once at the maximum batch (conv_wino_layout), used by pack AND launch
   bool wino_w = false;                  // backward-weight in the Winograd domain
   float* s = nullptr;                   // stored output [M][Cout]
   float* dy = nullptr;                  // grad w.r.t. conv output [M][Cout]
@@ -412,10 +414,15 @@ static int enable_wino(Net& n, ConvLayer& L, bool need_bwd) {
   if ((n.flags & CF_NO_WINO) || L.taps != 27 || L.pad_in || L.cond_fold || L.CinG != L.Cin) return 0;
   if (L.split_up ? L.Cs == 0 : L.nsrc != 1) return 0;
   const int K = L.split_up ? L.Cs : L.Cin;
-  if (conv_wino_ok(geom_wino_fwd(L, n.maxB), L.src, 1)) ICS_TRY(n.alloc(&L.ww, conv_wino_weight_floats(K, L.Cout)));
+  if (conv_wino_ok(geom_wino_fwd(L, n.maxB), L.src, 1)) {
+    ICS_TRY(n.alloc(&L.ww, conv_wino_weight_floats(K, L.Cout)));
+    L.ww_layout = conv_wino_layout(geom_wino_fwd(L, n.maxB));
+  }
   const ConvSrc sdy = src_plain(nullptr, L.Cout);
-  if (need_bwd && conv_wino_ok(geom_wino_bwd(L, n.maxB), &sdy, 1))
+  if (need_bwd && conv_wino_ok(geom_wino_bwd(L, n.maxB), &sdy, 1)) {
     ICS_TRY(n.alloc(&L.wwb, conv_wino_weight_floats(K, L.Cout)));
+    L.wwb_layout = conv_wino_layout(geom_wino_bwd(L, n.maxB));
+  }
   L.wino_w = need_bwd && conv_wino_wgrad_ok(L.split_up ? geom_skip_wgrad(L, n.maxB) : geom_fwd(L, n.maxB), L.src, 1);
   return 0;
 }
@@ -493,7 +500,7 @@ __global__ void fill_kernel(float* p, size_t n, float v) {
   if (i < n) p[i] = v;
 }
 static int fill(Net& n, float* p, size_t cnt, float v) {
-  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, n.st, p, cnt, v);
+  ICS_LAUNCH(fill_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, n.st, p, cnt, v);
   ICS_HIP(hipGetLastError());
   return 0;
 }
@@ -529,11 +536,9 @@ static int pack_layer(Net& n, ConvLayer& L, bool need_bwd) {
     else ICS_TRY(launch_pack_par(n.st, n.tp(L.t_w), L.Cin, L.Cout, L.Cs, L.Cu, L.wp_par, 8 * L.Cu, L.Npad));
   }
   if (wino_f)
-    ICS_TRY(launch_pack_wino(n.st, n.tp(L.t_w), L.Cin, L.Cout, 0, L.split_up ? L.Cs : L.Cin, 0, L.ww,
-                             conv_wino_layout(geom_wino_fwd(L, n.maxB))));
+    ICS_TRY(launch_pack_wino(n.st, n.tp(L.t_w), L.Cin, L.Cout, 0, L.split_up ? L.Cs : L.Cin, 0, L.ww, L.ww_layout));
   if (need_bwd && wino_b)
-    ICS_TRY(launch_pack_wino(n.st, n.tp(L.t_w), L.Cin, L.Cout, 0, L.split_up ? L.Cs : L.Cin, 1, L.wwb,
-                             conv_wino_layout(geom_wino_bwd(L, n.maxB))));
+    ICS_TRY(launch_pack_wino(n.st, n.tp(L.t_w), L.Cin, L.Cout, 0, L.split_up ? L.Cs : L.Cin, 1, L.wwb, L.wwb_layout));
   if (need_bwd && L.split_up) {
     if (L.Cs && !wino_b)
       ICS_TRY(launch_pack_sub(n.st, n.tp(L.t_w), L.taps, L.Cin, L.Cout, 0, L.Cs, 1, L.wf_skip, L.Kpad_b,
@@ -581,7 +586,7 @@ static int conv_forward(Net& n, ConvLayer& L, int B, bool training, bool update_
                    4.0 * (M * L.Cs + 2 * M * L.Cout + 27.0 * L.Cs * L.Cout));
       if (L.ww && conv_wino_ok(gs, L.src, 1))
         ICS_TRY(launch_conv_fwd_wino(n.st, gs, L.src[0], L.ww, bias, L.s, L.Cout, L.pre_act,
-                                     stats ? n.ws_stat : nullptr, &rpb, 1));
+                                     stats ? n.ws_stat : nullptr, &rpb, 1, L.ww_layout));
       else
       ICS_TRY(launch_conv_fwd(n.st, gs, L.src, 1, L.wp_skip, bias, L.s, L.Cout, L.pre_act, stats ? n.ws_stat : nullptr,
                               &rpb, 1));
@@ -605,7 +610,7 @@ static int conv_forward(Net& n, ConvLayer& L, int B, bool training, bool update_
                                    stats ? n.ws_stat : nullptr, &rpb));
   } else if (L.ww && conv_wino_ok(g, L.src, L.nsrc)) {
     ICS_TRY(launch_conv_fwd_wino(n.st, g, L.src[0], L.ww, bias, L.s, L.Cout, L.pre_act, stats ? n.ws_stat : nullptr,
-                                 &rpb, 0));
+                                 &rpb, 0, L.ww_layout));
   } else {
     ICS_TRY(launch_conv_fwd(n.st, g, L.src, L.nsrc, L.wp, bias, L.s, L.Cout, L.pre_act,
                             stats ? n.ws_stat : nullptr, &rpb, 0, n.fws(), n.ws_fwd_n));
@@ -681,7 +686,7 @@ static int side_join(Net& n) {
 // BwdStat for the backward-data launch whose output is dO of `next` (its only consumer); empty when not applicable
 static BwdStat bwd_stat_for(Net& n, ConvLayer* next, int B) {
   BwdStat bs;
-  if (next == nullptr || !next->has_bn || getenv("ICSG3D_NO_BWD_FOLD")) return bs;
+  if (next == nullptr || !next->has_bn || (n.flags & CF_NO_BWD_FOLD)) return bs;
   if ((size_t)2 * next->Npad * ((n.rows(*next, B) + 63) / 64) > n.ws_bwd2_n) return bs;
   bs.s = next->s; bs.mean = next->mean; bs.rstd = next->rstd; bs.scale = next->scale; bs.shift = next->shift;
   bs.partial = n.ws_bwd2; bs.post_act = next->post_act; bs.ld = next->Cout;
@@ -742,7 +747,8 @@ static int conv_grads_split_up(Net& n, ConvLayer& L, int B, ConvLayer* next) {
     n.prof.begin(n.st, "conv_dgrad:" + L.name + ".skip|", fl_skip,
                  4.0 * (M * L.Cs + M * L.Cout + 27.0 * L.Cs * L.Cout));
     if (L.wwb && conv_wino_ok(g, &sdy, 1))
-      ICS_TRY(launch_conv_fwd_wino(n.st, g, sdy, L.wwb, nullptr, L.dA_skip, L.Cs, ACT_NONE, nullptr, nullptr, 0));
+      ICS_TRY(launch_conv_fwd_wino(n.st, g, sdy, L.wwb, nullptr, L.dA_skip, L.Cs, ACT_NONE, nullptr, nullptr, 0,
+                                   L.wwb_layout));
     else
     ICS_TRY(launch_conv_fwd(n.st, g, &sdy, 1, L.wf_skip, nullptr, L.dA_skip, L.Cs, ACT_NONE, nullptr, nullptr, 0,
                             n.fws(), n.ws_fwd_n));
@@ -807,7 +813,7 @@ static int conv_grads_from_dy(Net& n, ConvLayer& L, int B, bool need_dA, bool pa
     ICS_TRY(launch_conv_wgrad(ws, g, L.src, L.nsrc, L.dy, L.Cout, dw, L.Cout, n.ws_wgrad, n.ws_wgrad_n, 0, 0, 0, 2));
     if (L.dw_phys) {
       const size_t cnt = (size_t)L.taps * L.Cin * L.Cout;
-      hipLaunchKernelGGL(unpad_dw_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ws, L.dw_phys, L.Cin,
+      ICS_LAUNCH(unpad_dw_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ws, L.dw_phys, L.Cin,
                          L.CinG, L.Cout, cnt, n.tg(L.t_w));
       ICS_HIP(hipGetLastError());
     }
@@ -823,8 +829,8 @@ static int conv_grads_from_dy(Net& n, ConvLayer& L, int B, bool need_dA, bool pa
     const BwdStat bs = bwd_stat_for(n, next, B);
     int blocks = 0;
     if (L.wwb && !L.split_up && conv_wino_ok(gb, &sdy, 1))
-      ICS_TRY(launch_conv_fwd_wino(n.st, gb, sdy, L.wwb, nullptr, L.dA, L.CinG, ACT_NONE, nullptr, nullptr, 0, &bs,
-                                   &blocks));
+      ICS_TRY(launch_conv_fwd_wino(n.st, gb, sdy, L.wwb, nullptr, L.dA, L.CinG, ACT_NONE, nullptr, nullptr, 0,
+                                   L.wwb_layout, &bs, &blocks));
     else {
       if (L.split_up && L.wf_stale) {              // see pack_layer
         ICS_TRY(launch_pack_bwd(n.st, n.tp(L.t_w), L.taps, L.Cin, L.Cout, L.wf, L.Kpad_b, L.Npad_b, L.Cout, 0, 1));
@@ -850,6 +856,7 @@ static int conv_backward(Net& n, ConvLayer& L, int B, GradSrc g0, GradSrc g1, co
   lb.B = B; lb.S = L.S; lb.lgS = ilog2(L.S); lb.C = L.Cout;
   lb.has_bn = L.has_bn; lb.pre_act = L.pre_act; lb.post_act = L.post_act;
   lb.pool_ties_all = n.pool_ties_all;
+  lb.flags = n.flags;
   const size_t M = n.rows(L, B);
   const BwdPre pre{n.ws_bwd2, L.bwd_pre_nblk, L.bwd_pre_ld};
   L.bwd_pre_nblk = 0;
@@ -1077,7 +1084,7 @@ static int unet_head_loss(Net& n, int B, int mode, int want_grad, bool want_metr
   ConvLayer& H = *n.head;
   const size_t M = n.rows(H, B);
   const ConvSrc& s0 = H.src[0];
-  if (H.nsrc != 1 || s0.up || s0.bcast || !head_fused_ok(n.ncls, s0.C, M, s0.act)) {
+  if (H.nsrc != 1 || s0.up || s0.bcast || !head_fused_ok(n.ncls, s0.C, M, s0.act, n.flags)) {
     ICS_TRY(unet_head_forward(n, B));
     return unet_loss(n, B, mode, want_grad, want_metrics);
   }
@@ -1138,19 +1145,19 @@ static int unet_backward(Net& n, int B) {
     n.prof.end(ws);
     n.prof.begin(ws, "wgrad_reduce_splits", 0, 0);
     ICS_TRY(launch_conv_wgrad(ws, gs, H.src, 1, H.s, nc1, n.head_dw_tmp, nc1, n.ws_wgrad, n.ws_wgrad_n, 0, 0, 0, 2));
-    hipLaunchKernelGGL(split_cols_kernel, dim3((128 * nc1 + 255) / 256), dim3(256), 0, ws, n.head_dw_tmp, 128, nc1,
+    ICS_LAUNCH(split_cols_kernel, dim3((128 * nc1 + 255) / 256), dim3(256), 0, ws, n.head_dw_tmp, 128, nc1,
                        n.ncls, n.tg(H.t_w), n.tg(H.t_gamma));
     ICS_HIP(hipGetLastError());
     n.prof.end(ws);
     // soft/bias | sig/bias (contiguous): the loss kernel left per-block column sums of dz in ws_bwd
-    hipLaunchKernelGGL(colsum_merge_kernel, dim3(nc1), dim3(256), 0, n.st, n.ws_bwd, n.head_nblk, nc1, n.tg(H.t_b));
+    ICS_LAUNCH(colsum_merge_kernel, dim3(nc1), dim3(256), 0, n.st, n.ws_bwd, n.head_nblk, nc1, n.tg(H.t_b));
     ICS_HIP(hipGetLastError());
     const ConvGeom gb = geom_bwd(H, B);
     ConvSrc sdz = src_plain(H.s, nc1);
     n.prof.begin(n.st, "conv_dgrad:head|", 2.0 * M * 128 * nc1, 4.0 * M * (128 + nc1));
     const BwdStat bs = bwd_stat_for(n, r.c18, B);
     int blocks = 0;
-    if (head_dgrad_ok(n.ncls, 128, M, &bs))
+    if (head_dgrad_ok(n.ncls, 128, M, &bs, n.flags))
       ICS_TRY(launch_head_dgrad(n.st, H.s, n.tp(H.t_w), n.tp(H.t_gamma), H.dA, 128, M, &bs, gb.Npad, &blocks));
     else
       ICS_TRY(launch_conv_fwd(n.st, gb, &sdz, 1, H.wf, nullptr, H.dA, 128, ACT_NONE, nullptr, nullptr, 0, nullptr, 0, &bs,
@@ -1468,7 +1475,7 @@ static int vae_step(Net& n, int B, bool training, float* metrics) {
                                 pm_part, pmc, n.alpha, n.beta, n.d_metrics, n.d_red, 2))) break;
     }
     if (training) {
-      hipLaunchKernelGGL(axpy_strided_kernel, dim3((unsigned)((M * n.C + 255) / 256)), dim3(256), 0, n.st, n.drecon,
+      ICS_LAUNCH(axpy_strided_kernel, dim3((unsigned)((M * n.C + 255) / 256)), dim3(256), 0, n.st, n.drecon,
                          ur.c1->dA, M, n.C, ur.c1->CinG);
       // decoder
       if ((rc = conv_backward(n, *r.dout, B, gs_direct(n.drecon, n.C, 0), gs_none(), nullptr, true, true))) break;
@@ -1589,7 +1596,8 @@ struct ics_net {
 extern "C" {
 
 const char* ics_last_error(void) { return g_err.c_str(); }
-const char* ics_version(void) { return "icsg3d_amd 0.1 (gfx950, fp32 MFMA implicit-GEMM)"; }
+const char* ics_version(void) { return "icsg3d_amd 0.4 (gfx950, fp32 MFMA implicit-GEMM + Winograd)"; }
+long long ics_kernel_launches(void) { return g_kernel_launches.load(std::memory_order_relaxed); }
 
 int ics_device_count(int* count) {
   ICS_HIP(hipGetDeviceCount(count));
@@ -1825,13 +1833,13 @@ int ics_unet_predict(ics_net* net, const float* x, int batch, float* soft, float
   float* stage = n.head->dy;   // [M][ncls+1] scratch: soft packed first, sig after it
   if (soft) {
     const size_t cnt = M * (size_t)n.ncls;
-    hipLaunchKernelGGL(gather_cols_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, n.st, n.head->s, ld, 0,
+    ICS_LAUNCH(gather_cols_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, n.st, n.head->s, ld, 0,
                        n.ncls, M, stage);
     ICS_HIP(hipGetLastError());
     ICS_HIP(hipMemcpyAsync(soft, stage, cnt * sizeof(float), hipMemcpyDeviceToHost, n.st));
   }
   if (sig) {
-    hipLaunchKernelGGL(gather_cols_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, n.st, n.head->s, ld, n.ncls,
+    ICS_LAUNCH(gather_cols_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, n.st, n.head->s, ld, n.ncls,
                        1, M, stage + M * (size_t)n.ncls);
     ICS_HIP(hipGetLastError());
     ICS_HIP(hipMemcpyAsync(sig, stage + M * (size_t)n.ncls, M * sizeof(float), hipMemcpyDeviceToHost, n.st));
@@ -1850,7 +1858,7 @@ int ics_unet_predict_labels(ics_net* net, const float* x, int batch, float thres
   const size_t M = n.rows(*n.head, batch);
   unsigned char* d_species = reinterpret_cast<unsigned char*>(n.head->dy);   // [M][ncls+1] float scratch
   unsigned char* d_mask = d_species + M;
-  hipLaunchKernelGGL(labels_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, n.st, n.head->s, n.ncls + 1,
+  ICS_LAUNCH(labels_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, n.st, n.head->s, n.ncls + 1,
                      n.ncls, M, thresh, d_species, d_mask);
   ICS_HIP(hipGetLastError());
   if (species) ICS_HIP(hipMemcpyAsync(species, d_species, M, hipMemcpyDeviceToHost, n.st));
@@ -1970,14 +1978,14 @@ static int decode_to_labels_device(Net& n, Net& u, const float* z, const float* 
   do {
     if ((rc = unet_forward_trunk(u, batch, false, false, false, n.recon))) break;
     if ((rc = unet_head_loss(u, batch, 0, 0))) break;
-    hipLaunchKernelGGL(labels_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, n.st, u.head->s, u.ncls + 1,
+    ICS_LAUNCH(labels_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, n.st, u.head->s, u.ncls + 1,
                        u.ncls, M, thresh, d_species, d_mask);
     if (want_density) {
-      hipLaunchKernelGGL(gather_cols_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, n.st, n.recon, n.C, 0, 1,
+      ICS_LAUNCH(gather_cols_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, n.st, n.recon, n.C, 0, 1,
                          M, d_aux);
     }
     if (want_minmax && n.C >= 4) {
-      hipLaunchKernelGGL(chan_minmax_kernel, dim3(batch * 3), dim3(256), 0, n.st, n.recon, M / batch, n.C, 1, 3,
+      ICS_LAUNCH(chan_minmax_kernel, dim3(batch * 3), dim3(256), 0, n.st, n.recon, M / batch, n.C, 1, 3,
                          d_aux + M);
     }
     if (hipGetLastError() != hipSuccess) { set_error("inference tail launch failed"); rc = -1; break; }
@@ -2189,8 +2197,9 @@ int ics_op_conv3d_forward(const float* x, const float* w, const float* bias, int
   if (conv_wino_ok(g, &s, 1)) {          // the path the engine takes for this shape (ICSG3D_NO_WINO: the direct kernels)
     float* ww = nullptr;
     ICS_TRY(n.alloc(&ww, conv_wino_weight_floats(Cin, Cout)));
-    ICS_TRY(launch_pack_wino(n.st, dw, Cin, Cout, 0, Cin, 0, ww, conv_wino_layout(g)));
-    ICS_TRY(launch_conv_fwd_wino(n.st, g, s, ww, bias ? db : nullptr, dyv, Cout, pre_act, nullptr, nullptr, 0));
+    const int layout = conv_wino_layout(g);
+    ICS_TRY(launch_pack_wino(n.st, dw, Cin, Cout, 0, Cin, 0, ww, layout));
+    ICS_TRY(launch_conv_fwd_wino(n.st, g, s, ww, bias ? db : nullptr, dyv, Cout, pre_act, nullptr, nullptr, 0, layout));
   } else {
     ICS_TRY(launch_conv_fwd(n.st, g, &s, 1, dwp, bias ? db : nullptr, dyv, Cout, pre_act, nullptr, nullptr));
   }
@@ -2244,10 +2253,11 @@ int ics_op_conv3d_bench(int B, int S, int Cin, int Cout, int taps, int mode, int
     if (mode == 0) {
       if (ablate) ICS_TRY(launch_conv_fwd_ablate(n.st, g, &sx, 1, dwp, dyv, Cout, ablate));
       else if (wf) ICS_TRY(launch_conv_fwd_wino(n.st, g, sx, wwf, (feat & 32) ? f_bias : nullptr, dyv, Cout, ACT_RELU,
-                                                (feat & 16) ? f_stat : nullptr, nullptr, 0));
+                                                (feat & 16) ? f_stat : nullptr, nullptr, 0, conv_wino_layout(g)));
       else ICS_TRY(launch_conv_fwd(n.st, g, &sx, 1, dwp, nullptr, dyv, Cout, ACT_RELU, nullptr, nullptr));
     } else if (mode == 1) {
-      if (wb) ICS_TRY(launch_conv_fwd_wino(n.st, gb, sd, wwb, nullptr, dgx, Cin, ACT_NONE, nullptr, nullptr, 0));
+      if (wb) ICS_TRY(launch_conv_fwd_wino(n.st, gb, sd, wwb, nullptr, dgx, Cin, ACT_NONE, nullptr, nullptr, 0,
+                                           conv_wino_layout(gb)));
       else ICS_TRY(launch_conv_fwd(n.st, gb, &sd, 1, dwf, nullptr, dgx, Cin, ACT_NONE, nullptr, nullptr));
     } else if (ablate) {
       ICS_TRY(launch_conv_wgrad_ablate(n.st, g, &sx, dyv, Cout, ws, ablate));
@@ -2300,8 +2310,9 @@ int ics_op_conv3d_backward(const float* x, const float* w, const float* dy, int 
     if (conv_wino_ok(gb, &sd, 1)) {
       float* wwb = nullptr;
       ICS_TRY(n.alloc(&wwb, conv_wino_weight_floats(Cin, Cout)));
-      ICS_TRY(launch_pack_wino(n.st, dw, Cin, Cout, 0, Cin, 1, wwb, conv_wino_layout(gb)));
-      ICS_TRY(launch_conv_fwd_wino(n.st, gb, sd, wwb, nullptr, dgx, Cin, ACT_NONE, nullptr, nullptr, 0));
+      const int layout = conv_wino_layout(gb);
+      ICS_TRY(launch_pack_wino(n.st, dw, Cin, Cout, 0, Cin, 1, wwb, layout));
+      ICS_TRY(launch_conv_fwd_wino(n.st, gb, sd, wwb, nullptr, dgx, Cin, ACT_NONE, nullptr, nullptr, 0, layout));
     } else
     ICS_TRY(launch_conv_fwd(n.st, gb, &sd, 1, dwf, nullptr, dgx, Cin, ACT_NONE, nullptr, nullptr));
     ICS_HIP(hipMemcpyAsync(dxo, dgx, M * Cin * 4, hipMemcpyDeviceToHost, n.st));

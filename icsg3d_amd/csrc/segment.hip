@@ -169,14 +169,14 @@ int launch_segment_atoms(hipStream_t st, const unsigned char* mask, const unsign
   ICS_HIP(hipMemsetAsync(size, 0, n * 4, st));
   ICS_HIP(hipMemsetAsync(hist, 0, natoms * nbins * 4, st));
   ICS_HIP(hipMemsetAsync(counts, 0, (size_t)B * 2 * 4, st));
-  hipLaunchKernelGGL(seg_init_kernel, dim3(gv), dim3(256), 0, st, mask, lab, n);
-  hipLaunchKernelGGL(seg_stats_init_kernel, dim3(ga), dim3(256), 0, st, stats, natoms, d);
-  hipLaunchKernelGGL(seg_merge_kernel, dim3(gv), dim3(256), 0, st, mask, lab, lgd, n);
-  hipLaunchKernelGGL(seg_flatten_kernel, dim3(gv), dim3(256), 0, st, lab, size, n);
-  hipLaunchKernelGGL(seg_rank_kernel, dim3(B), dim3(1024), 0, st, lab, size, rank, per, min_voxels, counts);
-  hipLaunchKernelGGL(seg_stats_kernel, dim3(gv), dim3(256), 0, st, lab, rank, species, lgd, per, n, max_atoms, nbins,
+  ICS_LAUNCH(seg_init_kernel, dim3(gv), dim3(256), 0, st, mask, lab, n);
+  ICS_LAUNCH(seg_stats_init_kernel, dim3(ga), dim3(256), 0, st, stats, natoms, d);
+  ICS_LAUNCH(seg_merge_kernel, dim3(gv), dim3(256), 0, st, mask, lab, lgd, n);
+  ICS_LAUNCH(seg_flatten_kernel, dim3(gv), dim3(256), 0, st, lab, size, n);
+  ICS_LAUNCH(seg_rank_kernel, dim3(B), dim3(1024), 0, st, lab, size, rank, per, min_voxels, counts);
+  ICS_LAUNCH(seg_stats_kernel, dim3(gv), dim3(256), 0, st, lab, rank, species, lgd, per, n, max_atoms, nbins,
                      d_R, stats, hist);
-  hipLaunchKernelGGL(seg_vote_kernel, dim3(ga), dim3(256), 0, st, hist, nbins, natoms, stats);
+  ICS_LAUNCH(seg_vote_kernel, dim3(ga), dim3(256), 0, st, hist, nbins, natoms, stats);
   ICS_HIP(hipGetLastError());
   *d_counts = counts;
   *d_stats = stats;

@@ -26,6 +26,10 @@ extern "C" {
 /* ---------------------------------------------------------------- library / device */
 const char* ics_last_error(void);
 const char* ics_version(void);
+/* Device kernels this process has enqueued through the library so far (every launch site counts itself; the
+ * runtime's copy / fill kernels and RCCL's kernels are not included).  bench.py reports the per-step difference as
+ * kernel_launches_per_step; rocprofv3 --kernel-trace of the same command shows the same number of ics:: kernels. */
+long long ics_kernel_launches(void);
 int ics_device_count(int* count);
 int ics_set_device(int device);
 /* HIP device properties the benchmark reports (name is a 256-byte buffer). */

@@ -105,3 +105,52 @@ def test_pointwise_gemm_large_m_matches_numpy():
     rdx, rdw = DY @ W.T, X.T @ DY
     assert np.abs(dx.reshape(-1, Cin) - rdx).max() <= 1e-5 * np.abs(rdx).max()
     assert np.abs(dw.reshape(Cin, Cout) - rdw).max() <= 2e-5 * np.abs(rdw).max()
+
+
+# ---- the window 2^29 <= B*S^3*C < 2^31: conv_wino.hip's 32-bit ELEMENT offsets still reach, conv_wino64.hip's 32-bit
+# BYTE offsets do not.  The weight layout is decided ONCE from the full predicate (size bound included) and handed to
+# the launch; deciding it from Cout % 64 alone once packed layout-1 weights for the layout-0 kernel here.
+def test_conv_wino_size_window_forward_backward(relerr, monkeypatch):
+    from icsg3d_amd import engine as E
+    B, S, Cin, Cout = 16, 64, 128, 128
+    assert (1 << 29) <= B * S ** 3 * max(Cin, Cout) < (1 << 31)
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((B, S, S, S, Cin), dtype=np.float32)
+    w = (rng.standard_normal((3, 3, 3, Cin, Cout)) / np.sqrt(27 * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    got = E.conv3d_forward(x, w, b, pre_act=0)
+    # fp64 oracle on the first and the last sample (the last one sits past the 2^31-byte mark)
+    for i in (0, B - 1):
+        ref = R.conv3d_fwd(x[i:i + 1].astype(np.float64), w.astype(np.float64), b.astype(np.float64))
+        assert relerr(got[i:i + 1], ref) <= TOL, i
+    if not os.environ.get("ICSG3D_NO_WINO"):
+        monkeypatch.setenv("ICSG3D_NO_WINO", "1")
+        direct = E.conv3d_forward(x, w, b, pre_act=0)
+        monkeypatch.delenv("ICSG3D_NO_WINO")
+        assert relerr(got, direct) <= 2 * TOL
+        assert not np.array_equal(got, direct)
+    del got
+    # backward-data through the same window (dy -> dx with the tap-flipped, transposed weights)
+    dy = rng.standard_normal((B, S, S, S, Cout), dtype=np.float32)
+    dx, _ = E.conv3d_backward(x, w, dy)
+    for i in (0, B - 1):
+        dx_ref, _, _ = R.conv3d_bwd(x[i:i + 1].astype(np.float64), w.astype(np.float64), dy[i:i + 1].astype(np.float64))
+        assert relerr(dx[i:i + 1], dx_ref) <= TOL, i
+
+
+def test_engine_large_max_batch_matches_small(relerr):
+    """An engine built for a batch inside the window serves SMALLER batches with the same weight images: one grid
+    through UnetEngine(d=64, max_batch=16) must equal the same grid through max_batch=1 (different Winograd kernels:
+    to rounding, not bit for bit)."""
+    from icsg3d_amd.engine import UnetEngine
+    from icsg3d_amd.synthetic import glorot_params, synthetic_batch, unet_param_shapes
+    PU = glorot_params(unet_param_shapes(1, 95), 1)
+    X, _, _ = synthetic_batch(1, 64, 1, seed=3)
+    small = UnetEngine(d=64, max_batch=1)
+    small.set_weights(PU)
+    soft1, sig1 = small.predict(X)
+    del small
+    big = UnetEngine(d=64, max_batch=16)
+    big.set_weights(PU)
+    soft16, sig16 = big.predict(X)
+    assert relerr(soft16, soft1) <= TOL and relerr(sig16, sig1) <= TOL
