@@ -2,14 +2,15 @@
 """Hot-path portion of /root/reference/generate.py on the MI355X engine: encode a base compound, sample
 z ~ N(z_mean, var), decode, segment with the U-Net, argmax species + 0.8 binary threshold, then connected
 components + majority vote + centroids -- one device-resident chain per batch (generate.py:196-236 ->
-ics_vae_decode_to_unet_atoms).  Written under output/results/<formula>__v=<var>/: densities, species, binary masks,
-voxel parameters and per-sample atom coordinates (.npy).  The steps after that in the reference (CIF writing with
-pymatgen, CGCNN property prediction, generate.py:247-300) are out of scope, and of
-watershed_clustering only the part that can be pinned without skimage is built (icsg3d_amd/watershed.py).
+ics_vae_decode_to_unet_atoms) -- and watershed_clustering's convexity test + recursive marker watershed for the
+non-convex components (icsg3d_amd/watershed.py; the scikit-image routines behind it are restated, parity unpinned).
+Written under output/results/<formula>__v=<var>/: densities, species, binary masks, voxel parameters and per-sample
+atom coordinates (.npy).  The steps after that in the reference (CIF writing with pymatgen, CGCNN property
+prediction, generate.py:247-300) are out of scope.
 
 Flags: the reference's, same names and defaults (generate.py:52-102): --name --base --batch_size --nsamples --var
 --eps_frac --clus_iters --alpha --beta --gamma --target --ncond --d.  --alpha/--beta/--gamma only feed
-to_pymatgen_structure and --clus_iters the marker watershed (both not built): accepted, recorded in run.json.
+to_pymatgen_structure (not built): accepted, recorded in run.json; --clus_iters is watershed_clustering's max_iters.
 --eps_frac goes where the reference puts it: the shift of the atom coordinates (generate.py:237-241); like the
 reference, to_lattice_params / to_voxel_params keep their default 0.25 (generate.py:211,214).
 Added: --channels (the reference hard-codes 4) and --synthetic (a Gaussian-blob base compound, condition bin
@@ -101,11 +102,18 @@ if __name__ == "__main__":
         # components (> 3 voxels) -> majority vote + centroids.  The reconstruction and the label volumes stay in HBM;
         # back come 2 bytes per voxel, the density channel, the coordinate channels' min / max (all to_lattice_params
         # reads, generate.py:211-217) and one row of integers per atom.
-        out = vae.decode_segment_atoms(z_samples, np.tile(cond, (bs, 1)), unet, thresh=0.8, min_voxels=3, max_atoms=2048)
+        # then, per sample, the convexity test and the recursive marker watershed of the non-convex components
+        # (watershed.py:76-150, --clus_iters): icsg3d_amd/watershed.py.  A sample that fails is skipped like in the
+        # reference ("Failed", continue: generate.py:228-236)
+        out = vae.decode_segment_atoms(z_samples, np.tile(cond, (bs, 1)), unet, thresh=0.8, min_voxels=3, max_atoms=2048,
+                                       split=True, max_iters=a.clus_iters)
         l_prime = to_lattice_params_from_minmax(out["coord_minmax"], d=d)
         dv_pred = to_voxel_params(l_prime, d=d)
         for i in range(bs):
             k = batch * bs + i
+            if out["failed"][i]:
+                print("Failed", k)
+                continue
             species_sample, mu = out["atoms"][i]
             mu = np.array(mu, np.float64).reshape(len(species_sample), 3)
             mu = mu * dv_pred[i] - (eps * l_prime[i]) + (dv_pred[i] / 2.0)              # generate.py:237-241

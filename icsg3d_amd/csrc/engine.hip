@@ -2052,9 +2052,8 @@ static int segment_to_host(Net& n, const unsigned char* d_mask, const unsigned c
   } while (0);
   (void)hipFree(ws);
   ICS_TRY(rc);
-  for (int b = 0; b < batch; ++b)
-    ICS_CHECK(counts[2 * b + 1] <= max_atoms, "more kept components than max_atoms in sample " + std::to_string(b) +
-                                              " (" + std::to_string(counts[2 * b + 1]) + ")");
+  // counts[2 b + 1] > max_atoms marks sample b as FAILED (its statistics rows are truncated): the caller skips that
+  // sample, as the reference does ("Failed", continue: generate.py:228-236) -- one bad sample does not fail the batch
   return 0;
 }
 
@@ -2087,6 +2086,24 @@ int ics_op_segment_atoms(const uint8_t* mask, const uint8_t* species, int batch,
   ICS_HIP(hipMemcpyAsync(dm, mask, M, hipMemcpyHostToDevice, n.st));
   ICS_HIP(hipMemcpyAsync(ds, species, M, hipMemcpyHostToDevice, n.st));
   return segment_to_host(n, dm, ds, batch, d, min_voxels, max_atoms, num_species, regions, counts, atom_stats);
+}
+
+int ics_op_label_boxes(const int32_t* vols, const int32_t* dims, int nbox, int connectivity, int max_labels,
+                       int32_t* labels, int32_t* nlabels, int32_t* stats) {
+  Net n;
+  ICS_TRY(net_common_init(n));
+  return segment_label_boxes(n.st, vols, dims, nbox, connectivity, max_labels, labels, nlabels, stats);
+}
+int ics_op_region_stats(const int32_t* R, const uint8_t* species, int D, int H, int W, int num_labels, int num_species,
+                        int32_t* stats) {
+  Net n;
+  ICS_TRY(net_common_init(n));
+  return segment_region_stats(n.st, R, species, D, H, W, num_labels, num_species, stats);
+}
+int ics_op_watershed_split(const int32_t* boxes, const int32_t* dims, const int32_t* cls, int nbox, int tie, int32_t* wss) {
+  Net n;
+  ICS_TRY(net_common_init(n));
+  return segment_watershed_split(n.st, boxes, dims, cls, nbox, tie, wss);
 }
 
 // ---------------------------------------------------------------- data parallel

@@ -16,4 +16,19 @@ int launch_segment_atoms(hipStream_t st, const unsigned char* mask, const unsign
                          int min_voxels, int max_atoms, int nbins, void* workspace, size_t workspace_bytes, int* d_R,
                          int** d_counts, int** d_stats);
 
+// ---- boxes: small dense int32 volumes [D][H][W] (extents <= 64), `nbox` of them back to back; HOST pointers in and out
+// (tens of KB per call: the recursion of segment_nuclei is driven from the host, watershed.py:40-150).
+// skimage.measure.label(box, connectivity): components of equal non-zero value, raster-order numbering; connectivity 1
+// (6 neighbours) or 3 (26).  stats (optional): [nbox][max_labels][7] = {count, z0, y0, x0, z1, y1, x1}.
+int segment_label_boxes(hipStream_t st, const int* h_vols, const int* h_dims, int nbox, int connectivity, int max_labels,
+                        int* h_labels, int* h_nlabels, int* h_stats);
+// centroids / majority_vote (watershed.py:153-187) for an arbitrary label volume R [D][H][W] with labels 1..nlab:
+// stats [nlab][kSegStatInts], rows of labels that do not occur keep voxels = 0.  HOST pointers.
+int segment_region_stats(hipStream_t st, const int* h_R, const unsigned char* h_species, int D, int H, int W, int nlab,
+                         int nbins, int* h_stats);
+// watershed.py:95-110 per box (values {0, cl}): ball(1) erosion / dilation, markers, priority flood, wss[wss == 1] = 0.
+// tie: 0 = skimage's heap order among the age-0 markers, 1 = FIFO (oracle/watershed_ref.py::watershed_flood).
+int segment_watershed_split(hipStream_t st, const int* h_boxes, const int* h_dims, const int* h_cls, int nbox, int tie,
+                            int* h_wss);
+
 }  // namespace ics

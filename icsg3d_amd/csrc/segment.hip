@@ -127,6 +127,23 @@ __global__ void seg_stats_init_kernel(int* __restrict__ stats, size_t natoms, in
   s[8] = s[9] = s[10] = 0;
 }
 
+// the same statistics for an arbitrary label volume R [D][H][W] (labels 1..nlab; the result of segment_nuclei)
+__global__ void region_stats_kernel(const int* __restrict__ R, const unsigned char* __restrict__ species, int D, int H,
+                                    int W, int nlab, int nbins, int* __restrict__ stats, unsigned* __restrict__ hist) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= D * H * W) return;
+  const int r = R[i];
+  if (r <= 0 || r > nlab) return;
+  const int x = i % W, y = (i / W) % H, z = i / (W * H);
+  int* s = stats + (size_t)(r - 1) * kSegStatInts;
+  atomicAdd(s + 1, 1);
+  atomicAdd(s + 2, z); atomicAdd(s + 3, y); atomicAdd(s + 4, x);
+  atomicMin(s + 5, z); atomicMin(s + 6, y); atomicMin(s + 7, x);
+  atomicMax(s + 8, z + 1); atomicMax(s + 9, y + 1); atomicMax(s + 10, x + 1);
+  const unsigned sp = species[i];
+  if (sp != 0 && sp < (unsigned)nbins) atomicAdd(hist + (size_t)(r - 1) * nbins + sp, 1u);
+}
+
 // majority_vote (watershed.py:153-163): most frequent non-zero species; equal counts -> the larger id
 __global__ void seg_vote_kernel(const unsigned* __restrict__ hist, int nbins, size_t natoms, int* __restrict__ stats) {
   const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -138,6 +155,253 @@ __global__ void seg_vote_kernel(const unsigned* __restrict__ hist, int nbins, si
     if (c != 0 && c >= bestc) { best = (unsigned)sp; bestc = c; }
   }
   stats[a * kSegStatInts] = (int)best;
+}
+
+
+// ======================================================================================================================
+// segment_nuclei's non-convex branch and its recursion (watershed.py:40-150), one workgroup per box
+// ======================================================================================================================
+// A "box" is a small dense int32 volume [D][H][W] (a component cropped to its bounding box, or a watershed result that is
+// segmented again): D, H, W <= 64.  The scikit-image 0.17.2 routines the reference calls on it are restated in
+// oracle/watershed_ref.py (PARITY UNPINNED: skimage absent); these kernels are held to that file bit for bit.
+struct BoxDesc {
+  long long off;         // element offset of the box in the flat input / output arrays
+  int D, H, W, cl;       // extents; cl: the component's label value (split kernel)
+  long long heap_off;    // element offset of this box's heap scratch (split kernel)
+};
+
+__device__ __forceinline__ int ld_i(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_i(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Connected components of EQUAL non-zero value (measure.label on an integer image) by min-index propagation + pointer
+// jumping inside one workgroup: lab[i] ends as the smallest linear index of i's component (0-based; -1 = background),
+// which is also what orders the final numbering (raster order of the first voxel).  conn26: 26-neighbourhood.
+// All label traffic bypasses the vector L1 (agent-scope relaxed atomics): the sweeps of different waves see each other.
+__device__ void box_label_roots(const int* __restrict__ val, int* lab, int D, int H, int W, bool conn26, int* s_flag) {
+  const int V = D * H * W, tid = threadIdx.x, nt = blockDim.x;
+  for (int i = tid; i < V; i += nt) st_i(lab + i, val[i] != 0 ? i : -1);
+  __syncthreads();
+  while (true) {                                   // labels only ever decrease: terminates
+    if (tid == 0) *s_flag = 0;
+    __syncthreads();
+    int changed = 0;
+    for (int i = tid; i < V; i += nt) {
+      const int v = val[i];
+      if (v == 0) continue;
+      const int x = i % W, y = (i / W) % H, z = i / (W * H);
+      int best = ld_i(lab + i);
+      const int cur = best;
+      const int r = conn26 ? 1 : 0;
+      for (int dz = -1; dz <= 1; ++dz)
+        for (int dy = -1; dy <= 1; ++dy)
+          for (int dx = -1; dx <= 1; ++dx) {
+            if (dz == 0 && dy == 0 && dx == 0) continue;
+            if (!r && (dz != 0) + (dy != 0) + (dx != 0) != 1) continue;
+            const int zz = z + dz, yy = y + dy, xx = x + dx;
+            if (zz < 0 || zz >= D || yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+            const int j = (zz * H + yy) * W + xx;
+            if (val[j] != v) continue;
+            const int lj = ld_i(lab + j);
+            best = lj < best ? lj : best;
+          }
+      const int lb = ld_i(lab + best);            // pointer jumping: the label of my label
+      best = lb < best ? lb : best;
+      if (best < cur) { st_i(lab + i, best); changed = 1; }
+    }
+    if (changed) *s_flag = 1;
+    __syncthreads();
+    const int any = *s_flag;
+    __syncthreads();
+    if (!any) break;
+  }
+}
+
+// raster-order ranks of the roots (lab[i] == i) -> lab[i] = 1-based component number, 0 = background; returns the count
+// (valid in every thread).  scratch: blockDim.x ints of LDS.
+__device__ int box_rank_labels(int* lab, int V, int* s_scan) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int chunk = (V + nt - 1) / nt, lo = tid * chunk, hi = lo + chunk < V ? lo + chunk : V;
+  int cnt = 0;
+  for (int i = lo; i < hi; ++i) cnt += ld_i(lab + i) == i;
+  s_scan[tid] = cnt;
+  __syncthreads();
+  for (int off = 1; off < nt; off <<= 1) {
+    const int a = tid >= off ? s_scan[tid - off] : 0;
+    __syncthreads();
+    s_scan[tid] += a;
+    __syncthreads();
+  }
+  const int total = s_scan[nt - 1];
+  int k = s_scan[tid] - cnt;
+  __syncthreads();
+  // roots first get their NEGATIVE rank code (-(rank) - 1 <= -2) so that root slots stay recognisable while the other
+  // voxels still look their root up
+  for (int i = lo; i < hi; ++i)
+    if (ld_i(lab + i) == i) st_i(lab + i, -(++k) - 1);
+  __syncthreads();
+  for (int i = tid; i < V; i += nt) {
+    const int l = ld_i(lab + i);
+    if (l >= 0) {                                  // non-root foreground voxel: l = root index (root != i)
+      const int code = ld_i(lab + l);
+      st_i(lab + i, code);                         // still negative: converted below
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < V; i += nt) {
+    const int l = ld_i(lab + i);
+    st_i(lab + i, l == -1 ? 0 : -(l + 1));
+  }
+  __syncthreads();
+  return total;
+}
+
+// measure.label(vol, connectivity) per box + per-label {count, z0, y0, x0, z1, y1, x1} (half-open): stats[box][label-1][7]
+__global__ __launch_bounds__(1024) void label_boxes_kernel(const int* __restrict__ vols, const BoxDesc* __restrict__ desc,
+                                                            int conn26, int max_labels, int* __restrict__ labels,
+                                                            int* __restrict__ nlabels, int* __restrict__ stats) {
+  __shared__ int s_flag;
+  __shared__ int s_scan[1024];
+  const BoxDesc d = desc[blockIdx.x];
+  const int V = d.D * d.H * d.W, tid = threadIdx.x, nt = blockDim.x;
+  const int* val = vols + d.off;
+  int* lab = labels + d.off;
+  box_label_roots(val, lab, d.D, d.H, d.W, conn26 != 0, &s_flag);
+  const int n = box_rank_labels(lab, V, s_scan);
+  if (tid == 0) nlabels[blockIdx.x] = n;
+  int* st = stats + (size_t)blockIdx.x * max_labels * 7;
+  const int nst = n < max_labels ? n : max_labels;
+  for (int a = tid; a < nst; a += nt) {
+    int* s = st + a * 7;
+    st_i(s, 0); st_i(s + 1, d.D); st_i(s + 2, d.H); st_i(s + 3, d.W); st_i(s + 4, 0); st_i(s + 5, 0); st_i(s + 6, 0);
+  }
+  __syncthreads();
+  for (int i = tid; i < V; i += nt) {
+    const int l = ld_i(lab + i);
+    if (l <= 0 || l > max_labels) continue;
+    const int x = i % d.W, y = (i / d.W) % d.H, z = i / (d.W * d.H);
+    int* s = st + (l - 1) * 7;
+    atomicAdd(s, 1);
+    atomicMin(s + 1, z); atomicMin(s + 2, y); atomicMin(s + 3, x);
+    atomicMax(s + 4, z + 1); atomicMax(s + 5, y + 1); atomicMax(s + 6, x + 1);
+  }
+}
+
+// ---- skimage's watershed heap (oracle/watershed_ref.py::_Heap): an entry is {key = (image level << 31) | age, index},
+// two 32-bit words; `smaller` compares the key only and is strict.
+struct WsHeap {
+  unsigned* key;   // [cap]
+  unsigned* idx;   // [cap]
+  int n;
+  __device__ __forceinline__ void push(unsigned k, unsigned ix) {
+    int child = n++;
+    key[child] = k; idx[child] = ix;
+    while (child > 0) {
+      const int parent = (child + 1) / 2 - 1;
+      const unsigned kc = key[child], kp = key[parent];
+      if (kc < kp) {
+        const unsigned ic = idx[child], ip = idx[parent];
+        key[child] = kp; idx[child] = ip; key[parent] = kc; idx[parent] = ic;
+        child = parent;
+      } else break;
+    }
+  }
+  __device__ __forceinline__ unsigned pop() {      // returns the index of the smallest entry
+    const unsigned top = idx[0];
+    --n;
+    if (n == 0) return top;
+    key[0] = key[n]; idx[0] = idx[n];
+    int i = 0;
+    while (true) {
+      const int l = 2 * i + 1, r = 2 * i + 2;
+      int smallest = i;
+      if (l < n) {
+        if (key[l] < key[i]) smallest = l;
+        if (r < n && key[r] < key[smallest]) smallest = r;
+      } else break;
+      if (smallest == i) break;
+      const unsigned ks = key[smallest], is = idx[smallest];
+      key[smallest] = key[i]; idx[smallest] = idx[i]; key[i] = ks; idx[i] = is;
+      i = smallest;
+    }
+    return top;
+  }
+};
+
+// watershed.py:95-110 for one non-convex component in its bounding box (values {0, cl}); wss out = labels 2.. or 0
+// (before the reference's max_class shift).  tie: 0 = skimage's heap order among equal (value, age) keys, 1 = FIFO.
+// work: int scratch [4][V] per box (fg / markers, bg, root labels, unused); heap scratch 2 x V unsigned per box.
+__global__ __launch_bounds__(1024) void ws_split_kernel(const int* __restrict__ boxes, const BoxDesc* __restrict__ desc,
+                                                         int tie, int* __restrict__ work, unsigned* __restrict__ heap_mem,
+                                                         int* __restrict__ wss_out) {
+  __shared__ int s_flag;
+  __shared__ int s_scan[1024];
+  const BoxDesc d = desc[blockIdx.x];
+  const int D = d.D, H = d.H, W = d.W, V = D * H * W, tid = threadIdx.x, nt = blockDim.x, cl = d.cl;
+  const int* val = boxes + d.off;
+  int* fg = work + d.off * 4;                      // [V]   eroded image (4 ints of scratch per voxel, three used)
+  int* bgm = fg + V;                               // [V]   dilated image
+  int* lab = bgm + V;                              // [V]   labels of fg (26-connectivity)
+  int* out = wss_out + d.off;
+  // erosion / dilation with ball(1) = the 7-voxel cross; out-of-box neighbours are ignored (scipy 'reflect' at radius 1)
+  for (int i = tid; i < V; i += nt) {
+    const int x = i % W, y = (i / W) % H, z = i / (W * H);
+    int mn = val[i], mx = val[i];
+    if (z > 0) { const int v = val[i - H * W]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+    if (z < D - 1) { const int v = val[i + H * W]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+    if (y > 0) { const int v = val[i - W]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+    if (y < H - 1) { const int v = val[i + W]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+    if (x > 0) { const int v = val[i - 1]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+    if (x < W - 1) { const int v = val[i + 1]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+    fg[i] = mn; bgm[i] = mx;
+  }
+  __threadfence_block();
+  __syncthreads();
+  box_label_roots(fg, lab, D, H, W, true, &s_flag);     // measure.label(fg): full connectivity
+  box_rank_labels(lab, V, s_scan);
+  // markers = label + 1; markers[unknown == 1] = 0 -- the reference compares (bg - fg) against 1, not against cl
+  int zeros = 0;
+  for (int i = tid; i < V; i += nt) {
+    int m = ld_i(lab + i) + 1;
+    if (bgm[i] - fg[i] == 1) { m = 0; zeros = 1; }
+    st_i(out + i, m);
+  }
+  if (tid == 0) s_flag = 0;
+  __syncthreads();
+  if (zeros) s_flag = 1;
+  __syncthreads();
+  const bool flood = s_flag != 0;
+  (void)cl;
+  if (flood && tid == 0) {
+    // sequential priority flood (skimage _watershed_cy.pyx, restated in oracle/watershed_ref.py::watershed_flood)
+    WsHeap hp{heap_mem + d.heap_off * 2, heap_mem + d.heap_off * 2 + V, 0};
+    // key = (image level << 31) | age: two image values (0 < cl), every marker enters with age 0 in raster order.
+    // FIFO tie rule (tie = 1): the markers carry their raster rank instead, and real ages start above every rank.
+    unsigned seq = 0;
+    for (int i = 0; i < V; ++i)
+      if (ld_i(out + i) != 0) hp.push(((val[i] != 0 ? 1u : 0u) << 31) | (tie ? seq++ : 0u), (unsigned)i);
+    unsigned age = tie ? (unsigned)V + 1u : 1u;
+    const int nb[6] = {-H * W, -W, -1, 1, W, H * W};
+    while (hp.n > 0) {
+      const int i = (int)hp.pop();
+      const int x = i % W, y = (i / W) % H, z = i / (W * H);
+      const bool ok[6] = {z > 0, y > 0, x > 0, x < W - 1, y < H - 1, z < D - 1};
+      const int li = ld_i(out + i);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        if (!ok[k]) continue;
+        const int j = i + nb[k];
+        if (ld_i(out + j) != 0) continue;
+        ++age;
+        st_i(out + j, li);
+        hp.push(((val[j] != 0 ? 1u : 0u) << 31) | age, (unsigned)j);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < V; i += nt) {
+    const int m = ld_i(out + i);
+    st_i(out + i, m == 1 ? 0 : m);                 // wss[wss == 1] = 0
+  }
 }
 
 }  // namespace
@@ -180,6 +444,118 @@ int launch_segment_atoms(hipStream_t st, const unsigned char* mask, const unsign
   ICS_HIP(hipGetLastError());
   *d_counts = counts;
   *d_stats = stats;
+  return 0;
+}
+
+}  // namespace ics
+
+namespace ics {
+
+// Host-side batching for the two box kernels: `dims` [nbox][3] (D, H, W), boxes laid out back to back in `vols`.
+static int box_descs(const int* dims, const int* cls, int nbox, std::vector<BoxDesc>* out, size_t* total) {
+  out->resize(nbox);
+  size_t off = 0;
+  for (int b = 0; b < nbox; ++b) {
+    const int D = dims[3 * b], H = dims[3 * b + 1], W = dims[3 * b + 2];
+    ICS_CHECK(D >= 1 && H >= 1 && W >= 1 && D <= 64 && H <= 64 && W <= 64, "box extents must be in [1, 64]");
+    (*out)[b] = BoxDesc{(long long)off, D, H, W, cls ? cls[b] : 0, (long long)off};
+    off += (size_t)D * H * W;
+  }
+  *total = off;
+  return 0;
+}
+
+int segment_label_boxes(hipStream_t st, const int* h_vols, const int* h_dims, int nbox, int connectivity, int max_labels,
+                        int* h_labels, int* h_nlabels, int* h_stats) {
+  ICS_CHECK(h_vols && h_dims && h_labels && h_nlabels && nbox >= 1 && max_labels >= 1, "bad label_boxes arguments");
+  ICS_CHECK(connectivity == 1 || connectivity == 3, "connectivity must be 1 (6 neighbours) or 3 (26)");
+  std::vector<BoxDesc> desc;
+  size_t total = 0;
+  ICS_TRY(box_descs(h_dims, nullptr, nbox, &desc, &total));
+  unsigned char* buf = nullptr;
+  const size_t b_vol = total * 4, b_desc = (size_t)nbox * sizeof(BoxDesc), b_n = (size_t)nbox * 4,
+               b_st = (size_t)nbox * max_labels * 7 * 4;
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  ICS_HIP(hipMalloc(reinterpret_cast<void**>(&buf), up(b_vol) * 2 + up(b_desc) + up(b_n) + up(b_st)));
+  int* d_vol = reinterpret_cast<int*>(buf);
+  int* d_lab = reinterpret_cast<int*>(buf + up(b_vol));
+  BoxDesc* d_desc = reinterpret_cast<BoxDesc*>(buf + 2 * up(b_vol));
+  int* d_n = reinterpret_cast<int*>(buf + 2 * up(b_vol) + up(b_desc));
+  int* d_st = reinterpret_cast<int*>(buf + 2 * up(b_vol) + up(b_desc) + up(b_n));
+  hipError_t e = hipMemcpyAsync(d_vol, h_vols, b_vol, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_desc, desc.data(), b_desc, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) {
+    ICS_LAUNCH(label_boxes_kernel, dim3(nbox), dim3(1024), 0, st, d_vol, d_desc, connectivity == 3 ? 1 : 0, max_labels,
+               d_lab, d_n, d_st);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(h_labels, d_lab, b_vol, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(h_nlabels, d_n, b_n, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess && h_stats) e = hipMemcpyAsync(h_stats, d_st, b_st, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(buf);
+  if (e != hipSuccess) { set_error(std::string("label_boxes: ") + hipGetErrorString(e)); return -1; }
+  return 0;
+}
+
+int segment_region_stats(hipStream_t st, const int* h_R, const unsigned char* h_species, int D, int H, int W, int nlab,
+                         int nbins, int* h_stats) {
+  ICS_CHECK(h_R && h_species && h_stats && D >= 1 && H >= 1 && W >= 1 && nlab >= 1 && nbins >= 2 && nbins <= 256,
+            "bad region_stats arguments");
+  const size_t V = (size_t)D * H * W;
+  ICS_CHECK(V < (1u << 30), "volume too large");
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t b_R = V * 4, b_sp = V, b_st = (size_t)nlab * kSegStatInts * 4, b_h = (size_t)nlab * nbins * 4;
+  unsigned char* buf = nullptr;
+  ICS_HIP(hipMalloc(reinterpret_cast<void**>(&buf), up(b_R) + up(b_sp) + up(b_st) + up(b_h)));
+  int* d_R = reinterpret_cast<int*>(buf);
+  unsigned char* d_sp = buf + up(b_R);
+  int* d_st = reinterpret_cast<int*>(buf + up(b_R) + up(b_sp));
+  unsigned* d_h = reinterpret_cast<unsigned*>(buf + up(b_R) + up(b_sp) + up(b_st));
+  hipError_t e = hipMemcpyAsync(d_R, h_R, b_R, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_sp, h_species, b_sp, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemsetAsync(d_h, 0, b_h, st);
+  if (e == hipSuccess) {
+    const int dmax = D > H ? (D > W ? D : W) : (H > W ? H : W);
+    ICS_LAUNCH(seg_stats_init_kernel, dim3((unsigned)((nlab + 255) / 256)), dim3(256), 0, st, d_st, (size_t)nlab, dmax);
+    ICS_LAUNCH(region_stats_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, d_R, d_sp, D, H, W, nlab, nbins,
+               d_st, d_h);
+    ICS_LAUNCH(seg_vote_kernel, dim3((unsigned)((nlab + 255) / 256)), dim3(256), 0, st, d_h, nbins, (size_t)nlab, d_st);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(h_stats, d_st, b_st, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(buf);
+  if (e != hipSuccess) { set_error(std::string("region_stats: ") + hipGetErrorString(e)); return -1; }
+  return 0;
+}
+
+int segment_watershed_split(hipStream_t st, const int* h_boxes, const int* h_dims, const int* h_cls, int nbox, int tie,
+                            int* h_wss) {
+  ICS_CHECK(h_boxes && h_dims && h_cls && h_wss && nbox >= 1 && (tie == 0 || tie == 1), "bad watershed_split arguments");
+  std::vector<BoxDesc> desc;
+  size_t total = 0;
+  ICS_TRY(box_descs(h_dims, h_cls, nbox, &desc, &total));
+  unsigned char* buf = nullptr;
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t b_vol = total * 4, b_desc = (size_t)nbox * sizeof(BoxDesc);
+  // work: 4 ints per voxel (BoxDesc::heap_off * 2 with room to spare), heap: 2 unsigned per voxel
+  ICS_HIP(hipMalloc(reinterpret_cast<void**>(&buf), up(b_vol) * 2 + up(b_desc) + up(b_vol * 4) + up(b_vol * 2)));
+  int* d_box = reinterpret_cast<int*>(buf);
+  int* d_out = reinterpret_cast<int*>(buf + up(b_vol));
+  BoxDesc* d_desc = reinterpret_cast<BoxDesc*>(buf + 2 * up(b_vol));
+  int* d_work = reinterpret_cast<int*>(buf + 2 * up(b_vol) + up(b_desc));
+  unsigned* d_heap = reinterpret_cast<unsigned*>(buf + 2 * up(b_vol) + up(b_desc) + up(b_vol * 4));
+  hipError_t e = hipMemcpyAsync(d_box, h_boxes, b_vol, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_desc, desc.data(), b_desc, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) {
+    ICS_LAUNCH(ws_split_kernel, dim3(nbox), dim3(1024), 0, st, d_box, d_desc, tie, d_work, d_heap, d_out);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(h_wss, d_out, b_vol, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(buf);
+  if (e != hipSuccess) { set_error(std::string("watershed_split: ") + hipGetErrorString(e)); return -1; }
   return 0;
 }
 

@@ -302,7 +302,9 @@ class VaeEngine(_Net):
                         want_regions=False):
         """decode_to_labels continued on the device through connected components + region statistics
         (generate.py:204-236, watershed.py:52-56,153-187): dict(species, mask, density, coord_minmax, regions | None,
-        n_components (B,), n_atoms (B,), stats int32 (B,max_atoms,11), atoms [(species list, mean list)])."""
+        n_components (B,), n_atoms (B,), stats int32 (B,max_atoms,11), atoms [(species list, mean list)], failed (B,)).
+        Every kept component is taken as convex here; icsg3d_amd.watershed.refine_atoms continues with the convexity
+        test and the recursive split (needs want_regions=True)."""
         from .watershed import STAT_FIELDS, _atoms_from_stats
         z, cond = _f32(z), _f32(cond)
         B, d = z.shape[0], self.d
@@ -320,9 +322,11 @@ class VaeEngine(_Net):
                 self._h, unet._h, L.fptr(z[s]), L.fptr(cond[s]), z[s].shape[0], float(thresh), int(min_voxels),
                 int(max_atoms), L.u8ptr(sp[s]), L.u8ptr(mk[s]), L.fptr(dens[s]) if want_density else None,
                 L.fptr(mm[s]), L.i32ptr(reg[s]) if want_regions else None, L.i32ptr(counts[s]), L.i32ptr(stats[s])))
+        failed = counts[:, 1] > max_atoms                 # more kept components than rows: sample skipped, not the batch
+        counts[failed, 1] = 0
         return {"species": sp, "mask": mk, "density": dens, "coord_minmax": mm, "regions": reg,
                 "n_components": counts[:, 0].copy(), "n_atoms": counts[:, 1].copy(), "stats": stats,
-                "atoms": _atoms_from_stats(counts, stats, d ** 3)}
+                "atoms": _atoms_from_stats(counts, stats, d ** 3), "failed": failed}
 
     def train_step(self, x, cond, eps):
         x, cond, eps, B = self._args(x, cond, eps)

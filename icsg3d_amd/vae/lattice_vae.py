@@ -249,14 +249,21 @@ class LatticeDFCVAE(DataParallelMixin):
         eng = self._engine(min(len(z), self.batch_size or 32))
         return eng.decode_to_labels(unet._engine(min(len(z), eng.max_batch)), z, cond, thresh)
 
-    def decode_segment_atoms(self, z, cond, unet, thresh=0.8, min_voxels=3, max_atoms=512, want_regions=False):
-        """decode_segment continued through connected components, majority vote and centroids on the device
-        (generate.py:228-236 -> watershed.py:52-56,153-187; the convexity test / marker watershed are not implemented,
-        see icsg3d_amd/watershed.py).  Adds n_components, n_atoms, stats, atoms = [(species list, mean list)]."""
+    def decode_segment_atoms(self, z, cond, unet, thresh=0.8, min_voxels=3, max_atoms=512, want_regions=False,
+                             split=True, max_iters=5):
+        """decode_segment continued through `watershed_clustering` (generate.py:228-236 -> watershed.py:40-203):
+        connected components, size filter, majority vote and centroids on the device for the whole batch; with
+        split=True the convexity test and the recursive marker watershed of the non-convex components follow
+        (icsg3d_amd.watershed.refine_atoms; max_iters = the reference's --clus_iters).  Adds n_components, n_atoms,
+        stats, atoms = [(species list, mean list)], failed (B,), split (B,)."""
         z = np.asarray(z)
         eng = self._engine(min(len(z), self.batch_size or 32))
-        return eng.decode_to_atoms(unet._engine(min(len(z), eng.max_batch)), z, cond, thresh, min_voxels, max_atoms,
-                                   want_regions=want_regions)
+        out = eng.decode_to_atoms(unet._engine(min(len(z), eng.max_batch)), z, cond, thresh, min_voxels, max_atoms,
+                                  want_regions=want_regions or split)
+        if split:
+            from ..watershed import refine_atoms
+            refine_atoms(out, max_iters=max_iters, num_species=unet.num_classes if hasattr(unet, "num_classes") else 95)
+        return out
 
     def save_(self, weights, model="saved_models/vae.h5"):
         self.model.load_weights(weights)

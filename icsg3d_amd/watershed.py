@@ -1,13 +1,19 @@
-"""Device-side counterpart of the integer part of /root/reference/watershed.py (`watershed_clustering`, :190-203):
-6-connected component labelling of the binary mask with the reference's size filter (`segment_nuclei` step 1,
-:52-56), the region matrix R for components that take the convex branch (:85-92), and `centroids` +
-`majority_vote` (:153-187).  Compute is libicsg3d_hip.so (csrc/segment.hip); there is no CPU fallback.
+"""Device-side counterpart of /root/reference/watershed.py (`watershed_clustering`, :190-203, and `segment_nuclei`,
+:40-150, `centroids` / `majority_vote`, :153-187).  Compute is libicsg3d_hip.so (csrc/segment.hip); there is no CPU
+fallback for the device steps.
 
-NOT implemented (skimage is absent from the image, so neither can be pinned): the convex-hull test
-(`morphology.convex_hull_image`, :80) and the marker watershed (`segmentation.watershed`, :96-150) that the
-reference applies to components whose convexity is below 0.8.  Every kept component is treated as convex; the
-per-region voxel counts and bounding boxes returned here are the inputs a host-side implementation of those two
-steps needs."""
+What runs where
+  * device: connected-component labelling (6- and 26-connectivity, components of equal value: skimage.measure.label),
+    the size filter, bounding boxes and voxel counts, ball(1) erosion / dilation, the markers, the priority flood of
+    segmentation.watershed, majority vote and coordinate sums of the final regions;
+  * host (this file): the recursion of segment_nuclei and its bookkeeping on R (a few numpy `where`s on boxes of a few
+    hundred voxels), and the convexity test -- a Qhull convex hull through scipy.spatial, which is also what
+    skimage.morphology.convex_hull_image calls; the reference runs it on the CPU too.
+
+PARITY UNPINNED: skimage absent.  The four scikit-image 0.17.2 routines `segment_nuclei` calls are not installable in
+this image; their published algorithms are restated in oracle/watershed_ref.py (test infrastructure) and this module +
+the kernels are held to that restatement bit for bit (tests/test_gpu_segment.py).  `centroids` / `majority_vote` ARE
+pinned by the reference's own functions (tests/golden/watershed_golden.npz)."""
 from __future__ import annotations
 
 import numpy as np
@@ -15,6 +21,7 @@ import numpy as np
 from . import _lib as L
 
 STAT_FIELDS = ("species", "voxels", "sum0", "sum1", "sum2", "lo0", "lo1", "lo2", "hi0", "hi1", "hi2")
+TIE_RULES = {"heap": 0, "fifo": 1}
 
 
 def _atoms_from_stats(counts, stats, voxels_per_sample):
@@ -25,19 +32,27 @@ def _atoms_from_stats(counts, stats, voxels_per_sample):
     out = []
     for b in range(stats.shape[0]):
         st = stats[b, :counts[b, 1]]
-        if len(st) and int(st[:, 1].sum()) == voxels_per_sample:
-            st = st[1:]
-        keep = st[:, 0] != 0
-        atoms = [int(v) for v in st[keep, 0]]
-        means = [st[i, 2:5].astype(np.float64) / np.float64(st[i, 1]) for i in np.nonzero(keep)[0]]
-        out.append((atoms, means))
+        out.append(_atoms_from_rows(st, voxels_per_sample))
     return out
+
+
+def _atoms_from_rows(st, voxels_per_sample):
+    """rows of region statistics in ascending label order (empty rows = labels that do not occur) -> (atoms, means)."""
+    st = st[st[:, 1] > 0]
+    if len(st) and int(st[:, 1].sum()) == voxels_per_sample:
+        st = st[1:]
+    keep = st[:, 0] != 0
+    atoms = [int(v) for v in st[keep, 0]]
+    means = [st[i, 2:5].astype(np.float64) / np.float64(st[i, 1]) for i in np.nonzero(keep)[0]]
+    return atoms, means
 
 
 def segment_atoms(mask, species, min_voxels=3, max_atoms=512, num_species=95, want_regions=True):
     """mask / species: (B,d,d,d) arrays (non-zero mask = foreground; species = class ids < num_species).
+    Connected components + size filter + region statistics with EVERY kept component taken as convex (the first pass
+    of segment_nuclei; `watershed_clustering` continues from it).
     Returns dict(regions int32 (B,d,d,d) | None, n_components (B,), n_atoms (B,), stats int32 (B,max_atoms,11),
-    atoms [(species list, mean list)] per sample)."""
+    atoms [(species list, mean list)] per sample, failed (B,) bool: more than max_atoms kept components)."""
     mask = np.ascontiguousarray(np.asarray(mask) != 0, dtype=np.uint8)
     species = np.ascontiguousarray(species, dtype=np.uint8)
     if mask.ndim != 4 or mask.shape != species.shape or len(set(mask.shape[1:])) != 1:
@@ -48,18 +63,190 @@ def segment_atoms(mask, species, min_voxels=3, max_atoms=512, num_species=95, wa
     stats = np.zeros((B, max_atoms, len(STAT_FIELDS)), np.int32)
     L.check(L.load().ics_op_segment_atoms(L.u8ptr(mask), L.u8ptr(species), B, d, int(min_voxels), int(max_atoms),
                                           int(num_species), L.i32ptr(regions), L.i32ptr(counts), L.i32ptr(stats)))
+    failed = counts[:, 1] > max_atoms
+    counts = counts.copy()
+    counts[failed, 1] = 0
     return {"regions": regions, "n_components": counts[:, 0].copy(), "n_atoms": counts[:, 1].copy(), "stats": stats,
-            "atoms": _atoms_from_stats(counts, stats, d ** 3)}
+            "atoms": _atoms_from_stats(counts, stats, d ** 3), "failed": failed}
 
 
-def watershed_clustering(M, S, Sb, max_iters=5, return_ws=False, verbose=False):
-    """Signature of the reference's entry point (watershed.py:190): (atoms, means[, R]) for ONE sample, computed on
-    the device.  `M` (density) and `max_iters` only feed the marker watershed, which is not implemented (see module
-    docstring): components are never split."""
+# ----------------------------------------------------------------------------------------------------------------------
+# device primitives on small boxes
+# ----------------------------------------------------------------------------------------------------------------------
+def label_boxes(vols, connectivity=1, max_labels=1024):
+    """skimage.measure.label(vol, connectivity=...) for each int volume in `vols` (extents <= 64): components of equal
+    non-zero value, raster-order numbering.  Returns [(labels int32, n, stats (n,7) = {voxels, z0, y0, x0, z1, y1, x1})]."""
+    vols = [np.ascontiguousarray(v, dtype=np.int32) for v in vols]
+    if not vols:
+        return []
+    dims = np.ascontiguousarray([v.shape for v in vols], dtype=np.int32)
+    flat = np.concatenate([v.ravel() for v in vols])
+    lab = np.empty_like(flat)
+    n = np.zeros(len(vols), np.int32)
+    while True:
+        stats = np.zeros((len(vols), max_labels, 7), np.int32)
+        L.check(L.load().ics_op_label_boxes(L.i32ptr(flat), L.i32ptr(dims), len(vols), int(connectivity), int(max_labels),
+                                            L.i32ptr(lab), L.i32ptr(n), L.i32ptr(stats)))
+        if int(n.max()) <= max_labels:
+            break
+        max_labels = int(n.max())
+    out, off = [], 0
+    for b, v in enumerate(vols):
+        out.append((lab[off:off + v.size].reshape(v.shape), int(n[b]), stats[b, :n[b]].copy()))
+        off += v.size
+    return out
+
+
+def watershed_split(boxes, cls, tie="heap"):
+    """watershed.py:95-110 for each box (values {0, cls[b]}): eroded cores -> markers -> priority flood -> `wss[wss == 1]
+    = 0`; labels 2.. or 0, before the reference's max_class shift."""
+    boxes = [np.ascontiguousarray(v, dtype=np.int32) for v in boxes]
+    if not boxes:
+        return []
+    dims = np.ascontiguousarray([v.shape for v in boxes], dtype=np.int32)
+    flat = np.concatenate([v.ravel() for v in boxes])
+    cl = np.ascontiguousarray(cls, dtype=np.int32)
+    wss = np.empty_like(flat)
+    L.check(L.load().ics_op_watershed_split(L.i32ptr(flat), L.i32ptr(dims), L.i32ptr(cl), len(boxes), TIE_RULES[tie],
+                                            L.i32ptr(wss)))
+    out, off = [], 0
+    for v in boxes:
+        out.append(wss[off:off + v.size].reshape(v.shape))
+        off += v.size
+    return out
+
+
+def region_stats(R, species, num_species=95):
+    """majority vote + voxel count + coordinate sums + bounding box of every label 1..max(R) of an int volume R (d,d,d)
+    (`centroids` / `majority_vote`, watershed.py:153-187), on the device.  Returns stats int32 (max(R), 11)."""
+    R = np.ascontiguousarray(R, dtype=np.int32)
+    species = np.ascontiguousarray(species, dtype=np.uint8)
+    nlab = int(R.max())
+    if nlab <= 0:
+        return np.zeros((0, len(STAT_FIELDS)), np.int32)
+    stats = np.zeros((nlab, len(STAT_FIELDS)), np.int32)
+    L.check(L.load().ics_op_region_stats(L.i32ptr(R), L.u8ptr(species), R.shape[0], R.shape[1], R.shape[2], nlab,
+                                         int(num_species), L.i32ptr(stats)))
+    return stats
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# host side: convexity test and the recursion of segment_nuclei
+# ----------------------------------------------------------------------------------------------------------------------
+def convex_hull_volume(img, tolerance=1e-10):
+    """np.count_nonzero(skimage.morphology.convex_hull_image(img)) for a 3-D box: Qhull over the voxel coordinates
+    offset by +-0.5 along each axis, grid points counted when every hull inequality is < tolerance (watershed.py:80-81)."""
+    from scipy.spatial import ConvexHull, QhullError
+    pts = np.argwhere(np.asarray(img) != 0).astype(np.float64)
+    if len(pts) == 0:
+        return 0
+    try:                                               # skimage first reduces the set to its hull vertices
+        h0 = ConvexHull(pts)
+        pts = h0.points[h0.vertices]
+    except (QhullError, ValueError):                   # flat / collinear sets: the offsets below make them solid
+        pass
+    off = np.zeros((6, 3))
+    off[[0, 1], 0] = (-0.5, 0.5); off[[2, 3], 1] = (-0.5, 0.5); off[[4, 5], 2] = (-0.5, 0.5)
+    hull = ConvexHull(np.unique((pts[:, None, :] + off[None]).reshape(-1, 3), axis=0))
+    grid = np.indices(img.shape).reshape(3, -1).astype(np.float64)
+    inside = np.ones(grid.shape[1], bool)
+    for eq in hull.equations:
+        inside &= (eq[:3] @ grid + eq[3]) < tolerance
+    return int(np.count_nonzero(inside))
+
+
+def segment_nuclei(binary, wmin=8, it=1, max_iters=5, min_convexity=0.8, tie="heap", labelled=None, trace=None):
+    """watershed.py:40-150 (species / intensity ride along in the reference without influencing R and are omitted).
+    binary: int volume (D,H,W).  labelled: optional (labels, n, stats) of `binary` already computed on the device
+    (the batched first pass).  Returns R float64 like the reference."""
+    binary = np.asarray(binary).astype(np.int32)
+    R = np.zeros(binary.shape)
+    labels, n, stats = labelled if labelled is not None else label_boxes([binary], connectivity=1)[0]
+    kept = [cl for cl in range(1, n + 1) if stats[cl - 1, 0] > 3]        # seg_counts > 3, background excluded
+    crops, todo = {}, []
+    for cl in kept:
+        z0, y0, x0, z1, y1, x1 = (int(v) for v in stats[cl - 1, 1:7])
+        sl = (slice(z0, z1), slice(y0, y1), slice(x0, x1))
+        box = np.where(labels[sl] == cl, cl, 0).astype(np.int32)         # binary_bbox: values {0, cl}
+        convexity = int(stats[cl - 1, 0]) / convex_hull_volume(box)
+        crops[cl] = (sl, box, convexity)
+        if convexity < min_convexity:
+            todo.append(cl)
+    splits = dict(zip(todo, watershed_split([crops[cl][1] for cl in todo], todo, tie=tie)))   # one launch per level
+    for cl in kept:
+        sl, box, convexity = crops[cl]
+        if convexity >= min_convexity:
+            max_class = np.max(R)
+            R[sl] = np.where(box == cl, max_class + 1, R[sl])
+            if trace is not None:
+                trace.append((it, cl, int(stats[cl - 1, 0]), float(convexity), "convex"))
+            continue
+        max_class = np.max(R)
+        wss = splits[cl].astype(np.float64) + max_class
+        wss[wss == max_class] = 0
+        nclasses = len(np.unique(wss)) - 1
+        if int(np.count_nonzero(wss) / wmin) > nclasses and it < max_iters:
+            if trace is not None:
+                trace.append((it, cl, int(stats[cl - 1, 0]), float(convexity), "recurse"))
+            Rp = segment_nuclei(wss, it=it + 1, max_iters=max_iters, min_convexity=min_convexity, tie=tie, trace=trace)
+            max_class = np.max(R)
+            Rp = Rp + max_class
+            Rp[Rp == max_class] = 0
+            R[sl] = np.where(Rp != 0, Rp, R[sl])
+        else:
+            if trace is not None:
+                trace.append((it, cl, int(stats[cl - 1, 0]), float(convexity), "split"))
+            R[sl] = np.where(wss != 0, wss, R[sl])
+    return R
+
+
+def centroids(seg_img, R, num_species=95):
+    """watershed.py:165-187 on the device's region statistics: (atoms, means)."""
+    R = np.asarray(R)
+    return _atoms_from_rows(region_stats(R.astype(np.int32), seg_img, num_species), R.size)
+
+
+def watershed_clustering(M, S, Sb, max_iters=5, return_ws=False, verbose=False, tie="heap"):
+    """The reference's entry point (watershed.py:190-203) for ONE sample: (atoms, means[, R]).  `M` (the density) is
+    accepted for signature parity; the reference passes it through segment_nuclei without using it."""
     S = np.asarray(S).squeeze()
     Sb = np.asarray(Sb).squeeze()
-    r = segment_atoms(Sb[None], S[None], want_regions=return_ws)
-    atoms, means = r["atoms"][0]
+    R = segment_nuclei((Sb != 0).astype(np.int32), max_iters=max_iters, tie=tie)
+    atoms, means = centroids(S, R)
     if return_ws:
-        return np.array(atoms), np.array(means), r["regions"][0].astype(np.float64)
+        return np.array(atoms), np.array(means), R
     return np.array(atoms), np.array(means)
+
+
+def refine_atoms(out, max_iters=5, num_species=95, tie="heap", min_convexity=0.8):
+    """Continue a batch result of `segment_atoms` / `decode_to_atoms` (every kept component taken as convex) through
+    the convexity test and the recursive split.  A sample whose kept components all pass keeps its device result (the
+    convex branch numbers the regions 1..n in label order, which is what the first pass returned); any other sample is
+    segmented again from its mask by `segment_nuclei` -- from scratch, because the reference's `markers[unknown == 1]`
+    quirk depends on the ORIGINAL component numbers, small dropped components included -- and gets fresh region
+    statistics.  Needs out["regions"] and out["species"].  Adds out["split"] (B,) bool; updates out["atoms"],
+    out["regions"]."""
+    B = len(out["atoms"])
+    split = np.zeros(B, bool)
+    for b in range(B):
+        if out.get("failed") is not None and out["failed"][b]:
+            continue
+        n = int(out["n_atoms"][b])
+        st = out["stats"][b, :n]
+        lab0 = out["regions"][b]
+        convex = True
+        for a in range(n):
+            z0, y0, x0, z1, y1, x1 = (int(v) for v in st[a, 5:11])
+            box = lab0[z0:z1, y0:y1, x0:x1] == a + 1
+            if int(st[a, 1]) / convex_hull_volume(box) < min_convexity:
+                convex = False
+                break
+        if convex:
+            continue
+        split[b] = True
+        R = segment_nuclei((out["mask"][b] != 0).astype(np.int32) if out.get("mask") is not None else (lab0 != 0).astype(np.int32),
+                           max_iters=max_iters, min_convexity=min_convexity, tie=tie)
+        out["atoms"][b] = centroids(out["species"][b], R, num_species)
+        out["regions"][b] = R.astype(np.int32)
+    out["split"] = split
+    return out

@@ -129,15 +129,38 @@ int ics_vae_decode_to_unet_labels(ics_net* vae, ics_net* unet, const float* z, c
  *     (watershed.py:85-92): kept components renumbered 1..n in ascending label order, 0 elsewhere;
  *   - centroids / majority_vote (watershed.py:153-187) per region: the most frequent non-zero species (equal counts:
  *     the larger id, as the reference's stable sort leaves it) and the integer coordinate sums of ALL its voxels.
- * NOT implemented: the convex-hull test (watershed.py:80) and the marker watershed that splits non-convex
- * components (watershed.py:96-150); the bounding boxes and voxel counts returned here are what a host-side
- * implementation of those needs.
+ * The convexity test (watershed.py:80) and the split of non-convex components (watershed.py:95-150) continue from
+ * these regions, counts and bounding boxes: ics_op_label_boxes / ics_op_watershed_split below, driven by
+ * icsg3d_amd/watershed.py (the recursion and the Qhull convexity test run on the host, as in the reference).
  * Outputs: regions int32 (B,d,d,d) or NULL; counts int32 (B,2) = {components, kept components};
  * atom_stats int32 (B,max_atoms,11) = {species, voxels, sum_z, sum_y, sum_x, z0, y0, x0, z1, y1, x1} (axes 0,1,2 of the
  * volume -- the reference calls them x,y,z; bounding box half-open), rows >= kept components are empty.
- * Fails if a sample has more than max_atoms kept components.  Integer atomics only: results are bit-exact. */
+ * A sample with more than max_atoms kept components reports counts[b][1] > max_atoms: its rows are truncated and the
+ * caller must skip it (the reference skips a failed sample too, generate.py:228-236); the call itself succeeds.
+ * Integer atomics only: results are bit-exact. */
 int ics_op_segment_atoms(const uint8_t* mask, const uint8_t* species, int batch, int d, int min_voxels, int max_atoms,
                          int num_species, int32_t* regions, int32_t* counts, int32_t* atom_stats);
+/* ---- segment_nuclei's non-convex branch and recursion (watershed.py:40-150) on small boxes.  A box is a dense int32
+ * volume [D][H][W] (extents 1..64) -- a component cropped to its bounding box, or a watershed result that is segmented
+ * again; `nbox` boxes lie back to back in `vols` / `boxes`, dims = [nbox][3].  HOST pointers; one workgroup per box.
+ * The scikit-image 0.17.2 routines these replace (requirements.txt:95) are absent from the image: PARITY UNPINNED, the
+ * algorithms are restated in oracle/watershed_ref.py and the kernels are held to that restatement bit for bit.
+ *   ics_op_label_boxes   = skimage.measure.label(box, connectivity) (watershed.py:52, :103): maximal sets of voxels of
+ *     EQUAL non-zero value, numbered from 1 in raster order of their first voxel; connectivity 1 = 6 neighbours,
+ *     3 = 26.  nlabels[nbox]; stats (or NULL) [nbox][max_labels][7] = {voxels, z0, y0, x0, z1, y1, x1} (half-open).
+ *   ics_op_watershed_split = watershed.py:95-110 for a box with values {0, cls[b]}: fg / bg = erosion / dilation with
+ *     ball(1) (out-of-box neighbours ignored), markers = label(fg) + 1 with `markers[(bg - fg) == 1] = 0` (the
+ *     reference compares against 1, so the shell opens only for the component labelled 1), the priority flood of
+ *     segmentation.watershed (two image levels; a binary heap on (level, age) with skimage's tie behaviour when
+ *     tie = 0, FIFO when tie = 1), `wss[wss == 1] = 0`.  wss: labels 2.. or 0, before the reference's max_class shift. */
+int ics_op_label_boxes(const int32_t* vols, const int32_t* dims, int nbox, int connectivity, int max_labels,
+                       int32_t* labels, int32_t* nlabels, int32_t* stats);
+int ics_op_watershed_split(const int32_t* boxes, const int32_t* dims, const int32_t* cls, int nbox, int tie, int32_t* wss);
+/* centroids / majority_vote (watershed.py:153-187) for an arbitrary region volume R [D][H][W] (labels 1..num_labels, e.g.
+ * what segment_nuclei returns after splits): stats [num_labels][11] as ics_op_segment_atoms; labels that do not occur
+ * keep voxels = 0.  Pinned by the reference's own two functions (tests/golden/watershed_golden.npz). */
+int ics_op_region_stats(const int32_t* R, const uint8_t* species, int D, int H, int W, int num_labels, int num_species,
+                        int32_t* stats);
 /* ics_vae_decode_to_unet_labels continued on the device through the component labelling above: the mask and species
  * volumes never leave HBM between the U-Net and the region statistics.  species/mask/density/coord_minmax/regions
  * are optional (NULL to skip). */
