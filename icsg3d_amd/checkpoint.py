@@ -212,7 +212,97 @@ def read_keras_h5(path):
         return layers
 
 
-def write_keras_h5(path, layers, full_model=False, model_name="model"):
+# ------------------------------------------------------------------------------------------ model.save: the layer graph
+_GLOROT = {"class_name": "VarianceScaling", "config": {"scale": 1.0, "mode": "fan_avg", "distribution": "uniform", "seed": None}}
+_ZEROS, _ONES = {"class_name": "Zeros", "config": {}}, {"class_name": "Ones", "config": {}}
+
+
+def _conv3d_cfg(name, filters, k, activation="linear"):
+    return {"name": name, "trainable": True, "dtype": "float32", "filters": int(filters), "kernel_size": [k, k, k],
+            "strides": [1, 1, 1], "padding": "same", "data_format": "channels_last", "dilation_rate": [1, 1, 1],
+            "activation": activation, "use_bias": True, "kernel_initializer": _GLOROT, "bias_initializer": _ZEROS,
+            "kernel_regularizer": None, "bias_regularizer": None, "activity_regularizer": None,
+            "kernel_constraint": None, "bias_constraint": None}
+
+
+def _bn_cfg(name):
+    return {"name": name, "trainable": True, "dtype": "float32", "axis": -1, "momentum": 0.99, "epsilon": 0.001,
+            "center": True, "scale": True, "beta_initializer": _ZEROS, "gamma_initializer": _ONES,
+            "moving_mean_initializer": _ZEROS, "moving_variance_initializer": _ONES, "beta_regularizer": None,
+            "gamma_regularizer": None, "beta_constraint": None, "gamma_constraint": None}
+
+
+def unet_model_config(input_shape=(32, 32, 32, 4), num_classes=95):
+    """The functional-model JSON Keras 2.3.1 stores as the `model_config` attribute of `model.save` for
+    AtomUnet.unet_3d_multiclass (/root/reference/unet/unet.py:272-355): every layer in creation order with the
+    auto-generated names Keras gives them in a fresh process (conv3d_k / re_lu_k / batch_normalization_k, k = 1..14;
+    max_pooling3d_1..3, up_sampling3d_1..3, concatenate_1..3; `unet_input`, `soft`, `sig` are named in the source) and the
+    inbound nodes the source wires.  This is what lets `load_model(path, custom_objects)` -- how the reference's
+    LatticeDFCVAE opens its perceptual U-Net (vae/lattice_vae.py:120), which then looks the taps up as re_lu_2/4/6/8
+    (:100,260-261) -- rebuild the network from a file written here.  The graph is fixed and known, so the JSON is emitted
+    from this table; a real Keras `load_model` could not be run in this image (Keras / TF absent)."""
+    layers = []
+
+    def add(name, cls, cfg, inbound):
+        layers.append({"name": name, "class_name": cls, "config": cfg,
+                       "inbound_nodes": [[[src, 0, 0, {}] for src in inbound]] if inbound else []})
+        return name
+
+    x = add("unet_input", "InputLayer", {"batch_input_shape": [None] + [int(v) for v in input_shape], "dtype": "float32",
+                                         "sparse": False, "name": "unet_input"}, [])
+    count = {"conv": 0, "pool": 0, "up": 0, "cat": 0}
+
+    def block(src, filters):
+        count["conv"] += 1
+        k = count["conv"]
+        c = add("conv3d_%d" % k, "Conv3D", _conv3d_cfg("conv3d_%d" % k, filters, 3), [src])
+        r = add("re_lu_%d" % k, "ReLU", {"name": "re_lu_%d" % k, "trainable": True, "dtype": "float32", "max_value": None,
+                                         "negative_slope": 0.0, "threshold": 0.0}, [c])
+        return add("batch_normalization_%d" % k, "BatchNormalization", _bn_cfg("batch_normalization_%d" % k), [r])
+
+    def pool(src):
+        count["pool"] += 1
+        n = "max_pooling3d_%d" % count["pool"]
+        return add(n, "MaxPooling3D", {"name": n, "trainable": True, "dtype": "float32", "pool_size": [2, 2, 2],
+                                       "padding": "valid", "strides": [2, 2, 2], "data_format": "channels_last"}, [src])
+
+    def up(src):
+        count["up"] += 1
+        n = "up_sampling3d_%d" % count["up"]
+        return add(n, "UpSampling3D", {"name": n, "trainable": True, "dtype": "float32", "size": [2, 2, 2],
+                                       "data_format": "channels_last"}, [src])
+
+    def cat(a, b):
+        count["cat"] += 1
+        n = "concatenate_%d" % count["cat"]
+        return add(n, "Concatenate", {"name": n, "trainable": True, "dtype": "float32", "axis": -1}, [a, b])
+
+    c1 = block(x, 32); c2 = block(c1, 64); p1 = pool(c2)
+    c3 = block(p1, 64); c4 = block(c3, 128); p2 = pool(c4)
+    c5 = block(p2, 128); c6 = block(c5, 256); p3 = pool(c6)
+    c9 = block(p3, 512); c10 = block(c9, 512); u1 = up(c10)
+    c13 = block(cat(c6, u1), 512); c14 = block(c13, 256); u3 = up(c14)
+    c15 = block(cat(c4, u3), 256); c16 = block(c15, 128); u4 = up(c16)
+    c17 = block(cat(c2, u4), 128); c18 = block(c17, 128)
+    add("soft", "Conv3D", _conv3d_cfg("soft", num_classes, 1, "softmax"), [c18])
+    add("sig", "Conv3D", _conv3d_cfg("sig", 1, 1, "sigmoid"), [c18])
+    return {"class_name": "Model",
+            "config": {"name": "unet", "layers": layers, "input_layers": [["unet_input", 0, 0]],
+                       "output_layers": [["soft", 0, 0], ["sig", 0, 0]]},
+            "keras_version": "2.3.1", "backend": "tensorflow"}
+
+
+def unet_training_config(lr=1e-6):
+    """`training_config` of the compiled AtomUnet (unet/unet.py:243-259): the weighted CCE is the closure `loss`
+    (:211-221, the key the reference's custom_objects uses, :393-399), metrics f1_m / wr_m on `soft`."""
+    return {"optimizer_config": {"class_name": "Adam",
+                                 "config": {"learning_rate": float(lr), "beta_1": 0.9, "beta_2": 0.999, "decay": 0.0,
+                                            "epsilon": 1e-07, "amsgrad": False}},
+            "loss": {"soft": "loss", "sig": "binary_crossentropy"}, "metrics": {"soft": ["f1_m", "wr_m"]},
+            "weighted_metrics": None, "sample_weight_mode": None, "loss_weights": None}
+
+
+def write_keras_h5(path, layers, full_model=False, model_name="model", model_config=None, training_config=None):
     d = os.path.dirname(path)
     if d:
         os.makedirs(d, exist_ok=True)
@@ -222,10 +312,13 @@ def write_keras_h5(path, layers, full_model=False, model_name="model"):
         node.attrs["backend"] = b"tensorflow"
         node.attrs["keras_version"] = b"2.3.1"
     if full_model:
-        # enough for Keras' load_weights (which only walks /model_weights); load_model would need the real
-        # layer graph JSON, which only Keras can write
-        w.root.attrs["model_config"] = json.dumps({"class_name": "Model", "config": {"name": model_name},
-                                                   "written_by": "icsg3d_amd"}).encode()
+        # model_config: the layer graph as Keras serialises it (unet_model_config) where this package knows the graph;
+        # otherwise a stub that is enough for Keras' load_weights (which only walks /model_weights)
+        cfg = model_config if model_config is not None else {"class_name": "Model", "config": {"name": model_name},
+                                                             "written_by": "icsg3d_amd"}
+        w.root.attrs["model_config"] = json.dumps(cfg).encode()
+        if training_config is not None:
+            w.root.attrs["training_config"] = json.dumps(training_config).encode()
     g.attrs["layer_names"] = np.array([ln.encode() for ln, _ in layers])
     for ln, ws in layers:
         lg = g.create_group(ln)
@@ -244,13 +337,26 @@ def _check_shapes(weights, expected_shapes, what):
                              "mismatch?)" % (what, name, tuple(weights[name].shape), tuple(shape)))
 
 
-def save_weights(path, weights, kind, meta=None, full_model=False):
+def save_weights(path, weights, kind, meta=None, full_model=False, model_config=None, training_config=None):
     """kind: "unet" | "vae".  `.npz` paths keep the archive format; everything else (the reference's
     `.hdf5` / `.h5` names) is Keras HDF5."""
     if path.endswith(".npz"):
         return save_npz(path, weights, meta)
     layers = unet_keras_layers(weights) if kind == "unet" else vae_keras_layers(weights)
-    write_keras_h5(path, layers, full_model=full_model, model_name=kind)
+    write_keras_h5(path, layers, full_model=full_model, model_name=kind, model_config=model_config,
+                   training_config=training_config)
+
+
+def read_model_config(path):
+    """(model_config, training_config | None) of a `model.save` file, parsed."""
+    with Hdf5File(path) as f:
+        def js(name):
+            v = f.attrs.get(name)
+            if v is None:
+                return None
+            v = np.asarray(v).ravel()[0] if isinstance(v, np.ndarray) else v
+            return json.loads(v.decode() if isinstance(v, (bytes, np.bytes_)) else str(v))
+        return js("model_config"), js("training_config")
 
 
 def load_weights(path, kind, expected_shapes=None):

@@ -189,11 +189,16 @@ class _UnetModel:
         _save_weight_file(path, self._o._get_weights(), "unet")
 
     def save(self, path):
-        """model.save(.h5) (unet/unet.py:379,389): the weight tree under /model_weights, which is all that this
-        package's loaders and Keras' `load_weights` read.  LIMITATION: `model_config` is a stub without the layer graph,
-        so Keras' `load_model` (how the reference's LatticeDFCVAE opens its perceptual U-Net, vae/lattice_vae.py:120)
-        cannot rebuild the network from a file written here -- build AtomUnet() there and `load_weights` the file."""
-        _save_weight_file(path, self._o._get_weights(), "unet", full_model=True)
+        """model.save(.h5) (unet/unet.py:379,389): the weight tree under /model_weights plus the `model_config` /
+        `training_config` attributes Keras 2.3.1 writes for this graph (checkpoint.unet_model_config: every layer of
+        unet_3d_multiclass with its auto-generated name and inbound nodes), which is what `load_model(path,
+        custom_objects)` -- how the reference's LatticeDFCVAE opens its perceptual U-Net (vae/lattice_vae.py:120) -- needs
+        to rebuild the network and find re_lu_2/4/6/8.  Not verifiable here: Keras itself is absent from the image."""
+        from ..checkpoint import unet_model_config, unet_training_config
+        o = self._o
+        _save_weight_file(path, o._get_weights(), "unet", full_model=True,
+                          model_config=unet_model_config(o.input_shape, o.num_classes),
+                          training_config=unet_training_config(getattr(o, "lr", 1e-6)))
 
 
 class _BestCheckpoint:

@@ -131,3 +131,87 @@ def test_full_size_unet_through_real_libhdf5(tmp_path):
     assert np.array_equal(h.read_dataset(q, "/model_weights/batch_normalization_14/batch_normalization_14/moving_variance:0"),
                           w["c18/moving_var"])
     assert np.array_equal(h.read_dataset(q, "/model_weights/soft/soft/kernel:0"), w["soft/kernel"])
+
+
+def test_unet_model_save_carries_the_keras_layer_graph(tmp_path):
+    """AtomUnet.model.save writes the functional-model JSON Keras 2.3.1 stores for unet_3d_multiclass
+    (/root/reference/unet/unet.py:272-355,378-379), so that load_model (vae/lattice_vae.py:120) can rebuild it and find
+    the perceptual taps re_lu_2/4/6/8 (:100).  Parse it back from the file, rebuild the layer list, run shape
+    inference over it and check names, shapes and inbound nodes.  (A real Keras load_model cannot be run here.)"""
+    from icsg3d_amd import checkpoint as ck
+    from icsg3d_amd.synthetic import bn_state_defaults, glorot_params, unet_param_shapes
+    C, ncls, d = 4, 95, 32
+    shapes = unet_param_shapes(C, ncls)
+    W = dict(glorot_params(shapes, 3))
+    W.update(bn_state_defaults(shapes))
+    path = str(tmp_path / "unet.h5")
+    ck.save_weights(path, W, "unet", full_model=True, model_config=ck.unet_model_config((d, d, d, C), ncls),
+                    training_config=ck.unet_training_config(3e-6))
+    cfg, tr = ck.read_model_config(path)
+    assert cfg["class_name"] == "Model" and cfg["keras_version"] == "2.3.1" and cfg["config"]["name"] == "unet"
+    layers = cfg["config"]["layers"]
+    names = [l["name"] for l in layers]
+    assert len(names) == len(set(names))
+    kinds = {}
+    for l in layers:
+        kinds.setdefault(l["class_name"], []).append(l["name"])
+    assert kinds["InputLayer"] == ["unet_input"]
+    assert kinds["Conv3D"] == ["conv3d_%d" % k for k in range(1, 15)] + ["soft", "sig"]
+    assert kinds["ReLU"] == ["re_lu_%d" % k for k in range(1, 15)]
+    assert kinds["BatchNormalization"] == ["batch_normalization_%d" % k for k in range(1, 15)]
+    assert kinds["MaxPooling3D"] == ["max_pooling3d_%d" % k for k in (1, 2, 3)]
+    assert kinds["UpSampling3D"] == ["up_sampling3d_%d" % k for k in (1, 2, 3)]
+    assert kinds["Concatenate"] == ["concatenate_%d" % k for k in (1, 2, 3)]
+    assert cfg["config"]["input_layers"] == [["unet_input", 0, 0]]
+    assert cfg["config"]["output_layers"] == [["soft", 0, 0], ["sig", 0, 0]]
+    # rebuild: every inbound layer exists BEFORE its consumer (creation order), shapes by inference
+    by = {l["name"]: l for l in layers}
+    shape = {}
+    for l in layers:
+        src = [n[0] for n in l["inbound_nodes"][0]] if l["inbound_nodes"] else []
+        assert all(s in shape for s in src), l["name"]
+        c = l["config"]
+        if l["class_name"] == "InputLayer":
+            shape[l["name"]] = tuple(c["batch_input_shape"][1:])
+        elif l["class_name"] == "Conv3D":
+            assert c["padding"] == "same" and c["strides"] == [1, 1, 1] and c["use_bias"] and c["data_format"] == "channels_last"
+            shape[l["name"]] = shape[src[0]][:3] + (c["filters"],)
+        elif l["class_name"] in ("ReLU", "BatchNormalization"):
+            shape[l["name"]] = shape[src[0]]
+        elif l["class_name"] == "MaxPooling3D":
+            assert c["pool_size"] == [2, 2, 2] and c["strides"] == [2, 2, 2] and c["padding"] == "valid"
+            shape[l["name"]] = tuple(v // 2 for v in shape[src[0]][:3]) + shape[src[0]][3:]
+        elif l["class_name"] == "UpSampling3D":
+            shape[l["name"]] = tuple(v * 2 for v in shape[src[0]][:3]) + shape[src[0]][3:]
+        elif l["class_name"] == "Concatenate":
+            assert c["axis"] == -1 and shape[src[0]][:3] == shape[src[1]][:3]
+            shape[l["name"]] = shape[src[0]][:3] + (shape[src[0]][3] + shape[src[1]][3],)
+    assert shape["soft"] == (d, d, d, ncls) and shape["sig"] == (d, d, d, 1)
+    assert by["soft"]["config"]["activation"] == "softmax" and by["sig"]["config"]["activation"] == "sigmoid"
+    assert by["soft"]["config"]["kernel_size"] == [1, 1, 1]
+    # the graph's wiring: Conv -> ReLU -> BN blocks (unet.py:276-278), [skip, upsampled] concat order (:312,322,332)
+    for k in range(1, 15):
+        assert by["re_lu_%d" % k]["inbound_nodes"] == [[["conv3d_%d" % k, 0, 0, {}]]]
+        assert by["batch_normalization_%d" % k]["inbound_nodes"] == [[["re_lu_%d" % k, 0, 0, {}]]]
+        assert by["batch_normalization_%d" % k]["config"]["epsilon"] == 0.001
+    assert [n[0] for n in by["concatenate_1"]["inbound_nodes"][0]] == ["batch_normalization_6", "up_sampling3d_1"]
+    assert [n[0] for n in by["concatenate_2"]["inbound_nodes"][0]] == ["batch_normalization_4", "up_sampling3d_2"]
+    assert [n[0] for n in by["concatenate_3"]["inbound_nodes"][0]] == ["batch_normalization_2", "up_sampling3d_3"]
+    assert by["up_sampling3d_1"]["inbound_nodes"][0][0][0] == "batch_normalization_8"
+    # the perceptual taps (lattice_vae.py:100): re_lu_2/4/6/8 = the ReLUs after c2, c4, c6, c10, i.e. the 2nd, 4th, 6th and
+    # 8th convolution, with 64 / 128 / 256 / 512 channels at 32 / 16 / 8 / 4 voxels
+    assert [shape["re_lu_%d" % k] for k in (2, 4, 6, 8)] == [(32, 32, 32, 64), (16, 16, 16, 128), (8, 8, 8, 256), (4, 4, 4, 512)]
+    # every weight in /model_weights belongs to a layer of the graph with the shape the graph implies
+    for ln, ws in ck.read_keras_h5(path):
+        assert ln in by
+        for wn, arr in ws:
+            if wn.endswith("kernel:0"):
+                k = by[ln]["config"]["kernel_size"][0]
+                cin = shape[by[ln]["inbound_nodes"][0][0][0]][3]
+                assert arr.shape == (k, k, k, cin, by[ln]["config"]["filters"])
+    # training_config: the closure `loss` (the key of the reference's custom_objects, unet.py:393-399) and the metrics
+    assert tr["loss"] == {"soft": "loss", "sig": "binary_crossentropy"} and tr["metrics"] == {"soft": ["f1_m", "wr_m"]}
+    assert tr["optimizer_config"]["class_name"] == "Adam" and abs(tr["optimizer_config"]["config"]["learning_rate"] - 3e-6) < 1e-12
+    # and the file still loads as weights, bit for bit
+    back = ck.load_weights(path, "unet", expected_shapes=dict(shapes))
+    assert all(np.array_equal(back[k], W[k]) for k in W)
