@@ -152,6 +152,22 @@ int main(void) {
     if (ics_op_segment_atoms(mask, species, B, 24, 3, 32, 95, regions, counts, stats) == 0) { fprintf(stderr, "grid check missing\n"); return 1; }
     free(mask); free(species); free(regions); free(stats);
   }
+  {  /* segment_nuclei's box operations (round 4): host-side batching, descriptor tables, scratch sizing */
+    int32_t dims[6] = {3, 4, 5, 2, 2, 7};
+    int32_t vols[60 + 28], labels[60 + 28], wss[60 + 28], nlab[2], cls[2] = {1, 5};
+    int32_t bstats[2 * 8 * 7], rstats[4 * 11];
+    uint8_t sp[60];
+    memset(vols, 0, sizeof vols); memset(sp, 0, sizeof sp);
+    vols[7] = 1; vols[8] = 1; vols[61] = 5;
+    OK(ics_op_label_boxes(vols, dims, 2, 1, 8, labels, nlab, bstats));
+    OK(ics_op_label_boxes(vols, dims, 2, 3, 8, labels, nlab, NULL));
+    OK(ics_op_watershed_split(vols, dims, cls, 2, 0, wss));
+    OK(ics_op_watershed_split(vols, dims, cls, 2, 1, wss));
+    OK(ics_op_region_stats(vols, sp, 3, 4, 5, 4, 95, rstats));
+    dims[0] = 65;
+    if (ics_op_label_boxes(vols, dims, 2, 1, 8, labels, nlab, bstats) == 0) { fprintf(stderr, "box extent check missing\n"); return 1; }
+    if (ics_op_label_boxes(vols, dims + 3, 1, 2, 8, labels, nlab, bstats) == 0) { fprintf(stderr, "connectivity check missing\n"); return 1; }
+  }
   printf("asan driver: all entry points walked, no sanitizer report\n");
   return 0;
 }

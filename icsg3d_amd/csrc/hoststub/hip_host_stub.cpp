@@ -74,6 +74,7 @@ int roctxRangePop(void) { return 0; }
 ncclResult_t ncclGetUniqueId(ncclUniqueId* id) { std::memset(id, 7, sizeof(*id)); return ncclSuccess; }
 ncclResult_t ncclCommInitRank(ncclComm_t* c, int, ncclUniqueId, int) { *c = (ncclComm_t)std::malloc(8); return ncclSuccess; }
 ncclResult_t ncclCommDestroy(ncclComm_t c) { std::free(c); return ncclSuccess; }
+ncclResult_t ncclCommSplit(ncclComm_t, int, int, ncclComm_t* c, ncclConfig_t*) { *c = (ncclComm_t)std::malloc(8); return ncclSuccess; }
 const char* ncclGetErrorString(ncclResult_t) { return "host-stub nccl error"; }
 static size_t nccl_size(ncclDataType_t t) { return (t == ncclDouble || t == ncclInt64 || t == ncclUint64) ? 8 : 4; }
 ncclResult_t ncclAllReduce(const void* s, void* r, size_t n, ncclDataType_t t, ncclRedOp_t, ncclComm_t, hipStream_t) {
