@@ -99,6 +99,9 @@ enum ConvFlags : int {
   CF_NO_FUSED_HEAD = 16384,    // ICSG3D_NO_FUSED_HEAD: 1x1x1 head GEMM + loss kernel / implicit-GEMM head backward-data
   CF_NO_BWD_FOLD = 32768,      // ICSG3D_NO_BWD_FOLD: BatchNorm-backward sums in their own pass, not in the consumer's dgrad
   CF_UP3_BIG_ALWAYS = 65536,   // ICSG3D_UP3_BIG_MIN_WG=1: 32-voxel conv_up3 workgroups wherever the shape allows (tests)
+  CF_NO_WINOG = 262144,        // ICSG3D_NO_WINOG: S = 4 layers through the 27-tap kernels instead of the Winograd-domain
+                               // batched GEMMs of conv_winog.hip (round 4)
+  CF_ZBATCH = 1 << 20,         // internal: conv_fwd_kernel runs gridDim.z independent GEMMs (launch_gemm_zbatch)
   CF_NO_TICKET = 131072,       // ICSG3D_NO_TICKET: finalize / split reductions as their own launches instead of in the
                                // last workgroup of the producer (round 4)
 };
@@ -224,6 +227,21 @@ size_t conv_up3_weight_floats(int Cu, int Cout);
 int launch_pack_up3(hipStream_t st, const float* w, int Cin_total, int Cout, int c_off, int Cu, float* dst);
 int launch_conv_fwd_up3(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, const float* wt, const float* bias,
                         float* out, int ldo, int pre_act, float* stat_partial, int* stat_blocks, int accumulate);
+// ---------------------------------------------------------------- Winograd-domain GEMMs for the S = 4 layers (conv_winog.hip)
+// 3x3x3 "same" convolution on 4^3 grids as input transform -> 64 plain GEMMs (launch_gemm_zbatch) -> output transform.
+// wg: weights transformed by launch_pack_wino(..., layout 2): [64][K/4][Nn][4].  v / m / z scratch: conv_winog_scratch_floats.
+bool conv_winog_ok(const ConvGeom& g, const ConvSrc* src, int nsrc);
+bool conv_winog_wgrad_ok(const ConvGeom& g, const ConvSrc* src, int nsrc);
+size_t conv_winog_weight_floats(int Cin, int Cout);
+void conv_winog_scratch_floats(const ConvGeom& g, size_t* v, size_t* m, size_t* z);
+// *rows_per_block = 64 (BatchNorm partials).  vt_keep (or nullptr): the transposed transform [64][Cin][T] backward-weight reads
+int launch_conv_fwd_winog(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, const float* wg, const float* bias, float* out,
+                          int ldo, int pre_act, float* stat_partial, int* rows_per_block, float* v_scratch, float* m_scratch,
+                          float* vt_keep);
+int launch_conv_wgrad_winog(hipStream_t st, const ConvGeom& g, const float* vt, const float* dy, int ldy, float* dw, int ldw,
+                            int row_pitch, int row_off, float* z_scratch, float* m_scratch);
+// nz independent plain GEMMs out_z[M][N] = A_z[M][K] x W_z[K][N] (conv_igemm.hip; W_z packed [K/4][N][4])
+int launch_gemm_zbatch(hipStream_t st, int nz, int M, int K, int N, const float* A, const float* Wp, float* out, int flags);
 // fixed-order reduction of split-K weight-gradient partials ws[split][k][n] into dw (conv_igemm.hip)
 int launch_wgrad_reduce_splits(hipStream_t st, const float* ws, int nsplit, size_t n_elems, int N, float* dw, int ldw,
                                int sub_rows, int row_pitch, int row_off);

@@ -70,6 +70,7 @@ int conv_flags_from_env() {
   if (getenv("ICSG3D_NO_FUSED_HEAD")) f |= CF_NO_FUSED_HEAD;
   if (getenv("ICSG3D_NO_BWD_FOLD")) f |= CF_NO_BWD_FOLD;
   if (getenv("ICSG3D_NO_TICKET")) f |= CF_NO_TICKET;
+  if (getenv("ICSG3D_NO_WINOG")) f |= CF_NO_WINOG;
   { const char* e = getenv("ICSG3D_UP3_BIG_MIN_WG"); if (e && *e && strtoul(e, nullptr, 10) <= 1) f |= CF_UP3_BIG_ALWAYS; }
   return f;
 }
@@ -249,6 +250,15 @@ __global__ __launch_bounds__(256, FOLD ? 2 : ((REUSE && PAR) ? 3 : 1)) void conv
   const int cls = PAR ? (int)blockIdx.y : 0;
   const int pz = cls >> 2, py = (cls >> 1) & 1, px = cls & 1;
   if (PAR) wp += (size_t)cls * g.Kpad * g.Npad;
+  // CF_ZBATCH (launch_gemm_zbatch): gridDim.z INDEPENDENT plain GEMMs, one per z -- the 64 frequency images of a
+  // Winograd-domain evaluation (conv_winog.hip): A, the packed weights and the output advance by whole matrices; no split-K
+  const bool zbatch = (g.flags & CF_ZBATCH) != 0;
+  if (zbatch) {
+    s0.p += (size_t)blockIdx.z * (size_t)M * (size_t)s0.C;
+    wp += (size_t)blockIdx.z * (size_t)g.Kpad * (size_t)g.Npad;
+    out += (size_t)blockIdx.z * (size_t)M * (size_t)ldo;
+  }
+  const int zsplit = zbatch ? 1 : (int)gridDim.z, zidx = zbatch ? 0 : (int)blockIdx.z;
 
   // ---- per-thread row bookkeeping
   const int mrow_base = mb * BM + (VEC ? (t >> 3) : (t >> 5));   // + 32*r (VEC) / 8*r (SCALAR)
@@ -501,7 +511,7 @@ __global__ __launch_bounds__(256, FOLD ? 2 : ((REUSE && PAR) ? 3 : 1)) void conv
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   // accumulate: the accumulators START from the previous contents of out (the parity-class pass of an up-split
   // layer), so the read's latency hides under the prologue instead of stalling the epilogue
-  if (accumulate && !PAR && gridDim.z == 1) {
+  if (accumulate && !PAR && zsplit == 1) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = n0 + wn * TN * 32 + j * 32 + li;
@@ -592,10 +602,10 @@ __global__ __launch_bounds__(256, FOLD ? 2 : ((REUSE && PAR) ? 3 : 1)) void conv
       if (zb == 0) G0 = 3 * cpt;
       if (zb == S - 1) G1 = 6 * cpt;
     }
-    if (gridDim.z > 1) {   // split-K: this block's slice of the groups; partial sums go to the workspace
-      const int per = (nG + (int)gridDim.z - 1) / (int)gridDim.z;
-      G0 = max(G0, (int)blockIdx.z * per);
-      G1 = min(G1, ((int)blockIdx.z + 1) * per);
+    if (zsplit > 1) {   // split-K: this block's slice of the groups; partial sums go to the workspace
+      const int per = (nG + zsplit - 1) / zsplit;
+      G0 = max(G0, zidx * per);
+      G1 = min(G1, (zidx + 1) * per);
     }
     if (G0 < G1) {
     // (gzy, cc) of the current / next group are carried incrementally: no integer division in the loop
@@ -639,9 +649,9 @@ __global__ __launch_bounds__(256, FOLD ? 2 : ((REUSE && PAR) ? 3 : 1)) void conv
     }   // G0 < G1
   } else {
   int cb = 0, ce = nchunks;
-  if (gridDim.z > 1) {
-    const int per = (nchunks + (int)gridDim.z - 1) / (int)gridDim.z;
-    cb = (int)blockIdx.z * per;
+  if (zsplit > 1) {
+    const int per = (nchunks + zsplit - 1) / zsplit;
+    cb = zidx * per;
     ce = min(nchunks, cb + per);
   }
   const bool gemm = VEC && !THIN && !PAR && !UP && ABL == 0 && g.taps == 1;   // block-uniform
@@ -745,7 +755,7 @@ __global__ __launch_bounds__(256, FOLD ? 2 : ((REUSE && PAR) ? 3 : 1)) void conv
   __syncthreads();
   }   // cb < ce
   }   // !REUSE
-  if (gridDim.z > 1) out += (size_t)blockIdx.z * (size_t)M * ldo;
+  if (zsplit > 1) out += (size_t)zidx * (size_t)M * ldo;
 
   // ---- epilogue: bias + activation, store, per-block BatchNorm partial statistics
   const int mrow0 = mb * BM + wm * TM * 32 + 4 * lh;
@@ -943,6 +953,17 @@ static bool conv_is_thin(const ConvGeom& g, const ConvSrc& s0, int nsrc) {
   return nsrc == 1 && s0.bcast == 0 && s0.C == g.Cin && (g.Cin == 4 || g.Cin == 8 || g.Cin == 16);
 }
 
+
+// nz independent plain GEMMs out_z[M][N] = A_z[M][K] x W_z[K][N] (A row-major, W in the packed [K/4][N][4] layout, both
+// advancing by whole matrices per z) on the 64 x 64 tile of conv_fwd_kernel: the frequency images of conv_winog.hip
+int launch_gemm_zbatch(hipStream_t st, int nz, int M, int K, int N, const float* A, const float* Wp, float* out, int flags) {
+  ICS_CHECK(nz >= 1 && nz <= 65535 && M >= 1 && K % 32 == 0 && N % 64 == 0, "z-batched GEMM: K % 32, N % 64 required");
+  ICS_CHECK((size_t)M * (size_t)std::max(K, N) < ((size_t)1 << 30), "z-batched GEMM: matrix too large for 32-bit offsets");
+  const ConvGeom g{M, 1, 0, K, N, 1, K, N, flags | CF_ZBATCH};
+  const ConvSrc s0{A, nullptr, nullptr, K, 0, ACT_NONE, 0}, s1{};
+  return launch_fwd_cfg<2, 2, 1, 1, true, 0, false, false, false, false, false, true, false>(
+      st, g, s0, s1, Wp, nullptr, out, N, ACT_NONE, nullptr, nullptr, 0, nz);
+}
 
 int conv_fwd_rows_per_block(const ConvGeom& g) {
   int bm, bn;
@@ -3164,6 +3185,46 @@ int launch_pack_bwd(hipStream_t st, const float* w, int taps, int Cin, int Cout,
 __device__ __forceinline__ void pack_wino_pair(size_t t, const float* __restrict__ w, int Cin_total, int Cout, int c_off,
                                                int Csub, int bwd, float* __restrict__ dst, int layout) {
   const int K = bwd ? Cout : Csub;
+  if (layout == 2) {
+    // conv_winog.hip: 64 plain GEMM images dst[f][K/4][Nn][4] (the packed-weight layout of conv_fwd_kernel, one per
+    // frequency); t = ((k >> 2) * Nn + n) * 4 + (k & 3): consecutive threads write consecutive floats of every image
+    const int Nn = bwd ? Csub : Cout;
+    const int k2 = (int)(t / ((size_t)4 * Nn)) * 4 + (int)(t & 3), n2 = (int)((t >> 2) % (size_t)Nn);
+    float g2[27];
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap)
+      g2[tap] = bwd ? w[((size_t)(26 - tap) * Cin_total + c_off + n2) * Cout + k2]
+                    : w[((size_t)tap * Cin_total + c_off + k2) * Cout + n2];
+    const size_t fs2 = (size_t)K * Nn;
+    float* d2 = dst + t;
+#pragma unroll
+    for (int fz = 0; fz < 4; ++fz)
+#pragma unroll
+      for (int fy = 0; fy < 4; ++fy)
+#pragma unroll
+        for (int fx = 0; fx < 4; ++fx) {
+          // U[fz][fy][fx] = sum_{a,b,c} G[fz][a] G[fy][b] G[fx][c] g[a][b][c],  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
+          float acc = 0.f;
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            const float ga = fz == 0 ? (a == 0 ? 1.f : 0.f) : fz == 3 ? (a == 2 ? 1.f : 0.f) : (fz == 2 && a == 1 ? -0.5f : 0.5f);
+            if (ga == 0.f) continue;
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+              const float gb = fy == 0 ? (b == 0 ? 1.f : 0.f) : fy == 3 ? (b == 2 ? 1.f : 0.f) : (fy == 2 && b == 1 ? -0.5f : 0.5f);
+              if (gb == 0.f) continue;
+#pragma unroll
+              for (int c = 0; c < 3; ++c) {
+                const float gc = fx == 0 ? (c == 0 ? 1.f : 0.f) : fx == 3 ? (c == 2 ? 1.f : 0.f) : (fx == 2 && c == 1 ? -0.5f : 0.5f);
+                if (gc == 0.f) continue;
+                acc += (ga * gb * gc) * g2[(a * 3 + b) * 3 + c];
+              }
+            }
+          }
+          d2[(size_t)((fz * 4 + fy) * 4 + fx) * fs2] = acc;
+        }
+    return;
+  }
   const int j = (int)(t & 1), n32 = (int)((t >> 1) & 31), h = (int)((t >> 6) & 1);
   const size_t rest = layout ? t >> 8 : t >> 7;
   const int c4 = (int)(rest % (size_t)(K / 4)), nchunk = (int)(rest / (size_t)(K / 4));

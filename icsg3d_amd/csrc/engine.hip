@@ -124,6 +124,12 @@ struct ConvLayer {
                                         // skip channels only in an up-split layer.  nullptr: layer not served
   int ww_layout = 0, wwb_layout = 0;    // decided once at the maximum batch (conv_wino_layout), used by pack AND launch
   bool wino_w = false;                  // backward-weight in the Winograd domain
+  // S = 4 layers (conv_winog.hip): Winograd-domain batched GEMMs.  wg / wgb: transformed forward / backward-data weights
+  // [64][K/4][N][4]; wg_v / wg_m: transform and GEMM-result scratch; wg_vt: the forward's transposed transform, kept for
+  // backward-weight (wg_w); wg_z / wg_du: backward-weight scratch (its own: the weight gradients may run on the side stream)
+  int wg_vt_batch = 0;                  // batch whose transform wg_vt holds (0: none)
+  float *wg = nullptr, *wgb = nullptr, *wg_v = nullptr, *wg_m = nullptr, *wg_vt = nullptr, *wg_z = nullptr, *wg_du = nullptr;
+  bool wg_w = false;
   float* s = nullptr;                   // stored output [M][Cout]
   float* dy = nullptr;                  // grad w.r.t. conv output [M][Cout]
   float* dA = nullptr;                  // grad w.r.t. virtual input [M][Cin]
@@ -181,6 +187,8 @@ struct Net {
   float* ws_bwd2 = nullptr;  size_t ws_bwd2_n = 0;    // BN-backward sums folded into a backward-data epilogue
   float* ws_wgrad = nullptr; size_t ws_wgrad_n = 0;
   float* ws_fwd = nullptr;   size_t ws_fwd_n = 0;     // forward / backward-data split-K partial sums
+  bool want_wgrad_inputs = false;   // forward passes keep what a backward-WEIGHT pass needs (conv_winog.hip's transposed
+                                    // transform): only inside the engine's own train step
   bool splitk = false;       // split-K only inside train steps: its plan depends on the batch size, and
                              // inference keeps "a sample's output does not depend on its batch" bit-exact
   float* fws() const { return splitk ? ws_fwd : nullptr; }
@@ -430,6 +438,29 @@ static int enable_wino(Net& n, ConvLayer& L, bool need_bwd) {
   return 0;
 }
 
+// S = 4 layers: conv_winog.hip
+static int enable_winog(Net& n, ConvLayer& L, bool need_bwd) {
+  if (L.ww || L.taps != 27 || L.pad_in || L.cond_fold || L.CinG != L.Cin || L.split_up || L.nsrc != 1) return 0;
+  const ConvGeom g = geom_fwd(L, n.maxB);
+  if (!conv_winog_ok(g, L.src, 1)) return 0;
+  size_t v, m, z;
+  conv_winog_scratch_floats(g, &v, &m, &z);
+  ICS_TRY(n.alloc(&L.wg, conv_winog_weight_floats(L.Cin, L.Cout)));
+  ICS_TRY(n.alloc(&L.wg_v, v));
+  ICS_TRY(n.alloc(&L.wg_m, m));
+  if (need_bwd) {
+    ConvGeom gb = geom_bwd(L, n.maxB);
+    gb.Cout = L.Cin;
+    const ConvSrc sdy = src_plain(nullptr, L.Cout);
+    if (conv_winog_ok(gb, &sdy, 1)) ICS_TRY(n.alloc(&L.wgb, conv_winog_weight_floats(L.Cin, L.Cout)));
+    L.wg_w = true;        // whether a given batch qualifies (B % 4 == 0) is decided per launch
+    ICS_TRY(n.alloc(&L.wg_vt, (size_t)64 * n.maxB * 8 * L.Cin));
+    ICS_TRY(n.alloc(&L.wg_z, z));
+    ICS_TRY(n.alloc(&L.wg_du, (size_t)64 * L.Cin * L.Cout));
+  }
+  return 0;
+}
+
 // workspace sizing over all layers (max batch)
 static int alloc_workspaces(Net& n, bool need_bwd) {
   size_t stat = 0, bwd = 0, wg = 0, fw = 0;
@@ -525,7 +556,9 @@ static int pack_layer(Net& n, ConvLayer& L, bool need_bwd) {
   // An up-split layer never reads the full images either: its forward always takes the [skip | up] pair, and the only
   // reader of wf is the direct backward-data path (input gradient WITHOUT parameter gradients), which no engine runs on
   // these layers today -- it re-packs on demand (wf_stale).  c13 / c15 / c17: 111 MB per step not written.
-  const bool wino_f = L.ww != nullptr, wino_b = L.wwb != nullptr;
+  const bool wino_f = L.ww != nullptr || L.wg != nullptr, wino_b = L.wwb != nullptr || L.wgb != nullptr;
+  if (L.wg) ICS_TRY(launch_pack_wino(n.st, n.tp(L.t_w), L.Cin, L.Cout, 0, L.Cin, 0, L.wg, 2));
+  if (need_bwd && L.wgb) ICS_TRY(launch_pack_wino(n.st, n.tp(L.t_w), L.Cin, L.Cout, 0, L.Cin, 1, L.wgb, 2));
   if (!wino_f && !L.split_up)
     ICS_TRY(launch_pack_fwd(n.st, n.tp(L.t_w), L.taps * L.CinG, L.Cout, L.wp, L.Kpad, L.Npad, 0, 0, 1,
                             L.CinG != L.Cin ? L.Cin : 0, L.CinG != L.Cin ? L.CinG : 0));
@@ -538,9 +571,9 @@ static int pack_layer(Net& n, ConvLayer& L, bool need_bwd) {
     if (L.w_up3) ICS_TRY(launch_pack_up3(n.st, n.tp(L.t_w), L.Cin, L.Cout, L.Cs, L.Cu, L.w_up3));
     else ICS_TRY(launch_pack_par(n.st, n.tp(L.t_w), L.Cin, L.Cout, L.Cs, L.Cu, L.wp_par, 8 * L.Cu, L.Npad));
   }
-  if (wino_f)
+  if (L.ww)
     ICS_TRY(launch_pack_wino(n.st, n.tp(L.t_w), L.Cin, L.Cout, 0, L.split_up ? L.Cs : L.Cin, 0, L.ww, L.ww_layout));
-  if (need_bwd && wino_b)
+  if (need_bwd && L.wwb)
     ICS_TRY(launch_pack_wino(n.st, n.tp(L.t_w), L.Cin, L.Cout, 0, L.split_up ? L.Cs : L.Cin, 1, L.wwb, L.wwb_layout));
   if (need_bwd && L.split_up) {
     if (L.Cs && !wino_b)
@@ -614,6 +647,12 @@ static int conv_forward(Net& n, ConvLayer& L, int B, bool training, bool update_
   } else if (L.ww && conv_wino_ok(g, L.src, L.nsrc)) {
     ICS_TRY(launch_conv_fwd_wino(n.st, g, L.src[0], L.ww, bias, L.s, L.Cout, L.pre_act, stats ? n.ws_stat : nullptr,
                                  &rpb, 0, L.ww_layout));
+  } else if (L.wg && conv_winog_ok(g, L.src, L.nsrc)) {
+    // the transposed transform is only written when a backward-weight pass will read it (not in the perceptual passes)
+    const bool keep = n.want_wgrad_inputs && L.wg_w && conv_winog_wgrad_ok(g, L.src, L.nsrc);
+    ICS_TRY(launch_conv_fwd_winog(n.st, g, L.src[0], L.wg, bias, L.s, L.Cout, L.pre_act, stats ? n.ws_stat : nullptr, &rpb,
+                                  L.wg_v, L.wg_m, keep ? L.wg_vt : nullptr));
+    L.wg_vt_batch = keep ? B : 0;
   } else {
     ICS_TRY(launch_conv_fwd(n.st, g, L.src, L.nsrc, L.wp, bias, L.s, L.Cout, L.pre_act,
                             stats ? n.ws_stat : nullptr, &rpb, 0, n.fws(), n.ws_fwd_n));
@@ -803,6 +842,9 @@ static int conv_grads_from_dy(Net& n, ConvLayer& L, int B, bool need_dA, bool pa
       ICS_TRY(launch_conv_wgrad_thin_c(ws, g, L.vsrc[0], L.dy, L.Cout, n.tg(L.t_w), L.Cout, L.Cin, n.ws_wgrad,
                                        n.ws_wgrad_n, 2));
       n.prof.end(ws);
+    } else if (L.wg_w && L.wg_vt_batch == B && conv_winog_wgrad_ok(g, L.src, L.nsrc)) {
+      ICS_TRY(launch_conv_wgrad_winog(ws, g, L.wg_vt, L.dy, L.Cout, dw, L.Cout, 0, 0, L.wg_z, L.wg_du));
+      n.prof.end(ws);
     } else if (L.wino_w && !L.split_up && conv_wino_wgrad_ok(g, L.src, L.nsrc)) {
       ICS_TRY(launch_conv_wgrad_wino(ws, g, L.src[0], L.dy, L.Cout, dw, L.Cout, n.ws_wgrad, n.ws_wgrad_n, 0, 0, 0, 1));
       n.prof.end(ws);
@@ -834,6 +876,9 @@ static int conv_grads_from_dy(Net& n, ConvLayer& L, int B, bool need_dA, bool pa
     if (L.wwb && !L.split_up && conv_wino_ok(gb, &sdy, 1))
       ICS_TRY(launch_conv_fwd_wino(n.st, gb, sdy, L.wwb, nullptr, L.dA, L.CinG, ACT_NONE, nullptr, nullptr, 0,
                                    L.wwb_layout, &bs, &blocks));
+    else if (L.wgb && conv_winog_ok(gb, &sdy, 1))       // no folded BatchNorm-backward sums here: blocks stays 0
+      ICS_TRY(launch_conv_fwd_winog(n.st, gb, sdy, L.wgb, nullptr, L.dA, L.CinG, ACT_NONE, nullptr, nullptr, L.wg_v, L.wg_m,
+                                    nullptr));
     else {
       if (L.split_up && L.wf_stale) {              // see pack_layer
         ICS_TRY(launch_pack_bwd(n.st, n.tp(L.t_w), L.taps, L.Cin, L.Cout, L.wf, L.Kpad_b, L.Npad_b, L.Cout, 0, 1));
@@ -1000,6 +1045,7 @@ static int unet_build(Net& n, const ics_unet_config& cfg) {
   use_padded_input(*r.c1);
   ICS_TRY(enable_split_up(n, *r.c13)); ICS_TRY(enable_split_up(n, *r.c15)); ICS_TRY(enable_split_up(n, *r.c17));
   for (int i = 0; i < 14; ++i) ICS_TRY(enable_wino(n, *n.layers[i], true));
+  for (int i = 0; i < 14; ++i) ICS_TRY(enable_winog(n, *n.layers[i], true));
   ICS_TRY(alloc_workspaces(n, true));
   ICS_TRY(init_bn_defaults(n));
   return 0;
@@ -1221,8 +1267,10 @@ static int unet_pm_backward(Net& n, int B) {
 static int unet_train_resident_impl(Net& n, int B, float* metrics);
 static int unet_train_resident(Net& n, int B, float* metrics) {
   n.splitk = true;
+  n.want_wgrad_inputs = true;
   const int rc = unet_train_resident_impl(n, B, metrics);
   n.splitk = false;
+  n.want_wgrad_inputs = false;
   return rc;
 }
 static int unet_train_resident_impl(Net& n, int B, float* metrics) {
@@ -2226,6 +2274,13 @@ int ics_op_conv3d_forward(const float* x, const float* w, const float* bias, int
     const int layout = conv_wino_layout(g);
     ICS_TRY(launch_pack_wino(n.st, dw, Cin, Cout, 0, Cin, 0, ww, layout));
     ICS_TRY(launch_conv_fwd_wino(n.st, g, s, ww, bias ? db : nullptr, dyv, Cout, pre_act, nullptr, nullptr, 0, layout));
+  } else if (conv_winog_ok(g, &s, 1)) {  // S = 4: Winograd-domain GEMMs (ICSG3D_NO_WINOG: the direct kernels)
+    float *wg = nullptr, *sv = nullptr, *sm = nullptr;
+    size_t v, m, z;
+    conv_winog_scratch_floats(g, &v, &m, &z);
+    ICS_TRY(n.alloc(&wg, conv_winog_weight_floats(Cin, Cout))); ICS_TRY(n.alloc(&sv, v)); ICS_TRY(n.alloc(&sm, m));
+    ICS_TRY(launch_pack_wino(n.st, dw, Cin, Cout, 0, Cin, 0, wg, 2));
+    ICS_TRY(launch_conv_fwd_winog(n.st, g, s, wg, bias ? db : nullptr, dyv, Cout, pre_act, nullptr, nullptr, sv, sm, nullptr));
   } else {
     ICS_TRY(launch_conv_fwd(n.st, g, &s, 1, dwp, bias ? db : nullptr, dyv, Cout, pre_act, nullptr, nullptr));
   }
@@ -2322,7 +2377,19 @@ int ics_op_conv3d_backward(const float* x, const float* w, const float* dy, int 
   const bool wino_w = conv_wino_wgrad_ok(g, &s, 1);
   const size_t wsn = wino_w ? conv_wino_wgrad_workspace_floats(g) : conv_wgrad_workspace_floats(g, &s, 1);
   ICS_TRY(n.alloc(&ws, wsn + 16));
-  if (dwo) {
+  if (dwo && conv_winog_wgrad_ok(g, &s, 1)) {
+    float *sv = nullptr, *sm = nullptr, *svt = nullptr, *sz = nullptr, *sdu = nullptr, *wg = nullptr, *tmp = nullptr;
+    size_t v, m, z;
+    conv_winog_scratch_floats(g, &v, &m, &z);
+    ICS_TRY(n.alloc(&sv, v)); ICS_TRY(n.alloc(&sm, m)); ICS_TRY(n.alloc(&svt, (size_t)64 * B * 8 * Cin)); ICS_TRY(n.alloc(&sz, z));
+    ICS_TRY(n.alloc(&sdu, (size_t)64 * Cin * Cout)); ICS_TRY(n.alloc(&wg, conv_winog_weight_floats(Cin, Cout)));
+    ICS_TRY(n.alloc(&tmp, M * Cout));
+    // the forward pass (as the engine runs it) leaves the transposed transform of x behind; its output is not needed here
+    ICS_TRY(launch_pack_wino(n.st, dw, Cin, Cout, 0, Cin, 0, wg, 2));
+    ICS_TRY(launch_conv_fwd_winog(n.st, g, s, wg, nullptr, tmp, Cout, ACT_NONE, nullptr, nullptr, sv, sm, svt));
+    ICS_TRY(launch_conv_wgrad_winog(n.st, g, svt, ddy, Cout, dgw, Cout, 0, 0, sz, sdu));
+    ICS_HIP(hipMemcpyAsync(dwo, dgw, (size_t)taps * Cin * Cout * 4, hipMemcpyDeviceToHost, n.st));
+  } else if (dwo) {
     if (wino_w) {
       ICS_TRY(launch_conv_wgrad_wino(n.st, g, s, ddy, Cout, dgw, Cout, ws, wsn, 0, 0, 0, 0));
     } else
@@ -2339,6 +2406,13 @@ int ics_op_conv3d_backward(const float* x, const float* w, const float* dy, int 
       const int layout = conv_wino_layout(gb);
       ICS_TRY(launch_pack_wino(n.st, dw, Cin, Cout, 0, Cin, 1, wwb, layout));
       ICS_TRY(launch_conv_fwd_wino(n.st, gb, sd, wwb, nullptr, dgx, Cin, ACT_NONE, nullptr, nullptr, 0, layout));
+    } else if (conv_winog_ok(gb, &sd, 1)) {
+      float *wgb = nullptr, *sv = nullptr, *sm = nullptr;
+      size_t v, m, z;
+      conv_winog_scratch_floats(gb, &v, &m, &z);
+      ICS_TRY(n.alloc(&wgb, conv_winog_weight_floats(Cin, Cout))); ICS_TRY(n.alloc(&sv, v)); ICS_TRY(n.alloc(&sm, m));
+      ICS_TRY(launch_pack_wino(n.st, dw, Cin, Cout, 0, Cin, 1, wgb, 2));
+      ICS_TRY(launch_conv_fwd_winog(n.st, gb, sd, wgb, nullptr, dgx, Cin, ACT_NONE, nullptr, nullptr, sv, sm, nullptr));
     } else
     ICS_TRY(launch_conv_fwd(n.st, gb, &sd, 1, dwf, nullptr, dgx, Cin, ACT_NONE, nullptr, nullptr));
     ICS_HIP(hipMemcpyAsync(dxo, dgx, M * Cin * 4, hipMemcpyDeviceToHost, n.st));

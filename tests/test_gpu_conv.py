@@ -25,6 +25,9 @@ CASES = [
     (1, 64, 64, 128, 3),   # S = 64 through the dx-reuse backward-weight kernel (half-line chunks with halo rows)
     # Winograd edge cases: odd batch with every block on the border (S = 8), one block row per axis, wide Cout
     (3, 8, 32, 32, 3), (5, 8, 64, 32, 3), (1, 16, 32, 96, 3), (2, 16, 96, 64, 3), (1, 8, 256, 512, 3),
+    # S = 4 with >= 128 input channels: the Winograd-domain batched GEMMs (conv_winog.hip); backward-weight there needs
+    # B % 4 == 0 (the GEMMs' reduction length = 8 B tiles), other batches take the 27-tap kernel for that gradient
+    (4, 4, 256, 512, 3), (3, 4, 128, 192, 3), (8, 4, 128, 64, 3),
 ]
 
 
@@ -33,6 +36,13 @@ def _wino(case):
     ICSG3D_NO_WINO, in which case there is nothing to A/B)."""
     B, S, Cin, Cout, k = case
     return k == 3 and S >= 8 and Cin % 32 == 0 and Cout % 32 == 0 and not os.environ.get("ICSG3D_NO_WINO")
+
+
+def _winog(case):
+    """True when the default path of this shape is conv_winog.hip (S = 4, Cin >= 128)."""
+    B, S, Cin, Cout, k = case
+    return (k == 3 and S == 4 and Cin % 32 == 0 and Cin >= 128 and Cout % 64 == 0 and not os.environ.get("ICSG3D_NO_WINO")
+            and not os.environ.get("ICSG3D_NO_WINOG"))
 
 
 def _data(B, S, Cin, Cout, k, seed=0):
@@ -63,6 +73,10 @@ def test_conv_forward(case, relerr, monkeypatch):
             monkeypatch.setenv("ICSG3D_NO_WINO64", "1")  # keep the 32 x 32 kernel covered at the same shapes
             w32 = E.conv3d_forward(x, w, b, pre_act=0)
             assert relerr(w32, ref) <= TOL and not np.array_equal(w32, got)
+    if _winog(case):
+        monkeypatch.setenv("ICSG3D_NO_WINOG", "1")
+        direct = E.conv3d_forward(x, w, b, pre_act=0)
+        assert relerr(direct, ref) <= TOL and not np.array_equal(direct, got)
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "B%d_S%d_%dto%d_k%d" % c)
@@ -83,6 +97,13 @@ def test_conv_backward(case, relerr, monkeypatch):
             monkeypatch.setenv("ICSG3D_NO_WINO64", "1")
             dx3, _ = E.conv3d_backward(x, w, dy)
             assert relerr(dx3, dx_ref) <= TOL and not np.array_equal(dx3, dx)
+    if _winog(case):
+        monkeypatch.setenv("ICSG3D_NO_WINOG", "1")
+        dx2, dw2 = E.conv3d_backward(x, w, dy)
+        assert relerr(dx2, dx_ref) <= TOL and relerr(dw2, dw_ref) <= TOL
+        # backward-data is itself a convolution Cout -> Cin: served when THAT geometry qualifies
+        assert np.array_equal(dx2, dx) == (not (case[3] >= 128 and case[3] % 32 == 0 and case[2] % 64 == 0))
+        assert np.array_equal(dw2, dw) == (case[0] % 4 != 0)     # backward-weight: the Winograd GEMMs only when B % 4 == 0
 
 
 def test_pointwise_gemm_large_m_matches_numpy():
