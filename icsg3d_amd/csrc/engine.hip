@@ -468,7 +468,11 @@ static int alloc_workspaces(Net& n, bool need_bwd) {
     ConvLayer& L = *Lp;
     const size_t M = n.rows(L, n.maxB);
     const ConvGeom g = geom_fwd(L, n.maxB);
-    const int rpb = conv_fwd_rows_per_block(g);
+    // per-block BatchNorm partials [3][Npad][blocks]: the split-K finish pass (and conv_winog.hip) write 64-row blocks
+    // whatever the tile of the GEMM launch -- a narrow 128 x 32 tile that splits K (the VAE decoder's thin layers when
+    // ICSG3D_NO_UPSPLIT routes them through the direct kernels) needs M / 64 columns, not M / 128: sizing by the tile
+    // alone left splitk_finish_kernel writing past the end (found by tests/test_gpu_switches.py once other allocations moved)
+    const int rpb = std::min(conv_fwd_rows_per_block(g), 64);
     stat = std::max(stat, (M + rpb - 1) / rpb * 3 * (size_t)L.Npad);
     if (L.split_up) stat = std::max(stat, 8 * ((M / 8 + 63) / 64) * 3 * (size_t)L.Npad);   // parity launch: 8 x gridM blocks
     fw = std::max(fw, conv_fwd_workspace_floats(g, L.src, L.nsrc));
