@@ -961,6 +961,13 @@ int launch_gemm_zbatch(hipStream_t st, int nz, int M, int K, int N, const float*
   ICS_CHECK((size_t)M * (size_t)std::max(K, N) < ((size_t)1 << 30), "z-batched GEMM: matrix too large for 32-bit offsets");
   const ConvGeom g{M, 1, 0, K, N, 1, K, N, flags | CF_ZBATCH};
   const ConvSrc s0{A, nullptr, nullptr, K, 0, ACT_NONE, 0}, s1{};
+  // 128 x 128 tiles when they still give every CU two workgroups (ICS_ZB_BIG=0: always 64 x 64)
+#ifndef ICS_ZB_BIG
+#define ICS_ZB_BIG 1
+#endif
+  if (ICS_ZB_BIG && M % 128 == 0 && N % 128 == 0 && (long)(M / 128) * (N / 128) * nz >= 512)
+    return launch_fwd_cfg<2, 2, 2, 2, true, 0, false, false, false, false, false, true, false>(
+        st, g, s0, s1, Wp, nullptr, out, N, ACT_NONE, nullptr, nullptr, 0, nz);
   return launch_fwd_cfg<2, 2, 1, 1, true, 0, false, false, false, false, false, true, false>(
       st, g, s0, s1, Wp, nullptr, out, N, ACT_NONE, nullptr, nullptr, 0, nz);
 }
