@@ -78,8 +78,12 @@ class DataParallelMixin:
         if self._dp is not None:
             dist, rank, world, sync_bn, force = self._dp
             if world > 1:
-                # creating an engine is a collective (communicator + broadcast): a rank that grows alone -- its batch
-                # differs -- would hang the others in ncclCommInitRank.  Fail loudly instead.
+                # creating an engine is a collective (communicator + broadcast).  This check is itself a collective
+                # (all_gather_object), so it catches exactly ONE case: every rank rebuilds its engine at the same
+                # step but for DIFFERENT batch sizes -- they would otherwise average gradients of differently-shaped
+                # batches or hang later in a mismatched collective.  A rank that rebuilds ALONE still blocks (here,
+                # in the gather, instead of in ncclCommInitRank): that cannot be detected without a timeout, and the
+                # callers avoid it by construction (shard_ids: every rank sees the same batch sizes at every step).
                 sizes = [None] * world
                 dist.all_gather_object(sizes, int(engine.max_batch))
                 if len(set(sizes)) != 1:
