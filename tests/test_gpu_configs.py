@@ -135,7 +135,8 @@ def test_config0_predict_on_exactly_16_grids():
 
 # the convolution launches bench.py times at B = 32 (the split plans of the backward-weight kernels depend on B:
 # one split per sample at B = 32), against the fp64 oracle.  ~0.9 TFLOP of fp64 BLAS per direction and shape.
-BENCH_SHAPES = [(32, 32, 128, 128), (32, 16, 256, 128)]
+BENCH_SHAPES = [(32, 32, 128, 128), (32, 16, 256, 128),
+                (32, 4, 512, 512), (32, 4, 256, 512)]      # c10 / c9: the Winograd-domain batched GEMMs (conv_winog.hip)
 
 
 @pytest.mark.parametrize("case", BENCH_SHAPES, ids=lambda c: "B%d_S%d_%dto%d" % c)
