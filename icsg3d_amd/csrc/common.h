@@ -101,6 +101,7 @@ enum ConvFlags : int {
   CF_UP3_BIG_ALWAYS = 65536,   // ICSG3D_UP3_BIG_MIN_WG=1: 32-voxel conv_up3 workgroups wherever the shape allows (tests)
   CF_NO_WINOG = 262144,        // ICSG3D_NO_WINOG: S = 4 layers through the 27-tap kernels instead of the Winograd-domain
                                // batched GEMMs of conv_winog.hip (round 4)
+  CF_NO_HEAD_BNFUSE = 524288,  // ICSG3D_NO_HEAD_BNFUSE: c18's BatchNorm backward as its own pass, not in the head's backward-data
   CF_ZBATCH = 1 << 20,         // internal: conv_fwd_kernel runs gridDim.z independent GEMMs (launch_gemm_zbatch)
   CF_NO_TICKET = 131072,       // ICSG3D_NO_TICKET: finalize / split reductions as their own launches instead of in the
                                // last workgroup of the producer (round 4)

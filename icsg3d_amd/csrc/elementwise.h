@@ -79,7 +79,13 @@ struct PmSums {
 bool head_fused_ok(int ncls, int cin, size_t M, int act, int flags);     // flags: the handle's ConvFlags
 bool head_dgrad_ok(int ncls, int cin, size_t M, const BwdStat* bs, int flags);
 int launch_head_dgrad(hipStream_t st, const float* dz, const float* wsoft_k, const float* wsig_k, float* dx, int ldo, size_t M,
-                      const BwdStat* bs, int Npad, int* blocks);
+                      const BwdStat* bs, int Npad, int* blocks, const float* c1c2 = nullptr, float* db_partial = nullptr);
+// the head -> c18 BatchNorm-backward fusion (round 4; elementwise.hip, head_dgrad_kernel<true>)
+int launch_xhat_affine(hipStream_t st, const float* mean, const float* rstd, int C, float* xs);
+int launch_head_bnfuse(hipStream_t st, const float* Q, const float* dzsum, const float* wsoft, const float* wsig,
+                       const float* gamma, const float* beta, double n, int ncls, float* dwsoft, float* dwsig, float* c1c2,
+                       float* dgamma, float* dbeta);
+int launch_colsum_finalize(hipStream_t st, const float* partial, int nblk, int C, float* out);
 int launch_head_fused(hipStream_t st, const float* x, int ldx, const float* scale, const float* shift, const float* wsoft_k,
                       const float* wsig_k, const float* bsoft, const float* bsig, float* z, const unsigned char* labels,
                       size_t M, int mode, int want_grad, float wsoft, double* partial, int partial_blocks, float* metrics,

@@ -1175,15 +1175,25 @@ int launch_head_fused(hipStream_t st, const float* x, int ldx, const float* scal
 // producer's BatchNorm-backward sums (sum d, sum d * xhat per channel -- what bn_bwd_reduce would compute) are
 // accumulated per lane over the wave's voxels and reduced once at the end: [2][Npad][blocks], block index fastest.
 constexpr int kHeadDP = 100;
+// BNF (round 4): the producer's whole BatchNorm-backward APPLY in the epilogue.  d = dz W^T is linear in dz, so the two
+// batch sums the apply needs -- sum_v d and sum_v d * xhat -- follow from quantities the head already has (its bias and
+// weight gradients: head_bnfuse_kernel below) BEFORE this kernel runs; the epilogue then writes
+//   dy = relu'(s) * scale * (d - c1 - xhat * c2)          (Conv -> ReLU -> BN blocks, unet.py:276-278)
+// straight into the producer's dy, and the per-block column sums of dy (its bias gradient) where the folded sums went:
+// c18's separate BatchNorm-backward pass over 3 x 537 MB disappears.  c1c2: [2][128]; db_partial: [gridDim.x][128].
+template <bool BNF>
 __global__ __launch_bounds__(256, 2) void head_dgrad_kernel(const float* __restrict__ dz, const float* __restrict__ wsoft_k,
                                                             const float* __restrict__ wsig_k, float* __restrict__ dx,
-                                                            int ldo, int ntiles, BwdStat bs, int Npad) {
+                                                            int ldo, int ntiles, BwdStat bs, int Npad,
+                                                            const float* __restrict__ c1c2, float* __restrict__ db_partial) {
   constexpr int NC = 95, NZ = 96, CH = 128;
   __shared__ __attribute__((aligned(16))) float Wc[CH * kHeadDP];
   __shared__ __attribute__((aligned(16))) float mu_s[CH], rs_s[CH];
+  __shared__ __attribute__((aligned(16))) float sc_s[BNF ? CH : 4], k1_s[BNF ? CH : 4], k2_s[BNF ? CH : 4];
   __shared__ float fold[4][2][CH];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const bool stat = bs.partial != nullptr;
+  const bool stat = BNF || bs.partial != nullptr;
+  if (BNF && tid < CH) { sc_s[tid] = bs.scale[tid]; k1_s[tid] = c1c2[tid]; k2_s[tid] = c1c2[CH + tid]; }
   for (int i = tid; i < CH * NZ; i += 256) {
     const int ch = i / NZ, cls = i - ch * NZ;
     Wc[ch * kHeadDP + cls] = cls < NC ? wsoft_k[ch * NC + cls] : wsig_k[ch];
@@ -1230,6 +1240,25 @@ __global__ __launch_bounds__(256, 2) void head_dgrad_kernel(const float* __restr
       __builtin_amdgcn_sched_barrier(0);
     }
     float* xr = dx + row * ldo + 4 * g;
+    if (BNF) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const hv4 mu = *reinterpret_cast<const hv4*>(&mu_s[16 * c + 4 * g]);
+        const hv4 rs = *reinterpret_cast<const hv4*>(&rs_s[16 * c + 4 * g]);
+        const hv4 sc = *reinterpret_cast<const hv4*>(&sc_s[16 * c + 4 * g]);
+        const hv4 k1 = *reinterpret_cast<const hv4*>(&k1_s[16 * c + 4 * g]);
+        const hv4 k2 = *reinterpret_cast<const hv4*>(&k2_s[16 * c + 4 * g]);
+        hv4 gy;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float xh = (sv[c][r] - mu[r]) * rs[r];
+          const float ds = sc[r] * (acc[c][r] - k1[r] - xh * k2[r]);
+          gy[r] = sv[c][r] > 0.f ? ds : 0.f;           // ReLU'(s) on the stored (post-ReLU) activation, as act_grad does
+        }
+        *reinterpret_cast<hv4*>(xr + 16 * c) = gy;
+        f1[c] += gy;
+      }
+    } else {
 #pragma unroll
     for (int c = 0; c < 8; ++c) *reinterpret_cast<hv4*>(xr + 16 * c) = acc[c];
     if (stat) {
@@ -1240,6 +1269,7 @@ __global__ __launch_bounds__(256, 2) void head_dgrad_kernel(const float* __restr
         f1[c] += acc[c];
         f2[c] += acc[c] * ((sv[c] - mu) * rs);
       }
+    }
     }
   }
   if (!stat) return;
@@ -1256,8 +1286,63 @@ __global__ __launch_bounds__(256, 2) void head_dgrad_kernel(const float* __restr
   {
     const int which = tid >> 7, ch = tid & 127;
     const float v = fold[0][which][ch] + fold[1][which][ch] + fold[2][which][ch] + fold[3][which][ch];
-    bs.partial[((size_t)which * Npad + ch) * gridDim.x + blockIdx.x] = v;
+    if (BNF) { if (which == 0) db_partial[(size_t)blockIdx.x * CH + ch] = v; }
+    else bs.partial[((size_t)which * Npad + ch) * gridDim.x + blockIdx.x] = v;
   }
+}
+
+// xhat = (s - mean) * rstd as an affine of the stored activation: scale = rstd, shift = -mean * rstd
+__global__ void xhat_affine_kernel(const float* __restrict__ mean, const float* __restrict__ rstd, int C,
+                                   float* __restrict__ xs) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  xs[c] = rstd[c];
+  xs[C + c] = -mean[c] * rstd[c];
+}
+// Q[ch][cls] = sum_v xhat[v][ch] dz[v][cls] (the head's weight-gradient GEMM run on xhat instead of on gamma xhat + beta),
+// dzsum[cls] = sum_v dz[v][cls] (the head's bias gradients).  One thread per channel:
+//   head dW[ch][cls] = gamma Q + beta dzsum                           (what the GEMM on the BatchNorm output would have given)
+//   sum_v d[v][ch]        = sum_cls W[ch][cls] dzsum[cls]  -> c1 = / n, the producer's dbeta
+//   sum_v d xhat [v][ch]  = sum_cls W[ch][cls] Q[ch][cls]  -> c2 = / n, the producer's dgamma
+__global__ __launch_bounds__(128) void head_bnfuse_kernel(const float* __restrict__ Q, const float* __restrict__ dzsum,
+                                                          const float* __restrict__ wsoft, const float* __restrict__ wsig,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          double n, int ncls, float* __restrict__ dwsoft,
+                                                          float* __restrict__ dwsig, float* __restrict__ c1c2,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int ch = threadIdx.x, nz = ncls + 1;
+  const float g = gamma[ch], b = beta[ch];
+  double sd = 0.0, sq = 0.0;
+  for (int cls = 0; cls < nz; ++cls) {
+    const float q = Q[ch * nz + cls], zs = dzsum[cls];
+    const float w = cls < ncls ? wsoft[ch * ncls + cls] : wsig[ch];
+    sd += (double)w * (double)zs;
+    sq += (double)w * (double)q;
+    const float dw = fmaf(g, q, b * zs);
+    if (cls < ncls) dwsoft[ch * ncls + cls] = dw; else dwsig[ch] = dw;
+  }
+  c1c2[ch] = (float)(sd / n);
+  c1c2[128 + ch] = (float)(sq / n);
+  dgamma[ch] = (float)sq;
+  dbeta[ch] = (float)sd;
+}
+int launch_xhat_affine(hipStream_t st, const float* mean, const float* rstd, int C, float* xs) {
+  ICS_LAUNCH(xhat_affine_kernel, dim3((C + 127) / 128), dim3(128), 0, st, mean, rstd, C, xs);
+  ICS_HIP(hipGetLastError());
+  return 0;
+}
+int launch_head_bnfuse(hipStream_t st, const float* Q, const float* dzsum, const float* wsoft, const float* wsig,
+                       const float* gamma, const float* beta, double n, int ncls, float* dwsoft, float* dwsig, float* c1c2,
+                       float* dgamma, float* dbeta) {
+  ICS_LAUNCH(head_bnfuse_kernel, dim3(1), dim3(128), 0, st, Q, dzsum, wsoft, wsig, gamma, beta, n, ncls, dwsoft, dwsig, c1c2,
+             dgamma, dbeta);
+  ICS_HIP(hipGetLastError());
+  return 0;
+}
+int launch_colsum_finalize(hipStream_t st, const float* partial, int nblk, int C, float* out) {
+  ICS_LAUNCH(colsum_finalize_kernel, dim3(C), dim3(256), 0, st, partial, nblk, C, out);
+  ICS_HIP(hipGetLastError());
+  return 0;
 }
 
 bool head_dgrad_ok(int ncls, int cin, size_t M, const BwdStat* bs, int flags) {
@@ -1265,16 +1350,24 @@ bool head_dgrad_ok(int ncls, int cin, size_t M, const BwdStat* bs, int flags) {
          !(flags & CF_NO_FUSED_HEAD);
 }
 int launch_head_dgrad(hipStream_t st, const float* dz, const float* wsoft_k, const float* wsig_k, float* dx, int ldo, size_t M,
-                      const BwdStat* bs, int Npad, int* blocks) {
+                      const BwdStat* bs, int Npad, int* blocks, const float* c1c2, float* db_partial) {
   ICS_CHECK(M % 16 == 0 && ldo % 4 == 0, "head backward-data: rows must come in sixteens, float4-aligned");
   const int ntiles = (int)(M / 16);
   int nblk = (ntiles + 3) / 4;
   if (nblk > 512) nblk = 512;
   const BwdStat b = bs ? *bs : BwdStat{};
-  ICS_LAUNCH(head_dgrad_kernel, dim3(nblk), dim3(256), 0, st, dz, wsoft_k, wsig_k, dx, ldo, ntiles, b, Npad);
+  if (c1c2 != nullptr) {       // fused BatchNorm-backward apply: dx receives the producer's dy, db_partial [nblk][128]
+    ICS_CHECK(bs != nullptr && b.s && b.mean && b.rstd && b.scale && db_partial && b.ld == 128 && b.post_act == ACT_NONE,
+              "fused head backward: the producer's activations, statistics and scale are needed");
+    ICS_LAUNCH(head_dgrad_kernel<true>, dim3(nblk), dim3(256), 0, st, dz, wsoft_k, wsig_k, dx, ldo, ntiles, b, Npad, c1c2, db_partial);
+    conv_set_last_kernel_id("head_dgrad_kernel<true>");
+    if (blocks) *blocks = nblk;
+  } else {
+    ICS_LAUNCH(head_dgrad_kernel<false>, dim3(nblk), dim3(256), 0, st, dz, wsoft_k, wsig_k, dx, ldo, ntiles, b, Npad, nullptr, nullptr);
+    conv_set_last_kernel_id("head_dgrad_kernel");
+    if (blocks) *blocks = b.partial ? nblk : 0;
+  }
   ICS_HIP(hipGetLastError());
-  conv_set_last_kernel_id("head_dgrad_kernel");
-  if (blocks) *blocks = b.partial ? nblk : 0;
   return 0;
 }
 

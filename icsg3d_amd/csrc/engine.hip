@@ -225,6 +225,7 @@ struct Net {
   ConvLayer* head = nullptr;
   float* head_bias_grad = nullptr;
   float* head_dw_tmp = nullptr;       // [128][ncls+1] head weight gradient before the soft | sig split
+  float* head_xs = nullptr;           // [2][128] c18's xhat as an affine of its stored activation (head BN-fuse)
   float* tap_copy[4] = {nullptr, nullptr, nullptr, nullptr};   // perceptual taps of the pass over y_true
   const float* tap_ref[4] = {nullptr, nullptr, nullptr, nullptr};   // set per VAE step: fused tap loss/gradient
   float tap_coef[4] = {0, 0, 0, 0};
@@ -1030,6 +1031,7 @@ static int unet_build(Net& n, const ics_unet_config& cfg) {
   ICS_TRY(alloc_layer(n, *n.head, true, false));
   ICS_TRY(n.alloc(&n.head_bias_grad, (size_t)256));
   ICS_TRY(n.alloc(&n.head_dw_tmp, (size_t)128 * (n.ncls + 1)));
+  ICS_TRY(n.alloc(&n.head_xs, (size_t)256));
   UnetRefs r = unet_refs(n);
   r.c1->src[0] = src_plain(n.x_in, n.C);
   r.c2->src[0] = src_layer(*r.c1, 0);
@@ -1189,27 +1191,53 @@ static int unet_backward(Net& n, int B) {
   const int nc1 = n.ncls + 1;
   // head: dz is in H.s (written by the loss kernel)
   const ConvGeom gh = geom_fwd(H, B);
+  // Round 4: c18's BatchNorm backward inside the head's backward-data kernel (elementwise.hip head_dgrad_kernel<true>):
+  // the head's weight-gradient GEMM runs on xhat (c18's normalised activation) instead of on gamma xhat + beta, and from
+  // its result Q and the head's bias gradients a 128-thread kernel forms the head's weight gradients AND c18's
+  // (c1, c2, dgamma, dbeta); the backward-data kernel then writes c18's dy directly.  Not with SyncBN (the two sums would
+  // need their all-reduce in between) and only for the Conv -> ReLU -> BN shape the kernel hard-codes.
+  const bool bnfuse = !(n.flags & CF_NO_HEAD_BNFUSE) && n.sync() == nullptr && r.c18->has_bn && r.c18->pre_act == ACT_RELU &&
+                      r.c18->post_act == ACT_NONE && r.c18->Cout == 128 && H.nsrc == 1 && head_dgrad_ok(n.ncls, 128, M, nullptr, n.flags);
   {
     // one GEMM over the [soft | sig] columns (one pass over c18's activations), then split into the two tensors
     ConvGeom gs = gh; gs.Cout = nc1; gs.Npad = round_up(nc1, 32);
-    hipStream_t ws = side_begin(n);
+    hipStream_t ws = bnfuse ? n.st : side_begin(n);     // fused: the backward-data kernel needs this GEMM's result
+    ConvSrc hsrc = H.src[0];
+    if (bnfuse) {
+      ICS_TRY(launch_xhat_affine(n.st, r.c18->mean, r.c18->rstd, 128, n.head_xs));
+      hsrc.scale = n.head_xs; hsrc.shift = n.head_xs + 128;
+    }
     n.prof.begin(ws, "conv_wgrad:head|", 2.0 * M * 128 * nc1, 4.0 * M * (128 + nc1));
-    ICS_TRY(launch_conv_wgrad(ws, gs, H.src, 1, H.s, nc1, n.head_dw_tmp, nc1, n.ws_wgrad, n.ws_wgrad_n, 0, 0, 0, 1));
+    ICS_TRY(launch_conv_wgrad(ws, gs, &hsrc, 1, H.s, nc1, n.head_dw_tmp, nc1, n.ws_wgrad, n.ws_wgrad_n, 0, 0, 0, 1));
     n.prof.end(ws);
     n.prof.begin(ws, "wgrad_reduce_splits", 0, 0);
-    ICS_TRY(launch_conv_wgrad(ws, gs, H.src, 1, H.s, nc1, n.head_dw_tmp, nc1, n.ws_wgrad, n.ws_wgrad_n, 0, 0, 0, 2));
-    ICS_LAUNCH(split_cols_kernel, dim3((128 * nc1 + 255) / 256), dim3(256), 0, ws, n.head_dw_tmp, 128, nc1,
-                       n.ncls, n.tg(H.t_w), n.tg(H.t_gamma));
-    ICS_HIP(hipGetLastError());
+    ICS_TRY(launch_conv_wgrad(ws, gs, &hsrc, 1, H.s, nc1, n.head_dw_tmp, nc1, n.ws_wgrad, n.ws_wgrad_n, 0, 0, 0, 2));
+    if (!bnfuse) {
+      ICS_LAUNCH(split_cols_kernel, dim3((128 * nc1 + 255) / 256), dim3(256), 0, ws, n.head_dw_tmp, 128, nc1,
+                         n.ncls, n.tg(H.t_w), n.tg(H.t_gamma));
+      ICS_HIP(hipGetLastError());
+    }
     n.prof.end(ws);
     // soft/bias | sig/bias (contiguous): the loss kernel left per-block column sums of dz in ws_bwd
     ICS_LAUNCH(colsum_merge_kernel, dim3(nc1), dim3(256), 0, n.st, n.ws_bwd, n.head_nblk, nc1, n.tg(H.t_b));
     ICS_HIP(hipGetLastError());
+    if (bnfuse)
+      ICS_TRY(launch_head_bnfuse(n.st, n.head_dw_tmp, n.tg(H.t_b), n.tp(H.t_w), n.tp(H.t_gamma), n.tp(r.c18->t_gamma),
+                                 n.tp(r.c18->t_beta), (double)M, n.ncls, n.tg(H.t_w), n.tg(H.t_gamma), r.c18->c1c2,
+                                 n.tg(r.c18->t_gamma), n.tg(r.c18->t_beta)));
     const ConvGeom gb = geom_bwd(H, B);
     ConvSrc sdz = src_plain(H.s, nc1);
     n.prof.begin(n.st, "conv_dgrad:head|", 2.0 * M * 128 * nc1, 4.0 * M * (128 + nc1));
-    const BwdStat bs = bwd_stat_for(n, r.c18, B);
+    BwdStat bs = bwd_stat_for(n, r.c18, B);
     int blocks = 0;
+    if (bnfuse) {
+      bs.s = r.c18->s; bs.mean = r.c18->mean; bs.rstd = r.c18->rstd; bs.scale = r.c18->scale; bs.shift = r.c18->shift;
+      bs.partial = nullptr; bs.post_act = ACT_NONE; bs.ld = 128;
+      ICS_TRY(launch_head_dgrad(n.st, H.s, n.tp(H.t_w), n.tp(H.t_gamma), r.c18->dy, 128, M, &bs, gb.Npad, &blocks,
+                                r.c18->c1c2, n.ws_bwd));
+      n.prof.end(n.st);
+      ICS_TRY(launch_colsum_finalize(n.st, n.ws_bwd, blocks, 128, n.tg(r.c18->t_b)));
+    } else {
     if (head_dgrad_ok(n.ncls, 128, M, &bs, n.flags))
       ICS_TRY(launch_head_dgrad(n.st, H.s, n.tp(H.t_w), n.tp(H.t_gamma), H.dA, 128, M, &bs, gb.Npad, &blocks));
     else
@@ -1217,6 +1245,7 @@ static int unet_backward(Net& n, int B) {
                               &blocks));
     bwd_stat_done(r.c18, bs, blocks, gb.Npad);
     n.prof.end(n.st);
+    }
   }
   // last argument: the layer fed ONLY by this layer's backward-data output (BatchNorm-backward sums folded in)
   auto bw = [&](ConvLayer* L, GradSrc g0, GradSrc g1, bool need_dA, ConvLayer* next = nullptr) {
@@ -1227,7 +1256,8 @@ static int unet_backward(Net& n, int B) {
   auto g_up = [&](ConvLayer* c) { return c->split_up ? gs_direct(c->dxl, c->Cu, 0) : gs_up(c->dA, c->Cin, c->src[0].C); };
   // after each layer its gradients (and everything behind them in the flat buffer) are final: grads_ready
   ICS_TRY(grads_ready(n, layer_lo(n, H)));
-  ICS_TRY(bw(r.c18, gs_direct(H.dA, 128, 0), gs_none(), true, r.c17));
+  if (bnfuse) ICS_TRY(conv_grads_from_dy(n, *r.c18, B, true, true, r.c17));     // c18's dy is already in place
+  else ICS_TRY(bw(r.c18, gs_direct(H.dA, 128, 0), gs_none(), true, r.c17));
   ICS_TRY(bw(r.c17, gs_direct(r.c18->dA, 128, 0), gs_none(), true, r.c17->split_up ? r.c16 : nullptr));
   ICS_TRY(bw(r.c16, g_up(r.c17), gs_none(), true, r.c15));
   ICS_TRY(bw(r.c15, gs_direct(r.c16->dA, 256, 0), gs_none(), true, r.c15->split_up ? r.c14 : nullptr));
