@@ -276,8 +276,8 @@ bool conv_winog_ok(const ConvGeom& g, const ConvSrc* src, int nsrc) {
   if (g.taps != 27 || nsrc != 1 || g.S != 4) return false;
   const ConvSrc& s = src[0];
   if (s.up || s.bcast || s.C != g.Cin) return false;
-  // 64 x 64 GEMM tiles want a real K and N; below 128 input channels the 27-tap kernels are latency-bound anyway
-  return g.Cin % 32 == 0 && g.Cin >= 128 && g.Cout % 64 == 0;
+  // 64 x 64 GEMM tiles want a real K and N
+  return g.Cin % 32 == 0 && g.Cin >= 64 && g.Cout % 64 == 0;
 }
 // backward-weight additionally needs the tile count (the GEMMs' reduction length) to be a multiple of 32
 bool conv_winog_wgrad_ok(const ConvGeom& g, const ConvSrc* src, int nsrc) {

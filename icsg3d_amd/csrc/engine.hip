@@ -1424,6 +1424,7 @@ static int vae_build(Net& n, const ics_vae_config& cfg, Net* pm) {
   r.dout->src[0] = src_layer(*r.dl[3], 0);
   use_padded_input(*r.e[0]);
   for (int i = 1; i < 4; ++i) ICS_TRY(enable_split_up(n, *r.dl[i]));
+  for (auto& Lp : n.layers) ICS_TRY(enable_winog(n, *Lp, true));      // e3 at d = 32 (4^3 x 64 -> 128)
   ICS_TRY(alloc_workspaces(n, true));
   ICS_TRY(init_bn_defaults(n));
   if (pm) {
@@ -1488,6 +1489,7 @@ static int vae_step(Net& n, int B, bool training, float* metrics) {
   hipStream_t saved = u.st;
   u.st = n.st;
   n.splitk = u.splitk = training;
+  n.want_wgrad_inputs = training;      // the VAE's own layers get parameter gradients; the perceptual U-Net's do not
   // SyncBN covers the perceptual U-Net's batch-statistics BatchNorm too (it borrows the VAE's communicator)
   ncclComm_t saved_comm = u.comm;
   const int saved_sync = u.sync_bn;
@@ -1606,6 +1608,7 @@ static int vae_step(Net& n, int B, bool training, float* metrics) {
   u.st = saved;
   u.comm = saved_comm; u.sync_bn = saved_sync; u.bn_sync = saved_bs;
   n.splitk = u.splitk = false;
+  n.want_wgrad_inputs = false;
   return rc;
 }
 

@@ -25,9 +25,9 @@ CASES = [
     (1, 64, 64, 128, 3),   # S = 64 through the dx-reuse backward-weight kernel (half-line chunks with halo rows)
     # Winograd edge cases: odd batch with every block on the border (S = 8), one block row per axis, wide Cout
     (3, 8, 32, 32, 3), (5, 8, 64, 32, 3), (1, 16, 32, 96, 3), (2, 16, 96, 64, 3), (1, 8, 256, 512, 3),
-    # S = 4 with >= 128 input channels: the Winograd-domain batched GEMMs (conv_winog.hip); backward-weight there needs
+    # S = 4 with >= 64 input channels: the Winograd-domain batched GEMMs (conv_winog.hip); backward-weight there needs
     # B % 4 == 0 (the GEMMs' reduction length = 8 B tiles), other batches take the 27-tap kernel for that gradient
-    (4, 4, 256, 512, 3), (3, 4, 128, 192, 3), (8, 4, 128, 64, 3),
+    (4, 4, 256, 512, 3), (3, 4, 128, 192, 3), (8, 4, 128, 64, 3), (4, 4, 64, 128, 3),
 ]
 
 
@@ -39,9 +39,9 @@ def _wino(case):
 
 
 def _winog(case):
-    """True when the default path of this shape is conv_winog.hip (S = 4, Cin >= 128)."""
+    """True when the default path of this shape is conv_winog.hip (S = 4, Cin >= 64)."""
     B, S, Cin, Cout, k = case
-    return (k == 3 and S == 4 and Cin % 32 == 0 and Cin >= 128 and Cout % 64 == 0 and not os.environ.get("ICSG3D_NO_WINO")
+    return (k == 3 and S == 4 and Cin % 32 == 0 and Cin >= 64 and Cout % 64 == 0 and not os.environ.get("ICSG3D_NO_WINO")
             and not os.environ.get("ICSG3D_NO_WINOG"))
 
 
@@ -102,7 +102,7 @@ def test_conv_backward(case, relerr, monkeypatch):
         dx2, dw2 = E.conv3d_backward(x, w, dy)
         assert relerr(dx2, dx_ref) <= TOL and relerr(dw2, dw_ref) <= TOL
         # backward-data is itself a convolution Cout -> Cin: served when THAT geometry qualifies
-        assert np.array_equal(dx2, dx) == (not (case[3] >= 128 and case[3] % 32 == 0 and case[2] % 64 == 0))
+        assert np.array_equal(dx2, dx) == (not (case[3] >= 64 and case[3] % 32 == 0 and case[2] % 64 == 0))
         assert np.array_equal(dw2, dw) == (case[0] % 4 != 0)     # backward-weight: the Winograd GEMMs only when B % 4 == 0
 
 
