@@ -244,11 +244,33 @@ def wcce_loss(y_onehot, p, weights):
     return loss.mean(axis=(1, 2, 3))
 
 
-def wcce_bwd(y_onehot, p, weights, dloss):
-    """d(sum_b dloss[b]*loss[b])/dp through the renormalisation and the clip (zero grad when clipped)."""
+def _pinned_inside(inside, v, pin, tol, what):
+    """K.clip's zero-gradient region is a kink like ReLU'(0): `pin` (the decisions of the implementation under test)
+    replaces `inside` -- but only where the clipped quantity is within `tol` (relative to the bound's distance from the
+    nearer end of [0, 1]) of a bound; a decision that differs anywhere else is an error.  Returns (inside, flips)."""
+    pin = np.asarray(pin, bool).reshape(inside.shape)
+    diff = pin != inside.astype(bool)
+    near = (np.abs(v - K_EPSILON) <= tol * K_EPSILON) | (np.abs((1 - v) - K_EPSILON) <= tol * K_EPSILON)
+    if np.any(diff & ~near):
+        raise AssertionError("%s: %d clip decisions differ away from the bounds" % (what, int(np.sum(diff & ~near))))
+    return pin.astype(inside.dtype), int(diff.sum())
+
+
+def wcce_bwd(y_onehot, p, weights, dloss, pin=None, pin_tol=0.5, flips=None):
+    """d(sum_b dloss[b]*loss[b])/dp through the renormalisation and the clip (zero grad when clipped).
+    pin: optional per-voxel decisions "the true class's probability is inside the clip range" of the implementation
+    under test (see _pinned_inside)."""
     S = p.sum(-1, keepdims=True)
     q = p / S
     inside = ((q >= K_EPSILON) & (q <= 1 - K_EPSILON)).astype(p.dtype)
+    if pin is not None:
+        # only the true class's entry carries a gradient: pin that one
+        qt = (q * y_onehot).sum(-1, keepdims=True)
+        it = ((qt >= K_EPSILON) & (qt <= 1 - K_EPSILON)).astype(p.dtype)
+        it, nf = _pinned_inside(it, qt, pin, pin_tol, "softmax clip")
+        inside = np.where(y_onehot > 0, it, inside)
+        if flips is not None:
+            flips["soft_clip"] = nf
     nvox = np.prod(p.shape[1:4])
     dq = -(y_onehot * weights) / np.clip(q, K_EPSILON, 1 - K_EPSILON) * inside
     dq = dq * (dloss.reshape(-1, 1, 1, 1, 1) / nvox)
@@ -266,10 +288,14 @@ def bce_loss(t, p):
     return (-(t * np.log(pc) + (1 - t) * np.log(1 - pc))).mean(-1)
 
 
-def bce_bwd(t, p, dl):
-    """dl has the shape of bce_loss's output."""
+def bce_bwd(t, p, dl, pin=None, pin_tol=0.5, flips=None):
+    """dl has the shape of bce_loss's output.  pin: optional clip decisions of the implementation under test."""
     pc = np.clip(p, K_EPSILON, 1 - K_EPSILON)
     inside = ((p >= K_EPSILON) & (p <= 1 - K_EPSILON)).astype(p.dtype)
+    if pin is not None:
+        inside, nf = _pinned_inside(inside, p, pin, pin_tol, "sigmoid clip")
+        if flips is not None:
+            flips["sig_clip"] = nf
     return (-(t / pc) + (1 - t) / (1 - pc)) * inside * dl[..., None] / p.shape[-1]
 
 
@@ -530,18 +556,26 @@ class UnetOracle:
         lsig = bce_loss(t, sig).mean()
         return np.array([lsoft + lsig, lsoft, lsig, f1_m(y, soft), wr_m(y, soft)])
 
-    def backward(self, labels, cache):
-        """Gradients of Loss = mean_b(wcce) + mean(bce) w.r.t. every trainable parameter."""
+    def backward(self, labels, cache, clip_pin=None):
+        """Gradients of Loss = mean_b(wcce) + mean(bce) w.r.t. every trainable parameter.
+        clip_pin: optional {"soft": bool (B,D,H,W), "sig": bool (B,D,H,W)} K.clip decisions of the implementation under
+        test (the clip's zero-gradient region is a kink, like ReLU'(0))."""
         P, S, b = self.P, self.S, self.blocks
+        clip_pin = clip_pin or {}
+        self.clip_flips = {}
         h = cache["_head"]
         soft, sig, c18 = h["soft"], h["sig"], h["c18"]
         B = soft.shape[0]
         y = one_hot(labels, self.num_classes)
         t = (labels != 0).astype(self.dtype)[..., None]
         g = {}
-        dsoft = wcce_bwd(y, soft, self.loss_weight, np.full(B, 1.0 / B))
+        pin_soft = clip_pin.get("soft")
+        dsoft = wcce_bwd(y, soft, self.loss_weight, np.full(B, 1.0 / B),
+                         pin=None if pin_soft is None else np.asarray(pin_soft)[..., None], flips=self.clip_flips)
         dzs = softmax_bwd(soft, dsoft)
-        dsig = bce_bwd(t, sig, np.full(sig.shape[:-1], 1.0 / sig[..., 0].size))
+        pin_sig = clip_pin.get("sig")
+        dsig = bce_bwd(t, sig, np.full(sig.shape[:-1], 1.0 / sig[..., 0].size),
+                       pin=None if pin_sig is None else np.asarray(pin_sig)[..., None], flips=self.clip_flips)
         dzg = dsig * sig * (1 - sig)
         d1, g["soft/kernel"], g["soft/bias"] = conv3d_bwd(c18, P["soft/kernel"], dzs)
         d2, g["sig/kernel"], g["sig/bias"] = conv3d_bwd(c18, P["sig/kernel"], dzg)
@@ -572,14 +606,15 @@ class UnetOracle:
             self.P[k], self.m[k], self.v[k] = adam_update(
                 self.P[k], grads[k], self.m[k], self.v[k], self.t, self.lr)
 
-    def train_on_batch(self, x, labels, kink=None, kink_tol=1e-4, affine=None):
+    def train_on_batch(self, x, labels, kink=None, kink_tol=1e-4, affine=None, clip_pin=None):
         """One Keras train_on_batch: returns [Loss, lsoft, lsig, f1, wr] (pre-update forward).
-        kink: optional {layer: stored activations of the implementation under test} (apply_kink)."""
+        kink: optional {layer: stored activations of the implementation under test} (apply_kink);
+        clip_pin: optional K.clip decisions of the losses (backward)."""
         cache = {}
         soft, sig = self.forward(x, training=True, cache=cache)
         metrics = self.loss_and_metrics(soft, sig, labels)
         self.kink_flips = apply_kink(self.blocks.values(), cache, self.P, kink, kink_tol, affine) if kink else {}
-        grads = self.backward(labels, cache)
+        grads = self.backward(labels, cache, clip_pin=clip_pin)
         for blk in self.blocks.values():
             blk.moving_update(self.S, cache, self.bn_unbias)
         self.apply_adam(grads)
