@@ -102,6 +102,7 @@ enum ConvFlags : int {
   CF_NO_WINOG = 262144,        // ICSG3D_NO_WINOG: S = 4 layers through the 27-tap kernels instead of the Winograd-domain
                                // batched GEMMs of conv_winog.hip (round 4)
   CF_NO_HEAD_BNFUSE = 524288,  // ICSG3D_NO_HEAD_BNFUSE: c18's BatchNorm backward as its own pass, not in the head's backward-data
+  CF_NO_UP3N = 1 << 21,        // ICSG3D_NO_UP3N: the VAE decoder's narrow upsampled layers through the 8-tap parity GEMMs
   CF_ZBATCH = 1 << 20,         // internal: conv_fwd_kernel runs gridDim.z independent GEMMs (launch_gemm_zbatch)
   CF_NO_TICKET = 131072,       // ICSG3D_NO_TICKET: finalize / split reductions as their own launches instead of in the
                                // last workgroup of the producer (round 4)
@@ -243,6 +244,13 @@ int launch_conv_wgrad_winog(hipStream_t st, const ConvGeom& g, const float* vt, 
                             int row_pitch, int row_off, float* z_scratch, float* m_scratch);
 // nz independent plain GEMMs out_z[M][N] = A_z[M][K] x W_z[K][N] (conv_igemm.hip; W_z packed [K/4][N][4])
 int launch_gemm_zbatch(hipStream_t st, int nz, int M, int K, int N, const float* A, const float* Wp, float* out, int flags);
+// the same 27-product form for NARROW outputs (Cout 16 / 32: the VAE decoder's d2 / d3), conv_up3n.hip; *stat_blocks = blocks
+// of 512 fine voxels written to stat_partial
+bool conv_up3n_ok(const ConvGeom& g, const ConvSrc& s0);
+size_t conv_up3n_weight_floats(int Cu, int Cout);
+int launch_pack_up3n(hipStream_t st, const float* w, int Cin_total, int Cout, int c_off, int Cu, float* dst);
+int launch_conv_fwd_up3n(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, const float* wt, const float* bias, float* out,
+                         int ldo, int pre_act, float* stat_partial, int* stat_blocks);
 // fixed-order reduction of split-K weight-gradient partials ws[split][k][n] into dw (conv_igemm.hip)
 int launch_wgrad_reduce_splits(hipStream_t st, const float* ws, int nsplit, size_t n_elems, int N, float* dw, int ldw,
                                int sub_rows, int row_pitch, int row_off);

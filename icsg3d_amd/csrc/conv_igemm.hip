@@ -72,6 +72,7 @@ int conv_flags_from_env() {
   if (getenv("ICSG3D_NO_TICKET")) f |= CF_NO_TICKET;
   if (getenv("ICSG3D_NO_WINOG")) f |= CF_NO_WINOG;
   if (getenv("ICSG3D_NO_HEAD_BNFUSE")) f |= CF_NO_HEAD_BNFUSE;
+  if (getenv("ICSG3D_NO_UP3N")) f |= CF_NO_UP3N;
   { const char* e = getenv("ICSG3D_UP3_BIG_MIN_WG"); if (e && *e && strtoul(e, nullptr, 10) <= 1) f |= CF_UP3_BIG_ALWAYS; }
   return f;
 }
@@ -1927,7 +1928,7 @@ int launch_conv_fwd_par(hipStream_t st, const ConvGeom& g, const ConvSrc& src, c
 // whatever their size.  The engine records the jobs once (the launch_pack_* calls below append to g_pack_rec
 // instead of launching) and replays them with ONE pack_table_kernel launch per step.
 struct PackJob {
-  int kind;                 // 0 fwd, 1 bwd, 2 sub, 3 fwd_sub, 4 par, 5 wino, 6 up3
+  int kind;                 // 0 fwd, 1 bwd, 2 sub, 3 fwd_sub, 4 par, 5 wino, 6 up3, 7 up3n
   const float* w;
   float* dst;
   int a[9];
@@ -3349,6 +3350,42 @@ __global__ void pack_up3_kernel(const float* __restrict__ w, int Cin_total, int 
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t < pairs) pack_up3_pair(t, w, Cin_total, Cout, c_off, Cu, dst);
 }
+// weights: dst[f][Cu/4][4 k][Cout] = (g (x) g (x) g) applied to w[tap][c_off + k][n]; one thread per (k, n) pair
+__device__ __forceinline__ void pack_up3n_pair_dev(size_t t, const float* __restrict__ w, int Cin_total, int Cout, int c_off,
+                                                   int Cu, float* __restrict__ dst) {
+  const int n = (int)(t % (size_t)Cout), k = (int)(t / (size_t)Cout);
+  float g[3][3][3];
+#pragma unroll
+  for (int tap = 0; tap < 27; ++tap) g[tap / 9][(tap / 3) % 3][tap % 3] = w[((size_t)tap * Cin_total + c_off + k) * Cout + n];
+  // g rows: (w[-1], w[-1] + w[0] + w[+1], w[+1]) along x, y, z
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) g[i][j][1] += g[i][j][0] + g[i][j][2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) g[i][1][kx] += g[i][0][kx] + g[i][2][kx];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) g[1][j][kx] += g[0][j][kx] + g[2][j][kx];
+  const size_t fs = (size_t)Cu * Cout;
+#pragma unroll
+  for (int f = 0; f < 27; ++f) dst[(size_t)f * fs + (size_t)k * Cout + n] = g[f / 9][(f / 3) % 3][f % 3];
+}
+__global__ void pack_up3n_kernel(const float* __restrict__ w, int Cin_total, int Cout, int c_off, int Cu,
+                                 float* __restrict__ dst, size_t pairs) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < pairs) pack_up3n_pair_dev(t, w, Cin_total, Cout, c_off, Cu, dst);
+}
+int launch_pack_up3n(hipStream_t st, const float* w, int Cin_total, int Cout, int c_off, int Cu, float* dst) {
+  const size_t pairs = (size_t)Cu * Cout;
+  if (g_pack_rec) { g_pack_rec->push_back(PackJob{7, w, dst, {Cin_total, Cout, c_off, Cu, 0, 0, 0, 0, 0}, (unsigned long long)pairs, 0}); return 0; }
+  ICS_LAUNCH(pack_up3n_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, st, w, Cin_total, Cout, c_off, Cu, dst, pairs);
+  ICS_HIP(hipGetLastError());
+  return 0;
+}
 size_t conv_up3_weight_floats(int Cu, int Cout) { return (size_t)27 * Cu * Cout; }
 int launch_pack_up3(hipStream_t st, const float* w, int Cin_total, int Cout, int c_off, int Cu, float* dst) {
   const size_t pairs = (size_t)Cu * Cout;
@@ -3393,6 +3430,7 @@ __global__ __launch_bounds__(256) void pack_table_kernel(const PackJob* __restri
     case 3: J.dst[i] = pack_fwd_sub_value(i, J.w, a[0], a[1], a[2], a[3], a[4], a[5]); break;
     case 5: pack_wino_pair(i, J.w, a[0], a[1], a[2], a[3], a[4], J.dst, a[5]); break;
     case 6: pack_up3_pair(i, J.w, a[0], a[1], a[2], a[3], J.dst); break;
+    case 7: pack_up3n_pair_dev(i, J.w, a[0], a[1], a[2], a[3], J.dst); break;
     default: J.dst[i] = pack_par_value(i, J.w, a[0], a[1], a[2], a[3], a[4], a[5]); break;
   }
 }

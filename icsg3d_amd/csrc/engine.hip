@@ -146,6 +146,7 @@ struct ConvLayer {
   float *wf_skip = nullptr, *w_up = nullptr;   // packed: dgrad of the skip channels; dxl = dyS x W_up
   float *wp_skip = nullptr, *wp_par = nullptr; // packed forward: skip channels (27 taps); 8 parity classes x 8 taps
   float* w_up3 = nullptr;                      // upsampled channels, 27-product form (conv_up3.hip): replaces wp_par
+  float* w_up3n = nullptr;                     // the same for narrow outputs (conv_up3n.hip; layers without skip channels)
   float *dyS = nullptr;                        // [M/8][ldS] tap-pooled dy, ldS = 27*Cout rounded up to 32 (pad = 0)
   int ldS = 0;
   float *dA_skip = nullptr, *dxl = nullptr;    // [M][Cs] grad of the skip input; [M/8][Cu] grad of the low-res input
@@ -403,6 +404,8 @@ static int enable_split_up(Net& n, ConvLayer& L) {
   ICS_TRY(n.alloc(&L.dw_up, (size_t)L.Cu * 27 * L.Cout));
   if (conv_up3_ok(geom_par_fwd(L, n.maxB), src_lowres(L)))
     ICS_TRY(n.alloc(&L.w_up3, conv_up3_weight_floats(L.Cu, L.Cout)));
+  else if (L.Cs == 0 && conv_up3n_ok(geom_par_fwd(L, n.maxB), src_lowres(L)))
+    ICS_TRY(n.alloc(&L.w_up3n, conv_up3n_weight_floats(L.Cu, L.Cout)));
   else
     ICS_TRY(n.alloc(&L.wp_par, (size_t)8 * 8 * L.Cu * L.Npad));
   if (L.Cs) {
@@ -574,6 +577,7 @@ static int pack_layer(Net& n, ConvLayer& L, bool need_bwd) {
       ICS_TRY(launch_pack_fwd_sub(n.st, n.tp(L.t_w), L.taps, L.Cin, L.Cout, 0, L.Cs, L.wp_skip,
                                   round_up(L.taps * L.Cs, 32), L.Npad));
     if (L.w_up3) ICS_TRY(launch_pack_up3(n.st, n.tp(L.t_w), L.Cin, L.Cout, L.Cs, L.Cu, L.w_up3));
+    else if (L.w_up3n) ICS_TRY(launch_pack_up3n(n.st, n.tp(L.t_w), L.Cin, L.Cout, L.Cs, L.Cu, L.w_up3n));
     else ICS_TRY(launch_pack_par(n.st, n.tp(L.t_w), L.Cin, L.Cout, L.Cs, L.Cu, L.wp_par, 8 * L.Cu, L.Npad));
   }
   if (L.ww)
@@ -613,9 +617,13 @@ static int conv_forward(Net& n, ConvLayer& L, int B, bool training, bool update_
     const ConvSrc lo = src_lowres(L);
     const bool only_up = L.Cs == 0;   // no skip part: the parity launch carries bias, activation and statistics
     // profile rows carry the MFMA work executed: 27 products per low-res voxel (conv_up3.hip) or 64 (8 parity GEMMs)
-    n.prof.begin(n.st, "conv_fwd:" + L.name + ".up|", 2.0 * M / 8 * (L.w_up3 ? 27 : 64) * L.Cu * L.Cout,
-                 4.0 * (M / 8 * L.Cu + M * L.Cout + (L.w_up3 ? 27.0 : 64.0) * L.Cu * L.Cout));
-    if (L.w_up3)
+    const bool p27 = L.w_up3 != nullptr || L.w_up3n != nullptr;
+    n.prof.begin(n.st, "conv_fwd:" + L.name + ".up|", 2.0 * M / 8 * (p27 ? 27 : 64) * L.Cu * L.Cout,
+                 4.0 * (M / 8 * L.Cu + M * L.Cout + (p27 ? 27.0 : 64.0) * L.Cu * L.Cout));
+    if (L.w_up3n)
+      ICS_TRY(launch_conv_fwd_up3n(n.st, gp, lo, L.w_up3n, bias, L.s, L.Cout, L.pre_act, stats ? n.ws_stat : nullptr,
+                                   &par_blocks));
+    else if (L.w_up3)
       ICS_TRY(launch_conv_fwd_up3(n.st, gp, lo, L.w_up3, only_up ? bias : nullptr, L.s, L.Cout,
                                   only_up ? L.pre_act : ACT_NONE, (only_up && stats) ? n.ws_stat : nullptr, &par_blocks, 0));
     else
