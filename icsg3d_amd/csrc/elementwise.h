@@ -84,7 +84,7 @@ int launch_head_dgrad(hipStream_t st, const float* dz, const float* wsoft_k, con
 int launch_xhat_affine(hipStream_t st, const float* mean, const float* rstd, int C, float* xs);
 int launch_head_bnfuse(hipStream_t st, const float* Q, const float* dzsum, const float* wsoft, const float* wsig,
                        const float* gamma, const float* beta, double n, int ncls, float* dwsoft, float* dwsig, float* c1c2,
-                       float* dgamma, float* dbeta);
+                       float* dgamma, float* dbeta, const BnSync* sync = nullptr);
 int launch_colsum_finalize(hipStream_t st, const float* partial, int nblk, int C, float* out);
 int launch_head_fused(hipStream_t st, const float* x, int ldx, const float* scale, const float* shift, const float* wsoft_k,
                       const float* wsig_k, const float* bsoft, const float* bsig, float* z, const unsigned char* labels,

@@ -1309,7 +1309,8 @@ __global__ __launch_bounds__(128) void head_bnfuse_kernel(const float* __restric
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           double n, int ncls, float* __restrict__ dwsoft,
                                                           float* __restrict__ dwsig, float* __restrict__ c1c2,
-                                                          float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                          double* __restrict__ sums) {
   const int ch = threadIdx.x, nz = ncls + 1;
   const float g = gamma[ch], b = beta[ch];
   double sd = 0.0, sq = 0.0;
@@ -1321,8 +1322,8 @@ __global__ __launch_bounds__(128) void head_bnfuse_kernel(const float* __restric
     const float dw = fmaf(g, q, b * zs);
     if (cls < ncls) dwsoft[ch * ncls + cls] = dw; else dwsig[ch] = dw;
   }
-  c1c2[ch] = (float)(sd / n);
-  c1c2[128 + ch] = (float)(sq / n);
+  if (sums) { sums[ch] = sd; sums[128 + ch] = sq; }       // SyncBN: all-reduced, then bn_bwd_sync_c_kernel forms c1 / c2
+  else { c1c2[ch] = (float)(sd / n); c1c2[128 + ch] = (float)(sq / n); }
   dgamma[ch] = (float)sq;
   dbeta[ch] = (float)sd;
 }
@@ -1333,10 +1334,16 @@ int launch_xhat_affine(hipStream_t st, const float* mean, const float* rstd, int
 }
 int launch_head_bnfuse(hipStream_t st, const float* Q, const float* dzsum, const float* wsoft, const float* wsig,
                        const float* gamma, const float* beta, double n, int ncls, float* dwsoft, float* dwsig, float* c1c2,
-                       float* dgamma, float* dbeta) {
+                       float* dgamma, float* dbeta, const BnSync* sync) {
   ICS_LAUNCH(head_bnfuse_kernel, dim3(1), dim3(128), 0, st, Q, dzsum, wsoft, wsig, gamma, beta, n, ncls, dwsoft, dwsig, c1c2,
-             dgamma, dbeta);
+             dgamma, dbeta, sync ? sync->local : nullptr);
   ICS_HIP(hipGetLastError());
+  if (sync) {   // global-batch statistics: the two sums over ALL ranks' voxels (every rank holds the same number of rows)
+    ncclResult_t r = ncclAllReduce(sync->local, sync->local, (size_t)256, ncclDouble, ncclSum, sync->comm, st);
+    ICS_CHECK(r == ncclSuccess, std::string("ncclAllReduce(SyncBN head fuse): ") + ncclGetErrorString(r));
+    ICS_LAUNCH(bn_bwd_sync_c_kernel, dim3(2), dim3(64), 0, st, sync->local, 128, n * (double)sync->nranks, c1c2, c1c2 + 128);
+    ICS_HIP(hipGetLastError());
+  }
   return 0;
 }
 int launch_colsum_finalize(hipStream_t st, const float* partial, int nblk, int C, float* out) {

@@ -1202,9 +1202,9 @@ static int unet_backward(Net& n, int B) {
   // Round 4: c18's BatchNorm backward inside the head's backward-data kernel (elementwise.hip head_dgrad_kernel<true>):
   // the head's weight-gradient GEMM runs on xhat (c18's normalised activation) instead of on gamma xhat + beta, and from
   // its result Q and the head's bias gradients a 128-thread kernel forms the head's weight gradients AND c18's
-  // (c1, c2, dgamma, dbeta); the backward-data kernel then writes c18's dy directly.  Not with SyncBN (the two sums would
-  // need their all-reduce in between) and only for the Conv -> ReLU -> BN shape the kernel hard-codes.
-  const bool bnfuse = !(n.flags & CF_NO_HEAD_BNFUSE) && n.sync() == nullptr && r.c18->has_bn && r.c18->pre_act == ACT_RELU &&
+  // (c1, c2, dgamma, dbeta); the backward-data kernel then writes c18's dy directly.  With SyncBN the two sums are
+  // all-reduced in between (256 doubles).  Only for the Conv -> ReLU -> BN shape the kernel hard-codes.
+  const bool bnfuse = !(n.flags & CF_NO_HEAD_BNFUSE) && r.c18->has_bn && r.c18->pre_act == ACT_RELU &&
                       r.c18->post_act == ACT_NONE && r.c18->Cout == 128 && H.nsrc == 1 && head_dgrad_ok(n.ncls, 128, M, nullptr, n.flags);
   {
     // one GEMM over the [soft | sig] columns (one pass over c18's activations), then split into the two tensors
@@ -1232,7 +1232,7 @@ static int unet_backward(Net& n, int B) {
     if (bnfuse)
       ICS_TRY(launch_head_bnfuse(n.st, n.head_dw_tmp, n.tg(H.t_b), n.tp(H.t_w), n.tp(H.t_gamma), n.tp(r.c18->t_gamma),
                                  n.tp(r.c18->t_beta), (double)M, n.ncls, n.tg(H.t_w), n.tg(H.t_gamma), r.c18->c1c2,
-                                 n.tg(r.c18->t_gamma), n.tg(r.c18->t_beta)));
+                                 n.tg(r.c18->t_gamma), n.tg(r.c18->t_beta), n.sync()));
     const ConvGeom gb = geom_bwd(H, B);
     ConvSrc sdz = src_plain(H.s, nc1);
     n.prof.begin(n.st, "conv_dgrad:head|", 2.0 * M * 128 * nc1, 4.0 * M * (128 + nc1));

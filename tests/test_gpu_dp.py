@@ -28,11 +28,7 @@ def _unet_pair(B=2, d=16):
 
 
 @pytest.mark.parametrize("sync_bn", [False, True])
-def test_single_rank_communicator_is_bit_identical(sync_bn, monkeypatch):
-    if sync_bn:
-        # SyncBN keeps c18's BatchNorm backward as its own pass (its two sums need their all-reduce); compare it with a
-        # plain engine that does the same, so that the only difference left is the statistics exchange
-        monkeypatch.setenv("ICSG3D_NO_HEAD_BNFUSE", "1")
+def test_single_rank_communicator_is_bit_identical(sync_bn):
     a, b, X, lab, _ = _unet_pair()
     b.set_sync_bn(sync_bn)
     assert b.comm_info()["nranks"] == 1 and a.comm_info()["nranks"] == 0
