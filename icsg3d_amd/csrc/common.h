@@ -104,8 +104,8 @@ enum ConvFlags : int {
   CF_NO_HEAD_BNFUSE = 524288,  // ICSG3D_NO_HEAD_BNFUSE: c18's BatchNorm backward as its own pass, not in the head's backward-data
   CF_NO_UP3N = 1 << 21,        // ICSG3D_NO_UP3N: the VAE decoder's narrow upsampled layers through the 8-tap parity GEMMs
   CF_ZBATCH = 1 << 20,         // internal: conv_fwd_kernel runs gridDim.z independent GEMMs (launch_gemm_zbatch)
-  CF_NO_TICKET = 131072,       // ICSG3D_NO_TICKET: finalize / split reductions as their own launches instead of in the
-                               // last workgroup of the producer (round 4)
+  CF_NO_TICKET = 131072,       // ICSG3D_NO_TICKET: one bias-gradient finalize launch per layer instead of one batched launch per
+                               // step / gradient bucket (round 4)
 };
 int conv_flags_from_env();
 

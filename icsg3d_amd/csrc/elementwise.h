@@ -66,7 +66,15 @@ struct BwdPre {
 };
 int launch_layer_bwd(hipStream_t st, const LayerBwd& L, float* dy, float* ws_partial, float* c1c2,
                      float* dgamma, float* dbeta, float* dbias, const BnSync* sync = nullptr,
-                     const BwdPre* pre = nullptr);
+                     const BwdPre* pre = nullptr, float* db_partial_own = nullptr, int* db_blocks = nullptr);
+// deferred bias-gradient finalizes (out[c] = sum over nblk partial rows [nblk][C]), up to 24 per launch
+struct ColsumJobs {
+  const float* partial[24];
+  float* out[24];
+  int nblk[24], C[24], blk0[25];
+  int n;
+};
+int launch_colsum_batch(hipStream_t st, const ColsumJobs& J);
 size_t layer_bwd_workspace_floats(const LayerBwd& L);
 int bn_bwd_num_blocks(const LayerBwd& L, int* rows_per_block);
 // perceptual-loss partial sums handed to vae_loss: n[l] partials for tap l, each tap's per-sample element count

@@ -734,9 +734,11 @@ int bn_bwd_num_blocks(const LayerBwd& L, int* rows_per_block) {
 }
 
 int launch_layer_bwd(hipStream_t st, const LayerBwd& L, float* dy, float* ws_partial, float* c1c2,
-                     float* dgamma, float* dbeta, float* dbias, const BnSync* sync, const BwdPre* pre) {
+                     float* dgamma, float* dbeta, float* dbias, const BnSync* sync, const BwdPre* pre,
+                     float* db_partial_own, int* db_blocks) {
   int rpb;
   const int nblk = bn_bwd_num_blocks(L, &rpb);
+  if (db_blocks) *db_blocks = nblk;
   const double n = (double)((size_t)L.B << (3 * L.lgS));
   float* c1 = c1c2;
   float* c2 = c1c2 + L.C;
@@ -777,7 +779,9 @@ int launch_layer_bwd(hipStream_t st, const LayerBwd& L, float* dy, float* ws_par
       ICS_HIP(hipGetLastError());
     }
   }
-  float* dbp = dbias ? ws_partial : nullptr;
+  // db_partial_own: the bias-gradient partials go to the layer's own buffer and the caller finalizes them later, together
+  // with every other layer's (launch_colsum_batch): one launch per step instead of one per layer
+  float* dbp = dbias ? (db_partial_own ? db_partial_own : ws_partial) : nullptr;
   if (fast) {
     // M = B * S^3 with S >= 4 a power of two and RPP <= 64 rows per pass: whole passes
 #define ICS_BNF(G0_, G1_, T_, U_) \
@@ -800,10 +804,28 @@ int launch_layer_bwd(hipStream_t st, const LayerBwd& L, float* dy, float* ws_par
     else ICS_LAUNCH((bn_bwd_apply_kernel<1, false>), dim3(nblk), dim3(256), 0, st, L, rpb, c1, c2, dy, dbp);
   }
   ICS_HIP(hipGetLastError());
-  if (dbias) {
+  if (dbias && !db_partial_own) {
     ICS_LAUNCH(colsum_finalize_kernel, dim3(L.C), dim3(256), 0, st, ws_partial, nblk, L.C, dbias);
     ICS_HIP(hipGetLastError());
   }
+  return 0;
+}
+// every pending bias-gradient finalize of a step in ONE launch: block -> (job, channel) through the prefix table
+__global__ __launch_bounds__(256) void colsum_batch_kernel(ColsumJobs J) {
+  __shared__ double sh[4];
+  int j = 0;
+  while (j + 1 < J.n && (int)blockIdx.x >= J.blk0[j + 1]) ++j;
+  const int c = (int)blockIdx.x - J.blk0[j], C = J.C[j], nblk = J.nblk[j];
+  const float* partial = J.partial[j];
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += 256) s += (double)partial[(size_t)b * C + c];
+  s = block_sum_d(s, sh);
+  if (threadIdx.x == 0) J.out[j][c] = (float)s;
+}
+int launch_colsum_batch(hipStream_t st, const ColsumJobs& J) {
+  if (J.n == 0) return 0;
+  ICS_LAUNCH(colsum_batch_kernel, dim3((unsigned)J.blk0[J.n]), dim3(256), 0, st, J);
+  ICS_HIP(hipGetLastError());
   return 0;
 }
 size_t layer_bwd_workspace_floats(const LayerBwd& L) {
@@ -1300,10 +1322,11 @@ __global__ void xhat_affine_kernel(const float* __restrict__ mean, const float* 
   xs[C + c] = -mean[c] * rstd[c];
 }
 // Q[ch][cls] = sum_v xhat[v][ch] dz[v][cls] (the head's weight-gradient GEMM run on xhat instead of on gamma xhat + beta),
-// dzsum[cls] = sum_v dz[v][cls] (the head's bias gradients).  One thread per channel:
+// dzsum[cls] = sum_v dz[v][cls] (the head's bias gradients).  Per channel:
 //   head dW[ch][cls] = gamma Q + beta dzsum                           (what the GEMM on the BatchNorm output would have given)
 //   sum_v d[v][ch]        = sum_cls W[ch][cls] dzsum[cls]  -> c1 = / n, the producer's dbeta
 //   sum_v d xhat [v][ch]  = sum_cls W[ch][cls] Q[ch][cls]  -> c2 = / n, the producer's dgamma
+// (class sums in fp64, fixed order: wave butterfly, then the two waves)
 __global__ __launch_bounds__(128) void head_bnfuse_kernel(const float* __restrict__ Q, const float* __restrict__ dzsum,
                                                           const float* __restrict__ wsoft, const float* __restrict__ wsig,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -1311,21 +1334,30 @@ __global__ __launch_bounds__(128) void head_bnfuse_kernel(const float* __restric
                                                           float* __restrict__ dwsig, float* __restrict__ c1c2,
                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                           double* __restrict__ sums) {
-  const int ch = threadIdx.x, nz = ncls + 1;
+  // one block per channel, one thread per class (first version: one thread per channel walking 96 classes with a
+  // 384-byte stride between lanes -- 52 us for 48 KB)
+  __shared__ double sh1[2], sh2[2];
+  const int ch = blockIdx.x, cls = threadIdx.x, nz = ncls + 1;
   const float g = gamma[ch], b = beta[ch];
-  double sd = 0.0, sq = 0.0;
-  for (int cls = 0; cls < nz; ++cls) {
+  double pd = 0.0, pq = 0.0;
+  if (cls < nz) {
     const float q = Q[ch * nz + cls], zs = dzsum[cls];
     const float w = cls < ncls ? wsoft[ch * ncls + cls] : wsig[ch];
-    sd += (double)w * (double)zs;
-    sq += (double)w * (double)q;
+    pd = (double)w * (double)zs;
+    pq = (double)w * (double)q;
     const float dw = fmaf(g, q, b * zs);
     if (cls < ncls) dwsoft[ch * ncls + cls] = dw; else dwsig[ch] = dw;
   }
-  if (sums) { sums[ch] = sd; sums[128 + ch] = sq; }       // SyncBN: all-reduced, then bn_bwd_sync_c_kernel forms c1 / c2
-  else { c1c2[ch] = (float)(sd / n); c1c2[128 + ch] = (float)(sq / n); }
-  dgamma[ch] = (float)sq;
-  dbeta[ch] = (float)sd;
+  pd = wave_sum_d(pd); pq = wave_sum_d(pq);
+  if ((threadIdx.x & 63) == 0) { sh1[threadIdx.x >> 6] = pd; sh2[threadIdx.x >> 6] = pq; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double sd = sh1[0] + sh1[1], sq = sh2[0] + sh2[1];
+    if (sums) { sums[ch] = sd; sums[128 + ch] = sq; }       // SyncBN: all-reduced, then bn_bwd_sync_c_kernel forms c1 / c2
+    else { c1c2[ch] = (float)(sd / n); c1c2[128 + ch] = (float)(sq / n); }
+    dgamma[ch] = (float)sq;
+    dbeta[ch] = (float)sd;
+  }
 }
 int launch_xhat_affine(hipStream_t st, const float* mean, const float* rstd, int C, float* xs) {
   ICS_LAUNCH(xhat_affine_kernel, dim3((C + 127) / 128), dim3(128), 0, st, mean, rstd, C, xs);
@@ -1335,7 +1367,8 @@ int launch_xhat_affine(hipStream_t st, const float* mean, const float* rstd, int
 int launch_head_bnfuse(hipStream_t st, const float* Q, const float* dzsum, const float* wsoft, const float* wsig,
                        const float* gamma, const float* beta, double n, int ncls, float* dwsoft, float* dwsig, float* c1c2,
                        float* dgamma, float* dbeta, const BnSync* sync) {
-  ICS_LAUNCH(head_bnfuse_kernel, dim3(1), dim3(128), 0, st, Q, dzsum, wsoft, wsig, gamma, beta, n, ncls, dwsoft, dwsig, c1c2,
+  ICS_CHECK(ncls + 1 <= 128, "head BN-fuse: at most 127 classes");
+  ICS_LAUNCH(head_bnfuse_kernel, dim3(128), dim3(128), 0, st, Q, dzsum, wsoft, wsig, gamma, beta, n, ncls, dwsoft, dwsig, c1c2,
              dgamma, dbeta, sync ? sync->local : nullptr);
   ICS_HIP(hipGetLastError());
   if (sync) {   // global-batch statistics: the two sums over ALL ranks' voxels (every rank holds the same number of rows)

@@ -134,6 +134,8 @@ struct ConvLayer {
   float* dy = nullptr;                  // grad w.r.t. conv output [M][Cout]
   float* dA = nullptr;                  // grad w.r.t. virtual input [M][Cin]
   float* c1c2 = nullptr;
+  float* db_partial = nullptr;          // [blocks][Cout] bias-gradient partials of the BatchNorm-backward apply pass (own buffer:
+                                        // finalized with every other layer's in one launch, Net::colsum)
   float* pooled = nullptr;              // MaxPool3D(o) if a pool follows
   unsigned char* pool_idx = nullptr;
   ConvSrc src[2];
@@ -217,6 +219,7 @@ struct Net {
   BnSync bn_sync{};
   const BnSync* sync() const { return (sync_bn && comm) ? &bn_sync : nullptr; }
   int head_nblk = 0;
+  ColsumJobs colsum{};               // bias-gradient finalizes pending since the last flush (colsum_flush)
 
   // U-Net specifics
   int ncls = 95;
@@ -318,6 +321,12 @@ static int alloc_layer(Net& n, ConvLayer& L, bool need_bwd, bool pooled) {
     ICS_TRY(n.alloc(&L.dy, M * L.Cout));
     ICS_TRY(n.alloc(&L.dA, M * L.CinG));
     ICS_TRY(n.alloc(&L.c1c2, (size_t)2 * L.Cout));
+    if ((L.Cout & (L.Cout - 1)) == 0 || L.Cout % 4 == 0) {
+      LayerBwd lb{};
+      lb.B = n.maxB; lb.S = L.S; lb.lgS = ilog2(L.S); lb.C = L.Cout;
+      int rpb;
+      ICS_TRY(n.alloc(&L.db_partial, (size_t)std::max(bn_bwd_num_blocks(lb, &rpb), 512) * L.Cout));
+    }
   }
   if (L.has_bn) {
     if (!n.bn_slab) {   // one slab for every layer's moving statistics (data parallel: one all-reduce)
@@ -906,6 +915,20 @@ static int conv_grads_from_dy(Net& n, ConvLayer& L, int B, bool need_dA, bool pa
   return 0;
 }
 
+static int colsum_push(Net& n, const float* partial, int nblk, int C, float* out) {
+  ColsumJobs& J = n.colsum;
+  if (J.n == 24) { ICS_TRY(launch_colsum_batch(n.st, J)); J.n = 0; }
+  if (J.n == 0) J.blk0[0] = 0;
+  J.partial[J.n] = partial; J.out[J.n] = out; J.nblk[J.n] = nblk; J.C[J.n] = C;
+  J.blk0[J.n + 1] = J.blk0[J.n] + C;
+  J.n += 1;
+  return 0;
+}
+static int colsum_flush(Net& n) {
+  ICS_TRY(launch_colsum_batch(n.st, n.colsum));
+  n.colsum.n = 0;
+  return 0;
+}
 static int conv_backward(Net& n, ConvLayer& L, int B, GradSrc g0, GradSrc g1, const float* dtap, bool need_dA,
                          bool param_grads, int tap = -1, ConvLayer* next = nullptr) {
   // next: the layer whose ONLY gradient source is this layer's backward-data output (same resolution, no pooling /
@@ -922,10 +945,13 @@ static int conv_backward(Net& n, ConvLayer& L, int B, GradSrc g0, GradSrc g1, co
   const BwdPre pre{n.ws_bwd2, L.bwd_pre_nblk, L.bwd_pre_ld};
   L.bwd_pre_nblk = 0;
   n.prof.begin(n.st, "bn_act_bwd:" + L.name, 0, 4.0 * M * L.Cout * (L.has_bn ? (pre.nblk ? 3.0 : 5.0) : 3.0));
+  const bool defer = param_grads && L.db_partial != nullptr && !(n.flags & CF_NO_TICKET);
+  int db_blocks = 0;
   ICS_TRY(launch_layer_bwd(n.st, lb, L.dy, n.ws_bwd, L.c1c2,
                            (param_grads && L.has_bn) ? n.tg(L.t_gamma) : nullptr,
                            (param_grads && L.has_bn) ? n.tg(L.t_beta) : nullptr,
-                           param_grads ? n.tg(L.t_b) : nullptr, n.sync(), &pre));
+                           param_grads ? n.tg(L.t_b) : nullptr, n.sync(), &pre, defer ? L.db_partial : nullptr, &db_blocks));
+  if (defer) ICS_TRY(colsum_push(n, L.db_partial, db_blocks, L.Cout, n.tg(L.t_b)));
   n.prof.end(n.st);
   return conv_grads_from_dy(n, L, B, need_dA, param_grads, next);
 }
@@ -954,6 +980,7 @@ static int grads_ready(Net& n, size_t lo) {
   if (!n.comm || !n.overlap) return 0;
   if (lo >= n.bucket_hi) return 0;
   if (lo != 0 && n.bucket_hi - lo < n.bucket_min) return 0;
+  ICS_TRY(colsum_flush(n));   // the bucket's bias gradients
   ICS_TRY(side_join(n));     // the bucket's weight gradients were computed on the side stream
   ICS_HIP(hipEventRecord(n.ev_grad, n.st));
   ICS_HIP(hipStreamWaitEvent(n.comm_st, n.ev_grad, 0));
@@ -969,6 +996,7 @@ static size_t layer_lo(const Net& n, const ConvLayer& L) { return n.tensors[L.t_
 
 static int adam_step(Net& n) {
   float gscale = 1.f;
+  ICS_TRY(colsum_flush(n));
   ICS_TRY(side_join(n));
   if (n.comm) {
     if (n.overlap) {
@@ -1242,9 +1270,9 @@ static int unet_backward(Net& n, int B) {
       bs.s = r.c18->s; bs.mean = r.c18->mean; bs.rstd = r.c18->rstd; bs.scale = r.c18->scale; bs.shift = r.c18->shift;
       bs.partial = nullptr; bs.post_act = ACT_NONE; bs.ld = 128;
       ICS_TRY(launch_head_dgrad(n.st, H.s, n.tp(H.t_w), n.tp(H.t_gamma), r.c18->dy, 128, M, &bs, gb.Npad, &blocks,
-                                r.c18->c1c2, n.ws_bwd));
+                                r.c18->c1c2, r.c18->db_partial));
       n.prof.end(n.st);
-      ICS_TRY(launch_colsum_finalize(n.st, n.ws_bwd, blocks, 128, n.tg(r.c18->t_b)));
+      ICS_TRY(colsum_push(n, r.c18->db_partial, blocks, 128, n.tg(r.c18->t_b)));
     } else {
     if (head_dgrad_ok(n.ncls, 128, M, &bs, n.flags))
       ICS_TRY(launch_head_dgrad(n.st, H.s, n.tp(H.t_w), n.tp(H.t_gamma), H.dA, 128, M, &bs, gb.Npad, &blocks));

@@ -56,7 +56,7 @@ def default_run():
                                     "ICSG3D_NO_THIN_N", "ICSG3D_NO_UPSPLIT", "ICSG3D_NO_THIN_C", "ICSG3D_NO_BWD_FOLD",
                                     "ICSG3D_NO_WGRAD3S", "ICSG3D_SIDE_STREAM", "ICSG3D_NO_COND_FOLD", "ICSG3D_NO_WINO",
                                     "ICSG3D_NO_WINO64", "ICSG3D_NO_UP3", "ICSG3D_NO_WINO_WGRAD", "ICSG3D_NO_FUSED_HEAD",
-                                    "ICSG3D_NO_FAST_BNBWD", "ICSG3D_NO_THIN1_2STAGE", "ICSG3D_NO_WINOG", "ICSG3D_NO_HEAD_BNFUSE", "ICSG3D_NO_UP3N",
+                                    "ICSG3D_NO_FAST_BNBWD", "ICSG3D_NO_THIN1_2STAGE", "ICSG3D_NO_WINOG", "ICSG3D_NO_HEAD_BNFUSE", "ICSG3D_NO_UP3N", "ICSG3D_NO_TICKET",
                                     # not a fallback: = 1 puts every upsampled-channel launch on the 32-voxel tile that
                                     # the bench-sized launches use (here: c15.up with ONE block row in y, the VAE's d1)
                                     "ICSG3D_UP3_BIG_MIN_WG"])
