@@ -103,6 +103,7 @@ enum ConvFlags : int {
                                // batched GEMMs of conv_winog.hip (round 4)
   CF_NO_HEAD_BNFUSE = 524288,  // ICSG3D_NO_HEAD_BNFUSE: c18's BatchNorm backward as its own pass, not in the head's backward-data
   CF_NO_UP3N = 1 << 21,        // ICSG3D_NO_UP3N: the VAE decoder's narrow upsampled layers through the 8-tap parity GEMMs
+  CF_NO_DGRAD_BNFUSE = 1 << 22,  // ICSG3D_NO_DGRAD_BNFUSE: c17 / c15 BatchNorm backward as its own pass behind c18 / c16 backward-data
   CF_ZBATCH = 1 << 20,         // internal: conv_fwd_kernel runs gridDim.z independent GEMMs (launch_gemm_zbatch)
   CF_NO_TICKET = 131072,       // ICSG3D_NO_TICKET: one bias-gradient finalize launch per layer instead of one batched launch per
                                // step / gradient bucket (round 4)
@@ -130,6 +131,9 @@ struct BwdStat {
   float* partial = nullptr;       // out: [2][Npad][gridM] per-block column sums (block index fastest)
   int post_act = ACT_NONE;
   int ld = 0;
+  // round 4: P's whole BatchNorm-backward apply in the launch's epilogue (conv_wino64.hip FOLD = 2) instead of the sums:
+  const float* abc = nullptr;     // [3][N]: dy_P = relu'(s) (a d + b s + c), from conv_bnfuse_kernel; the launch's `out` is P's dy
+  float* db_partial = nullptr;    // out: [blocks][N] column sums of the written dy_P
 };
 
 // ---------------------------------------------------------------- kernel launchers (conv_igemm.hip)

@@ -73,6 +73,7 @@ int conv_flags_from_env() {
   if (getenv("ICSG3D_NO_WINOG")) f |= CF_NO_WINOG;
   if (getenv("ICSG3D_NO_HEAD_BNFUSE")) f |= CF_NO_HEAD_BNFUSE;
   if (getenv("ICSG3D_NO_UP3N")) f |= CF_NO_UP3N;
+  if (getenv("ICSG3D_NO_DGRAD_BNFUSE")) f |= CF_NO_DGRAD_BNFUSE;
   { const char* e = getenv("ICSG3D_UP3_BIG_MIN_WG"); if (e && *e && strtoul(e, nullptr, 10) <= 1) f |= CF_UP3_BIG_ALWAYS; }
   return f;
 }

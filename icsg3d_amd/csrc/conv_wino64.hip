@@ -61,7 +61,12 @@ __device__ __forceinline__ float wact(float v, float slope) { return fmaxf(v, v 
 __host__ __device__ __forceinline__ float wslope(int act) { return act == ACT_RELU ? 0.f : (act == ACT_LRELU ? kLeaky : 1.f); }
 }  // namespace
 
-template <bool AFF, bool NOACT, bool FOLD>
+// FOLD: 0 plain; 1 the consumer-side BatchNorm-backward sums of the producer folded into the epilogue (BwdStat::partial);
+// 2 the producer's whole BatchNorm-backward APPLY in the epilogue (BwdStat::abc, round 4): the launch writes
+//   dy_P = relu'(s) * (a * d + b * s + c),   a = scale, b = -scale c2 rstd, c = scale (c2 rstd mean - c1)
+// (= scale (d - c1 - xhat c2), the three per-channel constants formed in fp64 by conv_bnfuse_kernel) and the per-block
+// column sums of dy_P (the producer's bias gradient) to BwdStat::db_partial [blocks][Cout].
+template <bool AFF, bool NOACT, int FOLD>
 __global__ __launch_bounds__(512) void conv_wino64_kernel(const float* __restrict__ x, int ldx,
                                                           const float* __restrict__ in_scale,
                                                           const float* __restrict__ in_shift, float in_slope,
@@ -413,7 +418,7 @@ __global__ __launch_bounds__(512) void conv_wino64_kernel(const float* __restric
 #define ICS_W64_EPI_PREFETCH 1   // 1: everything the final stage reads from global memory is requested before the first
 #endif                           //    pass, under the output transform, instead of after each pass' second barrier
 #if ICS_W64_EPI_PREFETCH
-  vf4 pbias[2], pacc[2][2], psv[2][2], pmu[2], prs[2];
+  vf4 pbias[2], pacc[2][2], psv[2][2], pmu[2], prs[2], pk[FOLD == 2 ? 2 : 1];
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     const int nn = n0 + (pass * 2 + jl) * 16 + cq * 4;
@@ -424,9 +429,15 @@ __global__ __launch_bounds__(512) void conv_wino64_kernel(const float* __restric
       pacc[pass][0] = *reinterpret_cast<const vf4*>(y + o0);
       pacc[pass][1] = *reinterpret_cast<const vf4*>(y + o0 + (size_t)S * S * ldo);
     }
-    if (FOLD) {
+    if (FOLD == 2) {                               // pmu / prs / pk hold a / b / c
+      pmu[pass] = *reinterpret_cast<const vf4*>(bs.abc + nn);
+      prs[pass] = *reinterpret_cast<const vf4*>(bs.abc + Cout + nn);
+      pk[pass] = *reinterpret_cast<const vf4*>(bs.abc + 2 * Cout + nn);
+    } else if (FOLD) {
       pmu[pass] = *reinterpret_cast<const vf4*>(bs.mean + nn);
       prs[pass] = *reinterpret_cast<const vf4*>(bs.rstd + nn);
+    }
+    if (FOLD) {
       const size_t s0 = vox0 * bs.ld + nn;
       psv[pass][0] = *reinterpret_cast<const vf4*>(bs.s + s0);
       psv[pass][1] = *reinterpret_cast<const vf4*>(bs.s + s0 + (size_t)S * S * bs.ld);
@@ -483,11 +494,22 @@ __global__ __launch_bounds__(512) void conv_wino64_kernel(const float* __restric
 #endif
     e0.x = wact(e0.x, pre_slope); e0.y = wact(e0.y, pre_slope); e0.z = wact(e0.z, pre_slope); e0.w = wact(e0.w, pre_slope);
     e1.x = wact(e1.x, pre_slope); e1.y = wact(e1.y, pre_slope); e1.z = wact(e1.z, pre_slope); e1.w = wact(e1.w, pre_slope);
+#if ICS_W64_EPI_PREFETCH
+    if (FOLD == 2) {
+      const vf4 ka = pmu[pass], kb = prs[pass], kc = pk[pass], sv0 = psv[pass][0], sv1 = psv[pass][1];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        e0[r] = sv0[r] > 0.f ? fmaf(ka[r], e0[r], fmaf(kb[r], sv0[r], kc[r])) : 0.f;
+        e1[r] = sv1[r] > 0.f ? fmaf(ka[r], e1[r], fmaf(kb[r], sv1[r], kc[r])) : 0.f;
+      }
+      f1[pass] = e0 + e1;
+    }
+#endif
     *reinterpret_cast<vf4*>(y + o0) = e0;
     *reinterpret_cast<vf4*>(y + o1) = e1;
     val[pass][0] = e0; val[pass][1] = e1;
     ICS_TL(6 + pass * 3);
-    if (FOLD) {
+    if (FOLD == 1) {
 #if ICS_W64_EPI_PREFETCH
       const vf4 b_mu = pmu[pass], b_rs = prs[pass], sv0 = psv[pass][0], sv1 = psv[pass][1];
 #else
@@ -514,6 +536,27 @@ __global__ __launch_bounds__(512) void conv_wino64_kernel(const float* __restric
   // red[0..512) / red[512..1024): [w][64], channel index (pass * 2 + jl) * 16 + cq * 4 + e
   const int cidx = jl * 16 + cq * 4;
   const size_t nstat = gridDim.x / nchunks;
+  if (FOLD == 2) {                                 // column sums of the written dy_P only: [blocks][Cout]
+#pragma unroll
+    for (int d = 8; d < 64; d <<= 1)
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f1[pass][e] += __shfl_xor(f1[pass][e], d);
+    if (lane < 8) {
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) *reinterpret_cast<vf4*>(&red[w * 64 + pass * 32 + cidx]) = f1[pass];
+    }
+    __syncthreads();
+    if (tid < 64) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < 8; ++ww) sacc += red[ww * 64 + tid];
+      bs.db_partial[(size_t)tblk * Cout + n0 + tid] = sacc;
+    }
+    ICS_TL_FLUSH();
+    return;
+  }
   if (FOLD) {                                      // [2][Npad][blocks] (block index fastest), as conv_igemm.hip's FOLD
 #pragma unroll
     for (int d = 8; d < 64; d <<= 1)
@@ -614,10 +657,14 @@ int launch_conv_fwd_wino64(hipStream_t st, const ConvGeom& g, const ConvSrc& s0,
   const bool aff = s0.scale != nullptr;
   const bool noact = s0.act == ACT_NONE;
   const float in_slope = wslope(s0.act), pre_slope = wslope(pre_act);
-  const bool fold = bwd != nullptr && bwd->partial != nullptr && !aff && stat_partial == nullptr && bias == nullptr &&
-                    pre_act == ACT_NONE && !accumulate && bwd->ld % 4 == 0;
-  if (bwd_blocks) *bwd_blocks = fold ? (int)(grid / (unsigned)(g.Cout / 64)) : 0;
-  const BwdStat bs = fold ? *bwd : BwdStat{};
+  const bool plain = bwd != nullptr && !aff && stat_partial == nullptr && bias == nullptr && pre_act == ACT_NONE &&
+                     !accumulate && bwd->ld % 4 == 0;
+  const bool apply = plain && bwd->abc != nullptr;           // the producer's BatchNorm-backward apply in the epilogue
+  ICS_CHECK(bwd == nullptr || bwd->abc == nullptr || (apply && bwd->db_partial != nullptr && bwd->s != nullptr),
+            "Winograd backward-data with the fused BatchNorm-backward apply: not a plain launch");
+  const bool fold = plain && !apply && bwd->partial != nullptr;
+  if (bwd_blocks) *bwd_blocks = (fold || apply) ? (int)(grid / (unsigned)(g.Cout / 64)) : 0;
+  const BwdStat bs = (fold || apply) ? *bwd : BwdStat{};
 #define ICS_WINO_LAUNCH(AFFV, NOACTV, FOLDV)                                                                          \
   do {                                                                                                                \
     ICS_LAUNCH((conv_wino64_kernel<AFFV, NOACTV, FOLDV>), dim3(grid), dim3(512), 0, st, s0.p, s0.C, s0.scale, \
@@ -625,10 +672,11 @@ int launch_conv_fwd_wino64(hipStream_t st, const ConvGeom& g, const ConvSrc& s0,
                        g.Cin, g.Cout, bs);                                                                            \
     conv_set_last_kernel_id("conv_wino64_kernel<" #AFFV ", " #NOACTV ", " #FOLDV ">");                                \
   } while (0)
-  if (fold) ICS_WINO_LAUNCH(false, true, true);
-  else if (!aff) ICS_WINO_LAUNCH(false, true, false);
-  else if (noact) ICS_WINO_LAUNCH(true, true, false);
-  else ICS_WINO_LAUNCH(true, false, false);
+  if (apply) ICS_WINO_LAUNCH(false, true, 2);
+  else if (fold) ICS_WINO_LAUNCH(false, true, 1);
+  else if (!aff) ICS_WINO_LAUNCH(false, true, 0);
+  else if (noact) ICS_WINO_LAUNCH(true, true, 0);
+  else ICS_WINO_LAUNCH(true, false, 0);
 #undef ICS_WINO_LAUNCH
   ICS_HIP(hipGetLastError());
   return 0;

@@ -15,6 +15,8 @@ struct BnParams {
   float* rstd;    // 1/sqrt(var+eps)
   float* scale;   // gamma*rstd
   float* shift;   // beta - mean*scale
+  float* xs = nullptr;   // optional [2][C]: xhat as an affine of the stored activation (rstd, -mean*rstd); written by the
+                         // training finalize without SyncBN only (conv_bnfuse_kernel's weight-gradient GEMM reads it)
 };
 
 // SyncBN exchange (opt-in data-parallel mode): `local` holds 3*C doubles (forward: n, mean, M2) or 2*C
@@ -68,6 +70,7 @@ int launch_layer_bwd(hipStream_t st, const LayerBwd& L, float* dy, float* ws_par
                      float* dgamma, float* dbeta, float* dbias, const BnSync* sync = nullptr,
                      const BwdPre* pre = nullptr, float* db_partial_own = nullptr, int* db_blocks = nullptr);
 // deferred bias-gradient finalizes (out[c] = sum over nblk partial rows [nblk][C]), up to 24 per launch
+__host__ __device__ inline int colsum_blocks(int C) { return C % 4 == 0 ? C / 4 : C; }   // blocks of colsum_batch_kernel per job
 struct ColsumJobs {
   const float* partial[24];
   float* out[24];
@@ -93,6 +96,14 @@ int launch_xhat_affine(hipStream_t st, const float* mean, const float* rstd, int
 int launch_head_bnfuse(hipStream_t st, const float* Q, const float* dzsum, const float* wsoft, const float* wsig,
                        const float* gamma, const float* beta, double n, int ncls, float* dwsoft, float* dwsig, float* c1c2,
                        float* dgamma, float* dbeta, const BnSync* sync = nullptr);
+// BatchNorm-backward constants of a 3x3x3 layer's producer from the layer's own (xhat-sourced) weight-gradient GEMM:
+// see conv_bnfuse_kernel
+bool conv_bnfuse_ok(int S, int Cin, int N);
+size_t conv_bnfuse_partial_floats(int B, int S, int C);
+int launch_conv_bnfuse(hipStream_t st, const float* dy, int B, int S, int Cin, int N, const float* db_partial, int db_nblk,
+                       const float* W, float* G, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                       const float* scale, float* abc, float* c1c2, float* dgamma, float* dbeta, float* ws_partial,
+                       size_t ws_partial_floats, double* ws_R);
 int launch_colsum_finalize(hipStream_t st, const float* partial, int nblk, int C, float* out);
 int launch_head_fused(hipStream_t st, const float* x, int ldx, const float* scale, const float* shift, const float* wsoft_k,
                       const float* wsig_k, const float* bsoft, const float* bsig, float* z, const unsigned char* labels,

@@ -85,6 +85,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
     bn.rstd[c] = rstd;
     bn.scale[c] = sc;
     bn.shift[c] = bn.beta[c] - (float)mean * sc;
+    if (bn.xs) { bn.xs[c] = rstd; bn.xs[gridDim.x + c] = -(float)mean * rstd; }   // as xhat_affine_kernel
     if (update_moving) {
       // keras 2.3.1 BatchNormalization.call: variance fed to the moving average is rescaled by
       // n/(n-(1+eps)); plain EMA with momentum 0.99
@@ -810,13 +811,35 @@ int launch_layer_bwd(hipStream_t st, const LayerBwd& L, float* dy, float* ws_par
   }
   return 0;
 }
-// every pending bias-gradient finalize of a step in ONE launch: block -> (job, channel) through the prefix table
+// every pending bias-gradient finalize of a step in ONE launch: block -> (job, channel group) through the prefix table.
+// A block owns 4 channels (one float4 of every partial row, 256 row groups) when the job's channel count allows, else one
+// channel (colsum_blocks).  c17's partials of a Winograd backward-data launch are 8192 rows: the one-channel form (4 of
+// every 64 bytes, 32 dependent iterations) took 28 us, 16 channels per block (128 iterations) 67.
 __global__ __launch_bounds__(256) void colsum_batch_kernel(ColsumJobs J) {
   __shared__ double sh[4];
+  __shared__ double sh4[4][4];
   int j = 0;
   while (j + 1 < J.n && (int)blockIdx.x >= J.blk0[j + 1]) ++j;
-  const int c = (int)blockIdx.x - J.blk0[j], C = J.C[j], nblk = J.nblk[j];
+  const int C = J.C[j], nblk = J.nblk[j];
   const float* partial = J.partial[j];
+  if (C % 4 == 0) {
+    const int c0 = ((int)blockIdx.x - J.blk0[j]) * 4;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 256) {
+      const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)b * C + c0);
+      a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
+    }
+    a0 = wave_sum_d(a0); a1 = wave_sum_d(a1); a2 = wave_sum_d(a2); a3 = wave_sum_d(a3);
+    if ((threadIdx.x & 63) == 0) {
+      const int w = threadIdx.x >> 6;
+      sh4[w][0] = a0; sh4[w][1] = a1; sh4[w][2] = a2; sh4[w][3] = a3;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) J.out[j][c0 + threadIdx.x] = (float)((sh4[0][threadIdx.x] + sh4[1][threadIdx.x]) +
+                                                               (sh4[2][threadIdx.x] + sh4[3][threadIdx.x]));
+    return;
+  }
+  const int c = (int)blockIdx.x - J.blk0[j];
   double s = 0.0;
   for (int b = threadIdx.x; b < nblk; b += 256) s += (double)partial[(size_t)b * C + c];
   s = block_sum_d(s, sh);
@@ -1379,6 +1402,211 @@ int launch_head_bnfuse(hipStream_t st, const float* Q, const float* dzsum, const
   }
   return 0;
 }
+// ------------------------------------------------------------------------------------------
+// BatchNorm-backward apply of a 3x3x3 layer's PRODUCER inside that layer's backward-data launch (round 4, the general form
+// of the head fusion above).  Layer L (weights W[t][c][n], output gradient dy) reads P's BatchNorm output
+// gamma xhat + beta (zero outside the grid).  d = dgrad_L(dy) is linear in dy, so the two batch sums P's BatchNorm backward
+// needs follow from L's own weight-gradient GEMM, run on xhat instead of on gamma xhat + beta:
+//   G[t][c][n]  = sum_v xhat[v + t][c] dy[v][n]             (the Winograd backward-weight kernel, source affine = xhat's)
+//   S_t[n]      = sum over the voxels v with v + t inside the grid of dy[v][n]   (27 border-class sums, as cond_wgrad above)
+//   dW[t][c][n] = gamma_c G + beta_c S_t[n]                 (what the GEMM on the BatchNorm output would have given)
+//   sum_v d[v][c]      = sum_{t,n} W[t][c][n] S_t[n]   -> c1 = / n, P's dbeta
+//   sum_v d xhat[v][c] = sum_{t,n} W[t][c][n] G[t][c][n] -> c2 = / n, P's dgamma
+// all known BEFORE L's backward-data kernel runs, whose epilogue then writes P's dy directly (conv_wino64.hip FOLD = 2):
+// P's separate pass over 3 x its activation bytes disappears.  Exact reassociations; the class sums in fp64, fixed order.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool tap_valid_for_class(int tapd /*0,1,2 = -1,0,+1*/, int cls /*0 first,1 interior,2 last*/) {
+  return !((cls == 0 && tapd == 0) || (cls == 2 && tapd == 2));
+}
+struct ClassBlocks { int blk0[28]; };   // first block of each of the 27 border classes (class 13, the interior, has none)
+constexpr int kClassRows = 64;          // voxel rows per block
+constexpr int kTotalSplit = 16;         // blocks that share the sum over all voxels (slot 13 and 27 .. 41 of R)
+// partial[blk][C]: sums of dy over the block's rows of its class; a class = {first plane, interior, last plane}^3
+__global__ __launch_bounds__(256) void class_sums_kernel(const float* __restrict__ dy, int B, int S, int C, ClassBlocks cb,
+                                                         float* __restrict__ partial) {
+  __shared__ hv4 sh[256];
+  int cls = 0;
+  while (cls < 26 && (int)blockIdx.x >= cb.blk0[cls + 1]) ++cls;
+  const int cz = cls / 9, cy = (cls / 3) % 3, cx = cls % 3;
+  const int C4 = C >> 2, c4 = threadIdx.x % C4, vr = threadIdx.x / C4, VR = 256 / C4;
+  auto lo = [&](int k) { return k == 0 ? 0 : (k == 1 ? 1 : S - 1); };
+  auto cnt = [&](int k) { return k == 1 ? S - 2 : 1; };
+  const int nz = cnt(cz), ny = cnt(cy), nx = cnt(cx), per = nz * ny * nx;
+  const int total = B * per;
+  const int r0 = ((int)blockIdx.x - cb.blk0[cls]) * kClassRows;
+  const int r1 = min(r0 + kClassRows, total);
+  hv4 acc = hv4{0.f, 0.f, 0.f, 0.f};
+  for (int i = r0 + vr; i < r1; i += VR) {
+    const int b = i / per, q = i - b * per;
+    const int ix = q % nx, iy = (q / nx) % ny, iz = q / (nx * ny);
+    const size_t v = (((size_t)b * S + (lo(cz) + iz)) * S + (lo(cy) + iy)) * S + (lo(cx) + ix);
+    acc += *reinterpret_cast<const hv4*>(dy + v * C + c4 * 4);
+  }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  if (vr == 0) {
+    hv4 t = sh[c4];
+    for (int r = 1; r < VR; ++r) t += sh[r * C4 + c4];
+    *reinterpret_cast<hv4*>(partial + (size_t)blockIdx.x * C + c4 * 4) = t;
+  }
+}
+// R[cls][n]: the class sums (cls != 13); the sum over ALL voxels (L's bias-gradient partials [nblk][C], up to a few
+// thousand rows) is shared by kTotalSplit blocks, slot 13 and 27 .. 41 of R, which conv_bnfuse_kernel adds up.
+// One block per slot, (C / 4 channel quads) x (1024 / (C / 4) row groups); the row groups are merged in a fixed order.
+struct dbl4 { double x, y, z, w; };
+__global__ __launch_bounds__(1024) void class_reduce_kernel(const float* __restrict__ partial, ClassBlocks cb, int C,
+                                                            const float* __restrict__ db_partial, int db_nblk,
+                                                            double* __restrict__ R) {
+  __shared__ dbl4 sh[1024];
+  const int slot = blockIdx.x;
+  const bool tot = slot == 13 || slot >= 27;
+  const int part = slot == 13 ? 0 : slot - 26;                       // stripe of the total
+  const int per = (db_nblk + kTotalSplit - 1) / kTotalSplit;
+  const int t0 = min(part * per, db_nblk), t1 = min(t0 + per, db_nblk);
+  const float* p = tot ? db_partial + (size_t)t0 * C : partial + (size_t)cb.blk0[slot] * C;
+  const int nb = tot ? t1 - t0 : cb.blk0[slot + 1] - cb.blk0[slot];
+  const int C4 = C >> 2, c4 = threadIdx.x % C4, rg = threadIdx.x / C4, RG = 1024 / C4;
+  dbl4 a{0.0, 0.0, 0.0, 0.0};
+  for (int k = rg; k < nb; k += RG) {
+    const hv4 v = *reinterpret_cast<const hv4*>(p + (size_t)k * C + c4 * 4);
+    a.x += (double)v[0]; a.y += (double)v[1]; a.z += (double)v[2]; a.w += (double)v[3];
+  }
+  sh[threadIdx.x] = a;
+  __syncthreads();
+  if (rg == 0) {
+    for (int r = 1; r < RG; ++r) {
+      const dbl4 b = sh[r * C4 + c4];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    double* o = R + (size_t)slot * C + c4 * 4;
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w;
+  }
+}
+// one block per input channel c of L (= channel of P)
+__global__ __launch_bounds__(256) void conv_bnfuse_kernel(const double* __restrict__ R, const float* __restrict__ W,
+                                                          float* __restrict__ G, int Cin, int N,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          const float* __restrict__ scale, double cnt,
+                                                          float* __restrict__ abc, float* __restrict__ c1c2,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  extern __shared__ double St[];          // [27][N]
+  __shared__ double sh1[4], sh2[4];
+  const int c = blockIdx.x;
+  constexpr int PF = 14;                  // this thread's (t, n) entries, requested ahead of the class-sum phase (N <= 128)
+  float wpf[PF], qpf[PF];
+  const bool pf = 27 * N <= PF * 256;
+  if (pf) {
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+      const int i = threadIdx.x + k * 256;
+      const int t = i / N, n = i - t * N;
+      const size_t idx = ((size_t)t * Cin + c) * N + n;
+      wpf[k] = i < 27 * N ? W[idx] : 0.f;
+      qpf[k] = i < 27 * N ? G[idx] : 0.f;
+    }
+  }
+  for (int n = threadIdx.x; n < N; n += 256) {
+    double r[27], border = 0.0;
+#pragma unroll
+    for (int cls = 0; cls < 27; ++cls) {
+      r[cls] = R[(size_t)cls * N + n];
+      if (cls != 13) border += r[cls];
+    }
+    for (int k = 27; k < 26 + kTotalSplit; ++k) r[13] += R[(size_t)k * N + n];   // the other stripes of the total
+    r[13] -= border;                                   // interior class = sum over all voxels - border classes
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+      double sv = 0.0;
+#pragma unroll
+      for (int cls = 0; cls < 27; ++cls)
+        if (tap_valid_for_class(t / 9, cls / 9) && tap_valid_for_class((t / 3) % 3, (cls / 3) % 3) &&
+            tap_valid_for_class(t % 3, cls % 3))
+          sv += r[cls];
+      St[t * N + n] = sv;
+    }
+  }
+  __syncthreads();
+  const float g = gamma[c], b = beta[c];
+  double pd = 0.0, pq = 0.0;
+  if (pf) {
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+      const int i = threadIdx.x + k * 256;
+      if (i < 27 * N) {
+        const int t = i / N, n = i - t * N;
+        const size_t idx = ((size_t)t * Cin + c) * N + n;
+        const float w = wpf[k], q = qpf[k];
+        const double sv = St[i];
+        pd += (double)w * sv;
+        pq += (double)w * (double)q;
+        G[idx] = (float)((double)g * (double)q + (double)b * sv);
+      }
+    }
+  } else {
+  for (int i = threadIdx.x; i < 27 * N; i += 256) {
+    const int t = i / N, n = i - t * N;
+    const size_t idx = ((size_t)t * Cin + c) * N + n;
+    const float w = W[idx], q = G[idx];
+    const double sv = St[i];
+    pd += (double)w * sv;
+    pq += (double)w * (double)q;
+    G[idx] = (float)((double)g * (double)q + (double)b * sv);
+  }
+  }
+  pd = wave_sum_d(pd); pq = wave_sum_d(pq);
+  if ((threadIdx.x & 63) == 0) { sh1[threadIdx.x >> 6] = pd; sh2[threadIdx.x >> 6] = pq; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double sd = (sh1[0] + sh1[1]) + (sh1[2] + sh1[3]), sq = (sh2[0] + sh2[1]) + (sh2[2] + sh2[3]);
+    const double k1 = sd / cnt, k2 = sq / cnt, sc = (double)scale[c], rs = (double)rstd[c], mu = (double)mean[c];
+    abc[c] = (float)sc;
+    abc[Cin + c] = (float)(-sc * k2 * rs);
+    abc[2 * Cin + c] = (float)(sc * (k2 * rs * mu - k1));
+    c1c2[c] = (float)k1; c1c2[Cin + c] = (float)k2;
+    dgamma[c] = (float)sq;
+    dbeta[c] = (float)sd;
+  }
+}
+static ClassBlocks class_blocks(int B, int S, int* total) {
+  ClassBlocks cb{};
+  int nb = 0;
+  for (int cls = 0; cls < 27; ++cls) {
+    cb.blk0[cls] = nb;
+    if (cls == 13) continue;
+    auto cnt = [&](int k) { return k == 1 ? S - 2 : 1; };
+    const long long rows = (long long)B * cnt(cls / 9) * cnt((cls / 3) % 3) * cnt(cls % 3);
+    nb += (int)((rows + kClassRows - 1) / kClassRows);
+  }
+  cb.blk0[27] = nb;
+  *total = nb;
+  return cb;
+}
+size_t conv_bnfuse_partial_floats(int B, int S, int C) {
+  int nb = 0;
+  class_blocks(B, S, &nb);
+  return (size_t)nb * C;
+}
+bool conv_bnfuse_ok(int S, int Cin, int N) {
+  const int C4 = N / 4;
+  return S >= 3 && N % 4 == 0 && C4 <= 256 && 256 % C4 == 0 && (C4 & (C4 - 1)) == 0 && (size_t)27 * N * sizeof(double) <= 60 * 1024 && Cin > 0;
+}
+// dy [B S^3][N] -> G (in: the xhat-sourced weight-gradient GEMM; out: L's weight gradient), abc / c1c2 / dgamma / dbeta of P
+int launch_conv_bnfuse(hipStream_t st, const float* dy, int B, int S, int Cin, int N, const float* db_partial, int db_nblk,
+                       const float* W, float* G, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                       const float* scale, float* abc, float* c1c2, float* dgamma, float* dbeta, float* ws_partial,
+                       size_t ws_partial_floats, double* ws_R) {
+  ICS_CHECK(conv_bnfuse_ok(S, Cin, N), "conv BN-fuse: unsupported shape");
+  int nb = 0;
+  const ClassBlocks cb = class_blocks(B, S, &nb);
+  ICS_CHECK((size_t)nb * N <= ws_partial_floats, "conv BN-fuse: class-sum workspace too small");
+  ICS_LAUNCH(class_sums_kernel, dim3(nb), dim3(256), 0, st, dy, B, S, N, cb, ws_partial);
+  ICS_LAUNCH(class_reduce_kernel, dim3(26 + kTotalSplit), dim3(1024), 0, st, ws_partial, cb, N, db_partial, db_nblk, ws_R);
+  ICS_LAUNCH(conv_bnfuse_kernel, dim3(Cin), dim3(256), (size_t)27 * N * sizeof(double), st, ws_R, W, G, Cin, N, gamma, beta,
+             mean, rstd, scale, (double)B * S * S * S, abc, c1c2, dgamma, dbeta);
+  ICS_HIP(hipGetLastError());
+  return 0;
+}
 int launch_colsum_finalize(hipStream_t st, const float* partial, int nblk, int C, float* out) {
   ICS_LAUNCH(colsum_finalize_kernel, dim3(C), dim3(256), 0, st, partial, nblk, C, out);
   ICS_HIP(hipGetLastError());
@@ -1758,9 +1986,6 @@ int launch_vae_dz(hipStream_t st, const float* mulv, int ld, int latent, int B, 
 //             whose tap-shifted position lies inside the grid = sums of the 27 REGION sums R[b][cls] of dy.
 // Exact reassociations of the same sums (the border regions are summed directly, the interior one is total - rest).
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool tap_valid_for_class(int tapd /*0,1,2 = -1,0,+1*/, int cls /*0 first,1 interior,2 last*/) {
-  return !((cls == 0 && tapd == 0) || (cls == 2 && tapd == 2));
-}
 __global__ void cond_bias_table_kernel(const float* __restrict__ w, const float* __restrict__ bias,
                                        const float* __restrict__ cond, int C, int ncond, int Cin_tot, int Cout, int B,
                                        float* __restrict__ T) {

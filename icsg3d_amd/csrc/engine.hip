@@ -136,6 +136,11 @@ struct ConvLayer {
   float* c1c2 = nullptr;
   float* db_partial = nullptr;          // [blocks][Cout] bias-gradient partials of the BatchNorm-backward apply pass (own buffer:
                                         // finalized with every other layer's in one launch, Net::colsum)
+  int db_blocks = 0;                    // rows of db_partial the last backward pass wrote
+  // round 4 (conv_bnfuse_kernel): this layer's BatchNorm-backward apply inside its CONSUMER's backward-data launch
+  float* xs = nullptr;                  // [2][Cout] xhat as an affine of the stored activation
+  float* abc = nullptr;                 // [3][Cout] the apply's per-channel constants
+  bool dy_ready = false;                // dy was written by the consumer's backward-data launch: skip bn_act_bwd
   float* pooled = nullptr;              // MaxPool3D(o) if a pool follows
   unsigned char* pool_idx = nullptr;
   ConvSrc src[2];
@@ -220,6 +225,9 @@ struct Net {
   const BnSync* sync() const { return (sync_bn && comm) ? &bn_sync : nullptr; }
   int head_nblk = 0;
   ColsumJobs colsum{};               // bias-gradient finalizes pending since the last flush (colsum_flush)
+  float* ws_cls = nullptr; size_t ws_cls_n = 0;   // conv_bnfuse: per-block border-class sums of a dy
+  double* ws_R = nullptr;                         // [27][Cmax] class sums
+  size_t bnfuse_min_bytes = (size_t)64 << 20;     // producer activation size from which the fusion pays (ICSG3D_DGRAD_BNFUSE_MIN)
 
   // U-Net specifics
   int ncls = 95;
@@ -325,8 +333,10 @@ static int alloc_layer(Net& n, ConvLayer& L, bool need_bwd, bool pooled) {
       LayerBwd lb{};
       lb.B = n.maxB; lb.S = L.S; lb.lgS = ilog2(L.S); lb.C = L.Cout;
       int rpb;
-      ICS_TRY(n.alloc(&L.db_partial, (size_t)std::max(bn_bwd_num_blocks(lb, &rpb), 512) * L.Cout));
+      // 512: the head's backward-data launch; M / 128: a Winograd backward-data launch (one row per tile block)
+      ICS_TRY(n.alloc(&L.db_partial, std::max((size_t)std::max(bn_bwd_num_blocks(lb, &rpb), 512), M / 128 + 1) * L.Cout));
     }
+    if (L.has_bn) { ICS_TRY(n.alloc(&L.xs, (size_t)2 * L.Cout)); ICS_TRY(n.alloc(&L.abc, (size_t)3 * L.Cout)); }
   }
   if (L.has_bn) {
     if (!n.bn_slab) {   // one slab for every layer's moving statistics (data parallel: one all-reduce)
@@ -527,6 +537,16 @@ static int alloc_workspaces(Net& n, bool need_bwd) {
       if (Lp->has_bn) b2 = std::max(b2, (size_t)2 * Lp->Npad * ((n.rows(*Lp, n.maxB) + 63) / 64));
     n.ws_bwd2_n = b2;
     ICS_TRY(n.alloc(&n.ws_bwd2, b2 + 16));
+    size_t cls = 0; int cmax = 0;
+    for (auto& Lp : n.layers)
+      if (Lp->taps == 27 && Lp->S >= 3 && Lp->Cout % 4 == 0) {
+        cls = std::max(cls, conv_bnfuse_partial_floats(n.maxB, Lp->S, Lp->Cout));
+        cmax = std::max(cmax, Lp->Cout);
+      }
+    n.ws_cls_n = cls;
+    ICS_TRY(n.alloc(&n.ws_cls, cls + 16));
+    ICS_TRY(n.alloc(&n.ws_R, (size_t)48 * cmax + 16));
+    if (const char* e = getenv("ICSG3D_DGRAD_BNFUSE_MIN")) n.bnfuse_min_bytes = (size_t)atoll(e);
   }
   n.ws_dbl_n = 1 << 16;
   for (auto& Lp : n.layers)
@@ -683,6 +703,7 @@ static int conv_forward(Net& n, ConvLayer& L, int B, bool training, bool update_
   }
   if (L.has_bn) {
     BnParams bn{n.tp(L.t_gamma), n.tp(L.t_beta), L.mm, L.mv, L.mean, L.rstd, L.scale, L.shift};
+    if (training && n.sync() == nullptr) bn.xs = L.xs;
     if (training) {
       const int nblk = par_blocks ? par_blocks : (int)((M + rpb - 1) / rpb);
       ICS_TRY(launch_bn_finalize(n.st, n.ws_stat, nblk, L.Npad, bn, L.Cout, update_moving ? 1 : 0, n.bn_unbias, n.sync()));
@@ -834,14 +855,39 @@ static int conv_grads_split_up(Net& n, ConvLayer& L, int B, ConvLayer* next) {
 }
 
 // weight / input gradients given L.dy
+static int colsum_push(Net& n, const float* partial, int nblk, int C, float* out);
+// Round 4: `next`'s BatchNorm backward inside L's backward-data launch (elementwise.hip conv_bnfuse_kernel, conv_wino64.hip
+// FOLD = 2).  For the Conv -> ReLU -> BN blocks of unet.py:276-336 whose gradient comes from ONE 3x3x3 consumer served by
+// the Winograd kernels, from the size on where the removed pass (3 x the activation bytes) outweighs the four small
+// launches the constants cost: c18 -> c17 and c16 -> c15 at B = 32.  Not with SyncBN (the two sums would need their own
+// all-reduce) and not with the weight gradients on the side stream (the backward-data launch waits for them here).
+static bool dgrad_bnfuse_ok(const Net& n, const ConvLayer& L, const ConvLayer* next, int B, bool need_dA, bool param_grads) {
+  if (next == nullptr || !need_dA || !param_grads || (n.flags & CF_NO_DGRAD_BNFUSE) || n.sync() != nullptr || n.side_on)
+    return false;
+  if (!next->has_bn || next->pre_act != ACT_RELU || next->post_act != ACT_NONE || next->xs == nullptr ||
+      next->db_partial == nullptr || next->dy == nullptr)
+    return false;
+  if (L.split_up || L.nsrc != 1 || L.taps != 27 || !L.wino_w || !L.wwb || L.wwb_layout != 1 || L.CinG != L.Cin ||
+      L.Cin != next->Cout || L.src[0].p != next->s || L.src[0].scale == nullptr || L.src[0].act != ACT_NONE || L.dw_phys)
+    return false;
+  if (n.rows(L, B) * (size_t)next->Cout * sizeof(float) < n.bnfuse_min_bytes) return false;
+  const ConvGeom g = geom_fwd(L, B);
+  ConvGeom gb = geom_bwd(L, B);
+  gb.Cout = L.Cin;
+  const ConvSrc sdy = src_plain(L.dy, L.Cout);
+  return conv_bnfuse_ok(L.S, L.Cin, L.Cout) && conv_wino_wgrad_ok(g, L.src, 1) && conv_wino_ok(gb, &sdy, 1) &&
+         conv_bnfuse_partial_floats(B, L.S, L.Cout) <= n.ws_cls_n && L.Cin % 4 == 0;
+}
 static int conv_grads_from_dy(Net& n, ConvLayer& L, int B, bool need_dA, bool param_grads, ConvLayer* next) {
   if (L.split_up && need_dA && param_grads) return conv_grads_split_up(n, L, B, next);
   if (L.split_up) next = nullptr;   // direct path of an up-split layer: dA covers [skip | up] channels
   const ConvGeom g = geom_fwd(L, B);
   const size_t M = n.rows(L, B);
+  const bool bnfuse = dgrad_bnfuse_ok(n, L, next, B, need_dA, param_grads);
   if (param_grads) {
     hipStream_t ws = side_begin(n);   // weight gradients: off the critical path (Net::st2); ALL of them, the
                                       // split-K workspace ws_wgrad is only ever touched from that stream
+                                      // (bnfuse implies the side stream is off: ws == n.st)
     n.prof.begin(ws, "conv_wgrad:" + L.name + "|", 2.0 * M * L.taps * L.Cin * L.Cout,
                  4.0 * (M * L.Cin + M * L.Cout + (double)L.taps * L.Cin * L.Cout));
     float* dw = L.dw_phys ? L.dw_phys : n.tg(L.t_w);
@@ -868,11 +914,25 @@ static int conv_grads_from_dy(Net& n, ConvLayer& L, int B, bool need_dA, bool pa
       ICS_TRY(launch_conv_wgrad_winog(ws, g, L.wg_vt, L.dy, L.Cout, dw, L.Cout, 0, 0, L.wg_z, L.wg_du));
       n.prof.end(ws);
     } else if (L.wino_w && !L.split_up && conv_wino_wgrad_ok(g, L.src, L.nsrc)) {
-      ICS_TRY(launch_conv_wgrad_wino(ws, g, L.src[0], L.dy, L.Cout, dw, L.Cout, n.ws_wgrad, n.ws_wgrad_n, 0, 0, 0, 1));
+      ConvSrc sx = L.src[0];
+      if (bnfuse) {     // the GEMM on xhat: conv_bnfuse_kernel turns its result into dW and next's BatchNorm-backward constants
+        sx.scale = next->xs; sx.shift = next->xs + next->Cout;
+      }
+      ICS_TRY(launch_conv_wgrad_wino(ws, g, sx, L.dy, L.Cout, dw, L.Cout, n.ws_wgrad, n.ws_wgrad_n, 0, 0, 0, 1));
       n.prof.end(ws);
       n.prof.begin(ws, "wgrad_reduce_splits", 0, 0);
-      ICS_TRY(launch_conv_wgrad_wino(ws, g, L.src[0], L.dy, L.Cout, dw, L.Cout, n.ws_wgrad, n.ws_wgrad_n, 0, 0, 0, 2));
+      ICS_TRY(launch_conv_wgrad_wino(ws, g, sx, L.dy, L.Cout, dw, L.Cout, n.ws_wgrad, n.ws_wgrad_n, 0, 0, 0, 2));
       n.prof.end(ws);
+      if (bnfuse) {
+        // L's total column sums of dy: its bias-gradient partials if their finalize is still pending, else the gradient
+        const bool pend = L.db_blocks > 0;
+        n.prof.begin(ws, "bnfuse:" + L.name, 0, 0);
+        ICS_TRY(launch_conv_bnfuse(ws, L.dy, B, L.S, L.Cin, L.Cout, pend ? L.db_partial : n.tg(L.t_b), pend ? L.db_blocks : 1,
+                                   n.tp(L.t_w), dw, n.tp(next->t_gamma), n.tp(next->t_beta), next->mean, next->rstd,
+                                   next->scale, next->abc, next->c1c2, n.tg(next->t_gamma), n.tg(next->t_beta), n.ws_cls,
+                                   n.ws_cls_n, n.ws_R));
+        n.prof.end(ws);
+      }
     } else {
     ICS_TRY(launch_conv_wgrad(ws, g, L.src, L.nsrc, L.dy, L.Cout, dw, L.Cout, n.ws_wgrad, n.ws_wgrad_n, 0, 0, 0, 1));
     n.prof.end(ws);
@@ -893,8 +953,21 @@ static int conv_grads_from_dy(Net& n, ConvLayer& L, int B, bool need_dA, bool pa
     ConvSrc sdy = src_plain(L.dy, L.Cout);
     n.prof.begin(n.st, "conv_dgrad:" + L.name + "|", 2.0 * M * L.taps * L.Cin * L.Cout,
                  4.0 * (M * L.Cin + M * L.Cout + (double)L.taps * L.Cin * L.Cout));
-    const BwdStat bs = bwd_stat_for(n, next, B);
     int blocks = 0;
+    if (bnfuse) {
+      BwdStat ba{};
+      ba.s = next->s; ba.ld = next->Cout; ba.abc = next->abc; ba.db_partial = next->db_partial;
+      ICS_TRY(launch_conv_fwd_wino(n.st, gb, sdy, L.wwb, nullptr, next->dy, next->Cout, ACT_NONE, nullptr, nullptr, 0,
+                                   L.wwb_layout, &ba, &blocks));
+      n.prof.end(n.st);
+      ICS_CHECK(blocks > 0, "fused BatchNorm-backward apply: the backward-data launch did not take it");
+      next->dy_ready = true;
+      next->db_blocks = 0;
+      if (n.flags & CF_NO_TICKET) ICS_TRY(launch_colsum_finalize(n.st, next->db_partial, blocks, next->Cout, n.tg(next->t_b)));
+      else { ICS_TRY(colsum_push(n, next->db_partial, blocks, next->Cout, n.tg(next->t_b))); next->db_blocks = blocks; }
+      return 0;
+    }
+    const BwdStat bs = bwd_stat_for(n, next, B);
     if (L.wwb && !L.split_up && conv_wino_ok(gb, &sdy, 1))
       ICS_TRY(launch_conv_fwd_wino(n.st, gb, sdy, L.wwb, nullptr, L.dA, L.CinG, ACT_NONE, nullptr, nullptr, 0,
                                    L.wwb_layout, &bs, &blocks));
@@ -920,7 +993,7 @@ static int colsum_push(Net& n, const float* partial, int nblk, int C, float* out
   if (J.n == 24) { ICS_TRY(launch_colsum_batch(n.st, J)); J.n = 0; }
   if (J.n == 0) J.blk0[0] = 0;
   J.partial[J.n] = partial; J.out[J.n] = out; J.nblk[J.n] = nblk; J.C[J.n] = C;
-  J.blk0[J.n + 1] = J.blk0[J.n] + C;
+  J.blk0[J.n + 1] = J.blk0[J.n] + colsum_blocks(C);
   J.n += 1;
   return 0;
 }
@@ -942,6 +1015,10 @@ static int conv_backward(Net& n, ConvLayer& L, int B, GradSrc g0, GradSrc g1, co
   lb.pool_ties_all = n.pool_ties_all;
   lb.flags = n.flags;
   const size_t M = n.rows(L, B);
+  if (L.dy_ready) {                  // written by the consumer's backward-data launch (conv_grads_from_dy, bnfuse)
+    L.dy_ready = false;
+    return conv_grads_from_dy(n, L, B, need_dA, param_grads, next);
+  }
   const BwdPre pre{n.ws_bwd2, L.bwd_pre_nblk, L.bwd_pre_ld};
   L.bwd_pre_nblk = 0;
   n.prof.begin(n.st, "bn_act_bwd:" + L.name, 0, 4.0 * M * L.Cout * (L.has_bn ? (pre.nblk ? 3.0 : 5.0) : 3.0));
@@ -951,7 +1028,8 @@ static int conv_backward(Net& n, ConvLayer& L, int B, GradSrc g0, GradSrc g1, co
                            (param_grads && L.has_bn) ? n.tg(L.t_gamma) : nullptr,
                            (param_grads && L.has_bn) ? n.tg(L.t_beta) : nullptr,
                            param_grads ? n.tg(L.t_b) : nullptr, n.sync(), &pre, defer ? L.db_partial : nullptr, &db_blocks));
-  if (defer) ICS_TRY(colsum_push(n, L.db_partial, db_blocks, L.Cout, n.tg(L.t_b)));
+  L.db_blocks = 0;
+  if (defer) { ICS_TRY(colsum_push(n, L.db_partial, db_blocks, L.Cout, n.tg(L.t_b))); L.db_blocks = db_blocks; }
   n.prof.end(n.st);
   return conv_grads_from_dy(n, L, B, need_dA, param_grads, next);
 }
@@ -1273,6 +1351,7 @@ static int unet_backward(Net& n, int B) {
                                 r.c18->c1c2, r.c18->db_partial));
       n.prof.end(n.st);
       ICS_TRY(colsum_push(n, r.c18->db_partial, blocks, 128, n.tg(r.c18->t_b)));
+      r.c18->db_blocks = blocks;
     } else {
     if (head_dgrad_ok(n.ncls, 128, M, &bs, n.flags))
       ICS_TRY(launch_head_dgrad(n.st, H.s, n.tp(H.t_w), n.tp(H.t_gamma), H.dA, 128, M, &bs, gb.Npad, &blocks));

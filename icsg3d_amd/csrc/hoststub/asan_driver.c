@@ -130,6 +130,7 @@ int main(void) {
   OK(ics_set_device(0));
   OK(ics_device_info(name, &cus, &hbm));
   printf("asan driver on %s (%s)\n", name, ics_version());
+  setenv("ICSG3D_DGRAD_BNFUSE_MIN", "0", 1);   /* walk the BatchNorm-backward-in-backward-data fusion at these small sizes too */
   if (run(16, 1, 3, 0)) return 1;
   if (run(16, 4, 2, 1)) return 1;      /* 4 channels (Cin 44 -> padded loaders), single-rank communicator */
   if (run(32, 1, 2, 2)) return 1;      /* d = 32 plans, SyncBN */

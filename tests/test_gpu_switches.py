@@ -33,9 +33,17 @@ zm, zlv, z = v.encode(X, cond, eps)
 rec = v.decode(z, cond)
 mv = v.train_step(X, cond, eps)
 g = u.get_grad("soft/kernel", (1, 1, 1, 128, 95))
+# gradients further down the backward pass (what the BatchNorm-backward fusions feed): sampled
+deep = {}
+for name, shape in (("c18/kernel", (3, 3, 3, 128, 128)), ("c18/bias", (128,)), ("c17/kernel", (3, 3, 3, 192, 128)),
+                    ("c17/gamma", (128,)), ("c17/beta", (128,)), ("c17/bias", (128,)), ("c16/kernel", (3, 3, 3, 256, 128)),
+                    ("c15/gamma", (256,)), ("c15/beta", (256,)), ("c15/bias", (256,)), ("c4/kernel", (3, 3, 3, 64, 128)),
+                    ("c3/gamma", (64,)), ("c3/bias", (64,)), ("c1/kernel", (3, 3, 3, 1, 32))):
+    a = u.get_grad(name, shape).ravel()
+    deep[name.replace("/", "_")] = a[::max(1, a.size // 512)].tolist()
 print(json.dumps({"soft": soft[:, ::5, ::5, ::5].ravel().tolist(), "sig": sig[:, ::5, ::5, ::5].ravel().tolist(),
                   "mu": np.asarray(mu).tolist(), "mv": np.asarray(mv).tolist(), "zm": zm.ravel()[::7].tolist(),
-                  "rec": rec[:, ::5, ::5, ::5].ravel().tolist(), "g": g.ravel()[::37].tolist()}))
+                  "rec": rec[:, ::5, ::5, ::5].ravel().tolist(), "g": g.ravel()[::37].tolist(), **deep}))
 """ % ROOT
 
 
@@ -59,9 +67,21 @@ def default_run():
                                     "ICSG3D_NO_FAST_BNBWD", "ICSG3D_NO_THIN1_2STAGE", "ICSG3D_NO_WINOG", "ICSG3D_NO_HEAD_BNFUSE", "ICSG3D_NO_UP3N", "ICSG3D_NO_TICKET",
                                     # not a fallback: = 1 puts every upsampled-channel launch on the 32-voxel tile that
                                     # the bench-sized launches use (here: c15.up with ONE block row in y, the VAE's d1)
-                                    "ICSG3D_UP3_BIG_MIN_WG"])
+                                    "ICSG3D_UP3_BIG_MIN_WG",
+                                    # not a fallback either: = 0 turns the BatchNorm-backward-in-backward-data fusion on at
+                                    # this size (c18 -> c17, c16 -> c15, c4 -> c3; default: from 64 MB of activations on)
+                                    "ICSG3D_DGRAD_BNFUSE_MIN=0", "ICSG3D_NO_DGRAD_BNFUSE"])
 def test_fallback_path_matches_default(default_run, switch):
-    alt = _run({switch: "1"})
+    name, _, val = switch.partition("=")
+    alt = _run({name: val or "1"})
+    # The sampled gradients of the deeper layers: a switch that changes a FORWARD summation order moves them by up to
+    # 7e-3 of their largest entry at this size (B = 2, d = 16: the BatchNorm layers at 2^3 .. 4^3 voxels see 16 .. 128
+    # values per channel and amplify 1e-7 forward differences; scripts/switch_deltas.py prints the table), the switches
+    # that only re-associate the backward pass stay below 3e-6.
+    backward_only = name in ("ICSG3D_DGRAD_BNFUSE_MIN", "ICSG3D_NO_DGRAD_BNFUSE", "ICSG3D_NO_BWD_FOLD",
+                             "ICSG3D_NO_HEAD_BNFUSE", "ICSG3D_NO_TICKET", "ICSG3D_NO_FAST_BNBWD")
     for k, ref in default_run.items():
         scale = max(float(np.abs(ref).max()), 1e-30)
-        assert float(np.abs(alt[k] - ref).max()) <= 2e-5 * scale, (switch, k)
+        deep = k.startswith("c") and "_" in k
+        tol = 2e-2 if (deep and not backward_only) else 2e-5
+        assert float(np.abs(alt[k] - ref).max()) <= tol * scale, (switch, k)
