@@ -134,6 +134,10 @@ struct BwdStat {
   // round 4: P's whole BatchNorm-backward apply in the launch's epilogue (conv_wino64.hip FOLD = 2) instead of the sums:
   const float* abc = nullptr;     // [3][N]: dy_P = relu'(s) (a d + b s + c), from conv_bnfuse_kernel; the launch's `out` is P's dy
   float* db_partial = nullptr;    // out: [blocks][N] column sums of the written dy_P
+  // with abc: P's second consumer is a MaxPool3D whose input gradient is added to d first (FOLD = 3)
+  const float* pool_d = nullptr;            // [rows/8][pool_ld] gradient w.r.t. the pooled tensor
+  int pool_ld = 0;
+  const unsigned char* pool_mask = nullptr; // [rows/8][N] bit k: window element k receives the gradient (launch_pool_fwd)
 };
 
 // ---------------------------------------------------------------- kernel launchers (conv_igemm.hip)

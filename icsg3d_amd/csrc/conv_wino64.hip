@@ -65,7 +65,9 @@ __host__ __device__ __forceinline__ float wslope(int act) { return act == ACT_RE
 // 2 the producer's whole BatchNorm-backward APPLY in the epilogue (BwdStat::abc, round 4): the launch writes
 //   dy_P = relu'(s) * (a * d + b * s + c),   a = scale, b = -scale c2 rstd, c = scale (c2 rstd mean - c1)
 // (= scale (d - c1 - xhat c2), the three per-channel constants formed in fp64 by conv_bnfuse_kernel) and the per-block
-// column sums of dy_P (the producer's bias gradient) to BwdStat::db_partial [blocks][Cout].
+// column sums of dy_P (the producer's bias gradient) to BwdStat::db_partial [blocks][Cout];
+// 3 = 2 with the producer's second consumer, a MaxPool3D, added to d first: d += pool_d[v >> 1] where this voxel's bit of
+//   the window's tie mask is set (BwdStat::pool_d / pool_mask; the masks are written by the forward pooling kernel).
 template <bool AFF, bool NOACT, int FOLD>
 __global__ __launch_bounds__(512) void conv_wino64_kernel(const float* __restrict__ x, int ldx,
                                                           const float* __restrict__ in_scale,
@@ -418,7 +420,8 @@ __global__ __launch_bounds__(512) void conv_wino64_kernel(const float* __restric
 #define ICS_W64_EPI_PREFETCH 1   // 1: everything the final stage reads from global memory is requested before the first
 #endif                           //    pass, under the output transform, instead of after each pass' second barrier
 #if ICS_W64_EPI_PREFETCH
-  vf4 pbias[2], pacc[2][2], psv[2][2], pmu[2], prs[2], pk[FOLD == 2 ? 2 : 1];
+  vf4 pbias[2], pacc[2][2], psv[2][2], pmu[2], prs[2], pk[FOLD >= 2 ? 2 : 1], ppool[FOLD == 3 ? 2 : 1];
+  unsigned pmask[2] = {0u, 0u};
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     const int nn = n0 + (pass * 2 + jl) * 16 + cq * 4;
@@ -429,7 +432,13 @@ __global__ __launch_bounds__(512) void conv_wino64_kernel(const float* __restric
       pacc[pass][0] = *reinterpret_cast<const vf4*>(y + o0);
       pacc[pass][1] = *reinterpret_cast<const vf4*>(y + o0 + (size_t)S * S * ldo);
     }
-    if (FOLD == 2) {                               // pmu / prs / pk hold a / b / c
+    if (FOLD == 3) {
+      const int Sh = S >> 1;
+      const size_t prow = (((size_t)b * Sh + (vz >> 1)) * Sh + (vy >> 1)) * Sh + (vx >> 1);
+      ppool[pass] = *reinterpret_cast<const vf4*>(bs.pool_d + prow * bs.pool_ld + nn);
+      pmask[pass] = *reinterpret_cast<const unsigned*>(bs.pool_mask + prow * Cout + nn);
+    }
+    if (FOLD >= 2) {                               // pmu / prs / pk hold a / b / c
       pmu[pass] = *reinterpret_cast<const vf4*>(bs.abc + nn);
       prs[pass] = *reinterpret_cast<const vf4*>(bs.abc + Cout + nn);
       pk[pass] = *reinterpret_cast<const vf4*>(bs.abc + 2 * Cout + nn);
@@ -495,7 +504,17 @@ __global__ __launch_bounds__(512) void conv_wino64_kernel(const float* __restric
     e0.x = wact(e0.x, pre_slope); e0.y = wact(e0.y, pre_slope); e0.z = wact(e0.z, pre_slope); e0.w = wact(e0.w, pre_slope);
     e1.x = wact(e1.x, pre_slope); e1.y = wact(e1.y, pre_slope); e1.z = wact(e1.z, pre_slope); e1.w = wact(e1.w, pre_slope);
 #if ICS_W64_EPI_PREFETCH
-    if (FOLD == 2) {
+    if (FOLD == 3) {                               // vz is even: the voxel pair (vz, vz + 1) shares its pooling window
+      const int k0 = ((vy & 1) << 1) | (vx & 1);
+      const vf4 pd = ppool[pass];
+      const unsigned m0 = pmask[pass] >> k0, m1 = m0 >> 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        e0[r] += ((m0 >> (8 * r)) & 1u) ? pd[r] : 0.f;
+        e1[r] += ((m1 >> (8 * r)) & 1u) ? pd[r] : 0.f;
+      }
+    }
+    if (FOLD >= 2) {
       const vf4 ka = pmu[pass], kb = prs[pass], kc = pk[pass], sv0 = psv[pass][0], sv1 = psv[pass][1];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -536,7 +555,7 @@ __global__ __launch_bounds__(512) void conv_wino64_kernel(const float* __restric
   // red[0..512) / red[512..1024): [w][64], channel index (pass * 2 + jl) * 16 + cq * 4 + e
   const int cidx = jl * 16 + cq * 4;
   const size_t nstat = gridDim.x / nchunks;
-  if (FOLD == 2) {                                 // column sums of the written dy_P only: [blocks][Cout]
+  if (FOLD >= 2) {                                 // column sums of the written dy_P only: [blocks][Cout]
 #pragma unroll
     for (int d = 8; d < 64; d <<= 1)
 #pragma unroll
@@ -660,6 +679,9 @@ int launch_conv_fwd_wino64(hipStream_t st, const ConvGeom& g, const ConvSrc& s0,
   const bool plain = bwd != nullptr && !aff && stat_partial == nullptr && bias == nullptr && pre_act == ACT_NONE &&
                      !accumulate && bwd->ld % 4 == 0;
   const bool apply = plain && bwd->abc != nullptr;           // the producer's BatchNorm-backward apply in the epilogue
+  const bool pool = apply && bwd->pool_d != nullptr;
+  ICS_CHECK(!pool || (bwd->pool_mask != nullptr && bwd->pool_ld % 4 == 0 && g.S % 2 == 0),
+            "Winograd backward-data with a pooled second gradient source: mask / leading dimension");
   ICS_CHECK(bwd == nullptr || bwd->abc == nullptr || (apply && bwd->db_partial != nullptr && bwd->s != nullptr),
             "Winograd backward-data with the fused BatchNorm-backward apply: not a plain launch");
   const bool fold = plain && !apply && bwd->partial != nullptr;
@@ -672,7 +694,8 @@ int launch_conv_fwd_wino64(hipStream_t st, const ConvGeom& g, const ConvSrc& s0,
                        g.Cin, g.Cout, bs);                                                                            \
     conv_set_last_kernel_id("conv_wino64_kernel<" #AFFV ", " #NOACTV ", " #FOLDV ">");                                \
   } while (0)
-  if (apply) ICS_WINO_LAUNCH(false, true, 2);
+  if (pool) ICS_WINO_LAUNCH(false, true, 3);
+  else if (apply) ICS_WINO_LAUNCH(false, true, 2);
   else if (fold) ICS_WINO_LAUNCH(false, true, 1);
   else if (!aff) ICS_WINO_LAUNCH(false, true, 0);
   else if (noact) ICS_WINO_LAUNCH(true, true, 0);

@@ -58,8 +58,12 @@ struct LayerBwd {
 int launch_bn_finalize(hipStream_t st, const float* partial, int nblk, int Npad, const BnParams& bn,
                        int C, int update_moving, int unbias, const BnSync* sync = nullptr);
 int launch_bn_eval_prepare(hipStream_t st, const BnParams& bn, int C);
+// tie_mask / tie_ssum (optional, [rows/8][C]): bit k of a window's mask = element k receives the window's gradient in the
+// backward pass (ties_all: all within kPoolTieTol of the maximum; else the first maximum); the sum of those elements'
+// stored activations
 int launch_pool_fwd(hipStream_t st, const float* s, const float* scale, const float* shift, int act,
-                    int B, int S, int C, float* out, unsigned char* idx);
+                    int B, int S, int C, float* out, unsigned char* idx, unsigned char* tie_mask = nullptr,
+                    float* tie_ssum = nullptr, int ties_all = 1);
 // per-block (sum d, sum d*xhat) already produced by the backward-data launch that wrote dO (BwdStat in common.h):
 // [2][ld][nblk]; nblk == 0 -> not available, run bn_bwd_reduce
 struct BwdPre {
@@ -100,10 +104,15 @@ int launch_head_bnfuse(hipStream_t st, const float* Q, const float* dzsum, const
 // see conv_bnfuse_kernel
 bool conv_bnfuse_ok(int S, int Cin, int N);
 size_t conv_bnfuse_partial_floats(int B, int S, int C);
-int launch_conv_bnfuse(hipStream_t st, const float* dy, int B, int S, int Cin, int N, const float* db_partial, int db_nblk,
-                       const float* W, float* G, const float* gamma, const float* beta, const float* mean, const float* rstd,
-                       const float* scale, float* abc, float* c1c2, float* dgamma, float* dbeta, float* ws_partial,
-                       size_t ws_partial_floats, double* ws_R);
+int launch_conv_bnfuse(hipStream_t st, const float* dy, int B, int S, int Cin, int CinTot, int N, const float* db_partial,
+                       int db_nblk, const float* W, float* G, const float* gamma, const float* beta, const float* mean,
+                       const float* rstd, const float* scale, float* abc, float* c1c2, float* dgamma, float* dbeta,
+                       float* ws_partial, size_t ws_partial_floats, double* ws_R, double* sums_out = nullptr);
+// second gradient source behind a MaxPool3D: its share of the two sums, added to sums_conv (launch_conv_bnfuse's sums_out)
+size_t pool_bnfuse_partial_doubles(size_t pooled_rows, int C);
+int launch_pool_bnfuse(hipStream_t st, const float* g, int ldg, const unsigned char* mask, const float* ssum, size_t pooled_rows,
+                       int C, double cnt, const double* sums_conv, const float* mean, const float* rstd, const float* scale,
+                       float* abc, float* c1c2, float* dgamma, float* dbeta, double* ws_partial, size_t ws_partial_doubles);
 int launch_colsum_finalize(hipStream_t st, const float* partial, int nblk, int C, float* out);
 int launch_head_fused(hipStream_t st, const float* x, int ldx, const float* scale, const float* shift, const float* wsoft_k,
                       const float* wsig_k, const float* bsoft, const float* bsig, float* z, const unsigned char* labels,

@@ -217,7 +217,9 @@ __global__ void pool_fwd_kernel(const float* __restrict__ s, const float* __rest
 // four channels per thread (C % 4 == 0): eight 16-byte loads in flight, one 16-byte and one 4-byte store
 __global__ __launch_bounds__(256) void pool_fwd4_kernel(const float* __restrict__ s, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, int act, int B, int S, int C,
-                                                         float* __restrict__ out, unsigned char* __restrict__ idx) {
+                                                         float* __restrict__ out, unsigned char* __restrict__ idx,
+                                                         unsigned char* __restrict__ tie_mask,
+                                                         float* __restrict__ tie_ssum, int ties_all) {
   typedef float qv4 __attribute__((ext_vector_type(4)));
   const int Sh = S >> 1, C4 = C >> 2;
   const size_t total = (size_t)B * Sh * Sh * Sh * C4;
@@ -248,17 +250,36 @@ __global__ __launch_bounds__(256) void pool_fwd4_kernel(const float* __restrict_
     }
   *reinterpret_cast<qv4*>(out + i * 4) = qv4{best[0], best[1], best[2], best[3]};
   *reinterpret_cast<unsigned*>(idx + i * 4) = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+  if (tie_mask != nullptr) {
+    // which window elements the backward pass routes the gradient to (bit k), and the sum of their stored activations:
+    // what gather_do / the fast BatchNorm-backward kernels decide per voxel, once per window (conv_wino64.hip FOLD = 3,
+    // pool_sums_kernel).  ties_all: every element within kPoolTieTol of the maximum (TF-CPU MaxPool3DGrad), else the first.
+    unsigned mk[4] = {0, 0, 0, 0};
+    float ss[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float o = act_fwd(fmaf(q[k][j], sc[j], sh[j]), act);
+        const bool hit = ties_all ? fabsf(o - best[j]) < kPoolTieTol : bi[j] == (unsigned)k;
+        if (hit) { mk[j] |= 1u << k; ss[j] += q[k][j]; }
+      }
+    *reinterpret_cast<unsigned*>(tie_mask + i * 4) = mk[0] | (mk[1] << 8) | (mk[2] << 16) | (mk[3] << 24);
+    *reinterpret_cast<qv4*>(tie_ssum + i * 4) = qv4{ss[0], ss[1], ss[2], ss[3]};
+  }
 }
 
 int launch_pool_fwd(hipStream_t st, const float* s, const float* scale, const float* shift, int act,
-                    int B, int S, int C, float* out, unsigned char* idx) {
+                    int B, int S, int C, float* out, unsigned char* idx, unsigned char* tie_mask, float* tie_ssum,
+                    int ties_all) {
   if (C % 4 == 0 && ((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(idx)) & 15) == 0) {
     const size_t total4 = (size_t)B * (S / 2) * (S / 2) * (S / 2) * (C / 4);
     ICS_LAUNCH(pool_fwd4_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, s, scale, shift, act, B,
-                       S, C, out, idx);
+                       S, C, out, idx, tie_mask, tie_ssum, ties_all);
     ICS_HIP(hipGetLastError());
     return 0;
   }
+  ICS_CHECK(tie_mask == nullptr, "pool forward: the tie masks need the four-channel kernel");
   const size_t total = (size_t)B * (S / 2) * (S / 2) * (S / 2) * C;
   ICS_LAUNCH(pool_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, s, scale,
                      shift, act, B, S, C, out, idx);
@@ -825,7 +846,15 @@ __global__ __launch_bounds__(256) void colsum_batch_kernel(ColsumJobs J) {
   if (C % 4 == 0) {
     const int c0 = ((int)blockIdx.x - J.blk0[j]) * 4;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    for (int b = threadIdx.x; b < nblk; b += 256) {
+    int b = threadIdx.x;
+    for (; b + 768 < nblk; b += 1024) {           // four rows in flight per thread (same order of additions)
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(partial + (size_t)(b + 256 * u) * C + c0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { a0 += (double)v[u].x; a1 += (double)v[u].y; a2 += (double)v[u].z; a3 += (double)v[u].w; }
+    }
+    for (; b < nblk; b += 256) {
       const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)b * C + c0);
       a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
     }
@@ -1483,16 +1512,20 @@ __global__ __launch_bounds__(1024) void class_reduce_kernel(const float* __restr
   }
 }
 // one block per input channel c of L (= channel of P)
+// CinTot: row pitch of W / G in channels (an up-split layer's skip channels are its first gridDim.x of CinTot);
+// sums_out != nullptr: only the weight-gradient fix and the two sums [2][gridDim.x] (the producer has a second gradient
+// source whose sums are added later: pool_bnfuse_kernel)
 __global__ __launch_bounds__(256) void conv_bnfuse_kernel(const double* __restrict__ R, const float* __restrict__ W,
-                                                          float* __restrict__ G, int Cin, int N,
+                                                          float* __restrict__ G, int CinTot, int N,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
                                                           const float* __restrict__ scale, double cnt,
                                                           float* __restrict__ abc, float* __restrict__ c1c2,
-                                                          float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                          double* __restrict__ sums_out) {
   extern __shared__ double St[];          // [27][N]
   __shared__ double sh1[4], sh2[4];
-  const int c = blockIdx.x;
+  const int c = blockIdx.x, Cin = gridDim.x;
   constexpr int PF = 14;                  // this thread's (t, n) entries, requested ahead of the class-sum phase (N <= 128)
   float wpf[PF], qpf[PF];
   const bool pf = 27 * N <= PF * 256;
@@ -1501,7 +1534,7 @@ __global__ __launch_bounds__(256) void conv_bnfuse_kernel(const double* __restri
     for (int k = 0; k < PF; ++k) {
       const int i = threadIdx.x + k * 256;
       const int t = i / N, n = i - t * N;
-      const size_t idx = ((size_t)t * Cin + c) * N + n;
+      const size_t idx = ((size_t)t * CinTot + c) * N + n;
       wpf[k] = i < 27 * N ? W[idx] : 0.f;
       qpf[k] = i < 27 * N ? G[idx] : 0.f;
     }
@@ -1535,7 +1568,7 @@ __global__ __launch_bounds__(256) void conv_bnfuse_kernel(const double* __restri
       const int i = threadIdx.x + k * 256;
       if (i < 27 * N) {
         const int t = i / N, n = i - t * N;
-        const size_t idx = ((size_t)t * Cin + c) * N + n;
+        const size_t idx = ((size_t)t * CinTot + c) * N + n;
         const float w = wpf[k], q = qpf[k];
         const double sv = St[i];
         pd += (double)w * sv;
@@ -1546,7 +1579,7 @@ __global__ __launch_bounds__(256) void conv_bnfuse_kernel(const double* __restri
   } else {
   for (int i = threadIdx.x; i < 27 * N; i += 256) {
     const int t = i / N, n = i - t * N;
-    const size_t idx = ((size_t)t * Cin + c) * N + n;
+    const size_t idx = ((size_t)t * CinTot + c) * N + n;
     const float w = W[idx], q = G[idx];
     const double sv = St[i];
     pd += (double)w * sv;
@@ -1559,6 +1592,7 @@ __global__ __launch_bounds__(256) void conv_bnfuse_kernel(const double* __restri
   __syncthreads();
   if (threadIdx.x == 0) {
     const double sd = (sh1[0] + sh1[1]) + (sh1[2] + sh1[3]), sq = (sh2[0] + sh2[1]) + (sh2[2] + sh2[3]);
+    if (sums_out != nullptr) { sums_out[c] = sd; sums_out[Cin + c] = sq; return; }
     const double k1 = sd / cnt, k2 = sq / cnt, sc = (double)scale[c], rs = (double)rstd[c], mu = (double)mean[c];
     abc[c] = (float)sc;
     abc[Cin + c] = (float)(-sc * k2 * rs);
@@ -1592,18 +1626,95 @@ bool conv_bnfuse_ok(int S, int Cin, int N) {
   return S >= 3 && N % 4 == 0 && C4 <= 256 && 256 % C4 == 0 && (C4 & (C4 - 1)) == 0 && (size_t)27 * N * sizeof(double) <= 60 * 1024 && Cin > 0;
 }
 // dy [B S^3][N] -> G (in: the xhat-sourced weight-gradient GEMM; out: L's weight gradient), abc / c1c2 / dgamma / dbeta of P
-int launch_conv_bnfuse(hipStream_t st, const float* dy, int B, int S, int Cin, int N, const float* db_partial, int db_nblk,
-                       const float* W, float* G, const float* gamma, const float* beta, const float* mean, const float* rstd,
-                       const float* scale, float* abc, float* c1c2, float* dgamma, float* dbeta, float* ws_partial,
-                       size_t ws_partial_floats, double* ws_R) {
+int launch_conv_bnfuse(hipStream_t st, const float* dy, int B, int S, int Cin, int CinTot, int N, const float* db_partial,
+                       int db_nblk, const float* W, float* G, const float* gamma, const float* beta, const float* mean,
+                       const float* rstd, const float* scale, float* abc, float* c1c2, float* dgamma, float* dbeta,
+                       float* ws_partial, size_t ws_partial_floats, double* ws_R, double* sums_out) {
   ICS_CHECK(conv_bnfuse_ok(S, Cin, N), "conv BN-fuse: unsupported shape");
   int nb = 0;
   const ClassBlocks cb = class_blocks(B, S, &nb);
   ICS_CHECK((size_t)nb * N <= ws_partial_floats, "conv BN-fuse: class-sum workspace too small");
   ICS_LAUNCH(class_sums_kernel, dim3(nb), dim3(256), 0, st, dy, B, S, N, cb, ws_partial);
   ICS_LAUNCH(class_reduce_kernel, dim3(26 + kTotalSplit), dim3(1024), 0, st, ws_partial, cb, N, db_partial, db_nblk, ws_R);
-  ICS_LAUNCH(conv_bnfuse_kernel, dim3(Cin), dim3(256), (size_t)27 * N * sizeof(double), st, ws_R, W, G, Cin, N, gamma, beta,
-             mean, rstd, scale, (double)B * S * S * S, abc, c1c2, dgamma, dbeta);
+  ICS_LAUNCH(conv_bnfuse_kernel, dim3(Cin), dim3(256), (size_t)27 * N * sizeof(double), st, ws_R, W, G, CinTot, N, gamma, beta,
+             mean, rstd, scale, (double)B * S * S * S, abc, c1c2, dgamma, dbeta, sums_out);
+  ICS_HIP(hipGetLastError());
+  return 0;
+}
+// The MaxPool3D consumer's share of the producer's two sums, on the pooled grid: a window hands its gradient g to the
+// k elements of its tie mask, so  sum_v d = sum_w k g  and  sum_v d xhat = sum_w g (ssum - k mean) rstd  with ssum the
+// sum of the stored activations of those elements (launch_pool_fwd).  partial [blocks][2][C] doubles.
+constexpr int kPoolSumRows = 64;          // pooled rows per block
+__global__ __launch_bounds__(256) void pool_sums_kernel(const float* __restrict__ g, int ldg, const unsigned char* __restrict__ mask,
+                                                        const float* __restrict__ ssum, const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd, size_t rows, int C,
+                                                        double* __restrict__ partial) {
+  __shared__ dbl4 sh[2][256];
+  const int C4 = C >> 2, c4 = threadIdx.x % C4, rg = threadIdx.x / C4, RG = 256 / C4, c = c4 * 4;
+  const size_t r0 = (size_t)blockIdx.x * kPoolSumRows;
+  const size_t r1 = r0 + kPoolSumRows < rows ? r0 + kPoolSumRows : rows;
+  const hv4 mu = *reinterpret_cast<const hv4*>(mean + c), rs = *reinterpret_cast<const hv4*>(rstd + c);
+  dbl4 a{0.0, 0.0, 0.0, 0.0}, q{0.0, 0.0, 0.0, 0.0};
+  for (size_t r = r0 + rg; r < r1; r += RG) {
+    const hv4 gv = *reinterpret_cast<const hv4*>(g + r * ldg + c);
+    const hv4 sv = *reinterpret_cast<const hv4*>(ssum + r * C + c);
+    const unsigned m = *reinterpret_cast<const unsigned*>(mask + r * C + c);
+    float kf[4], xs[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      kf[j] = (float)__popc((m >> (8 * j)) & 0xffu);
+      xs[j] = (sv[j] - kf[j] * mu[j]) * rs[j];
+    }
+    a.x += (double)(gv[0] * kf[0]); a.y += (double)(gv[1] * kf[1]); a.z += (double)(gv[2] * kf[2]); a.w += (double)(gv[3] * kf[3]);
+    q.x += (double)(gv[0] * xs[0]); q.y += (double)(gv[1] * xs[1]); q.z += (double)(gv[2] * xs[2]); q.w += (double)(gv[3] * xs[3]);
+  }
+  sh[0][threadIdx.x] = a; sh[1][threadIdx.x] = q;
+  __syncthreads();
+  if (rg == 0) {
+    for (int r = 1; r < RG; ++r) {
+      const dbl4 b1 = sh[0][r * C4 + c4], b2 = sh[1][r * C4 + c4];
+      a.x += b1.x; a.y += b1.y; a.z += b1.z; a.w += b1.w;
+      q.x += b2.x; q.y += b2.y; q.z += b2.z; q.w += b2.w;
+    }
+    double* o = partial + (size_t)blockIdx.x * 2 * C;
+    o[c] = a.x; o[c + 1] = a.y; o[c + 2] = a.z; o[c + 3] = a.w;
+    o[C + c] = q.x; o[C + c + 1] = q.y; o[C + c + 2] = q.z; o[C + c + 3] = q.w;
+  }
+}
+// one block per channel: (conv consumer's sums) + (pool consumer's block partials) -> the apply's constants
+__global__ __launch_bounds__(256) void pool_bnfuse_kernel(const double* __restrict__ sums_conv, const double* __restrict__ partial,
+                                                          int nblk, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          const float* __restrict__ scale, double cnt, float* __restrict__ abc,
+                                                          float* __restrict__ c1c2, float* __restrict__ dgamma,
+                                                          float* __restrict__ dbeta) {
+  __shared__ double sh[4];
+  const int c = blockIdx.x, C = gridDim.x;
+  double a = 0.0, q = 0.0;
+  for (int k = threadIdx.x; k < nblk; k += 256) { a += partial[(size_t)k * 2 * C + c]; q += partial[(size_t)k * 2 * C + C + c]; }
+  a = block_sum_d(a, sh);
+  q = block_sum_d(q, sh);
+  if (threadIdx.x == 0) {
+    const double sd = sums_conv[c] + a, sq = sums_conv[C + c] + q;
+    const double k1 = sd / cnt, k2 = sq / cnt, sc = (double)scale[c], rs = (double)rstd[c], mu = (double)mean[c];
+    abc[c] = (float)sc;
+    abc[C + c] = (float)(-sc * k2 * rs);
+    abc[2 * C + c] = (float)(sc * (k2 * rs * mu - k1));
+    c1c2[c] = (float)k1; c1c2[C + c] = (float)k2;
+    dgamma[c] = (float)sq;
+    dbeta[c] = (float)sd;
+  }
+}
+size_t pool_bnfuse_partial_doubles(size_t pooled_rows, int C) { return (pooled_rows + kPoolSumRows - 1) / kPoolSumRows * 2 * C; }
+int launch_pool_bnfuse(hipStream_t st, const float* g, int ldg, const unsigned char* mask, const float* ssum, size_t pooled_rows,
+                       int C, double cnt, const double* sums_conv, const float* mean, const float* rstd, const float* scale,
+                       float* abc, float* c1c2, float* dgamma, float* dbeta, double* ws_partial, size_t ws_partial_doubles) {
+  const int C4 = C / 4;
+  ICS_CHECK(C % 4 == 0 && C4 <= 256 && 256 % C4 == 0 && ldg % 4 == 0, "pool BN-fuse: unsupported channel count");
+  const size_t nblk = (pooled_rows + kPoolSumRows - 1) / kPoolSumRows;
+  ICS_CHECK(nblk * 2 * C <= ws_partial_doubles, "pool BN-fuse: workspace too small");
+  ICS_LAUNCH(pool_sums_kernel, dim3((unsigned)nblk), dim3(256), 0, st, g, ldg, mask, ssum, mean, rstd, pooled_rows, C, ws_partial);
+  ICS_LAUNCH(pool_bnfuse_kernel, dim3(C), dim3(256), 0, st, sums_conv, ws_partial, (int)nblk, mean, rstd, scale, cnt, abc, c1c2,
+             dgamma, dbeta);
   ICS_HIP(hipGetLastError());
   return 0;
 }

@@ -141,6 +141,13 @@ struct ConvLayer {
   float* xs = nullptr;                  // [2][Cout] xhat as an affine of the stored activation
   float* abc = nullptr;                 // [3][Cout] the apply's per-channel constants
   bool dy_ready = false;                // dy was written by the consumer's backward-data launch: skip bn_act_bwd
+  // ... and the same for a layer with TWO consumers, a skip concat and a MaxPool3D (c2): the skip consumer's backward-data
+  // launch is deferred until the pool consumer's gradient exists and then writes this layer's dy (conv_wino64.hip FOLD = 3)
+  unsigned char* tie_mask = nullptr;    // [M/8][Cout] which window elements receive the pooled gradient (launch_pool_fwd)
+  float* tie_ssum = nullptr;            // [M/8][Cout] sum of their stored activations
+  double* bn_sums = nullptr;            // [2][Cout] the skip consumer's share of (sum d, sum d xhat)
+  ConvLayer* skip_prod = nullptr;       // on the CONSUMER (c17): the layer its skip channels come from
+  ConvLayer* deferred_skip = nullptr;   // on the PRODUCER (c2): consumer whose skip backward-data launch is pending
   float* pooled = nullptr;              // MaxPool3D(o) if a pool follows
   unsigned char* pool_idx = nullptr;
   ConvSrc src[2];
@@ -227,6 +234,7 @@ struct Net {
   ColsumJobs colsum{};               // bias-gradient finalizes pending since the last flush (colsum_flush)
   float* ws_cls = nullptr; size_t ws_cls_n = 0;   // conv_bnfuse: per-block border-class sums of a dy
   double* ws_R = nullptr;                         // [27][Cmax] class sums
+  double* ws_pool = nullptr; size_t ws_pool_n = 0;  // pool_sums_kernel's block partials
   size_t bnfuse_min_bytes = (size_t)64 << 20;     // producer activation size from which the fusion pays (ICSG3D_DGRAD_BNFUSE_MIN)
 
   // U-Net specifics
@@ -365,6 +373,11 @@ static int alloc_layer(Net& n, ConvLayer& L, bool need_bwd, bool pooled) {
   if (pooled) {
     ICS_TRY(n.alloc(&L.pooled, M / 8 * L.Cout));
     ICS_TRY(n.alloc(&L.pool_idx, M / 8 * L.Cout));
+    if (need_bwd && L.has_bn && L.Cout % 4 == 0) {
+      ICS_TRY(n.alloc(&L.tie_mask, M / 8 * L.Cout));
+      ICS_TRY(n.alloc(&L.tie_ssum, M / 8 * L.Cout));
+      ICS_TRY(n.alloc(&L.bn_sums, (size_t)2 * L.Cout));
+    }
   }
   return 0;
 }
@@ -546,6 +559,11 @@ static int alloc_workspaces(Net& n, bool need_bwd) {
     n.ws_cls_n = cls;
     ICS_TRY(n.alloc(&n.ws_cls, cls + 16));
     ICS_TRY(n.alloc(&n.ws_R, (size_t)48 * cmax + 16));
+    size_t pl = 0;
+    for (auto& Lp : n.layers)
+      if (Lp->tie_mask) pl = std::max(pl, pool_bnfuse_partial_doubles(n.rows(*Lp, n.maxB) / 8, Lp->Cout));
+    n.ws_pool_n = pl;
+    ICS_TRY(n.alloc(&n.ws_pool, pl + 16));
     if (const char* e = getenv("ICSG3D_DGRAD_BNFUSE_MIN")) n.bnfuse_min_bytes = (size_t)atoll(e);
   }
   n.ws_dbl_n = 1 << 16;
@@ -713,8 +731,10 @@ static int conv_forward(Net& n, ConvLayer& L, int B, bool training, bool update_
   }
   if (L.pooled) {
     n.prof.begin(n.st, "pool_fwd", 0, 4.0 * M * L.Cout * 1.125);
+    const bool ties = training && L.tie_mask != nullptr && n.want_wgrad_inputs;   // only a train step's backward reads them
     ICS_TRY(launch_pool_fwd(n.st, L.s, L.has_bn ? L.scale : nullptr, L.shift, L.has_bn ? L.post_act : ACT_NONE,
-                            B, L.S, L.Cout, L.pooled, L.pool_idx));
+                            B, L.S, L.Cout, L.pooled, L.pool_idx, ties ? L.tie_mask : nullptr, ties ? L.tie_ssum : nullptr,
+                            n.pool_ties_all));
     n.prof.end(n.st);
   }
   return 0;
@@ -786,9 +806,31 @@ static void bwd_stat_done(ConvLayer* next, const BwdStat& bs, int blocks, int np
 // Up-split backward of a [skip | upsampled] concat conv: with dyS = dy pooled per tap onto the low-res
 // grid (pool27), the up channels need only  dW_up = xl^T dyS  and  dxl = dyS W_up  on M/8 rows; the skip
 // channels run the ordinary kernels on a Cs-channel problem.  Exact (a reassociation of the same sums).
+// Round 4, second form of the BatchNorm-backward fusion (see dgrad_bnfuse_ok below): the producer P of L's skip channels has a
+// second consumer behind a MaxPool3D (c2: c17's skip channels and c3).  L's share of P's two sums comes from L's skip
+// weight-gradient GEMM (on xhat) right here; L's skip backward-data launch waits until the pool consumer's gradient
+// exists (conv_backward of P), takes the constants, adds the routed pool gradient and writes P's dy: P's reduce AND
+// apply passes disappear (c2: 0.13 + 0.16 ms).
+static bool skip_bnfuse_ok(const Net& n, const ConvLayer& L, int B) {
+  const ConvLayer* P = L.skip_prod;
+  if (P == nullptr || !L.split_up || L.Cs == 0 || (n.flags & CF_NO_DGRAD_BNFUSE) || n.sync() != nullptr || n.side_on) return false;
+  if (!P->has_bn || P->pre_act != ACT_RELU || P->post_act != ACT_NONE || P->tie_mask == nullptr || P->xs == nullptr ||
+      P->db_partial == nullptr || !P->pooled || P->Cout != L.Cs || L.src[0].p != P->s || L.src[0].scale == nullptr ||
+      L.src[0].act != ACT_NONE || !n.want_wgrad_inputs)
+    return false;
+  if (!L.wino_w || !L.wwb || L.wwb_layout != 1) return false;
+  if (n.rows(L, B) * (size_t)P->Cout * sizeof(float) < 2 * n.bnfuse_min_bytes) return false;
+  const ConvGeom gw = geom_skip_wgrad(L, B), gd = geom_skip_dgrad(L, B);
+  const ConvSrc sdy = src_plain(L.dy, L.Cout);
+  return conv_bnfuse_ok(L.S, L.Cs, L.Cout) && conv_wino_wgrad_ok(gw, L.src, 1) && conv_wino_ok(gd, &sdy, 1) &&
+         conv_bnfuse_partial_floats(B, L.S, L.Cout) <= n.ws_cls_n && L.Cs % 4 == 0 &&
+         pool_bnfuse_partial_doubles(n.rows(L, B) / 8, P->Cout) <= n.ws_pool_n;
+}
 static int conv_grads_split_up(Net& n, ConvLayer& L, int B, ConvLayer* next) {
   const size_t M = n.rows(L, B);
   const double fl_skip = 2.0 * M * 27 * L.Cs * L.Cout, fl_up = 2.0 * (M / 8) * 27 * L.Cu * L.Cout;
+  const bool skipfuse = skip_bnfuse_ok(n, L, B);
+  ConvLayer* P = L.skip_prod;
   n.prof.begin(n.st, "pool27:" + L.name, 0, 4.0 * M * L.Cout * (1 + 27.0 / 8));
   ICS_TRY(launch_pool27(n.st, L.dy, B, L.S, L.Cout, L.dyS, L.ldS));
   n.prof.end(n.st);
@@ -798,8 +840,10 @@ static int conv_grads_split_up(Net& n, ConvLayer& L, int B, ConvLayer* next) {
     n.prof.begin(ws, "conv_wgrad:" + L.name + ".skip|", fl_skip,
                  4.0 * (M * L.Cs + M * L.Cout + 27.0 * L.Cs * L.Cout));
     const bool wino = L.wino_w && conv_wino_wgrad_ok(g, L.src, 1);
+    ConvSrc sx = L.src[0];
+    if (skipfuse) { sx.scale = P->xs; sx.shift = P->xs + P->Cout; }   // the GEMM on xhat (conv_bnfuse_kernel)
     if (wino)
-      ICS_TRY(launch_conv_wgrad_wino(ws, g, L.src[0], L.dy, L.Cout, n.tg(L.t_w), L.Cout, n.ws_wgrad, n.ws_wgrad_n,
+      ICS_TRY(launch_conv_wgrad_wino(ws, g, sx, L.dy, L.Cout, n.tg(L.t_w), L.Cout, n.ws_wgrad, n.ws_wgrad_n,
                                      L.Cs, L.Cin, 0, 1));
     else
     ICS_TRY(launch_conv_wgrad(ws, g, L.src, 1, L.dy, L.Cout, n.tg(L.t_w), L.Cout, n.ws_wgrad, n.ws_wgrad_n, L.Cs,
@@ -807,12 +851,21 @@ static int conv_grads_split_up(Net& n, ConvLayer& L, int B, ConvLayer* next) {
     n.prof.end(ws);
     n.prof.begin(ws, "wgrad_reduce_splits", 0, 0);
     if (wino)
-      ICS_TRY(launch_conv_wgrad_wino(ws, g, L.src[0], L.dy, L.Cout, n.tg(L.t_w), L.Cout, n.ws_wgrad, n.ws_wgrad_n,
+      ICS_TRY(launch_conv_wgrad_wino(ws, g, sx, L.dy, L.Cout, n.tg(L.t_w), L.Cout, n.ws_wgrad, n.ws_wgrad_n,
                                      L.Cs, L.Cin, 0, 2));
     else
     ICS_TRY(launch_conv_wgrad(ws, g, L.src, 1, L.dy, L.Cout, n.tg(L.t_w), L.Cout, n.ws_wgrad, n.ws_wgrad_n, L.Cs,
                               L.Cin, 0, 2));
     n.prof.end(ws);
+    if (skipfuse) {     // the skip rows of dW become final here (the gradient buckets may leave before P's backward)
+      const bool pend = L.db_blocks > 0;
+      n.prof.begin(ws, "bnfuse:" + L.name + ".skip", 0, 0);
+      ICS_TRY(launch_conv_bnfuse(ws, L.dy, B, L.S, L.Cs, L.Cin, L.Cout, pend ? L.db_partial : n.tg(L.t_b), pend ? L.db_blocks : 1,
+                                 n.tp(L.t_w), n.tg(L.t_w), n.tp(P->t_gamma), n.tp(P->t_beta), P->mean, P->rstd, P->scale,
+                                 nullptr, nullptr, nullptr, nullptr, n.ws_cls, n.ws_cls_n, n.ws_R, P->bn_sums));
+      n.prof.end(ws);
+      P->deferred_skip = &L;
+    }
   }
   {
     const ConvGeom g = geom_up_wgrad(L, B);
@@ -826,7 +879,7 @@ static int conv_grads_split_up(Net& n, ConvLayer& L, int B, ConvLayer* next) {
     ICS_TRY(launch_permute_up_dw(ws, L.dw_up, L.Cu, L.Cout, L.Cin, L.Cs, n.tg(L.t_w)));
     n.prof.end(ws);
   }
-  if (L.Cs) {
+  if (L.Cs && !skipfuse) {
     const ConvGeom g = geom_skip_dgrad(L, B);
     ConvSrc sdy = src_plain(L.dy, L.Cout);
     n.prof.begin(n.st, "conv_dgrad:" + L.name + ".skip|", fl_skip,
@@ -927,7 +980,7 @@ static int conv_grads_from_dy(Net& n, ConvLayer& L, int B, bool need_dA, bool pa
         // L's total column sums of dy: its bias-gradient partials if their finalize is still pending, else the gradient
         const bool pend = L.db_blocks > 0;
         n.prof.begin(ws, "bnfuse:" + L.name, 0, 0);
-        ICS_TRY(launch_conv_bnfuse(ws, L.dy, B, L.S, L.Cin, L.Cout, pend ? L.db_partial : n.tg(L.t_b), pend ? L.db_blocks : 1,
+        ICS_TRY(launch_conv_bnfuse(ws, L.dy, B, L.S, L.Cin, L.Cin, L.Cout, pend ? L.db_partial : n.tg(L.t_b), pend ? L.db_blocks : 1,
                                    n.tp(L.t_w), dw, n.tp(next->t_gamma), n.tp(next->t_beta), next->mean, next->rstd,
                                    next->scale, next->abc, next->c1c2, n.tg(next->t_gamma), n.tg(next->t_beta), n.ws_cls,
                                    n.ws_cls_n, n.ws_R));
@@ -1017,6 +1070,32 @@ static int conv_backward(Net& n, ConvLayer& L, int B, GradSrc g0, GradSrc g1, co
   const size_t M = n.rows(L, B);
   if (L.dy_ready) {                  // written by the consumer's backward-data launch (conv_grads_from_dy, bnfuse)
     L.dy_ready = false;
+    return conv_grads_from_dy(n, L, B, need_dA, param_grads, next);
+  }
+  if (L.deferred_skip != nullptr) {  // skip_bnfuse_ok: g0 is the pool consumer's gradient, g1 the pending skip launch
+    ConvLayer& K = *L.deferred_skip;
+    L.deferred_skip = nullptr;
+    ICS_CHECK(g0.kind == GS_POOL && g0.off == 0 && param_grads && tap < 0 && dtap == nullptr,
+              "deferred skip backward-data: the producer's other gradient source must be its MaxPool3D");
+    n.prof.begin(n.st, "bnfuse:" + L.name + ".pool", 0, 0);
+    ICS_TRY(launch_pool_bnfuse(n.st, g0.p, g0.ld, L.tie_mask, L.tie_ssum, M / 8, L.Cout, (double)M, L.bn_sums, L.mean, L.rstd,
+                               L.scale, L.abc, L.c1c2, n.tg(L.t_gamma), n.tg(L.t_beta), n.ws_pool, n.ws_pool_n));
+    n.prof.end(n.st);
+    const ConvGeom g = geom_skip_dgrad(K, B);
+    ConvSrc sdy = src_plain(K.dy, K.Cout);
+    n.prof.begin(n.st, "conv_dgrad:" + K.name + ".skip|", 2.0 * M * 27 * K.Cs * K.Cout,
+                 4.0 * (M * K.Cs + M * K.Cout + 27.0 * K.Cs * K.Cout));
+    BwdStat ba{};
+    ba.s = L.s; ba.ld = L.Cout; ba.abc = L.abc; ba.db_partial = L.db_partial;
+    ba.pool_d = g0.p; ba.pool_ld = g0.ld; ba.pool_mask = L.tie_mask;
+    int blocks = 0;
+    ICS_TRY(launch_conv_fwd_wino(n.st, g, sdy, K.wwb, nullptr, L.dy, L.Cout, ACT_NONE, nullptr, nullptr, 0, K.wwb_layout, &ba,
+                                 &blocks));
+    n.prof.end(n.st);
+    ICS_CHECK(blocks > 0, "deferred skip backward-data: the launch did not take the fused apply");
+    L.db_blocks = 0;
+    if (n.flags & CF_NO_TICKET) ICS_TRY(launch_colsum_finalize(n.st, L.db_partial, blocks, L.Cout, n.tg(L.t_b)));
+    else { ICS_TRY(colsum_push(n, L.db_partial, blocks, L.Cout, n.tg(L.t_b))); L.db_blocks = blocks; }
     return conv_grads_from_dy(n, L, B, need_dA, param_grads, next);
   }
   const BwdPre pre{n.ws_bwd2, L.bwd_pre_nblk, L.bwd_pre_ld};
@@ -1162,6 +1241,7 @@ static int unet_build(Net& n, const ics_unet_config& cfg) {
   r.c17->src[0] = src_layer(*r.c2, 0); r.c17->src[1] = src_layer(*r.c16, 1); r.c17->nsrc = 2;
   r.c18->src[0] = src_layer(*r.c17, 0);
   n.head->src[0] = src_layer(*r.c18, 0);
+  r.c13->skip_prod = r.c6; r.c15->skip_prod = r.c4; r.c17->skip_prod = r.c2;
   use_padded_input(*r.c1);
   ICS_TRY(enable_split_up(n, *r.c13)); ICS_TRY(enable_split_up(n, *r.c15)); ICS_TRY(enable_split_up(n, *r.c17));
   for (int i = 0; i < 14; ++i) ICS_TRY(enable_wino(n, *n.layers[i], true));
