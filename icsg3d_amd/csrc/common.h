@@ -1,6 +1,7 @@
 // Shared declarations for the icsg3d_amd HIP library (gfx950 / MI355X only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <atomic>
 #include <cstdint>
 #include <cstdio>
@@ -13,10 +14,29 @@ namespace ics {
 // number rocprofv3 --kernel-trace reports for the same run minus the runtime's own copy / fill kernels and RCCL's
 // (ics_kernel_launches; bench.py's kernel_launches_per_step).
 extern std::atomic<long long> g_kernel_launches;
+// Per-launch timing (engine.hip Profiler): while a LaunchTimer is installed on this thread, every launch carries its own
+// start / stop event pair in the dispatch itself (hipExtLaunchKernelGGL) instead of two hipEventRecord markers on the
+// stream around it -- the markers cost the timed region ~10 us per bracket (0.16 ms per U-Net step in round 4's bench).
+struct LaunchTimer {
+  virtual void next(hipEvent_t* start, hipEvent_t* stop) = 0;
+  virtual ~LaunchTimer() = default;
+};
+extern thread_local LaunchTimer* tl_launch_timer;
+template <typename... P, typename... A>
+inline void ics_launch(void (*kernel)(P...), dim3 grid, dim3 block, size_t shmem, hipStream_t st, A&&... args) {
+  static_assert(sizeof...(P) == sizeof...(A), "kernel argument count");
+  if (tl_launch_timer != nullptr) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    tl_launch_timer->next(&e0, &e1);
+    hipExtLaunchKernelGGL(kernel, grid, block, (std::uint32_t)shmem, st, e0, e1, 0u, static_cast<P>(args)...);
+  } else {
+    hipLaunchKernelGGL(kernel, grid, block, shmem, st, static_cast<P>(args)...);
+  }
+}
 #define ICS_LAUNCH(...)                                      \
   do {                                                       \
     ::ics::g_kernel_launches.fetch_add(1, std::memory_order_relaxed); \
-    hipLaunchKernelGGL(__VA_ARGS__);                         \
+    ::ics::ics_launch(__VA_ARGS__);                          \
   } while (0)
 
 // ---------------------------------------------------------------- error plumbing

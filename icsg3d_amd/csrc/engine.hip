@@ -28,6 +28,7 @@ struct Range {
 };
 
 std::atomic<long long> g_kernel_launches{0};
+thread_local LaunchTimer* tl_launch_timer = nullptr;
 static thread_local std::string g_err;
 void set_error(const std::string& msg) { g_err = msg; }
 
@@ -48,11 +49,15 @@ struct Tensor {
   float* ptr = nullptr;  // device pointer (state tensors own theirs; trainable: P + off)
 };
 
-struct Profiler {
+struct Profiler : LaunchTimer {
   struct Row { std::string label; int64_t launches = 0; double ms = 0, flop = 0, bytes = 0; };
-  struct Pending { int row; hipEvent_t a, b; std::string label; double flop, bytes; };
+  struct Pending { int row; std::vector<hipEvent_t> ev; std::string label; double flop, bytes; };   // ev: (start, stop) pairs
   bool on = false;
   bool active = false;                  // the bracket being measured passed the filter
+  // default: every kernel launched inside a bracket carries its own event pair (common.h LaunchTimer) and the bracket's
+  // time is the sum of its kernels' durations; ICSG3D_PROF_BRACKET=1: two hipEventRecord markers around the bracket (also
+  // sees what is not a kernel of this library -- RCCL calls, copies -- and costs ~10 us of stream time per bracket)
+  bool bracket = getenv("ICSG3D_PROF_BRACKET") != nullptr;
   std::string filter;                   // non-empty: only launch sites whose label starts with it get events
   std::vector<Row> rows;
   std::map<std::string, int> index;
@@ -62,21 +67,26 @@ struct Profiler {
     if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
     hipEvent_t e; (void)hipEventCreate(&e); return e;
   }
+  void next(hipEvent_t* a, hipEvent_t* b) override {
+    *a = get(); *b = get();
+    pending.back().ev.push_back(*a); pending.back().ev.push_back(*b);
+  }
   // A label ending in '|' gets the exact template instantiation of the conv kernel launched inside the
   // bracket appended at end() (conv_last_kernel_id(): the name rocprofv3 prints for the same launch).
   void begin(hipStream_t st, const std::string& label, double flop, double bytes) {
     if (!on) return;
     active = filter.empty() || label.compare(0, filter.size(), filter) == 0;
     if (!active) return;
-    Pending p{-1, get(), get(), label, flop, bytes};
-    (void)hipEventRecord(p.a, st);
-    pending.push_back(p);
+    pending.push_back(Pending{-1, {}, label, flop, bytes});
+    if (bracket) { hipEvent_t a = get(); (void)hipEventRecord(a, st); pending.back().ev.push_back(a); }
+    else tl_launch_timer = this;
   }
   void end(hipStream_t st) {
     if (!on || !active) return;
     active = false;
+    tl_launch_timer = nullptr;
     Pending& p = pending.back();
-    (void)hipEventRecord(p.b, st);
+    if (bracket) { hipEvent_t b = get(); (void)hipEventRecord(b, st); p.ev.push_back(b); }
     if (!p.label.empty() && p.label.back() == '|') p.label += conv_last_kernel_id();
     auto it = index.find(p.label);
     int r;
@@ -87,15 +97,18 @@ struct Profiler {
   }
   void resolve() {   // call after a stream sync
     for (auto& p : pending) {
-      float ms = 0.f;
-      if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) rows[p.row].ms += ms;
-      pool.push_back(p.a); pool.push_back(p.b);
+      for (size_t i = 0; i + 1 < p.ev.size(); i += 2) {
+        float ms = 0.f;
+        if (p.row >= 0 && hipEventElapsedTime(&ms, p.ev[i], p.ev[i + 1]) == hipSuccess) rows[p.row].ms += ms;
+      }
+      for (hipEvent_t e : p.ev) pool.push_back(e);
     }
     pending.clear();
   }
   void reset() { resolve(); rows.clear(); index.clear(); }
   ~Profiler() {
-    for (auto& p : pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    if (tl_launch_timer == this) tl_launch_timer = nullptr;
+    for (auto& p : pending) for (hipEvent_t e : p.ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : pool) (void)hipEventDestroy(e);
   }
 };
