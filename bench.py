@@ -192,8 +192,8 @@ def main():
         prefix = ""
         if gem:
             dom_rows = max(gem.values(), key=lambda rs: sum(r["ms"] for r in rs))
-            prefix = os.path.commonprefix([r["label"].split("|", 1)[0] for r in dom_rows])
-            prefix = prefix.split(":", 1)[0] + ":" if ":" in prefix else prefix
+            # exactly the launch sites the dominant kernel ran at (';'-separated label prefixes, each up to its '|')
+            prefix = ";".join(sorted({r["label"].split("|", 1)[0] + "|" for r in dom_rows}))
         # timed region: events only around the dominant kernel's launch sites (its live average duration is the
         # roofline's denominator); every other launch runs as in a training job
         for e in profiled:

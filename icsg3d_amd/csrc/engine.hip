@@ -58,7 +58,7 @@ struct Profiler : LaunchTimer {
   // time is the sum of its kernels' durations; ICSG3D_PROF_BRACKET=1: two hipEventRecord markers around the bracket (also
   // sees what is not a kernel of this library -- RCCL calls, copies -- and costs ~10 us of stream time per bracket)
   bool bracket = getenv("ICSG3D_PROF_BRACKET") != nullptr;
-  std::string filter;                   // non-empty: only launch sites whose label starts with it get events
+  std::string filter;                   // non-empty: only launch sites whose label starts with one of its ';'-separated prefixes get events
   std::vector<Row> rows;
   std::map<std::string, int> index;
   std::vector<Pending> pending;
@@ -75,7 +75,13 @@ struct Profiler : LaunchTimer {
   // bracket appended at end() (conv_last_kernel_id(): the name rocprofv3 prints for the same launch).
   void begin(hipStream_t st, const std::string& label, double flop, double bytes) {
     if (!on) return;
-    active = filter.empty() || label.compare(0, filter.size(), filter) == 0;
+    active = filter.empty();
+    for (size_t i = 0; !active && i < filter.size();) {          // ';'-separated list of label prefixes
+      size_t j = filter.find(';', i);
+      if (j == std::string::npos) j = filter.size();
+      active = j > i && label.compare(0, j - i, filter, i, j - i) == 0;
+      i = j + 1;
+    }
     if (!active) return;
     pending.push_back(Pending{-1, {}, label, flop, bytes});
     if (bracket) { hipEvent_t a = get(); (void)hipEventRecord(a, st); pending.back().ev.push_back(a); }

@@ -202,8 +202,9 @@ int ics_net_set_optimizer_state(ics_net* net, const float* m, const float* v, si
 /* Per-kernel timing with HIP events on the engine's stream (bench.py roofline): enable, run steps,
  * then read back rows {label, launches, total_ms, total_flop, total_bytes}. */
 int ics_net_profile_enable(ics_net* net, int on);
-/* Restrict the events to the launch sites whose label starts with `prefix` (NULL / "" = every launch): bench.py times its
- * K steps with events around the dominant kernel's launch sites only, so that the timed region is the training job. */
+/* Restrict the events to the launch sites whose label starts with `prefix` -- or with one of several prefixes separated by
+ * ';' -- (NULL / "" = every launch): bench.py times its K steps with events on the dominant kernel's launch sites only, so
+ * that the timed region is the training job. */
 int ics_net_profile_filter(ics_net* net, const char* prefix);
 int ics_net_profile_count(ics_net* net, int* rows);
 int ics_net_profile_row(ics_net* net, int row, const char** label, int64_t* launches, double* total_ms,

@@ -27,8 +27,12 @@ def _unet_pair(B=2, d=16):
     return a, b, X, lab, cond
 
 
-@pytest.mark.parametrize("sync_bn", [False, True])
-def test_single_rank_communicator_is_bit_identical(sync_bn):
+# fuse: the BatchNorm-backward-in-backward-data fusions forced on at this small size (default: from 64 MB of activations
+# on, i.e. only at bench sizes) -- their weight-gradient fix-ups must be final before the gradient buckets leave
+@pytest.mark.parametrize("sync_bn,fuse", [(False, False), (True, False), (False, True)])
+def test_single_rank_communicator_is_bit_identical(sync_bn, fuse, monkeypatch):
+    if fuse:
+        monkeypatch.setenv("ICSG3D_DGRAD_BNFUSE_MIN", "0")
     a, b, X, lab, _ = _unet_pair()
     b.set_sync_bn(sync_bn)
     assert b.comm_info()["nranks"] == 1 and a.comm_info()["nranks"] == 0
