@@ -51,7 +51,8 @@ __host__ __device__ __forceinline__ float wslope(int act) { return act == ACT_RE
 // AFF: the source carries a per-channel affine (+ activation of slope in_slope); NOACT: affine only.
 // FOLD (backward-data launches): the tile just produced is dO of the producer layer P; the block also adds its share of
 // P's BatchNorm-backward sums (BwdStat, common.h) -- the pass bn_bwd_reduce_kernel would otherwise make over dO and s.
-template <bool AFF, bool NOACT, bool FOLD>
+// FOLD = 2: the producer's whole BatchNorm-backward apply in the epilogue (see conv_wino64.hip; BwdStat::abc / db_partial)
+template <bool AFF, bool NOACT, int FOLD>
 __global__ __launch_bounds__(512) void conv_wino_kernel(const float* __restrict__ x, int ldx,
                                                         const float* __restrict__ in_scale,
                                                         const float* __restrict__ in_shift, float in_slope,
@@ -257,7 +258,11 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const float* __restrict_
   wf4 csum = {0.f, 0.f, 0.f, 0.f};
   wf4 f1 = {0.f, 0.f, 0.f, 0.f}, f2s = {0.f, 0.f, 0.f, 0.f};    // FOLD: sum d, sum d * xhat of this thread's 4 columns
   wf4 b_mu = f1, b_rs = f1, b_sc = {1.f, 1.f, 1.f, 1.f}, b_sh = f1;
-  if (FOLD) {
+  if (FOLD == 2) {                                 // b_mu / b_rs / b_sc hold the apply's a / b / c
+    b_mu = *reinterpret_cast<const wf4*>(bs.abc + n0 + 4 * k);
+    b_rs = *reinterpret_cast<const wf4*>(bs.abc + Cout + n0 + 4 * k);
+    b_sc = *reinterpret_cast<const wf4*>(bs.abc + 2 * Cout + n0 + 4 * k);
+  } else if (FOLD) {
     b_mu = *reinterpret_cast<const wf4*>(bs.mean + n0 + 4 * k);
     b_rs = *reinterpret_cast<const wf4*>(bs.rstd + n0 + 4 * k);
     if (bs.post_act != ACT_NONE) {
@@ -309,11 +314,22 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const float* __restrict_
     }
     e0.x = wact(e0.x, pre_slope); e0.y = wact(e0.y, pre_slope); e0.z = wact(e0.z, pre_slope); e0.w = wact(e0.w, pre_slope);
     e1.x = wact(e1.x, pre_slope); e1.y = wact(e1.y, pre_slope); e1.z = wact(e1.z, pre_slope); e1.w = wact(e1.w, pre_slope);
+    if (FOLD == 2) {
+      const size_t s0 = ((((size_t)b * S + vz) * S + vy) * S + vx) * bs.ld + n0 + 4 * k;
+      const wf4 sv0 = *reinterpret_cast<const wf4*>(bs.s + s0);
+      const wf4 sv1 = *reinterpret_cast<const wf4*>(bs.s + s0 + (size_t)S * S * bs.ld);
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        e0[r4] = sv0[r4] > 0.f ? fmaf(b_mu[r4], e0[r4], fmaf(b_rs[r4], sv0[r4], b_sc[r4])) : 0.f;
+        e1[r4] = sv1[r4] > 0.f ? fmaf(b_mu[r4], e1[r4], fmaf(b_rs[r4], sv1[r4], b_sc[r4])) : 0.f;
+      }
+      f1 += e0 + e1;
+    }
     *reinterpret_cast<wf4*>(y + o0) = e0;
     *reinterpret_cast<wf4*>(y + o1) = e1;
     val[2 * pass] = e0; val[2 * pass + 1] = e1;
     csum += e0 + e1;
-    if (FOLD) {
+    if (FOLD == 1) {
       const size_t s0 = ((((size_t)b * S + vz) * S + vy) * S + vx) * bs.ld + n0 + 4 * k;
       const wf4 sv0 = *reinterpret_cast<const wf4*>(bs.s + s0);
       const wf4 sv1 = *reinterpret_cast<const wf4*>(bs.s + s0 + (size_t)S * S * bs.ld);
@@ -342,6 +358,14 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const float* __restrict_
     for (int ww = 0; ww < 8; ++ww) sacc += red[ww * 32 + i];
     return sacc;
   };
+  if (FOLD == 2) {                                 // column sums of the written dy_P: [blocks][Cout]
+    f1 = colreduce(f1);
+    __syncthreads();
+    if (lane < 8) *reinterpret_cast<wf4*>(&red[w * 32 + 4 * lane]) = f1;
+    __syncthreads();
+    if (tid < 32) bs.db_partial[(size_t)tblk * Cout + n0 + tid] = sum8(tid);
+    return;
+  }
   if (FOLD) {                                      // [2][Npad][blocks] (block index fastest), as conv_igemm.hip's FOLD
     f1 = colreduce(f1); f2s = colreduce(f2s);
     __syncthreads();
@@ -787,10 +811,14 @@ int launch_conv_fwd_wino(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, c
   const float in_slope = wslope(s0.act), pre_slope = wslope(pre_act);
   // the folded BatchNorm-backward sums: plain backward-data launches only (no source affine, no statistics, no
   // activation); the producer's tensors must be float4-addressable like the output
-  const bool fold = bwd != nullptr && bwd->partial != nullptr && !aff && stat_partial == nullptr && bias == nullptr &&
-                    pre_act == ACT_NONE && !accumulate && bwd->ld % 4 == 0;
-  if (bwd_blocks) *bwd_blocks = fold ? (int)(grid / (unsigned)(g.Cout / 32)) : 0;
-  const BwdStat bs = fold ? *bwd : BwdStat{};
+  const bool plain = bwd != nullptr && !aff && stat_partial == nullptr && bias == nullptr && pre_act == ACT_NONE &&
+                     !accumulate && bwd->ld % 4 == 0;
+  const bool apply = plain && bwd->abc != nullptr && bwd->pool_d == nullptr;
+  ICS_CHECK(bwd == nullptr || bwd->abc == nullptr || (apply && bwd->db_partial != nullptr && bwd->s != nullptr),
+            "Winograd backward-data with the fused BatchNorm-backward apply: not a plain launch (or a pooled source: 64-channel kernel only)");
+  const bool fold = plain && !apply && bwd->partial != nullptr;
+  if (bwd_blocks) *bwd_blocks = (fold || apply) ? (int)(grid / (unsigned)(g.Cout / 32)) : 0;
+  const BwdStat bs = (fold || apply) ? *bwd : BwdStat{};
 #define ICS_WINO_LAUNCH(AFFV, NOACTV, FOLDV)                                                                        \
   do {                                                                                                              \
     ICS_LAUNCH((conv_wino_kernel<AFFV, NOACTV, FOLDV>), dim3(grid), dim3(512), 0, st, s0.p, s0.C, s0.scale, \
@@ -798,10 +826,11 @@ int launch_conv_fwd_wino(hipStream_t st, const ConvGeom& g, const ConvSrc& s0, c
                        g.Cin, g.Cout, bs);                                                                          \
     conv_set_last_kernel_id("conv_wino_kernel<" #AFFV ", " #NOACTV ", " #FOLDV ">");                                \
   } while (0)
-  if (fold) ICS_WINO_LAUNCH(false, true, true);
-  else if (!aff) ICS_WINO_LAUNCH(false, true, false);
-  else if (noact) ICS_WINO_LAUNCH(true, true, false);
-  else ICS_WINO_LAUNCH(true, false, false);
+  if (apply) ICS_WINO_LAUNCH(false, true, 2);
+  else if (fold) ICS_WINO_LAUNCH(false, true, 1);
+  else if (!aff) ICS_WINO_LAUNCH(false, true, 0);
+  else if (noact) ICS_WINO_LAUNCH(true, true, 0);
+  else ICS_WINO_LAUNCH(true, false, 0);
 #undef ICS_WINO_LAUNCH
   ICS_HIP(hipGetLastError());
   return 0;

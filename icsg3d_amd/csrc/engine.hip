@@ -939,7 +939,7 @@ static bool dgrad_bnfuse_ok(const Net& n, const ConvLayer& L, const ConvLayer* n
   if (!next->has_bn || next->pre_act != ACT_RELU || next->post_act != ACT_NONE || next->xs == nullptr ||
       next->db_partial == nullptr || next->dy == nullptr)
     return false;
-  if (L.split_up || L.nsrc != 1 || L.taps != 27 || !L.wino_w || !L.wwb || L.wwb_layout != 1 || L.CinG != L.Cin ||
+  if (L.split_up || L.nsrc != 1 || L.taps != 27 || !L.wino_w || !L.wwb || L.CinG != L.Cin ||
       L.Cin != next->Cout || L.src[0].p != next->s || L.src[0].scale == nullptr || L.src[0].act != ACT_NONE || L.dw_phys)
     return false;
   if (n.rows(L, B) * (size_t)next->Cout * sizeof(float) < n.bnfuse_min_bytes) return false;
