@@ -59,8 +59,12 @@ def _layer_shape(name, B, d):
 
 
 # B = 4: at d = 16 the S = 4 layers (c5, c6, c14) then take conv_winog.hip's backward-weight GEMMs too (they need B % 4 == 0)
-@pytest.mark.parametrize("ties,B", [("tf_cpu", 2), ("first", 2), ("tf_cpu", 3), ("tf_cpu", 4)])
-def test_unet_train_step_matches_oracle(ties, B, relerr):
+# fuse: the BatchNorm-backward-in-backward-data fusions (engine.hip dgrad_bnfuse_ok / skip_bnfuse_ok) forced on at this size --
+# by default they start at 64 MB of activations, i.e. at the bench's batch -- under both max-pool tie rules (the deferred
+# skip launch routes the pooled gradient through the forward's tie masks)
+@pytest.mark.parametrize("ties,B,fuse", [("tf_cpu", 2, False), ("first", 2, False), ("tf_cpu", 3, False), ("tf_cpu", 4, False),
+                                         ("tf_cpu", 2, True), ("first", 2, True), ("tf_cpu", 4, True)])
+def test_unet_train_step_matches_oracle(ties, B, fuse, relerr, monkeypatch):
     """Gradients, BN moving statistics and the Adam update of one train step.
 
     ReLU'(0) is discontinuous, so the fp64 oracle is evaluated with the engine's own ReLU masks
@@ -68,9 +72,16 @@ def test_unet_train_step_matches_oracle(ties, B, relerr):
     kink, so this pins everything but the sign of sub-rounding pre-activations."""
     d, C = 16, 1
     lr = 1e-3
+    if fuse:
+        monkeypatch.setenv("ICSG3D_DGRAD_BNFUSE_MIN", "0")
     orc, eng, X, lab = _setup(B, d, C, ties, lr=lr)
     p0 = {k: v.copy() for k, v in orc.P.items()}
+    eng.profile_enable(True)
     m = eng.train_step(X, lab)
+    sites = {r["label"].split("|")[0] for r in eng.profile_rows()}
+    eng.profile_enable(False)
+    fused = {"bnfuse:c18", "bnfuse:c16", "bnfuse:c17.skip", "bnfuse:c2.pool", "bnfuse:c2", "bnfuse:c15.skip", "bnfuse:c4.pool"}
+    assert (fused <= sites) if fuse else not (fused & sites), sorted(x for x in sites if x.startswith("bnfuse"))
     kink = {n: eng.get_activation(n, _layer_shape(n, B, d)) for n in UNET_LAYERS}
     affine = {n: eng.get_bn_affine(n, _layer_shape(n, B, d)[-1]) for n in ("c2", "c4", "c6")}
     m_ref = orc.train_on_batch(X, lab, kink=kink, affine=affine)
