@@ -109,6 +109,11 @@ int launch_conv_bnfuse(hipStream_t st, const float* dy, int B, int S, int Cin, i
                        const float* rstd, const float* scale, float* abc, float* c1c2, float* dgamma, float* dbeta,
                        float* ws_partial, size_t ws_partial_floats, double* ws_R, double* sums_out = nullptr);
 // second gradient source behind a MaxPool3D: its share of the two sums, added to sums_conv (launch_conv_bnfuse's sums_out)
+// a layer whose only gradient source is its max-pool: the BatchNorm-backward sums on the pooled grid, as BwdPre partials
+bool pool_presum_ok(int C, int ldg);
+int pool_presum_blocks(size_t pooled_rows);
+int launch_pool_presum(hipStream_t st, const float* g, int ldg, const unsigned char* mask, const float* ssum, size_t pooled_rows,
+                       int C, const float* mean, const float* rstd, float* pre, size_t pre_floats, int* blocks);
 size_t pool_bnfuse_partial_doubles(size_t pooled_rows, int C);
 int launch_pool_bnfuse(hipStream_t st, const float* g, int ldg, const unsigned char* mask, const float* ssum, size_t pooled_rows,
                        int C, double cnt, const double* sums_conv, const float* mean, const float* rstd, const float* scale,

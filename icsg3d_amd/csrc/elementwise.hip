@@ -1645,10 +1645,13 @@ int launch_conv_bnfuse(hipStream_t st, const float* dy, int B, int S, int Cin, i
 // k elements of its tie mask, so  sum_v d = sum_w k g  and  sum_v d xhat = sum_w g (ssum - k mean) rstd  with ssum the
 // sum of the stored activations of those elements (launch_pool_fwd).  partial [blocks][2][C] doubles.
 constexpr int kPoolSumRows = 64;          // pooled rows per block
+// pre != nullptr: the block sums go out as floats in bn_bwd_finalize_kernel's layout [2][C][gridDim.x] (block index
+// fastest) -- the layer's ONLY gradient source is the max-pool (the perceptual U-Net's tap layers in a DFC-VAE step), so
+// the sums on the pooled grid replace the BatchNorm-backward reduce pass over the fine grid (launch_pool_presum).
 __global__ __launch_bounds__(256) void pool_sums_kernel(const float* __restrict__ g, int ldg, const unsigned char* __restrict__ mask,
                                                         const float* __restrict__ ssum, const float* __restrict__ mean,
                                                         const float* __restrict__ rstd, size_t rows, int C,
-                                                        double* __restrict__ partial) {
+                                                        double* __restrict__ partial, float* __restrict__ pre) {
   __shared__ dbl4 sh[2][256];
   const int C4 = C >> 2, c4 = threadIdx.x % C4, rg = threadIdx.x / C4, RG = 256 / C4, c = c4 * 4;
   const size_t r0 = (size_t)blockIdx.x * kPoolSumRows;
@@ -1675,6 +1678,16 @@ __global__ __launch_bounds__(256) void pool_sums_kernel(const float* __restrict_
       const dbl4 b1 = sh[0][r * C4 + c4], b2 = sh[1][r * C4 + c4];
       a.x += b1.x; a.y += b1.y; a.z += b1.z; a.w += b1.w;
       q.x += b2.x; q.y += b2.y; q.z += b2.z; q.w += b2.w;
+    }
+    if (pre != nullptr) {
+      const size_t nb = gridDim.x;
+      const double av[4] = {a.x, a.y, a.z, a.w}, qv[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        pre[(size_t)(c + j) * nb + blockIdx.x] = (float)av[j];
+        pre[((size_t)C + c + j) * nb + blockIdx.x] = (float)qv[j];
+      }
+      return;
     }
     double* o = partial + (size_t)blockIdx.x * 2 * C;
     o[c] = a.x; o[c + 1] = a.y; o[c + 2] = a.z; o[c + 3] = a.w;
@@ -1704,6 +1717,20 @@ __global__ __launch_bounds__(256) void pool_bnfuse_kernel(const double* __restri
     dbeta[c] = (float)sd;
   }
 }
+bool pool_presum_ok(int C, int ldg) { return C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0 && ldg % 4 == 0; }
+int pool_presum_blocks(size_t pooled_rows) { return (int)((pooled_rows + kPoolSumRows - 1) / kPoolSumRows); }
+// pre: [2][C][blocks] floats (BwdPre with ld = C)
+int launch_pool_presum(hipStream_t st, const float* g, int ldg, const unsigned char* mask, const float* ssum, size_t pooled_rows,
+                       int C, const float* mean, const float* rstd, float* pre, size_t pre_floats, int* blocks) {
+  ICS_CHECK(pool_presum_ok(C, ldg), "pool pre-sum: unsupported channel count");
+  const int nblk = pool_presum_blocks(pooled_rows);
+  ICS_CHECK((size_t)2 * C * nblk <= pre_floats, "pool pre-sum: workspace too small");
+  ICS_LAUNCH(pool_sums_kernel, dim3((unsigned)nblk), dim3(256), 0, st, g, ldg, mask, ssum, mean, rstd, pooled_rows, C,
+             static_cast<double*>(nullptr), pre);
+  ICS_HIP(hipGetLastError());
+  *blocks = nblk;
+  return 0;
+}
 size_t pool_bnfuse_partial_doubles(size_t pooled_rows, int C) { return (pooled_rows + kPoolSumRows - 1) / kPoolSumRows * 2 * C; }
 int launch_pool_bnfuse(hipStream_t st, const float* g, int ldg, const unsigned char* mask, const float* ssum, size_t pooled_rows,
                        int C, double cnt, const double* sums_conv, const float* mean, const float* rstd, const float* scale,
@@ -1712,7 +1739,8 @@ int launch_pool_bnfuse(hipStream_t st, const float* g, int ldg, const unsigned c
   ICS_CHECK(C % 4 == 0 && C4 <= 256 && 256 % C4 == 0 && ldg % 4 == 0, "pool BN-fuse: unsupported channel count");
   const size_t nblk = (pooled_rows + kPoolSumRows - 1) / kPoolSumRows;
   ICS_CHECK(nblk * 2 * C <= ws_partial_doubles, "pool BN-fuse: workspace too small");
-  ICS_LAUNCH(pool_sums_kernel, dim3((unsigned)nblk), dim3(256), 0, st, g, ldg, mask, ssum, mean, rstd, pooled_rows, C, ws_partial);
+  ICS_LAUNCH(pool_sums_kernel, dim3((unsigned)nblk), dim3(256), 0, st, g, ldg, mask, ssum, mean, rstd, pooled_rows, C, ws_partial,
+             nullptr);
   ICS_LAUNCH(pool_bnfuse_kernel, dim3(C), dim3(256), 0, st, sums_conv, ws_partial, (int)nblk, mean, rstd, scale, cnt, abc, c1c2,
              dgamma, dbeta);
   ICS_HIP(hipGetLastError());

@@ -163,6 +163,7 @@ struct ConvLayer {
   // ... and the same for a layer with TWO consumers, a skip concat and a MaxPool3D (c2): the skip consumer's backward-data
   // launch is deferred until the pool consumer's gradient exists and then writes this layer's dy (conv_wino64.hip FOLD = 3)
   unsigned char* tie_mask = nullptr;    // [M/8][Cout] which window elements receive the pooled gradient (launch_pool_fwd)
+  int tie_batch = 0;                    // batch whose masks / sums the buffers hold (0: none)
   float* tie_ssum = nullptr;            // [M/8][Cout] sum of their stored activations
   double* bn_sums = nullptr;            // [2][Cout] the skip consumer's share of (sum d, sum d xhat)
   ConvLayer* skip_prod = nullptr;       // on the CONSUMER (c17): the layer its skip channels come from
@@ -221,6 +222,8 @@ struct Net {
   float* ws_bwd2 = nullptr;  size_t ws_bwd2_n = 0;    // BN-backward sums folded into a backward-data epilogue
   float* ws_wgrad = nullptr; size_t ws_wgrad_n = 0;
   float* ws_fwd = nullptr;   size_t ws_fwd_n = 0;     // forward / backward-data split-K partial sums
+  bool want_tie_stats = false;      // forward passes write the max-pool tie masks / sums although no weight gradients follow
+                                    // (the perceptual U-Net's pass over the reconstruction inside a DFC-VAE train step)
   bool want_wgrad_inputs = false;   // forward passes keep what a backward-WEIGHT pass needs (conv_winog.hip's transposed
                                     // transform): only inside the engine's own train step
   bool splitk = false;       // split-K only inside train steps: its plan depends on the batch size, and
@@ -750,7 +753,8 @@ static int conv_forward(Net& n, ConvLayer& L, int B, bool training, bool update_
   }
   if (L.pooled) {
     n.prof.begin(n.st, "pool_fwd", 0, 4.0 * M * L.Cout * 1.125);
-    const bool ties = training && L.tie_mask != nullptr && n.want_wgrad_inputs;   // only a train step's backward reads them
+    const bool ties = training && L.tie_mask != nullptr && (n.want_wgrad_inputs || n.want_tie_stats);   // a backward pass follows
+    L.tie_batch = ties ? B : 0;
     ICS_TRY(launch_pool_fwd(n.st, L.s, L.has_bn ? L.scale : nullptr, L.shift, L.has_bn ? L.post_act : ACT_NONE,
                             B, L.S, L.Cout, L.pooled, L.pool_idx, ties ? L.tie_mask : nullptr, ties ? L.tie_ssum : nullptr,
                             n.pool_ties_all));
@@ -1117,8 +1121,20 @@ static int conv_backward(Net& n, ConvLayer& L, int B, GradSrc g0, GradSrc g1, co
     else { ICS_TRY(colsum_push(n, L.db_partial, blocks, L.Cout, n.tg(L.t_b))); L.db_blocks = blocks; }
     return conv_grads_from_dy(n, L, B, need_dA, param_grads, next);
   }
-  const BwdPre pre{n.ws_bwd2, L.bwd_pre_nblk, L.bwd_pre_ld};
+  BwdPre pre{n.ws_bwd2, L.bwd_pre_nblk, L.bwd_pre_ld};
   L.bwd_pre_nblk = 0;
+  // the max-pool is the ONLY gradient source (plus, for a perceptual tap layer, a term that enters behind the BatchNorm):
+  // the two BatchNorm-backward sums from the pooled grid (pool_sums_kernel) instead of a reduce pass over the fine grid
+  if (pre.nblk == 0 && L.has_bn && L.post_act == ACT_NONE && g0.kind == GS_POOL && g0.off == 0 && g1.kind == GS_NONE &&
+      dtap == nullptr && L.tie_mask != nullptr && L.tie_batch == B && !(n.flags & CF_NO_POOL_PRESUM) &&
+      pool_presum_ok(L.Cout, g0.ld) && (size_t)2 * L.Cout * pool_presum_blocks(M / 8) <= n.ws_bwd2_n) {
+    int pb = 0;
+    n.prof.begin(n.st, "pool_presum:" + L.name, 0, 0);
+    ICS_TRY(launch_pool_presum(n.st, g0.p, g0.ld, L.tie_mask, L.tie_ssum, M / 8, L.Cout, L.mean, L.rstd, n.ws_bwd2, n.ws_bwd2_n,
+                               &pb));
+    n.prof.end(n.st);
+    pre.nblk = pb; pre.ld = L.Cout;
+  }
   n.prof.begin(n.st, "bn_act_bwd:" + L.name, 0, 4.0 * M * L.Cout * (L.has_bn ? (pre.nblk ? 3.0 : 5.0) : 3.0));
   const bool defer = param_grads && L.db_partial != nullptr && !(n.flags & CF_NO_TICKET);
   int db_blocks = 0;
@@ -1727,7 +1743,10 @@ static int vae_step(Net& n, int B, bool training, float* metrics) {
     if (rc) break;
     if ((rc = vae_encode_fwd(n, B, training))) break;
     if ((rc = vae_decode_fwd(n, B, training))) break;
-    if ((rc = unet_forward_trunk(u, B, training, false, true, n.recon))) break;
+    u.want_tie_stats = training;       // this pass is differentiated (unet_pm_backward)
+    rc = unet_forward_trunk(u, B, training, false, true, n.recon);
+    u.want_tie_stats = false;
+    if (rc) break;
     // loss terms (+ gradients when training)
     double* mse_part = n.ws_dbl;
     const int mse_bps = 16;
