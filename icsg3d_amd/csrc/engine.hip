@@ -237,6 +237,7 @@ struct Net {
   ncclComm_t comm = nullptr;
   ncclComm_t comm_bn = nullptr;      // SyncBN's own communicator (ncclCommSplit of comm): its small per-layer collectives
                                      // on st no longer serialise behind the gradient buckets on comm_st
+  ncclComm_t small() const { return comm_bn ? comm_bn : comm; }   // the communicator of the small collectives on st
   int rank = 0, nranks = 1;
   double* d_red = nullptr;           // [16] small reductions (timing max, metric sums)
   hipStream_t comm_st = nullptr;
@@ -1354,7 +1355,7 @@ static int unet_loss(Net& n, int B, int mode, int want_grad, bool want_metrics =
   n.prof.end(n.st);
   if (mode != 0 && n.comm && want_metrics) {
     ICS_TRY(launch_head_metrics(n.st, n.ws_dbl, n.head_nblk, (double)M, n.d_metrics, n.d_red, 1));
-    ncclResult_t r = ncclAllReduce(n.d_red, n.d_red, 7, ncclDouble, ncclSum, n.comm_bn, n.st);
+    ncclResult_t r = ncclAllReduce(n.d_red, n.d_red, 7, ncclDouble, ncclSum, n.small(), n.st);
     ICS_CHECK(r == ncclSuccess, std::string("ncclAllReduce(metrics): ") + ncclGetErrorString(r));
     ICS_TRY(launch_head_metrics(n.st, n.ws_dbl, n.head_nblk, (double)M, n.d_metrics, n.d_red, 2));
   }
@@ -1381,7 +1382,7 @@ static int unet_head_loss(Net& n, int B, int mode, int want_grad, bool want_metr
   n.prof.end(n.st);
   if (mode != 0 && n.comm && want_metrics) {
     ICS_TRY(launch_head_metrics(n.st, n.ws_dbl, n.head_nblk, (double)M, n.d_metrics, n.d_red, 1));
-    ncclResult_t r = ncclAllReduce(n.d_red, n.d_red, 7, ncclDouble, ncclSum, n.comm_bn, n.st);
+    ncclResult_t r = ncclAllReduce(n.d_red, n.d_red, 7, ncclDouble, ncclSum, n.small(), n.st);
     ICS_CHECK(r == ncclSuccess, std::string("ncclAllReduce(metrics): ") + ncclGetErrorString(r));
     ICS_TRY(launch_head_metrics(n.st, n.ws_dbl, n.head_nblk, (double)M, n.d_metrics, n.d_red, 2));
   }
@@ -1788,7 +1789,7 @@ static int vae_step(Net& n, int B, bool training, float* metrics) {
       // data parallel: all-reduce the sums (numerators / denominators), then form the means
       if ((rc = launch_vae_loss(n.st, r.zml->s, 2 * n.latent, n.latent, B, mse_part, B * mse_bps, (double)M * n.C,
                                 pm_part, pmc, n.alpha, n.beta, n.d_metrics, n.d_red, 1))) break;
-      if (ncclAllReduce(n.d_red, n.d_red, 5, ncclDouble, ncclSum, n.comm_bn, n.st) != ncclSuccess) {
+      if (ncclAllReduce(n.d_red, n.d_red, 5, ncclDouble, ncclSum, n.small(), n.st) != ncclSuccess) {
         set_error("ncclAllReduce(vae metrics) failed"); rc = -1; break;
       }
       if ((rc = launch_vae_loss(n.st, r.zml->s, 2 * n.latent, n.latent, B, mse_part, B * mse_bps, (double)M * n.C,
@@ -2462,9 +2463,16 @@ int ics_net_comm_init(ics_net* net, int rank, int nranks, const char uid[128]) {
   // statistics on the gradient communicator every SyncBN collective of the backward pass waited for the bucket in
   // flight (and the next bucket for it), and the overlap was lost.  A second communicator over the same ranks
   // (ncclCommSplit, color 0, key = rank: no second unique id to hand around) removes the coupling.
-  ncclResult_t rs = ncclCommSplit(n.comm, 0, rank, &n.comm_bn, nullptr);
-  ICS_CHECK(rs == ncclSuccess && n.comm_bn != nullptr, std::string("ncclCommSplit(SyncBN): ") + ncclGetErrorString(rs));
-  n.bn_sync = BnSync{n.comm_bn, nranks, n.sync_local, n.sync_gathered};
+  // Not fatal if the split fails (it is a collective: it fails on every rank or on none): the small collectives then share
+  // the gradient communicator as before round 4 -- correct, only without the overlap.
+  ncclResult_t rs = getenv("ICSG3D_NO_COMM_SPLIT") ? ncclInvalidUsage : ncclCommSplit(n.comm, 0, rank, &n.comm_bn, nullptr);
+  if (rs != ncclSuccess || n.comm_bn == nullptr) {
+    if (!getenv("ICSG3D_NO_COMM_SPLIT"))
+      fprintf(stderr, "icsg3d: ncclCommSplit failed (%s): BatchNorm / metric collectives share the gradient communicator\n",
+              ncclGetErrorString(rs));
+    n.comm_bn = nullptr;
+  }
+  n.bn_sync = BnSync{n.small(), nranks, n.sync_local, n.sync_gathered};
   ICS_HIP(hipStreamSynchronize(n.st));
   return 0;
 }
