@@ -1434,8 +1434,11 @@ static int unet_backward(Net& n, int B) {
     hipStream_t ws = bnfuse ? n.st : side_begin(n);     // fused: the backward-data kernel needs this GEMM's result
     ConvSrc hsrc = H.src[0];
     if (bnfuse) {
-      ICS_TRY(launch_xhat_affine(n.st, r.c18->mean, r.c18->rstd, 128, n.head_xs));
-      hsrc.scale = n.head_xs; hsrc.shift = n.head_xs + 128;
+      // xhat as an affine of c18's stored activation: written by the forward's BatchNorm finalize, except under SyncBN
+      // (its statistics come from the rank-merge kernels)
+      float* xs = n.sync() ? n.head_xs : r.c18->xs;
+      if (n.sync()) ICS_TRY(launch_xhat_affine(n.st, r.c18->mean, r.c18->rstd, 128, xs));
+      hsrc.scale = xs; hsrc.shift = xs + 128;
     }
     n.prof.begin(ws, "conv_wgrad:head|", 2.0 * M * 128 * nc1, 4.0 * M * (128 + nc1));
     ICS_TRY(launch_conv_wgrad(ws, gs, &hsrc, 1, H.s, nc1, n.head_dw_tmp, nc1, n.ws_wgrad, n.ws_wgrad_n, 0, 0, 0, 1));
