@@ -840,7 +840,7 @@ static bool skip_bnfuse_ok(const Net& n, const ConvLayer& L, int B) {
   if (P == nullptr || !L.split_up || L.Cs == 0 || (n.flags & CF_NO_DGRAD_BNFUSE) || n.sync() != nullptr || n.side_on) return false;
   if (!P->has_bn || P->pre_act != ACT_RELU || P->post_act != ACT_NONE || P->tie_mask == nullptr || P->xs == nullptr ||
       P->db_partial == nullptr || !P->pooled || P->Cout != L.Cs || L.src[0].p != P->s || L.src[0].scale == nullptr ||
-      L.src[0].act != ACT_NONE || !n.want_wgrad_inputs)
+      L.src[0].act != ACT_NONE || !n.want_wgrad_inputs || P->tie_batch != B)
     return false;
   if (!L.wino_w || !L.wwb || L.wwb_layout != 1) return false;
   if (n.rows(L, B) * (size_t)P->Cout * sizeof(float) < 2 * n.bnfuse_min_bytes) return false;
