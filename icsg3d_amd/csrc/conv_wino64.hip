@@ -555,6 +555,44 @@ __global__ __launch_bounds__(512) void conv_wino64_kernel(const float* __restric
   // red[0..512) / red[512..1024): [w][64], channel index (pass * 2 + jl) * 16 + cq * 4 + e
   const int cidx = jl * 16 + cq * 4;
   const size_t nstat = gridDim.x / nchunks;
+#ifndef ICS_W64_STATS_LDS
+#define ICS_W64_STATS_LDS 1   // 1: per-thread values through LDS, merged by 256 + 64 threads; 0: xor-shuffle trees
+#endif
+#if ICS_W64_STATS_LDS
+  // (see the statistics epilogue below: the xor-shuffle trees were VALU issue time on two waves per SIMD)
+  float* smf = lds + 8 * PW + 1024;              // [64 voxel pairs][16 channel quads] float4 (x 2 quantities): 32 KB
+  if (FOLD) {
+    const int e = tid >> 3;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int qd = pass * 8 + (tid & 7);
+      *reinterpret_cast<vf4*>(&smf[(e * 16 + qd) * 4]) = f1[pass];
+      if (FOLD == 1) *reinterpret_cast<vf4*>(&smf[4096 + (e * 16 + qd) * 4]) = f2s[pass];
+    }
+    __syncthreads();
+    if (tid < 256) {
+      const int c = tid & 63, sub = tid >> 6;
+      float a = 0.f, q = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        a += smf[(sub * 16 + i) * 64 + c];
+        if (FOLD == 1) q += smf[4096 + (sub * 16 + i) * 64 + c];
+      }
+      red[sub * 64 + c] = a;
+      if (FOLD == 1) red[512 + sub * 64 + c] = q;
+    }
+    __syncthreads();
+    if (FOLD >= 2) {                               // column sums of the written dy_P only: [blocks][Cout]
+      if (tid < 64) bs.db_partial[(size_t)tblk * Cout + n0 + tid] = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
+    } else if (tid < 128) {                        // [2][Npad][blocks] (block index fastest), as conv_igemm.hip's FOLD
+      const int c = tid & 63, which = tid >> 6;
+      const float* r = red + which * 512;
+      bs.partial[((size_t)which * Npad + n0 + c) * nstat + tblk] = (r[c] + r[64 + c]) + (r[128 + c] + r[192 + c]);
+    }
+    ICS_TL_FLUSH();
+    return;
+  }
+#else
   if (FOLD >= 2) {                                 // column sums of the written dy_P only: [blocks][Cout]
 #pragma unroll
     for (int d = 8; d < 64; d <<= 1)
@@ -604,10 +642,67 @@ __global__ __launch_bounds__(512) void conv_wino64_kernel(const float* __restric
     ICS_TL_FLUSH();
     return;
   }
+#endif
   if (stat_partial == nullptr) { ICS_TL_FLUSH(); return; }
 
-  // block-level (count, mean, M2) per column (conv_igemm.hip's layout [3][Npad][nblocks], block index fastest) as a
-  // tree of equal-count Chan merges: thread (2 voxels) -> wave (16) -> block (128); one trip through LDS
+  // block-level (count, mean, M2) per column (conv_igemm.hip's layout [3][Npad][nblocks], block index fastest).
+#ifndef ICS_W64_STATS_LDS
+#define ICS_W64_STATS_LDS 1   // 1: pair statistics through LDS, merged by 256 + 64 threads; 0: the xor-shuffle Chan tree
+#endif
+#if ICS_W64_STATS_LDS
+  // The statistics epilogue cost every forward launch 1.5 us per workgroup (0.30 ms per U-Net step over the nine layers;
+  // the BatchNorm-affine source costs nothing: scripts/wino_bench.py WINO_FEAT=8 / 16) -- almost all of it VALU issue on
+  // two waves per SIMD: 48 xor-shuffles with their address arithmetic and 40 Chan merges per thread.  Now a thread only
+  // forms the exact (mean, M2) of its two voxels per channel and parks them: [64 voxel pairs][16 channel quads] float4,
+  // behind the output-transform buffers (no barrier needed in front).  Four waves then merge 16 pairs each per channel
+  // (mean of means, M2 = sum M2_i + 2 sum (mean_i - m)^2: the same two-level form as before, no cancellation), 64 threads
+  // merge the four partials.
+  float* sm = lds + 8 * PW + 1024;               // [64][16] float4 means | [64][16] float4 M2: 32 KB
+  {
+    const int e = tid >> 3;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const vf4 dlt = val[pass][1] - val[pass][0];
+      const vf4 mnv = val[pass][0] + 0.5f * dlt;
+      const vf4 m2v = 0.5f * dlt * dlt;
+      const int qd = pass * 8 + (tid & 7);
+      *reinterpret_cast<vf4*>(&sm[(e * 16 + qd) * 4]) = mnv;
+      *reinterpret_cast<vf4*>(&sm[4096 + (e * 16 + qd) * 4]) = m2v;
+    }
+  }
+  __syncthreads();
+  if (tid < 256) {
+    const int c = tid & 63, sub = tid >> 6;
+    float mi[16], msum = 0.f, q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      mi[i] = sm[(sub * 16 + i) * 64 + c];
+      msum += mi[i];
+      q += sm[4096 + (sub * 16 + i) * 64 + c];
+    }
+    const float m = msum * (1.f / 16.f);
+    float dev = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dev += (mi[i] - m) * (mi[i] - m);
+    red[sub * 64 + c] = m;
+    red[512 + sub * 64 + c] = q + 2.f * dev;       // 32 voxels
+  }
+  __syncthreads();
+  if (tid < 64) {
+    float mw[4], msum = 0.f, q = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < 4; ++ww) { mw[ww] = red[ww * 64 + tid]; msum += mw[ww]; q += red[512 + ww * 64 + tid]; }
+    const float mean_t = msum * 0.25f;
+    float dev = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < 4; ++ww) dev += (mw[ww] - mean_t) * (mw[ww] - mean_t);
+    float* sp = stat_partial + (size_t)(n0 + tid) * nstat + tblk;
+    sp[0] = (float)kRows;
+    sp[(size_t)Npad * nstat] = mean_t;
+    sp[(size_t)2 * Npad * nstat] = q + dev * (float)(kRows / 4);
+  }
+#else
+  // a tree of equal-count Chan merges: thread (2 voxels) -> wave (16) -> block (128); one trip through LDS
   vf4 mn[2], m2[2];
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
@@ -650,6 +745,7 @@ __global__ __launch_bounds__(512) void conv_wino64_kernel(const float* __restric
     sp[(size_t)Npad * nstat] = mean_t;
     sp[(size_t)2 * Npad * nstat] = q + dev * (float)(kRows / 8);
   }
+#endif
   ICS_TL_FLUSH();
 }
 
