@@ -416,6 +416,16 @@ __global__ __launch_bounds__(512) void conv_wino64_kernel(const float* __restric
   const int slot_rd = ((ttx * 4 + o) * 2 + jl) * PS + (tile >> 2) * 16 + cq * 4;
   vf4 val[2][2];
   vf4 f1[2], f2s[2];
+  // packed fp32 (full rate when no MFMA is in flight): subtraction through the neg modifiers, wave-uniform scalars from SGPRs
+  typedef float vf2 __attribute__((ext_vector_type(2)));
+  auto pk_sub = [](vf2 a, vf2 b) { vf2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; };
+  auto sub4 = [&](vf4 a, vf4 b) { const vf2 lo = pk_sub(a.xy, b.xy), hi = pk_sub(a.zw, b.zw); return vf4{lo.x, lo.y, hi.x, hi.y}; };
+  auto pk_fma_s = [](vf2 sc, vf2 x, vf2 y) { vf2 r; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "s"(sc), "v"(x), "v"(y)); return r; };
+  auto pk_mul_s = [](vf2 sc, vf2 x) { vf2 r; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "s"(sc), "v"(x)); return r; };
+  auto fma4s = [&](vf2 sc, vf4 x, vf4 y) { const vf2 lo = pk_fma_s(sc, x.xy, y.xy), hi = pk_fma_s(sc, x.zw, y.zw); return vf4{lo.x, lo.y, hi.x, hi.y}; };
+  auto mul4s = [&](vf2 sc, vf4 x) { const vf2 lo = pk_mul_s(sc, x.xy), hi = pk_mul_s(sc, x.zw); return vf4{lo.x, lo.y, hi.x, hi.y}; };
+  const float k1f = fyh ? 0.f : 1.f, k2f = fyh ? -1.f : 0.f, k3f = fyh ? -1.f : 1.f;
+  const vf2 k1 = {k1f, k1f}, k2 = {k2f, k2f}, k3 = {k3f, k3f}, half2 = {0.5f, 0.5f};
 #ifndef ICS_W64_EPI_PREFETCH
 #define ICS_W64_EPI_PREFETCH 1   // 1: everything the final stage reads from global memory is requested before the first
 #endif                           //    pass, under the output transform, instead of after each pass' second barrier
@@ -460,21 +470,26 @@ __global__ __launch_bounds__(512) void conv_wino64_kernel(const float* __restric
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
       const int j = pass * 2 + jj;
+      // Whole accumulator quads (the four tiles i of a lane) at a time: the epilogue is VALU issue time on two waves per
+      // SIMD (575 instructions after the last MFMA when this was written element by element), and on float4 values the
+      // compiler selects v_pk_add_f32 -- full rate when no MFMA is in flight.
+      vf4 qv[2][2];                              // [fy local][dx]
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float qv[2][2];                          // [fy local][dx]
+      for (int fy = 0; fy < 2; ++fy) {
+        qv[fy][0] = acc[fy * 4 + 0][j] + acc[fy * 4 + 1][j] + acc[fy * 4 + 2][j];
+        qv[fy][1] = sub4(sub4(acc[fy * 4 + 1][j], acc[fy * 4 + 2][j]), acc[fy * 4 + 3][j]);
+      }
 #pragma unroll
-        for (int fy = 0; fy < 2; ++fy) {
-          qv[fy][0] = acc[fy * 4 + 0][j][i] + acc[fy * 4 + 1][j][i] + acc[fy * 4 + 2][j][i];
-          qv[fy][1] = acc[fy * 4 + 1][j][i] - acc[fy * 4 + 2][j][i] - acc[fy * 4 + 3][j][i];
-        }
+      for (int dx = 0; dx < 2; ++dx) {
+        // rows of A^T: the wave with fy 0,1 gives dy0 = q0 + q1, dy1 = q1; the one with fy 2,3: dy0 = q0, dy1 = -(q0 + q1)
+        // -- as d0 = q0 + k1 q1, d1 = k2 q0 + k3 q1 with wave-uniform coefficients in SGPR pairs (the selects and
+        // negations were 112 VALU instructions per thread)
+        const vf4 d0 = fma4s(k1, qv[1][dx], qv[0][dx]);
+        const vf4 d1 = fma4s(k3, qv[1][dx], mul4s(k2, qv[0][dx]));
 #pragma unroll
-        for (int dx = 0; dx < 2; ++dx) {
-          // rows of A^T: the wave with fy 0,1 gives dy0 += q0 + q1, dy1 += q1; the one with fy 2,3: dy0 += q0, dy1 -= q0 + q1
-          const float d0 = fyh ? qv[0][dx] : qv[0][dx] + qv[1][dx];
-          const float d1 = fyh ? -qv[0][dx] - qv[1][dx] : qv[1][dx];
-          part[w * PW + ((i * 4 + 0 + dx) * 2 + jj) * PS + lane] = d0;
-          part[w * PW + ((i * 4 + 2 + dx) * 2 + jj) * PS + lane] = d1;
+        for (int i = 0; i < 4; ++i) {
+          part[w * PW + ((i * 4 + 0 + dx) * 2 + jj) * PS + lane] = d0[i];
+          part[w * PW + ((i * 4 + 2 + dx) * 2 + jj) * PS + lane] = d1[i];
         }
       }
     }
@@ -490,12 +505,12 @@ __global__ __launch_bounds__(512) void conv_wino64_kernel(const float* __restric
     const size_t o1 = o0 + (size_t)S * S * ldo;
 #if ICS_W64_EPI_PREFETCH
     const vf4 bv = pbias[pass];
-    vf4 e0 = p[0] + p[1] + p[2] + bv, e1 = p[1] - p[2] - p[3] + bv;
+    vf4 e0 = p[0] + p[1] + p[2] + bv, e1 = sub4(sub4(p[1], p[2]), p[3]) + bv;
     if (accumulate) { e0 += pacc[pass][0]; e1 += pacc[pass][1]; }
 #else
     vf4 bv = {0.f, 0.f, 0.f, 0.f};
     if (bias != nullptr) bv = *reinterpret_cast<const vf4*>(bias + nn);
-    vf4 e0 = p[0] + p[1] + p[2] + bv, e1 = p[1] - p[2] - p[3] + bv;
+    vf4 e0 = p[0] + p[1] + p[2] + bv, e1 = sub4(sub4(p[1], p[2]), p[3]) + bv;
     if (accumulate) {
       e0 += *reinterpret_cast<const vf4*>(y + o0);
       e1 += *reinterpret_cast<const vf4*>(y + o1);
@@ -662,9 +677,10 @@ __global__ __launch_bounds__(512) void conv_wino64_kernel(const float* __restric
     const int e = tid >> 3;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
-      const vf4 dlt = val[pass][1] - val[pass][0];
-      const vf4 mnv = val[pass][0] + 0.5f * dlt;
-      const vf4 m2v = 0.5f * dlt * dlt;
+      const vf4 dlt = sub4(val[pass][1], val[pass][0]);
+      const vf4 hd = mul4s(half2, dlt);
+      const vf4 mnv = val[pass][0] + hd;
+      const vf4 m2v = hd * dlt;
       const int qd = pass * 8 + (tid & 7);
       *reinterpret_cast<vf4*>(&sm[(e * 16 + qd) * 4]) = mnv;
       *reinterpret_cast<vf4*>(&sm[4096 + (e * 16 + qd) * 4]) = m2v;
