@@ -463,10 +463,13 @@ __global__ __launch_bounds__(512) void conv_wino64_kernel(const float* __restric
     }
   }
 #endif
-#pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    __syncthreads();
-    ICS_TL(4 + pass * 3);
+#ifndef ICS_W64_EPI_EARLY
+#define ICS_W64_EPI_EARLY 0     // 1: a pass' transform arithmetic ahead of the barrier that frees the LDS region it is written to
+                                // (a wave that leaves the main loop early would use its wait): measured +-0 on all nine
+                                // layers, forward and backward-data -- its VALU work competes with the late wave's MFMAs
+#endif
+  vf4 dd[2][2][2];              // [jj][dx][dy row]: the wave's share of the output transform of one pass
+  auto xf = [&](const int pass) {
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
       const int j = pass * 2 + jj;
@@ -484,15 +487,33 @@ __global__ __launch_bounds__(512) void conv_wino64_kernel(const float* __restric
         // rows of A^T: the wave with fy 0,1 gives dy0 = q0 + q1, dy1 = q1; the one with fy 2,3: dy0 = q0, dy1 = -(q0 + q1)
         // -- as d0 = q0 + k1 q1, d1 = k2 q0 + k3 q1 with wave-uniform coefficients in SGPR pairs (the selects and
         // negations were 112 VALU instructions per thread)
-        const vf4 d0 = fma4s(k1, qv[1][dx], qv[0][dx]);
-        const vf4 d1 = fma4s(k3, qv[1][dx], mul4s(k2, qv[0][dx]));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          part[w * PW + ((i * 4 + 0 + dx) * 2 + jj) * PS + lane] = d0[i];
-          part[w * PW + ((i * 4 + 2 + dx) * 2 + jj) * PS + lane] = d1[i];
-        }
+        dd[jj][dx][0] = fma4s(k1, qv[1][dx], qv[0][dx]);
+        dd[jj][dx][1] = fma4s(k3, qv[1][dx], mul4s(k2, qv[0][dx]));
       }
     }
+  };
+#if ICS_W64_EPI_EARLY
+  xf(0);                        // a wave that leaves the main loop early does this while the last one still runs MFMAs
+#endif
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+#if !ICS_W64_EPI_EARLY
+    xf(pass);
+#endif
+    __syncthreads();
+    ICS_TL(4 + pass * 3);
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          part[w * PW + ((i * 4 + 0 + dx) * 2 + jj) * PS + lane] = dd[jj][dx][0][i];
+          part[w * PW + ((i * 4 + 2 + dx) * 2 + jj) * PS + lane] = dd[jj][dx][1][i];
+        }
+#if ICS_W64_EPI_EARLY
+    if (pass == 0) xf(1);
+#endif
     __syncthreads();
     ICS_TL(5 + pass * 3);
     const int nn = n0 + (pass * 2 + jl) * 16 + cq * 4;             // this thread's four output channels
