@@ -68,6 +68,7 @@ struct Profiler : LaunchTimer {
     hipEvent_t e; (void)hipEventCreate(&e); return e;
   }
   void next(hipEvent_t* a, hipEvent_t* b) override {
+    if (!active || pending.empty()) { *a = *b = nullptr; return; }   // a bracket left open by an error path: plain launch
     *a = get(); *b = get();
     pending.back().ev.push_back(*a); pending.back().ev.push_back(*b);
   }
@@ -102,6 +103,8 @@ struct Profiler : LaunchTimer {
     p.row = r;
   }
   void resolve() {   // call after a stream sync
+    if (tl_launch_timer == this) tl_launch_timer = nullptr;
+    active = false;
     for (auto& p : pending) {
       for (size_t i = 0; i + 1 < p.ev.size(); i += 2) {
         float ms = 0.f;
