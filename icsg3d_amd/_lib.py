@@ -57,6 +57,7 @@ SIGNATURES = {
     "ics_unet_train_step_resident": (C.c_int, [_H, _F]),
     "ics_vae_create": (C.c_int, [C.POINTER(VaeConfig), _H, C.POINTER(_H)]),
     "ics_vae_encode": (C.c_int, [_H, _F, _F, _F, C.c_int, _F, _F, _F]),
+    "ics_unet_metric_sums": (C.c_int, [_H, C.POINTER(C.c_double)]),
     "ics_vae_decode": (C.c_int, [_H, _F, _F, C.c_int, _F]),
     "ics_vae_train_step": (C.c_int, [_H, _F, _F, _F, C.c_int, _F]),
     "ics_vae_test_step": (C.c_int, [_H, _F, _F, _F, C.c_int, _F]),
@@ -95,6 +96,8 @@ SIGNATURES = {
     "ics_net_comm_broadcast_state": (C.c_int, [_H, C.c_int]),
     "ics_net_set_sync_bn": (C.c_int, [_H, C.c_int]),
     "ics_net_comm_info": (C.c_int, [_H, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ics_op_unet_head": (C.c_int, [_F, _F, _F, _F, _F, _U8, C.c_size_t, C.c_int, C.c_float, C.c_int, C.c_int, _F, _F,
+                                  C.POINTER(C.c_double)]),
     "ics_op_conv3d_forward": (C.c_int, [_F, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _F]),
     "ics_op_conv3d_bench": (C.c_int, [C.c_int] * 8 + [_F]),
     "ics_op_conv3d_backward": (C.c_int, [_F, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _F, _F]),

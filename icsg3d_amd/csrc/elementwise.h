@@ -122,14 +122,15 @@ int launch_colsum_finalize(hipStream_t st, const float* partial, int nblk, int C
 int launch_head_fused(hipStream_t st, const float* x, int ldx, const float* scale, const float* shift, const float* wsoft_k,
                       const float* wsig_k, const float* bsoft, const float* bsig, float* z, const unsigned char* labels,
                       size_t M, int mode, int want_grad, float wsoft, double* partial, int partial_blocks, float* metrics,
-                      int* nblk_out = nullptr, float* dz_colsum = nullptr);
+                      int* nblk_out = nullptr, float* dz_colsum = nullptr, double* keep = nullptr);
 int launch_head(hipStream_t st, float* z, int ldz, int ncls, const unsigned char* labels, size_t M,
                 int mode, int want_grad, float wsoft, double* partial, int partial_blocks,
-                float* metrics, int* nblk_out = nullptr, float* dz_colsum = nullptr);
+                float* metrics, int* nblk_out = nullptr, float* dz_colsum = nullptr, double* keep = nullptr);
 // dz_colsum: optional [blocks][ncls+1] per-block column sums of the dz the kernel writes (head bias gradients)
 // phase 0: reduce block partials + finalize; 1: reduce only -> sums[7]; 2: finalize from sums[7]
+// keep: optional [7], receives the (global) sums the ratios were formed from in phases 0 and 2
 int launch_head_metrics(hipStream_t st, const double* partial, int nblk, double M, float* metrics, double* sums,
-                        int phase);
+                        int phase, double* keep = nullptr);
 int launch_adam(hipStream_t st, float* p, const float* g, float* m, float* v, size_t n, float lr_t,
                 float gscale);
 int launch_bn_apply(hipStream_t st, const float* s, const float* scale, const float* shift, int act,

@@ -1229,7 +1229,7 @@ bool head_fused_ok(int ncls, int cin, size_t M, int act, int flags) {
 int launch_head_fused(hipStream_t st, const float* x, int ldx, const float* scale, const float* shift, const float* wsoft_k,
                       const float* wsig_k, const float* bsoft, const float* bsig, float* z, const unsigned char* labels,
                       size_t M, int mode, int want_grad, float wsoft, double* partial, int partial_blocks, float* metrics,
-                      int* nblk_out, float* dz_colsum) {
+                      int* nblk_out, float* dz_colsum, double* keep) {
   ICS_CHECK(M % 16 == 0 && ldx % 4 == 0, "fused head: rows must come in sixteens, float4-aligned");
   const int ntiles = (int)(M / 16);
   int nblk = (ntiles + 3) / 4;
@@ -1239,7 +1239,7 @@ int launch_head_fused(hipStream_t st, const float* x, int ldx, const float* scal
                      labels, ntiles, mode, want_grad, wsoft, (float)(1.0 / (double)M), partial, dz_colsum);
   ICS_HIP(hipGetLastError());
   if (nblk_out) *nblk_out = nblk;
-  if (mode != 0 && metrics != nullptr) ICS_TRY(launch_head_metrics(st, partial, nblk, (double)M, metrics, nullptr, 0));
+  if (mode != 0 && metrics != nullptr) ICS_TRY(launch_head_metrics(st, partial, nblk, (double)M, metrics, nullptr, 0, keep));
   return 0;
 }
 
@@ -1784,7 +1784,8 @@ int launch_head_dgrad(hipStream_t st, const float* dz, const float* wsoft_k, con
 //   phase 1: reduce only -> sums[0..5], sums[6] = M;   phase 2: finalize from (all-reduced) sums.
 __global__ __launch_bounds__(256) void head_finalize_kernel(const double* __restrict__ partial, int nblk,
                                                             double M, float* __restrict__ metrics,
-                                                            double* __restrict__ sums, int phase) {
+                                                            double* __restrict__ sums, int phase,
+                                                            double* __restrict__ keep) {
   __shared__ double sh[4];
   double acc[6];
   if (phase == 2) {
@@ -1806,6 +1807,11 @@ __global__ __launch_bounds__(256) void head_finalize_kernel(const double* __rest
     sums[6] = M;
     return;
   }
+  if (keep) {   // the global sums behind the ratios (ics_unet_metric_sums): [sum lsoft, sum lsig, tp, predicted, wr tp, wr possible, M]
+#pragma unroll
+    for (int k = 0; k < 6; ++k) keep[k] = acc[k];
+    keep[6] = M;
+  }
   const double eps = 1e-7;
   const double lsoft = acc[0] / M, lsig = acc[1] / M;
   const double tp = acc[2], predicted = acc[3], possible = M;
@@ -1819,15 +1825,15 @@ __global__ __launch_bounds__(256) void head_finalize_kernel(const double* __rest
   metrics[4] = (float)wr;
 }
 int launch_head_metrics(hipStream_t st, const double* partial, int nblk, double M, float* metrics, double* sums,
-                        int phase) {
-  ICS_LAUNCH(head_finalize_kernel, dim3(1), dim3(256), 0, st, partial, nblk, M, metrics, sums, phase);
+                        int phase, double* keep) {
+  ICS_LAUNCH(head_finalize_kernel, dim3(1), dim3(256), 0, st, partial, nblk, M, metrics, sums, phase, keep);
   ICS_HIP(hipGetLastError());
   return 0;
 }
 
 int launch_head(hipStream_t st, float* z, int ldz, int ncls, const unsigned char* labels, size_t M,
                 int mode, int want_grad, float wsoft, double* partial, int partial_blocks,
-                float* metrics, int* nblk_out, float* dz_colsum) {
+                float* metrics, int* nblk_out, float* dz_colsum, double* keep) {
   ICS_CHECK(ncls <= 128, "head kernel supports at most 128 classes");
   int rpb = (int)((M + partial_blocks - 1) / partial_blocks);
   rpb = (rpb + 15) / 16 * 16;
@@ -1836,7 +1842,7 @@ int launch_head(hipStream_t st, float* z, int ldz, int ncls, const unsigned char
                      want_grad, wsoft, (float)(1.0 / (double)M), partial, dz_colsum);
   ICS_HIP(hipGetLastError());
   if (nblk_out) *nblk_out = nblk;
-  if (mode != 0 && metrics != nullptr) ICS_TRY(launch_head_metrics(st, partial, nblk, (double)M, metrics, nullptr, 0));
+  if (mode != 0 && metrics != nullptr) ICS_TRY(launch_head_metrics(st, partial, nblk, (double)M, metrics, nullptr, 0, keep));
   return 0;
 }
 

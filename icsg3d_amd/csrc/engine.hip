@@ -242,7 +242,7 @@ struct Net {
                                      // on st no longer serialise behind the gradient buckets on comm_st
   ncclComm_t small() const { return comm_bn ? comm_bn : comm; }   // the communicator of the small collectives on st
   int rank = 0, nranks = 1;
-  double* d_red = nullptr;           // [16] small reductions (timing max, metric sums)
+  double* d_red = nullptr;           // [16] small reductions (timing max, metric sums); [8..14] = the last head metric sums
   hipStream_t comm_st = nullptr;
   hipEvent_t ev_grad = nullptr, ev_comm = nullptr;
   size_t bucket_hi = 0, bucket_min = 0;   // gradients at offsets >= bucket_hi are already being reduced
@@ -1354,13 +1354,13 @@ static int unet_loss(Net& n, int B, int mode, int want_grad, bool want_metrics =
   const size_t M = n.rows(*n.head, B);
   n.prof.begin(n.st, "head_softmax_loss", 0, 4.0 * M * (n.ncls + 1) * 2);
   ICS_TRY(launch_head(n.st, n.head->s, n.ncls + 1, n.ncls, n.labels, M, mode, want_grad, n.loss_weight,
-                      n.ws_dbl, 2048, n.comm ? nullptr : n.d_metrics, &n.head_nblk, want_grad ? n.ws_bwd : nullptr));
+                      n.ws_dbl, 2048, n.comm ? nullptr : n.d_metrics, &n.head_nblk, want_grad ? n.ws_bwd : nullptr, n.d_red + 8));
   n.prof.end(n.st);
   if (mode != 0 && n.comm && want_metrics) {
     ICS_TRY(launch_head_metrics(n.st, n.ws_dbl, n.head_nblk, (double)M, n.d_metrics, n.d_red, 1));
     ncclResult_t r = ncclAllReduce(n.d_red, n.d_red, 7, ncclDouble, ncclSum, n.small(), n.st);
     ICS_CHECK(r == ncclSuccess, std::string("ncclAllReduce(metrics): ") + ncclGetErrorString(r));
-    ICS_TRY(launch_head_metrics(n.st, n.ws_dbl, n.head_nblk, (double)M, n.d_metrics, n.d_red, 2));
+    ICS_TRY(launch_head_metrics(n.st, n.ws_dbl, n.head_nblk, (double)M, n.d_metrics, n.d_red, 2, n.d_red + 8));
   }
   return 0;
 }
@@ -1381,13 +1381,13 @@ static int unet_head_loss(Net& n, int B, int mode, int want_grad, bool want_metr
   n.prof.begin(n.st, "head_fused", 2.0 * M * 128 * (n.ncls + 1), 4.0 * M * (128 + (mode == 1 && !want_grad ? 0 : n.ncls + 1)));
   ICS_TRY(launch_head_fused(n.st, s0.p, s0.C, s0.scale, s0.shift, n.tp(H.t_w), n.tp(H.t_gamma), n.tp(H.t_b),
                             n.tp(H.t_b) + n.ncls, H.s, n.labels, M, mode, want_grad, n.loss_weight, n.ws_dbl, 2048,
-                            n.comm ? nullptr : n.d_metrics, &n.head_nblk, want_grad ? n.ws_bwd : nullptr));
+                            n.comm ? nullptr : n.d_metrics, &n.head_nblk, want_grad ? n.ws_bwd : nullptr, n.d_red + 8));
   n.prof.end(n.st);
   if (mode != 0 && n.comm && want_metrics) {
     ICS_TRY(launch_head_metrics(n.st, n.ws_dbl, n.head_nblk, (double)M, n.d_metrics, n.d_red, 1));
     ncclResult_t r = ncclAllReduce(n.d_red, n.d_red, 7, ncclDouble, ncclSum, n.small(), n.st);
     ICS_CHECK(r == ncclSuccess, std::string("ncclAllReduce(metrics): ") + ncclGetErrorString(r));
-    ICS_TRY(launch_head_metrics(n.st, n.ws_dbl, n.head_nblk, (double)M, n.d_metrics, n.d_red, 2));
+    ICS_TRY(launch_head_metrics(n.st, n.ws_dbl, n.head_nblk, (double)M, n.d_metrics, n.d_red, 2, n.d_red + 8));
   }
   return 0;
 }
@@ -2224,6 +2224,15 @@ int ics_unet_test_step(ics_net* net, const float* x, const uint8_t* labels, int 
   return 0;
 }
 
+int ics_unet_metric_sums(ics_net* net, double sums[7]) {
+  ICS_TRY(require_kind(net, 0));
+  ICS_CHECK(sums, "null argument");
+  Net& n = net->n;
+  ICS_HIP(hipMemcpyAsync(sums, n.d_red + 8, 7 * sizeof(double), hipMemcpyDeviceToHost, n.st));
+  ICS_HIP(hipStreamSynchronize(n.st));
+  return 0;
+}
+
 // ---------------------------------------------------------------- VAE entry points
 int ics_vae_encode(ics_net* net, const float* x, const float* cond, const float* eps, int batch, float* z_mean,
                    float* z_log_var, float* z) {
@@ -2569,6 +2578,52 @@ int ics_op_conv3d_forward(const float* x, const float* w, const float* bias, int
     ICS_TRY(launch_conv_fwd(n.st, g, &s, 1, dwp, bias ? db : nullptr, dyv, Cout, pre_act, nullptr, nullptr));
   }
   ICS_HIP(hipMemcpyAsync(y, dyv, M * Cout * 4, hipMemcpyDeviceToHost, n.st));
+  ICS_HIP(hipStreamSynchronize(n.st));
+  return 0;
+}
+
+// The two 1x1x1 heads + losses + metrics on a given trunk output (kernel parity tests against the reference's own formulas,
+// tests/golden/loss_golden.npz): the same two launch sequences unet_head_loss chooses between.
+int ics_op_unet_head(const float* x, const float* wsoft, const float* bsoft, const float* wsig, const float* bsig,
+                     const uint8_t* labels, size_t M, int ncls, float loss_weight, int mode, int fused, float* out,
+                     float metrics[5], double sums[7]) {
+  ICS_CHECK(x && wsoft && bsoft && wsig && bsig && labels && M >= 1 && ncls >= 2 && ncls <= 128 && mode >= 0 && mode <= 2,
+            "bad head arguments");
+  Net n;
+  ICS_TRY(op_prepare(n));
+  const int nz = ncls + 1, Kpad = 128, Npad = round_up(nz, 32);
+  float *dx, *dws, *dwg, *db, *dwp, *dz, *dmet, *dcol;
+  double *dpart, *dsum;
+  unsigned char* dlab;
+  ICS_TRY(n.alloc(&dx, M * 128)); ICS_TRY(n.alloc(&dws, (size_t)128 * ncls)); ICS_TRY(n.alloc(&dwg, (size_t)128));
+  ICS_TRY(n.alloc(&db, (size_t)nz)); ICS_TRY(n.alloc(&dwp, (size_t)Kpad * Npad)); ICS_TRY(n.alloc(&dz, M * nz));
+  ICS_TRY(n.alloc(&dmet, (size_t)8)); ICS_TRY(n.alloc(&dcol, (size_t)2048 * (nz + 4))); ICS_TRY(n.alloc(&dpart, (size_t)2048 * 6));
+  ICS_TRY(n.alloc(&dsum, (size_t)8)); ICS_TRY(n.alloc(&dlab, M));
+  ICS_HIP(hipMemcpyAsync(dx, x, M * 128 * 4, hipMemcpyHostToDevice, n.st));
+  ICS_HIP(hipMemcpyAsync(dws, wsoft, (size_t)128 * ncls * 4, hipMemcpyHostToDevice, n.st));
+  ICS_HIP(hipMemcpyAsync(dwg, wsig, (size_t)128 * 4, hipMemcpyHostToDevice, n.st));
+  ICS_HIP(hipMemcpyAsync(db, bsoft, (size_t)ncls * 4, hipMemcpyHostToDevice, n.st));
+  ICS_HIP(hipMemcpyAsync(db + ncls, bsig, 4, hipMemcpyHostToDevice, n.st));
+  ICS_HIP(hipMemcpyAsync(dlab, labels, M, hipMemcpyHostToDevice, n.st));
+  const float lw = loss_weight > 0.f ? loss_weight : (float)ncls;       // unet/unet.py:253: the integer 95
+  const int hmode = mode == 0 ? 0 : 1, want_grad = mode == 2;
+  if (fused) {
+    ICS_CHECK(head_fused_ok(ncls, 128, M, ACT_NONE, 0), "this shape has no fused head kernel");
+    ICS_TRY(launch_head_fused(n.st, dx, 128, nullptr, nullptr, dws, dwg, db, db + ncls, dz, dlab, M, hmode, want_grad, lw,
+                              dpart, 2048, dmet, nullptr, want_grad ? dcol : nullptr, dsum));
+  } else {
+    ICS_TRY(launch_pack_fwd(n.st, dws, 128, ncls, dwp, Kpad, Npad, 0, 0, 1));
+    ICS_TRY(launch_pack_fwd(n.st, dwg, 128, 1, dwp, Kpad, Npad, 0, ncls, 0));
+    ConvGeom g{1, 1, 0, 128, nz, 1, Kpad, Npad, n.flags};
+    g.B = (int)M;                                                      // 1x1x1: rows are rows
+    ConvSrc s = src_plain(dx, 128);
+    ICS_TRY(launch_conv_fwd(n.st, g, &s, 1, dwp, db, dz, nz, ACT_NONE, nullptr, nullptr));
+    ICS_TRY(launch_head(n.st, dz, nz, ncls, dlab, M, hmode, want_grad, lw, dpart, 2048, dmet, nullptr,
+                        want_grad ? dcol : nullptr, dsum));
+  }
+  if (out) ICS_HIP(hipMemcpyAsync(out, dz, M * nz * 4, hipMemcpyDeviceToHost, n.st));
+  if (hmode && metrics) ICS_HIP(hipMemcpyAsync(metrics, dmet, 5 * 4, hipMemcpyDeviceToHost, n.st));
+  if (hmode && sums) ICS_HIP(hipMemcpyAsync(sums, dsum, 7 * 8, hipMemcpyDeviceToHost, n.st));
   ICS_HIP(hipStreamSynchronize(n.st));
   return 0;
 }

@@ -73,6 +73,7 @@ static int run(int d, int C, int B, int with_comm) {
   for (int b = 1; b <= B; ++b) {   /* every batch size up to max_batch: the split plans depend on it */
     OK(ics_unet_train_step(unet, x, lab, b, mm));
     OK(ics_unet_test_step(unet, x, lab, b, mm));
+    { double ms[7]; OK(ics_unet_metric_sums(unet, ms)); }
     OK(ics_unet_predict(unet, x, b, soft, sig));
     OK(ics_unet_predict_labels(unet, x, b, 0.8f, sp, mk));
     OK(ics_vae_train_step(vae, x, cond, eps, b, mv));
@@ -141,6 +142,16 @@ int main(void) {
     OK(ics_op_conv3d_forward(x, w, NULL, B, S, Cin, Cout, 27, 1, y));
     OK(ics_op_conv3d_backward(x, w, y, B, S, Cin, Cout, 27, dx, dw));
     free(x); free(y); free(w); free(dx); free(dw);
+  }
+  {   /* the op-level head: both launch sequences */
+    const size_t M = 64;
+    float *x = calloc(M * 128, 4), *ws = calloc(128 * 95, 4), *bs = calloc(95, 4), *wg = calloc(128, 4), bg[1] = {0.f};
+    float *out = calloc(M * 96, 4), met[5];
+    double sums[7];
+    uint8_t* lab = calloc(M, 1);
+    for (int f = 0; f < 2; ++f)
+      for (int mode = 0; mode < 3; ++mode) OK(ics_op_unet_head(x, ws, bs, wg, bg, lab, M, 95, 0.f, mode, f, out, met, sums));
+    free(x); free(ws); free(bs); free(wg); free(out); free(lab);
   }
   {   /* connected components on host arrays */
     const int B = 2, d = 16;

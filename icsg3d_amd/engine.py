@@ -222,6 +222,13 @@ class UnetEngine(_Net):
         L.check(self._lib.ics_unet_test_step(self._h, L.fptr(x), L.u8ptr(lab), x.shape[0], L.fptr(m)))
         return m
 
+    def metric_sums(self):
+        """The K.sum terms of the last step's metrics (unet/unet.py:159-193): dict(sum_lsoft, sum_lsig, tp, predicted,
+        wr_tp, wr_possible, voxels)."""
+        s = (C.c_double * 7)()
+        L.check(self._lib.ics_unet_metric_sums(self._h, s))
+        return dict(zip(("sum_lsoft", "sum_lsig", "tp", "predicted", "wr_tp", "wr_possible", "voxels"), [float(v) for v in s]))
+
     def upload_batch(self, x, labels):
         x = self._check_x(x)
         lab = self._labels(labels, x.shape[0])
@@ -363,6 +370,22 @@ def conv3d_forward(x, w, bias=None, pre_act=0):
     b = _f32(bias) if bias is not None else None
     L.check(lib.ics_op_conv3d_forward(L.fptr(x), L.fptr(w), L.fptr(b), B, S, Cin, Cout, taps, pre_act, L.fptr(y)))
     return y
+
+
+def unet_head(x, wsoft, bsoft, wsig, bsig, labels, mode=1, fused=True, loss_weight=0.0):
+    """Single-op entry (kernel parity tests): the heads + losses + metrics on a given trunk output x (M,128).
+    Returns (out (M, ncls+1) | None, metrics (5,), sums dict) -- see ics_op_unet_head."""
+    lib = L.load()
+    x, wsoft, bsoft, wsig, bsig = _f32(x), _f32(wsoft), _f32(bsoft), _f32(wsig), _f32(bsig)
+    M, ncls = x.shape[0], wsoft.shape[1]
+    lab = np.ascontiguousarray(labels, dtype=np.uint8).reshape(M)
+    out = np.empty((M, ncls + 1), np.float32) if mode != 1 else None
+    m = np.zeros(5, np.float32)
+    s = (C.c_double * 7)()
+    L.check(lib.ics_op_unet_head(L.fptr(x), L.fptr(wsoft), L.fptr(bsoft), L.fptr(wsig), L.fptr(bsig), L.u8ptr(lab), M, ncls,
+                                 float(loss_weight), int(mode), 1 if fused else 0, L.fptr(out), L.fptr(m), s))
+    keys = ("sum_lsoft", "sum_lsig", "tp", "predicted", "wr_tp", "wr_possible", "voxels")
+    return out, m, dict(zip(keys, [float(v) for v in s]))
 
 
 def conv3d_backward(x, w, dy):

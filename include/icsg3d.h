@@ -69,6 +69,11 @@ int ics_unet_train_step(ics_net* net, const float* x, const uint8_t* labels, int
 /* model.test_on_batch / validation pass: eval-mode BN, same metrics, no update. */
 int ics_unet_test_step(ics_net* net, const float* x, const uint8_t* labels, int batch,
                        float metrics[5]);
+/* The K.sum(...) terms behind the ratios of r_m / p_m / f1_m / wr_m (unet/unet.py:159-193) and the two loss means of
+ * the LAST train / test step (data parallel: after the all-reduce, i.e. over the global batch):
+ * sums = [sum_voxels wcce, sum_voxels bce, true_positives, predicted_positives, wr true_positives, wr possible_positives,
+ * voxel count (= possible_positives of r_m: y_true is one-hot)].  The counts are integers held in doubles. */
+int ics_unet_metric_sums(ics_net* net, double sums[7]);
 
 /* Benchmark path: batch resident in HBM, steps enqueued back-to-back on the engine's stream. */
 int ics_unet_upload_batch(ics_net* net, const float* x, const uint8_t* labels, int batch);
@@ -236,6 +241,15 @@ int ics_op_conv3d_forward(const float* x, const float* w, const float* bias, int
 int ics_op_conv3d_backward(const float* x, const float* w, const float* dy, int B, int S, int Cin,
                            int Cout, int taps, float* dx, float* dw);
 
+/* The two 1x1x1 heads with their losses and metrics on a GIVEN trunk output (kernel parity tests against the reference's own
+ * formulas): soft = softmax(x wsoft + bsoft), sig = sigmoid(x wsig + bsig) (unet/unet.py:339-352), then
+ * weighted_categorical_crossentropy / binary_crossentropy / f1_m / wr_m (unet/unet.py:159-221,252-259).
+ * x [M][128], wsoft [128][ncls], bsoft [ncls], wsig [128], bsig [1], labels uint8 [M]; loss_weight <= 0: the scalar ncls.
+ * mode 0: out [M][ncls+1] = probabilities (soft | sig); 1: metrics[5] and sums[7] (ics_unet_metric_sums) only;
+ * 2: also out = dLoss/dlogits.  fused != 0: the GEMM inside the loss kernel (M % 16 == 0, ncls == 95), else GEMM + loss kernel. */
+int ics_op_unet_head(const float* x, const float* wsoft, const float* bsoft, const float* wsig, const float* bsig,
+                     const uint8_t* labels, size_t M, int ncls, float loss_weight, int mode, int fused, float* out,
+                     float metrics[5], double sums[7]);
 /* kernel micro-benchmark on device-resident constant data, HIP-event timed: mode 0 forward
  * (ablate 0 = full kernel, 1 = MFMA+LDS reads only, 2 = MFMA only), 1 backward-data, 2 backward-weight. */
 int ics_op_conv3d_bench(int B, int S, int Cin, int Cout, int taps, int mode, int ablate, int iters,

@@ -688,6 +688,35 @@ def vae_param_shapes(in_ch=1, cond=10, filters=(16, 32, 64, 128), latent=256, d=
     return sh
 
 
+def sampling(zm, zlv, eps):
+    """lattice_vae.py:53-66 with the K.random_normal draw injected."""
+    return zm + np.exp(0.5 * zlv) * eps
+
+
+def mse_loss(x, recon):
+    """lattice_vae.py:232-233: keras `mse` over the FLATTENED tensors -> one scalar (mean over batch too)."""
+    return ((np.asarray(x) - recon) ** 2).mean()
+
+
+def kld_loss(zm, zlv):
+    """lattice_vae.py:235-239 -> (B,)."""
+    return -0.5 * (1 + zlv - zm ** 2 - np.exp(zlv)).sum(-1)
+
+
+def perceptual_from_taps(h1, h2, weights):
+    """lattice_vae.py:264-270: sum_l w_l * mean over the flattened features of (h1_l - h2_l)^2 -> (B,)."""
+    pm = 0.0
+    for a, b_, w in zip(h1, h2, weights):
+        B = a.shape[0]
+        pm = pm + w * ((a - b_).reshape(B, -1) ** 2).mean(-1)
+    return pm
+
+
+def vae_dfc_loss(mse, pm, kld, alpha, beta):
+    """lattice_vae.py:247-253: K.mean(rs + alpha * pm + beta * kl) -- scalar + (B,) + (B,) then the batch mean."""
+    return (mse + alpha * pm + beta * kld).mean()
+
+
 class VaeOracle:
     metric_names = ["Loss", "PM", "MSE", "KLD"]    # lattice_vae.py:123
 
@@ -734,7 +763,7 @@ class VaeOracle:
         hd = np.maximum(a, 0)
         zm = dense_fwd(hd, P["z_mean/kernel"], P["z_mean/bias"])
         zlv = dense_fwd(hd, P["z_log_var/kernel"], P["z_log_var/bias"])
-        z = zm + np.exp(0.5 * zlv) * np.asarray(eps, self.dtype)   # sampling, lattice_vae.py:53-66
+        z = sampling(zm, zlv, np.asarray(eps, self.dtype))
         cache["_enc"] = {"flat": flat, "a": a, "hd": hd, "zm": zm, "zlv": zlv, "eps": eps,
                          "e4shape": h.shape}
         return zm, zlv, z
@@ -756,16 +785,13 @@ class VaeOracle:
     def losses(self, x, recon, zm, zlv, training, pm_cache=None):
         """Returns ([Loss, PM, MSE, KLD] with PM/KLD batch-averaged, per-sample pm, taps)."""
         x = np.asarray(x, self.dtype)
-        mse = ((x - recon) ** 2).mean()
-        kld = -0.5 * (1 + zlv - zm ** 2 - np.exp(zlv)).sum(-1)
+        mse = mse_loss(x, recon)
+        kld = kld_loss(zm, zlv)
         c1, c2 = {}, ({} if pm_cache is None else pm_cache)
         h1 = self.unet.pm_forward(x, training, c1)
         h2 = self.unet.pm_forward(recon, training, c2)
-        pm = 0.0
-        for a, b_, w in zip(h1, h2, self.pm_w):
-            B = a.shape[0]
-            pm = pm + w * ((a - b_).reshape(B, -1) ** 2).mean(-1)
-        loss = (mse + self.alpha * pm + self.beta * kld).mean()
+        pm = perceptual_from_taps(h1, h2, self.pm_w)
+        loss = vae_dfc_loss(mse, pm, kld, self.alpha, self.beta)
         return np.array([loss, pm.mean(), mse, kld.mean()]), h1, h2
 
     def forward_losses(self, x, cond, eps, training):

@@ -28,6 +28,9 @@ CASES = [
     # S = 4 with >= 64 input channels: the Winograd-domain batched GEMMs (conv_winog.hip); backward-weight there needs
     # B % 4 == 0 (the GEMMs' reduction length = 8 B tiles), other batches take the 27-tap kernel for that gradient
     (4, 4, 256, 512, 3), (3, 4, 128, 192, 3), (8, 4, 128, 64, 3), (4, 4, 64, 128, 3),
+    # the reference scripts' default input_shape (d,d,d,4) (train_unet.py:84, train_vae.py:90): encoder conv-0 is a real
+    # 44-channel convolution (4 + 4*10), U-Net c1 has Cin = 4, decoder_output has Cout = 4
+    (2, 16, 44, 16, 3), (2, 32, 4, 32, 3), (2, 16, 16, 4, 3), (1, 32, 44, 16, 3),
 ]
 
 

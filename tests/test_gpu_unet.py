@@ -62,15 +62,17 @@ def _layer_shape(name, B, d):
 # fuse: the BatchNorm-backward-in-backward-data fusions (engine.hip dgrad_bnfuse_ok / skip_bnfuse_ok) forced on at this size --
 # by default they start at 64 MB of activations, i.e. at the bench's batch -- under both max-pool tie rules (the deferred
 # skip launch routes the pooled gradient through the forward's tie masks)
-@pytest.mark.parametrize("ties,B,fuse", [("tf_cpu", 2, False), ("first", 2, False), ("tf_cpu", 3, False), ("tf_cpu", 4, False),
-                                         ("tf_cpu", 2, True), ("first", 2, True), ("tf_cpu", 4, True)])
-def test_unet_train_step_matches_oracle(ties, B, fuse, relerr, monkeypatch):
+# C = 4: the reference scripts' default input_shape (train_unet.py:84) -- c1 is then a 4-channel convolution
+@pytest.mark.parametrize("ties,B,fuse,C", [("tf_cpu", 2, False, 1), ("first", 2, False, 1), ("tf_cpu", 3, False, 1),
+                                           ("tf_cpu", 4, False, 1), ("tf_cpu", 2, True, 1), ("first", 2, True, 1),
+                                           ("tf_cpu", 4, True, 1), ("tf_cpu", 2, False, 4), ("tf_cpu", 3, True, 4)])
+def test_unet_train_step_matches_oracle(ties, B, fuse, C, relerr, monkeypatch):
     """Gradients, BN moving statistics and the Adam update of one train step.
 
     ReLU'(0) is discontinuous, so the fp64 oracle is evaluated with the engine's own ReLU masks
     (exported activations); the oracle refuses masks that differ anywhere except within 1e-5 of the
     kink, so this pins everything but the sign of sub-rounding pre-activations."""
-    d, C = 16, 1
+    d = 16
     lr = 1e-3
     if fuse:
         monkeypatch.setenv("ICSG3D_DGRAD_BNFUSE_MIN", "0")

@@ -61,12 +61,14 @@ def _pm_layer_shapes(B, d):
     return {n: (B, d // r, d // r, d // r, cout[n]) for n, r in res.items()}
 
 
-@pytest.mark.parametrize("B", [2, 3, 5])
-def test_vae_train_step_matches_oracle(B, relerr):
+# C = 4: the reference scripts' default input_shape (train_vae.py:90): e0 is a real 44-channel convolution (no analytic
+# fold of the tiled condition, which exists for C = 1 only), dout has 4 output channels, the frozen U-Net's c1 4 inputs
+@pytest.mark.parametrize("B,C", [(2, 1), (3, 1), (5, 1), (2, 4), (3, 4)])
+def test_vae_train_step_matches_oracle(B, C, relerr):
     """One DFC-VAE train step: [Loss, PM, MSE, KLD], all gradients, BN statistics, frozen U-Net.
     Activation kinks are pinned to the engine's stored activations (oracle.apply_kink).  Odd batch sizes: ragged
     last tiles, split plans and block-to-sample mappings that do not divide evenly."""
-    d, C = 16, 1
+    d = 16
     uo, vo, ue, ve, X, cond, eps = _setup(B, d, C)
     m = ve.train_step(X, cond, eps)
     kink = {n: ve.get_activation(n, s) for n, s in _vae_layer_shapes(B, d, C).items()}
