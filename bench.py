@@ -11,6 +11,10 @@ Prints ONE JSON line on rank 0.
   python bench.py --gpus 1 --steps 20 --warmup 5
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N ...        (no launcher: starts the line above as a child process before touching the GPU,
+                                       relays its JSON line and exit status; never prints an n_gpus: 1 line for N > 1)
+  python bench.py --workload predict  (BASELINE configs[0]: U-Net forward-only, 16 grids)
+  python bench.py --workload generate (generate.py:204-236: decoder -> U-Net -> labels -> atoms on the device)
 """
 from __future__ import annotations
 
@@ -42,27 +46,29 @@ VAE_FLOP_PER_GRID = 33.73e9            # VAE 3 x 2.126 + perceptual
 PMC_TRAFFIC_FILES = ("r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json")
 
 
-def cpu_baseline():
-    """oracle/torch_ref.py (fp32 torch-CPU restatement of the same train step, all host cores) in a
-    subprocess -- the checker timed as a baseline, never the product path.  The GPU number is quoted at 32 grids per
-    step; a 32-grid CPU step takes ~40 s, so the sample is bounded: one warm-up + one timed step at 8 grids, then one
-    timed step at 16 grids (`value`).  Both per-grid rates are reported so that the batch dependence of the CPU path
-    is visible instead of assumed."""
+def cpu_baseline(batch=32, d=32):
+    """oracle/torch_ref.py (fp32 torch-CPU restatement of the same train steps, all host cores) in a subprocess -- the
+    checker timed as a baseline, never the product path.  The sample is the GPU figure's own batch: one warm-up step at 8
+    grids (thread pools, allocator), then ONE timed U-Net train step at `batch` grids (`value`) and ONE timed DFC-VAE train
+    step at `batch` grids (`vae`).  ~20 s + ~5 s on the GPU box's 128 cores; bounded by a 900 s timeout."""
     code = ("import json,sys; sys.path.insert(0, %r); from oracle import torch_ref as T; "
-            "v8,c,s8 = T.time_unet_train_step(B=8, d=32, in_ch=1, steps=1, warmup=1); "
-            "v16,c,s16 = T.time_unet_train_step(B=16, d=32, in_ch=1, steps=1, warmup=0); "
-            "print(json.dumps({'v8': v8, 'v16': v16, 'cores': c, 's8': s8, 's16': s16}))" % ROOT)
+            "T.time_unet_train_step(B=8, d=%d, in_ch=1, steps=1, warmup=0); "
+            "v,c,s = T.time_unet_train_step(B=%d, d=%d, in_ch=1, steps=1, warmup=0); "
+            "vv,c,sv = T.time_vae_train_step(B=%d, d=%d, in_ch=1, steps=1, warmup=0); "
+            "vp,c,sp = T.time_unet_predict(B=16, d=%d, in_ch=1, steps=1, warmup=0); "
+            "print(json.dumps({'v': v, 's': s, 'vv': vv, 'sv': sv, 'vp': vp, 'sp': sp, 'cores': c}))"
+            % (ROOT, d, batch, d, batch, d, d))
     try:
         out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
         r = json.loads(out.stdout.strip().splitlines()[-1])
-        return {"value": round(r["v16"], 4), "unit": "voxel-grids/s", "cores": int(r["cores"]), "kind": "port",
-                "value_at_8_grids_per_step": round(r["v8"], 4),
-                "sample": "oracle/torch_ref.py fp32 U-Net fwd+bwd+Adam, torch-CPU channels_last_3d, all host cores: "
-                          "one warm-up + one timed step on 8 synthetic 32^3 grids (%.1f s/step), then one timed step on "
-                          "16 grids (%.1f s/step; `value`).  The GPU figure is quoted at 32 grids per step; a 32-grid CPU "
-                          "step (~%.0f s) is outside the bounded sample -- the per-grid rates at 8 and 16 grids are both "
-                          "given so the trend is visible.  The reference's Keras/TF path is not installable "
-                          "here" % (r["s8"], r["s16"], 2 * r["s16"])}
+        return {"value": round(r["v"], 4), "unit": "voxel-grids/s", "cores": int(r["cores"]), "kind": "port",
+                "vae": {"value": round(r["vv"], 4), "unit": "voxel-grids/s", "s_per_step": round(r["sv"], 2)},
+                "predict": {"value": round(r["vp"], 4), "unit": "voxel-grids/s", "s_per_call": round(r["sp"], 2)},
+                "sample": "oracle/torch_ref.py fp32, torch-CPU channels_last_3d, all host cores: one untimed warm-up step "
+                          "at 8 grids, then ONE timed U-Net fwd+bwd+Adam step on %d synthetic %d^3 grids (%.1f s; `value`, "
+                          "the batch the GPU figure is quoted on), ONE timed DFC-VAE train step on %d grids (%.1f s; `vae`) "
+                          "and ONE timed U-Net forward on 16 grids (%.1f s; `predict`, BASELINE configs[0]).  The "
+                          "reference's Keras/TF path is not installable here" % (batch, d, r["s"], batch, r["sv"], r["sp"])}
     except Exception as e:  # pragma: no cover
         return {"value": None, "unit": "voxel-grids/s", "cores": os.cpu_count(), "kind": "port",
                 "sample": "cpu baseline failed: %s" % e}
@@ -113,17 +119,23 @@ def main():
     ap.add_argument("--d", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the DFC-VAE block (profiling runs)")
-    ap.add_argument("--workload", choices=("unet", "vae", "joint"), default="unet",
-                    help="unet = the contract line (BASELINE configs[1] + the configs[2] secondary block); "
-                         "vae / joint = profiling runs of the DFC-VAE step alone / U-Net + DFC-VAE step per iteration")
+    ap.add_argument("--workload", choices=("unet", "vae", "joint", "predict", "generate"), default="unet",
+                    help="unet = the contract line (BASELINE configs[1] + the configs[2] secondary block + the two inference "
+                         "blocks); vae / joint = profiling runs of the DFC-VAE step alone / U-Net + DFC-VAE step per iteration; "
+                         "predict = configs[0] (U-Net forward-only, 16 grids); generate = decoder -> U-Net -> labels -> atoms")
+    ap.add_argument("--no-inference", action="store_true", help="skip the predict / generate blocks of the contract line")
     ap.add_argument("--sync-bn", action="store_true", help="data parallel: global-batch BatchNorm statistics")
     ap.add_argument("--dump-rows", type=str, default=None, help="write the per-launch-site profile rows (JSON) here")
     args = ap.parse_args()
 
+    # --gpus N > 1 without a launcher: become the launcher BEFORE any HIP call (icsg3d_amd/launcher.py); a mismatch
+    # between --gpus and WORLD_SIZE, or fewer than N visible GPUs, exits non-zero -- never an n_gpus: 1 line for --gpus 8
+    from icsg3d_amd.launcher import ensure_ranks
+    ensure_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
@@ -164,8 +176,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    def timed(step, engines, profiled):
-        """W warm-up steps, then EXACTLY K steps between barrier + device sync on both sides; max over ranks."""
+    def timed(step, engines, profiled, step_profile=None):
+        """W warm-up steps, then EXACTLY K steps between barrier + device sync on both sides; max over ranks.
+        step_profile: the step of the untimed all-events pass when it must differ (joint: the two engines serialised, so
+        that a kernel's event bracket does not time a kernel of the other stream it shares the chip with)."""
         def barrier():
             for e in engines:
                 e.sync()
@@ -180,7 +194,7 @@ def main():
             e.profile_filter("")
             e.profile_enable(True)
         for _ in range(2):
-            step()
+            (step_profile or step)()
         barrier()
         rows_all = [r for e in profiled for r in e.profile_rows()]
         for r in rows_all:
@@ -201,10 +215,14 @@ def main():
             e.profile_enable(True)
         barrier()
         t0 = time.perf_counter()
+        for e in engines:
+            e.timer_start()              # an event on each engine's stream: the GPU's own clock over the same K steps
         for _ in range(args.steps):
             step()
+        gpu_ms = max(e.timer_stop() for e in engines)
         barrier()
         elapsed = max_over_ranks(time.perf_counter() - t0)
+        timed.gpu_active_s = gpu_ms * 1e-3
         rows = [r for e in profiled for r in e.profile_rows()]
         for e in profiled:
             e.profile_enable(False)
@@ -234,10 +252,14 @@ def main():
         unet.upload_batch(X, labels)
         if use_dist:
             init_engine_comm(unet, dist, rank, world, sync_bn=args.sync_bn, force=force)
+            got = unet.comm_info()["nranks"]
+            if got != world:
+                raise SystemExit("RCCL communicator has %d ranks, --gpus %d" % (got, world))
 
     if args.workload == "unet":
         elapsed, elapsed_plain, rows_live, rows = timed(lambda: unet.train_step_resident(False), [unet], [unet])
         unet_launches = timed.kernel_launches_per_step
+        gpu_active_s = timed.gpu_active_s
         metrics = unet.train_step_resident(True)   # untimed: sanity that the job is still finite
         if not np.all(np.isfinite(metrics)):
             raise SystemExit("non-finite training metrics: %s" % metrics)
@@ -266,6 +288,11 @@ def main():
                 "value": round(value, 2), "unit": "voxel-grids/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                # ranks of the RCCL communicator the gradient all-reduce ran on (0: single process, no communicator)
+                "rccl_ranks": comm["nranks"],
+                # the K timed steps on the GPU's own clock (HIP events on the engine's stream around the same region):
+                # ms_per_step must agree with gpu_active_s / steps, or the host clock timed something else
+                "gpu_active_s": round(gpu_active_s, 5),
                 "config": {"workload": "AtomUnet fwd+bwd+Adam train step, %d x %d^3 x 1 grids per GPU "
                                        "(BASELINE.json configs[1]; the metric's VAE half is timed right after as "
                                        "`secondary` = configs[2], and `unet_plus_vae` is one U-Net step + one DFC-VAE step "
@@ -320,8 +347,140 @@ def main():
                             for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:10]},
             }
 
+    # ---- inference configurations (N = 1): BASELINE configs[0] and the generate.py tail
+    def simple_timed(call, engine, profiled):
+        """W warm-up calls, an all-events profiling pass of 2 calls, then K timed calls (host clock around device syncs +
+        the engine's own device timer).  Returns (seconds, gpu seconds, per-call profile rows)."""
+        for _ in range(args.warmup):
+            call()
+        engine.sync()
+        for e in profiled:
+            e.profile_filter("")
+            e.profile_enable(True)
+        for _ in range(2):
+            call()
+        engine.sync()
+        rows = [r for e in profiled for r in e.profile_rows()]
+        for e in profiled:
+            e.profile_enable(False)
+        for r in rows:
+            r["ms"] /= 2.0; r["flop"] /= 2.0; r["bytes"] /= 2.0; r["launches"] //= 2
+        engine.sync()
+        t0 = time.perf_counter()
+        engine.timer_start()
+        for _ in range(args.steps):
+            call()
+        gpu_ms = engine.timer_stop()
+        engine.sync()
+        return time.perf_counter() - t0, gpu_ms * 1e-3, rows
+
+    def kernel_table(rows, top=6):
+        kern = by_kernel(rows)
+        gemms = {k: v for k, v in kern.items() if v["flop"] > 0}
+        dom_name, dom = max(gemms.items(), key=lambda kv: kv[1]["ms"])
+        exec_flop = sum(v["flop"] * wino(k) for k, v in kern.items())
+        table = {k: {"ms_per_call": round(v["ms"], 3),
+                     "tflops": round(v["flop"] * wino(k) / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 and v["flop"] > 0 else None}
+                 for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:top]}
+        return dom_name, dom, exec_flop, table
+
+    def predict_block(eng):
+        """BASELINE configs[0]: model.predict on 16 synthetic grids, eval-mode BatchNorm, inputs resident in HBM, the two
+        output tensors left in HBM (`value`); and the same forward ending in the uint8 argmax / 0.8-threshold volumes of
+        generate.py:221-225 (`labels_only`: 2 bytes per voxel of output instead of 384)."""
+        Bp = min(16, eng.max_batch)
+        Xp, labp, _ = synthetic_batch(Bp, d, C, seed=100)
+        eng.upload_batch(Xp, labp)
+        sec, gpu_s, rows = simple_timed(lambda: eng.predict_resident(False), eng, [eng])
+        sec_l, gpu_l, _ = simple_timed(lambda: eng.predict_resident(True, 0.8), eng, [eng])
+        dom_name, dom, exec_flop, table = kernel_table(rows)
+        scale = (d / 32.0) ** 3
+        ms = sec / args.steps * 1e3
+        flop = 125.886e9 * scale * Bp                                   # SURVEY 8(d): U-Net forward per grid
+        by_full = (95.75e6 + 70.78e6) * scale * Bp + 124.6e6            # SURVEY 8(d): sum in + sum out per grid + weights
+        by_lab = by_full - (96 * 4 - 2) * (32 ** 3) * scale * Bp        # the head's 96 floats per voxel -> 2 bytes
+        ex = dom["flop"] * wino(dom_name) / (dom["ms"] * 1e-3) / 1e12
+        return {"workload": "AtomUnet.model.predict, %d x %d^3 x 1 grids, eval-mode BatchNorm (BASELINE.json configs[0]); "
+                            "inputs and outputs resident in HBM" % (Bp, d),
+                "value": round(Bp * args.steps / sec, 2), "unit": "voxel-grids/s", "ms_per_call": round(ms, 3),
+                "gpu_active_s": round(gpu_s, 5), "steps": args.steps, "warmup": args.warmup, "batch": Bp,
+                "labels_only": {"value": round(Bp * args.steps / sec_l, 2), "ms_per_call": round(sec_l / args.steps * 1e3, 3),
+                                "hbm_frac": round(by_lab / (sec_l / args.steps) / (PEAK_HBM_GBS * 1e9), 4),
+                                "algorithmic_gb_per_call": round(by_lab / 1e9, 3)},
+                "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": round(ex, 2), "peak": PEAK_FP32_TFLOPS,
+                             "unit": "TFLOP/s", "frac": round(ex / PEAK_FP32_TFLOPS, 4),
+                             "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 4),
+                             "traffic": None},
+                "roofline_call": {"executed_tflop_per_call": round(exec_flop / 1e12, 3),
+                                  "compute_frac": round(exec_flop / (ms * 1e-3) / (PEAK_FP32_TFLOPS * 1e12), 4),
+                                  "direct_conv_tflop_per_call": round(flop / 1e12, 3),
+                                  "direct_conv_equivalent_tflops": round(flop / (ms * 1e-3) / 1e12, 2),
+                                  "hbm_frac": round(by_full / (ms * 1e-3) / (PEAK_HBM_GBS * 1e9), 4),
+                                  "algorithmic_gb_per_call": round(by_full / 1e9, 3)},
+                "kernels": table}
+
+    def generate_block(eng):
+        """generate.py:204-236 on the device: decoder.predict -> unet.model.predict -> argmax / threshold -> connected
+        components (> 3 voxels) -> majority vote + centroids, one C-ABI call per batch (ics_vae_decode_to_unet_atoms).
+        z and cond go up (1 KB per grid); species, mask, the density channel and one row of integers per atom come back
+        (the arrays generate.py saves).  The convexity test / recursive split of the non-convex components is host work
+        (icsg3d_amd/watershed.py, Qhull) and is not in this figure.  Random weights never reach sig >= 0.8, so the threshold
+        is the 90 % quantile of this batch's own sigmoid output -- components exist, the device pass has work to do."""
+        Bg = eng.max_batch
+        gvae = VaeEngine(eng, in_channels=C, d=d, max_batch=Bg)
+        gvae.set_weights(glorot_params(vae_param_shapes(C, d=d), seed=3))
+        rng = np.random.default_rng(7)
+        z = rng.standard_normal((Bg, 256)).astype(np.float32)
+        cnd = np.eye(10, dtype=np.float32)[np.arange(Bg) % 10]
+        thr = float(np.quantile(eng.predict(gvae.decode(z[:2], cnd[:2]))[1], 0.9))
+        res = {}
+
+        def call():
+            res["out"] = gvae.decode_to_atoms(eng, z, cnd, thresh=thr, max_atoms=4096)
+        sec, gpu_s, rows = simple_timed(call, gvae, [gvae, eng])
+        dom_name, dom, exec_flop, table = kernel_table(rows)
+        scale = (d / 32.0) ** 3
+        ms = sec / args.steps * 1e3
+        flop = (125.886e9 + 1.62e9) * scale * Bg                        # SURVEY 8(a): U-Net fwd + decoder fwd per grid
+        ex = dom["flop"] * wino(dom_name) / (dom["ms"] * 1e-3) / 1e12
+        out_g = res["out"]
+        gvae.close()
+        return {"workload": "generate.py:204-236 tail: decoder -> U-Net -> argmax / threshold -> components -> atoms, "
+                            "%d x %d^3 x 1 grids per call; host <-> device copies of the call included" % (Bg, d),
+                "value": round(Bg * args.steps / sec, 2), "unit": "voxel-grids/s", "ms_per_call": round(ms, 3),
+                "gpu_active_s": round(gpu_s, 5), "steps": args.steps, "warmup": args.warmup, "batch": Bg,
+                "threshold": round(thr, 4), "mask_fraction": round(float(out_g["mask"].mean()), 4),
+                "atoms_per_grid": round(float(np.mean(out_g["n_atoms"])), 1),
+                "components_per_grid": round(float(np.mean(out_g["n_components"])), 1),
+                "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": round(ex, 2), "peak": PEAK_FP32_TFLOPS,
+                             "unit": "TFLOP/s", "frac": round(ex / PEAK_FP32_TFLOPS, 4), "traffic": None},
+                "roofline_call": {"executed_tflop_per_call": round(exec_flop / 1e12, 3),
+                                  "compute_frac": round(exec_flop / (ms * 1e-3) / (PEAK_FP32_TFLOPS * 1e12), 4),
+                                  "direct_conv_tflop_per_call": round(flop / 1e12, 3)},
+                "kernels": table}
+
+    if args.workload in ("predict", "generate"):
+        if world != 1:
+            raise SystemExit("--workload %s is a single-GPU configuration" % args.workload)
+        eng = UnetEngine(in_channels=C, num_classes=95, d=d, max_batch=B)
+        eng.set_weights(PU)
+        blk = predict_block(eng) if args.workload == "predict" else generate_block(eng)
+        out = {"metric": "voxel-grids/s (%s) for %d^3 grids" % ("U-Net forward-only" if args.workload == "predict"
+                                                                  else "generate tail: decoder + U-Net forward + atoms", d),
+               "n_gpus": 1, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+               "data": "synthetic", "config": {"workload": blk["workload"], "global_batch": blk["batch"], "grid": d,
+                                               "parallelism": "dp1"}}
+        out.update({k: v for k, v in blk.items() if k != "workload"})
+        out["ms_per_step"] = out["ms_per_call"]
+        if not args.no_cpu_baseline:
+            cb = cpu_baseline(B, d)
+            out["cpu_baseline"] = {"value": cb.get("predict", {}).get("value"), "unit": "voxel-grids/s", "cores": cb["cores"],
+                                   "kind": "port", "sample": cb["sample"]}
+        else:
+            out["cpu_baseline"] = None
+
     # ---- DFC-VAE step (BASELINE configs[2]): encoder + decoder + frozen perceptual U-Net (batch-statistics BN)
-    if not (args.workload == "unet" and args.no_secondary):
+    if args.workload in ("unet", "vae", "joint") and not (args.workload == "unet" and args.no_secondary):
         pm = unet if args.workload == "unet" else UnetEngine(in_channels=C, d=d, max_batch=B)
         if pm is not unet:
             pm.set_weights(PU)
@@ -336,10 +495,16 @@ def main():
                 unet.train_step_resident(False)
                 vae.train_step_resident(False)
             engines, profiled = [unet, vae], [unet, vae, pm]
+
+            def step_serial():           # the all-events pass: one engine at a time, or a bracket on one stream times
+                unet.train_step_resident(False); unet.sync()     # a kernel slowed down by the other stream's kernels
+                vae.train_step_resident(False); vae.sync()
         else:
             step = lambda: vae.train_step_resident(False)  # noqa: E731
             engines, profiled = [vae], [vae, pm]
-        elapsed_v, elapsed_v_plain, _rows_v_live, rows_v = timed(step, engines, profiled)
+            step_serial = None
+        elapsed_v, elapsed_v_plain, _rows_v_live, rows_v = timed(step, engines, profiled, step_serial)
+        gpu_active_v = timed.gpu_active_s
         mv = vae.train_step_resident(True)
         if not np.all(np.isfinite(mv)):
             raise SystemExit("non-finite DFC-VAE metrics: %s" % mv)
@@ -354,6 +519,7 @@ def main():
                                 "+ bwd-data, Adam), %d x %d^3 x 1 grids per GPU (BASELINE.json configs[2])" % (B, d)),
                    "value": round(world * B * args.steps / elapsed_v, 2), "unit": "voxel-grids/s",
                    "ms_per_step": round(ms_v, 3), "ms_per_step_events_off": round(elapsed_v_plain / args.steps * 1e3, 3),
+                   "gpu_active_s": round(gpu_active_v, 5),
                    "steps": args.steps, "warmup": args.warmup,
                    "executed_tflop_per_step": round(exec_flop / 1e12, 3),
                    "compute_frac": round(exec_flop / (ms_v * 1e-3) / (PEAK_FP32_TFLOPS * 1e12), 4),
@@ -386,13 +552,23 @@ def main():
                 out["roofline"] = {"bound": "mfma", "kernel": dom_name, "achieved": round(ex, 2),
                                    "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(ex / PEAK_FP32_TFLOPS, 4),
                                    "algorithmic_equivalent_tflops": blk["dominant_kernel"]["algorithmic_equivalent_tflops"],
-                                   "traffic": None}
+                                   "traffic": None,
+                                   "source": ("untimed all-events pass with the two engines SERIALISED (in the timed region "
+                                              "they run on two streams and share the chip: a per-kernel bracket there times "
+                                              "contention, not the kernel); step-level compute_frac is the timed figure")
+                                             if args.workload == "joint" else "untimed all-events pass"}
                 out["detail"] = blk
                 out["cpu_baseline"] = None
 
+    if args.workload == "unet" and world == 1 and not args.no_inference:
+        out["inference"] = {"predict": predict_block(unet), "generate": generate_block(unet)}
     if rank == 0:
         if args.workload == "unet" and world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(B, d)
+            if "secondary" in out and out["cpu_baseline"].get("vae"):
+                out["secondary"]["cpu_baseline"] = out["cpu_baseline"]["vae"]
+            if "inference" in out and out["cpu_baseline"].get("predict"):
+                out["inference"]["predict"]["cpu_baseline"] = out["cpu_baseline"]["predict"]
         line = json.dumps(out) + "\n"
         if json_fd is not None:
             sys.stdout.flush()

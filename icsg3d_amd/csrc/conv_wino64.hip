@@ -429,6 +429,8 @@ __global__ __launch_bounds__(512) void conv_wino64_kernel(const float* __restric
 #ifndef ICS_W64_EPI_PREFETCH
 #define ICS_W64_EPI_PREFETCH 1   // 1: everything the final stage reads from global memory is requested before the first
 #endif                           //    pass, under the output transform, instead of after each pass' second barrier
+  static_assert(ICS_W64_EPI_PREFETCH || FOLD < 2, "the FOLD >= 2 epilogues (BatchNorm-backward fold, pooled gradient) exist only "
+                                                  "in the prefetching final stage");
 #if ICS_W64_EPI_PREFETCH
   vf4 pbias[2], pacc[2][2], psv[2][2], pmu[2], prs[2], pk[FOLD >= 2 ? 2 : 1], ppool[FOLD == 3 ? 2 : 1];
   unsigned pmask[2] = {0u, 0u};

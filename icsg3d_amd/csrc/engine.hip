@@ -277,6 +277,7 @@ struct Net {
   float tap_coef[4] = {0, 0, 0, 0};
   double* tap_partial[4] = {nullptr, nullptr, nullptr, nullptr};
   int resident_batch = 0;
+  hipEvent_t timer_ev[2] = {nullptr, nullptr};   // ics_net_timer_start / _stop
   int last_batch = 0;                 // batch of the most recent forward (activation export)
 
   // VAE specifics
@@ -291,6 +292,7 @@ struct Net {
     if (comm_bn) ncclCommDestroy(comm_bn);
     if (comm) ncclCommDestroy(comm);
     for (void* p : allocs) (void)hipFree(p);
+    for (hipEvent_t e : timer_ev) if (e) (void)hipEventDestroy(e);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
     if (st2) (void)hipStreamDestroy(st2);
@@ -1417,7 +1419,16 @@ __global__ void split_cols_kernel(const float* __restrict__ tmp, int K, int N, i
   else b[k * (N - na) + (c - na)] = tmp[i];
 }
 
+// Cross-layer backward state (a consumer's launch leaves work or results for its producer's backward) is cleared on the
+// success path as it is consumed; an error between a consumer and its producer would leave it set for the NEXT pass
+// (a stale dy taken for a fresh one, finalize jobs pointing at old partials).  Every backward pass starts clean.
+static void reset_backward_state(Net& n) {
+  for (auto& L : n.layers) { L->dy_ready = false; L->deferred_skip = nullptr; L->db_blocks = 0; }
+  n.colsum.n = 0;
+}
+
 static int unet_backward(Net& n, int B) {
+  reset_backward_state(n);
   UnetRefs r = unet_refs(n);
   ConvLayer& H = *n.head;
   const size_t M = n.rows(H, B);
@@ -1733,6 +1744,8 @@ static int vae_step(Net& n, int B, bool training, float* metrics) {
   const BnSync saved_bs = u.bn_sync;
   if (n.sync()) { u.comm = n.comm; u.sync_bn = 1; u.bn_sync = n.bn_sync; }
   int rc = 0;
+  reset_backward_state(n);
+  reset_backward_state(u);
   do {
     VaeRefs r = vae_refs(n);
     UnetRefs ur = unet_refs(u);
@@ -2195,6 +2208,50 @@ int ics_unet_predict_labels(ics_net* net, const float* x, int batch, float thres
   return 0;
 }
 
+// Benchmark path of model.predict (BASELINE configs[0]): the forward pass on the batch ics_unet_upload_batch left in HBM,
+// enqueued without a host round trip; the outputs stay on the device (probabilities [M][ncls+1] in the head's buffer, or
+// -- labels_only -- the uint8 argmax / threshold volumes of generate.py:221-225 in its scratch).
+int ics_unet_predict_resident(ics_net* net, int labels_only, float thresh) {
+  ICS_TRY(require_kind(net, 0));
+  Net& n = net->n;
+  ICS_CHECK(n.resident_batch > 0, "no resident batch: call ics_unet_upload_batch first");
+  const int batch = n.resident_batch;
+  ICS_TRY(unet_forward_trunk(n, batch, false, false, false, n.x_in));
+  ICS_TRY(unet_head_loss(n, batch, 0, 0));
+  if (labels_only) {
+    const size_t M = n.rows(*n.head, batch);
+    unsigned char* d_species = reinterpret_cast<unsigned char*>(n.head->dy);
+    n.prof.begin(n.st, "labels", 0, 4.0 * M * (n.ncls + 1) + 2.0 * M);
+    ICS_LAUNCH(labels_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, n.st, n.head->s, n.ncls + 1,
+                       n.ncls, M, thresh, d_species, d_species + M);
+    n.prof.end(n.st);
+    ICS_HIP(hipGetLastError());
+  }
+  return 0;
+}
+
+// Device-clock bracket on the engine's stream (bench.py's gpu_active_s): start records an event, stop records a second
+// one, waits for it and returns the milliseconds between the two as the GPU saw them.
+int ics_net_timer_start(ics_net* net) {
+  ICS_CHECK(net, "null handle");
+  Net& n = net->n;
+  ICS_HIP(hipSetDevice(n.device));
+  if (!n.timer_ev[0]) { ICS_HIP(hipEventCreate(&n.timer_ev[0])); ICS_HIP(hipEventCreate(&n.timer_ev[1])); }
+  ICS_HIP(hipEventRecord(n.timer_ev[0], n.st));
+  return 0;
+}
+int ics_net_timer_stop(ics_net* net, double* ms) {
+  ICS_CHECK(net && ms, "null argument");
+  Net& n = net->n;
+  ICS_CHECK(n.timer_ev[0] != nullptr, "ics_net_timer_stop without ics_net_timer_start");
+  ICS_HIP(hipEventRecord(n.timer_ev[1], n.st));
+  ICS_HIP(hipEventSynchronize(n.timer_ev[1]));
+  float f = 0.f;
+  ICS_HIP(hipEventElapsedTime(&f, n.timer_ev[0], n.timer_ev[1]));
+  *ms = (double)f;
+  return 0;
+}
+
 int ics_unet_upload_batch(ics_net* net, const float* x, const uint8_t* labels, int batch) {
   ICS_TRY(require_kind(net, 0));
   ICS_TRY(unet_upload(net->n, x, labels, batch));
@@ -2478,13 +2535,27 @@ int ics_net_comm_init(ics_net* net, int rank, int nranks, const char uid[128]) {
   // statistics on the gradient communicator every SyncBN collective of the backward pass waited for the bucket in
   // flight (and the next bucket for it), and the overlap was lost.  A second communicator over the same ranks
   // (ncclCommSplit, color 0, key = rank: no second unique id to hand around) removes the coupling.
-  // Not fatal if the split fails (it is a collective: it fails on every rank or on none): the small collectives then share
-  // the gradient communicator as before round 4 -- correct, only without the overlap.
-  ncclResult_t rs = getenv("ICSG3D_NO_COMM_SPLIT") ? ncclInvalidUsage : ncclCommSplit(n.comm, 0, rank, &n.comm_bn, nullptr);
-  if (rs != ncclSuccess || n.comm_bn == nullptr) {
-    if (!getenv("ICSG3D_NO_COMM_SPLIT"))
-      fprintf(stderr, "icsg3d: ncclCommSplit failed (%s): BatchNorm / metric collectives share the gradient communicator\n",
-              ncclGetErrorString(rs));
+  // Not fatal if the split fails: the small collectives then share the gradient communicator as before round 4 --
+  // correct, only without the overlap.  The ranks AGREE on the outcome (a min all-reduce of the success flag on the
+  // gradient communicator): a rank that fell back alone while the others used comm_bn would hang the first collective.
+  // ICSG3D_NO_COMM_SPLIT=1 (set it on every rank) is the escape hatch: one communicator, everything serialised on it.
+  // Two communicators in flight on one device: every rank issues the same operations in the same host order on the same
+  // two streams; an RCCL kernel that waits for its peers holds a few workgroups, the compute kernels ahead of the other
+  // stream's collective never wait on anything, so both collectives become resident on every rank and complete.
+  const bool want_split = getenv("ICSG3D_NO_COMM_SPLIT") == nullptr;
+  ncclResult_t rs = want_split ? ncclCommSplit(n.comm, 0, rank, &n.comm_bn, nullptr) : ncclInvalidUsage;
+  double ok = (rs == ncclSuccess && n.comm_bn != nullptr) ? 1.0 : 0.0;
+  const double mine = ok;
+  ICS_HIP(hipMemcpyAsync(n.d_red, &ok, sizeof(double), hipMemcpyHostToDevice, n.st));
+  ncclResult_t ra = ncclAllReduce(n.d_red, n.d_red, 1, ncclDouble, ncclMin, n.comm, n.st);
+  ICS_CHECK(ra == ncclSuccess, std::string("ncclAllReduce(split agreement): ") + ncclGetErrorString(ra));
+  ICS_HIP(hipMemcpyAsync(&ok, n.d_red, sizeof(double), hipMemcpyDeviceToHost, n.st));
+  ICS_HIP(hipStreamSynchronize(n.st));
+  if (ok < 0.5) {
+    if (want_split)
+      fprintf(stderr, "icsg3d: ncclCommSplit failed on %s (%s): BatchNorm / metric collectives share the gradient communicator "
+                      "on every rank\n", mine < 0.5 ? "this rank" : "another rank", ncclGetErrorString(rs));
+    if (n.comm_bn) ncclCommDestroy(n.comm_bn);
     n.comm_bn = nullptr;
   }
   n.bn_sync = BnSync{n.small(), nranks, n.sync_local, n.sync_gathered};

@@ -74,6 +74,11 @@ static int run(int d, int C, int B, int with_comm) {
     OK(ics_unet_train_step(unet, x, lab, b, mm));
     OK(ics_unet_test_step(unet, x, lab, b, mm));
     { double ms[7]; OK(ics_unet_metric_sums(unet, ms)); }
+    OK(ics_unet_upload_batch(unet, x, lab, b));
+    OK(ics_net_timer_start(unet));
+    OK(ics_unet_predict_resident(unet, 0, 0.8f));
+    OK(ics_unet_predict_resident(unet, 1, 0.8f));
+    { double tms; OK(ics_net_timer_stop(unet, &tms)); }
     OK(ics_unet_predict(unet, x, b, soft, sig));
     OK(ics_unet_predict_labels(unet, x, b, 0.8f, sp, mk));
     OK(ics_vae_train_step(vae, x, cond, eps, b, mv));

@@ -33,6 +33,7 @@ hipError_t hipEventCreate(hipEvent_t* e) { *e = (hipEvent_t)std::malloc(8); retu
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = (hipEvent_t)std::malloc(8); return hipSuccess; }
 hipError_t hipEventDestroy(hipEvent_t e) { std::free(e); return hipSuccess; }
 hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.001f; return hipSuccess; }
 hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidDevice; }

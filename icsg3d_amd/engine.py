@@ -112,6 +112,15 @@ class _Net:
     def sync(self):
         L.check(self._lib.ics_net_sync(self._h))
 
+    def timer_start(self):
+        L.check(self._lib.ics_net_timer_start(self._h))
+
+    def timer_stop(self):
+        """milliseconds of device time on the engine's stream since timer_start (waits for the work in between)"""
+        ms = C.c_double(0)
+        L.check(self._lib.ics_net_timer_stop(self._h, C.byref(ms)))
+        return ms.value
+
     # ---- profiling (HIP events on the engine's stream)
     def profile_enable(self, on=True):
         L.check(self._lib.ics_net_profile_enable(self._h, 1 if on else 0))
@@ -233,6 +242,10 @@ class UnetEngine(_Net):
         x = self._check_x(x)
         lab = self._labels(labels, x.shape[0])
         L.check(self._lib.ics_unet_upload_batch(self._h, L.fptr(x), L.u8ptr(lab), x.shape[0]))
+
+    def predict_resident(self, labels_only=False, thresh=0.8):
+        """model.predict on the uploaded batch, enqueued only; the outputs stay in HBM (benchmark path)."""
+        L.check(self._lib.ics_unet_predict_resident(self._h, 1 if labels_only else 0, float(thresh)))
 
     def train_step_resident(self, want_metrics=False):
         if want_metrics:

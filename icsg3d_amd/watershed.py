@@ -51,8 +51,9 @@ def segment_atoms(mask, species, min_voxels=3, max_atoms=512, num_species=95, wa
     """mask / species: (B,d,d,d) arrays (non-zero mask = foreground; species = class ids < num_species).
     Connected components + size filter + region statistics with EVERY kept component taken as convex (the first pass
     of segment_nuclei; `watershed_clustering` continues from it).
-    Returns dict(regions int32 (B,d,d,d) | None, n_components (B,), n_atoms (B,), stats int32 (B,max_atoms,11),
-    atoms [(species list, mean list)] per sample, failed (B,) bool: more than max_atoms kept components)."""
+    Returns dict(regions int32 (B,d,d,d) | None, mask u8, species u8 (the inputs, as `refine_atoms` needs them),
+    n_components (B,), n_atoms (B,), stats int32 (B,max_atoms,11), atoms [(species list, mean list)] per sample,
+    failed (B,) bool: more than max_atoms kept components)."""
     mask = np.ascontiguousarray(np.asarray(mask) != 0, dtype=np.uint8)
     species = np.ascontiguousarray(species, dtype=np.uint8)
     if mask.ndim != 4 or mask.shape != species.shape or len(set(mask.shape[1:])) != 1:
@@ -66,8 +67,8 @@ def segment_atoms(mask, species, min_voxels=3, max_atoms=512, num_species=95, wa
     failed = counts[:, 1] > max_atoms
     counts = counts.copy()
     counts[failed, 1] = 0
-    return {"regions": regions, "n_components": counts[:, 0].copy(), "n_atoms": counts[:, 1].copy(), "stats": stats,
-            "atoms": _atoms_from_stats(counts, stats, d ** 3), "failed": failed}
+    return {"regions": regions, "mask": mask, "species": species, "n_components": counts[:, 0].copy(),
+            "n_atoms": counts[:, 1].copy(), "stats": stats, "atoms": _atoms_from_stats(counts, stats, d ** 3), "failed": failed}
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -133,9 +134,19 @@ def region_stats(R, species, num_species=95):
 # ----------------------------------------------------------------------------------------------------------------------
 # host side: convexity test and the recursion of segment_nuclei
 # ----------------------------------------------------------------------------------------------------------------------
-def convex_hull_volume(img, tolerance=1e-10):
+class DegenerateComponent(ValueError):
+    """A kept component (> 3 voxels) whose voxels are coplanar or collinear.  scikit-image 0.17.2's convex_hull_image
+    (the reference's pin, requirements.txt) reduces a 3-D point set to its hull vertices with an UNGUARDED
+    scipy.spatial.ConvexHull(coords); Qhull refuses flat input, the QhullError leaves watershed_clustering, and
+    generate.py:246-248 prints "Failed" and skips the whole sample.  Parity means the same here: the sample fails."""
+
+
+def convex_hull_volume(img, tolerance=1e-10, degenerate="raise"):
     """np.count_nonzero(skimage.morphology.convex_hull_image(img)) for a 3-D box: Qhull over the voxel coordinates
-    offset by +-0.5 along each axis, grid points counted when every hull inequality is < tolerance (watershed.py:80-81)."""
+    offset by +-0.5 along each axis, grid points counted when every hull inequality is < tolerance (watershed.py:80-81).
+    degenerate: "raise" (default, the reference stack's behaviour: DegenerateComponent for coplanar / collinear sets) or
+    "solid" (lenient, NOT the reference: the +-0.5 offsets alone make the set full-dimensional, as later scikit-image
+    releases effectively do)."""
     from scipy.spatial import ConvexHull, QhullError
     pts = np.argwhere(np.asarray(img) != 0).astype(np.float64)
     if len(pts) == 0:
@@ -143,8 +154,10 @@ def convex_hull_volume(img, tolerance=1e-10):
     try:                                               # skimage first reduces the set to its hull vertices
         h0 = ConvexHull(pts)
         pts = h0.points[h0.vertices]
-    except (QhullError, ValueError):                   # flat / collinear sets: the offsets below make them solid
-        pass
+    except (QhullError, ValueError) as e:              # flat / collinear sets
+        if degenerate != "solid":
+            raise DegenerateComponent("component of %d voxels is flat: convex_hull_image fails in the reference stack "
+                                      "(%s)" % (len(pts), type(e).__name__)) from e
     off = np.zeros((6, 3))
     off[[0, 1], 0] = (-0.5, 0.5); off[[2, 3], 1] = (-0.5, 0.5); off[[4, 5], 2] = (-0.5, 0.5)
     hull = ConvexHull(np.unique((pts[:, None, :] + off[None]).reshape(-1, 3), axis=0))
@@ -155,10 +168,12 @@ def convex_hull_volume(img, tolerance=1e-10):
     return int(np.count_nonzero(inside))
 
 
-def segment_nuclei(binary, wmin=8, it=1, max_iters=5, min_convexity=0.8, tie="heap", labelled=None, trace=None):
+def segment_nuclei(binary, wmin=8, it=1, max_iters=5, min_convexity=0.8, tie="heap", labelled=None, trace=None,
+                   degenerate="raise"):
     """watershed.py:40-150 (species / intensity ride along in the reference without influencing R and are omitted).
     binary: int volume (D,H,W).  labelled: optional (labels, n, stats) of `binary` already computed on the device
-    (the batched first pass).  Returns R float64 like the reference."""
+    (the batched first pass).  Returns R float64 like the reference.  Raises DegenerateComponent where the reference
+    stack raises QhullError (a flat kept component), unless degenerate="solid"."""
     binary = np.asarray(binary).astype(np.int32)
     R = np.zeros(binary.shape)
     labels, n, stats = labelled if labelled is not None else label_boxes([binary], connectivity=1)[0]
@@ -168,7 +183,7 @@ def segment_nuclei(binary, wmin=8, it=1, max_iters=5, min_convexity=0.8, tie="he
         z0, y0, x0, z1, y1, x1 = (int(v) for v in stats[cl - 1, 1:7])
         sl = (slice(z0, z1), slice(y0, y1), slice(x0, x1))
         box = np.where(labels[sl] == cl, cl, 0).astype(np.int32)         # binary_bbox: values {0, cl}
-        convexity = int(stats[cl - 1, 0]) / convex_hull_volume(box)
+        convexity = int(stats[cl - 1, 0]) / convex_hull_volume(box, degenerate=degenerate)
         crops[cl] = (sl, box, convexity)
         if convexity < min_convexity:
             todo.append(cl)
@@ -188,7 +203,8 @@ def segment_nuclei(binary, wmin=8, it=1, max_iters=5, min_convexity=0.8, tie="he
         if int(np.count_nonzero(wss) / wmin) > nclasses and it < max_iters:
             if trace is not None:
                 trace.append((it, cl, int(stats[cl - 1, 0]), float(convexity), "recurse"))
-            Rp = segment_nuclei(wss, it=it + 1, max_iters=max_iters, min_convexity=min_convexity, tie=tie, trace=trace)
+            Rp = segment_nuclei(wss, it=it + 1, max_iters=max_iters, min_convexity=min_convexity, tie=tie, trace=trace,
+                                degenerate=degenerate)
             max_class = np.max(R)
             Rp = Rp + max_class
             Rp[Rp == max_class] = 0
@@ -206,46 +222,58 @@ def centroids(seg_img, R, num_species=95):
     return _atoms_from_rows(region_stats(R.astype(np.int32), seg_img, num_species), R.size)
 
 
-def watershed_clustering(M, S, Sb, max_iters=5, return_ws=False, verbose=False, tie="heap"):
+def watershed_clustering(M, S, Sb, max_iters=5, return_ws=False, verbose=False, tie="heap", degenerate="raise"):
     """The reference's entry point (watershed.py:190-203) for ONE sample: (atoms, means[, R]).  `M` (the density) is
-    accepted for signature parity; the reference passes it through segment_nuclei without using it."""
+    accepted for signature parity; the reference passes it through segment_nuclei without using it.  A flat kept
+    component raises (DegenerateComponent) as the reference stack does; callers catch it like generate.py:246."""
     S = np.asarray(S).squeeze()
     Sb = np.asarray(Sb).squeeze()
-    R = segment_nuclei((Sb != 0).astype(np.int32), max_iters=max_iters, tie=tie)
+    R = segment_nuclei((Sb != 0).astype(np.int32), max_iters=max_iters, tie=tie, degenerate=degenerate)
     atoms, means = centroids(S, R)
     if return_ws:
         return np.array(atoms), np.array(means), R
     return np.array(atoms), np.array(means)
 
 
-def refine_atoms(out, max_iters=5, num_species=95, tie="heap", min_convexity=0.8):
+def refine_atoms(out, max_iters=5, num_species=95, tie="heap", min_convexity=0.8, degenerate="raise"):
     """Continue a batch result of `segment_atoms` / `decode_to_atoms` (every kept component taken as convex) through
     the convexity test and the recursive split.  A sample whose kept components all pass keeps its device result (the
     convex branch numbers the regions 1..n in label order, which is what the first pass returned); any other sample is
     segmented again from its mask by `segment_nuclei` -- from scratch, because the reference's `markers[unknown == 1]`
     quirk depends on the ORIGINAL component numbers, small dropped components included -- and gets fresh region
-    statistics.  Needs out["regions"] and out["species"].  Adds out["split"] (B,) bool; updates out["atoms"],
-    out["regions"]."""
+    statistics.  Needs out["regions"], out["mask"] and out["species"] (both producers return them; the mask cannot be
+    rebuilt from the regions, which have lost the <= 3-voxel components).  A sample with a flat kept component fails as
+    in the reference stack (out["failed"][b] = True, no atoms) unless degenerate="solid".
+    Adds out["split"] (B,) bool; updates out["atoms"], out["regions"], out["failed"]."""
+    for key in ("regions", "mask", "species"):
+        if out.get(key) is None:
+            raise ValueError("refine_atoms needs out[%r] (segment_atoms / decode_to_atoms with want_regions=True)" % key)
     B = len(out["atoms"])
     split = np.zeros(B, bool)
+    if out.get("failed") is None:
+        out["failed"] = np.zeros(B, bool)
     for b in range(B):
-        if out.get("failed") is not None and out["failed"][b]:
+        if out["failed"][b]:
             continue
         n = int(out["n_atoms"][b])
         st = out["stats"][b, :n]
         lab0 = out["regions"][b]
-        convex = True
-        for a in range(n):
-            z0, y0, x0, z1, y1, x1 = (int(v) for v in st[a, 5:11])
-            box = lab0[z0:z1, y0:y1, x0:x1] == a + 1
-            if int(st[a, 1]) / convex_hull_volume(box) < min_convexity:
-                convex = False
-                break
-        if convex:
+        try:
+            convex = True
+            for a in range(n):
+                z0, y0, x0, z1, y1, x1 = (int(v) for v in st[a, 5:11])
+                box = lab0[z0:z1, y0:y1, x0:x1] == a + 1
+                if int(st[a, 1]) / convex_hull_volume(box, degenerate=degenerate) < min_convexity:
+                    convex = False          # (the reference tests every component: a later flat one still fails the sample)
+            if convex:
+                continue
+            split[b] = True
+            R = segment_nuclei((out["mask"][b] != 0).astype(np.int32), max_iters=max_iters, min_convexity=min_convexity,
+                               tie=tie, degenerate=degenerate)
+        except DegenerateComponent:
+            out["failed"][b] = True          # generate.py:246-248: "Failed", continue
+            out["atoms"][b] = ([], [])
             continue
-        split[b] = True
-        R = segment_nuclei((out["mask"][b] != 0).astype(np.int32) if out.get("mask") is not None else (lab0 != 0).astype(np.int32),
-                           max_iters=max_iters, min_convexity=min_convexity, tie=tie)
         out["atoms"][b] = centroids(out["species"][b], R, num_species)
         out["regions"][b] = R.astype(np.int32)
     out["split"] = split

@@ -78,6 +78,9 @@ int ics_unet_metric_sums(ics_net* net, double sums[7]);
 /* Benchmark path: batch resident in HBM, steps enqueued back-to-back on the engine's stream. */
 int ics_unet_upload_batch(ics_net* net, const float* x, const uint8_t* labels, int batch);
 int ics_unet_train_step_resident(ics_net* net, float metrics_or_null[5]);
+/* model.predict on the resident batch (unet/unet.py:383-385; BASELINE configs[0]), enqueued only: eval-mode forward, the
+ * outputs stay in HBM -- probabilities, or with labels_only the uint8 argmax / (sig >= thresh) volumes (generate.py:221-225). */
+int ics_unet_predict_resident(ics_net* net, int labels_only, float thresh);
 
 /* ---------------------------------------------------------------- LatticeDFCVAE
  * LatticeDFCVAE.__init__/_set_model/build_encoder/build_decoder (vae/lattice_vae.py:89-230);
@@ -206,6 +209,10 @@ int ics_net_set_optimizer_state(ics_net* net, const float* m, const float* v, si
 
 /* Per-kernel timing with HIP events on the engine's stream (bench.py roofline): enable, run steps,
  * then read back rows {label, launches, total_ms, total_flop, total_bytes}. */
+/* Device-clock bracket on the engine's stream: start records an event; stop records another, waits for it and returns the
+ * milliseconds between them (bench.py's gpu_active_s, the self-check of ms_per_step). */
+int ics_net_timer_start(ics_net* net);
+int ics_net_timer_stop(ics_net* net, double* ms);
 int ics_net_profile_enable(ics_net* net, int on);
 /* Restrict the events to the launch sites whose label starts with `prefix` -- or with one of several prefixes separated by
  * ';' -- (NULL / "" = every launch): bench.py times its K steps with events on the dominant kernel's launch sites only, so

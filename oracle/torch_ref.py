@@ -249,3 +249,67 @@ def time_unet_train_step(B=4, d=32, in_ch=1, steps=2, warmup=1, threads=None):
             times.append(dt)
     sec = float(np.mean(times))
     return B / sec, threads, sec
+
+
+def time_vae_train_step(B=4, d=32, in_ch=1, steps=1, warmup=0, threads=None):
+    """fp32 torch-CPU DFC-VAE train step (encoder + decoder + frozen perceptual U-Net c1..c10 on x and on the
+    reconstruction, batch-statistics BN, backward, Adam) on synthetic data; returns (grids_per_s, threads, secs/step)."""
+    import time
+    from . import numpy_ref as R
+    if threads:
+        torch.set_num_threads(threads)
+    threads = torch.get_num_threads()
+    ush, vsh = R.unet_param_shapes(in_ch, 95), R.vae_param_shapes(in_ch, d=d)
+    pu = Params(R.init_params(ush, 1, np.float32), R.init_bn_state(ush, np.float32), torch.float32, requires_grad=False)
+    pv = Params(R.init_params(vsh, 3, np.float32), R.init_bn_state(vsh, np.float32), torch.float32)
+    for p in (pu, pv):
+        for k, t in list(p.t.items()):
+            if t.ndim == 5:
+                p.t[k] = t.detach().contiguous(memory_format=torch.channels_last_3d).requires_grad_(p is pv)
+    opt = torch.optim.Adam(list(pv.t.values()), lr=5e-4, eps=1e-7)
+    X, _, cond = R.synthetic_batch(B, d, in_ch, seed=0)
+    xt = to_t(X, torch.float32).contiguous(memory_format=torch.channels_last_3d)
+    ct = torch.as_tensor(cond, dtype=torch.float32)
+    et = torch.as_tensor(np.random.default_rng(2).standard_normal((B, 256)), dtype=torch.float32)
+    _POOL_TIES["mode"] = "first"
+    times = []
+    for it in range(warmup + steps):
+        t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        zm, zlv, z, recon = vae_forward(xt, ct, et, pv, True, in_ch, 10, d)
+        loss, _, _, _ = vae_losses(xt, recon, zm, zlv, pu, True, 0.5, 3e-4, "first")
+        loss.backward()
+        opt.step()
+        dt = time.perf_counter() - t0
+        if it >= warmup:
+            times.append(dt)
+    _POOL_TIES["mode"] = "tf_cpu"
+    sec = float(np.mean(times))
+    return B / sec, threads, sec
+
+
+def time_unet_predict(B=16, d=32, in_ch=1, steps=1, warmup=0, threads=None):
+    """fp32 torch-CPU U-Net forward (eval-mode BN, both heads) on B synthetic grids -- BASELINE configs[0]'s CPU-runnable
+    case; returns (grids_per_s, threads, secs/call)."""
+    import time
+    from . import numpy_ref as R
+    if threads:
+        torch.set_num_threads(threads)
+    threads = torch.get_num_threads()
+    shapes = R.unet_param_shapes(in_ch, 95)
+    p = Params(R.init_params(shapes, 1, np.float32), R.init_bn_state(shapes, np.float32), torch.float32, requires_grad=False)
+    for k, t in list(p.t.items()):
+        if t.ndim == 5:
+            p.t[k] = t.detach().contiguous(memory_format=torch.channels_last_3d)
+    X, _, _ = R.synthetic_batch(B, d, in_ch, seed=0)
+    xt = to_t(X, torch.float32).contiguous(memory_format=torch.channels_last_3d)
+    times = []
+    with torch.no_grad():
+        for it in range(warmup + steps):
+            t0 = time.perf_counter()
+            unet_forward(xt, p, False, "first")
+            dt = time.perf_counter() - t0
+            if it >= warmup:
+                times.append(dt)
+    sec = float(np.mean(times))
+    return B / sec, threads, sec

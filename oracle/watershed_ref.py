@@ -113,10 +113,12 @@ def dilate_ball1(a):
     return ndimage.grey_dilation(np.asarray(a), footprint=CROSS)
 
 
-def convex_hull_image(img, tolerance=1e-10):
+def convex_hull_image(img, tolerance=1e-10, degenerate="raise"):
     """skimage.morphology.convex_hull_image(img) for a 3-D volume (offset_coordinates=True, tolerance=1e-10).
-    Degenerate inputs (all voxels coplanar / collinear) skip the pre-reduction to hull vertices, which Qhull refuses;
-    the offset points are always full-dimensional."""
+    scikit-image 0.17.2 reduces the coordinates to their hull vertices with an unguarded ConvexHull(coords): coplanar /
+    collinear inputs raise QhullError there, the error leaves watershed_clustering and generate.py:246-248 skips the
+    sample.  degenerate="raise" (default) reproduces that (the QhullError propagates); "solid" skips the pre-reduction
+    instead (the offset points are always full-dimensional) -- lenient, not the reference."""
     from scipy.spatial import ConvexHull, QhullError
     img = np.asarray(img)
     if np.count_nonzero(img) == 0:
@@ -126,7 +128,8 @@ def convex_hull_image(img, tolerance=1e-10):
         h0 = ConvexHull(coords)
         coords = h0.points[h0.vertices]
     except (QhullError, ValueError):
-        pass
+        if degenerate != "solid":
+            raise
     offsets = np.zeros((6, 3))
     for k, (axis, off) in enumerate((a, o) for a in range(3) for o in (-0.5, 0.5)):
         offsets[k, axis] = off
@@ -264,7 +267,7 @@ def split_component(binary_bbox, cl, tie="heap"):
     return wss
 
 
-def segment_nuclei(binary, wmin=8, it=1, max_iters=5, min_convexity=0.8, tie="heap", trace=None):
+def segment_nuclei(binary, wmin=8, it=1, max_iters=5, min_convexity=0.8, tie="heap", trace=None, degenerate="raise"):
     """watershed.py:40-150 (species / intensity only ride along in the reference and never influence R).
     Returns R float64 like the reference.  trace (list) collects (it, cl, count, convexity, branch) tuples."""
     R = np.zeros(binary.shape)
@@ -278,7 +281,7 @@ def segment_nuclei(binary, wmin=8, it=1, max_iters=5, min_convexity=0.8, tie="he
         bb = bbox_of(binary_cl != 0)
         sl = (slice(bb[0], bb[3]), slice(bb[1], bb[4]), slice(bb[2], bb[5]))
         binary_bbox = binary_cl[sl]
-        chull = convex_hull_image(binary_bbox)
+        chull = convex_hull_image(binary_bbox, degenerate=degenerate)
         convexity = np.count_nonzero(binary_bbox) / np.count_nonzero(chull)
         if convexity >= min_convexity:
             max_class = np.max(R)
@@ -294,7 +297,8 @@ def segment_nuclei(binary, wmin=8, it=1, max_iters=5, min_convexity=0.8, tie="he
         if int(np.count_nonzero(wss) / wmin) > nclasses and it < max_iters:
             if trace is not None:
                 trace.append((it, int(cl), int(np.count_nonzero(binary_bbox)), float(convexity), "recurse"))
-            Rp = segment_nuclei(wss, it=it + 1, max_iters=max_iters, min_convexity=min_convexity, tie=tie, trace=trace)
+            Rp = segment_nuclei(wss, it=it + 1, max_iters=max_iters, min_convexity=min_convexity, tie=tie, trace=trace,
+                                degenerate=degenerate)
             max_class = np.max(R)
             Rp = Rp + max_class
             Rp[Rp == max_class] = 0
@@ -306,10 +310,11 @@ def segment_nuclei(binary, wmin=8, it=1, max_iters=5, min_convexity=0.8, tie="he
     return R
 
 
-def watershed_clustering(M, S, Sb, max_iters=5, tie="heap", trace=None):
-    """watershed.py:190-203: (atoms, means, R)."""
+def watershed_clustering(M, S, Sb, max_iters=5, tie="heap", trace=None, degenerate="raise"):
+    """watershed.py:190-203: (atoms, means, R).  A flat kept component raises scipy's QhullError, as in the reference
+    stack (convex_hull_image above), unless degenerate="solid"."""
     S = np.asarray(S).squeeze()
     Sb = np.asarray(Sb).squeeze()
-    R = segment_nuclei(Sb, max_iters=max_iters, tie=tie, trace=trace)
+    R = segment_nuclei(Sb, max_iters=max_iters, tie=tie, trace=trace, degenerate=degenerate)
     atoms, means = centroids(S.astype(np.int64), R)
     return atoms, means, R

@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 
 from oracle import numpy_ref as R
+from saturated import saturate_head
 
 pytestmark = pytest.mark.gpu
 
@@ -115,9 +116,12 @@ def test_config0_predict_on_exactly_16_grids():
     from icsg3d_amd.synthetic import synthetic_batch
     B, d = 16, 32
     uo = R.UnetOracle(in_ch=1, seed=1)
+    X, lab, _ = synthetic_batch(B, d, 1, seed=0, noise=1e-3)
+    # a confident head fitted on the two oracle-checked grids (tests/saturated.py): argmax, f1 / wr and the 0.8 mask are then
+    # compared at non-trivial values instead of 0 == 0
+    saturate_head(uo, X[[0, 15]].astype(np.float64), lab[[0, 15]], training=False)
     eng = UnetEngine(in_channels=1, d=d, max_batch=B)
     eng.set_weights(uo.P)
-    X, lab, _ = synthetic_batch(B, d, 1, seed=0, noise=1e-3)
     soft, sig = eng.predict(X)
     assert soft.shape == (16, d, d, d, 95) and sig.shape == (16, d, d, d, 1)
     np.testing.assert_allclose(soft.sum(-1), 1.0, atol=2e-6)
@@ -129,6 +133,13 @@ def test_config0_predict_on_exactly_16_grids():
         top2 = np.sort(sr, -1)[..., -2:]
         sure = (top2[..., 1] - top2[..., 0]) > 1e-4
         assert np.array_equal(soft[i:i + 1].argmax(-1)[sure], sr.argmax(-1)[sure])
+        assert (gr >= 0.8).any() and len(np.unique(sr.argmax(-1))) >= 3            # the decisions are not constant
+        sure_s = np.abs(gr[..., 0] - 0.8) > 1e-4
+        assert np.array_equal((sig[i:i + 1, ..., 0] >= 0.8)[sure_s], (gr[..., 0] >= 0.8)[sure_s])
+        m = eng.test_step(X[i:i + 1], lab[i:i + 1])
+        m_ref = uo.test_on_batch(X[i:i + 1].astype(np.float64), lab[i:i + 1])
+        assert m_ref[3] > 0.05 and m_ref[4] > 0.05
+        np.testing.assert_allclose(m, m_ref, rtol=1e-4)
     sp, mk = eng.predict_labels(X, 0.8)
     assert np.array_equal(sp, soft.argmax(-1)) and np.array_equal(mk, sig[..., 0] >= 0.8)
 

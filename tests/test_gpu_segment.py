@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
 
 GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "watershed_golden.npz"))
 CASES = sorted({k.split("/")[0] for k in GOLD.files})
+FLAT_CASES = {"handmade", "noise"}      # hold a kept component (> 3 voxels) whose voxels are coplanar / collinear
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -28,11 +29,32 @@ def test_segment_atoms_matches_reference_outputs(case):
     atoms, means = r["atoms"][0]
     assert atoms == list(GOLD[case + "/atoms"])
     assert np.array_equal(np.array(means, np.float64).reshape(len(atoms), 3), GOLD[case + "/means"])
-    # the reference-shaped entry point (watershed.py:190): the full path, convexity test and splits included
-    a2, m2, R2 = watershed_clustering(np.zeros_like(mask, dtype=np.float32), species, mask, return_ws=True)
-    a3, m3, R3 = W.watershed_clustering(None, species, mask)
+    # the reference-shaped entry point (watershed.py:190): the full path, convexity test and splits included.
+    # A kept component that is flat (coplanar / collinear voxels: the 4-voxel line of 'hand', many in 'noise') makes
+    # scikit-image 0.17.2's convex_hull_image raise, and the reference skips the sample (generate.py:246-248): so do we
+    from scipy.spatial import QhullError
+    from icsg3d_amd.watershed import DegenerateComponent
+    trace = []
+    try:
+        W.watershed_clustering(None, species, mask, trace=trace)
+        flat = False
+    except QhullError:
+        flat = True
+    if flat:
+        with pytest.raises(DegenerateComponent):
+            watershed_clustering(np.zeros_like(mask, dtype=np.float32), species, mask, return_ws=True)
+    assert flat == (case in FLAT_CASES), case
+    mode = "solid" if flat else "raise"
+    trace = []
+    a2, m2, R2 = watershed_clustering(np.zeros_like(mask, dtype=np.float32), species, mask, return_ws=True, degenerate=mode)
+    a3, m3, R3 = W.watershed_clustering(None, species, mask, trace=trace, degenerate=mode)
     assert np.array_equal(R2, R3) and list(a2) == list(a3)
     assert np.array_equal(np.array(m2).reshape(len(a2), 3), np.array(m3).reshape(len(a3), 3))
+    # where every kept component took the convex branch the result must STILL be the reference-run golden one
+    # (R of the fixture = all components convex; atoms / means = the reference's own centroids on it)
+    if all(t[4] == "convex" for t in trace):
+        assert np.array_equal(R2, GOLD[case + "/R"]) and list(a2) == list(GOLD[case + "/atoms"])
+        assert np.array_equal(np.array(m2, np.float64).reshape(len(a2), 3), GOLD[case + "/means"])
 
 
 @pytest.mark.parametrize("B,d,p", [(3, 32, 0.30), (2, 64, 0.26), (5, 16, 0.45), (1, 64, 0.7)])
@@ -181,20 +203,37 @@ def test_segment_nuclei_and_clustering_match_oracle_with_splits_and_recursion():
     m2[0, 0, 0:2] = 1
     assert np.array_equal(segment_nuclei(m2), W.segment_nuclei(m2))
     # random volume at 64^3: many components, some non-convex
+    # (it holds flat kept components: the reference stack fails such a sample -- both sides raise; "solid" compares the rest)
+    from scipy.spatial import QhullError
+    from icsg3d_amd.watershed import DegenerateComponent
     m3 = (np.random.default_rng(5).uniform(size=(64, 64, 64)) < 0.2).astype(np.int32)
-    assert np.array_equal(segment_nuclei(m3), W.segment_nuclei(m3))
+    with pytest.raises(DegenerateComponent):
+        segment_nuclei(m3)
+    with pytest.raises(QhullError):
+        W.segment_nuclei(m3)
+    assert np.array_equal(segment_nuclei(m3, degenerate="solid"), W.segment_nuclei(m3, degenerate="solid"))
 
 
 def test_refine_atoms_continues_the_batch_result():
     from icsg3d_amd.watershed import refine_atoms, segment_atoms
     d = 32
-    masks = np.stack([_balls(d, TOUCHING), _balls(d, [((10, 10, 10), 3), ((22, 20, 12), 3)])]).astype(np.uint8)
+    plate = _balls(d, [((10, 10, 10), 3)])
+    plate[25, 20:22, 20:22] = 1                          # a 2 x 2 plate: 4 coplanar voxels, kept by the size filter
+    masks = np.stack([_balls(d, TOUCHING), _balls(d, [((10, 10, 10), 3), ((22, 20, 12), 3)]), plate]).astype(np.uint8)
     rng = np.random.default_rng(3)
     species = np.where(masks != 0, rng.integers(1, 95, size=masks.shape), 0).astype(np.uint8)
-    out = segment_atoms(masks, species, max_atoms=64)
-    out["mask"], out["species"] = masks, species
+    out = segment_atoms(masks, species, max_atoms=64)    # carries mask and species for refine_atoms
     refine_atoms(out)
-    assert list(out["split"]) == [True, False]
+    assert list(out["split"]) == [True, False, False]
+    # the flat component fails the SAMPLE as in the reference stack (generate.py:246-248), not the batch
+    assert list(out["failed"]) == [False, False, True] and out["atoms"][2] == ([], [])
+    from scipy.spatial import QhullError
+    with pytest.raises(QhullError):
+        W.watershed_clustering(None, species[2], masks[2])
+    lenient = refine_atoms(segment_atoms(masks, species, max_atoms=64), degenerate="solid")
+    assert not lenient["failed"].any() and len(lenient["atoms"][2][0]) == 2
+    with pytest.raises(ValueError, match="needs out"):
+        refine_atoms({k: v for k, v in segment_atoms(masks, species, max_atoms=64).items() if k != "mask"})
     for b in range(2):
         a_ref, mu_ref, R_ref = W.watershed_clustering(None, species[b], masks[b])
         a, mu = out["atoms"][b]

@@ -41,10 +41,32 @@ for name, shape in (("c18/kernel", (3, 3, 3, 128, 128)), ("c18/bias", (128,)), (
                     ("c3/gamma", (64,)), ("c3/bias", (64,)), ("c1/kernel", (3, 3, 3, 1, 32))):
     a = u.get_grad(name, shape).ravel()
     deep[name.replace("/", "_")] = a[::max(1, a.size // 512)].tolist()
-print(json.dumps({"soft": soft[:, ::5, ::5, ::5].ravel().tolist(), "sig": sig[:, ::5, ::5, ::5].ravel().tolist(),
+# ... and EVERY U-Net gradient tensor of this configuration against the fp64 oracle with this run's own ReLU / pool
+# decisions pinned (as tests/test_gpu_unet.py does for the default configuration): a fallback path with a real bug in
+# c1..c17 cannot hide inside the loose engine-vs-engine bound the BatchNorm amplification forces on the deep gradients
+from oracle import numpy_ref as R
+orc = R.UnetOracle(in_ch=1, seed=1, lr=1e-4)
+orc.P = {k: np.asarray(PU[k], np.float64) for k in orc.P}
+LAYERS = ["c1", "c2", "c3", "c4", "c5", "c6", "c9", "c10", "c13", "c14", "c15", "c16", "c17", "c18"]
+RES = {"c1": 1, "c2": 1, "c3": 2, "c4": 2, "c5": 4, "c6": 4, "c9": 8, "c10": 8, "c13": 4, "c14": 4, "c15": 2, "c16": 2, "c17": 1, "c18": 1}
+COUT = dict((n, c) for n, _, c in R.UNET_CONVS)
+shp = lambda n: (B, d // RES[n], d // RES[n], d // RES[n], COUT[n])
+kink = {n: u.get_activation(n, shp(n)) for n in LAYERS}
+affine = {n: u.get_bn_affine(n, COUT[n]) for n in ("c2", "c4", "c6")}
+orc.train_on_batch(X.astype(np.float64), lab, kink=kink, affine=affine)
+oracle_err = {}
+for name, shape, trainable in u.tensor_infos():
+    if trainable:
+        ref = orc.last_grads[name]
+        oracle_err[name] = float(np.abs(u.get_grad(name, shape) - ref).max() / np.abs(ref).max())
+print(json.dumps({"oracle_err": oracle_err, "oracle_flips": int(sum(orc.kink_flips.values())),
+                  "soft": soft[:, ::5, ::5, ::5].ravel().tolist(), "sig": sig[:, ::5, ::5, ::5].ravel().tolist(),
                   "mu": np.asarray(mu).tolist(), "mv": np.asarray(mv).tolist(), "zm": zm.ravel()[::7].tolist(),
                   "rec": rec[:, ::5, ::5, ::5].ravel().tolist(), "g": g.ravel()[::37].tolist(), **deep}))
 """ % ROOT
+
+
+ORACLE_GRAD_TOL = 1e-4     # every gradient tensor of every configuration vs the fp64 oracle (one-step tests: 6e-5 measured 4e-5)
 
 
 def _run(env_extra):
@@ -52,7 +74,13 @@ def _run(env_extra):
     env.update(env_extra)
     out = subprocess.run([sys.executable, "-c", SCRIPT], capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
-    return {k: np.asarray(v) for k, v in json.loads(out.stdout.strip().splitlines()[-1]).items()}
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    err, flips = res.pop("oracle_err"), res.pop("oracle_flips")
+    worst = max(err, key=err.get)
+    print("%s: worst gradient error vs the fp64 oracle %.2e (%s), %d decisions pinned" % (env_extra or "default", err[worst], worst, flips))
+    assert err[worst] <= ORACLE_GRAD_TOL, (env_extra, worst, err[worst])
+    assert flips <= 64, flips
+    return {k: np.asarray(v) for k, v in res.items()}
 
 
 @pytest.fixture(scope="module")
@@ -74,10 +102,12 @@ def default_run():
 def test_fallback_path_matches_default(default_run, switch):
     name, _, val = switch.partition("=")
     alt = _run({name: val or "1"})
-    # The sampled gradients of the deeper layers: a switch that changes a FORWARD summation order moves them by up to
-    # 7e-3 of their largest entry at this size (B = 2, d = 16: the BatchNorm layers at 2^3 .. 4^3 voxels see 16 .. 128
-    # values per channel and amplify 1e-7 forward differences; scripts/switch_deltas.py prints the table), the switches
-    # that only re-associate the backward pass stay below 3e-6.
+    # The sampled gradients of the deeper layers, engine vs engine: a switch that changes a FORWARD summation order moves
+    # them by up to 7e-3 of their largest entry at this size (B = 2, d = 16: the BatchNorm layers at 2^3 .. 4^3 voxels see
+    # 16 .. 128 values per channel and amplify 1e-7 forward differences into different ReLU / pool decisions;
+    # scripts/switch_deltas.py prints the table), the switches that only re-associate the backward pass stay below 3e-6.
+    # That bound is loose by necessity -- the tight check of the deep gradients is _run's: every gradient tensor of THIS
+    # configuration against the fp64 oracle with its own decisions pinned, <= 1e-4.
     backward_only = name in ("ICSG3D_DGRAD_BNFUSE_MIN", "ICSG3D_NO_DGRAD_BNFUSE", "ICSG3D_NO_BWD_FOLD",
                              "ICSG3D_NO_HEAD_BNFUSE", "ICSG3D_NO_TICKET", "ICSG3D_NO_FAST_BNBWD", "ICSG3D_NO_POOL_PRESUM")
     for k, ref in default_run.items():

@@ -8,7 +8,7 @@ from oracle import numpy_ref as R
 pytestmark = pytest.mark.gpu
 
 FWD_TOL = 1e-5       # north_star: outputs within 1e-5 tensor-relative of the CPU reference
-GRAD_TOL = 1e-4      # fp32 rounding through 16 conv+BN layers, tensor-relative (measured <= 4e-5)
+GRAD_TOL = 6e-5      # fp32 rounding through 16 conv+BN layers, tensor-relative (measured <= 4e-5: 2x regressions show red)
 STEP_TOL = 1e-5
 
 
@@ -42,6 +42,7 @@ def test_unet_predict_matches_oracle(B, d, C, relerr):
     assert np.array_equal(sp[clear], soft_ref.argmax(-1)[clear])
     clear_s = np.abs(sig_ref[..., 0] - 0.8) > 1e-4
     assert np.array_equal(mk[clear_s], (sig_ref[..., 0] >= 0.8)[clear_s])
+    # (Glorot heads: the mask is empty and f1 = wr = 0 here; tests/test_gpu_metrics.py repeats this with a confident head)
     m_ref = orc.test_on_batch(X, lab)
     m = eng.test_step(X, lab)
     np.testing.assert_allclose(m, m_ref, rtol=1e-4, atol=1e-6)

@@ -100,9 +100,22 @@ def test_convex_hull_image_solid_shapes():
     two[5, 5, 4:12] = 1
     hull2 = W.convex_hull_image(two)
     assert hull2[two != 0].all() and np.count_nonzero(two) / np.count_nonzero(hull2) < 0.8
+    # coplanar / collinear voxels: scikit-image 0.17.2's unguarded ConvexHull(coords) raises QhullError (the reference's
+    # generate.py then skips the sample); "solid" is the lenient alternative
+    from scipy.spatial import QhullError
     flat = np.zeros((3, 6, 6), np.int32)
-    flat[1, 1:5, 1:5] = 1                                                   # coplanar voxels: Qhull's pre-reduction is skipped
-    assert W.convex_hull_image(flat)[1, 1:5, 1:5].all()
+    flat[1, 1:5, 1:5] = 1
+    line = np.zeros((3, 3, 6), np.int32)
+    line[1, 1, 1:5] = 1
+    for v in (flat, line):
+        with pytest.raises(QhullError):
+            W.convex_hull_image(v)
+    assert W.convex_hull_image(flat, degenerate="solid")[1, 1:5, 1:5].all()
+    from icsg3d_amd.watershed import DegenerateComponent, convex_hull_volume
+    for v in (flat, line):
+        with pytest.raises(DegenerateComponent):
+            convex_hull_volume(v)
+        assert convex_hull_volume(v, degenerate="solid") == np.count_nonzero(W.convex_hull_image(v, degenerate="solid"))
 
 
 def test_watershed_flood_hand_example_and_tie_rules():

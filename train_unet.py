@@ -18,6 +18,7 @@ launcher spell --d as --dim: torch.distributed.run's own parser rejects `--d` as
 import argparse
 import json
 import os
+import sys
 
 import numpy as np
 
@@ -41,8 +42,14 @@ if __name__ == "__main__":
     p.add_argument("--channels", type=int, default=4, help="input channels (density + 3 coordinate grids)")
     p.add_argument("--synthetic", type=int, default=0, help="train on N synthetic grids instead of data/<name>")
     p.add_argument("--sync_bn", type=int, default=0, help="data parallel: BatchNorm statistics over all ranks")
+    p.add_argument("--gpus", type=int, default=0,
+                   help="data parallel over N GPUs of this node: without torch.distributed.run the script starts its N "
+                        "ranks itself (icsg3d_amd/launcher.py); 0 = whatever the environment says (default)")
     a = p.parse_args()
 
+    if a.gpus:                                   # before anything touches the GPU; exits with the ranks' status
+        from icsg3d_amd.launcher import ensure_ranks
+        ensure_ranks(a.gpus, os.path.abspath(__file__), sys.argv[1:])
     dp = from_env()                              # (dist, rank, world, local_rank) under torch.distributed.run
     rank, world = (dp[1], dp[2]) if dp else (0, 1)
     mode, d = a.name, a.d

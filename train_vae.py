@@ -11,6 +11,7 @@ trains on its share of the ids at the PER-GPU --batch_size (train_unet.py explai
 import argparse
 import json
 import os
+import sys
 
 from icsg3d_amd.dataparallel import from_env, shard_ids
 from icsg3d_amd.utils import data_split
@@ -31,8 +32,14 @@ if __name__ == "__main__":
     p.add_argument("--channels", type=int, default=4)
     p.add_argument("--synthetic", type=int, default=0)
     p.add_argument("--sync_bn", type=int, default=0)
+    p.add_argument("--gpus", type=int, default=0,
+                   help="data parallel over N GPUs of this node: without torch.distributed.run the script starts its N "
+                        "ranks itself (icsg3d_amd/launcher.py); 0 = whatever the environment says (default)")
     a = p.parse_args()
 
+    if a.gpus:                                   # before anything touches the GPU; exits with the ranks' status
+        from icsg3d_amd.launcher import ensure_ranks
+        ensure_ranks(a.gpus, os.path.abspath(__file__), sys.argv[1:])
     dp = from_env()
     rank, world = (dp[1], dp[2]) if dp else (0, 1)
     mode, d, bs = a.name, a.d, a.batch_size
