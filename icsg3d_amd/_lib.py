@@ -25,7 +25,7 @@ class IcsError(RuntimeError):
 class UnetConfig(C.Structure):
     _fields_ = [("in_channels", C.c_int), ("num_classes", C.c_int), ("d", C.c_int),
                 ("max_batch", C.c_int), ("lr", C.c_float), ("loss_weight", C.c_float),
-                ("pool_ties_all", C.c_int), ("bn_unbias", C.c_int)]
+                ("pool_ties_all", C.c_int), ("bn_unbias", C.c_int), ("bce_from_logits", C.c_int)]
 
 
 class VaeConfig(C.Structure):

@@ -125,6 +125,7 @@ enum ConvFlags : int {
   CF_NO_UP3N = 1 << 21,        // ICSG3D_NO_UP3N: the VAE decoder's narrow upsampled layers through the 8-tap parity GEMMs
   CF_NO_DGRAD_BNFUSE = 1 << 22,  // ICSG3D_NO_DGRAD_BNFUSE: c17 / c15 BatchNorm backward as its own pass behind c18 / c16 backward-data
   CF_NO_POOL_PRESUM = 1 << 23,   // ICSG3D_NO_POOL_PRESUM: pool-only layers (perceptual taps) keep the BatchNorm-backward reduce pass
+  CF_NO_HEAD_LABELS = 1 << 24,   // ICSG3D_NO_HEAD_LABELS: inference labels from the stored probabilities (labels_kernel), not from the fused head's registers
   CF_ZBATCH = 1 << 20,         // internal: conv_fwd_kernel runs gridDim.z independent GEMMs (launch_gemm_zbatch)
   CF_NO_TICKET = 131072,       // ICSG3D_NO_TICKET: one bias-gradient finalize launch per layer instead of one batched launch per
                                // step / gradient bucket (round 4)

@@ -75,6 +75,7 @@ int conv_flags_from_env() {
   if (getenv("ICSG3D_NO_UP3N")) f |= CF_NO_UP3N;
   if (getenv("ICSG3D_NO_DGRAD_BNFUSE")) f |= CF_NO_DGRAD_BNFUSE;
   if (getenv("ICSG3D_NO_POOL_PRESUM")) f |= CF_NO_POOL_PRESUM;
+  if (getenv("ICSG3D_NO_HEAD_LABELS")) f |= CF_NO_HEAD_LABELS;
   { const char* e = getenv("ICSG3D_UP3_BIG_MIN_WG"); if (e && *e && strtoul(e, nullptr, 10) <= 1) f |= CF_UP3_BIG_ALWAYS; }
   return f;
 }

@@ -122,7 +122,9 @@ int launch_colsum_finalize(hipStream_t st, const float* partial, int nblk, int C
 int launch_head_fused(hipStream_t st, const float* x, int ldx, const float* scale, const float* shift, const float* wsoft_k,
                       const float* wsig_k, const float* bsoft, const float* bsig, float* z, const unsigned char* labels,
                       size_t M, int mode, int want_grad, float wsoft, double* partial, int partial_blocks, float* metrics,
-                      int* nblk_out = nullptr, float* dz_colsum = nullptr, double* keep = nullptr);
+                      int* nblk_out = nullptr, float* dz_colsum = nullptr, double* keep = nullptr,
+                      float thresh = 0.f, unsigned char* species = nullptr, unsigned char* mask = nullptr);
+// mode 0: probabilities -> z; 1: loss / metrics (+ dz with want_grad); 2: uint8 argmax species + (sig >= thresh) mask only
 int launch_head(hipStream_t st, float* z, int ldz, int ncls, const unsigned char* labels, size_t M,
                 int mode, int want_grad, float wsoft, double* partial, int partial_blocks,
                 float* metrics, int* nblk_out = nullptr, float* dz_colsum = nullptr, double* keep = nullptr);

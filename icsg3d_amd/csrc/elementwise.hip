@@ -903,6 +903,11 @@ __global__ __launch_bounds__(256) void head_kernel(float* __restrict__ z, int ld
                                                    float wsoft, float inv_bv, double* __restrict__ partial,
                                                    float* __restrict__ dz_colsum) {
   constexpr int J = 8;
+  // want_grad bit 1: binary_crossentropy in TF 2.1's logits form (tf.keras.backend.binary_crossentropy short-circuits to
+  // sigmoid_cross_entropy_with_logits when the prediction's producer op is a Sigmoid -- SURVEY App. B, confidence M):
+  // max(z, 0) - z t + log1p(exp(-|z|)), gradient sigmoid(z) - t with no clip kink.  Default: the clipped-probability form.
+  const bool bce_z = (want_grad & 2) != 0;
+  want_grad &= 1;
   __shared__ double shd[16][6];
   __shared__ float shc[4][132];
   float cacc[J], cacc_sig = 0.f;          // column sums of dz over this lane's voxels (head bias gradients)
@@ -981,7 +986,8 @@ __global__ __launch_bounds__(256) void head_kernel(float* __restrict__ z, int ld
     const float pc = fminf(fmaxf(ps, kKEps), 1.f - kKEps);
     if (sl == 0 && rv) {
       a_ls += (double)(-wsoft * logf(qc));
-      a_lg += (double)(-(tsig * logf(pc) + (1.f - tsig) * logf(1.f - pc)));
+      a_lg += bce_z ? (double)(fmaxf(zsig, 0.f) - zsig * tsig + log1pf(expf(-fabsf(zsig))))
+                    : (double)(-(tsig * logf(pc) + (1.f - tsig) * logf(1.f - pc)));
       const bool hit = pt_raw > 0.5f;
       a_tp += hit ? 1.0 : 0.0;
       a_pred += (double)npred;
@@ -996,7 +1002,7 @@ __global__ __launch_bounds__(256) void head_kernel(float* __restrict__ z, int ld
         const float dzv = gs * (p[j] - (c == lab ? 1.f : 0.f));
         if (j < nj && c < ncls) { zr[c] = dzv; cacc[j] += dzv; }
       }
-      const float dzs = inside_s ? (ps - tsig) * inv_bv : 0.f;
+      const float dzs = (inside_s || bce_z) ? (ps - tsig) * inv_bv : 0.f;
       if (sl == 0) { zr[ncls] = dzs; cacc_sig += dzs; }
     }
   }
@@ -1055,8 +1061,12 @@ __global__ __launch_bounds__(256, 2) void head_fused_kernel(const float* __restr
                                                          const float* __restrict__ bsoft, const float* __restrict__ bsig,
                                                          float* __restrict__ z, const unsigned char* __restrict__ labels,
                                                          int ntiles, int mode, int want_grad, float wsoft, float inv_bv,
-                                                         double* __restrict__ partial, float* __restrict__ dz_colsum) {
+                                                         double* __restrict__ partial, float* __restrict__ dz_colsum,
+                                                         float thresh, unsigned char* __restrict__ species,
+                                                         unsigned char* __restrict__ mask) {
   constexpr int NC = 95, NZ = 96, CH = 128;
+  const bool bce_z = (want_grad & 2) != 0;                 // binary_crossentropy in the logits form (see head_kernel)
+  want_grad &= 1;
   __shared__ __attribute__((aligned(16))) float Wt[NZ * kHeadWP];
   __shared__ __attribute__((aligned(16))) float biasp[NZ];
   __shared__ float shc[4][NZ];
@@ -1144,6 +1154,31 @@ __global__ __launch_bounds__(256, 2) void head_fused_kernel(const float* __restr
       for (int r = 0; r < 4; ++r) { p[t][r] = p[t][r] * rsum; psl += p[t][r]; }
     const float ps = 1.f / (1.f + expf(-zsig));
     float* zr = z + row * NZ + 4 * g;
+    if (mode == 2) {
+      // generate.py:221-225 without the probabilities ever leaving the registers: np.argmax over the 95 class
+      // probabilities (first maximum = lowest class among equals) and sig >= thresh, one byte each per voxel.
+      // The same p values mode 0 stores, so the labels equal argmax / threshold of a mode-0 output bit for bit.
+      float bv = -1.f;
+      int bc = 0;
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = 16 * t + 4 * g + r;               // ascending within the lane
+          if (c < NC && p[t][r] > bv) { bv = p[t][r]; bc = c; }
+        }
+#pragma unroll
+      for (int off = 16; off <= 32; off <<= 1) {
+        const float ov = __shfl_xor(bv, off);
+        const int oc = __shfl_xor(bc, off);
+        if (ov > bv || (ov == bv && oc < bc)) { bv = ov; bc = oc; }
+      }
+      if (g == 0) {
+        species[row] = (unsigned char)bc;
+        mask[row] = ps >= thresh ? 1 : 0;
+      }
+      continue;
+    }
     if (mode == 0) {
 #pragma unroll
       for (int t = 0; t < 6; ++t) {
@@ -1174,7 +1209,8 @@ __global__ __launch_bounds__(256, 2) void head_fused_kernel(const float* __restr
     const float pc = fminf(fmaxf(ps, kKEps), 1.f - kKEps);
     if (g == 0) {
       a_ls += (double)(-wsoft * logf(qc));
-      a_lg += (double)(-(tsig * logf(pc) + (1.f - tsig) * logf(1.f - pc)));
+      a_lg += bce_z ? (double)(fmaxf(zsig, 0.f) - zsig * tsig + log1pf(expf(-fabsf(zsig))))
+                    : (double)(-(tsig * logf(pc) + (1.f - tsig) * logf(1.f - pc)));
       const bool hit = pt_raw > 0.5f;
       a_tp += hit ? 1.0 : 0.0;
       a_pred += (double)npred;
@@ -1182,7 +1218,7 @@ __global__ __launch_bounds__(256, 2) void head_fused_kernel(const float* __restr
     }
     if (want_grad) {
       const float gs = inside ? wsoft * inv_bv : 0.f;
-      const float dzs = inside_s ? (ps - tsig) * inv_bv : 0.f;
+      const float dzs = (inside_s || bce_z) ? (ps - tsig) * inv_bv : 0.f;
 #pragma unroll
       for (int t = 0; t < 6; ++t) {
         hv4 o;
@@ -1198,7 +1234,7 @@ __global__ __launch_bounds__(256, 2) void head_fused_kernel(const float* __restr
       }
     }
   }
-  if (mode == 0) return;
+  if (mode == 0 || mode == 2) return;
   if (want_grad && dz_colsum != nullptr) {
     // per-block column sums of dz (soft | sig bias gradients): 16 voxel lanes, then the 4 waves, fixed order
 #pragma unroll
@@ -1229,17 +1265,19 @@ bool head_fused_ok(int ncls, int cin, size_t M, int act, int flags) {
 int launch_head_fused(hipStream_t st, const float* x, int ldx, const float* scale, const float* shift, const float* wsoft_k,
                       const float* wsig_k, const float* bsoft, const float* bsig, float* z, const unsigned char* labels,
                       size_t M, int mode, int want_grad, float wsoft, double* partial, int partial_blocks, float* metrics,
-                      int* nblk_out, float* dz_colsum, double* keep) {
+                      int* nblk_out, float* dz_colsum, double* keep, float thresh, unsigned char* species,
+                      unsigned char* mask) {
+  ICS_CHECK(mode != 2 || (species != nullptr && mask != nullptr), "fused head, label mode: null output");
   ICS_CHECK(M % 16 == 0 && ldx % 4 == 0, "fused head: rows must come in sixteens, float4-aligned");
   const int ntiles = (int)(M / 16);
   int nblk = (ntiles + 3) / 4;
   const int cap = partial_blocks < 512 ? partial_blocks : 512;   // 2 workgroups per CU, whole rounds of tiles at B = 32
   if (nblk > cap) nblk = cap;
   ICS_LAUNCH(head_fused_kernel, dim3(nblk), dim3(256), 0, st, x, ldx, scale, shift, wsoft_k, wsig_k, bsoft, bsig, z,
-                     labels, ntiles, mode, want_grad, wsoft, (float)(1.0 / (double)M), partial, dz_colsum);
+                     labels, ntiles, mode, want_grad, wsoft, (float)(1.0 / (double)M), partial, dz_colsum, thresh, species, mask);
   ICS_HIP(hipGetLastError());
   if (nblk_out) *nblk_out = nblk;
-  if (mode != 0 && metrics != nullptr) ICS_TRY(launch_head_metrics(st, partial, nblk, (double)M, metrics, nullptr, 0, keep));
+  if (mode == 1 && metrics != nullptr) ICS_TRY(launch_head_metrics(st, partial, nblk, (double)M, metrics, nullptr, 0, keep));
   return 0;
 }
 

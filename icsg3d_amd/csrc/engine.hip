@@ -217,6 +217,7 @@ struct Net {
   int pack_njobs = -1;               // -1: not recorded yet
   unsigned pack_nblocks = 0;
   int pool_ties_all = 1, bn_unbias = 1;
+  int bce_from_logits = 0;            // binary_crossentropy: 0 clipped probabilities (default), 1 TF 2.1's logits short-circuit
   Profiler prof;
   std::vector<std::unique_ptr<ConvLayer>> layers;
   // shared workspaces
@@ -1237,7 +1238,7 @@ static int unet_build(Net& n, const ics_unet_config& cfg) {
   n.side_on = getenv("ICSG3D_SIDE_STREAM") != nullptr;
   n.kind = 0; n.maxB = cfg.max_batch; n.d = cfg.d; n.C = cfg.in_channels; n.ncls = cfg.num_classes;
   n.lr = cfg.lr; n.loss_weight = cfg.loss_weight > 0 ? cfg.loss_weight : (float)cfg.num_classes;
-  n.pool_ties_all = cfg.pool_ties_all; n.bn_unbias = cfg.bn_unbias;
+  n.pool_ties_all = cfg.pool_ties_all; n.bn_unbias = cfg.bn_unbias; n.bce_from_logits = cfg.bce_from_logits ? 1 : 0;
   const int d = cfg.d;
   struct Spec { const char* name; int cin, cout, S; bool pooled; };
   const Spec specs[14] = {
@@ -1355,7 +1356,7 @@ static int unet_head_forward(Net& n, int B) {
 static int unet_loss(Net& n, int B, int mode, int want_grad, bool want_metrics = true) {
   const size_t M = n.rows(*n.head, B);
   n.prof.begin(n.st, "head_softmax_loss", 0, 4.0 * M * (n.ncls + 1) * 2);
-  ICS_TRY(launch_head(n.st, n.head->s, n.ncls + 1, n.ncls, n.labels, M, mode, want_grad, n.loss_weight,
+  ICS_TRY(launch_head(n.st, n.head->s, n.ncls + 1, n.ncls, n.labels, M, mode, want_grad | (n.bce_from_logits << 1), n.loss_weight,
                       n.ws_dbl, 2048, n.comm ? nullptr : n.d_metrics, &n.head_nblk, want_grad ? n.ws_bwd : nullptr, n.d_red + 8));
   n.prof.end(n.st);
   if (mode != 0 && n.comm && want_metrics) {
@@ -1382,7 +1383,7 @@ static int unet_head_loss(Net& n, int B, int mode, int want_grad, bool want_metr
   n.last_batch = B;
   n.prof.begin(n.st, "head_fused", 2.0 * M * 128 * (n.ncls + 1), 4.0 * M * (128 + (mode == 1 && !want_grad ? 0 : n.ncls + 1)));
   ICS_TRY(launch_head_fused(n.st, s0.p, s0.C, s0.scale, s0.shift, n.tp(H.t_w), n.tp(H.t_gamma), n.tp(H.t_b),
-                            n.tp(H.t_b) + n.ncls, H.s, n.labels, M, mode, want_grad, n.loss_weight, n.ws_dbl, 2048,
+                            n.tp(H.t_b) + n.ncls, H.s, n.labels, M, mode, want_grad | (n.bce_from_logits << 1), n.loss_weight, n.ws_dbl, 2048,
                             n.comm ? nullptr : n.d_metrics, &n.head_nblk, want_grad ? n.ws_bwd : nullptr, n.d_red + 8));
   n.prof.end(n.st);
   if (mode != 0 && n.comm && want_metrics) {
@@ -1391,6 +1392,34 @@ static int unet_head_loss(Net& n, int B, int mode, int want_grad, bool want_metr
     ICS_CHECK(r == ncclSuccess, std::string("ncclAllReduce(metrics): ") + ncclGetErrorString(r));
     ICS_TRY(launch_head_metrics(n.st, n.ws_dbl, n.head_nblk, (double)M, n.d_metrics, n.d_red, 2, n.d_red + 8));
   }
+  return 0;
+}
+
+__global__ void labels_kernel(const float* __restrict__ p, int ld, int ncls, size_t M, float thresh,
+                              unsigned char* __restrict__ species, unsigned char* __restrict__ mask);
+// generate.py:220-225: model.predict -> argmax / (sig >= thresh).  Where the fused head serves the shape the labels come
+// straight out of its registers (the [M][96] probability tensor is neither written nor read back: 384 -> 2 bytes per voxel);
+// otherwise GEMM + softmax kernel + labels_kernel.  Both give argmax / threshold of the SAME fp32 probabilities.
+static int unet_head_labels(Net& n, int B, float thresh, unsigned char* d_species, unsigned char* d_mask, hipStream_t st) {
+  ConvLayer& H = *n.head;
+  const size_t M = n.rows(H, B);
+  const ConvSrc& s0 = H.src[0];
+  if (H.nsrc == 1 && !s0.up && !s0.bcast && head_fused_ok(n.ncls, s0.C, M, s0.act, n.flags) && !(n.flags & CF_NO_HEAD_LABELS)) {
+    ICS_TRY(unet_pack(n));
+    n.last_batch = B;
+    n.prof.begin(st, "head_fused", 2.0 * M * 128 * (n.ncls + 1), 4.0 * M * 128 + 2.0 * M);
+    ICS_TRY(launch_head_fused(st, s0.p, s0.C, s0.scale, s0.shift, n.tp(H.t_w), n.tp(H.t_gamma), n.tp(H.t_b),
+                              n.tp(H.t_b) + n.ncls, H.s, n.labels, M, 2, 0, n.loss_weight, n.ws_dbl, 2048, nullptr, nullptr,
+                              nullptr, nullptr, thresh, d_species, d_mask));
+    n.prof.end(st);
+    return 0;
+  }
+  ICS_TRY(unet_head_loss(n, B, 0, 0));
+  n.prof.begin(st, "labels", 0, 4.0 * M * (n.ncls + 1) + 2.0 * M);
+  ICS_LAUNCH(labels_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, H.s, n.ncls + 1, n.ncls, M, thresh,
+                     d_species, d_mask);
+  n.prof.end(st);
+  ICS_HIP(hipGetLastError());
   return 0;
 }
 
@@ -2195,13 +2224,10 @@ int ics_unet_predict_labels(ics_net* net, const float* x, int batch, float thres
   Net& n = net->n;
   ICS_TRY(unet_upload(n, x, nullptr, batch));
   ICS_TRY(unet_forward_trunk(n, batch, false, false, false, n.x_in));
-  ICS_TRY(unet_head_loss(n, batch, 0, 0));
   const size_t M = n.rows(*n.head, batch);
   unsigned char* d_species = reinterpret_cast<unsigned char*>(n.head->dy);   // [M][ncls+1] float scratch
   unsigned char* d_mask = d_species + M;
-  ICS_LAUNCH(labels_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, n.st, n.head->s, n.ncls + 1,
-                     n.ncls, M, thresh, d_species, d_mask);
-  ICS_HIP(hipGetLastError());
+  ICS_TRY(unet_head_labels(n, batch, thresh, d_species, d_mask, n.st));
   if (species) ICS_HIP(hipMemcpyAsync(species, d_species, M, hipMemcpyDeviceToHost, n.st));
   if (mask) ICS_HIP(hipMemcpyAsync(mask, d_mask, M, hipMemcpyDeviceToHost, n.st));
   ICS_HIP(hipStreamSynchronize(n.st));
@@ -2217,17 +2243,12 @@ int ics_unet_predict_resident(ics_net* net, int labels_only, float thresh) {
   ICS_CHECK(n.resident_batch > 0, "no resident batch: call ics_unet_upload_batch first");
   const int batch = n.resident_batch;
   ICS_TRY(unet_forward_trunk(n, batch, false, false, false, n.x_in));
-  ICS_TRY(unet_head_loss(n, batch, 0, 0));
   if (labels_only) {
     const size_t M = n.rows(*n.head, batch);
     unsigned char* d_species = reinterpret_cast<unsigned char*>(n.head->dy);
-    n.prof.begin(n.st, "labels", 0, 4.0 * M * (n.ncls + 1) + 2.0 * M);
-    ICS_LAUNCH(labels_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, n.st, n.head->s, n.ncls + 1,
-                       n.ncls, M, thresh, d_species, d_species + M);
-    n.prof.end(n.st);
-    ICS_HIP(hipGetLastError());
+    return unet_head_labels(n, batch, thresh, d_species, d_species + M, n.st);
   }
-  return 0;
+  return unet_head_loss(n, batch, 0, 0);
 }
 
 // Device-clock bracket on the engine's stream (bench.py's gpu_active_s): start records an event, stop records a second
@@ -2371,9 +2392,7 @@ static int decode_to_labels_device(Net& n, Net& u, const float* z, const float* 
   float* d_aux = reinterpret_cast<float*>(d_mask + M);                       // density [M] | minmax [B][3][2]
   do {
     if ((rc = unet_forward_trunk(u, batch, false, false, false, n.recon))) break;
-    if ((rc = unet_head_loss(u, batch, 0, 0))) break;
-    ICS_LAUNCH(labels_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, n.st, u.head->s, u.ncls + 1,
-                       u.ncls, M, thresh, d_species, d_mask);
+    if ((rc = unet_head_labels(u, batch, thresh, d_species, d_mask, n.st))) break;
     if (want_density) {
       ICS_LAUNCH(gather_cols_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, n.st, n.recon, n.C, 0, 1,
                          M, d_aux);
@@ -2658,6 +2677,8 @@ int ics_op_conv3d_forward(const float* x, const float* w, const float* bias, int
 int ics_op_unet_head(const float* x, const float* wsoft, const float* bsoft, const float* wsig, const float* bsig,
                      const uint8_t* labels, size_t M, int ncls, float loss_weight, int mode, int fused, float* out,
                      float metrics[5], double sums[7]) {
+  const int bce = ((mode >> 2) & 1) << 1;
+  mode &= 3;
   ICS_CHECK(x && wsoft && bsoft && wsig && bsig && labels && M >= 1 && ncls >= 2 && ncls <= 128 && mode >= 0 && mode <= 2,
             "bad head arguments");
   Net n;
@@ -2680,7 +2701,7 @@ int ics_op_unet_head(const float* x, const float* wsoft, const float* bsoft, con
   const int hmode = mode == 0 ? 0 : 1, want_grad = mode == 2;
   if (fused) {
     ICS_CHECK(head_fused_ok(ncls, 128, M, ACT_NONE, 0), "this shape has no fused head kernel");
-    ICS_TRY(launch_head_fused(n.st, dx, 128, nullptr, nullptr, dws, dwg, db, db + ncls, dz, dlab, M, hmode, want_grad, lw,
+    ICS_TRY(launch_head_fused(n.st, dx, 128, nullptr, nullptr, dws, dwg, db, db + ncls, dz, dlab, M, hmode, want_grad | bce, lw,
                               dpart, 2048, dmet, nullptr, want_grad ? dcol : nullptr, dsum));
   } else {
     ICS_TRY(launch_pack_fwd(n.st, dws, 128, ncls, dwp, Kpad, Npad, 0, 0, 1));
@@ -2689,7 +2710,7 @@ int ics_op_unet_head(const float* x, const float* wsoft, const float* bsoft, con
     g.B = (int)M;                                                      // 1x1x1: rows are rows
     ConvSrc s = src_plain(dx, 128);
     ICS_TRY(launch_conv_fwd(n.st, g, &s, 1, dwp, db, dz, nz, ACT_NONE, nullptr, nullptr));
-    ICS_TRY(launch_head(n.st, dz, nz, ncls, dlab, M, hmode, want_grad, lw, dpart, 2048, dmet, nullptr,
+    ICS_TRY(launch_head(n.st, dz, nz, ncls, dlab, M, hmode, want_grad | bce, lw, dpart, 2048, dmet, nullptr,
                         want_grad ? dcol : nullptr, dsum));
   }
   if (out) ICS_HIP(hipMemcpyAsync(out, dz, M * nz * 4, hipMemcpyDeviceToHost, n.st));

@@ -39,7 +39,7 @@ static int tensor_io(ics_net* net) {
 
 static int run(int d, int C, int B, int with_comm) {
   const size_t M = (size_t)B * d * d * d;
-  ics_unet_config uc = {C, 95, d, B, 1e-3f, 0.f, 1, 1};
+  ics_unet_config uc = {C, 95, d, B, 1e-3f, 0.f, 1, 1, with_comm == 2};
   ics_vae_config vc = {C, 10, 256, {16, 32, 64, 128}, d, B, 5e-4f, 0.5f, 3e-4f, {1.f, 1.f, 1.f, 1.f}, 1};
   ics_net *unet = NULL, *vae = NULL;
   OK(ics_unet_create(&uc, &unet));

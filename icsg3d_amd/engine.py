@@ -173,13 +173,13 @@ def comm_unique_id():
 
 class UnetEngine(_Net):
     def __init__(self, in_channels=1, num_classes=95, d=32, max_batch=32, lr=1e-6, loss_weight=0.0,
-                 pool_ties="tf_cpu", bn_unbias=True, device=None):
+                 pool_ties="tf_cpu", bn_unbias=True, device=None, bce_from_logits=False):
         super().__init__()
         if device is not None:
             L.check(self._lib.ics_set_device(int(device)))
         self.in_channels, self.num_classes, self.d, self.max_batch = in_channels, num_classes, d, max_batch
         cfg = L.UnetConfig(in_channels, num_classes, d, max_batch, lr, loss_weight,
-                           1 if pool_ties == "tf_cpu" else 0, 1 if bn_unbias else 0)
+                           1 if pool_ties == "tf_cpu" else 0, 1 if bn_unbias else 0, 1 if bce_from_logits else 0)
         L.check(self._lib.ics_unet_create(C.byref(cfg), C.byref(self._h)))
 
     def _check_x(self, x):
@@ -385,7 +385,7 @@ def conv3d_forward(x, w, bias=None, pre_act=0):
     return y
 
 
-def unet_head(x, wsoft, bsoft, wsig, bsig, labels, mode=1, fused=True, loss_weight=0.0):
+def unet_head(x, wsoft, bsoft, wsig, bsig, labels, mode=1, fused=True, loss_weight=0.0, bce_from_logits=False):
     """Single-op entry (kernel parity tests): the heads + losses + metrics on a given trunk output x (M,128).
     Returns (out (M, ncls+1) | None, metrics (5,), sums dict) -- see ics_op_unet_head."""
     lib = L.load()
@@ -396,7 +396,8 @@ def unet_head(x, wsoft, bsoft, wsig, bsig, labels, mode=1, fused=True, loss_weig
     m = np.zeros(5, np.float32)
     s = (C.c_double * 7)()
     L.check(lib.ics_op_unet_head(L.fptr(x), L.fptr(wsoft), L.fptr(bsoft), L.fptr(wsig), L.fptr(bsig), L.u8ptr(lab), M, ncls,
-                                 float(loss_weight), int(mode), 1 if fused else 0, L.fptr(out), L.fptr(m), s))
+                                 float(loss_weight), int(mode) | (4 if bce_from_logits else 0), 1 if fused else 0, L.fptr(out),
+                                 L.fptr(m), s))
     keys = ("sum_lsoft", "sum_lsig", "tp", "predicted", "wr_tp", "wr_possible", "voxels")
     return out, m, dict(zip(keys, [float(v) for v in s]))
 

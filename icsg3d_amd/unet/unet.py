@@ -224,12 +224,15 @@ class AtomUnet(DataParallelMixin):
     num_classes, class_weights, weights, input_shape, lr: as the reference.  class_weights is
     stored and, as in the reference, not used by the loss: the compiled loss weight is
     the scalar float(num_classes).  Extra keyword `pool_ties`: "tf_cpu" (TensorFlow-CPU
-    MaxPool3DGrad tie rule, default) or "first".
+    MaxPool3DGrad tie rule, default) or "first"; `bce_from_logits`: False (default) = "binary_crossentropy" on clipped
+    probabilities, True = TF 2.1's short-circuit to sigmoid_cross_entropy_with_logits for a Sigmoid output (SURVEY
+    App. B: which of the two Keras 2.3.1 / TF 2.1 takes cannot be checked offline; they differ only at saturation).
     """
 
     def __init__(self, num_classes=95, class_weights=None, weights=None, input_shape=(32, 32, 32, 4),
-                 lr=1e-6, pool_ties="tf_cpu", max_batch=None):
+                 lr=1e-6, pool_ties="tf_cpu", max_batch=None, bce_from_logits=False):
         self.class_weights = class_weights
+        self.bce_from_logits = bool(bce_from_logits)
         self.input_shape = tuple(input_shape)
         self.lr = lr
         self.num_classes = num_classes
@@ -261,14 +264,15 @@ class AtomUnet(DataParallelMixin):
             carry = dict(self._host_weights)
             self._eng = UnetEngine(in_channels=self.input_shape[-1], num_classes=self.num_classes,
                                    d=self.input_shape[0], max_batch=max(batch, self._max_batch or 0), lr=self.lr,
-                                   pool_ties=self.pool_ties)
+                                   pool_ties=self.pool_ties, bce_from_logits=self.bce_from_logits)
             self._eng.set_weights(carry)
             self._dp_attach(self._eng)
         elif grow and batch > self._eng.max_batch:
             carry, opt = self._eng.get_weights(), self._eng.get_optimizer_state()
             self._eng.close()
             self._eng = UnetEngine(in_channels=self.input_shape[-1], num_classes=self.num_classes,
-                                   d=self.input_shape[0], max_batch=batch, lr=self.lr, pool_ties=self.pool_ties)
+                                   d=self.input_shape[0], max_batch=batch, lr=self.lr, pool_ties=self.pool_ties,
+                                   bce_from_logits=self.bce_from_logits)
             self._eng.set_weights(carry)
             self._eng.set_optimizer_state(*opt)
             self._dp_attach(self._eng)

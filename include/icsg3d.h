@@ -50,6 +50,10 @@ typedef struct ics_unet_config {
   float loss_weight; /* scalar class weight; <=0 selects float(num_classes)  */
   int pool_ties_all; /* 1: TF-CPU MaxPool3DGrad tie rule (default), 0: first max only     */
   int bn_unbias;     /* 1: Keras moving-variance n/(n-(1+eps)) rescale (default)          */
+  int bce_from_logits; /* "binary_crossentropy" of the sig head (unet/unet.py:254-256): 0 (default) = the clipped-probability
+                        * form -[t log p + (1-t) log(1-p)], p in [1e-7, 1-1e-7]; 1 = tf.keras.backend.binary_crossentropy's
+                        * short-circuit for a Sigmoid producer op, sigmoid_cross_entropy_with_logits (TF 2.1; SURVEY App. B,
+                        * confidence M).  The two agree to ~1e-7 relative except at saturated probabilities.       */
 } ics_unet_config;
 
 int ics_unet_create(const ics_unet_config* cfg, ics_net** out);
@@ -253,7 +257,7 @@ int ics_op_conv3d_backward(const float* x, const float* w, const float* dy, int 
  * weighted_categorical_crossentropy / binary_crossentropy / f1_m / wr_m (unet/unet.py:159-221,252-259).
  * x [M][128], wsoft [128][ncls], bsoft [ncls], wsig [128], bsig [1], labels uint8 [M]; loss_weight <= 0: the scalar ncls.
  * mode 0: out [M][ncls+1] = probabilities (soft | sig); 1: metrics[5] and sums[7] (ics_unet_metric_sums) only;
- * 2: also out = dLoss/dlogits.  fused != 0: the GEMM inside the loss kernel (M % 16 == 0, ncls == 95), else GEMM + loss kernel. */
+ * 2: also out = dLoss/dlogits; + 4: binary_crossentropy in the logits form (ics_unet_config.bce_from_logits).  fused != 0: the GEMM inside the loss kernel (M % 16 == 0, ncls == 95), else GEMM + loss kernel. */
 int ics_op_unet_head(const float* x, const float* wsoft, const float* bsoft, const float* wsig, const float* bsig,
                      const uint8_t* labels, size_t M, int ncls, float loss_weight, int mode, int fused, float* out,
                      float metrics[5], double sums[7]);

@@ -288,6 +288,18 @@ def bce_loss(t, p):
     return (-(t * np.log(pc) + (1 - t) * np.log(1 - pc))).mean(-1)
 
 
+def bce_logits_loss(t, z):
+    """tf.nn.sigmoid_cross_entropy_with_logits, which tf.keras.backend.binary_crossentropy (TF 2.1) substitutes when the
+    prediction's producer op is a Sigmoid (confidence M): max(z, 0) - z t + log1p(exp(-|z|)), mean over the
+    last axis like bce_loss."""
+    return (np.maximum(z, 0) - z * t + np.log1p(np.exp(-np.abs(z)))).mean(-1)
+
+
+def bce_logits_bwd(t, z, dl):
+    """d bce_logits_loss / dz = sigmoid(z) - t: no clip, no kink."""
+    return (sigmoid(z) - t) * dl[..., None] / z.shape[-1]
+
+
 def bce_bwd(t, p, dl, pin=None, pin_tol=0.5, flips=None):
     """dl has the shape of bce_loss's output.  pin: optional clip decisions of the implementation under test."""
     pc = np.clip(p, K_EPSILON, 1 - K_EPSILON)
@@ -505,8 +517,9 @@ class UnetOracle:
     metric_names = ["Loss", "lsoft", "lsig", "f1", "wr"]   # unet/unet.py:250
 
     def __init__(self, in_ch=1, num_classes=95, seed=1, lr=1e-6, dtype=np.float64,
-                 pool_ties="tf_cpu", bn_unbias=True, loss_weight=None):
+                 pool_ties="tf_cpu", bn_unbias=True, loss_weight=None, bce_from_logits=False):
         self.in_ch, self.num_classes, self.lr, self.dtype = in_ch, num_classes, lr, dtype
+        self.bce_from_logits = bce_from_logits      # the sig head's loss: clipped probabilities (default) or TF's logits form
         self.pool_ties, self.bn_unbias = pool_ties, bn_unbias
         # unet.py:253 passes the INTEGER num_classes as "weights" -> scalar 95.0
         self.loss_weight = float(num_classes) if loss_weight is None else loss_weight
@@ -549,11 +562,16 @@ class UnetOracle:
 
     predict = forward
 
-    def loss_and_metrics(self, soft, sig, labels):
+    def loss_and_metrics(self, soft, sig, labels, zg=None):
+        """zg: the sigmoid head's logits, needed when bce_from_logits (forward() leaves them in cache["_head"]["zg"])."""
         y = one_hot(labels, self.num_classes)
         t = (labels != 0).astype(self.dtype)[..., None]
         lsoft = wcce_loss(y, soft, self.loss_weight).mean()
-        lsig = bce_loss(t, sig).mean()
+        if self.bce_from_logits:
+            zg = np.log(sig) - np.log1p(-sig) if zg is None else zg
+            lsig = bce_logits_loss(t, zg).mean()
+        else:
+            lsig = bce_loss(t, sig).mean()
         return np.array([lsoft + lsig, lsoft, lsig, f1_m(y, soft), wr_m(y, soft)])
 
     def backward(self, labels, cache, clip_pin=None):
@@ -574,9 +592,12 @@ class UnetOracle:
                          pin=None if pin_soft is None else np.asarray(pin_soft)[..., None], flips=self.clip_flips)
         dzs = softmax_bwd(soft, dsoft)
         pin_sig = clip_pin.get("sig")
-        dsig = bce_bwd(t, sig, np.full(sig.shape[:-1], 1.0 / sig[..., 0].size),
-                       pin=None if pin_sig is None else np.asarray(pin_sig)[..., None], flips=self.clip_flips)
-        dzg = dsig * sig * (1 - sig)
+        if self.bce_from_logits:
+            dzg = bce_logits_bwd(t, h["zg"], np.full(sig.shape[:-1], 1.0 / sig[..., 0].size))
+        else:
+            dsig = bce_bwd(t, sig, np.full(sig.shape[:-1], 1.0 / sig[..., 0].size),
+                           pin=None if pin_sig is None else np.asarray(pin_sig)[..., None], flips=self.clip_flips)
+            dzg = dsig * sig * (1 - sig)
         d1, g["soft/kernel"], g["soft/bias"] = conv3d_bwd(c18, P["soft/kernel"], dzs)
         d2, g["sig/kernel"], g["sig/bias"] = conv3d_bwd(c18, P["sig/kernel"], dzg)
         d = d1 + d2
@@ -612,7 +633,7 @@ class UnetOracle:
         clip_pin: optional K.clip decisions of the losses (backward)."""
         cache = {}
         soft, sig = self.forward(x, training=True, cache=cache)
-        metrics = self.loss_and_metrics(soft, sig, labels)
+        metrics = self.loss_and_metrics(soft, sig, labels, cache["_head"]["zg"])
         self.kink_flips = apply_kink(self.blocks.values(), cache, self.P, kink, kink_tol, affine) if kink else {}
         grads = self.backward(labels, cache, clip_pin=clip_pin)
         for blk in self.blocks.values():
@@ -622,8 +643,9 @@ class UnetOracle:
         return metrics
 
     def test_on_batch(self, x, labels):
-        soft, sig = self.forward(x, training=False)
-        return self.loss_and_metrics(soft, sig, labels)
+        cache = {}
+        soft, sig = self.forward(x, training=False, cache=cache)
+        return self.loss_and_metrics(soft, sig, labels, cache["_head"]["zg"])
 
     # -- perceptual sub-model (vae/lattice_vae.py:257-270): taps = ReLU outputs of c2,c4,c6,c10
     def pm_forward(self, x, training, cache):

@@ -113,7 +113,7 @@ def _check_counts(sums, lab, soft_ref):
 
 
 @pytest.mark.parametrize("C", [1, 4])
-def test_unet_eval_metrics_and_mask_with_confident_head(C, relerr):
+def test_unet_eval_metrics_and_mask_with_confident_head(C, relerr, monkeypatch):
     B, d = 2, 16
     orc, eng, X, lab = _setup(B, d, C, training=False)
     soft_ref, sig_ref = orc.forward(X, training=False)
@@ -135,6 +135,21 @@ def test_unet_eval_metrics_and_mask_with_confident_head(C, relerr):
     clear = (srt[..., -1] - srt[..., -2]) > 1e-4
     assert np.array_equal(sp[clear], soft_ref.argmax(-1)[clear]) and clear.mean() > 0.99
     assert len(np.unique(sp)) >= 4                                   # several species predicted, not one constant label
+    # the labels come out of the fused head's registers (mode 2: no probability tensor): bit-identical to np.argmax / the
+    # threshold of the probabilities the same engine returns, and to the stored-probabilities path (ICSG3D_NO_HEAD_LABELS)
+    assert np.array_equal(sp, soft.argmax(-1)) and np.array_equal(mk.astype(bool), sig[..., 0] >= 0.8)
+    from icsg3d_amd.engine import UnetEngine
+    monkeypatch.setenv("ICSG3D_NO_HEAD_LABELS", "1")
+    two_step = UnetEngine(in_channels=C, d=d, max_batch=B)
+    monkeypatch.delenv("ICSG3D_NO_HEAD_LABELS")
+    two_step.set_weights({**orc.P, **orc.S})
+    two_step.profile_enable(True)
+    sp2, mk2 = two_step.predict_labels(X, 0.8)
+    assert "labels" in {r["label"].split("|")[0] for r in two_step.profile_rows()}
+    eng.profile_enable(True)
+    eng.predict_labels(X, 0.8)
+    assert "labels" not in {r["label"].split("|")[0] for r in eng.profile_rows()}
+    assert np.array_equal(sp, sp2) and np.array_equal(mk, mk2)
 
 
 @pytest.mark.parametrize("C", [1, 4])
@@ -151,3 +166,67 @@ def test_unet_train_step_metrics_with_confident_head(C):
     ref, exact = _check_counts(eng.metric_sums(), lab, soft_ref)
     assert ref["tp"] > 1000 and ref["wr_tp"] > 10
     np.testing.assert_allclose(m[3:], m_ref[3:], rtol=1e-5 if exact else 1e-3)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_bce_from_logits_switch_on_the_device(fused):
+    """ics_unet_config.bce_from_logits: TF 2.1's sigmoid_cross_entropy_with_logits short-circuit (confidence
+    M) next to the default clipped-probability form.  Logits up to +-25: the two forms differ there (the clip bounds the
+    per-voxel loss at 16.1 and zeroes the gradient), and each must equal its oracle."""
+    from icsg3d_amd.engine import unet_head
+    rng = np.random.default_rng(12)
+    M = 512
+    lab = np.where(rng.uniform(size=M) < 0.4, rng.integers(1, NC, size=M), 0).astype(np.uint8)
+    t = (lab != 0).astype(np.float64)[:, None]
+    zg = rng.normal(size=M) * 4
+    zg[:40] = np.where(t[:40, 0] > 0, -25.0, 25.0)                   # confidently WRONG voxels: p clipped, loss 16.1 vs 25
+    x = np.zeros((M, 128), np.float32)
+    x[:, :NC] = rng.normal(size=(M, NC))
+    x[:, NC] = zg
+    z64 = x[:, NC].astype(np.float64)[:, None]
+    dz_l, m_l, _ = unet_head(x, *_identity_head(), lab, mode=2, fused=fused, bce_from_logits=True)
+    dz_c, m_c, _ = unet_head(x, *_identity_head(), lab, mode=2, fused=fused, bce_from_logits=False)
+    ref_l = R.bce_logits_loss(t, z64).mean()
+    ref_c = R.bce_loss(t, R.sigmoid(z64)).mean()
+    assert ref_l > 1.2 * ref_c                                       # the forms really differ on this input
+    np.testing.assert_allclose(m_l[2], ref_l, rtol=1e-5)
+    # the clipped form AT saturation is an fp32 statement: the upper bound 1 - 1e-7 is 1 - 2^-23 in fp32, so a clipped
+    # voxel's -log(1 - p) is 15.94 there and 16.12 in fp64 (Keras computes it in fp32 too).  Held to the same formula
+    # evaluated in fp32 numpy; against the fp64 value it is within 0.5 %.
+    f = np.float32
+    p32 = (f(1) / (f(1) + np.exp(-x[:, NC:NC + 1]))).astype(f)
+    pc = np.clip(p32, f(1e-7), f(1) - f(1e-7))
+    t32 = t.astype(f)
+    ref_c32 = (-(t32 * np.log(pc) + (f(1) - t32) * np.log(f(1) - pc))).astype(np.float64).mean()
+    np.testing.assert_allclose(m_c[2], ref_c32, rtol=2e-5)
+    np.testing.assert_allclose(m_c[2], ref_c, rtol=5e-3)
+    np.testing.assert_allclose(m_l[1], m_c[1], rtol=1e-7)            # the softmax head does not care
+    g_l = R.bce_logits_bwd(t, z64, np.full(M, 1.0 / M))[:, 0]
+    np.testing.assert_allclose(dz_l[:, NC], g_l, rtol=2e-5, atol=1e-9 / M)
+    assert np.all(dz_c[:40, NC] == 0) and np.all(np.abs(dz_l[:40, NC] * M) > 0.99)     # clip kink vs |sigmoid - t| ~ 1
+    np.testing.assert_array_equal(dz_l[:, :NC], dz_c[:, :NC])
+
+
+def test_unet_train_step_with_bce_from_logits_matches_oracle(relerr):
+    """One full train step under the logits form of the sigmoid head's loss: metrics and every gradient tensor."""
+    from icsg3d_amd.engine import UnetEngine
+    from test_gpu_unet import UNET_LAYERS, _layer_shape
+    B, d, C = 2, 16, 1
+    orc = R.UnetOracle(in_ch=C, seed=1, lr=1e-3, bce_from_logits=True)
+    X, lab, _ = R.synthetic_batch(B, d, C, seed=0, dtype=np.float64)
+    X = X + 1e-3 * np.random.default_rng(5).uniform(size=X.shape)
+    saturate_head(orc, X, lab, True, sharp_sig=8.0)                  # sigmoid logits up to ~20: saturation is exercised
+    eng = UnetEngine(in_channels=C, d=d, max_batch=B, lr=1e-3, bce_from_logits=True)
+    eng.set_weights(orc.P)
+    m = eng.train_step(X, lab)
+    kink = {n: eng.get_activation(n, _layer_shape(n, B, d)) for n in UNET_LAYERS}
+    affine = {n: eng.get_bn_affine(n, _layer_shape(n, B, d)[-1]) for n in ("c2", "c4", "c6")}
+    m_ref = orc.train_on_batch(X, lab, kink=kink, affine=affine)
+    np.testing.assert_allclose(m[:3], m_ref[:3], rtol=2e-5)
+    worst = 0.0
+    for name, shape, trainable in eng.tensor_infos():
+        if trainable:
+            e = relerr(eng.get_grad(name, shape), orc.last_grads[name])
+            worst = max(worst, e)
+            assert e <= 1e-4, (name, e)
+    print("bce_from_logits train step: worst gradient error %.2e" % worst)

@@ -95,3 +95,20 @@ def test_vae_cond_tiling_and_shapes():
     t = v.tile_cond(cond, 16)
     assert t.shape == (1, 16, 16, 16, 40) and t[0, 5, 6, 7, 13] == 1.0 and t[0, 0, 0, 0, 12] == 0.0
     assert dict(R.vae_param_shapes(1, d=64))["dec_dense/kernel"] == (266, 2048)  # seed (d/8)^3*4 (F12 extension)
+
+
+def test_bce_logits_form_matches_clipped_form_away_from_saturation_and_its_gradient():
+    """The two candidate semantics of Keras' "binary_crossentropy" on a Sigmoid output: equal to ~1e-7
+    relative where p is not saturated, different at saturation; the logits form's gradient is sigmoid(z) - t (checked by
+    finite differences)."""
+    rng = np.random.default_rng(4)
+    z = rng.normal(size=(2, 3, 3, 3, 1)) * 2
+    t = (rng.uniform(size=z.shape) < 0.4).astype(np.float64)
+    a, b = R.bce_logits_loss(t, z), R.bce_loss(t, R.sigmoid(z))
+    np.testing.assert_allclose(a, b, rtol=1e-6)
+    zs = np.array([[[[[30.0]]]], [[[[-30.0]]]]])
+    ts = np.array([[[[[0.0]]]], [[[[1.0]]]]])
+    assert np.all(R.bce_logits_loss(ts, zs) > 29) and np.all(R.bce_loss(ts, R.sigmoid(zs)) < 17)     # clip at 1e-7: -log(1e-7) = 16.1
+    w = rng.normal(size=z.shape[:-1])
+    g = R.bce_logits_bwd(t, z, w)
+    np.testing.assert_allclose(g, fd(lambda: float((R.bce_logits_loss(t, z) * w).sum()), z), rtol=1e-6, atol=1e-9)
