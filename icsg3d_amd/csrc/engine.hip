@@ -204,6 +204,7 @@ struct Net {
   hipStream_t st2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool side_on = true, side_dirty = false;
+  bool pm_side = false;               // VAE engine: the perceptual y_true pass on st2 (vae_step)
   int maxB = 0, d = 0, C = 0;
   std::vector<void*> allocs;
   std::vector<Tensor> tensors;
@@ -1636,6 +1637,7 @@ static VaeRefs vae_refs(Net& n) {
 
 static int vae_build(Net& n, const ics_vae_config& cfg, Net* pm) {
   n.kind = 1; n.maxB = cfg.max_batch; n.d = cfg.d; n.C = cfg.in_channels; n.pm = pm;
+  n.pm_side = getenv("ICSG3D_NO_PM_SIDE") == nullptr;
   n.ncond = cfg.cond_shape; n.latent = cfg.latent_dim; n.lr = cfg.lr; n.alpha = cfg.alpha; n.beta = cfg.beta;
   n.bn_unbias = cfg.bn_unbias; n.pool_ties_all = pm ? pm->pool_ties_all : 1;
   for (int i = 0; i < 4; ++i) { n.filters[i] = cfg.filters[i]; n.pm_w[i] = cfg.pm_layer_weights[i]; }
@@ -1785,13 +1787,31 @@ static int vae_step(Net& n, int B, bool training, float* metrics) {
     // y_pred into the layers' own buffers (state kept for the backward pass)
     // (Measured on MI355X: running this pass on a second stream, concurrently with the encoder / decoder, overlaps
     // 3.8 ms of kernels but each runs slower while sharing the chip -- step 12.69 vs 12.59 ms: not done.)
+    // Round 5: the y_true pass needs nothing but x and produces nothing the encoder / decoder read, and those are ~60
+    // small-grid launches at the 5 us floor that leave most of the chip idle: the pass runs on the VAE's second stream
+    // next to them and is joined before the y_pred pass (which reuses the U-Net's layer buffers).  Not under SyncBN (the
+    // pass's statistics collectives would interleave with the encoder's on one communicator).  ICSG3D_NO_PM_SIDE=1: serial.
+    // ... and not while every launch is being timed (profiler on, no site filter): a kernel's event bracket would then
+    // time the kernels of the other stream it shares the chip with -- the per-kernel table comes from a serial step.
+    const bool timing_all = (n.prof.on && n.prof.filter.empty()) || (u.prof.on && u.prof.filter.empty());
+    const bool pm_side = n.pm_side && !n.sync() && !u.sync() && !timing_all;
+    if (pm_side) {
+      if (hipEventRecord(n.ev_fork, n.st) != hipSuccess || hipStreamWaitEvent(n.st2, n.ev_fork, 0) != hipSuccess) {
+        set_error("side stream fork failed"); rc = -1; break;
+      }
+      u.st = n.st2;
+    }
     float* own_s[4];
     for (int l = 0; l < 4; ++l) { own_s[l] = taps[l]->s; taps[l]->s = u.tap_copy[l]; }
     rc = unet_forward_trunk(u, B, training, false, true, n.x_in);
     for (int l = 0; l < 4; ++l) taps[l]->s = own_s[l];
+    u.st = n.st;
     if (rc) break;
     if ((rc = vae_encode_fwd(n, B, training))) break;
     if ((rc = vae_decode_fwd(n, B, training))) break;
+    if (pm_side && (hipEventRecord(n.ev_join, n.st2) != hipSuccess || hipStreamWaitEvent(n.st, n.ev_join, 0) != hipSuccess)) {
+      set_error("side stream join failed"); rc = -1; break;
+    }
     u.want_tie_stats = training;       // this pass is differentiated (unet_pm_backward)
     rc = unet_forward_trunk(u, B, training, false, true, n.recon);
     u.want_tie_stats = false;
