@@ -804,7 +804,8 @@ static GradSrc gs_pool(const float* p, int ld, const ConvLayer& producer) {
 
 // side stream: everything issued on st so far is visible to work issued on the returned stream
 static hipStream_t side_begin(Net& n) {
-  if (!n.side_on) return n.st;
+  // (one stream while every launch is timed: an event bracket must not time the other stream's kernels)
+  if (!n.side_on || (n.prof.on && n.prof.filter.empty())) return n.st;
   (void)hipEventRecord(n.ev_fork, n.st);
   (void)hipStreamWaitEvent(n.st2, n.ev_fork, 0);
   n.side_dirty = true;
@@ -1638,6 +1639,11 @@ static VaeRefs vae_refs(Net& n) {
 static int vae_build(Net& n, const ics_vae_config& cfg, Net* pm) {
   n.kind = 1; n.maxB = cfg.max_batch; n.d = cfg.d; n.C = cfg.in_channels; n.pm = pm;
   n.pm_side = getenv("ICSG3D_NO_PM_SIDE") == nullptr;
+  // Round 5: the VAE's weight-gradient launches (small GEMMs, split reductions, the condition-weight sums: ~0.7 ms) leave the
+  // critical chain bn_bwd -> backward-data -> next layer for the second stream, as the U-Net engine can (opt-in there):
+  // 5.71 -> 5.44 ms per step.  (Round 1 measured the opposite, 12.59 -> 12.71 ms: the kernels were 2x longer and filled
+  // the chip.)  ICSG3D_NO_VAE_SIDE_WGRAD=1: one stream.
+  n.side_on = getenv("ICSG3D_NO_VAE_SIDE_WGRAD") == nullptr;
   n.ncond = cfg.cond_shape; n.latent = cfg.latent_dim; n.lr = cfg.lr; n.alpha = cfg.alpha; n.beta = cfg.beta;
   n.bn_unbias = cfg.bn_unbias; n.pool_ties_all = pm ? pm->pool_ties_all : 1;
   for (int i = 0; i < 4; ++i) { n.filters[i] = cfg.filters[i]; n.pm_w[i] = cfg.pm_layer_weights[i]; }

@@ -98,7 +98,10 @@ def default_run():
                                     "ICSG3D_UP3_BIG_MIN_WG",
                                     # not a fallback either: = 0 turns the BatchNorm-backward-in-backward-data fusion on at
                                     # this size (c18 -> c17, c16 -> c15, c4 -> c3; default: from 64 MB of activations on)
-                                    "ICSG3D_DGRAD_BNFUSE_MIN=0", "ICSG3D_NO_DGRAD_BNFUSE"])
+                                    "ICSG3D_DGRAD_BNFUSE_MIN=0", "ICSG3D_NO_DGRAD_BNFUSE",
+                                    # round 5: the DFC-VAE step's two-stream schedule (perceptual y_true pass / weight
+                                    # gradients on the second stream) against the serial one
+                                    "ICSG3D_NO_PM_SIDE", "ICSG3D_NO_VAE_SIDE_WGRAD", "ICSG3D_NO_HEAD_LABELS"])
 def test_fallback_path_matches_default(default_run, switch):
     name, _, val = switch.partition("=")
     alt = _run({name: val or "1"})
@@ -109,7 +112,8 @@ def test_fallback_path_matches_default(default_run, switch):
     # That bound is loose by necessity -- the tight check of the deep gradients is _run's: every gradient tensor of THIS
     # configuration against the fp64 oracle with its own decisions pinned, <= 1e-4.
     backward_only = name in ("ICSG3D_DGRAD_BNFUSE_MIN", "ICSG3D_NO_DGRAD_BNFUSE", "ICSG3D_NO_BWD_FOLD",
-                             "ICSG3D_NO_HEAD_BNFUSE", "ICSG3D_NO_TICKET", "ICSG3D_NO_FAST_BNBWD", "ICSG3D_NO_POOL_PRESUM")
+                             "ICSG3D_NO_HEAD_BNFUSE", "ICSG3D_NO_TICKET", "ICSG3D_NO_FAST_BNBWD", "ICSG3D_NO_POOL_PRESUM",
+                             "ICSG3D_NO_PM_SIDE", "ICSG3D_NO_VAE_SIDE_WGRAD", "ICSG3D_NO_HEAD_LABELS")
     for k, ref in default_run.items():
         scale = max(float(np.abs(ref).max()), 1e-30)
         deep = k.startswith("c") and "_" in k
