@@ -18,6 +18,19 @@ pairs = [
     (os.path.join(src, "prof_vae", "prof_kernel_stats.csv"), "%s_vae_b32_kernel_stats.csv" % tag),
     (os.path.join(pmc, "summary.txt"), "%s_pmc_summary.txt" % tag),
     (os.path.join(pmc, "traffic.json"), "%s_pmc_traffic.json" % tag),
+    # round 5: inference configurations and the d = 64 grid, each engine on its own
+    (os.path.join(src, "bench_predict.json"), "%s_bench_predict.json" % tag),
+    (os.path.join(src, "bench_generate.json"), "%s_bench_generate.json" % tag),
+    (os.path.join(src, "bench_unet_d64.json"), "%s_d64_bench_unet.json" % tag),
+    (os.path.join(src, "bench_vae_d64.json"), "%s_d64_bench_vae.json" % tag),
+    (os.path.join(src, "prof_predict", "prof_kernel_stats.csv"), "%s_predict_kernel_stats.csv" % tag),
+    (os.path.join(src, "prof_generate", "prof_kernel_stats.csv"), "%s_generate_kernel_stats.csv" % tag),
+    (os.path.join(src, "prof_unet_d64", "prof_kernel_stats.csv"), "%s_d64_unet_b8_kernel_stats.csv" % tag),
+    (os.path.join(src, "prof_vae_d64", "prof_kernel_stats.csv"), "%s_d64_vae_b8_kernel_stats.csv" % tag),
+    (os.path.join(root, "gpurun_out", "pmc_%s_d64" % tag, "summary.txt"), "%s_d64_pmc_summary.txt" % tag),
+    (os.path.join(root, "gpurun_out", "pmc_%s_d64" % tag, "traffic.json"), "%s_d64_pmc_traffic.json" % tag),
+    (os.path.join(root, "gpurun_out", "%s_step_trace_vae.txt" % tag), "%s_step_trace_vae.txt" % tag),
+    (os.path.join(root, "gpurun_out", "%s_step_trace_unet.txt" % tag), "%s_step_trace_unet.txt" % tag),
 ]
 for a, b in pairs:
     if os.path.exists(a):
