@@ -58,6 +58,7 @@ SIGNATURES = {
     "ics_vae_create": (C.c_int, [C.POINTER(VaeConfig), _H, C.POINTER(_H)]),
     "ics_vae_encode": (C.c_int, [_H, _F, _F, _F, C.c_int, _F, _F, _F]),
     "ics_unet_predict_resident": (C.c_int, [_H, C.c_int, C.c_float]),
+    "ics_net_wait_for": (C.c_int, [_H, _H]),
     "ics_net_timer_start": (C.c_int, [_H]),
     "ics_net_timer_stop": (C.c_int, [_H, C.POINTER(C.c_double)]),
     "ics_unet_metric_sums": (C.c_int, [_H, C.POINTER(C.c_double)]),
@@ -118,6 +119,11 @@ def load():
         raise IcsLibraryError(
             "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C icsg3d_amd/csrc`). There is no CPU fallback." % LIB_PATH)
+    # The engines run up to five HIP streams at once in one process (U-Net: compute + RCCL; DFC-VAE: compute + second stream +
+    # RCCL).  The ROCm runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); two of OUR streams on
+    # one queue serialise and the two-stream schedule of the DFC-VAE step loses 10 % instead of gaining 7 % (measured,
+    # DESIGN.md section 10).  Read by the runtime when HIP initialises, i.e. at the first HIP call -- which this library makes.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     try:
         lib = C.CDLL(LIB_PATH, mode=C.RTLD_LOCAL)
     except OSError as e:  # pragma: no cover

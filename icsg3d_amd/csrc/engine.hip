@@ -280,6 +280,7 @@ struct Net {
   double* tap_partial[4] = {nullptr, nullptr, nullptr, nullptr};
   int resident_batch = 0;
   hipEvent_t timer_ev[2] = {nullptr, nullptr};   // ics_net_timer_start / _stop
+  hipEvent_t ev_order = nullptr;                 // ics_net_wait_for
   int last_batch = 0;                 // batch of the most recent forward (activation export)
 
   // VAE specifics
@@ -295,6 +296,7 @@ struct Net {
     if (comm) ncclCommDestroy(comm);
     for (void* p : allocs) (void)hipFree(p);
     for (hipEvent_t e : timer_ev) if (e) (void)hipEventDestroy(e);
+    if (ev_order) (void)hipEventDestroy(ev_order);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
     if (st2) (void)hipStreamDestroy(st2);
@@ -303,12 +305,40 @@ struct Net {
     if (comm_st) (void)hipStreamDestroy(comm_st);
     if (st) (void)hipStreamDestroy(st);
   }
+  // Device memory comes out of a few large slabs per handle (ICSG3D_NO_ARENA=1: one hipMalloc per buffer, as before round
+  // 5): buffers below kArenaBig are carved out of chunks (128 MB, doubling to 1 GB) at 2 MB alignment (256 B for small ones), larger ones get their
+  // own allocation.  A handle's few hundred buffers then sit in a handful of contiguous, large-page-backed ranges whatever
+  // the process allocated or freed before -- see DESIGN.md section 10 (the DFC-VAE's two-stream schedule ran 10 % slower when
+  // its buffers had been allocated one by one after a U-Net training step).
+  static constexpr size_t kArenaChunk = (size_t)1 << 30, kArenaBig = (size_t)1 << 28;
+  char* arena_cur = nullptr;
+  size_t arena_left = 0, arena_next = (size_t)1 << 27;
+  bool arena_on = getenv("ICSG3D_NO_ARENA") == nullptr;
   template <typename T>
   int alloc(T** out, size_t n) {
+    const size_t bytes = n * sizeof(T) + 256;
     void* p = nullptr;
-    ICS_HIP(hipMalloc(&p, n * sizeof(T) + 256));
-    ICS_HIP(hipMemsetAsync(p, 0, n * sizeof(T) + 256, st));
-    allocs.push_back(p);
+    if (!arena_on || bytes >= kArenaBig) {
+      ICS_HIP(hipMalloc(&p, bytes));
+      allocs.push_back(p);
+    } else {
+      const size_t align = bytes >= ((size_t)1 << 21) ? ((size_t)1 << 21) : 256;
+      size_t pad = (align - (reinterpret_cast<uintptr_t>(arena_cur) & (align - 1))) & (align - 1);
+      if (arena_cur == nullptr || pad + bytes > arena_left) {
+        void* c = nullptr;
+        const size_t chunk = std::max(arena_next, bytes);
+        ICS_HIP(hipMalloc(&c, chunk));
+        allocs.push_back(c);
+        arena_cur = static_cast<char*>(c);
+        arena_left = chunk;
+        arena_next = std::min(kArenaChunk, arena_next * 2);
+        pad = 0;
+      }
+      p = arena_cur + pad;
+      arena_cur += pad + bytes;
+      arena_left -= pad + bytes;
+    }
+    ICS_HIP(hipMemsetAsync(p, 0, bytes, st));
     *out = reinterpret_cast<T*>(p);
     return 0;
   }
@@ -2014,6 +2044,10 @@ int ics_device_info(char* name, int* cus, size_t* hbm) {
   return 0;
 }
 
+// A C caller that never goes through icsg3d_amd/_lib.py gets the same default (see there): eight hardware queues, unless the
+// environment already says otherwise.  Runs when the library is loaded; the runtime reads it when HIP initialises.
+__attribute__((constructor)) static void ics_runtime_env_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 static int net_common_init(Net& n) {
   n.flags = conv_flags_from_env();
   ICS_HIP(hipGetDevice(&n.device));
@@ -2275,6 +2309,21 @@ int ics_unet_predict_resident(ics_net* net, int labels_only, float thresh) {
     return unet_head_labels(n, batch, thresh, d_species, d_species + M, n.st);
   }
   return unet_head_loss(n, batch, 0, 0);
+}
+
+// Device-side ordering between two engines of one process (joint U-Net + DFC-VAE training on one GPU): everything enqueued
+// on `other`'s stream so far completes before anything enqueued on `net`'s stream from now on starts.  No host wait.
+int ics_net_wait_for(ics_net* net, ics_net* other) {
+  ICS_CHECK(net && other, "null handle");
+  if (net == other) return 0;
+  Net& a = net->n;
+  Net& b = other->n;
+  ICS_CHECK(a.device == b.device, "engines on different devices");
+  ICS_HIP(hipSetDevice(a.device));
+  if (!b.ev_order) ICS_HIP(hipEventCreateWithFlags(&b.ev_order, hipEventDisableTiming));
+  ICS_HIP(hipEventRecord(b.ev_order, b.st));
+  ICS_HIP(hipStreamWaitEvent(a.st, b.ev_order, 0));
+  return 0;
 }
 
 // Device-clock bracket on the engine's stream (bench.py's gpu_active_s): start records an event, stop records a second

@@ -82,6 +82,8 @@ static int run(int d, int C, int B, int with_comm) {
     OK(ics_unet_predict(unet, x, b, soft, sig));
     OK(ics_unet_predict_labels(unet, x, b, 0.8f, sp, mk));
     OK(ics_vae_train_step(vae, x, cond, eps, b, mv));
+    OK(ics_net_wait_for(unet, vae));
+    OK(ics_net_wait_for(vae, unet));
     OK(ics_vae_test_step(vae, x, cond, eps, b, mv));
     OK(ics_vae_encode(vae, x, cond, eps, b, z, z + (size_t)B * 256, z + (size_t)B * 512));
     OK(ics_vae_decode(vae, z, cond, b, rec));

@@ -112,6 +112,10 @@ class _Net:
     def sync(self):
         L.check(self._lib.ics_net_sync(self._h))
 
+    def wait_for(self, other):
+        """device-side: what `other` has enqueued so far finishes before what this engine enqueues next starts"""
+        L.check(self._lib.ics_net_wait_for(self._h, other._h))
+
     def timer_start(self):
         L.check(self._lib.ics_net_timer_start(self._h))
 

@@ -202,7 +202,8 @@ def test_bce_from_logits_switch_on_the_device(fused):
     np.testing.assert_allclose(m_c[2], ref_c, rtol=5e-3)
     np.testing.assert_allclose(m_l[1], m_c[1], rtol=1e-7)            # the softmax head does not care
     g_l = R.bce_logits_bwd(t, z64, np.full(M, 1.0 / M))[:, 0]
-    np.testing.assert_allclose(dz_l[:, NC], g_l, rtol=2e-5, atol=1e-9 / M)
+    # (tensor-relative: sigmoid(z) - t of a nearly-right confident voxel is a difference of two fp32 numbers close to 1)
+    assert np.abs(dz_l[:, NC] - g_l).max() <= 1e-6 * np.abs(g_l).max()
     assert np.all(dz_c[:40, NC] == 0) and np.all(np.abs(dz_l[:40, NC] * M) > 0.99)     # clip kink vs |sigmoid - t| ~ 1
     np.testing.assert_array_equal(dz_l[:, :NC], dz_c[:, :NC])
 
