@@ -491,13 +491,13 @@ def main():
         if use_dist:
             init_engine_comm(vae, dist, rank, world, sync_bn=args.sync_bn, force=force)
         if args.workload == "joint":
-            # the two engines own a stream each; left alone they share the chip and BOTH slow down (measured with one
-            # hardware queue per stream: 35.0 ms against 27.9 + 5.4 one after the other), so the steps are chained on the
-            # device (ics_net_wait_for: an event, no host wait)
+            # the two engines would own a stream each and, left alone, share the chip -- BOTH slow down (35.0 ms per pair
+            # against 27.9 + 5.4 one after the other); chaining the streams with events costs more still (40.9).  The VAE
+            # engine enqueues on the U-Net engine's stream instead: the steps alternate in program order.
+            vae.share_stream(unet)
+
             def step():
-                unet.wait_for(vae)
                 unet.train_step_resident(False)
-                vae.wait_for(unet)
                 vae.train_step_resident(False)
             engines, profiled = [unet, vae], [unet, vae, pm]
 

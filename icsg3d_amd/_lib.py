@@ -58,7 +58,7 @@ SIGNATURES = {
     "ics_vae_create": (C.c_int, [C.POINTER(VaeConfig), _H, C.POINTER(_H)]),
     "ics_vae_encode": (C.c_int, [_H, _F, _F, _F, C.c_int, _F, _F, _F]),
     "ics_unet_predict_resident": (C.c_int, [_H, C.c_int, C.c_float]),
-    "ics_net_wait_for": (C.c_int, [_H, _H]),
+    "ics_net_share_stream": (C.c_int, [_H, _H]),
     "ics_net_timer_start": (C.c_int, [_H]),
     "ics_net_timer_stop": (C.c_int, [_H, C.POINTER(C.c_double)]),
     "ics_unet_metric_sums": (C.c_int, [_H, C.POINTER(C.c_double)]),

@@ -68,6 +68,7 @@ static int run(int d, int C, int B, int with_comm) {
   float* z = (float*)calloc((size_t)B * 256 * 3, sizeof(float));
   float* rec = (float*)malloc(M * C * sizeof(float));
   float mm[5], mv[4], minmax[6 * 8];
+  { ics_net* v2 = NULL; OK(ics_vae_create(&vc, unet, &v2)); OK(ics_net_share_stream(v2, unet)); OK(ics_net_destroy(v2)); }
   OK(ics_net_profile_enable(unet, 1));
   OK(ics_net_profile_enable(vae, 1));
   for (int b = 1; b <= B; ++b) {   /* every batch size up to max_batch: the split plans depend on it */
@@ -82,8 +83,6 @@ static int run(int d, int C, int B, int with_comm) {
     OK(ics_unet_predict(unet, x, b, soft, sig));
     OK(ics_unet_predict_labels(unet, x, b, 0.8f, sp, mk));
     OK(ics_vae_train_step(vae, x, cond, eps, b, mv));
-    OK(ics_net_wait_for(unet, vae));
-    OK(ics_net_wait_for(vae, unet));
     OK(ics_vae_test_step(vae, x, cond, eps, b, mv));
     OK(ics_vae_encode(vae, x, cond, eps, b, z, z + (size_t)B * 256, z + (size_t)B * 512));
     OK(ics_vae_decode(vae, z, cond, b, rec));

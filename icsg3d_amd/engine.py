@@ -112,9 +112,10 @@ class _Net:
     def sync(self):
         L.check(self._lib.ics_net_sync(self._h))
 
-    def wait_for(self, other):
-        """device-side: what `other` has enqueued so far finishes before what this engine enqueues next starts"""
-        L.check(self._lib.ics_net_wait_for(self._h, other._h))
+    def share_stream(self, other):
+        """enqueue on `other`'s stream from now on (joint training of two engines on one GPU: steps alternate in order)"""
+        L.check(self._lib.ics_net_share_stream(self._h, other._h))
+        self._stream_owner = other          # keep it alive
 
     def timer_start(self):
         L.check(self._lib.ics_net_timer_start(self._h))

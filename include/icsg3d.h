@@ -213,10 +213,10 @@ int ics_net_set_optimizer_state(ics_net* net, const float* m, const float* v, si
 
 /* Per-kernel timing with HIP events on the engine's stream (bench.py roofline): enable, run steps,
  * then read back rows {label, launches, total_ms, total_flop, total_bytes}. */
-/* Device-side ordering between two engines of one process (each owns its stream): what `other` has enqueued so far finishes
- * before what `net` enqueues from now on starts; no host wait.  New (the reference trains its two nets in separate runs):
- * joint U-Net + DFC-VAE training on one GPU alternates the two steps with it instead of letting them share the chip. */
-int ics_net_wait_for(ics_net* net, ics_net* other);
+/* Two engines of one process on ONE stream: `net` enqueues on `other`'s stream from now on (its own is kept for destruction),
+ * so their steps alternate in program order with no events and no host waits.  New (the reference trains its two nets in
+ * separate runs): joint U-Net + DFC-VAE training on one GPU.  `other` must outlive `net`'s use of it. */
+int ics_net_share_stream(ics_net* net, ics_net* other);
 /* Device-clock bracket on the engine's stream: start records an event; stop records another, waits for it and returns the
  * milliseconds between them (bench.py's gpu_active_s, the self-check of ms_per_step). */
 int ics_net_timer_start(ics_net* net);
