@@ -1,5 +1,6 @@
 cd $GRAFT_REPO_ROOT
-for env in "GPU_MAX_HW_QUEUES=4" "GPU_MAX_HW_QUEUES=8" "GPU_MAX_HW_QUEUES=8 ICSG3D_NO_PM_SIDE=1 ICSG3D_NO_VAE_SIDE_WGRAD=1" "GPU_MAX_HW_QUEUES=4 ICSG3D_NO_PM_SIDE=1 ICSG3D_NO_VAE_SIDE_WGRAD=1" "GPU_MAX_HW_QUEUES=16"; do
-  echo "== env: $env"
-  env $env python bench.py --workload joint --no-cpu-baseline 2>/dev/null | python -c "import json,sys; o=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('joint', o['ms_per_step'], o['value'])"
+for k in none 30 28 26 24 20 16; do
+  if [ $k = none ]; then e=""; else e="ICSG3D_PM_SIDE_CUS=$k"; fi
+  echo "== $e"
+  env $e python scripts/quick_bench_vae.py 32 32 30 2>&1 | sed -n 2,2p
 done

@@ -56,6 +56,41 @@ def main():
             ref.close()
         eng.close()
         dist.barrier()
+    # ---- DFC-VAE: the same two statements for the second engine (its step runs on two streams; under SyncBN the perceptual
+    # pass stays on the main stream; the gradient buckets wait for the side stream's weight gradients)
+    from icsg3d_amd.engine import VaeEngine
+    from icsg3d_amd.synthetic import vae_param_shapes
+    PV = glorot_params(vae_param_shapes(1, d=d), 3)
+    Xv, _, cond = synthetic_batch(B * world, d, 1, seed=1, noise=1e-3)
+    eps = np.random.default_rng(2).standard_normal((B * world, 256)).astype(np.float32)
+    for sync_bn in (True, False):
+        pm = UnetEngine(in_channels=1, d=d, max_batch=B)
+        pm.set_weights(P)
+        ve = VaeEngine(pm, in_channels=1, d=d, max_batch=B, lr=5e-4)
+        ve.set_weights(PV if rank == 0 else glorot_params(vae_param_shapes(1, d=d), 78))
+        init_engine_comm(ve, dist, rank, world, sync_bn=sync_bn)
+        m = [ve.train_step(Xv[lo:lo + B], cond[lo:lo + B], eps[lo:lo + B]) for _ in range(2)]
+        w = ve.get_weights()
+        g = {n: ve.get_grad(n, s) for n, s, tr in ve.tensor_infos() if tr}
+        for k in sorted(w):
+            box = [None] * world
+            dist.all_gather_object(box, np.ascontiguousarray(w[k]).tobytes())
+            assert all(b == box[0] for b in box), "VAE replicas diverged in %s (sync_bn=%s)" % (k, sync_bn)
+        if rank == 0 and sync_bn:
+            pmr = UnetEngine(in_channels=1, d=d, max_batch=B * world)
+            pmr.set_weights(P)
+            ref = VaeEngine(pmr, in_channels=1, d=d, max_batch=B * world, lr=5e-4)
+            ref.set_weights(PV)
+            mr = [ref.train_step(Xv, cond, eps) for _ in range(2)]
+            gr = {n: ref.get_grad(n, s) for n, s, tr in ref.tensor_infos() if tr}
+            gs = max(float(np.abs(v).max()) for v in gr.values())
+            out["vae_sync_bn"] = {
+                "metrics_err": max(float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-12)) for a, b in zip(m, mr)),
+                # (conv biases in front of BatchNorm have an exactly-zero true gradient: their own scale is rounding noise)
+                "grad_err": max(float(np.abs(g[k] - gr[k]).max() / max(np.abs(gr[k]).max(), 1e-4 * gs)) for k in g)}
+            ref.close(); pmr.close()
+        ve.close(); pm.close()
+        dist.barrier()
     if rank == 0:
         print("DP2_RESULT " + json.dumps(out))
     dist.destroy_process_group()
