@@ -24,7 +24,7 @@ def test_decode_to_unet_labels_matches_two_step_path_and_oracle():
             o.S[k] = rng.uniform(0.5, 1.5, o.S[k].shape) if k.endswith("var") else rng.uniform(-0.2, 0.2, o.S[k].shape)
     z = rng.standard_normal((B, 256))
     cond = np.eye(10)[[1, 4, 7]]
-    # a confident segmentation head (tests/saturated.py): with Glorot heads sig never reaches 0.8 and the mask comparison
+    # a confident segmentation head (oracle/confident_head.py): with Glorot heads sig never reaches 0.8 and the mask comparison
     # below would be all-zeros == all-zeros.  Pseudo-labels: the densest 3 % of each decoded grid.
     rec0 = vo.predict_decoder(z, cond)
     dens = rec0[..., 0]

@@ -117,7 +117,7 @@ def test_config0_predict_on_exactly_16_grids():
     B, d = 16, 32
     uo = R.UnetOracle(in_ch=1, seed=1)
     X, lab, _ = synthetic_batch(B, d, 1, seed=0, noise=1e-3)
-    # a confident head fitted on the two oracle-checked grids (tests/saturated.py): argmax, f1 / wr and the 0.8 mask are then
+    # a confident head fitted on the two oracle-checked grids (oracle/confident_head.py): argmax, f1 / wr and the 0.8 mask are then
     # compared at non-trivial values instead of 0 == 0
     saturate_head(uo, X[[0, 15]].astype(np.float64), lab[[0, 15]], training=False)
     eng = UnetEngine(in_channels=1, d=d, max_batch=B)

@@ -3,7 +3,7 @@ counts, round-half-even at p = 0.5 and the 0.8 mask, at values that are NOT zero
 
 Expected values: (1) the reference's own formulas (unet/unet.py:159-221) evaluated on seeded (labels, p) --
 tests/golden/loss_golden.npz, "reference formulas, stand-in backend"; (2) the fp64 oracle on a confident head
-(tests/saturated.py).  Everything goes through the C ABI."""
+(oracle/confident_head.py).  Everything goes through the C ABI."""
 import os
 
 import numpy as np
