@@ -56,19 +56,23 @@ def cpu_baseline(batch=32, d=32):
             "v,c,s = T.time_unet_train_step(B=%d, d=%d, in_ch=1, steps=1, warmup=0); "
             "vv,c,sv = T.time_vae_train_step(B=%d, d=%d, in_ch=1, steps=1, warmup=0); "
             "vp,c,sp = T.time_unet_predict(B=16, d=%d, in_ch=1, steps=1, warmup=0); "
-            "print(json.dumps({'v': v, 's': s, 'vv': vv, 'sv': sv, 'vp': vp, 'sp': sp, 'cores': c}))"
-            % (ROOT, d, batch, d, batch, d, d))
+            "vg,c,sg = T.time_generate_tail(B=%d, d=%d, in_ch=1); "
+            "print(json.dumps({'v': v, 's': s, 'vv': vv, 'sv': sv, 'vp': vp, 'sp': sp, 'vg': vg, 'sg': sg, 'cores': c}))"
+            % (ROOT, d, batch, d, batch, d, d, batch, d))
     try:
         out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
         r = json.loads(out.stdout.strip().splitlines()[-1])
         return {"value": round(r["v"], 4), "unit": "voxel-grids/s", "cores": int(r["cores"]), "kind": "port",
                 "vae": {"value": round(r["vv"], 4), "unit": "voxel-grids/s", "s_per_step": round(r["sv"], 2)},
                 "predict": {"value": round(r["vp"], 4), "unit": "voxel-grids/s", "s_per_call": round(r["sp"], 2)},
+                "generate": {"value": round(r["vg"], 4), "unit": "voxel-grids/s", "s_per_call": round(r["sg"], 2)},
                 "sample": "oracle/torch_ref.py fp32, torch-CPU channels_last_3d, all host cores: one untimed warm-up step "
                           "at 8 grids, then ONE timed U-Net fwd+bwd+Adam step on %d synthetic %d^3 grids (%.1f s; `value`, "
-                          "the batch the GPU figure is quoted on), ONE timed DFC-VAE train step on %d grids (%.1f s; `vae`) "
-                          "and ONE timed U-Net forward on 16 grids (%.1f s; `predict`, BASELINE configs[0]).  The "
-                          "reference's Keras/TF path is not installable here" % (batch, d, r["s"], batch, r["sv"], r["sp"])}
+                          "the batch the GPU figure is quoted on), ONE timed DFC-VAE train step on %d grids (%.1f s; `vae`), "
+                          "ONE timed U-Net forward on 16 grids (%.1f s; `predict`, BASELINE configs[0]) and ONE generate tail on "
+                          "%d latent vectors (decoder + U-Net forward + argmax / threshold + scipy.ndimage components, %.1f s; "
+                          "`generate`).  The reference's Keras/TF path is not installable here"
+                          % (batch, d, r["s"], batch, r["sv"], r["sp"], batch, r["sg"])}
     except Exception as e:  # pragma: no cover
         return {"value": None, "unit": "voxel-grids/s", "cores": os.cpu_count(), "kind": "port",
                 "sample": "cpu baseline failed: %s" % e}
@@ -474,7 +478,7 @@ def main():
         out["ms_per_step"] = out["ms_per_call"]
         if not args.no_cpu_baseline:
             cb = cpu_baseline(B, d)
-            out["cpu_baseline"] = {"value": cb.get("predict", {}).get("value"), "unit": "voxel-grids/s", "cores": cb["cores"],
+            out["cpu_baseline"] = {"value": cb.get(args.workload, {}).get("value"), "unit": "voxel-grids/s", "cores": cb["cores"],
                                    "kind": "port", "sample": cb["sample"]}
         else:
             out["cpu_baseline"] = None
@@ -574,6 +578,7 @@ def main():
                 out["secondary"]["cpu_baseline"] = out["cpu_baseline"]["vae"]
             if "inference" in out and out["cpu_baseline"].get("predict"):
                 out["inference"]["predict"]["cpu_baseline"] = out["cpu_baseline"]["predict"]
+                out["inference"]["generate"]["cpu_baseline"] = out["cpu_baseline"].get("generate")
         line = json.dumps(out) + "\n"
         if json_fd is not None:
             sys.stdout.flush()

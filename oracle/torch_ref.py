@@ -313,3 +313,38 @@ def time_unet_predict(B=16, d=32, in_ch=1, steps=1, warmup=0, threads=None):
                 times.append(dt)
     sec = float(np.mean(times))
     return B / sec, threads, sec
+
+
+def time_generate_tail(B=32, d=32, in_ch=1, threads=None):
+    """fp32 torch-CPU generate.py:204-236 tail on B synthetic latent vectors: decoder forward -> U-Net forward (eval BN) ->
+    argmax / threshold -> connected components (> 3 voxels) -> majority vote + centroids (oracle/watershed_ref.py's
+    scipy.ndimage-based convex-branch pass, one sample at a time as the reference does).  The threshold is the 90 %
+    quantile of the sigmoid output, as in bench.py's GPU block (random weights never reach 0.8).
+    Returns (grids_per_s, threads, secs/call)."""
+    import time
+    from . import numpy_ref as R
+    from . import watershed_ref as W
+    if threads:
+        torch.set_num_threads(threads)
+    threads = torch.get_num_threads()
+    ush, vsh = R.unet_param_shapes(in_ch, 95), R.vae_param_shapes(in_ch, d=d)
+    pu = Params(R.init_params(ush, 1, np.float32), R.init_bn_state(ush, np.float32), torch.float32, requires_grad=False)
+    pv = Params(R.init_params(vsh, 3, np.float32), R.init_bn_state(vsh, np.float32), torch.float32, requires_grad=False)
+    for p in (pu, pv):
+        for k, t in list(p.t.items()):
+            if t.ndim == 5:
+                p.t[k] = t.detach().contiguous(memory_format=torch.channels_last_3d)
+    rng = np.random.default_rng(7)
+    z = torch.as_tensor(rng.standard_normal((B, 256)), dtype=torch.float32)
+    cond = torch.as_tensor(np.eye(10, dtype=np.float32)[np.arange(B) % 10])
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        rec = vae_decode(z, cond, pv, False, d)
+        soft, sig = unet_forward(rec.contiguous(memory_format=torch.channels_last_3d), pu, False, "first")
+        species = soft.argmax(1).numpy().astype(np.uint8)
+        sg = sig[:, 0].numpy()
+        mask = (sg >= np.quantile(sg, 0.9)).astype(np.uint8)
+        for b in range(B):
+            W.watershed_clustering_convex(species[b], mask[b])
+        sec = time.perf_counter() - t0
+    return B / sec, threads, sec
