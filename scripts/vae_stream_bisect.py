@@ -1,4 +1,8 @@
-"""Developer probe: the DFC-VAE step after a U-Net training phase in the same process (bench.py's contract order)."""
+"""Developer probe (round 5): the DFC-VAE step after a U-Net training phase in the same process
+(bench.py's contract order) ran 10 % slower than in a fresh process under the two-stream schedule.  Modes a..g bisect it
+(profiling first / plain steps first / separate perceptual engine / metrics read-back / predict first / tap buffers
+allocated early / serial schedule); the cause was two of the library's streams sharing one of the runtime's four default
+hardware queues (GPU_MAX_HW_QUEUES=8 python scripts/vae_stream_bisect.py b  is fast).  usage: vae_stream_bisect.py <mode>"""
 import sys, time, numpy as np
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from icsg3d_amd.engine import UnetEngine, VaeEngine
