@@ -1,7 +1,7 @@
 #!/bin/bash
 # On a multi-GPU MI355X node, from the repo root: the weak-scaling curve of the contract line at N = 1, 2, 4, 8 (32 grids per
-# GPU; `python bench.py --gpus N` starts its own ranks), the two-rank parity test, and a kernel trace of one 2-rank run that
-# shows the RCCL buckets on the communication stream next to the backward kernels.  Nothing here has run yet: every box this
+# GPU; `python bench.py --gpus N` starts its own ranks), the two-rank parity test, and the per-launch-site rows of a 2-rank run
+# (the RCCL buckets on the communication stream next to the backward kernels).  Nothing here has run yet: every box this
 # repository has seen had ONE GPU.  Outputs -> gpurun_out/scale_<tag>/; copy scale.json and the trace summary into profiles/.
 TAG=${1:-r6}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -36,9 +36,8 @@ for key, r in rows.items():
 json.dump(rows, open(os.path.join(out, "scale.json"), "w"), indent=1)
 print(json.dumps(rows, indent=1))
 PY
+# (No rocprofv3 around the launcher: a profiled process that has initialised the GPU must not exec its ranks.  The engine's own
+# profiler rows carry the RCCL buckets -- "rccl_allreduce_grads", HIP events on the communication stream: bench.py --dump-rows.)
 if [ 2 -le $NG ]; then
-  cd /tmp && export TMPDIR=/tmp
-  rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof_n2 -o prof -- python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
-    --master-addr 127.0.0.1 --master-port 29611 $ROOT/bench.py --gpus 2 --steps 6 --warmup 2 --no-cpu-baseline --no-secondary --no-inference > $OUT/prof_n2.log 2>&1
-  find $OUT -name "*kernel_trace.csv" -size +64M -delete
+  python bench.py --gpus 2 --no-cpu-baseline --no-secondary --no-inference --dump-rows $OUT/rows_n2.jsonl > $OUT/bench_rows_n2.json 2> $OUT/bench_rows_n2.err
 fi
