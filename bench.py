@@ -448,6 +448,21 @@ def main():
         flop = (125.886e9 + 1.62e9) * scale * Bg                        # U-Net fwd + decoder fwd per grid
         ex = dom["flop"] * wino(dom_name) / (dom["ms"] * 1e-3) / 1e12
         out_g = res["out"]
+        # what generate.py does next on the host (icsg3d_amd/watershed.refine_atoms): the convexity test of every kept
+        # component (an exact 26-direction bound first, Qhull only where that is inconclusive) and, for the samples with
+        # a non-convex component, the recursive marker watershed (device flood, host recursion).  Timed once, untimed warm-up.
+        from icsg3d_amd.watershed import refine_atoms
+        refine_atoms(gvae.decode_to_atoms(eng, z, cnd, thresh=thr, max_atoms=4096, want_regions=True), degenerate="solid")
+        t0 = time.perf_counter()
+        out_r = gvae.decode_to_atoms(eng, z, cnd, thresh=thr, max_atoms=4096, want_regions=True)
+        t1 = time.perf_counter()
+        refine_atoms(out_r, degenerate="solid")
+        t2 = time.perf_counter()
+        refine = {"device_call_with_regions_ms": round((t1 - t0) * 1e3, 2), "host_refine_ms": round((t2 - t1) * 1e3, 2),
+                  "samples_split": int(out_r["split"].sum()), "components_tested": int(out_r["n_atoms"].sum()),
+                  "end_to_end_grids_per_s": round(Bg / (t2 - t0), 1),
+                  "note": "random-weight masks: degenerate='solid' so that flat fragments do not fail the sample (the "
+                          "reference stack would skip it, generate.py:246-248)"}
         gvae.close()
         return {"workload": "generate.py:204-236 tail: decoder -> U-Net -> argmax / threshold -> components -> atoms, "
                             "%d x %d^3 x 1 grids per call; host <-> device copies of the call included" % (Bg, d),
@@ -456,6 +471,7 @@ def main():
                 "threshold": round(thr, 4), "mask_fraction": round(float(out_g["mask"].mean()), 4),
                 "atoms_per_grid": round(float(np.mean(out_g["n_atoms"])), 1),
                 "components_per_grid": round(float(np.mean(out_g["n_components"])), 1),
+                "refine": refine,
                 "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": round(ex, 2), "peak": PEAK_FP32_TFLOPS,
                              "unit": "TFLOP/s", "frac": round(ex / PEAK_FP32_TFLOPS, 4), "traffic": None},
                 "roofline_call": {"executed_tflop_per_call": round(exec_flop / 1e12, 3),

@@ -71,6 +71,7 @@ SIGNATURES = {
     "ics_vae_decode_to_unet_atoms": (C.c_int, [_H, _H, _F, _F, C.c_int, C.c_float, C.c_int, C.c_int, _U8, _U8, _F, _F,
                                                _I32, _I32, _I32]),
     "ics_op_segment_atoms": (C.c_int, [_U8, _U8, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _I32, _I32, _I32]),
+    "ics_release_caches": (C.c_int, []),
     "ics_op_label_boxes": (C.c_int, [_I32, _I32, C.c_int, C.c_int, C.c_int, _I32, _I32, _I32]),
     "ics_op_watershed_split": (C.c_int, [_I32, _I32, _I32, C.c_int, C.c_int, _I32]),
     "ics_op_region_stats": (C.c_int, [_I32, _U8, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _I32]),

@@ -2579,22 +2579,48 @@ int ics_op_segment_atoms(const uint8_t* mask, const uint8_t* species, int batch,
   return segment_to_host(n, dm, ds, batch, d, min_voxels, max_atoms, num_species, regions, counts, atom_stats);
 }
 
+// The three box-level entry points run tens of times per sample from the host recursion of segment_nuclei
+// (icsg3d_amd/watershed.py): one stream per host thread, created on first use and kept (a handle with two streams, two
+// events and its own allocations per call cost 10 - 16 ms against kernels of tens of microseconds).
+namespace {
+struct OpStream { hipStream_t st = nullptr; int device = -1; };
+thread_local OpStream tl_op_stream;
+int op_stream(hipStream_t* out) {
+  int dev = 0;
+  ICS_HIP(hipGetDevice(&dev));
+  if (tl_op_stream.st == nullptr || tl_op_stream.device != dev) {
+    if (tl_op_stream.st) (void)hipStreamDestroy(tl_op_stream.st);
+    tl_op_stream.st = nullptr;
+    ICS_HIP(hipStreamCreateWithFlags(&tl_op_stream.st, hipStreamNonBlocking));
+    tl_op_stream.device = dev;
+  }
+  *out = tl_op_stream.st;
+  return 0;
+}
+}  // namespace
+int ics_release_caches() {
+  if (tl_op_stream.st) { (void)hipStreamSynchronize(tl_op_stream.st); (void)hipStreamDestroy(tl_op_stream.st); }
+  tl_op_stream = OpStream{};
+  segment_release_scratch();
+  return 0;
+}
+
 int ics_op_label_boxes(const int32_t* vols, const int32_t* dims, int nbox, int connectivity, int max_labels,
                        int32_t* labels, int32_t* nlabels, int32_t* stats) {
-  Net n;
-  ICS_TRY(net_common_init(n));
-  return segment_label_boxes(n.st, vols, dims, nbox, connectivity, max_labels, labels, nlabels, stats);
+  hipStream_t st;
+  ICS_TRY(op_stream(&st));
+  return segment_label_boxes(st, vols, dims, nbox, connectivity, max_labels, labels, nlabels, stats);
 }
 int ics_op_region_stats(const int32_t* R, const uint8_t* species, int D, int H, int W, int num_labels, int num_species,
                         int32_t* stats) {
-  Net n;
-  ICS_TRY(net_common_init(n));
-  return segment_region_stats(n.st, R, species, D, H, W, num_labels, num_species, stats);
+  hipStream_t st;
+  ICS_TRY(op_stream(&st));
+  return segment_region_stats(st, R, species, D, H, W, num_labels, num_species, stats);
 }
 int ics_op_watershed_split(const int32_t* boxes, const int32_t* dims, const int32_t* cls, int nbox, int tie, int32_t* wss) {
-  Net n;
-  ICS_TRY(net_common_init(n));
-  return segment_watershed_split(n.st, boxes, dims, cls, nbox, tie, wss);
+  hipStream_t st;
+  ICS_TRY(op_stream(&st));
+  return segment_watershed_split(st, boxes, dims, cls, nbox, tie, wss);
 }
 
 // ---------------------------------------------------------------- data parallel

@@ -31,4 +31,7 @@ int segment_region_stats(hipStream_t st, const int* h_R, const unsigned char* h_
 int segment_watershed_split(hipStream_t st, const int* h_boxes, const int* h_dims, const int* h_cls, int nbox, int tie,
                             int* h_wss);
 
+// frees the calling thread's grow-only scratch of the three box-level entry points above
+void segment_release_scratch();
+
 }  // namespace ics

@@ -465,6 +465,32 @@ static int box_descs(const int* dims, const int* cls, int nbox, std::vector<BoxD
   return 0;
 }
 
+// The box-level entry points are called once per recursion level of segment_nuclei -- tens of times per sample, a few tens of
+// KB each.  A hipMalloc / hipFree pair per call (the free synchronises the device) cost more than the kernels: the scratch
+// is a grow-only buffer per host thread, released by segment_release_scratch() (ics_release_caches) or with the process.
+namespace {
+struct Scratch { unsigned char* p = nullptr; size_t cap = 0; int device = -1; };
+thread_local Scratch tl_scratch;
+int scratch_get(size_t bytes, unsigned char** out) {
+  int dev = 0;
+  ICS_HIP(hipGetDevice(&dev));
+  Scratch& s = tl_scratch;
+  if (s.p == nullptr || s.cap < bytes || s.device != dev) {
+    if (s.p) (void)hipFree(s.p);
+    s.p = nullptr; s.cap = 0;
+    const size_t want = std::max(bytes + bytes / 2, (size_t)1 << 20);
+    ICS_HIP(hipMalloc(reinterpret_cast<void**>(&s.p), want));
+    s.cap = want; s.device = dev;
+  }
+  *out = s.p;
+  return 0;
+}
+}  // namespace
+void segment_release_scratch() {
+  if (tl_scratch.p) (void)hipFree(tl_scratch.p);
+  tl_scratch = Scratch{};
+}
+
 int segment_label_boxes(hipStream_t st, const int* h_vols, const int* h_dims, int nbox, int connectivity, int max_labels,
                         int* h_labels, int* h_nlabels, int* h_stats) {
   ICS_CHECK(h_vols && h_dims && h_labels && h_nlabels && nbox >= 1 && max_labels >= 1, "bad label_boxes arguments");
@@ -476,7 +502,7 @@ int segment_label_boxes(hipStream_t st, const int* h_vols, const int* h_dims, in
   const size_t b_vol = total * 4, b_desc = (size_t)nbox * sizeof(BoxDesc), b_n = (size_t)nbox * 4,
                b_st = (size_t)nbox * max_labels * 7 * 4;
   auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-  ICS_HIP(hipMalloc(reinterpret_cast<void**>(&buf), up(b_vol) * 2 + up(b_desc) + up(b_n) + up(b_st)));
+  ICS_TRY(scratch_get(up(b_vol) * 2 + up(b_desc) + up(b_n) + up(b_st), &buf));
   int* d_vol = reinterpret_cast<int*>(buf);
   int* d_lab = reinterpret_cast<int*>(buf + up(b_vol));
   BoxDesc* d_desc = reinterpret_cast<BoxDesc*>(buf + 2 * up(b_vol));
@@ -493,7 +519,6 @@ int segment_label_boxes(hipStream_t st, const int* h_vols, const int* h_dims, in
   if (e == hipSuccess) e = hipMemcpyAsync(h_nlabels, d_n, b_n, hipMemcpyDeviceToHost, st);
   if (e == hipSuccess && h_stats) e = hipMemcpyAsync(h_stats, d_st, b_st, hipMemcpyDeviceToHost, st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
-  (void)hipFree(buf);
   if (e != hipSuccess) { set_error(std::string("label_boxes: ") + hipGetErrorString(e)); return -1; }
   return 0;
 }
@@ -507,7 +532,7 @@ int segment_region_stats(hipStream_t st, const int* h_R, const unsigned char* h_
   auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
   const size_t b_R = V * 4, b_sp = V, b_st = (size_t)nlab * kSegStatInts * 4, b_h = (size_t)nlab * nbins * 4;
   unsigned char* buf = nullptr;
-  ICS_HIP(hipMalloc(reinterpret_cast<void**>(&buf), up(b_R) + up(b_sp) + up(b_st) + up(b_h)));
+  ICS_TRY(scratch_get(up(b_R) + up(b_sp) + up(b_st) + up(b_h), &buf));
   int* d_R = reinterpret_cast<int*>(buf);
   unsigned char* d_sp = buf + up(b_R);
   int* d_st = reinterpret_cast<int*>(buf + up(b_R) + up(b_sp));
@@ -525,7 +550,6 @@ int segment_region_stats(hipStream_t st, const int* h_R, const unsigned char* h_
   }
   if (e == hipSuccess) e = hipMemcpyAsync(h_stats, d_st, b_st, hipMemcpyDeviceToHost, st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
-  (void)hipFree(buf);
   if (e != hipSuccess) { set_error(std::string("region_stats: ") + hipGetErrorString(e)); return -1; }
   return 0;
 }
@@ -540,7 +564,7 @@ int segment_watershed_split(hipStream_t st, const int* h_boxes, const int* h_dim
   auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
   const size_t b_vol = total * 4, b_desc = (size_t)nbox * sizeof(BoxDesc);
   // work: 4 ints per voxel (BoxDesc::heap_off * 2 with room to spare), heap: 2 unsigned per voxel
-  ICS_HIP(hipMalloc(reinterpret_cast<void**>(&buf), up(b_vol) * 2 + up(b_desc) + up(b_vol * 4) + up(b_vol * 2)));
+  ICS_TRY(scratch_get(up(b_vol) * 2 + up(b_desc) + up(b_vol * 4) + up(b_vol * 2), &buf));
   int* d_box = reinterpret_cast<int*>(buf);
   int* d_out = reinterpret_cast<int*>(buf + up(b_vol));
   BoxDesc* d_desc = reinterpret_cast<BoxDesc*>(buf + 2 * up(b_vol));
@@ -554,7 +578,6 @@ int segment_watershed_split(hipStream_t st, const int* h_boxes, const int* h_dim
   }
   if (e == hipSuccess) e = hipMemcpyAsync(h_wss, d_out, b_vol, hipMemcpyDeviceToHost, st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
-  (void)hipFree(buf);
   if (e != hipSuccess) { set_error(std::string("watershed_split: ") + hipGetErrorString(e)); return -1; }
   return 0;
 }

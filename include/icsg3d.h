@@ -168,6 +168,9 @@ int ics_op_segment_atoms(const uint8_t* mask, const uint8_t* species, int batch,
 int ics_op_label_boxes(const int32_t* vols, const int32_t* dims, int nbox, int connectivity, int max_labels,
                        int32_t* labels, int32_t* nlabels, int32_t* stats);
 int ics_op_watershed_split(const int32_t* boxes, const int32_t* dims, const int32_t* cls, int nbox, int tie, int32_t* wss);
+/* The three box-level entry points below keep one stream and one grow-only device scratch buffer per host thread (they are
+ * called tens of times per sample from the host recursion of segment_nuclei); this releases the calling thread's. */
+int ics_release_caches(void);
 /* centroids / majority_vote (watershed.py:153-187) for an arbitrary region volume R [D][H][W] (labels 1..num_labels, e.g.
  * what segment_nuclei returns after splits): stats [num_labels][11] as ics_op_segment_atoms; labels that do not occur
  * keep voxels = 0.  Pinned by the reference's own two functions (tests/golden/watershed_golden.npz). */

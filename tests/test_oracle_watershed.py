@@ -176,3 +176,54 @@ def test_product_convexity_test_matches_oracle_hull():
         specs = [((rng.integers(4, 12), rng.integers(4, 12), rng.integers(4, 12)), rng.integers(2, 5)) for _ in range(2)]
         box = _balls(16, specs)
         assert convex_hull_volume(box) == np.count_nonzero(W.convex_hull_image(box))
+
+
+def test_convexity_prefilter_decides_exactly_like_the_hull():
+    """icsg3d_amd.watershed.convexity_at_least: the flat test (exact integers) fails exactly the sets Qhull refuses, the
+    26-direction polytope never counts fewer grid points than the hull, and the decision `convexity >= threshold` is the
+    hull's for every threshold -- on balls, unions of balls, random subsets and thin / flat sets -- no GPU needed."""
+    from scipy.spatial import QhullError
+    from icsg3d_amd.watershed import DegenerateComponent, convexity_at_least, dop_count, is_flat
+    rng = np.random.default_rng(21)
+    cases = []
+    for _ in range(30):
+        specs = [((rng.integers(3, 9), rng.integers(3, 9), rng.integers(3, 9)), rng.integers(1, 4)) for _ in range(rng.integers(1, 4))]
+        cases.append(_balls(12, specs))
+    for _ in range(30):                                   # sparse random subsets: ragged, mostly non-convex
+        dims = tuple(int(v) for v in rng.integers(2, 7, size=3))
+        cases.append((rng.uniform(size=dims) < rng.uniform(0.2, 0.9)).astype(np.int32))
+    for _ in range(20):                                   # plates, lines, L-shapes in a plane, two parallel layers
+        a = np.zeros((5, 6, 6), np.int32)
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            a[2, 1:rng.integers(3, 6), 1:rng.integers(3, 6)] = 1
+        elif kind == 1:
+            a[2, 2, 1:rng.integers(4, 6)] = 1
+        elif kind == 2:
+            a[2, 1:4, 1] = 1; a[2, 1, 1:5] = 1
+        else:
+            a[1:3, 1:4, 1:4] = 1
+        cases.append(a)
+    decided_cheaply = flat = 0
+    for img in cases:
+        n = int(np.count_nonzero(img))
+        if n < 4:
+            continue
+        pts = np.argwhere(img != 0)
+        try:
+            hull = np.count_nonzero(W.convex_hull_image(img))
+            qhull_refuses = False
+        except QhullError:
+            qhull_refuses = True
+        assert is_flat(pts) == qhull_refuses, pts.tolist()
+        if qhull_refuses:
+            flat += 1
+            with pytest.raises(DegenerateComponent):
+                convexity_at_least(img, 0.8)
+            hull = np.count_nonzero(W.convex_hull_image(img, degenerate="solid"))
+        assert dop_count(img) >= hull
+        for thr in (0.5, 0.8, 0.9, 1.0):
+            ok, val = convexity_at_least(img, thr, degenerate="solid")
+            assert ok == (n / hull >= thr), (thr, n, hull, val)
+            decided_cheaply += int(ok and val != n / hull)
+    assert flat >= 10 and decided_cheaply >= 20           # both branches were exercised
