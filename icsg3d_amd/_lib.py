@@ -38,6 +38,7 @@ class VaeConfig(C.Structure):
 _F = C.POINTER(C.c_float)
 _U8 = C.POINTER(C.c_uint8)
 _I32 = C.POINTER(C.c_int32)
+_I64 = C.POINTER(C.c_int64)
 _H = C.c_void_p
 
 # name -> (restype, argtypes); every symbol include/icsg3d.h declares
@@ -69,8 +70,8 @@ SIGNATURES = {
     "ics_vae_train_step_resident": (C.c_int, [_H, _F]),
     "ics_vae_decode_to_unet_labels": (C.c_int, [_H, _H, _F, _F, C.c_int, C.c_float, _U8, _U8, _F, _F]),
     "ics_vae_decode_to_unet_atoms": (C.c_int, [_H, _H, _F, _F, C.c_int, C.c_float, C.c_int, C.c_int, _U8, _U8, _F, _F,
-                                               _I32, _I32, _I32]),
-    "ics_op_segment_atoms": (C.c_int, [_U8, _U8, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _I32, _I32, _I32]),
+                                               _I32, _I32, _I32, _I64]),
+    "ics_op_segment_atoms": (C.c_int, [_U8, _U8, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _I32, _I32, _I32, _I64]),
     "ics_release_caches": (C.c_int, []),
     "ics_op_label_boxes": (C.c_int, [_I32, _I32, C.c_int, C.c_int, C.c_int, _I32, _I32, _I32]),
     "ics_op_watershed_split": (C.c_int, [_I32, _I32, _I32, C.c_int, C.c_int, _I32]),
@@ -156,6 +157,10 @@ def u8ptr(a):
 
 def i32ptr(a):
     return a.ctypes.data_as(_I32) if a is not None else None
+
+
+def i64ptr(a):
+    return a.ctypes.data_as(_I64) if a is not None else None
 
 
 def device_count():

@@ -2518,7 +2518,7 @@ int ics_vae_decode_to_unet_labels(ics_net* vae, ics_net* unet, const float* z, c
 // connected components + region statistics of device-resident mask / species volumes; results to the host
 static int segment_to_host(Net& n, const unsigned char* d_mask, const unsigned char* d_species, int batch, int d,
                            int min_voxels, int max_atoms, int nbins, int32_t* regions, int32_t* counts,
-                           int32_t* atom_stats) {
+                           int32_t* atom_stats, int64_t* bounds) {
   ICS_CHECK(counts && atom_stats && max_atoms >= 1, "null argument");
   const size_t M = (size_t)batch * d * d * d;
   const size_t wsb = segment_workspace_bytes(batch, d, max_atoms, nbins);
@@ -2530,14 +2530,17 @@ static int segment_to_host(Net& n, const unsigned char* d_mask, const unsigned c
   do {
     if (regions) d_R = reinterpret_cast<int*>(ws + wsb16);
     int *d_counts = nullptr, *d_stats = nullptr;
+    long long* d_bounds = nullptr;
     if ((rc = launch_segment_atoms(n.st, d_mask, d_species, batch, d, min_voxels, max_atoms, nbins, ws, wsb, d_R,
-                                   &d_counts, &d_stats)))
+                                   &d_counts, &d_stats, bounds ? &d_bounds : nullptr)))
       break;
     hipError_t e = hipSuccess;
     if (regions) e = hipMemcpyAsync(regions, d_R, M * 4, hipMemcpyDeviceToHost, n.st);
     if (e == hipSuccess) e = hipMemcpyAsync(counts, d_counts, (size_t)batch * 2 * 4, hipMemcpyDeviceToHost, n.st);
     if (e == hipSuccess)
       e = hipMemcpyAsync(atom_stats, d_stats, (size_t)batch * max_atoms * kSegStatInts * 4, hipMemcpyDeviceToHost, n.st);
+    if (e == hipSuccess && bounds)
+      e = hipMemcpyAsync(bounds, d_bounds, (size_t)batch * max_atoms * kSegBoundInts * 8, hipMemcpyDeviceToHost, n.st);
     if (e == hipSuccess) e = hipStreamSynchronize(n.st);
     if (e != hipSuccess) { set_error(std::string("segmentation copy-out: ") + hipGetErrorString(e)); rc = -1; }
   } while (0);
@@ -2551,7 +2554,7 @@ static int segment_to_host(Net& n, const unsigned char* d_mask, const unsigned c
 int ics_vae_decode_to_unet_atoms(ics_net* vae, ics_net* unet, const float* z, const float* cond, int batch,
                                  float thresh, int min_voxels, int max_atoms, uint8_t* species, uint8_t* mask,
                                  float* density, float* coord_minmax, int32_t* regions, int32_t* counts,
-                                 int32_t* atom_stats) {
+                                 int32_t* atom_stats, int64_t* convexity_bounds) {
   ICS_TRY(require_kind(vae, 1));
   ICS_TRY(require_kind(unet, 0));
   Net& n = vae->n;
@@ -2561,12 +2564,12 @@ int ics_vae_decode_to_unet_atoms(ics_net* vae, ics_net* unet, const float* z, co
                                   &d_species, &d_mask, &d_aux));
   ICS_TRY(tail_copy_out(n, batch, d_species, d_mask, d_aux, species, mask, density, coord_minmax));
   ICS_TRY(segment_to_host(n, d_mask, d_species, batch, n.d, min_voxels, max_atoms, unet->n.ncls, regions, counts,
-                          atom_stats));
+                          atom_stats, convexity_bounds));
   return 0;
 }
 
 int ics_op_segment_atoms(const uint8_t* mask, const uint8_t* species, int batch, int d, int min_voxels, int max_atoms,
-                         int num_species, int32_t* regions, int32_t* counts, int32_t* atom_stats) {
+                         int num_species, int32_t* regions, int32_t* counts, int32_t* atom_stats, int64_t* convexity_bounds) {
   ICS_CHECK(mask && species && batch >= 1 && max_atoms >= 1 && min_voxels >= 0, "bad segmentation arguments");
   ICS_CHECK(d >= 16 && d <= 256 && (d & (d - 1)) == 0, "grid must be a power of two in [16, 256]");
   Net n;
@@ -2576,7 +2579,7 @@ int ics_op_segment_atoms(const uint8_t* mask, const uint8_t* species, int batch,
   ICS_TRY(n.alloc(&dm, M)); ICS_TRY(n.alloc(&ds, M));
   ICS_HIP(hipMemcpyAsync(dm, mask, M, hipMemcpyHostToDevice, n.st));
   ICS_HIP(hipMemcpyAsync(ds, species, M, hipMemcpyHostToDevice, n.st));
-  return segment_to_host(n, dm, ds, batch, d, min_voxels, max_atoms, num_species, regions, counts, atom_stats);
+  return segment_to_host(n, dm, ds, batch, d, min_voxels, max_atoms, num_species, regions, counts, atom_stats, convexity_bounds);
 }
 
 // The three box-level entry points run tens of times per sample from the host recursion of segment_nuclei

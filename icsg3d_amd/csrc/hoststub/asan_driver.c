@@ -91,8 +91,8 @@ static int run(int d, int C, int B, int with_comm) {
       int32_t* regions = (int32_t*)malloc(M * sizeof(int32_t));
       int32_t counts[2 * 8];
       int32_t* stats = (int32_t*)malloc((size_t)b * 64 * 11 * sizeof(int32_t));
-      OK(ics_vae_decode_to_unet_atoms(vae, unet, z, cond, b, 0.8f, 3, 64, sp, mk, rec, minmax, regions, counts, stats));
-      OK(ics_vae_decode_to_unet_atoms(vae, unet, z, cond, b, 0.8f, 3, 64, NULL, NULL, NULL, NULL, NULL, counts, stats));
+      { int64_t* bnd = calloc((size_t)b * 64 * 8, 8); OK(ics_vae_decode_to_unet_atoms(vae, unet, z, cond, b, 0.8f, 3, 64, sp, mk, rec, minmax, regions, counts, stats, bnd)); free(bnd); }
+      OK(ics_vae_decode_to_unet_atoms(vae, unet, z, cond, b, 0.8f, 3, 64, NULL, NULL, NULL, NULL, NULL, counts, stats, NULL));
       free(regions); free(stats);
     }
   }
@@ -166,8 +166,9 @@ int main(void) {
     int32_t* regions = malloc(M * sizeof(int32_t));
     int32_t counts[4];
     int32_t* stats = malloc((size_t)B * 32 * 11 * sizeof(int32_t));
-    OK(ics_op_segment_atoms(mask, species, B, d, 3, 32, 95, regions, counts, stats));
-    if (ics_op_segment_atoms(mask, species, B, 24, 3, 32, 95, regions, counts, stats) == 0) { fprintf(stderr, "grid check missing\n"); return 1; }
+    { int64_t* bnd = calloc((size_t)B * 32 * 8, 8); OK(ics_op_segment_atoms(mask, species, B, d, 3, 32, 95, regions, counts, stats, bnd)); free(bnd); }
+    OK(ics_op_segment_atoms(mask, species, B, d, 3, 32, 95, regions, counts, stats, NULL));
+    if (ics_op_segment_atoms(mask, species, B, 24, 3, 32, 95, regions, counts, stats, NULL) == 0) { fprintf(stderr, "grid check missing\n"); return 1; }
     free(mask); free(species); free(regions); free(stats);
   }
   {  /* segment_nuclei's box operations (round 4): host-side batching, descriptor tables, scratch sizing */

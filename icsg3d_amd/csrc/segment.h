@@ -14,7 +14,11 @@ size_t segment_workspace_bytes(int B, int d, int max_atoms, int nbins);
 // *d_stats -> device int [B][max_atoms][kSegStatInts]; both inside `workspace`.
 int launch_segment_atoms(hipStream_t st, const unsigned char* mask, const unsigned char* species, int B, int d,
                          int min_voxels, int max_atoms, int nbins, void* workspace, size_t workspace_bytes, int* d_R,
-                         int** d_counts, int** d_stats);
+                         int** d_counts, int** d_stats, long long** d_bounds = nullptr);
+// d_bounds (optional): *d_bounds -> device int64 [B][max_atoms][8] inside `workspace`: {grid points of the region's bounding
+// box inside its 26-direction polytope (an upper bound of the convex hull image's count), sum zz, yy, xx, zy, zx, yx of
+// the voxel coordinates, 0} -- what the convexity test of segment_nuclei is decided from for most components.
+constexpr int kSegBoundInts = 8;
 
 // ---- boxes: small dense int32 volumes [D][H][W] (extents <= 64), `nbox` of them back to back; HOST pointers in and out
 // (tens of KB per call: the recursion of segment_nuclei is driven from the host, watershed.py:40-150).

@@ -97,9 +97,16 @@ __global__ __launch_bounds__(1024) void seg_rank_kernel(const unsigned* __restri
 
 // R volume + per-region integer statistics: stats[b][a] = {species, voxels, sum z, sum y, sum x, z0, y0, x0, z1, y1, x1}
 // (bounding box half-open like skimage's regionprops), hist[b][a][species]
+// 13 of the 26 directions with components in {-1, 0, 1} (the others are their negatives): the ORDER is the one
+// icsg3d_amd/watershed.py builds with itertools.product((-1, 0, 1), repeat=3) filtered by d > (0, 0, 0)
+__constant__ int kDopDir[13][3] = {{0, 0, 1}, {0, 1, -1}, {0, 1, 0}, {0, 1, 1}, {1, -1, -1}, {1, -1, 0}, {1, -1, 1},
+                                   {1, 0, -1}, {1, 0, 0}, {1, 0, 1}, {1, 1, -1}, {1, 1, 0}, {1, 1, 1}};
+constexpr int kSupInts = 26;     // per region: max of d.p for the 13 directions, then min
+
 __global__ void seg_stats_kernel(const unsigned* __restrict__ lab, const unsigned* __restrict__ rank,
                                  const unsigned char* __restrict__ species, int lgd, int per, size_t n, int max_atoms,
-                                 int nbins, int* __restrict__ R, int* __restrict__ stats, unsigned* __restrict__ hist) {
+                                 int nbins, int* __restrict__ R, int* __restrict__ stats, unsigned* __restrict__ hist,
+                                 int* __restrict__ sup, unsigned long long* __restrict__ mom) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const unsigned l = lab[i];
@@ -116,6 +123,68 @@ __global__ void seg_stats_kernel(const unsigned* __restrict__ lab, const unsigne
   atomicMax(s + 8, z + 1); atomicMax(s + 9, y + 1); atomicMax(s + 10, x + 1);
   const unsigned sp = species[i];
   if (sp != 0 && sp < (unsigned)nbins) atomicAdd(hist + (b * max_atoms + (r - 1)) * nbins + sp, 1u);
+  if (sup != nullptr) {
+    // what the convexity test of segment_nuclei (watershed.py:80-83) can be decided from without a convex hull: the
+    // support values of the component along 26 directions (its discrete orientation polytope contains the hull) and the
+    // second moments of its voxel coordinates (coplanar <=> the 3 x 3 scatter matrix is singular) -- integers, exact
+    int* su = sup + (b * max_atoms + (r - 1)) * kSupInts;
+#pragma unroll
+    for (int k = 0; k < 13; ++k) {
+      const int pr = kDopDir[k][0] * z + kDopDir[k][1] * y + kDopDir[k][2] * x;
+      atomicMax(su + k, pr);
+      atomicMin(su + 13 + k, pr);
+    }
+    unsigned long long* mo = mom + (b * max_atoms + (r - 1)) * 6;
+    atomicAdd(mo + 0, (unsigned long long)(z * z)); atomicAdd(mo + 1, (unsigned long long)(y * y));
+    atomicAdd(mo + 2, (unsigned long long)(x * x)); atomicAdd(mo + 3, (unsigned long long)(z * y));
+    atomicAdd(mo + 4, (unsigned long long)(z * x)); atomicAdd(mo + 5, (unsigned long long)(y * x));
+  }
+}
+
+__global__ void seg_sup_init_kernel(int* __restrict__ sup, unsigned long long* __restrict__ mom, size_t natoms) {
+  const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= natoms) return;
+  for (int k = 0; k < 13; ++k) { sup[a * kSupInts + k] = -(1 << 30); sup[a * kSupInts + 13 + k] = 1 << 30; }
+  for (int k = 0; k < 6; ++k) mom[a * 6 + k] = 0ull;
+}
+
+// One wave per region: the number of grid points of the region's bounding box inside its 26-direction polytope, on doubled
+// coordinates (the reference's convex_hull_image offsets every voxel by +-0.5 along one axis at a time: a support value
+// moves by max_k |d_k| / 2 = 1/2):  2 min_p(d.p) - 1 <= 2 d.g <= 2 max_p(d.p) + 1  for the 13 directions.  An UPPER bound
+// of np.count_nonzero(convex_hull_image(component)).  bounds[a] = {count, sum zz, yy, xx, zy, zx, yx, 0}.
+__global__ __launch_bounds__(64) void seg_dop_kernel(const int* __restrict__ stats, const int* __restrict__ sup,
+                                                     const unsigned long long* __restrict__ mom,
+                                                     long long* __restrict__ bounds) {
+  const size_t a = blockIdx.x;
+  const int* s = stats + a * kSegStatInts;
+  long long* o = bounds + a * 8;
+  const int nvox = s[1];
+  if (nvox <= 0) {
+    if (threadIdx.x < 8) o[threadIdx.x] = 0;
+    return;
+  }
+  const int z0 = s[5], y0 = s[6], x0 = s[7], D = s[8] - z0, H = s[9] - y0, W = s[10] - x0;
+  int hi[13], lo[13];
+#pragma unroll
+  for (int k = 0; k < 13; ++k) { hi[k] = 2 * sup[a * kSupInts + k] + 1; lo[k] = 2 * sup[a * kSupInts + 13 + k] - 1; }
+  int cnt = 0;
+  for (int i = threadIdx.x; i < D * H * W; i += 64) {
+    const int x = x0 + i % W, y = y0 + (i / W) % H, z = z0 + i / (W * H);
+    bool in = true;
+#pragma unroll
+    for (int k = 0; k < 13; ++k) {
+      const int g = 2 * (kDopDir[k][0] * z + kDopDir[k][1] * y + kDopDir[k][2] * x);
+      in = in && g <= hi[k] && g >= lo[k];
+    }
+    cnt += in ? 1 : 0;
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d);
+  if (threadIdx.x == 0) {
+    o[0] = cnt;
+    for (int k = 0; k < 6; ++k) o[1 + k] = (long long)mom[a * 6 + k];
+    o[7] = 0;
+  }
 }
 
 __global__ void seg_stats_init_kernel(int* __restrict__ stats, size_t natoms, int d) {
@@ -408,12 +477,13 @@ __global__ __launch_bounds__(1024) void ws_split_kernel(const int* __restrict__ 
 
 size_t segment_workspace_bytes(int B, int d, int max_atoms, int nbins) {
   const size_t n = (size_t)B * d * d * d;
-  return n * 4 * 3 + (size_t)B * max_atoms * ((size_t)kSegStatInts * 4 + (size_t)nbins * 4) + (size_t)B * 8 + 256;
+  return n * 4 * 3 + (size_t)B * max_atoms * ((size_t)kSegStatInts * 4 + (size_t)nbins * 4) + (size_t)B * 8 + 256 +
+         (size_t)B * max_atoms * ((size_t)kSupInts * 4 + 6 * 8 + 8 * 8) + 64;     // convexity bounds (optional)
 }
 
 int launch_segment_atoms(hipStream_t st, const unsigned char* mask, const unsigned char* species, int B, int d,
                          int min_voxels, int max_atoms, int nbins, void* workspace, size_t workspace_bytes, int* d_R,
-                         int** d_counts, int** d_stats) {
+                         int** d_counts, int** d_stats, long long** d_bounds) {
   int lgd = 0;
   while ((1 << lgd) < d) ++lgd;
   ICS_CHECK((1 << lgd) == d && d >= 16 && d <= 256, "grid must be a power of two in [16, 256]");
@@ -429,6 +499,12 @@ int launch_segment_atoms(hipStream_t st, const unsigned char* mask, const unsign
   unsigned* hist = reinterpret_cast<unsigned*>(stats + (size_t)B * max_atoms * kSegStatInts);
   int* counts = reinterpret_cast<int*>(hist + (size_t)B * max_atoms * nbins);
   const size_t natoms = (size_t)B * max_atoms;
+  // optional convexity bounds: 8-byte aligned behind the counts
+  uintptr_t bp = (reinterpret_cast<uintptr_t>(counts + (size_t)B * 2) + 63) & ~(uintptr_t)63;
+  long long* bounds = reinterpret_cast<long long*>(bp);
+  unsigned long long* mom = reinterpret_cast<unsigned long long*>(bounds + natoms * 8);
+  int* sup = reinterpret_cast<int*>(mom + natoms * 6);
+  const bool want_bounds = d_bounds != nullptr;
   const unsigned gv = (unsigned)((n + 255) / 256), ga = (unsigned)((natoms + 255) / 256);
   ICS_HIP(hipMemsetAsync(size, 0, n * 4, st));
   ICS_HIP(hipMemsetAsync(hist, 0, natoms * nbins * 4, st));
@@ -438,9 +514,14 @@ int launch_segment_atoms(hipStream_t st, const unsigned char* mask, const unsign
   ICS_LAUNCH(seg_merge_kernel, dim3(gv), dim3(256), 0, st, mask, lab, lgd, n);
   ICS_LAUNCH(seg_flatten_kernel, dim3(gv), dim3(256), 0, st, lab, size, n);
   ICS_LAUNCH(seg_rank_kernel, dim3(B), dim3(1024), 0, st, lab, size, rank, per, min_voxels, counts);
+  if (want_bounds) ICS_LAUNCH(seg_sup_init_kernel, dim3(ga), dim3(256), 0, st, sup, mom, natoms);
   ICS_LAUNCH(seg_stats_kernel, dim3(gv), dim3(256), 0, st, lab, rank, species, lgd, per, n, max_atoms, nbins,
-                     d_R, stats, hist);
+                     d_R, stats, hist, want_bounds ? sup : nullptr, want_bounds ? mom : nullptr);
   ICS_LAUNCH(seg_vote_kernel, dim3(ga), dim3(256), 0, st, hist, nbins, natoms, stats);
+  if (want_bounds) {
+    ICS_LAUNCH(seg_dop_kernel, dim3((unsigned)natoms), dim3(64), 0, st, stats, sup, mom, bounds);
+    *d_bounds = bounds;
+  }
   ICS_HIP(hipGetLastError());
   *d_counts = counts;
   *d_stats = stats;

@@ -341,16 +341,18 @@ class VaeEngine(_Net):
         mm = np.zeros((B, 3, 2), np.float32)
         counts = np.zeros((B, 2), np.int32)
         stats = np.zeros((B, max_atoms, len(STAT_FIELDS)), np.int32)
+        bounds = np.zeros((B, max_atoms, 8), np.int64) if want_regions else None    # refine_atoms' convexity shortcut
         for i in range(0, B, mb):
             s = slice(i, i + mb)
             L.check(self._lib.ics_vae_decode_to_unet_atoms(
                 self._h, unet._h, L.fptr(z[s]), L.fptr(cond[s]), z[s].shape[0], float(thresh), int(min_voxels),
                 int(max_atoms), L.u8ptr(sp[s]), L.u8ptr(mk[s]), L.fptr(dens[s]) if want_density else None,
-                L.fptr(mm[s]), L.i32ptr(reg[s]) if want_regions else None, L.i32ptr(counts[s]), L.i32ptr(stats[s])))
+                L.fptr(mm[s]), L.i32ptr(reg[s]) if want_regions else None, L.i32ptr(counts[s]), L.i32ptr(stats[s]),
+                L.i64ptr(bounds[s]) if bounds is not None else None))
         failed = counts[:, 1] > max_atoms                 # more kept components than rows: sample skipped, not the batch
         counts[failed, 1] = 0
         return {"species": sp, "mask": mk, "density": dens, "coord_minmax": mm, "regions": reg,
-                "n_components": counts[:, 0].copy(), "n_atoms": counts[:, 1].copy(), "stats": stats,
+                "n_components": counts[:, 0].copy(), "n_atoms": counts[:, 1].copy(), "stats": stats, "bounds": bounds,
                 "atoms": _atoms_from_stats(counts, stats, d ** 3), "failed": failed}
 
     def train_step(self, x, cond, eps):

@@ -52,8 +52,9 @@ def segment_atoms(mask, species, min_voxels=3, max_atoms=512, num_species=95, wa
     Connected components + size filter + region statistics with EVERY kept component taken as convex (the first pass
     of segment_nuclei; `watershed_clustering` continues from it).
     Returns dict(regions int32 (B,d,d,d) | None, mask u8, species u8 (the inputs, as `refine_atoms` needs them),
-    n_components (B,), n_atoms (B,), stats int32 (B,max_atoms,11), atoms [(species list, mean list)] per sample,
-    failed (B,) bool: more than max_atoms kept components)."""
+    n_components (B,), n_atoms (B,), stats int32 (B,max_atoms,11), bounds int64 (B,max_atoms,8) | None = the device's
+    convexity bounds per region (ics_op_segment_atoms: polytope count and second moments), atoms [(species list, mean
+    list)] per sample, failed (B,) bool: more than max_atoms kept components)."""
     mask = np.ascontiguousarray(np.asarray(mask) != 0, dtype=np.uint8)
     species = np.ascontiguousarray(species, dtype=np.uint8)
     if mask.ndim != 4 or mask.shape != species.shape or len(set(mask.shape[1:])) != 1:
@@ -62,13 +63,16 @@ def segment_atoms(mask, species, min_voxels=3, max_atoms=512, num_species=95, wa
     regions = np.empty(mask.shape, np.int32) if want_regions else None
     counts = np.zeros((B, 2), np.int32)
     stats = np.zeros((B, max_atoms, len(STAT_FIELDS)), np.int32)
+    bounds = np.zeros((B, max_atoms, 8), np.int64) if want_regions else None
     L.check(L.load().ics_op_segment_atoms(L.u8ptr(mask), L.u8ptr(species), B, d, int(min_voxels), int(max_atoms),
-                                          int(num_species), L.i32ptr(regions), L.i32ptr(counts), L.i32ptr(stats)))
+                                          int(num_species), L.i32ptr(regions), L.i32ptr(counts), L.i32ptr(stats),
+                                          L.i64ptr(bounds)))
     failed = counts[:, 1] > max_atoms
     counts = counts.copy()
     counts[failed, 1] = 0
     return {"regions": regions, "mask": mask, "species": species, "n_components": counts[:, 0].copy(),
-            "n_atoms": counts[:, 1].copy(), "stats": stats, "atoms": _atoms_from_stats(counts, stats, d ** 3), "failed": failed}
+            "n_atoms": counts[:, 1].copy(), "stats": stats, "bounds": bounds,
+            "atoms": _atoms_from_stats(counts, stats, d ** 3), "failed": failed}
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -185,6 +189,16 @@ def is_flat(pts):
     if len(nc) == 0:
         return True                                    # collinear
     return not np.any(v @ c[nc[0]] != 0)              # every point in the plane through the first three
+
+
+def _scatter_is_singular(n, s1, s2):
+    """coplanar / collinear <=> det(n * sum p p^T - (sum p)(sum p)^T) == 0, in exact Python integers.
+    s1 = (sum z, sum y, sum x), s2 = (sum zz, yy, xx, zy, zx, yx)."""
+    sz, sy, sx = s1
+    zz, yy, xx, zy, zx, yx = s2
+    a, b_, c = n * zz - sz * sz, n * zy - sz * sy, n * zx - sz * sx
+    d, e, f = n * yy - sy * sy, n * yx - sy * sx, n * xx - sx * sx
+    return a * (d * f - e * e) - b_ * (b_ * f - e * c) + c * (b_ * e - d * c) == 0
 
 
 def dop_count(img):
@@ -308,9 +322,18 @@ def refine_atoms(out, max_iters=5, num_species=95, tie="heap", min_convexity=0.8
         n = int(out["n_atoms"][b])
         st = out["stats"][b, :n]
         lab0 = out["regions"][b]
+        bnd = out["bounds"][b, :n] if out.get("bounds") is not None else None
         try:
             convex = True
             for a in range(n):
+                if bnd is not None:
+                    # decided from the device's integers where they are conclusive: flat (singular scatter matrix) -> the
+                    # reference stack's Qhull call fails; voxels / polytope count >= threshold -> convex, no hull needed
+                    flat = _scatter_is_singular(int(st[a, 1]), [int(v) for v in st[a, 2:5]], [int(v) for v in bnd[a, 1:7]])
+                    if flat and degenerate != "solid":
+                        raise DegenerateComponent("component %d of sample %d is flat" % (a + 1, b))
+                    if int(st[a, 1]) / int(bnd[a, 0]) >= min_convexity:
+                        continue
                 z0, y0, x0, z1, y1, x1 = (int(v) for v in st[a, 5:11])
                 box = lab0[z0:z1, y0:y1, x0:x1] == a + 1
                 if not convexity_at_least(box, min_convexity, degenerate)[0]:

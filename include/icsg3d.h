@@ -149,9 +149,16 @@ int ics_vae_decode_to_unet_labels(ics_net* vae, ics_net* unet, const float* z, c
  * volume -- the reference calls them x,y,z; bounding box half-open), rows >= kept components are empty.
  * A sample with more than max_atoms kept components reports counts[b][1] > max_atoms: its rows are truncated and the
  * caller must skip it (the reference skips a failed sample too, generate.py:228-236); the call itself succeeds.
+ * convexity_bounds int64 (B,max_atoms,8) or NULL = {P, sum zz, sum yy, sum xx, sum zy, sum zx, sum yx, 0} per region:
+ * P = the number of grid points of the region's bounding box inside its 26-direction polytope (directions in {-1,0,1}^3,
+ * the voxels offset by +-0.5 along one axis at a time as convex_hull_image does).  The convex hull is a subset of that
+ * polytope, so voxels / P is a LOWER bound of the convexity watershed.py:80-83 tests: where it reaches min_convexity no
+ * hull is needed; the second moments decide coplanarity (the 3 x 3 scatter matrix is singular), i.e. the components for
+ * which the reference stack's Qhull call fails.  Exact integer arithmetic (icsg3d_amd/watershed.py: refine_atoms).
  * Integer atomics only: results are bit-exact. */
 int ics_op_segment_atoms(const uint8_t* mask, const uint8_t* species, int batch, int d, int min_voxels, int max_atoms,
-                         int num_species, int32_t* regions, int32_t* counts, int32_t* atom_stats);
+                         int num_species, int32_t* regions, int32_t* counts, int32_t* atom_stats,
+                         int64_t* convexity_bounds);
 /* ---- segment_nuclei's non-convex branch and recursion (watershed.py:40-150) on small boxes.  A box is a dense int32
  * volume [D][H][W] (extents 1..64) -- a component cropped to its bounding box, or a watershed result that is segmented
  * again; `nbox` boxes lie back to back in `vols` / `boxes`, dims = [nbox][3].  HOST pointers; one workgroup per box.
@@ -178,11 +185,11 @@ int ics_op_region_stats(const int32_t* R, const uint8_t* species, int D, int H, 
                         int32_t* stats);
 /* ics_vae_decode_to_unet_labels continued on the device through the component labelling above: the mask and species
  * volumes never leave HBM between the U-Net and the region statistics.  species/mask/density/coord_minmax/regions
- * are optional (NULL to skip). */
+ * and convexity_bounds are optional (NULL to skip). */
 int ics_vae_decode_to_unet_atoms(ics_net* vae, ics_net* unet, const float* z, const float* cond, int batch,
                                  float thresh, int min_voxels, int max_atoms, uint8_t* species, uint8_t* mask,
                                  float* density, float* coord_minmax, int32_t* regions, int32_t* counts,
-                                 int32_t* atom_stats);
+                                 int32_t* atom_stats, int64_t* convexity_bounds);
 
 /* ---------------------------------------------------------------- common to both engines */
 int ics_net_destroy(ics_net* net);

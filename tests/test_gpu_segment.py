@@ -239,3 +239,53 @@ def test_refine_atoms_continues_the_batch_result():
         a, mu = out["atoms"][b]
         assert np.array_equal(out["regions"][b], R_ref.astype(np.int32)) and list(a) == list(a_ref)
         assert np.array_equal(np.array(mu).reshape(len(a), 3), np.array(mu_ref).reshape(len(a_ref), 3))
+
+
+@pytest.mark.parametrize("B,d,p", [(3, 32, 0.30), (2, 16, 0.45), (1, 64, 0.22)])
+def test_device_convexity_bounds_equal_the_host_integers(B, d, p):
+    """ics_op_segment_atoms' convexity_bounds: per region the 26-direction polytope count and the second moments, the
+    integers refine_atoms decides most components from without a hull -- equal to the host functions
+    (icsg3d_amd.watershed.dop_count / is_flat, themselves held to Qhull's hull in tests/test_oracle_watershed.py)."""
+    from icsg3d_amd.watershed import _scatter_is_singular, dop_count, is_flat, segment_atoms
+    rng = np.random.default_rng(200 + d)
+    mask = (rng.uniform(size=(B, d, d, d)) < p).astype(np.uint8)
+    mask[0, :3] = 0
+    mask[0, 1, 2:6, 2:6] = 1                          # a 4 x 4 plate (flat, kept) ...
+    mask[0, 1, 10, 8:14] = 1                          # ... and a 6-voxel line, isolated in an emptied slab
+    species = rng.integers(0, 95, size=mask.shape).astype(np.uint8)
+    r = segment_atoms(mask, species, min_voxels=3, max_atoms=4096)
+    assert not r["failed"].any()
+    nflat = ncheap = 0
+    for b in range(B):
+        R = r["regions"][b]
+        n = int(r["n_atoms"][b])
+        for a in list(range(min(n, 40))) + list(range(max(n - 5, 0), n)):
+            st, bd = r["stats"][b, a], r["bounds"][b, a]
+            z0, y0, x0, z1, y1, x1 = (int(v) for v in st[5:11])
+            box = R[z0:z1, y0:y1, x0:x1] == a + 1
+            assert int(bd[0]) == dop_count(box), (b, a)
+            pts = np.argwhere(R == a + 1)
+            assert [int(v) for v in bd[1:7]] == [int((pts[:, i] * pts[:, j]).sum()) for i, j in
+                                                 ((0, 0), (1, 1), (2, 2), (0, 1), (0, 2), (1, 2))]
+            flat = _scatter_is_singular(int(st[1]), [int(v) for v in st[2:5]], [int(v) for v in bd[1:7]])
+            assert flat == is_flat(pts), (b, a)
+            nflat += int(flat)
+            ncheap += int(int(st[1]) / int(bd[0]) >= 0.8)
+    assert nflat >= 2 and ncheap >= 1
+
+
+def test_refine_atoms_takes_the_same_decisions_with_and_without_device_bounds():
+    from icsg3d_amd.watershed import refine_atoms, segment_atoms
+    d = 32
+    masks = np.stack([_balls(d, TOUCHING), _balls(d, [((10, 10, 10), 3), ((22, 20, 12), 3), ((8, 24, 24), 4)]),
+                      _balls(d, [((16, 16, 16), 6)])]).astype(np.uint8)
+    rng = np.random.default_rng(4)
+    species = np.where(masks != 0, rng.integers(1, 95, size=masks.shape), 0).astype(np.uint8)
+    with_b = refine_atoms(segment_atoms(masks, species, max_atoms=64))
+    no_b = segment_atoms(masks, species, max_atoms=64)
+    no_b["bounds"] = None
+    refine_atoms(no_b)
+    assert list(with_b["split"]) == list(no_b["split"]) == [True, False, False]
+    for b in range(3):
+        assert np.array_equal(with_b["regions"][b], no_b["regions"][b])
+        assert with_b["atoms"][b][0] == no_b["atoms"][b][0]
