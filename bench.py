@@ -463,6 +463,26 @@ def main():
                   "end_to_end_grids_per_s": round(Bg / (t2 - t0), 1),
                   "note": "random-weight masks: degenerate='solid' so that flat fragments do not fail the sample (the "
                           "reference stack would skip it, generate.py:246-248)"}
+        # ... and the same host step on what a trained segmentation produces: nine ball-shaped atoms per grid, every component
+        # convex -- decided from the device's integers (polytope count, second moments), no hull, no recursion
+        from icsg3d_amd.watershed import segment_atoms
+        zz, yy, xx = np.mgrid[:d, :d, :d]
+        balls = np.zeros((Bg, d, d, d), np.uint8)
+        for b_ in range(Bg):
+            for k in range(9):
+                c = (np.array([5 + 11 * (k // 9 % 3), 5 + 11 * (k // 3 % 3), 5 + 11 * (k % 3)]) + rng.uniform(-1, 1, 3)) * d / 32.0
+                r = rng.uniform(2.2, 3.6) * d / 32.0
+                balls[b_][((zz - c[0]) ** 2 + (yy - c[1]) ** 2 + (xx - c[2]) ** 2) <= r * r] = 1
+        sp_b = np.where(balls != 0, rng.integers(1, 95, size=balls.shape), 0).astype(np.uint8)
+        refine_atoms(segment_atoms(balls[:2], sp_b[:2], max_atoms=64))
+        t0 = time.perf_counter()
+        ob = segment_atoms(balls, sp_b, max_atoms=64)
+        t1 = time.perf_counter()
+        refine_atoms(ob)
+        t2 = time.perf_counter()
+        refine["convex_case"] = {"host_arrays_device_pass_ms": round((t1 - t0) * 1e3, 2), "host_refine_ms": round((t2 - t1) * 1e3, 2),
+                                 "atoms_per_grid": round(float(ob["n_atoms"].mean()), 1), "samples_split": int(ob["split"].sum()),
+                                 "note": "synthetic masks of nine balls per grid (all convex), ics_op_segment_atoms + refine_atoms"}
         gvae.close()
         return {"workload": "generate.py:204-236 tail: decoder -> U-Net -> argmax / threshold -> components -> atoms, "
                             "%d x %d^3 x 1 grids per call; host <-> device copies of the call included" % (Bg, d),
