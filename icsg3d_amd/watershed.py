@@ -232,9 +232,11 @@ def convexity_at_least(img, threshold, degenerate="raise"):
     return c >= threshold, c
 
 
-def segment_nuclei(binary, wmin=8, it=1, max_iters=5, min_convexity=0.8, tie="heap", labelled=None, trace=None,
+def _segment_nuclei_recursive(binary, wmin=8, it=1, max_iters=5, min_convexity=0.8, tie="heap", labelled=None, trace=None,
                    degenerate="raise"):
-    """watershed.py:40-150 (species / intensity ride along in the reference without influencing R and are omitted).
+    """The reference's control flow verbatim (depth first, one device call per level and parent): kept as the statement the
+    breadth-first `segment_nuclei_batch` below is tested against.
+    watershed.py:40-150 (species / intensity ride along in the reference without influencing R and are omitted).
     binary: int volume (D,H,W).  labelled: optional (labels, n, stats) of `binary` already computed on the device
     (the batched first pass).  Returns R float64 like the reference.  Raises DegenerateComponent where the reference
     stack raises QhullError (a flat kept component), unless degenerate="solid"."""
@@ -267,7 +269,7 @@ def segment_nuclei(binary, wmin=8, it=1, max_iters=5, min_convexity=0.8, tie="he
         if int(np.count_nonzero(wss) / wmin) > nclasses and it < max_iters:
             if trace is not None:
                 trace.append((it, cl, int(stats[cl - 1, 0]), float(convexity), "recurse"))
-            Rp = segment_nuclei(wss, it=it + 1, max_iters=max_iters, min_convexity=min_convexity, tie=tie, trace=trace,
+            Rp = _segment_nuclei_recursive(wss, it=it + 1, max_iters=max_iters, min_convexity=min_convexity, tie=tie, trace=trace,
                                 degenerate=degenerate)
             max_class = np.max(R)
             Rp = Rp + max_class
@@ -278,6 +280,101 @@ def segment_nuclei(binary, wmin=8, it=1, max_iters=5, min_convexity=0.8, tie="he
                 trace.append((it, cl, int(stats[cl - 1, 0]), float(convexity), "split"))
             R[sl] = np.where(wss != 0, wss, R[sl])
     return R
+
+
+class _Node:
+    """One call of the reference's segment_nuclei: a volume to label, its recursion depth, its components in label order."""
+    __slots__ = ("vol", "it", "root", "comps")
+
+    def __init__(self, vol, it, root):
+        self.vol, self.it, self.root, self.comps = vol, it, root, []
+
+
+def segment_nuclei_batch(binaries, wmin=8, max_iters=5, min_convexity=0.8, tie="heap", traces=None, degenerate="raise"):
+    """segment_nuclei (watershed.py:40-150) for SEVERAL volumes at once, breadth first: every recursion level of every
+    sample shares ONE label launch and ONE marker-watershed launch (the reference -- and `_segment_nuclei_recursive` -- go
+    depth first: one device round trip per level and parent, 55 ms per all-split sample).  The result is the reference's,
+    number for number: what a (sub-)call returns depends on its input only up to the values' equality pattern, and the
+    offsets `max_class` that its caller adds are applied afterwards in the reference's own order (`_assemble`).
+    Returns (Rs, errors): R float64 per sample, or None with the DegenerateComponent the sample raised (flat component)."""
+    roots = [_Node(np.asarray(b).astype(np.int32), 1, i) for i, b in enumerate(binaries)]
+    errors = [None] * len(roots)
+    level = list(roots)
+    while level:
+        labelled = label_boxes([n.vol for n in level], connectivity=1)
+        todo = []
+        for node, (labels, nlab, stats) in zip(level, labelled):
+            if errors[node.root] is not None:
+                continue
+            for cl in range(1, nlab + 1):
+                if stats[cl - 1, 0] <= 3:                            # seg_counts > 3, background excluded
+                    continue
+                z0, y0, x0, z1, y1, x1 = (int(v) for v in stats[cl - 1, 1:7])
+                sl = (slice(z0, z1), slice(y0, y1), slice(x0, x1))
+                box = np.where(labels[sl] == cl, cl, 0).astype(np.int32)       # binary_bbox: values {0, cl}
+                try:
+                    is_convex, convexity = convexity_at_least(box, min_convexity, degenerate)
+                except DegenerateComponent as e:
+                    errors[node.root] = e
+                    break
+                comp = {"cl": cl, "sl": sl, "box": box, "count": int(stats[cl - 1, 0]), "convexity": float(convexity),
+                        "kind": "convex" if is_convex else "split", "wss": None, "child": None, "node": node}
+                node.comps.append(comp)
+                if not is_convex:
+                    todo.append(comp)
+        todo = [c for c in todo if errors[c["node"].root] is None]
+        level = []
+        if todo:
+            for comp, wss in zip(todo, watershed_split([c["box"] for c in todo], [c["cl"] for c in todo], tie=tie)):
+                comp["wss"] = wss                                     # labels 2.. or 0 (before the caller's offset)
+                nclasses = len(np.unique(wss)) - 1
+                if int(np.count_nonzero(wss) / wmin) > nclasses and comp["node"].it < max_iters:
+                    comp["kind"] = "recurse"
+                    comp["child"] = _Node(wss, comp["node"].it + 1, comp["node"].root)
+                    level.append(comp["child"])
+    Rs = []
+    for i, root in enumerate(roots):
+        if errors[i] is not None:
+            Rs.append(None)
+            continue
+        Rs.append(_assemble(root, traces[i] if traces is not None else None))
+    return Rs, errors
+
+
+def _assemble(node, trace):
+    """The bookkeeping of segment_nuclei on R in the reference's order (watershed.py:84-92,104-150)."""
+    R = np.zeros(node.vol.shape)
+    for comp in node.comps:
+        cl, sl = comp["cl"], comp["sl"]
+        if trace is not None:
+            trace.append((node.it, cl, comp["count"], comp["convexity"], comp["kind"]))
+        max_class = np.max(R)
+        if comp["kind"] == "convex":
+            R[sl] = np.where(comp["box"] == cl, max_class + 1, R[sl])
+        elif comp["kind"] == "recurse":
+            Rp = _assemble(comp["child"], trace)
+            max_class = np.max(R)
+            Rp = Rp + max_class
+            Rp[Rp == max_class] = 0
+            R[sl] = np.where(Rp != 0, Rp, R[sl])
+        else:
+            wss = comp["wss"].astype(np.float64) + max_class
+            wss[wss == max_class] = 0
+            R[sl] = np.where(wss != 0, wss, R[sl])
+    return R
+
+
+def segment_nuclei(binary, wmin=8, it=1, max_iters=5, min_convexity=0.8, tie="heap", labelled=None, trace=None,
+                   degenerate="raise"):
+    """watershed.py:40-150 for one volume (species / intensity ride along in the reference without influencing R and are
+    omitted): `segment_nuclei_batch` on a batch of one.  Returns R float64 like the reference; raises DegenerateComponent
+    where the reference stack raises QhullError (a flat kept component), unless degenerate="solid".  `it` > 1 and
+    `labelled` belong to the recursive form and are accepted for signature compatibility (it shortens the recursion)."""
+    Rs, errors = segment_nuclei_batch([binary], wmin=wmin, max_iters=max_iters - (it - 1), min_convexity=min_convexity, tie=tie,
+                                      traces=[trace] if trace is not None else None, degenerate=degenerate)
+    if errors[0] is not None:
+        raise errors[0]
+    return Rs[0]
 
 
 def centroids(seg_img, R, num_species=95):
@@ -302,13 +399,14 @@ def watershed_clustering(M, S, Sb, max_iters=5, return_ws=False, verbose=False, 
 def refine_atoms(out, max_iters=5, num_species=95, tie="heap", min_convexity=0.8, degenerate="raise"):
     """Continue a batch result of `segment_atoms` / `decode_to_atoms` (every kept component taken as convex) through
     the convexity test and the recursive split.  A sample whose kept components all pass keeps its device result (the
-    convex branch numbers the regions 1..n in label order, which is what the first pass returned); any other sample is
-    segmented again from its mask by `segment_nuclei` -- from scratch, because the reference's `markers[unknown == 1]`
-    quirk depends on the ORIGINAL component numbers, small dropped components included -- and gets fresh region
-    statistics.  Needs out["regions"], out["mask"] and out["species"] (both producers return them; the mask cannot be
-    rebuilt from the regions, which have lost the <= 3-voxel components).  A sample with a flat kept component fails as
-    in the reference stack (out["failed"][b] = True, no atoms) unless degenerate="solid".
-    Adds out["split"] (B,) bool; updates out["atoms"], out["regions"], out["failed"]."""
+    convex branch numbers the regions 1..n in label order, which is what the first pass returned); the other samples are
+    segmented again from their masks by `segment_nuclei_batch` -- from scratch, because the reference's
+    `markers[unknown == 1]` quirk depends on the ORIGINAL component numbers, small dropped components included; all of
+    them together, one launch per recursion level -- and get fresh region statistics.  Needs out["regions"], out["mask"]
+    and out["species"] (both producers return them; the mask cannot be rebuilt from the regions, which have lost the
+    <= 3-voxel components).  A sample with a flat kept component fails as in the reference stack (out["failed"][b] =
+    True, no atoms) unless degenerate="solid".  Convex and flat components are decided from out["bounds"] (the device's
+    integers) where present.  Adds out["split"] (B,) bool; updates out["atoms"], out["regions"], out["failed"]."""
     for key in ("regions", "mask", "species"):
         if out.get(key) is None:
             raise ValueError("refine_atoms needs out[%r] (segment_atoms / decode_to_atoms with want_regions=True)" % key)
@@ -338,16 +436,20 @@ def refine_atoms(out, max_iters=5, num_species=95, tie="heap", min_convexity=0.8
                 box = lab0[z0:z1, y0:y1, x0:x1] == a + 1
                 if not convexity_at_least(box, min_convexity, degenerate)[0]:
                     convex = False          # (the reference tests every component: a later flat one still fails the sample)
-            if convex:
-                continue
-            split[b] = True
-            R = segment_nuclei((out["mask"][b] != 0).astype(np.int32), max_iters=max_iters, min_convexity=min_convexity,
-                               tie=tie, degenerate=degenerate)
+            split[b] = not convex
         except DegenerateComponent:
             out["failed"][b] = True          # generate.py:246-248: "Failed", continue
             out["atoms"][b] = ([], [])
-            continue
-        out["atoms"][b] = centroids(out["species"][b], R, num_species)
-        out["regions"][b] = R.astype(np.int32)
+    todo = [b for b in range(B) if split[b] and not out["failed"][b]]
+    if todo:
+        Rs, errors = segment_nuclei_batch([(out["mask"][b] != 0).astype(np.int32) for b in todo], max_iters=max_iters,
+                                          min_convexity=min_convexity, tie=tie, degenerate=degenerate)
+        for b, R, err in zip(todo, Rs, errors):
+            if err is not None:
+                out["failed"][b] = True
+                out["atoms"][b] = ([], [])
+                continue
+            out["atoms"][b] = centroids(out["species"][b], R, num_species)
+            out["regions"][b] = R.astype(np.int32)
     out["split"] = split
     return out

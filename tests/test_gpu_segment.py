@@ -289,3 +289,34 @@ def test_refine_atoms_takes_the_same_decisions_with_and_without_device_bounds():
     for b in range(3):
         assert np.array_equal(with_b["regions"][b], no_b["regions"][b])
         assert with_b["atoms"][b][0] == no_b["atoms"][b][0]
+
+
+def test_breadth_first_batch_equals_the_depth_first_recursion():
+    """segment_nuclei_batch (one label launch and one flood launch per recursion LEVEL for all samples) against the
+    reference's control flow (`_segment_nuclei_recursive`: depth first, one round trip per level and parent): identical R,
+    identical visiting order (traces), identical failures."""
+    from icsg3d_amd.watershed import DegenerateComponent, _segment_nuclei_recursive, segment_nuclei_batch
+    d = 32
+    rng = np.random.default_rng(17)
+    vols = [_balls(d, TOUCHING),
+            _balls(d, [((10, 10, 10), 3), ((22, 20, 12), 3)]),
+            _balls(d, [((8, 8, 6), 4), ((8, 8, 12), 4), ((8, 14, 9), 4), ((22, 22, 22), 5), ((22, 22, 15), 4)]),
+            (rng.uniform(size=(d, d, d)) < 0.24).astype(np.int32),          # ragged: many non-convex components, some flat
+            np.zeros((d, d, d), np.int32)]
+    for mode in ("solid", "raise"):
+        traces = [[] for _ in vols]
+        Rs, errors = segment_nuclei_batch(vols, traces=traces, degenerate=mode)
+        for i, v in enumerate(vols):
+            tr = []
+            try:
+                R_ref = _segment_nuclei_recursive(v, trace=tr, degenerate=mode)
+            except DegenerateComponent:
+                assert errors[i] is not None and Rs[i] is None, i
+                continue
+            assert errors[i] is None and np.array_equal(Rs[i], R_ref), (mode, i)
+            assert [(t[0], t[1], t[2], t[4]) for t in traces[i]] == [(t[0], t[1], t[2], t[4]) for t in tr], (mode, i)
+    assert any(t[4] == "recurse" for t in traces[0]) and any(e is not None for e in errors)      # both paths were taken
+    # max_iters reaches the batch the same way
+    Rs1, _ = segment_nuclei_batch(vols[:3], max_iters=1, degenerate="solid")
+    for i in range(3):
+        assert np.array_equal(Rs1[i], _segment_nuclei_recursive(vols[i], max_iters=1, degenerate="solid"))
