@@ -227,3 +227,45 @@ def test_convexity_prefilter_decides_exactly_like_the_hull():
             assert ok == (n / hull >= thr), (thr, n, hull, val)
             decided_cheaply += int(ok and val != n / hull)
     assert flat >= 10 and decided_cheaply >= 20           # both branches were exercised
+
+
+def test_breadth_first_host_logic_against_the_oracle_without_a_gpu(monkeypatch):
+    """icsg3d_amd.watershed.segment_nuclei_batch / _assemble / refine bookkeeping are HOST logic: with the two device
+    primitives replaced by the oracle's own routines (label_equal, split_component) the breadth-first batch must return
+    the oracle's depth-first R, visiting order and failures -- on CPU."""
+    from scipy.spatial import QhullError
+    import icsg3d_amd.watershed as P
+
+    def label_boxes(vols, connectivity=1, max_labels=1024):
+        out = []
+        for v in vols:
+            lab, n = W.label_equal(v, connectivity=connectivity)
+            stats = np.zeros((n, 7), np.int32)
+            for cl in range(1, n + 1):
+                m = lab == cl
+                stats[cl - 1] = (int(m.sum()),) + W.bbox_of(m)
+            out.append((lab, n, stats))
+        return out
+
+    monkeypatch.setattr(P, "label_boxes", label_boxes)
+    monkeypatch.setattr(P, "watershed_split", lambda boxes, cls, tie="heap": [W.split_component(b, c, tie=tie).astype(np.int32)
+                                                                             for b, c in zip(boxes, cls)])
+    rng = np.random.default_rng(31)
+    vols = [_balls(24, [((7, 7, 5), 4), ((7, 7, 11), 4), ((7, 13, 8), 4), ((17, 17, 17), 4)]),
+            _balls(24, [((8, 8, 8), 3), ((16, 15, 10), 3)]),
+            (rng.uniform(size=(16, 16, 16)) < 0.3).astype(np.int32)]
+    for mode in ("solid", "raise"):
+        traces = [[] for _ in vols]
+        Rs, errors = P.segment_nuclei_batch(vols, traces=traces, degenerate=mode)
+        for i, v in enumerate(vols):
+            tr = []
+            try:
+                R_ref = W.segment_nuclei(v, trace=tr, degenerate=mode)
+            except QhullError:
+                assert errors[i] is not None and Rs[i] is None
+                continue
+            assert errors[i] is None and np.array_equal(Rs[i], R_ref), (mode, i)
+            assert [(t[0], t[1], t[2], t[4]) for t in traces[i]] == [(t[0], t[1], t[2], t[4]) for t in tr]
+    assert any(t[4] in ("recurse", "split") for t in traces[0])
+    # the single-volume wrapper and the depth-first form give the same thing
+    assert np.array_equal(P.segment_nuclei(vols[0]), P._segment_nuclei_recursive(vols[0]))
