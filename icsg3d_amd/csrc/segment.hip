@@ -404,6 +404,12 @@ __global__ __launch_bounds__(1024) void ws_split_kernel(const int* __restrict__ 
                                                          int* __restrict__ wss_out) {
   __shared__ int s_flag;
   __shared__ int s_scan[1024];
+  // The flood is sequential (one thread emulates skimage's heap operation by operation); with its heap and label array in
+  // global memory every step was a chain of L2 round trips (38 ms for the slowest box of a level).  Boxes of up to
+  // kWsLdsVox voxels -- every realistic atom pair; the whole-sample blobs of random-weight masks do not fit -- run it in LDS:
+  // key [V] | index [V] | labels [V] = 12 bytes per voxel.
+  constexpr int kWsLdsVox = 12288;
+  __shared__ unsigned s_mem[3 * kWsLdsVox];
   const BoxDesc d = desc[blockIdx.x];
   const int D = d.D, H = d.H, W = d.W, V = D * H * W, tid = threadIdx.x, nt = blockDim.x, cl = d.cl;
   const int* val = boxes + d.off;
@@ -440,33 +446,46 @@ __global__ __launch_bounds__(1024) void ws_split_kernel(const int* __restrict__ 
   __syncthreads();
   const bool flood = s_flag != 0;
   (void)cl;
+  const bool in_lds = V <= kWsLdsVox;
+  int* fl = in_lds ? reinterpret_cast<int*>(s_mem + 2 * V) : out;     // the label array the flood works on
+  if (flood && in_lds) {
+    for (int i = tid; i < V; i += nt) fl[i] = ld_i(out + i);
+    __syncthreads();
+  }
   if (flood && tid == 0) {
     // sequential priority flood (skimage _watershed_cy.pyx, restated in oracle/watershed_ref.py::watershed_flood)
-    WsHeap hp{heap_mem + d.heap_off * 2, heap_mem + d.heap_off * 2 + V, 0};
+    WsHeap hp{in_lds ? s_mem : heap_mem + d.heap_off * 2, in_lds ? s_mem + V : heap_mem + d.heap_off * 2 + V, 0};
     // key = (image level << 31) | age: two image values (0 < cl), every marker enters with age 0 in raster order.
     // FIFO tie rule (tie = 1): the markers carry their raster rank instead, and real ages start above every rank.
+    // (only this thread touches fl from here to the barrier: plain accesses, in LDS or -- large boxes -- through L2)
+    auto ldl = [&](int i) { return in_lds ? fl[i] : ld_i(fl + i); };
+    auto stl = [&](int i, int v) { if (in_lds) fl[i] = v; else st_i(fl + i, v); };
     unsigned seq = 0;
     for (int i = 0; i < V; ++i)
-      if (ld_i(out + i) != 0) hp.push(((val[i] != 0 ? 1u : 0u) << 31) | (tie ? seq++ : 0u), (unsigned)i);
+      if (ldl(i) != 0) hp.push(((val[i] != 0 ? 1u : 0u) << 31) | (tie ? seq++ : 0u), (unsigned)i);
     unsigned age = tie ? (unsigned)V + 1u : 1u;
     const int nb[6] = {-H * W, -W, -1, 1, W, H * W};
     while (hp.n > 0) {
       const int i = (int)hp.pop();
       const int x = i % W, y = (i / W) % H, z = i / (W * H);
       const bool ok[6] = {z > 0, y > 0, x > 0, x < W - 1, y < H - 1, z < D - 1};
-      const int li = ld_i(out + i);
+      const int li = ldl(i);
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
         if (!ok[k]) continue;
         const int j = i + nb[k];
-        if (ld_i(out + j) != 0) continue;
+        if (ldl(j) != 0) continue;
         ++age;
-        st_i(out + j, li);
+        stl(j, li);
         hp.push(((val[j] != 0 ? 1u : 0u) << 31) | age, (unsigned)j);
       }
     }
   }
   __syncthreads();
+  if (flood && in_lds) {
+    for (int i = tid; i < V; i += nt) st_i(out + i, fl[i]);
+    __syncthreads();
+  }
   for (int i = tid; i < V; i += nt) {
     const int m = ld_i(out + i);
     st_i(out + i, m == 1 ? 0 : m);                 // wss[wss == 1] = 0
