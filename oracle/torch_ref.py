@@ -126,8 +126,9 @@ def unet_forward(x, p, training, ties="tf_cpu", stats=None):
     return torch.softmax(zs, 1), torch.sigmoid(zg)
 
 
-def unet_loss(soft, sig, labels, num_classes=95, weight=None):
-    """[Loss, lsoft, lsig] as torch scalars (unet/unet.py:211-219,252-256)."""
+def unet_loss(soft, sig, labels, num_classes=95, weight=None, bce_from_logits=False):
+    """[Loss, lsoft, lsig] as torch scalars (unet/unet.py:211-219,252-256).  bce_from_logits: the sigmoid head's loss in
+    TF 2.1's short-circuit form, sigmoid_cross_entropy_with_logits on the head's logits (confidence M)."""
     weight = float(num_classes) if weight is None else weight
     lab = torch.as_tensor(labels.astype(np.int64))
     y = F.one_hot(lab, num_classes).permute(0, 4, 1, 2, 3).to(soft.dtype)
@@ -135,17 +136,20 @@ def unet_loss(soft, sig, labels, num_classes=95, weight=None):
     q = soft / soft.sum(1, keepdim=True)
     qc = torch.clamp(q, K_EPS, 1 - K_EPS)
     lsoft = (-(y * torch.log(qc) * weight).sum(1)).mean(dim=(1, 2, 3)).mean()
-    pc = torch.clamp(sig, K_EPS, 1 - K_EPS)
-    lsig = (-(t * torch.log(pc) + (1 - t) * torch.log(1 - pc))).mean()
+    if bce_from_logits:
+        lsig = F.binary_cross_entropy_with_logits(torch.logit(sig), t)       # logit(sigmoid(z)) = z
+    else:
+        pc = torch.clamp(sig, K_EPS, 1 - K_EPS)
+        lsig = (-(t * torch.log(pc) + (1 - t) * torch.log(1 - pc))).mean()
     return lsoft + lsig, lsoft, lsig
 
 
-def unet_step_grads(P, S, x, labels, dtype=torch.float64, ties="tf_cpu", num_classes=95):
+def unet_step_grads(P, S, x, labels, dtype=torch.float64, ties="tf_cpu", num_classes=95, bce_from_logits=False):
     """Returns (metrics[3], grads dict (numpy, Keras layouts), bn batch stats)."""
     p = Params(P, S, dtype)
     stats = {}
     soft, sig = unet_forward(to_t(x, dtype), p, True, ties, stats)
-    loss, lsoft, lsig = unet_loss(soft, sig, labels, num_classes)
+    loss, lsoft, lsig = unet_loss(soft, sig, labels, num_classes, bce_from_logits=bce_from_logits)
     loss.backward()
     return (np.array([loss.item(), lsoft.item(), lsig.item()]), p.grads_numpy(), stats,
             to_n(soft), to_n(sig))

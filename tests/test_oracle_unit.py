@@ -112,3 +112,24 @@ def test_bce_logits_form_matches_clipped_form_away_from_saturation_and_its_gradi
     w = rng.normal(size=z.shape[:-1])
     g = R.bce_logits_bwd(t, z, w)
     np.testing.assert_allclose(g, fd(lambda: float((R.bce_logits_loss(t, z) * w).sum()), z), rtol=1e-6, atol=1e-9)
+
+
+def test_numpy_oracle_bce_from_logits_matches_independent_torch_autograd():
+    """The switch's oracle path is pinned the way the default path is: the fp64 numpy restatement against torch-CPU autograd
+    (oracle/torch_ref.py, an independent implementation) -- metrics and every gradient tensor of one U-Net step, d = 8."""
+    from oracle import torch_ref as T
+    B, d = 2, 8
+    orc = R.UnetOracle(in_ch=1, seed=1, lr=1e-3, pool_ties="first", bce_from_logits=True)
+    X, lab, _ = R.synthetic_batch(B, d, 1, seed=0, dtype=np.float64)
+    X = X + 1e-3 * np.random.default_rng(5).uniform(size=X.shape)
+    orc.P["sig/kernel"] = orc.P["sig/kernel"] * 3.0           # logits up to ~ +-10 (torch.logit(sigmoid(z)) stays finite in fp64)
+    P0 = {k: v.copy() for k, v in orc.P.items()}
+    S0 = {k: v.copy() for k, v in orc.S.items()}
+    m_t, g_t, _, _, sig_t = T.unet_step_grads(P0, S0, X, lab, ties="first", bce_from_logits=True)
+    m_c, _, _, _, _ = T.unet_step_grads(P0, S0, X, lab, ties="first", bce_from_logits=False)
+    m = orc.train_on_batch(X, lab)
+    np.testing.assert_allclose(m[:3], m_t, rtol=1e-10)
+    zmax = np.abs(np.log(sig_t / (1 - sig_t))).max()
+    assert 3 < zmax < 30 and abs(m_t[2] - m_c[2]) > 1e-12 * m_t[2], (zmax, m_t[2], m_c[2])
+    for k, g in g_t.items():
+        np.testing.assert_allclose(orc.last_grads[k], g, rtol=1e-7, atol=1e-12 * max(np.abs(g).max(), 1e-30) + 1e-14, err_msg=k)
