@@ -48,31 +48,43 @@ PMC_TRAFFIC_FILES = ("r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traff
 
 def cpu_baseline(batch=32, d=32):
     """oracle/torch_ref.py (fp32 torch-CPU restatement of the same train steps, all host cores) in a subprocess -- the
-    checker timed as a baseline, never the product path.  The sample is the GPU figure's own batch: one warm-up step at 8
-    grids (thread pools, allocator), then ONE timed U-Net train step at `batch` grids (`value`) and ONE timed DFC-VAE train
-    step at `batch` grids (`vae`).  ~20 s + ~5 s on the GPU box's 128 cores; bounded by a 900 s timeout."""
+    checker timed as a baseline, never the product path.  The sample is the GPU figure's own batch.  Every leg gets one
+    untimed warm-up call of its own kind first (oneDNN primitives, allocator, thread pools, scipy import: ADVICE r5), then
+    the MEDIAN of 3 timed U-Net train steps at `batch` grids (`value`) and of 3 timed DFC-VAE train steps (`vae`), and of 2
+    timed calls for the two inference legs; min / max are reported next to each median.
+    ~60 s + ~20 s + ~15 s on the GPU box's 128 cores; bounded by a 1500 s timeout."""
     code = ("import json,sys; sys.path.insert(0, %r); from oracle import torch_ref as T; "
+            "r = {}; "
             "T.time_unet_train_step(B=8, d=%d, in_ch=1, steps=1, warmup=0); "
-            "v,c,s = T.time_unet_train_step(B=%d, d=%d, in_ch=1, steps=1, warmup=0); "
-            "vv,c,sv = T.time_vae_train_step(B=%d, d=%d, in_ch=1, steps=1, warmup=0); "
-            "vp,c,sp = T.time_unet_predict(B=16, d=%d, in_ch=1, steps=1, warmup=0); "
-            "vg,c,sg = T.time_generate_tail(B=%d, d=%d, in_ch=1); "
-            "print(json.dumps({'v': v, 's': s, 'vv': vv, 'sv': sv, 'vp': vp, 'sp': sp, 'vg': vg, 'sg': sg, 'cores': c}))"
-            % (ROOT, d, batch, d, batch, d, d, batch, d))
+            "v,c,s = T.time_unet_train_step(B=%d, d=%d, in_ch=1, steps=3, warmup=0); r['u'] = T.time_unet_train_step.samples; "
+            "T.time_vae_train_step(B=8, d=%d, in_ch=1, steps=1, warmup=0); "
+            "vv,c,sv = T.time_vae_train_step(B=%d, d=%d, in_ch=1, steps=3, warmup=0); r['v'] = T.time_vae_train_step.samples; "
+            "vp,c,sp = T.time_unet_predict(B=16, d=%d, in_ch=1, steps=2, warmup=1); r['p'] = T.time_unet_predict.samples; "
+            "vg,c,sg = T.time_generate_tail(B=%d, d=%d, in_ch=1, steps=2, warmup=1); r['g'] = T.time_generate_tail.samples; "
+            "r.update({'v_': v, 's': s, 'vv': vv, 'sv': sv, 'vp': vp, 'sp': sp, 'vg': vg, 'sg': sg, 'cores': c}); "
+            "print(json.dumps(r))"
+            % (ROOT, d, batch, d, d, batch, d, d, batch, d))
     try:
-        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1500)
         r = json.loads(out.stdout.strip().splitlines()[-1])
-        return {"value": round(r["v"], 4), "unit": "voxel-grids/s", "cores": int(r["cores"]), "kind": "port",
-                "vae": {"value": round(r["vv"], 4), "unit": "voxel-grids/s", "s_per_step": round(r["sv"], 2)},
-                "predict": {"value": round(r["vp"], 4), "unit": "voxel-grids/s", "s_per_call": round(r["sp"], 2)},
-                "generate": {"value": round(r["vg"], 4), "unit": "voxel-grids/s", "s_per_call": round(r["sg"], 2)},
-                "sample": "oracle/torch_ref.py fp32, torch-CPU channels_last_3d, all host cores: one untimed warm-up step "
-                          "at 8 grids, then ONE timed U-Net fwd+bwd+Adam step on %d synthetic %d^3 grids (%.1f s; `value`, "
-                          "the batch the GPU figure is quoted on), ONE timed DFC-VAE train step on %d grids (%.1f s; `vae`), "
-                          "ONE timed U-Net forward on 16 grids (%.1f s; `predict`, BASELINE configs[0]) and ONE generate tail on "
-                          "%d latent vectors (decoder + U-Net forward + argmax / threshold + scipy.ndimage components, %.1f s; "
-                          "`generate`).  The reference's Keras/TF path is not installable here"
-                          % (batch, d, r["s"], batch, r["sv"], r["sp"], batch, r["sg"])}
+
+        def leg(value, sec, samples, key):
+            return {"value": round(value, 4), "unit": "voxel-grids/s", key: round(sec, 2), "samples": len(samples),
+                    "s_min": round(min(samples), 2), "s_max": round(max(samples), 2)}
+        u = leg(r["v_"], r["s"], r["u"], "s_per_step")
+        return {"value": u["value"], "unit": "voxel-grids/s", "cores": int(r["cores"]), "kind": "port",
+                "s_per_step": u["s_per_step"], "samples": u["samples"], "s_min": u["s_min"], "s_max": u["s_max"],
+                "vae": leg(r["vv"], r["sv"], r["v"], "s_per_step"),
+                "predict": leg(r["vp"], r["sp"], r["p"], "s_per_call"),
+                "generate": leg(r["vg"], r["sg"], r["g"], "s_per_call"),
+                "sample": "oracle/torch_ref.py fp32, torch-CPU channels_last_3d, all host cores; each leg after one untimed "
+                          "warm-up call of its own kind: MEDIAN of 3 timed U-Net fwd+bwd+Adam steps on %d synthetic %d^3 grids "
+                          "(%.1f s, min %.1f / max %.1f; `value`, the batch the GPU figure is quoted on), median of 3 timed "
+                          "DFC-VAE train steps on %d grids (%.1f s; `vae`), median of 2 U-Net forwards on 16 grids (%.1f s; "
+                          "`predict`, BASELINE configs[0]) and of 2 generate tails on %d latent vectors (decoder + U-Net forward "
+                          "+ argmax / threshold + scipy.ndimage components, threshold fixed beforehand, %.1f s; `generate`).  "
+                          "The reference's Keras/TF path is not installable here"
+                          % (batch, d, r["s"], min(r["u"]), max(r["u"]), batch, r["sv"], r["sp"], batch, r["sg"])}
     except Exception as e:  # pragma: no cover
         return {"value": None, "unit": "voxel-grids/s", "cores": os.cpu_count(), "kind": "port",
                 "sample": "cpu baseline failed: %s" % e}
@@ -120,7 +132,12 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="grids per GPU")
-    ap.add_argument("--d", type=int, default=32)
+    ap.add_argument("--d", "--dim", dest="d", type=int, default=32,
+                    help="grid edge (torch.distributed.run's own parser rejects --d as an ambiguous abbreviation: the "
+                         "self-launch forwards it as --dim)")
+    ap.add_argument("--soak-seconds", type=float, default=10.0,
+                    help="after the timed region: the same U-Net step for at least this long, reported as `sustained` "
+                         "(never `value`); 0 skips it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the DFC-VAE block (profiling runs)")
     ap.add_argument("--workload", choices=("unet", "vae", "joint", "predict", "generate"), default="unet",
@@ -142,6 +159,11 @@ def main():
     if world != args.gpus:
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # hang protection: no beat for ICSG3D_WATCHDOG_S (120) seconds -> this rank says where it is and exits 3; under
+    # torch.distributed.run that ends the job with a non-zero status instead of holding the node (icsg3d_amd/watchdog.py)
+    from icsg3d_amd.watchdog import StepWatchdog
+    wd = StepWatchdog()
+    wd.beat("library load / device %d" % local_rank)
 
     # the engine binds system ROCm; load it before anything else can pull in another HIP runtime
     from icsg3d_amd import _lib
@@ -166,6 +188,7 @@ def main():
         os.dup2(2, 1)
         import torch  # noqa: F401  (control plane only: gloo rendezvous, barrier, max-reduce)
         import torch.distributed as dist
+        wd.beat("gloo rendezvous")
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
     B, d, C = args.batch, args.d, 1
@@ -184,14 +207,18 @@ def main():
         """W warm-up steps, then EXACTLY K steps between barrier + device sync on both sides; max over ranks.
         step_profile: the step of the untimed all-events pass when it must differ (joint: the two engines serialised, so
         that a kernel's event bracket does not time a kernel of the other stream it shares the chip with)."""
-        def barrier():
+        def barrier(where="barrier"):
+            wd.beat(where + ": device sync")
             for e in engines:
                 e.sync()
             if dist is not None:
+                wd.beat(where + ": gloo barrier")
                 dist.barrier()
+            wd.beat(where + ": done")
+        wd.beat("warm-up steps")
         for _ in range(args.warmup):
             step()
-        barrier()
+        barrier("after warm-up")
         # untimed profiling pass: HIP events around EVERY launch (on the stream it is launched on) -> the per-kernel
         # table and the dominant kernel with its launch sites
         for e in profiled:
@@ -199,7 +226,7 @@ def main():
             e.profile_enable(True)
         for _ in range(2):
             (step_profile or step)()
-        barrier()
+        barrier("after the all-events pass")
         rows_all = [r for e in profiled for r in e.profile_rows()]
         for r in rows_all:
             r["ms"] /= 2.0; r["flop"] /= 2.0; r["bytes"] /= 2.0; r["launches"] //= 2     # per step
@@ -217,14 +244,15 @@ def main():
         for e in profiled:
             e.profile_filter(prefix)
             e.profile_enable(True)
-        barrier()
+        barrier("before the timed steps")
         t0 = time.perf_counter()
         for e in engines:
             e.timer_start()              # an event on each engine's stream: the GPU's own clock over the same K steps
         for _ in range(args.steps):
             step()
+        wd.beat("timed steps enqueued: waiting for the device")
         gpu_ms = max(e.timer_stop() for e in engines)
-        barrier()
+        barrier("after the timed steps")
         elapsed = max_over_ranks(time.perf_counter() - t0)
         timed.gpu_active_s = gpu_ms * 1e-3
         rows = [r for e in profiled for r in e.profile_rows()]
@@ -238,15 +266,45 @@ def main():
                 f.write(json.dumps({"steps": args.steps, "rows": rows}) + "\n")
         # the same K steps without the per-launch events (what a training job sees); the library counts every kernel
         # it enqueues (ics_kernel_launches): the per-step difference is the number rocprofv3 --kernel-trace shows
-        barrier()
+        barrier("before the events-off steps")
         n0 = lib.ics_kernel_launches()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
-        barrier()
+        barrier("after the events-off steps")
         elapsed_plain = max_over_ranks(time.perf_counter() - t0)
         timed.kernel_launches_per_step = (lib.ics_kernel_launches() - n0) / float(args.steps)
         return elapsed, elapsed_plain, rows, rows_all
+
+    def soak(step, engines, ms_per_step):
+        """the timed region is 20 steps = 0.56 s -- too short for the driver's GPU sampler to see and too
+        short to say what the chip does after ten seconds at 100 TFLOP/s.  The same step, events off, for >= --soak-seconds,
+        between the same barriers, on the host clock and on the GPU's own; reported as `sustained`, never as `value`."""
+        n = max(args.steps, int(args.soak_seconds / max(ms_per_step * 1e-3, 1e-6)) + 1)
+        wd.beat("sustained soak: %d steps" % n)
+        for e in engines:
+            e.sync()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for e in engines:
+            e.timer_start()
+        for i in range(n):
+            step()
+            if i % 64 == 63:
+                wd.beat("sustained soak: step %d of %d enqueued" % (i + 1, n))
+        gpu_ms = max(e.timer_stop() for e in engines)
+        for e in engines:
+            e.sync()
+        if dist is not None:
+            wd.beat("sustained soak: gloo barrier")
+            dist.barrier()
+        sec = max_over_ranks(time.perf_counter() - t0)
+        wd.beat("sustained soak done")
+        return {"steps": n, "seconds": round(sec, 3), "ms_per_step": round(sec / n * 1e3, 3),
+                "gpu_active_s": round(gpu_ms * 1e-3, 4), "value": round(world * B * n / sec, 2), "unit": "voxel-grids/s",
+                "note": "the same train step, no events, run back to back for >= %.0f s after the timed region "
+                        "(sustained clocks; visible to a coarse GPU-utilisation sampler); not `value`" % args.soak_seconds}
 
     out = None
     unet = None
@@ -264,6 +322,8 @@ def main():
         elapsed, elapsed_plain, rows_live, rows = timed(lambda: unet.train_step_resident(False), [unet], [unet])
         unet_launches = timed.kernel_launches_per_step
         gpu_active_s = timed.gpu_active_s
+        sustained = soak(lambda: unet.train_step_resident(False), [unet], elapsed_plain / args.steps * 1e3) \
+            if args.soak_seconds > 0 else None
         metrics = unet.train_step_resident(True)   # untimed: sanity that the job is still finite
         if not np.all(np.isfinite(metrics)):
             raise SystemExit("non-finite training metrics: %s" % metrics)
@@ -297,6 +357,7 @@ def main():
                 # the K timed steps on the GPU's own clock (HIP events on the engine's stream around the same region):
                 # ms_per_step must agree with gpu_active_s / steps, or the host clock timed something else
                 "gpu_active_s": round(gpu_active_s, 5),
+                "sustained": sustained,
                 "config": {"workload": "AtomUnet fwd+bwd+Adam train step, %d x %d^3 x 1 grids per GPU "
                                        "(BASELINE.json configs[1]; the metric's VAE half is timed right after as "
                                        "`secondary` = configs[2], and `unet_plus_vae` is one U-Net step + one DFC-VAE step "
@@ -513,6 +574,7 @@ def main():
         out.update({k: v for k, v in blk.items() if k != "workload"})
         out["ms_per_step"] = out["ms_per_call"]
         if not args.no_cpu_baseline:
+            wd.pause("CPU baseline subprocess (no collective in it)")
             cb = cpu_baseline(B, d)
             out["cpu_baseline"] = {"value": cb.get(args.workload, {}).get("value"), "unit": "voxel-grids/s", "cores": cb["cores"],
                                    "kind": "port", "sample": cb["sample"]}
@@ -609,6 +671,7 @@ def main():
         out["inference"] = {"predict": predict_block(unet), "generate": generate_block(unet)}
     if rank == 0:
         if args.workload == "unet" and world == 1 and not args.no_cpu_baseline:
+            wd.pause("CPU baseline subprocess (no collective in it)")
             out["cpu_baseline"] = cpu_baseline(B, d)
             if "secondary" in out and out["cpu_baseline"].get("vae"):
                 out["secondary"]["cpu_baseline"] = out["cpu_baseline"]["vae"]
@@ -622,8 +685,10 @@ def main():
         else:
             sys.stdout.write(line)
     if dist is not None:
+        wd.beat("final gloo barrier")
         dist.barrier()
         dist.destroy_process_group()
+    wd.stop()
 
 
 if __name__ == "__main__":

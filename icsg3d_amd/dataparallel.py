@@ -67,9 +67,15 @@ class DataParallelMixin:
     already reduced over the ranks, so every rank takes the same checkpoint decisions and only rank 0 writes."""
 
     _dp = None
+    _wd = None
 
     def enable_data_parallel(self, dist, rank: int, world: int, sync_bn: bool = False, force: bool = False):
         self._dp = (dist, int(rank), int(world), bool(sync_bn), bool(force))
+        if self._wd is None:
+            # hang protection (icsg3d_amd/watchdog.py): a step that does not return within ICSG3D_WATCHDOG_S seconds ends
+            # this rank with a message instead of holding every GPU of the job in a collective for ever
+            from .watchdog import StepWatchdog
+            self._wd = StepWatchdog(rank=int(rank))
         if getattr(self, "_eng", None) is not None:
             self._dp_attach(self._eng)
         return self
@@ -90,6 +96,10 @@ class DataParallelMixin:
                     raise RuntimeError("data parallel: ranks built engines for different batch sizes %s; shard the "
                                        "ids with shard_ids() so that every rank sees the same batches" % sizes)
             init_engine_comm(engine, dist, rank, world, sync_bn=sync_bn, force=force)
+
+    def _dp_beat(self, where: str):
+        if self._wd is not None:
+            self._wd.beat(where)
 
     def _dp_is_writer(self) -> bool:
         return self._dp is None or self._dp[1] == 0

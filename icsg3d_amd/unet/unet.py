@@ -137,10 +137,12 @@ class _UnetModel:
     # -- training steps
     def train_on_batch(self, X, y):
         labels = _to_labels(y[0] if isinstance(y, (list, tuple)) else y, self._o.num_classes)
+        self._o._dp_beat("AtomUnet train_on_batch")
         return [float(v) for v in self._o._engine(len(X), grow=True).train_step(X, labels)]
 
     def test_on_batch(self, X, y):
         labels = _to_labels(y[0] if isinstance(y, (list, tuple)) else y, self._o.num_classes)
+        self._o._dp_beat("AtomUnet test_on_batch")
         return [float(v) for v in self._o._engine(len(X), grow=True).test_step(X, labels)]
 
     def fit_generator(self, generator, validation_data=None, epochs=1, callbacks=None, workers=4,
@@ -202,7 +204,10 @@ class _UnetModel:
 
 
 class _BestCheckpoint:
-    """ModelCheckpoint(filepath, monitor="val_loss", save_best_only=True, mode="min")."""
+    """ModelCheckpoint(filepath, monitor="val_loss", save_best_only=True, mode="min") (/root/reference/unet/unet.py:361-367).
+    The reference does not set save_weights_only, so Keras writes the FULL model (model_config + training_config +
+    model_weights/...) into the ".best.hdf5" path; so does this (model.save), and load_weights reads either layout, as
+    Keras' does (unet.py:378)."""
 
     def __init__(self, model, filepath):
         self.model, self.filepath, self.best = model, filepath, np.inf
@@ -215,7 +220,7 @@ class _BestCheckpoint:
                       % (epoch + 1, self.best, v, self.filepath))
             self.best = v
             if self.model._o._dp_is_writer():        # data parallel: same decision on every rank, rank 0 writes
-                self.model.save_weights(self.filepath)
+                self.model.save(self.filepath)
 
 
 class AtomUnet(DataParallelMixin):

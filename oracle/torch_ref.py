@@ -43,6 +43,78 @@ def kernel_grad_n(g):        # (Cout,Cin,kd,kh,kw) -> (kd,kh,kw,Cin,Cout)
     return np.ascontiguousarray(np.transpose(g.detach().numpy(), (2, 3, 4, 1, 0)))
 
 
+# ------------------------------------------------------------------------------ fp64 convolution as GEMMs
+# torch's fp64 conv3d on CPU parallelises over the batch only and took 168 s for one U-Net step at B = 32 on the GPU box's
+# 128 cores (round 6, first run of tests/test_gpu_fullsize_oracle.py).  The same sums as 9 GEMMs per layer -- one per (dz, dy)
+# tap pair, the three dx taps side by side in K -- run on MKL's threaded dgemm.  Same definition as F.conv3d (cross-
+# correlation, zero "same" padding, unet/unet.py:276-336); tests/test_oracle_pinned_torch.py holds the two to 1e-12.
+GEMM_CONV_MIN_WORK = 2e9      # multiply-adds from which conv3d() takes the GEMM form (fp64 only); 0 forces it, inf disables
+
+
+def _tap_cols(xp, dz, dy, B, D, H, W, C):
+    """(B*D*H*W, 3C): for every output voxel the three x-neighbours of tap row (dz, dy) of the padded NDHWC tensor."""
+    v = xp[:, dz:dz + D, dy:dy + H]                       # (B, D, H, W + 2, C), C contiguous
+    st = v.stride()
+    return v.as_strided((B, D, H, W, 3 * C), (st[0], st[1], st[2], st[3], 1)).reshape(B * D * H * W, 3 * C)
+
+
+def _conv_gemm_fwd(x, w):
+    """x (B, Cin, D, H, W), w (Cout, Cin, 3, 3, 3) -> (B, Cout, D, H, W) (a permuted view of an NDHWC result)."""
+    B, C, D, H, W = x.shape
+    Co = w.shape[0]
+    xp = F.pad(x.permute(0, 2, 3, 4, 1), (0, 0, 1, 1, 1, 1, 1, 1)).contiguous()
+    wk = w.permute(2, 3, 4, 1, 0).contiguous()            # (3, 3, 3, Cin, Cout)
+    y = x.new_zeros(B * D * H * W, Co)
+    for dz in range(3):
+        for dy in range(3):
+            y.addmm_(_tap_cols(xp, dz, dy, B, D, H, W, C), wk[dz, dy].reshape(3 * C, Co))
+    return y.view(B, D, H, W, Co).permute(0, 4, 1, 2, 3)
+
+
+def _conv_gemm_wgrad(x, dy):
+    B, C, D, H, W = x.shape
+    Co = dy.shape[1]
+    xp = F.pad(x.permute(0, 2, 3, 4, 1), (0, 0, 1, 1, 1, 1, 1, 1)).contiguous()
+    dyf = dy.permute(0, 2, 3, 4, 1).reshape(B * D * H * W, Co)
+    dw = x.new_empty(3, 3, 3 * C, Co)
+    for dz in range(3):
+        for dy_ in range(3):
+            torch.mm(_tap_cols(xp, dz, dy_, B, D, H, W, C).t(), dyf, out=dw[dz, dy_])
+    return dw.view(3, 3, 3, C, Co).permute(4, 3, 0, 1, 2).contiguous()
+
+
+class _Conv3dGemm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return _conv_gemm_fwd(x, w) + b.view(1, -1, 1, 1, 1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx = _conv_gemm_fwd(dy, w.flip(2, 3, 4).transpose(0, 1)) if ctx.needs_input_grad[0] else None
+        dw = _conv_gemm_wgrad(x, dy) if ctx.needs_input_grad[1] else None
+        db = dy.sum((0, 2, 3, 4)) if ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
+def conv3d(x, w, b):
+    """3x3x3 "same" convolution + bias: F.conv3d, or the GEMM form above for large fp64 problems."""
+    work = float(x.shape[0]) * x.shape[2] * x.shape[3] * x.shape[4] * 27 * w.shape[0] * w.shape[1]
+    if x.dtype == torch.float64 and work >= GEMM_CONV_MIN_WORK:
+        return _Conv3dGemm.apply(x, w, b)
+    return F.conv3d(x, w, b, padding=1)
+
+
+def conv1(x, w, b):
+    """1x1x1 convolution (the two heads, unet/unet.py:339-352): one matmul over the channel axis for large fp64 inputs."""
+    if x.dtype == torch.float64 and x.numel() * w.shape[0] >= GEMM_CONV_MIN_WORK:
+        B, C, D, H, W = x.shape
+        y = x.permute(0, 2, 3, 4, 1).reshape(-1, C) @ w.view(w.shape[0], C).t() + b
+        return y.view(B, D, H, W, -1).permute(0, 4, 1, 2, 3)
+    return F.conv3d(x, w, b)
+
+
 class Params:
     """Holds torch leaf tensors converted from the oracle's name->numpy dict."""
 
@@ -66,13 +138,17 @@ class Params:
         return out
 
 
-def maxpool(x, ties):
+def maxpool(x, ties, route=None):
+    """route: optional tensor to take the routing decision from (the tested implementation's own pool input, Pins.route)."""
     y = F.max_pool3d(x, 2)
     if ties == "first":
+        if route is not None:
+            raise ValueError("pinned routing is implemented for the tf_cpu tie rule")
         return y
     # TF-CPU MaxPool3DGrad semantics: gradient to every element within 1e-5 of the window max
-    up = F.interpolate(y.detach(), scale_factor=2, mode="nearest")
-    mask = ((x.detach() - up).abs() < 1e-5).to(x.dtype)
+    r = x.detach() if route is None else route
+    up = F.interpolate(F.max_pool3d(r, 2), scale_factor=2, mode="nearest")
+    mask = ((r - up).abs() < 1e-5).to(x.dtype)
     routed = F.avg_pool3d(x * mask, 2) * 8.0
     return y.detach() + routed - routed.detach()
 
@@ -83,6 +159,73 @@ def act(x, kind):
     if kind == "relu":
         return F.relu(x)
     return F.leaky_relu(x, LEAKY)
+
+
+# ------------------------------------------------------------------------------ pinned decisions (fp32 implementation under test)
+class _PinnedAct(torch.autograd.Function):
+    """ReLU / LeakyReLU whose DERIVATIVE takes the side of the kink from `impl` (the tested implementation's value at the same
+    place) instead of from x: act'(0) is a discontinuity, and an fp32 implementation legitimately lands a handful of
+    pre-activations on the other side of it than fp64 does (numpy_ref.apply_kink is the same device for the numpy oracle)."""
+
+    @staticmethod
+    def forward(ctx, x, impl, slope):
+        ctx.save_for_backward(impl > 0)
+        ctx.slope = slope
+        return torch.where(x > 0, x, slope * x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (pos,) = ctx.saved_tensors
+        return torch.where(pos, dy, ctx.slope * dy), None, None
+
+
+class _PinnedClamp(torch.autograd.Function):
+    """K.clip(x, lo, hi) whose zero-gradient region is given (`inside`, 0/1) instead of derived from x."""
+
+    @staticmethod
+    def forward(ctx, x, inside, lo, hi):
+        ctx.save_for_backward(inside)
+        return torch.clamp(x, lo, hi)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (inside,) = ctx.saved_tensors
+        return dy * inside, None, None, None
+
+
+class Pins:
+    """Decisions of the implementation under test, for a training step of one network.
+    kink   {layer: its stored activation s = pre_act(conv + b), NDHWC float32}
+    affine {layer: (scale32, shift32)} of the layers in front of a max-pool: the implementation's pool input
+           o = act(fma(s, scale, shift)) is rebuilt in fp32 and decides the (equally discontinuous) routing.
+    A decision may differ from the fp64 one only where BOTH values -- the oracle's PRE-activation and the implementation's
+    stored value -- are within `tol` x max(1, max|pre-activation| of the layer) of the kink (forward parity is 1e-5 of the
+    tensor's largest entry, so that is the scale on which an fp32 value may land on the other side); anything else raises.
+    (Stricter than numpy_ref.apply_kink, which sees only post-activation values: for a ReLU layer one of the two is then
+    always 0 and its test `min(|ref|, |impl|) > tol` cannot fire.)  worst[layer] = the largest such relative distance from
+    the kink among the pinned decisions."""
+
+    def __init__(self, kink=None, affine=None, tol=1e-4, dtype=torch.float64):
+        self.kink, self.affine, self.tol, self.dtype = kink or {}, affine or {}, tol, dtype
+        self.flips, self.route, self.worst = {}, {}, {}
+
+    def impl(self, name, like):
+        if name not in self.kink:
+            return None
+        t = to_t(np.asarray(self.kink[name]).reshape(tuple(like.permute(0, 2, 3, 4, 1).shape)), self.dtype)
+        return t
+
+    def count(self, name, ref, impl):
+        """ref: the oracle's value in front of the activation; impl: the implementation's (pre- or post-activation: same sign)."""
+        diff = (impl > 0) != (ref > 0)
+        n = int(diff.sum())
+        if n:
+            dist = torch.maximum(ref.abs(), impl.abs())[diff] / max(1.0, float(ref.abs().max()))
+            self.worst[name] = max(self.worst.get(name, 0.0), float(dist.max()))
+            if self.worst[name] > self.tol:
+                raise AssertionError("activation signs of %s differ away from the kink (%d elements, up to %.3g from it)"
+                                     % (name, int((dist > self.tol).sum()), self.worst[name]))
+        self.flips[name] = self.flips.get(name, 0) + n
 
 
 def bn(x, p, name, training, stats_out=None):
@@ -96,20 +239,49 @@ def bn(x, p, name, training, stats_out=None):
     return F.batch_norm(x, p.s[name + "/moving_mean"], p.s[name + "/moving_var"], g, b, False, 0.0, BN_EPS)
 
 
-def block(x, p, name, pre, has_bn, post, training, taps=None, stats=None):
-    s = act(F.conv3d(x, p.t[name + "/kernel"], p.t[name + "/bias"], padding=1), pre)
+_SLOPE = {"relu": 0.0, "lrelu": LEAKY}
+
+
+def block(x, p, name, pre, has_bn, post, training, taps=None, stats=None, pins=None):
+    y = conv3d(x, p.t[name + "/kernel"], p.t[name + "/bias"])
+    si = pins.impl(name, y) if pins is not None else None
+    if si is None:
+        s = act(y, pre)
+    else:
+        s = y
+        if pre is not None:
+            s = _PinnedAct.apply(y, si, _SLOPE[pre])
+            pins.count(name, y.detach(), si)
     if taps is not None:
         taps[name] = s
     if not has_bn:
         return s
-    return act(bn(s, p, name, training, stats), post)
+    o = bn(s, p, name, training, stats)
+    if si is not None and name in pins.affine:
+        sc, sh = pins.affine[name]
+        view = (1, -1, 1, 1, 1)
+        o32 = (si * torch.as_tensor(np.asarray(sc, np.float64)).view(view)
+               + torch.as_tensor(np.asarray(sh, np.float64)).view(view)).to(torch.float32)
+        pins.route[name] = act(o32, post).to(s.dtype)
+    if si is None or post is None:
+        return act(o, post)
+    if not training:
+        raise ValueError("kink pinning is for training-mode steps")
+    sd = s.detach()
+    mean = sd.mean(dim=(0, 2, 3, 4), keepdim=True)
+    var = ((sd - mean) ** 2).mean(dim=(0, 2, 3, 4), keepdim=True)
+    inv = p.t[name + "/gamma"].detach().view(1, -1, 1, 1, 1) / torch.sqrt(var + BN_EPS)
+    bn_impl = si * inv + (p.t[name + "/beta"].detach().view(1, -1, 1, 1, 1) - mean * inv)
+    pins.count(name, o.detach(), bn_impl)
+    return _PinnedAct.apply(o, bn_impl, _SLOPE[post])
 
 
-def unet_trunk(x, p, training, ties, upto=None, taps=None, stats=None):
-    f = lambda n, t: block(t, p, n, "relu", True, None, training, taps, stats)
-    c2 = f("c2", f("c1", x)); p1 = maxpool(c2, ties)
-    c4 = f("c4", f("c3", p1)); p2 = maxpool(c4, ties)
-    c6 = f("c6", f("c5", p2)); p3 = maxpool(c6, ties)
+def unet_trunk(x, p, training, ties, upto=None, taps=None, stats=None, pins=None):
+    f = lambda n, t: block(t, p, n, "relu", True, None, training, taps, stats, pins)
+    rt = (lambda n: pins.route.get(n)) if pins is not None else (lambda n: None)
+    c2 = f("c2", f("c1", x)); p1 = maxpool(c2, ties, rt("c2"))
+    c4 = f("c4", f("c3", p1)); p2 = maxpool(c4, ties, rt("c4"))
+    c6 = f("c6", f("c5", p2)); p3 = maxpool(c6, ties, rt("c6"))
     c10 = f("c10", f("c9", p3))
     if upto == "c10":
         return c10
@@ -119,84 +291,145 @@ def unet_trunk(x, p, training, ties, upto=None, taps=None, stats=None):
     return f("c18", f("c17", torch.cat([c2, up(c16)], 1)))
 
 
-def unet_forward(x, p, training, ties="tf_cpu", stats=None):
-    c18 = unet_trunk(x, p, training, ties, stats=stats)
-    zs = F.conv3d(c18, p.t["soft/kernel"], p.t["soft/bias"])
-    zg = F.conv3d(c18, p.t["sig/kernel"], p.t["sig/bias"])
+def unet_forward(x, p, training, ties="tf_cpu", stats=None, pins=None):
+    c18 = unet_trunk(x, p, training, ties, stats=stats, pins=pins)
+    zs = conv1(c18, p.t["soft/kernel"], p.t["soft/bias"])
+    zg = conv1(c18, p.t["sig/kernel"], p.t["sig/bias"])
     return torch.softmax(zs, 1), torch.sigmoid(zg)
 
 
-def unet_loss(soft, sig, labels, num_classes=95, weight=None, bce_from_logits=False):
+def _pin_inside(inside, v, pin, tol, what, flips, key):
+    """numpy_ref._pinned_inside: `pin` replaces the clip's inside / outside decision, but only where the clipped quantity is
+    within tol (relative to the bound's distance from the nearer end of [0, 1]) of a bound."""
+    pin = torch.as_tensor(np.asarray(pin, bool)).reshape(inside.shape)
+    diff = pin != inside
+    near = ((v - K_EPS).abs() <= tol * K_EPS) | (((1 - v) - K_EPS).abs() <= tol * K_EPS)
+    if bool((diff & ~near).any()):
+        raise AssertionError("%s: %d clip decisions differ away from the bounds" % (what, int((diff & ~near).sum())))
+    flips[key] = int(diff.sum())
+    return pin
+
+
+def unet_loss(soft, sig, labels, num_classes=95, weight=None, bce_from_logits=False, clip_pin=None, clip_flips=None):
     """[Loss, lsoft, lsig] as torch scalars (unet/unet.py:211-219,252-256).  bce_from_logits: the sigmoid head's loss in
-    TF 2.1's short-circuit form, sigmoid_cross_entropy_with_logits on the head's logits (confidence M)."""
+    TF 2.1's short-circuit form, sigmoid_cross_entropy_with_logits on the head's logits (confidence M).
+    clip_pin: optional {"soft": bool (B,D,H,W), "sig": bool (B,D,H,W)} -- the tested implementation's K.clip decisions
+    ("the true class's probability / the sigmoid output is inside [1e-7, 1 - 1e-7]"), pinned like the ReLU masks."""
     weight = float(num_classes) if weight is None else weight
+    clip_pin = clip_pin or {}
+    clip_flips = {} if clip_flips is None else clip_flips
     lab = torch.as_tensor(labels.astype(np.int64))
     y = F.one_hot(lab, num_classes).permute(0, 4, 1, 2, 3).to(soft.dtype)
     t = (lab != 0).to(soft.dtype).unsqueeze(1)
     q = soft / soft.sum(1, keepdim=True)
-    qc = torch.clamp(q, K_EPS, 1 - K_EPS)
+    if clip_pin.get("soft") is not None:
+        qd = q.detach()
+        inside = (qd >= K_EPS) & (qd <= 1 - K_EPS)
+        qt = (qd * y).sum(1, keepdim=True)                  # only the true class's entry carries a gradient: pin that one
+        it = _pin_inside((qt >= K_EPS) & (qt <= 1 - K_EPS), qt, np.asarray(clip_pin["soft"])[:, None], 0.5,
+                         "softmax clip", clip_flips, "soft_clip")
+        inside = torch.where(y > 0, it, inside)
+        qc = _PinnedClamp.apply(q, inside.to(q.dtype), K_EPS, 1 - K_EPS)
+    else:
+        qc = torch.clamp(q, K_EPS, 1 - K_EPS)
     lsoft = (-(y * torch.log(qc) * weight).sum(1)).mean(dim=(1, 2, 3)).mean()
     if bce_from_logits:
         lsig = F.binary_cross_entropy_with_logits(torch.logit(sig), t)       # logit(sigmoid(z)) = z
     else:
-        pc = torch.clamp(sig, K_EPS, 1 - K_EPS)
+        if clip_pin.get("sig") is not None:
+            sd = sig.detach()
+            inside = _pin_inside((sd >= K_EPS) & (sd <= 1 - K_EPS), sd, np.asarray(clip_pin["sig"])[:, None], 0.5,
+                                 "sigmoid clip", clip_flips, "sig_clip")
+            pc = _PinnedClamp.apply(sig, inside.to(sig.dtype), K_EPS, 1 - K_EPS)
+        else:
+            pc = torch.clamp(sig, K_EPS, 1 - K_EPS)
         lsig = (-(t * torch.log(pc) + (1 - t) * torch.log(1 - pc))).mean()
     return lsoft + lsig, lsoft, lsig
 
 
-def unet_step_grads(P, S, x, labels, dtype=torch.float64, ties="tf_cpu", num_classes=95, bce_from_logits=False):
-    """Returns (metrics[3], grads dict (numpy, Keras layouts), bn batch stats)."""
+def unet_metrics(soft, labels, num_classes=95):
+    """f1_m / wr_m (unet/unet.py:159-193) on torch tensors: K.round is half-to-even (torch.round likewise)."""
+    lab = torch.as_tensor(labels.astype(np.int64))
+    p = soft.detach()
+    y = F.one_hot(lab, num_classes).permute(0, 4, 1, 2, 3).to(p.dtype)
+    yp = torch.round(torch.clamp(y * p, 0, 1))
+    tp, possible, predicted = yp.sum(), y.sum(), torch.round(torch.clamp(p, 0, 1)).sum()
+    precision, recall = tp / (predicted + K_EPS), tp / (possible + K_EPS)
+    f1 = 2 * ((precision * recall) / (precision + recall + K_EPS))
+    wr = yp[:, 1:].sum() / (y[:, 1:].sum() + K_EPS)
+    unet_metrics.counts = {"tp": float(tp), "predicted": float(predicted), "wr_tp": float(yp[:, 1:].sum()),
+                           "wr_possible": float(y[:, 1:].sum()), "voxels": float(possible)}
+    return float(f1), float(wr)
+
+
+def unet_step_grads(P, S, x, labels, dtype=torch.float64, ties="tf_cpu", num_classes=95, bce_from_logits=False,
+                    kink=None, affine=None, clip_pin=None, kink_tol=1e-4, want_outputs=True):
+    """Returns (metrics[3], grads dict (numpy, Keras layouts), bn batch stats, soft, sig).
+    kink / affine / clip_pin: decisions of the implementation under test (Pins, unet_loss); the flips are left in
+    unet_step_grads.flips = {"kink": {layer: n}, "clip": {...}}, f1 / wr in unet_step_grads.f1_wr."""
     p = Params(P, S, dtype)
     stats = {}
-    soft, sig = unet_forward(to_t(x, dtype), p, True, ties, stats)
-    loss, lsoft, lsig = unet_loss(soft, sig, labels, num_classes, bce_from_logits=bce_from_logits)
+    pins = Pins(kink, affine, kink_tol, dtype) if kink else None
+    soft, sig = unet_forward(to_t(x, dtype), p, True, ties, stats, pins)
+    cf = {}
+    loss, lsoft, lsig = unet_loss(soft, sig, labels, num_classes, bce_from_logits=bce_from_logits, clip_pin=clip_pin,
+                                  clip_flips=cf)
     loss.backward()
+    unet_step_grads.flips = {"kink": pins.flips if pins else {}, "clip": cf}
+    unet_step_grads.pin_worst = dict(pins.worst) if pins else {}
+    unet_step_grads.f1_wr = unet_metrics(soft, labels, num_classes)
     return (np.array([loss.item(), lsoft.item(), lsig.item()]), p.grads_numpy(), stats,
-            to_n(soft), to_n(sig))
+            to_n(soft) if want_outputs else None, to_n(sig) if want_outputs else None)
 
 
 # ------------------------------------------------------------------------------ VAE
-def vae_forward(x, cond, eps, pv, training, in_ch, ncond, d, nf=4, stats=None):
+def vae_forward(x, cond, eps, pv, training, in_ch, ncond, d, nf=4, stats=None, pins=None):
     B = x.shape[0]
     ct = cond.reshape(B, ncond, 1, 1, 1).repeat(1, in_ch, d, d, d)     # K.tile quirk: C*cond channels
     h = torch.cat([x, ct], 1)
     for i in range(nf):
-        h = maxpool_first(block(h, pv, "e%d" % i, None, True, "lrelu", training, None, stats), pv)
-    h = block(h, pv, "e4", "lrelu", False, None, training)
+        o = block(h, pv, "e%d" % i, None, True, "lrelu", training, None, stats, pins)
+        h = maxpool(o, _POOL_TIES["mode"], pins.route.get("e%d" % i) if pins is not None else None)
+    h = block(h, pv, "e4", "lrelu", False, None, training, pins=pins)
     flat = h.permute(0, 2, 3, 4, 1).reshape(B, -1)                      # Keras Flatten is (D,H,W,C)
-    hd = F.relu(flat @ pv.t["enc_dense/kernel"] + pv.t["enc_dense/bias"])
+    a = flat @ pv.t["enc_dense/kernel"] + pv.t["enc_dense/bias"]
+    if pins is not None and "enc_dense" in pins.kink:
+        hi = torch.as_tensor(np.asarray(pins.kink["enc_dense"]).reshape(tuple(a.shape)), dtype=a.dtype)
+        hd = _PinnedAct.apply(a, hi, 0.0)
+        pins.count("enc_dense", a.detach(), hi)
+    else:
+        hd = F.relu(a)
     zm = hd @ pv.t["z_mean/kernel"] + pv.t["z_mean/bias"]
     zlv = hd @ pv.t["z_log_var/kernel"] + pv.t["z_log_var/bias"]
     z = zm + torch.exp(0.5 * zlv) * eps
-    recon = vae_decode(z, cond, pv, training, d, nf, stats)
+    recon = vae_decode(z, cond, pv, training, d, nf, stats, pins)
     return zm, zlv, z, recon
 
 
 _POOL_TIES = {"mode": "tf_cpu"}
 
 
-def maxpool_first(x, pv):
-    return maxpool(x, _POOL_TIES["mode"])
-
-
-def vae_decode(z, cond, pv, training, d, nf=4, stats=None):
+def vae_decode(z, cond, pv, training, d, nf=4, stats=None, pins=None):
     B = z.shape[0]
     h = torch.cat([z, cond], 1) @ pv.t["dec_dense/kernel"] + pv.t["dec_dense/bias"]
     s = d // 8
     h = h.reshape(B, s, s, s, 4).permute(0, 4, 1, 2, 3)                 # Keras Reshape is (D,H,W,C)
     for i in range(nf):
-        h = block(h, pv, "d%d" % i, None, True, "lrelu", training, None, stats)
+        h = block(h, pv, "d%d" % i, None, True, "lrelu", training, None, stats, pins)
         if i < nf - 1:
             h = F.interpolate(h, scale_factor=2, mode="nearest")
-    return block(h, pv, "dout", None, True, "relu", training, None, stats)
+    return block(h, pv, "dout", None, True, "relu", training, None, stats, pins)
 
 
-def vae_losses(x, recon, zm, zlv, pu, training, alpha, beta, ties, pm_w=(1, 1, 1, 1)):
+def vae_losses(x, recon, zm, zlv, pu, training, alpha, beta, ties, pm_w=(1, 1, 1, 1), pins_pm=None):
+    """pins_pm: decisions of the tested implementation's perceptual pass over the RECONSTRUCTION (the pass over x carries
+    no gradient)."""
     mse = ((x - recon) ** 2).mean()
     kld = -0.5 * (1 + zlv - zm ** 2 - torch.exp(zlv)).sum(-1)
     t1, t2 = {}, {}
-    unet_trunk(x, pu, training, ties, upto="c10", taps=t1)
-    unet_trunk(recon, pu, training, ties, upto="c10", taps=t2)
+    with torch.no_grad():
+        unet_trunk(x, pu, training, ties, upto="c10", taps=t1)
+    unet_trunk(recon, pu, training, ties, upto="c10", taps=t2, pins=pins_pm)
     pm = 0.0
     B = x.shape[0]
     for n, w in zip(("c2", "c4", "c6", "c10"), pm_w):
@@ -206,7 +439,10 @@ def vae_losses(x, recon, zm, zlv, pu, training, alpha, beta, ties, pm_w=(1, 1, 1
 
 
 def vae_step_grads(Pv, Sv, Pu, Su, x, cond, eps, in_ch=1, ncond=10, d=32, alpha=0.5, beta=3e-4,
-                   dtype=torch.float64, ties="tf_cpu", training=True, nf=4):
+                   dtype=torch.float64, ties="tf_cpu", training=True, nf=4,
+                   kink=None, kink_pm=None, affine=None, affine_pm=None, kink_tol=1e-4):
+    """kink / affine: decisions of the tested implementation's VAE layers, kink_pm / affine_pm: of its perceptual U-Net pass
+    over the reconstruction (Pins); flips land in vae_step_grads.flips."""
     _POOL_TIES["mode"] = ties
     pv = Params(Pv, Sv, dtype)
     pu = Params(Pu, Su, dtype, requires_grad=False)
@@ -214,8 +450,14 @@ def vae_step_grads(Pv, Sv, Pu, Su, x, cond, eps, in_ch=1, ncond=10, d=32, alpha=
     xt = to_t(x, dtype)
     ct = torch.as_tensor(cond, dtype=dtype)
     et = torch.as_tensor(eps, dtype=dtype)
-    zm, zlv, z, recon = vae_forward(xt, ct, et, pv, training, in_ch, ncond, d, nf, stats)
-    loss, pm, mse, kld = vae_losses(xt, recon, zm, zlv, pu, training, alpha, beta, ties)
+    pins = Pins(kink, affine, kink_tol, dtype) if kink else None
+    pins_pm = Pins(kink_pm, affine_pm, kink_tol, dtype) if kink_pm else None
+    zm, zlv, z, recon = vae_forward(xt, ct, et, pv, training, in_ch, ncond, d, nf, stats, pins)
+    loss, pm, mse, kld = vae_losses(xt, recon, zm, zlv, pu, training, alpha, beta, ties, pins_pm=pins_pm)
+    fl = dict(pins.flips) if pins else {}
+    fl.update({"pm/" + k: v for k, v in (pins_pm.flips if pins_pm else {}).items()})
+    vae_step_grads.flips = fl
+    vae_step_grads.pin_worst = {**(pins.worst if pins else {}), **{"pm/" + k: v for k, v in (pins_pm.worst if pins_pm else {}).items()}}
     if training:
         loss.backward()
     return (np.array([loss.item(), pm.item(), mse.item(), kld.item()]),
@@ -251,7 +493,8 @@ def time_unet_train_step(B=4, d=32, in_ch=1, steps=2, warmup=1, threads=None):
         dt = time.perf_counter() - t0
         if it >= warmup:
             times.append(dt)
-    sec = float(np.mean(times))
+    time_unet_train_step.samples = list(times)
+    sec = float(np.median(times))
     return B / sec, threads, sec
 
 
@@ -288,7 +531,8 @@ def time_vae_train_step(B=4, d=32, in_ch=1, steps=1, warmup=0, threads=None):
         if it >= warmup:
             times.append(dt)
     _POOL_TIES["mode"] = "tf_cpu"
-    sec = float(np.mean(times))
+    time_vae_train_step.samples = list(times)
+    sec = float(np.median(times))
     return B / sec, threads, sec
 
 
@@ -315,16 +559,19 @@ def time_unet_predict(B=16, d=32, in_ch=1, steps=1, warmup=0, threads=None):
             dt = time.perf_counter() - t0
             if it >= warmup:
                 times.append(dt)
-    sec = float(np.mean(times))
+    time_unet_predict.samples = list(times)
+    sec = float(np.median(times))
     return B / sec, threads, sec
 
 
-def time_generate_tail(B=32, d=32, in_ch=1, threads=None):
+def time_generate_tail(B=32, d=32, in_ch=1, threads=None, steps=1, warmup=0):
     """fp32 torch-CPU generate.py:204-236 tail on B synthetic latent vectors: decoder forward -> U-Net forward (eval BN) ->
     argmax / threshold -> connected components (> 3 voxels) -> majority vote + centroids (oracle/watershed_ref.py's
     scipy.ndimage-based convex-branch pass, one sample at a time as the reference does).  The threshold is the 90 %
-    quantile of the sigmoid output, as in bench.py's GPU block (random weights never reach 0.8).
-    Returns (grids_per_s, threads, secs/call)."""
+    quantile of the sigmoid output of a 2-sample call made BEFORE the timed region, as in bench.py's GPU block (random
+    weights never reach 0.8).  Like the GPU figure it stops at the components of the convex branch; the hull test and the
+    recursive split are timed separately (bench.py inference.generate.refine.cpu_baseline).
+    Returns (grids_per_s, threads, median secs/call)."""
     import time
     from . import numpy_ref as R
     from . import watershed_ref as W
@@ -341,14 +588,21 @@ def time_generate_tail(B=32, d=32, in_ch=1, threads=None):
     rng = np.random.default_rng(7)
     z = torch.as_tensor(rng.standard_normal((B, 256)), dtype=torch.float32)
     cond = torch.as_tensor(np.eye(10, dtype=np.float32)[np.arange(B) % 10])
+    times = []
     with torch.no_grad():
-        t0 = time.perf_counter()
-        rec = vae_decode(z, cond, pv, False, d)
-        soft, sig = unet_forward(rec.contiguous(memory_format=torch.channels_last_3d), pu, False, "first")
-        species = soft.argmax(1).numpy().astype(np.uint8)
-        sg = sig[:, 0].numpy()
-        mask = (sg >= np.quantile(sg, 0.9)).astype(np.uint8)
-        for b in range(B):
-            W.watershed_clustering_convex(species[b], mask[b])
-        sec = time.perf_counter() - t0
+        rec = vae_decode(z[:2], cond[:2], pv, False, d)
+        _, sig = unet_forward(rec.contiguous(memory_format=torch.channels_last_3d), pu, False, "first")
+        thr = float(np.quantile(sig[:, 0].numpy(), 0.9))
+        for it in range(warmup + steps):
+            t0 = time.perf_counter()
+            rec = vae_decode(z, cond, pv, False, d)
+            soft, sig = unet_forward(rec.contiguous(memory_format=torch.channels_last_3d), pu, False, "first")
+            species = soft.argmax(1).numpy().astype(np.uint8)
+            mask = (sig[:, 0].numpy() >= thr).astype(np.uint8)
+            for b in range(B):
+                W.watershed_clustering_convex(species[b], mask[b])
+            if it >= warmup:
+                times.append(time.perf_counter() - t0)
+    time_generate_tail.samples = list(times)
+    sec = float(np.median(times))
     return B / sec, threads, sec

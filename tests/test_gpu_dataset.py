@@ -52,6 +52,11 @@ def test_training_scripts_run_from_the_on_disk_dataset(tmp_path):
         assert os.path.exists(tmp_path / "saved_models" / "unet" / "x" / f), f
     assert is_hdf5(str(tmp_path / "saved_models" / "unet" / "x" / "unet_weights_x.best.hdf5"))
     assert is_hdf5(str(tmp_path / "saved_models" / "unet" / "x" / "unet_weights_x.best.h5"))
+    # ModelCheckpoint without save_weights_only (/root/reference/unet/unet.py:361-367) writes a FULL model into the
+    # "weights" path: model_config at the root, the tensors under model_weights/
+    from icsg3d_amd.hdf5_min import Hdf5File
+    with Hdf5File(str(tmp_path / "saved_models" / "unet" / "x" / "unet_weights_x.best.hdf5")) as f:
+        assert "model_config" in f.attrs and "model_weights" in f.keys(), (list(f.attrs), list(f.keys()))
     assert "nan" not in r.stdout.lower() and "val_loss improved" in r.stdout
     cw = np.load(tmp_path / "saved_models" / "unet" / "x" / "class_weights.npy")
     assert cw.shape == (95,) and cw[0] == 0.0 and np.all(np.isfinite(cw))       # train_unet.py:107-111

@@ -1,0 +1,208 @@
+"""Whole-network train steps AT THE STATED BATCH against the fp64 oracle (missing 2 / next 1):
+BASELINE configs[1] (U-Net fwd+bwd, B = 32, 32^3), configs[2] (DFC-VAE step, B = 32) and configs[4]'s per-GPU shape
+(64^3, B = 8).  B = 32 is the only place the 1 M-row BatchNorm reductions, the B-dependent split-K / bucket plans, the
+default-on BatchNorm-backward fusions (>= 64 MB: c18 -> c17, c16 -> c15, c17.skip / pool -> c2, head -> c18) and the
+1 M-voxel loss / metric reductions run; until round 6 only "finite, decreasing, bit-stable" guarded them
+(tests/test_gpu_fullsize.py, test_gpu_configs.py).
+
+The checker is oracle/torch_ref.py in fp64 on the box's host cores (multi-threaded: the numpy oracle's single-threaded
+elementwise passes would take minutes at this size) with the ENGINE'S OWN ReLU / LeakyReLU / max-pool / loss-clip decisions
+pinned (torch_ref.Pins; held to numpy_ref.apply_kink on CPU by tests/test_oracle_pinned_torch.py), a bound on how many needed
+pinning and on how far from the kink any of them lies.  Parity stays unpinned w.r.t. Keras itself.
+Reference: /root/reference/unet/unet.py:272-355,370, vae/lattice_vae.py:160-270,296."""
+import time
+
+import numpy as np
+import pytest
+
+from oracle import numpy_ref as R
+from oracle import torch_ref as T
+
+pytestmark = [pytest.mark.gpu, pytest.mark.slow]
+
+FWD_TOL = 1e-5
+VAE_FWD_TOL = 3e-5
+STAT_TOL = 2e-5
+GRAD_TOL = 6e-5               # tests/test_gpu_fullwidth.py's bound at B = 2 / 1
+VAE_GRAD_TOL = {32: 6e-5, 64: 1.5e-4}
+HEAD_SUM_TOL = 3e-4           # head weight gradients: fp32 operand error of dz at saturated voxels
+MAX_FLIP_FRAC = 5e-6
+KINK_TOL = 1e-4               # a pinned decision lies within this x max|pre-activation| of its layer from the kink, or the oracle raises
+
+UNET_LAYERS = [n for n, _, _ in R.UNET_CONVS]
+RES = {"c1": 1, "c2": 1, "c3": 2, "c4": 2, "c5": 4, "c6": 4, "c9": 8, "c10": 8, "c13": 4, "c14": 4,
+       "c15": 2, "c16": 2, "c17": 1, "c18": 1}
+COUT = dict((n, c) for n, _, c in R.UNET_CONVS)
+NEED_GB = {32: 70, 64: 140}   # host memory the fp64 autograd graph + the pins need (measured); less -> skip, never an OOM kill
+
+
+def _host_ok(d):
+    import psutil
+    avail = psutil.virtual_memory().available / 2 ** 30
+    if avail < NEED_GB[d]:
+        pytest.skip("host has %.0f GB available, the fp64 oracle at this size needs %d" % (avail, NEED_GB[d]))
+
+
+def _inputs(B, d):
+    X, lab, cond = R.synthetic_batch(B, d, 1, seed=0, dtype=np.float64)
+    X = X + 1e-3 * np.random.default_rng(5).uniform(size=X.shape)
+    eps = np.random.default_rng(2).standard_normal((B, 256))
+    return X, lab, cond.astype(np.float64), eps
+
+
+def _ushape(n, B, d):
+    S = d // RES[n]
+    return (B, S, S, S, COUT[n])
+
+
+def _vae_shapes(B, d):
+    sh, S, f = {}, d, (16, 32, 64, 128)
+    for i in range(4):
+        sh["e%d" % i] = (B, S, S, S, f[i]); S //= 2
+    sh["e4"] = (B, S, S, S, 4)
+    sh["enc_dense"] = (B, 256)
+    S = d // 8
+    for i in range(4):
+        sh["d%d" % i] = (B, S, S, S, f[3 - i])
+        if i < 3:
+            S *= 2
+    sh["dout"] = (B, d, d, d, 1)
+    return sh
+
+
+def _batch_stats_from_moving(eng, n, C, nel):
+    mm, mv = eng.get_tensor(n + "/moving_mean", (C,)), eng.get_tensor(n + "/moving_var", (C,))
+    mean = mm.astype(np.float64) / 0.01
+    var = (mv.astype(np.float64) - 0.99) / 0.01 / (nel / (nel - (1.0 + 1e-3)))
+    return mean, var
+
+
+def _grad_err(g, ref, ref_all, name, floor=0.0):
+    scale = np.abs(ref).max()
+    if name.endswith("/bias") and name[:-4] + "kernel" in ref_all:
+        scale = max(scale, np.abs(ref_all[name[:-4] + "kernel"]).max())
+    return float(np.abs(np.asarray(g, np.float64) - ref).max() / max(scale, floor, 1e-300))
+
+
+@pytest.mark.parametrize("d,B", [(32, 32), (64, 8)])
+def test_unet_step_at_stated_batch_matches_pinned_fp64_oracle(d, B):
+    from icsg3d_amd.engine import UnetEngine
+    _host_ok(d)
+    X, lab, _, _ = _inputs(B, d)
+    lr = 1e-3
+    shapes = R.unet_param_shapes(1, 95)
+    P, S = R.init_params(shapes, 1), R.init_bn_state(shapes)
+    eng = UnetEngine(in_channels=1, d=d, max_batch=B, lr=lr)
+    eng.set_weights(P)
+    eng.profile_filter("")
+    eng.profile_enable(True)
+    m = eng.train_step(X, lab)
+    rows = {r["label"]: r["launches"] for r in eng.profile_rows()}
+    eng.profile_enable(False)
+    # the BatchNorm-backward fusions ran at their DEFAULT threshold (64 MB of producer activations): this is the size they exist for
+    for site in ("bnfuse:c18", "bnfuse:c16", "bnfuse:c17.skip", "bnfuse:c2.pool"):
+        assert rows.get(site, 0) >= 1, (site, sorted(k for k in rows if k.startswith("bnfuse")))
+    sums = eng.metric_sums()
+    grads = {name: eng.get_grad(name, shape) for name, shape, tr in eng.tensor_infos() if tr}
+    kink = {n: eng.get_activation(n, _ushape(n, B, d)) for n in UNET_LAYERS}
+    affine = {n: eng.get_bn_affine(n, COUT[n]) for n in ("c2", "c4", "c6")}
+    dz_eng = eng.get_activation("head", (B, d, d, d, 96))
+    clip_pin = {"sig": dz_eng[..., 95] != 0, "soft": np.any(dz_eng[..., :95] != 0, axis=-1)}
+    del dz_eng
+    stats_eng = {n: _batch_stats_from_moving(eng, n, COUT[n], B * (d // RES[n]) ** 3) for n in UNET_LAYERS}
+
+    t0 = time.time()
+    m_ref, g_ref, stats, _, _ = T.unet_step_grads(P, S, X, lab, kink=kink, affine=affine, clip_pin=clip_pin, want_outputs=False,
+                                                  kink_tol=KINK_TOL)
+    f1_ref, wr_ref = T.unet_step_grads.f1_wr
+    fl = T.unet_step_grads.flips
+    print("d=%d B=%d: fp64 torch oracle step (pinned) %.0f s on the host cores" % (d, B, time.time() - t0))
+
+    # ---- metrics: 1 M-voxel loss reductions, and the integer counts behind f1 / wr
+    np.testing.assert_allclose(m[:3], m_ref, rtol=FWD_TOL)
+    np.testing.assert_allclose(m[3:], [f1_ref, wr_ref], rtol=1e-4, atol=1e-6)
+    cnt = T.unet_metrics.counts          # the K.sum terms behind f1_m / wr_m (unet/unet.py:159-193): integers
+    assert sums["voxels"] == B * d ** 3 == cnt["voxels"]
+    for k in ("tp", "predicted", "wr_tp", "wr_possible"):
+        assert sums[k] == cnt[k], (k, sums[k], cnt[k])
+    # ---- BatchNorm batch statistics of every layer (up to 1.05 M rows per channel), recovered from the moving statistics
+    worst_stat = 0.0
+    for n in UNET_LAYERS:
+        mean, var = stats_eng[n]
+        rm, rv, nel = stats[n]
+        assert nel == B * (d // RES[n]) ** 3
+        e = max(np.abs(mean - rm).max() / max(np.abs(rm).max(), 1.0), np.abs(var - rv).max() / max(np.abs(rv).max(), 1.0))
+        worst_stat = max(worst_stat, e)
+        assert e <= STAT_TOL, (n, e)
+    # ---- decisions that needed pinning
+    flips = sum(fl["kink"].values())
+    total = sum(int(np.prod(_ushape(n, B, d))) for n in UNET_LAYERS)
+    pw = T.unet_step_grads.pin_worst
+    print("d=%d B=%d: ReLU decisions pinned %d of %d (the farthest %.2e of its layer's largest pre-activation from the kink), "
+          "loss-clip decisions %s" % (d, B, flips, total, max(pw.values(), default=0.0), fl["clip"]))
+    assert flips <= max(8, MAX_FLIP_FRAC * total), (flips, total)
+    assert sum(fl["clip"].values()) <= max(64, MAX_FLIP_FRAC * B * d ** 3)
+    # ---- every gradient tensor
+    worst = worst_head = 0.0
+    for name, g in grads.items():
+        e = _grad_err(g, g_ref[name], g_ref, name)
+        if name.split("/")[0] in ("soft", "sig"):
+            worst_head = max(worst_head, e)
+            assert e <= HEAD_SUM_TOL, (name, e)
+            continue
+        worst = max(worst, e)
+        assert e <= GRAD_TOL, (name, e)
+    print("d=%d B=%d: metrics %s (oracle %s); worst BN statistic error %.2e; worst pinned gradient error %.2e (head tensors %.2e)"
+          % (d, B, m, m_ref, worst_stat, worst, worst_head))
+
+
+@pytest.mark.parametrize("d,B", [(32, 32), (64, 8)])
+def test_vae_step_at_stated_batch_matches_pinned_fp64_oracle(d, B):
+    from icsg3d_amd.engine import UnetEngine, VaeEngine
+    _host_ok(d)
+    X, _, cond, eps = _inputs(B, d)
+    ush, vsh = R.unet_param_shapes(1, 95), R.vae_param_shapes(1, d=d)
+    Pu, Su = R.init_params(ush, 1), R.init_bn_state(ush)
+    Pv, Sv = R.init_params(vsh, 3), R.init_bn_state(vsh)
+    ue = UnetEngine(in_channels=1, d=d, max_batch=B); ue.set_weights(Pu)
+    ve = VaeEngine(ue, in_channels=1, d=d, max_batch=B, lr=5e-4); ve.set_weights(Pv)
+    m = ve.train_step(X, cond, eps)
+    grads = {name: ve.get_grad(name, shape) for name, shape, tr in ve.tensor_infos() if tr}
+    vs = _vae_shapes(B, d)
+    ps = {n: _ushape(n, B, d) for n in UNET_LAYERS[:8]}
+    kink = {n: ve.get_activation(n, s) for n, s in vs.items()}
+    kink_pm = {n: ue.get_activation(n, s) for n, s in ps.items()}
+    aff = {n: ve.get_bn_affine(n, vs[n][-1]) for n in ("e0", "e1", "e2", "e3")}
+    aff_pm = {n: ue.get_bn_affine(n, ps[n][-1]) for n in ("c2", "c4", "c6")}
+    bn_layers = [n for n in vs if n not in ("e4", "enc_dense")]
+    stats_eng = {n: _batch_stats_from_moving(ve, n, vs[n][-1], int(np.prod(vs[n][:-1]))) for n in bn_layers}
+    # the frozen perceptual U-Net: weights AND moving statistics untouched by the step
+    for n in UNET_LAYERS[:8]:
+        np.testing.assert_array_equal(ue.get_tensor(n + "/moving_var", (COUT[n],)), np.ones(COUT[n], np.float32))
+
+    t0 = time.time()
+    m_ref, g_ref, stats, _, _, _ = T.vae_step_grads(Pv, Sv, Pu, Su, X, cond, eps, in_ch=1, d=d, kink=kink, kink_pm=kink_pm,
+                                                    affine=aff, affine_pm=aff_pm, kink_tol=KINK_TOL)
+    fl = T.vae_step_grads.flips
+    print("d=%d B=%d: fp64 torch DFC-VAE oracle step (pinned) %.0f s" % (d, B, time.time() - t0))
+    np.testing.assert_allclose(m, m_ref, rtol=VAE_FWD_TOL)
+    worst_stat = 0.0
+    for n in bn_layers:
+        mean, var = stats_eng[n]
+        rm, rv, nel = stats[n]
+        e = max(np.abs(mean - rm).max() / max(np.abs(rm).max(), 1.0), np.abs(var - rv).max() / max(np.abs(rv).max(), 1.0))
+        worst_stat = max(worst_stat, e)
+        assert e <= STAT_TOL, (n, e)
+    flips = sum(fl.values())
+    total = sum(int(np.prod(s)) for s in vs.values()) + sum(int(np.prod(s)) for s in ps.values())
+    print("d=%d B=%d: VAE + perceptual decisions pinned: %d of %d (the farthest %.2e of its layer's largest pre-activation from "
+          "the kink)" % (d, B, flips, total, max(T.vae_step_grads.pin_worst.values(), default=0.0)))
+    assert flips <= max(8, MAX_FLIP_FRAC * total), (flips, total)
+    gscale = max(np.abs(g).max() for g in g_ref.values())
+    worst = 0.0
+    for name, g in grads.items():
+        e = _grad_err(g, g_ref[name], g_ref, name, floor=1e-6 * gscale)
+        worst = max(worst, e)
+        assert e <= VAE_GRAD_TOL[d], (name, e)
+    print("d=%d B=%d: [Loss, PM, MSE, KLD] %s (oracle %s); worst BN statistic error %.2e; worst pinned gradient error %.2e"
+          % (d, B, m, m_ref, worst_stat, worst))
