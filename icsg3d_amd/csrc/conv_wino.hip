@@ -31,6 +31,22 @@
 
 #include <algorithm>
 
+#ifdef ICS_WG_TIMELINE
+// variant builds only (scripts/variants.sh conv_wino "wgtl:-DICS_WG_TIMELINE"): per workgroup of conv_wino_wgrad_kernel
+// wall-clock stamps {0 entry, 1 first block staged + first operands built (main loop starts), 2..9 main loop done on wave
+// 0..7, 10 after the epilogue's last store, 11 blocks in this split} + HW_ID / XCC_ID, fetched with
+// ics_debug_wgrad_timeline (scripts/wgrad_timeline.py).  The stamps are scalar stores from lane 0 of a wave.
+__device__ unsigned long long ics_wg_tl[16 * 8192];
+extern "C" int ics_debug_wgrad_timeline(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(ics_wg_tl), (size_t)n * 8);
+}
+#define ICS_WGTL(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 8192) ics_wg_tl[(size_t)blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+#define ICS_WGTL0(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) ics_wg_tl[(size_t)blockIdx.x * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define ICS_WGTL(i)
+#define ICS_WGTL0(i)
+#endif
+
 namespace ics {
 
 typedef float wf2 __attribute__((ext_vector_type(2)));
@@ -447,6 +463,7 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(const float* __res
                                                               float* __restrict__ ws, int S, int Cin, int Cout,
                                                               int per_split) {
   __shared__ __attribute__((aligned(16))) float lds[2 * (GXF + GYF)];      // 156 672 B
+  ICS_WGTL0(0);
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fz = w >> 1, fyh = w & 1;
@@ -670,6 +687,7 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(const float* __res
   rd(0, 0);
   tr_y(0); tr_y(1); tr_x(t0p, u[0]); tr_x(t1p, u[0] + 4); tr_d(); tr_v(rlp, vv[0]); tr_v(rhp, vv[0] + 4);
   rd(0, 1);
+  ICS_WGTL0(1);
 #ifndef ICS_WG_ABL
 #define ICS_WG_ABL 0        // ablation (scripts/variants.sh): 1 no transforms / operand reads / staging stores, 4 no staging,
                             // 8 no MFMA, 16 no barrier, 64 no staging loads
@@ -726,6 +744,7 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(const float* __res
     block(blk, 0, 1);
     block(blk + 1, 1, 0);
   }
+  ICS_WGTL(2 + w);
 
   // ---------------------------------------------------------------- epilogue: G^T contraction, signs of the f = 3 rows
   // in registers: fx -> c and this wave's share of fy -> b;  part[w 8][9 (b,c)][4 rr][64 lanes]  (73 728 B per pass)
@@ -779,6 +798,16 @@ __global__ __launch_bounds__(512) void conv_wino_wgrad_kernel(const float* __res
       }
     }
   }
+#ifdef ICS_WG_TIMELINE
+  __syncthreads();
+  if (threadIdx.x == 0 && blockIdx.x < 8192) {
+    unsigned long long* r = ics_wg_tl + (size_t)blockIdx.x * 16;
+    r[10] = wall_clock64();
+    r[11] = (unsigned long long)per_split;
+    r[14] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID: wave[3:0] simd[5:4] pipe[7:6] cu[11:8] sh[12] se[15:13]
+    r[15] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
+  }
+#endif
 }
 
 // ---------------------------------------------------------------- host side

@@ -18,11 +18,11 @@ python bench.py --workload generate --no-cpu-baseline > $OUT/bench_generate.json
 python bench.py --workload unet --d 64 --batch 8 --no-cpu-baseline --no-secondary --no-inference > $OUT/bench_unet_d64.json 2> $OUT/bench_unet_d64.err
 python bench.py --workload vae --d 64 --batch 8 --no-cpu-baseline > $OUT/bench_vae_d64.json 2> $OUT/bench_vae_d64.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof_unet -o prof -- python3 $ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-secondary --no-inference > $OUT/prof_unet.log 2>&1
+rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof_unet -o prof -- python3 $ROOT/bench.py --steps 8 --warmup 2 --soak-seconds 0 --no-cpu-baseline --no-secondary --no-inference > $OUT/prof_unet.log 2>&1
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof_vae -o prof -- python3 $ROOT/bench.py --steps 8 --warmup 2 --workload vae > $OUT/prof_vae.log 2>&1
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof_predict -o prof -- python3 $ROOT/bench.py --steps 8 --warmup 2 --workload predict --no-cpu-baseline > $OUT/prof_predict.log 2>&1
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof_generate -o prof -- python3 $ROOT/bench.py --steps 8 --warmup 2 --workload generate --no-cpu-baseline > $OUT/prof_generate.log 2>&1
-rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof_unet_d64 -o prof -- python3 $ROOT/bench.py --steps 4 --warmup 2 --d 64 --batch 8 --no-cpu-baseline --no-secondary --no-inference > $OUT/prof_unet_d64.log 2>&1
+rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof_unet_d64 -o prof -- python3 $ROOT/bench.py --steps 4 --warmup 2 --soak-seconds 0 --d 64 --batch 8 --no-cpu-baseline --no-secondary --no-inference > $OUT/prof_unet_d64.log 2>&1
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof_vae_d64 -o prof -- python3 $ROOT/bench.py --steps 4 --warmup 2 --d 64 --batch 8 --workload vae > $OUT/prof_vae_d64.log 2>&1
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*.db" -delete
 cd $ROOT && KSTATS=$OUT/prof_unet/prof_kernel_stats.csv bash scripts/run_pmc.sh $TAG

@@ -13,7 +13,7 @@ P5="TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_AC
 i=0
 for P in "$P1" "$P2" "$P3" "$P4" "$P5"; do
   i=$((i+1))
-  timeout 600 rocprofv3 --kernel-trace --pmc $P -f csv -d $OUT/p$i -o p$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-inference "$@" > $OUT/p$i.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $P -f csv -d $OUT/p$i -o p$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --soak-seconds 0 --no-cpu-baseline --no-secondary --no-inference "$@" > $OUT/p$i.log 2>&1
   rm -f $OUT/p$i/*kernel_trace.csv $OUT/p$i/*.db
 done
 KSTATS=${KSTATS:-} python3 $GRAFT_REPO_ROOT/scripts/pmc_summary.py $OUT conv_wino64_kernel conv_up3_kernel conv_wino_kernel conv_wino_wgrad_kernel conv_fwd_kernel conv_wgrad_kernel conv_wgrad3_kernel conv_wgrad3s_kernel conv_thin_n thin1_ bn_bwd pool27 pool_fwd head_fused_kernel head_dgrad_kernel reduce_splits adam > $OUT/summary.txt 2>&1

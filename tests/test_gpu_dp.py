@@ -107,7 +107,7 @@ def test_bench_through_torchrun_single_rank():
     env = dict(os.environ, ICSG3D_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
            "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3",
-           "--warmup", "1", "--batch", "4", "--no-cpu-baseline"]
+           "--warmup", "1", "--batch", "4", "--no-cpu-baseline", "--soak-seconds", "1"]
     p = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=ROOT, timeout=850)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
@@ -115,6 +115,9 @@ def test_bench_through_torchrun_single_rank():
     r = json.loads(lines[0])
     assert r["n_gpus"] == 1 and r["value"] > 0 and "RCCL buckets" in r["config"]["grad_allreduce"]
     assert r["secondary"]["value"] > 0 and r["roofline"]["frac"] > 0
+    # the sustained figure next to the 3-step one: the same step for >= 1 s, on the host clock and on the GPU's own
+    su = r["sustained"]
+    assert su["seconds"] >= 1.0 and su["steps"] > 3 and abs(su["gpu_active_s"] - su["seconds"]) < 0.2 * su["seconds"]
 
 
 def test_class_api_data_parallel_single_rank(tmp_path):
