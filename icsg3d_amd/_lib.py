@@ -91,6 +91,7 @@ SIGNATURES = {
     "ics_net_num_params": (C.c_int, [_H, C.POINTER(C.c_size_t)]),
     "ics_net_get_optimizer_state": (C.c_int, [_H, _F, _F, C.c_size_t, C.POINTER(C.c_int)]),
     "ics_net_set_optimizer_state": (C.c_int, [_H, _F, _F, C.c_size_t, C.c_int]),
+    "ics_net_graph_probe": (C.c_int, [_H, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "ics_net_profile_enable": (C.c_int, [_H, C.c_int]),
     "ics_net_profile_filter": (C.c_int, [_H, C.c_char_p]),
     "ics_net_profile_count": (C.c_int, [_H, C.POINTER(C.c_int)]),

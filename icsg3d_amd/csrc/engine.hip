@@ -16,6 +16,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <vector>
 
 namespace ics {
@@ -2351,6 +2352,55 @@ int ics_net_timer_stop(ics_net* net, double* ms) {
   return 0;
 }
 
+// Measurement aid (round 6): the resident train step of `net` eagerly and as a replayed hipGraph.
+// The step is captured from the engine's stream (its second stream joins the capture through the fork / join events the
+// step records anyway) and replayed `iters` times; both forms are timed with events on the engine's stream.  The replay
+// re-runs the CAPTURED launches: Adam's bias-corrected step size is a launch argument computed on the host, so a replayed
+// step repeats the captured step's lr_t -- good enough to time, not to train; a product path would keep the step count in
+// device memory.  Not available with a communicator (RCCL calls are not captured here) or while profiling.
+int ics_net_graph_probe(ics_net* net, int iters, double* eager_ms, double* graph_ms, int* graph_nodes) {
+  ICS_CHECK(net && eager_ms && graph_ms && iters >= 1, "bad arguments");
+  Net& n = net->n;
+  ICS_CHECK(n.resident_batch > 0, "no resident batch: upload one first");
+  ICS_CHECK(n.comm == nullptr && !n.prof.on, "graph probe: no communicator, no profiler");
+  const int B = n.resident_batch;
+  auto step = [&]() { return n.kind == 1 ? vae_step(n, B, true, nullptr) : unet_train_resident(n, B, nullptr); };
+  hipEvent_t e0, e1;
+  ICS_HIP(hipEventCreate(&e0)); ICS_HIP(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) ICS_TRY(step());
+  ICS_HIP(hipStreamSynchronize(n.st));
+  ICS_HIP(hipEventRecord(e0, n.st));
+  for (int i = 0; i < iters; ++i) ICS_TRY(step());
+  ICS_HIP(hipEventRecord(e1, n.st));
+  ICS_HIP(hipEventSynchronize(e1));
+  float f = 0.f;
+  ICS_HIP(hipEventElapsedTime(&f, e0, e1));
+  *eager_ms = (double)f / iters;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  ICS_HIP(hipStreamBeginCapture(n.st, hipStreamCaptureModeRelaxed));
+  const int rc = step();
+  const hipError_t ec = hipStreamEndCapture(n.st, &graph);
+  ICS_TRY(rc);
+  ICS_CHECK(ec == hipSuccess && graph != nullptr, std::string("hipStreamEndCapture: ") + hipGetErrorString(ec));
+  size_t nodes = 0;
+  (void)hipGraphGetNodes(graph, nullptr, &nodes);
+  if (graph_nodes) *graph_nodes = (int)nodes;
+  ICS_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+  for (int i = 0; i < 3; ++i) ICS_HIP(hipGraphLaunch(exec, n.st));
+  ICS_HIP(hipStreamSynchronize(n.st));
+  ICS_HIP(hipEventRecord(e0, n.st));
+  for (int i = 0; i < iters; ++i) ICS_HIP(hipGraphLaunch(exec, n.st));
+  ICS_HIP(hipEventRecord(e1, n.st));
+  ICS_HIP(hipEventSynchronize(e1));
+  ICS_HIP(hipEventElapsedTime(&f, e0, e1));
+  *graph_ms = (double)f / iters;
+  (void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  n.adam_t += 6 + 2 * iters;      // keep the host's step count in line with the updates the replays applied
+  return 0;
+}
+
 int ics_unet_upload_batch(ics_net* net, const float* x, const uint8_t* labels, int batch) {
   ICS_TRY(require_kind(net, 0));
   ICS_TRY(unet_upload(net->n, x, labels, batch));
@@ -2573,6 +2623,7 @@ int ics_op_segment_atoms(const uint8_t* mask, const uint8_t* species, int batch,
   ICS_CHECK(mask && species && batch >= 1 && max_atoms >= 1 && min_voxels >= 0, "bad segmentation arguments");
   ICS_CHECK(d >= 16 && d <= 256 && (d & (d - 1)) == 0, "grid must be a power of two in [16, 256]");
   Net n;
+  n.arena_next = (size_t)1 << 22;      // a temporary Net: see op_prepare
   ICS_TRY(net_common_init(n));
   const size_t M = (size_t)batch * d * d * d;
   unsigned char *dm, *ds;
@@ -2587,11 +2638,28 @@ int ics_op_segment_atoms(const uint8_t* mask, const uint8_t* species, int batch,
 // events and its own allocations per call cost 10 - 16 ms against kernels of tens of microseconds).
 namespace {
 struct OpStream { hipStream_t st = nullptr; int device = -1; };
-thread_local OpStream tl_op_stream;
+// as segment.hip's scratch: a thread that exits hands its stream to a list of orphans instead of leaking it (or calling into
+// a runtime that may be shutting down); the next op_stream() creation and ics_release_caches destroy them
+std::mutex g_stream_orphan_mu;
+std::vector<hipStream_t> g_stream_orphans;
+void reap_stream_orphans() {
+  std::vector<hipStream_t> take;
+  { std::lock_guard<std::mutex> lk(g_stream_orphan_mu); take.swap(g_stream_orphans); }
+  for (hipStream_t s : take) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+}
+struct OpStreamTL {
+  OpStream o;
+  ~OpStreamTL() {
+    if (o.st) { std::lock_guard<std::mutex> lk(g_stream_orphan_mu); g_stream_orphans.push_back(o.st); }
+  }
+};
+thread_local OpStreamTL tl_op_stream_holder;
+#define tl_op_stream (tl_op_stream_holder.o)
 int op_stream(hipStream_t* out) {
   int dev = 0;
   ICS_HIP(hipGetDevice(&dev));
   if (tl_op_stream.st == nullptr || tl_op_stream.device != dev) {
+    reap_stream_orphans();
     if (tl_op_stream.st) (void)hipStreamDestroy(tl_op_stream.st);
     tl_op_stream.st = nullptr;
     ICS_HIP(hipStreamCreateWithFlags(&tl_op_stream.st, hipStreamNonBlocking));
@@ -2604,9 +2672,11 @@ int op_stream(hipStream_t* out) {
 int ics_release_caches() {
   if (tl_op_stream.st) { (void)hipStreamSynchronize(tl_op_stream.st); (void)hipStreamDestroy(tl_op_stream.st); }
   tl_op_stream = OpStream{};
+  reap_stream_orphans();
   segment_release_scratch();
   return 0;
 }
+#undef tl_op_stream
 
 int ics_op_label_boxes(const int32_t* vols, const int32_t* dims, int nbox, int connectivity, int max_labels,
                        int32_t* labels, int32_t* nlabels, int32_t* stats) {
@@ -2740,7 +2810,13 @@ int ics_net_comm_allreduce_max(ics_net* net, double* value) {
 }
 
 // ---------------------------------------------------------------- single-op entry points
-static int op_prepare(Net& n) { return net_common_init(n); }
+// Short-lived Nets behind the single-op entry points: their buffers are a few KB to MB, so the arena starts at 4 MB (doubling
+// as usual) instead of the 128 MB first slab of a long-lived engine handle -- a 128 MB hipMalloc + a synchronising hipFree per
+// call was the very overhead the box-level ops got rid of in round 5.
+static int op_prepare(Net& n) {
+  n.arena_next = (size_t)1 << 22;
+  return net_common_init(n);
+}
 
 int ics_op_conv3d_forward(const float* x, const float* w, const float* bias, int B, int S, int Cin, int Cout,
                           int taps, int pre_act, float* y) {

@@ -115,6 +115,18 @@ static int run(int d, int C, int B, int with_comm) {
   OK(ics_net_get_optimizer_state(unet, m1, v1, np, &step));
   OK(ics_net_set_optimizer_state(unet, m1, v1, np, step));
   OK(ics_net_reset_optimizer(unet));
+  {   /* the graph probe needs the profiler off and a resident batch */
+    double em, gm; int nodes, rk, nr, nb;
+    OK(ics_net_profile_enable(unet, 0)); OK(ics_net_profile_enable(vae, 0));
+    OK(ics_net_comm_info(unet, &rk, &nr, &nb));
+    if (nr == 0) {
+      OK(ics_net_graph_probe(unet, 2, &em, &gm, &nodes));
+      OK(ics_net_graph_probe(vae, 2, &em, &gm, &nodes));
+    } else if (ics_net_graph_probe(unet, 2, &em, &gm, &nodes) == 0) {
+      fprintf(stderr, "graph probe must refuse an engine with a communicator\n"); return 1;
+    }
+    OK(ics_net_profile_enable(unet, 1)); OK(ics_net_profile_enable(vae, 1));
+  }
   {
     size_t cnt = (size_t)B * (d / 8) * (d / 8) * (d / 8) * 512;      /* c10 activation */
     float* act = (float*)malloc(cnt * sizeof(float));

@@ -35,6 +35,17 @@ hipError_t hipEventDestroy(hipEvent_t e) { std::free(e); return hipSuccess; }
 hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.001f; return hipSuccess; }
+// stream capture / graphs (ics_net_graph_probe): a captured "graph" is an opaque allocation, a replay is a no-op
+hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { return hipSuccess; }
+hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) { *g = (hipGraph_t)std::malloc(8); return hipSuccess; }
+hipError_t hipGraphGetNodes(hipGraph_t, hipGraphNode_t*, size_t* n) { *n = 0; return hipSuccess; }
+hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t, hipGraphNode_t*, char*, size_t) {
+  *e = (hipGraphExec_t)std::malloc(8);
+  return hipSuccess;
+}
+hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipSuccess; }
+hipError_t hipGraphExecDestroy(hipGraphExec_t e) { std::free(e); return hipSuccess; }
+hipError_t hipGraphDestroy(hipGraph_t g) { std::free(g); return hipSuccess; }
 hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidDevice; }
 hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }

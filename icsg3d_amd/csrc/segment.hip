@@ -15,6 +15,8 @@
 // 1-2 M voxels per call).
 #include "common.h"
 #include "segment.h"
+#include <mutex>
+#include <vector>
 
 namespace ics {
 namespace {
@@ -570,12 +572,31 @@ static int box_descs(const int* dims, const int* cls, int nbox, std::vector<BoxD
 // is a grow-only buffer per host thread, released by segment_release_scratch() (ics_release_caches) or with the process.
 namespace {
 struct Scratch { unsigned char* p = nullptr; size_t cap = 0; int device = -1; };
-thread_local Scratch tl_scratch;
+// A host thread that used the box-level ops and then exits (a pool worker, a loader thread) must not leak its buffer until
+// the process ends -- and a thread_local destructor must not call into a HIP runtime that may already be
+// shutting down.  So the destructor only hands the buffer to a process-wide list of orphans; the next scratch allocation
+// of any thread, and ics_release_caches, free them.
+std::mutex g_orphan_mu;
+std::vector<unsigned char*> g_orphans;
+void reap_orphans() {
+  std::vector<unsigned char*> take;
+  { std::lock_guard<std::mutex> lk(g_orphan_mu); take.swap(g_orphans); }
+  for (unsigned char* p : take) (void)hipFree(p);
+}
+struct ScratchTL {
+  Scratch s;
+  ~ScratchTL() {
+    if (s.p) { std::lock_guard<std::mutex> lk(g_orphan_mu); g_orphans.push_back(s.p); }
+  }
+};
+thread_local ScratchTL tl_scratch_holder;
+#define tl_scratch (tl_scratch_holder.s)
 int scratch_get(size_t bytes, unsigned char** out) {
   int dev = 0;
   ICS_HIP(hipGetDevice(&dev));
   Scratch& s = tl_scratch;
   if (s.p == nullptr || s.cap < bytes || s.device != dev) {
+    reap_orphans();
     if (s.p) (void)hipFree(s.p);
     s.p = nullptr; s.cap = 0;
     const size_t want = std::max(bytes + bytes / 2, (size_t)1 << 20);
@@ -589,7 +610,9 @@ int scratch_get(size_t bytes, unsigned char** out) {
 void segment_release_scratch() {
   if (tl_scratch.p) (void)hipFree(tl_scratch.p);
   tl_scratch = Scratch{};
+  reap_orphans();
 }
+#undef tl_scratch
 
 int segment_label_boxes(hipStream_t st, const int* h_vols, const int* h_dims, int nbox, int connectivity, int max_labels,
                         int* h_labels, int* h_nlabels, int* h_stats) {

@@ -59,6 +59,20 @@ def max_over_ranks(dist, value: float) -> float:
     return float(t.item())
 
 
+class _Watched:
+    def __init__(self, wd, where):
+        self.wd, self.where = wd, where
+
+    def __enter__(self):
+        if self.wd is not None:
+            self.wd.beat(self.where)
+
+    def __exit__(self, *exc):
+        if self.wd is not None:
+            self.wd.pause(self.where + " (returned)")
+        return False
+
+
 class DataParallelMixin:
     """Data parallelism through the class API (AtomUnet / LatticeDFCVAE).  `enable_data_parallel` records the
     process group; the communicator is attached whenever the model (re)creates its engine -- all ranks do that
@@ -76,6 +90,7 @@ class DataParallelMixin:
             # this rank with a message instead of holding every GPU of the job in a collective for ever
             from .watchdog import StepWatchdog
             self._wd = StepWatchdog(rank=int(rank))
+            self._wd.pause("between steps")
         if getattr(self, "_eng", None) is not None:
             self._dp_attach(self._eng)
         return self
@@ -97,9 +112,11 @@ class DataParallelMixin:
                                        "ids with shard_ids() so that every rank sees the same batches" % sizes)
             init_engine_comm(engine, dist, rank, world, sync_bn=sync_bn, force=force)
 
-    def _dp_beat(self, where: str):
-        if self._wd is not None:
-            self._wd.beat(where)
+    def _dp_watch(self, where: str):
+        """Context manager around ONE engine call of a data-parallel model: the watchdog runs while the call is in flight
+        (that is where a collective can hang) and is paused between calls -- loading the next batch, a validation plot or
+        the rest of the host program are not steps, and a process that merely stops training must not be ended."""
+        return _Watched(self._wd, where)
 
     def _dp_is_writer(self) -> bool:
         return self._dp is None or self._dp[1] == 0

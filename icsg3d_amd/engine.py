@@ -127,6 +127,12 @@ class _Net:
         return ms.value
 
     # ---- profiling (HIP events on the engine's stream)
+    def graph_probe(self, iters=20):
+        """Measurement aid: the resident train step eagerly and as a replayed hipGraph -> (eager ms, graph ms, graph nodes)."""
+        a, b, n = C.c_double(0), C.c_double(0), C.c_int(0)
+        L.check(self._lib.ics_net_graph_probe(self._h, int(iters), C.byref(a), C.byref(b), C.byref(n)))
+        return a.value, b.value, n.value
+
     def profile_enable(self, on=True):
         L.check(self._lib.ics_net_profile_enable(self._h, 1 if on else 0))
 

@@ -137,13 +137,13 @@ class _UnetModel:
     # -- training steps
     def train_on_batch(self, X, y):
         labels = _to_labels(y[0] if isinstance(y, (list, tuple)) else y, self._o.num_classes)
-        self._o._dp_beat("AtomUnet train_on_batch")
-        return [float(v) for v in self._o._engine(len(X), grow=True).train_step(X, labels)]
+        with self._o._dp_watch("AtomUnet train_on_batch"):
+            return [float(v) for v in self._o._engine(len(X), grow=True).train_step(X, labels)]
 
     def test_on_batch(self, X, y):
         labels = _to_labels(y[0] if isinstance(y, (list, tuple)) else y, self._o.num_classes)
-        self._o._dp_beat("AtomUnet test_on_batch")
-        return [float(v) for v in self._o._engine(len(X), grow=True).test_step(X, labels)]
+        with self._o._dp_watch("AtomUnet test_on_batch"):
+            return [float(v) for v in self._o._engine(len(X), grow=True).test_step(X, labels)]
 
     def fit_generator(self, generator, validation_data=None, epochs=1, callbacks=None, workers=4,
                       use_multiprocessing=False, verbose=1, max_queue_size=10):

@@ -81,13 +81,13 @@ class _VaeModel:
 
     def train_on_batch(self, inputs, target=None, eps=None):
         M, cond = inputs
-        self._o._dp_beat("LatticeDFCVAE train_on_batch")
-        return [float(v) for v in self._o._engine(len(M), grow=True).train_step(M, cond, self._eps(len(M), eps))]
+        with self._o._dp_watch("LatticeDFCVAE train_on_batch"):
+            return [float(v) for v in self._o._engine(len(M), grow=True).train_step(M, cond, self._eps(len(M), eps))]
 
     def test_on_batch(self, inputs, target=None, eps=None):
         M, cond = inputs
-        self._o._dp_beat("LatticeDFCVAE test_on_batch")
-        return [float(v) for v in self._o._engine(len(M), grow=True).test_step(M, cond, self._eps(len(M), eps))]
+        with self._o._dp_watch("LatticeDFCVAE test_on_batch"):
+            return [float(v) for v in self._o._engine(len(M), grow=True).test_step(M, cond, self._eps(len(M), eps))]
 
     def load_weights(self, path):
         o = self._o

@@ -76,7 +76,10 @@ int ics_unet_test_step(ics_net* net, const float* x, const uint8_t* labels, int 
 /* The K.sum(...) terms behind the ratios of r_m / p_m / f1_m / wr_m (unet/unet.py:159-193) and the two loss means of
  * the LAST train / test step (data parallel: after the all-reduce, i.e. over the global batch):
  * sums = [sum_voxels wcce, sum_voxels bce, true_positives, predicted_positives, wr true_positives, wr possible_positives,
- * voxel count (= possible_positives of r_m: y_true is one-hot)].  The counts are integers held in doubles. */
+ * voxel count (= possible_positives of r_m: y_true is one-hot)].  The counts are integers held in doubles.
+ * Valid only after a step that RETURNED metrics (ics_unet_train_step / _test_step, or _train_step_resident with a non-NULL
+ * metrics pointer): a resident step enqueued without metrics skips the reduction over the ranks under data parallelism, and
+ * the sums then still hold the last metric-returning step's values. */
 int ics_unet_metric_sums(ics_net* net, double sums[7]);
 
 /* Benchmark path: batch resident in HBM, steps enqueued back-to-back on the engine's stream. */
@@ -231,6 +234,10 @@ int ics_net_share_stream(ics_net* net, ics_net* other);
  * milliseconds between them (bench.py's gpu_active_s, the self-check of ms_per_step). */
 int ics_net_timer_start(ics_net* net);
 int ics_net_timer_stop(ics_net* net, double* ms);
+/* Measurement aid (no reference counterpart): the resident train step eagerly and as a replayed
+ * hipGraph, milliseconds per step over `iters` steps each, and the number of nodes the captured graph holds.  The replay
+ * repeats the captured step's host-computed Adam step size: for timing, not for training. */
+int ics_net_graph_probe(ics_net* net, int iters, double* eager_ms, double* graph_ms, int* graph_nodes);
 int ics_net_profile_enable(ics_net* net, int on);
 /* Restrict the events to the launch sites whose label starts with `prefix` -- or with one of several prefixes separated by
  * ';' -- (NULL / "" = every launch): bench.py times its K steps with events on the dominant kernel's launch sites only, so

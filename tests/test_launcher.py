@@ -151,6 +151,22 @@ def test_watchdog_ends_a_hung_rank_and_the_job(tmp_path, clean_env):
     assert hit == [3]
     wd.stop()
 
+    # through the class API (DataParallelMixin): the watchdog runs only while an engine call is in flight -- a process that
+    # stops training (this very pytest process after test_gpu_dp.py, round 6's first GPU run) must not be ended
+    from icsg3d_amd.dataparallel import DataParallelMixin
+    hit2 = []
+    m = DataParallelMixin()
+    m._wd = StepWatchdog(timeout=0.3, rank=0, exit_fn=hit2.append, poll=0.05)
+    m._wd.pause("between steps")
+    with m._dp_watch("train_on_batch"):
+        time.sleep(0.1)
+    time.sleep(0.7)
+    assert hit2 == []                        # idle between calls: quiet
+    with m._dp_watch("train_on_batch"):
+        time.sleep(0.7)                      # a call that does not return in time
+    assert hit2 == [3]
+    m._wd.stop()
+
     script = tmp_path / "stub_hang.py"
     script.write_text(textwrap.dedent("""
         import os, sys, time
