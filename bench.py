@@ -60,7 +60,7 @@ def cpu_baseline(batch=32, d=32):
             "T.time_vae_train_step(B=8, d=%d, in_ch=1, steps=1, warmup=0); "
             "vv,c,sv = T.time_vae_train_step(B=%d, d=%d, in_ch=1, steps=3, warmup=0); r['v'] = T.time_vae_train_step.samples; "
             "vp,c,sp = T.time_unet_predict(B=16, d=%d, in_ch=1, steps=2, warmup=1); r['p'] = T.time_unet_predict.samples; "
-            "vg,c,sg = T.time_generate_tail(B=%d, d=%d, in_ch=1, steps=2, warmup=1); r['g'] = T.time_generate_tail.samples; "
+            "vg,c,sg = T.time_generate_tail(B=%d, d=%d, in_ch=1, steps=2, warmup=1, full_samples=8); r['g'] = T.time_generate_tail.samples; r['gf'] = T.time_generate_tail.full; "
             "r.update({'v_': v, 's': s, 'vv': vv, 'sv': sv, 'vp': vp, 'sp': sp, 'vg': vg, 'sg': sg, 'cores': c}); "
             "print(json.dumps(r))"
             % (ROOT, d, batch, d, d, batch, d, d, batch, d))
@@ -76,7 +76,14 @@ def cpu_baseline(batch=32, d=32):
                 "s_per_step": u["s_per_step"], "samples": u["samples"], "s_min": u["s_min"], "s_max": u["s_max"],
                 "vae": leg(r["vv"], r["sv"], r["v"], "s_per_step"),
                 "predict": leg(r["vp"], r["sp"], r["p"], "s_per_call"),
-                "generate": leg(r["vg"], r["sg"], r["g"], "s_per_call"),
+                "generate": dict(leg(r["vg"], r["sg"], r["g"], "s_per_call"),
+                                 # the host step the GPU block reports as `refine`: hull test of every kept component +
+                                 # recursive marker watershed, oracle/watershed_ref.py one grid at a time (pure-Python heap)
+                                 refine=None if not r.get("gf") else {
+                                     "grids": r["gf"]["grids"], "s_per_grid": round(r["gf"]["s_per_grid"], 4),
+                                     "grids_per_s": round(1.0 / r["gf"]["s_per_grid"], 2), "failed": r["gf"]["failed"],
+                                     "what": "oracle/watershed_ref.watershed_clustering (convex-hull test + marker watershed "
+                                             "+ recursion, watershed.py:190-203) on the first grids of the same call's masks"}),
                 "sample": "oracle/torch_ref.py fp32, torch-CPU channels_last_3d, all host cores; each leg after one untimed "
                           "warm-up call of its own kind: MEDIAN of 3 timed U-Net fwd+bwd+Adam steps on %d synthetic %d^3 grids "
                           "(%.1f s, min %.1f / max %.1f; `value`, the batch the GPU figure is quoted on), median of 3 timed "
@@ -678,6 +685,8 @@ def main():
             if "inference" in out and out["cpu_baseline"].get("predict"):
                 out["inference"]["predict"]["cpu_baseline"] = out["cpu_baseline"]["predict"]
                 out["inference"]["generate"]["cpu_baseline"] = out["cpu_baseline"].get("generate")
+                if (out["cpu_baseline"].get("generate") or {}).get("refine"):       # like for like with the refine block
+                    out["inference"]["generate"]["refine"]["cpu_baseline"] = out["cpu_baseline"]["generate"]["refine"]
         line = json.dumps(out) + "\n"
         if json_fd is not None:
             sys.stdout.flush()

@@ -2691,6 +2691,11 @@ int ics_op_region_stats(const int32_t* R, const uint8_t* species, int D, int H, 
   return segment_region_stats(st, R, species, D, H, W, num_labels, num_species, stats);
 }
 int ics_op_watershed_split(const int32_t* boxes, const int32_t* dims, const int32_t* cls, int nbox, int tie, int32_t* wss) {
+  // Round 6: the boxes of a level go to host threads (segment_watershed_split_host: the flood is sequential per box and a
+  // CPU core walks it ~30x faster than one GPU lane); ICSG3D_WS_DEVICE=1 keeps the kernel (A/B, tests run both).
+  const char* env = getenv("ICSG3D_WS_DEVICE");       // read per call: tests flip it inside one process
+  const bool on_device = env != nullptr && atoi(env) != 0;
+  if (!on_device) return segment_watershed_split_host(boxes, dims, cls, nbox, tie, wss);
   hipStream_t st;
   ICS_TRY(op_stream(&st));
   return segment_watershed_split(st, boxes, dims, cls, nbox, tie, wss);

@@ -35,6 +35,10 @@ int segment_region_stats(hipStream_t st, const int* h_R, const unsigned char* h_
 int segment_watershed_split(hipStream_t st, const int* h_boxes, const int* h_dims, const int* h_cls, int nbox, int tie,
                             int* h_wss);
 
+// The same split on host threads (no device work: the flood is a chain of dependent heap operations);
+// bit-identical to the kernel.  ics_op_watershed_split takes this form unless ICSG3D_WS_DEVICE=1.
+int segment_watershed_split_host(const int* h_boxes, const int* h_dims, const int* h_cls, int nbox, int tie, int* h_wss);
+
 // frees the calling thread's grow-only scratch of the three box-level entry points above
 void segment_release_scratch();
 

@@ -15,7 +15,11 @@
 // 1-2 M voxels per call).
 #include "common.h"
 #include "segment.h"
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 namespace ics {
@@ -674,6 +678,147 @@ int segment_region_stats(hipStream_t st, const int* h_R, const unsigned char* h_
   if (e == hipSuccess) e = hipMemcpyAsync(h_stats, d_st, b_st, hipMemcpyDeviceToHost, st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   if (e != hipSuccess) { set_error(std::string("region_stats: ") + hipGetErrorString(e)); return -1; }
+  return 0;
+}
+
+// ---- the same split on the HOST (round 6).  The priority flood is a chain of dependent heap operations: one GPU lane walks
+// it at ~3 us per voxel (dependent LDS / L2 round trips at 2 GHz), a CPU core at ~0.1 us, and the pop order of equal keys is
+// part of the result, so the flood cannot be spread over lanes without changing it (phases A / B of the
+// flood are order-free, the competition for the pockets they leave is not).  The boxes of one recursion level are independent:
+// they are dealt to host threads.  Same arithmetic as ws_split_kernel, statement by statement (tests hold both to
+// oracle/watershed_ref.py bit for bit; ICSG3D_WS_DEVICE=1 keeps the kernel).
+namespace {
+struct HostHeap {                                    // oracle/watershed_ref.py::_Heap == WsHeap above
+  std::vector<unsigned> key, idx;
+  int n = 0;
+  void push(unsigned k, unsigned ix) {
+    int child = n++;
+    key[child] = k; idx[child] = ix;
+    while (child > 0) {
+      const int parent = (child + 1) / 2 - 1;
+      if (key[child] < key[parent]) { std::swap(key[child], key[parent]); std::swap(idx[child], idx[parent]); child = parent; }
+      else break;
+    }
+  }
+  unsigned pop() {
+    const unsigned top = idx[0];
+    --n;
+    if (n == 0) return top;
+    key[0] = key[n]; idx[0] = idx[n];
+    int i = 0;
+    while (true) {
+      const int l = 2 * i + 1, r = 2 * i + 2;
+      int smallest = i;
+      if (l < n) {
+        if (key[l] < key[i]) smallest = l;
+        if (r < n && key[r] < key[smallest]) smallest = r;
+      } else break;
+      if (smallest == i) break;
+      std::swap(key[i], key[smallest]); std::swap(idx[i], idx[smallest]);
+      i = smallest;
+    }
+    return top;
+  }
+};
+
+void host_split_box(const int* val, int D, int H, int W, int tie, int* out) {
+  const int V = D * H * W, HW = H * W;
+  std::vector<int> fg(V), bgm(V), lab(V, 0);
+  for (int i = 0; i < V; ++i) {                      // ball(1) erosion / dilation, out-of-box neighbours ignored
+    const int x = i % W, y = (i / W) % H, z = i / HW;
+    int mn = val[i], mx = val[i];
+    auto see = [&](int v) { mn = v < mn ? v : mn; mx = v > mx ? v : mx; };
+    if (z > 0) see(val[i - HW]);
+    if (z < D - 1) see(val[i + HW]);
+    if (y > 0) see(val[i - W]);
+    if (y < H - 1) see(val[i + W]);
+    if (x > 0) see(val[i - 1]);
+    if (x < W - 1) see(val[i + 1]);
+    fg[i] = mn; bgm[i] = mx;
+  }
+  // measure.label(fg), full connectivity: components of equal non-zero value, numbered in raster order of their first voxel
+  std::vector<int> stack;
+  int next = 0;
+  for (int s0 = 0; s0 < V; ++s0) {
+    if (fg[s0] == 0 || lab[s0] != 0) continue;
+    lab[s0] = ++next;
+    stack.assign(1, s0);
+    while (!stack.empty()) {
+      const int i = stack.back(); stack.pop_back();
+      const int x = i % W, y = (i / W) % H, z = i / HW;
+      for (int dz = -1; dz <= 1; ++dz) {
+        const int zz = z + dz; if (zz < 0 || zz >= D) continue;
+        for (int dy = -1; dy <= 1; ++dy) {
+          const int yy = y + dy; if (yy < 0 || yy >= H) continue;
+          for (int dx = -1; dx <= 1; ++dx) {
+            const int xx = x + dx; if (xx < 0 || xx >= W) continue;
+            const int j = (zz * H + yy) * W + xx;
+            if (lab[j] == 0 && fg[j] == fg[i]) { lab[j] = next; stack.push_back(j); }
+          }
+        }
+      }
+    }
+  }
+  bool zeros = false;                                // markers = label + 1; markers[(bg - fg) == 1] = 0 (the reference's quirk)
+  for (int i = 0; i < V; ++i) {
+    int m = lab[i] + 1;
+    if (bgm[i] - fg[i] == 1) { m = 0; zeros = true; }
+    out[i] = m;
+  }
+  if (zeros) {                                       // skimage _watershed_cy.pyx as restated in watershed_ref.watershed_flood
+    HostHeap hp;
+    hp.key.resize(V); hp.idx.resize(V);
+    unsigned seq = 0;
+    for (int i = 0; i < V; ++i)
+      if (out[i] != 0) hp.push(((val[i] != 0 ? 1u : 0u) << 31) | (tie ? seq++ : 0u), (unsigned)i);
+    unsigned age = tie ? (unsigned)V + 1u : 1u;
+    const int nb[6] = {-HW, -W, -1, 1, W, HW};
+    while (hp.n > 0) {
+      const int i = (int)hp.pop();
+      const int x = i % W, y = (i / W) % H, z = i / HW;
+      const bool ok[6] = {z > 0, y > 0, x > 0, x < W - 1, y < H - 1, z < D - 1};
+      const int li = out[i];
+      for (int k = 0; k < 6; ++k) {
+        if (!ok[k]) continue;
+        const int j = i + nb[k];
+        if (out[j] != 0) continue;
+        ++age;
+        out[j] = li;
+        hp.push(((val[j] != 0 ? 1u : 0u) << 31) | age, (unsigned)j);
+      }
+    }
+  }
+  for (int i = 0; i < V; ++i) if (out[i] == 1) out[i] = 0;     // wss[wss == 1] = 0
+}
+}  // namespace
+
+int segment_watershed_split_host(const int* h_boxes, const int* h_dims, const int* h_cls, int nbox, int tie, int* h_wss) {
+  ICS_CHECK(h_boxes && h_dims && h_cls && h_wss && nbox >= 1 && (tie == 0 || tie == 1), "bad watershed_split arguments");
+  std::vector<BoxDesc> desc;
+  size_t total = 0;
+  ICS_TRY(box_descs(h_dims, h_cls, nbox, &desc, &total));
+  // largest boxes first (a level lasts as long as its slowest box), one box at a time per thread
+  std::vector<int> order(nbox);
+  for (int b = 0; b < nbox; ++b) order[b] = b;
+  std::sort(order.begin(), order.end(), [&](int a, int b) {
+    return (long long)desc[a].D * desc[a].H * desc[a].W > (long long)desc[b].D * desc[b].H * desc[b].W;
+  });
+  std::atomic<int> next{0};
+  auto work = [&]() {
+    for (int k = next.fetch_add(1); k < nbox; k = next.fetch_add(1)) {
+      const BoxDesc& d = desc[order[k]];
+      host_split_box(h_boxes + d.off, d.D, d.H, d.W, tie, h_wss + d.off);
+    }
+  };
+  unsigned hw = std::thread::hardware_concurrency();
+  if (const char* e = getenv("ICSG3D_HOST_THREADS")) hw = (unsigned)std::max(1, atoi(e));
+  const int nthreads = (int)std::min<size_t>({(size_t)nbox, (size_t)std::max(1u, hw / 2), (size_t)64});
+  if (nthreads <= 1 || total < 4096) { work(); return 0; }
+  std::vector<std::thread> pool;
+  pool.reserve(nthreads - 1);
+  for (int t = 1; t < nthreads; ++t) pool.emplace_back(work);
+  work();
+  for (auto& th : pool) th.join();
   return 0;
 }
 

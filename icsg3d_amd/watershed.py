@@ -214,20 +214,98 @@ def dop_count(img):
     return int(np.count_nonzero(np.all((g <= hi) & (g >= lo), axis=1)))
 
 
+def fill_count(img, max_iters=4):
+    """A LOWER bound of np.count_nonzero(convex_hull_image(img)) (round 6), in exact boolean arithmetic: along every axis-
+    parallel grid line, every grid point between the first and the last voxel of the set lies on a segment between two
+    voxel centres, hence inside the hull (and at least 0.29 voxels inside the hull of the +-0.5 offset set that
+    convex_hull_image builds: no tolerance question); repeated until nothing changes, the filled set is still inside the
+    hull.  voxels / fill_count is therefore an UPPER bound of the convexity watershed.py:80-83 tests: where it stays below
+    min_convexity the component is non-convex and Qhull is not needed (about half of the ragged components)."""
+    a = np.asarray(img) != 0
+    n = int(a.sum())
+    for _ in range(max_iters):
+        for ax in range(3):
+            fwd = np.maximum.accumulate(a, axis=ax)
+            bwd = np.flip(np.maximum.accumulate(np.flip(a, ax), axis=ax), ax)
+            a = a | (fwd & bwd)
+        m = int(a.sum())
+        if m == n:
+            break
+        n = m
+    return n
+
+
+def convexity_bounds(img, degenerate="raise"):
+    """(voxels, lower, upper): exact-integer bounds lower <= convexity <= upper of a component box, no hull.  Flat components
+    raise DegenerateComponent exactly where the reference stack's Qhull call fails (degenerate="raise")."""
+    img = np.asarray(img)
+    n = int(np.count_nonzero(img))
+    if degenerate != "solid" and n > 0 and is_flat(np.argwhere(img != 0)):
+        raise DegenerateComponent("component of %d voxels is flat: convex_hull_image fails in the reference stack" % n)
+    if n == 0:
+        return 0, 0.0, 0.0
+    return n, n / dop_count(img), n / fill_count(img)
+
+
+def convexity_many(boxes, threshold, degenerate="raise", pool=None):
+    """[(is_convex, value) | DegenerateComponent] for a list of component boxes -- `convexity_at_least` for each, with the
+    hulls that the integer bounds leave undecided computed on a thread pool (Qhull runs without the GIL)."""
+    out, undecided = [None] * len(boxes), []
+    for i, box in enumerate(boxes):
+        try:
+            n, lo, hi = convexity_bounds(box, degenerate)
+        except DegenerateComponent as e:
+            out[i] = e
+            continue
+        if lo >= threshold:
+            out[i] = (True, lo)
+        elif hi < threshold:
+            out[i] = (False, hi)
+        else:
+            undecided.append((i, n))
+
+    def exact(job):
+        i, n = job
+        try:
+            c = n / convex_hull_volume(boxes[i], degenerate=degenerate)
+            return i, (c >= threshold, c)
+        except DegenerateComponent as e:     # (unreachable after the flat test; kept for safety)
+            return i, e
+    if len(undecided) > 3 and pool is not False:
+        for i, r in (pool or _hull_pool()).map(exact, undecided):
+            out[i] = r
+    else:
+        for job in undecided:
+            i, r = exact(job)
+            out[i] = r
+    return out
+
+
+_HULL_POOL = None
+
+
+def _hull_pool():
+    global _HULL_POOL
+    if _HULL_POOL is None:
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        _HULL_POOL = ThreadPoolExecutor(max_workers=max(2, min(32, (os.cpu_count() or 4) // 2)), thread_name_prefix="icsg3d-hull")
+    return _HULL_POOL
+
+
 def convexity_at_least(img, threshold, degenerate="raise"):
     """(convexity >= threshold, value) for a component box, deciding exactly what
     `np.count_nonzero(img) / np.count_nonzero(convex_hull_image(img)) >= threshold` decides (watershed.py:80-83) -- but
     through the cheap upper bound of the hull first: voxels / dop_count is a LOWER bound of the convexity, and when it
     already reaches the threshold (198 of 200 ball-shaped components in a test draw) Qhull is not needed (0.15 ms instead
-    of 1.3 ms per component on the host).  `value` is then that lower bound, otherwise the exact convexity.  Flat components
-    raise DegenerateComponent first, exactly where the reference stack's Qhull call fails (degenerate="raise")."""
-    img = np.asarray(img)
-    n = int(np.count_nonzero(img))
-    if degenerate != "solid" and n > 0 and is_flat(np.argwhere(img != 0)):
-        raise DegenerateComponent("component of %d voxels is flat: convex_hull_image fails in the reference stack" % n)
-    lower = n / dop_count(img) if n else 0.0
+    of 1.3 ms per component on the host); and through an upper bound (fill_count) that settles about half of the non-convex
+    ones.  `value` is then that bound, otherwise the exact convexity.  Flat components raise DegenerateComponent first,
+    exactly where the reference stack's Qhull call fails (degenerate="raise")."""
+    n, lower, upper = convexity_bounds(img, degenerate)
     if lower >= threshold:
         return True, lower
+    if n == 0 or upper < threshold:          # (round 6) the inner bound of the hull already says non-convex
+        return False, upper
     c = n / convex_hull_volume(img, degenerate=degenerate)
     return c >= threshold, c
 
@@ -303,6 +381,9 @@ def segment_nuclei_batch(binaries, wmin=8, max_iters=5, min_convexity=0.8, tie="
     while level:
         labelled = label_boxes([n.vol for n in level], connectivity=1)
         todo = []
+        # every kept component of the level: crop, then ONE batch of convexity decisions (integer bounds first, the hulls
+        # they leave undecided on a thread pool); the reference's order is restored when the results are consumed
+        cand = []
         for node, (labels, nlab, stats) in zip(level, labelled):
             if errors[node.root] is not None:
                 continue
@@ -312,16 +393,20 @@ def segment_nuclei_batch(binaries, wmin=8, max_iters=5, min_convexity=0.8, tie="
                 z0, y0, x0, z1, y1, x1 = (int(v) for v in stats[cl - 1, 1:7])
                 sl = (slice(z0, z1), slice(y0, y1), slice(x0, x1))
                 box = np.where(labels[sl] == cl, cl, 0).astype(np.int32)       # binary_bbox: values {0, cl}
-                try:
-                    is_convex, convexity = convexity_at_least(box, min_convexity, degenerate)
-                except DegenerateComponent as e:
-                    errors[node.root] = e
-                    break
-                comp = {"cl": cl, "sl": sl, "box": box, "count": int(stats[cl - 1, 0]), "convexity": float(convexity),
-                        "kind": "convex" if is_convex else "split", "wss": None, "child": None, "node": node}
-                node.comps.append(comp)
-                if not is_convex:
-                    todo.append(comp)
+                cand.append((node, cl, sl, box, int(stats[cl - 1, 0])))
+        decisions = convexity_many([c[3] for c in cand], min_convexity, degenerate)
+        for (node, cl, sl, box, count), dec in zip(cand, decisions):
+            if errors[node.root] is not None:                        # an earlier component of this sample was flat:
+                continue                                             # the reference never reaches this one
+            if isinstance(dec, DegenerateComponent):
+                errors[node.root] = dec
+                continue
+            is_convex, convexity = dec
+            comp = {"cl": cl, "sl": sl, "box": box, "count": count, "convexity": float(convexity),
+                    "kind": "convex" if is_convex else "split", "wss": None, "child": None, "node": node}
+            node.comps.append(comp)
+            if not is_convex:
+                todo.append(comp)
         todo = [c for c in todo if errors[c["node"].root] is None]
         level = []
         if todo:
@@ -414,6 +499,10 @@ def refine_atoms(out, max_iters=5, num_species=95, tie="heap", min_convexity=0.8
     split = np.zeros(B, bool)
     if out.get("failed") is None:
         out["failed"] = np.zeros(B, bool)
+    # pass 1: what the device's integers decide (flat / convex), and the boxes they leave for the host -- gathered over the
+    # whole batch so that their bounds and hulls are computed together (convexity_many: thread pool)
+    verdict = [[] for _ in range(B)]          # per sample, per component: True (convex) / "flat" / index into `jobs`
+    jobs = []
     for b in range(B):
         if out["failed"][b]:
             continue
@@ -421,25 +510,37 @@ def refine_atoms(out, max_iters=5, num_species=95, tie="heap", min_convexity=0.8
         st = out["stats"][b, :n]
         lab0 = out["regions"][b]
         bnd = out["bounds"][b, :n] if out.get("bounds") is not None else None
-        try:
-            convex = True
-            for a in range(n):
-                if bnd is not None:
-                    # decided from the device's integers where they are conclusive: flat (singular scatter matrix) -> the
-                    # reference stack's Qhull call fails; voxels / polytope count >= threshold -> convex, no hull needed
-                    flat = _scatter_is_singular(int(st[a, 1]), [int(v) for v in st[a, 2:5]], [int(v) for v in bnd[a, 1:7]])
-                    if flat and degenerate != "solid":
-                        raise DegenerateComponent("component %d of sample %d is flat" % (a + 1, b))
-                    if int(st[a, 1]) / int(bnd[a, 0]) >= min_convexity:
-                        continue
-                z0, y0, x0, z1, y1, x1 = (int(v) for v in st[a, 5:11])
-                box = lab0[z0:z1, y0:y1, x0:x1] == a + 1
-                if not convexity_at_least(box, min_convexity, degenerate)[0]:
-                    convex = False          # (the reference tests every component: a later flat one still fails the sample)
-            split[b] = not convex
-        except DegenerateComponent:
-            out["failed"][b] = True          # generate.py:246-248: "Failed", continue
-            out["atoms"][b] = ([], [])
+        for a in range(n):
+            if bnd is not None:
+                # decided from the device's integers where they are conclusive: flat (singular scatter matrix) -> the
+                # reference stack's Qhull call fails; voxels / polytope count >= threshold -> convex, no hull needed
+                if degenerate != "solid" and _scatter_is_singular(int(st[a, 1]), [int(v) for v in st[a, 2:5]],
+                                                                  [int(v) for v in bnd[a, 1:7]]):
+                    verdict[b].append("flat")
+                    continue
+                if int(st[a, 1]) / int(bnd[a, 0]) >= min_convexity:
+                    verdict[b].append(True)
+                    continue
+            z0, y0, x0, z1, y1, x1 = (int(v) for v in st[a, 5:11])
+            verdict[b].append(len(jobs))
+            jobs.append(lab0[z0:z1, y0:y1, x0:x1] == a + 1)
+    decisions = convexity_many(jobs, min_convexity, degenerate)
+    # pass 2: the reference's order per sample -- every component is tested, the first flat one fails the sample
+    for b in range(B):
+        if out["failed"][b]:
+            continue
+        convex = True
+        for v in verdict[b]:
+            if v is True:
+                continue
+            d = "flat" if isinstance(v, str) else decisions[v]
+            if isinstance(d, (str, DegenerateComponent)):
+                out["failed"][b] = True          # generate.py:246-248: "Failed", continue
+                out["atoms"][b] = ([], [])
+                break
+            if not d[0]:
+                convex = False                   # (a later flat component still fails the sample)
+        split[b] = (not convex) and not out["failed"][b]
     todo = [b for b in range(B) if split[b] and not out["failed"][b]]
     if todo:
         Rs, errors = segment_nuclei_batch([(out["mask"][b] != 0).astype(np.int32) for b in todo], max_iters=max_iters,

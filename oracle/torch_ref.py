@@ -564,7 +564,7 @@ def time_unet_predict(B=16, d=32, in_ch=1, steps=1, warmup=0, threads=None):
     return B / sec, threads, sec
 
 
-def time_generate_tail(B=32, d=32, in_ch=1, threads=None, steps=1, warmup=0):
+def time_generate_tail(B=32, d=32, in_ch=1, threads=None, steps=1, warmup=0, full_samples=0):
     """fp32 torch-CPU generate.py:204-236 tail on B synthetic latent vectors: decoder forward -> U-Net forward (eval BN) ->
     argmax / threshold -> connected components (> 3 voxels) -> majority vote + centroids (oracle/watershed_ref.py's
     scipy.ndimage-based convex-branch pass, one sample at a time as the reference does).  The threshold is the 90 %
@@ -605,4 +605,20 @@ def time_generate_tail(B=32, d=32, in_ch=1, threads=None, steps=1, warmup=0):
                 times.append(time.perf_counter() - t0)
     time_generate_tail.samples = list(times)
     sec = float(np.median(times))
+    # ... and what generate.py does with those volumes next (watershed.py:190-203 in full: convex-hull test of every kept
+    # component, marker watershed + recursion where one fails) -- the CPU counterpart of bench.py's
+    # inference.generate.refine block.  Pure-Python heap flood (oracle/watershed_ref.py), so a BOUNDED sample: the first
+    # `full_samples` grids, one at a time as the reference does.
+    time_generate_tail.full = None
+    if full_samples:
+        nf = min(int(full_samples), B)
+        t0 = time.perf_counter()
+        failed = 0
+        for b in range(nf):
+            try:
+                W.watershed_clustering(None, species[b], mask[b], degenerate="solid")
+            except Exception:
+                failed += 1
+        dt = time.perf_counter() - t0
+        time_generate_tail.full = {"grids": nf, "seconds": dt, "s_per_grid": dt / nf, "failed": failed}
     return B / sec, threads, sec

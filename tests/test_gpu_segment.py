@@ -151,9 +151,13 @@ def test_label_boxes_matches_oracle(conn):
             assert list(st[a, 1:4]) == list(idx.min(0)) and list(st[a, 4:7]) == list(idx.max(0) + 1)
 
 
+@pytest.mark.parametrize("where", ["host", "device"])
 @pytest.mark.parametrize("tie", ["heap", "fifo"])
-def test_watershed_split_matches_oracle(tie):
+def test_watershed_split_matches_oracle(tie, where, monkeypatch):
+    """Both forms of ics_op_watershed_split: the host-thread flood that ships since round 6 (the flood is a chain of
+    dependent heap operations; a CPU core walks it ~30x faster than one GPU lane) and the kernel (ICSG3D_WS_DEVICE=1)."""
     from icsg3d_amd.watershed import watershed_split
+    monkeypatch.setenv("ICSG3D_WS_DEVICE", "1" if where == "device" else "0")
     rng = np.random.default_rng(7)
     boxes, cls = [], []
     two = _balls(16, [((6, 6, 4), 4), ((6, 6, 10), 4)])
@@ -178,6 +182,10 @@ def test_watershed_split_matches_oracle(tie):
     if tie == "fifo":
         other = watershed_split(boxes, cls, tie="heap")
         assert any(not np.array_equal(a, b) for a, b in zip(got, other))
+    # host and device forms agree bit for bit (many boxes: the host form deals them to threads)
+    monkeypatch.setenv("ICSG3D_WS_DEVICE", "0" if where == "device" else "1")
+    for a, b in zip(got, watershed_split(boxes * 5, cls * 5, tie=tie)):
+        assert np.array_equal(a, b)
 
 
 def test_segment_nuclei_and_clustering_match_oracle_with_splits_and_recursion():

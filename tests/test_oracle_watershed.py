@@ -183,7 +183,7 @@ def test_convexity_prefilter_decides_exactly_like_the_hull():
     26-direction polytope never counts fewer grid points than the hull, and the decision `convexity >= threshold` is the
     hull's for every threshold -- on balls, unions of balls, random subsets and thin / flat sets -- no GPU needed."""
     from scipy.spatial import QhullError
-    from icsg3d_amd.watershed import DegenerateComponent, convexity_at_least, dop_count, is_flat
+    from icsg3d_amd.watershed import DegenerateComponent, convexity_at_least, convexity_many, dop_count, fill_count, is_flat
     rng = np.random.default_rng(21)
     cases = []
     for _ in range(30):
@@ -204,7 +204,8 @@ def test_convexity_prefilter_decides_exactly_like_the_hull():
         else:
             a[1:3, 1:4, 1:4] = 1
         cases.append(a)
-    decided_cheaply = flat = 0
+    decided_cheaply = flat = decided_nonconvex = 0
+    solid = []
     for img in cases:
         n = int(np.count_nonzero(img))
         if n < 4:
@@ -221,12 +222,19 @@ def test_convexity_prefilter_decides_exactly_like_the_hull():
             with pytest.raises(DegenerateComponent):
                 convexity_at_least(img, 0.8)
             hull = np.count_nonzero(W.convex_hull_image(img, degenerate="solid"))
-        assert dop_count(img) >= hull
+        assert dop_count(img) >= hull >= fill_count(img) >= n      # outer polytope >= hull >= axis-line fill >= the set
         for thr in (0.5, 0.8, 0.9, 1.0):
             ok, val = convexity_at_least(img, thr, degenerate="solid")
             assert ok == (n / hull >= thr), (thr, n, hull, val)
             decided_cheaply += int(ok and val != n / hull)
+            decided_nonconvex += int((not ok) and val != n / hull)
+        solid.append((img, n, hull))
     assert flat >= 10 and decided_cheaply >= 20           # both branches were exercised
+    assert decided_nonconvex >= 10                        # ... and the upper bound settled some non-convex ones without a hull
+    # the batched form (thread pool for the hulls the bounds leave open) takes the same decisions, in order
+    many = convexity_many([c[0] for c in solid], 0.8, degenerate="solid")
+    assert [m[0] for m in many] == [n / hull >= 0.8 for _, n, hull in solid]
+    assert [m[0] for m in convexity_many([c[0] for c in solid], 0.8, degenerate="solid", pool=False)] == [m[0] for m in many]
 
 
 def test_breadth_first_host_logic_against_the_oracle_without_a_gpu(monkeypatch):
