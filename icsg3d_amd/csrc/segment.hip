@@ -17,7 +17,9 @@
 #include "segment.h"
 #include <algorithm>
 #include <atomic>
+#include <climits>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -816,6 +818,137 @@ int segment_watershed_split_host(const int* h_boxes, const int* h_dims, const in
   if (nthreads <= 1 || total < 4096) { work(); return 0; }
   std::vector<std::thread> pool;
   pool.reserve(nthreads - 1);
+  for (int t = 1; t < nthreads; ++t) pool.emplace_back(work);
+  work();
+  for (auto& th : pool) th.join();
+  return 0;
+}
+
+// ---- exact-integer convexity bounds of the components of labelled boxes, on host threads (round 6).
+// icsg3d_amd/watershed.py decides `voxels / count_nonzero(convex_hull_image(component)) >= min_convexity`
+// (/root/reference/watershed.py:80-83) from two bounds of the hull's grid-point count wherever they are conclusive, and
+// calls Qhull only in between: P >= hull >= F with P = grid points of the bounding box inside the component's 26-direction
+// polytope (the voxel set offset by +-0.5 along one axis at a time, as convex_hull_image builds it) and F = the component
+// closed under "every grid point between two voxels of an axis-parallel line".  Also the flatness test (coplanar /
+// collinear sets make the reference stack's Qhull call fail).  In numpy these cost 0.17 ms per component -- more than
+// everything else of a recursion level once the flood left the GPU; here ~10 us, all components of a level in parallel.
+// bounds [nbox][max_labels][4] = {voxels, P, F, flat}; rows of labels with <= min_voxels voxels stay zero.
+namespace {
+void component_bounds_one(const int* lab, int H, int W, int cl, const int* st, long long* out) {
+  const int z0 = st[1], y0 = st[2], x0 = st[3], bd = st[4] - st[1], bh = st[5] - st[2], bw = st[6] - st[3];
+  const int V = bd * bh * bw;
+  std::vector<unsigned char> a(V), f;
+  std::vector<int> px, py, pz;
+  for (int z = 0; z < bd; ++z)
+    for (int y = 0; y < bh; ++y)
+      for (int x = 0; x < bw; ++x) {
+        const bool in = lab[((size_t)(z0 + z) * H + (y0 + y)) * W + (x0 + x)] == cl;
+        a[(z * bh + y) * bw + x] = in;
+        if (in) { pz.push_back(z); py.push_back(y); px.push_back(x); }
+      }
+  const int n = (int)px.size();
+  out[0] = n;
+  if (n == 0) { out[1] = out[2] = 0; out[3] = 1; return; }
+  // flat: all points collinear or coplanar (icsg3d_amd/watershed.py::is_flat, exact integers)
+  bool flat = true;
+  {
+    int i1 = -1;
+    for (int i = 1; i < n && i1 < 0; ++i)
+      if (pz[i] != pz[0] || py[i] != py[0] || px[i] != px[0]) i1 = i;
+    if (i1 >= 0) {
+      const int az = pz[i1] - pz[0], ay = py[i1] - py[0], ax = px[i1] - px[0];
+      int cz = 0, cy = 0, cx = 0;
+      bool have = false;
+      for (int i = 1; i < n && !have; ++i) {
+        const int vz = pz[i] - pz[0], vy = py[i] - py[0], vx = px[i] - px[0];
+        cz = vy * ax - vx * ay; cy = vx * az - vz * ax; cx = vz * ay - vy * az;      // cross(v, a)
+        have = cz != 0 || cy != 0 || cx != 0;
+      }
+      if (have)
+        for (int i = 1; i < n && flat; ++i)
+          if ((pz[i] - pz[0]) * cz + (py[i] - py[0]) * cy + (px[i] - px[0]) * cx != 0) flat = false;
+    }
+  }
+  out[3] = flat ? 1 : 0;
+  // P: the 13 direction classes with components in {-1, 0, 1}; doubled coordinates, the +-0.5 offsets move a support value by
+  // max_k |d_k| / 2 = 1/2 -> pad 1 on the doubled scale
+  int dirs[13][3], nd = 0;
+  for (int dz = -1; dz <= 1; ++dz)
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx)
+        if (dz > 0 || (dz == 0 && (dy > 0 || (dy == 0 && dx > 0)))) { dirs[nd][0] = dz; dirs[nd][1] = dy; dirs[nd][2] = dx; ++nd; }
+  int lo[13], hi[13];
+  for (int k = 0; k < 13; ++k) { lo[k] = INT_MAX; hi[k] = INT_MIN; }
+  for (int i = 0; i < n; ++i)
+    for (int k = 0; k < 13; ++k) {
+      const int pr = dirs[k][0] * pz[i] + dirs[k][1] * py[i] + dirs[k][2] * px[i];
+      lo[k] = pr < lo[k] ? pr : lo[k]; hi[k] = pr > hi[k] ? pr : hi[k];
+    }
+  long long P = 0;
+  for (int z = 0; z < bd; ++z)
+    for (int y = 0; y < bh; ++y)
+      for (int x = 0; x < bw; ++x) {
+        bool in = true;
+        for (int k = 0; k < 13 && in; ++k) {
+          const int g = 2 * (dirs[k][0] * z + dirs[k][1] * y + dirs[k][2] * x);
+          in = g <= 2 * hi[k] + 1 && g >= 2 * lo[k] - 1;
+        }
+        P += in;
+      }
+  out[1] = P;
+  // F: closure under axis-line fills (icsg3d_amd/watershed.py::_fill_mask: at most 4 rounds, which the tests hold equal)
+  f = a;
+  long long cnt = n;
+  const int stride[3] = {bh * bw, bw, 1}, ext[3] = {bd, bh, bw};
+  for (int round = 0; round < 4; ++round) {
+    for (int ax = 0; ax < 3; ++ax) {
+      const int o1 = (ax + 1) % 3, o2 = (ax + 2) % 3;
+      for (int u = 0; u < ext[o1]; ++u)
+        for (int v = 0; v < ext[o2]; ++v) {
+          const int base = u * stride[o1] + v * stride[o2];
+          int first = -1, last = -1;
+          for (int t = 0; t < ext[ax]; ++t)
+            if (f[base + t * stride[ax]]) { if (first < 0) first = t; last = t; }
+          for (int t = first; t >= 0 && t <= last; ++t) f[base + t * stride[ax]] = 1;
+        }
+    }
+    long long m = 0;
+    for (int i = 0; i < V; ++i) m += f[i];
+    if (m == cnt) break;
+    cnt = m;
+  }
+  out[2] = cnt;
+}
+}  // namespace
+
+int segment_component_bounds(const int* h_labels, const int* h_dims, int nbox, const int* h_nlabels, const int* h_stats,
+                             int max_labels, int min_voxels, long long* h_bounds) {
+  ICS_CHECK(h_labels && h_dims && h_nlabels && h_stats && h_bounds && nbox >= 1 && max_labels >= 1, "bad component_bounds arguments");
+  std::vector<BoxDesc> desc;
+  size_t total = 0;
+  ICS_TRY(box_descs(h_dims, nullptr, nbox, &desc, &total));
+  std::memset(h_bounds, 0, (size_t)nbox * max_labels * 4 * sizeof(long long));
+  struct Job { int box, cl; };
+  std::vector<Job> jobs;
+  for (int b = 0; b < nbox; ++b) {
+    ICS_CHECK(h_nlabels[b] >= 0 && h_nlabels[b] <= max_labels, "component_bounds: nlabels exceeds max_labels");
+    for (int c = 0; c < h_nlabels[b]; ++c)
+      if (h_stats[((size_t)b * max_labels + c) * 7] > min_voxels) jobs.push_back(Job{b, c + 1});
+  }
+  std::atomic<size_t> next{0};
+  auto work = [&]() {
+    for (size_t k = next.fetch_add(1); k < jobs.size(); k = next.fetch_add(1)) {
+      const Job j = jobs[k];
+      const BoxDesc& d = desc[j.box];
+      component_bounds_one(h_labels + d.off, d.H, d.W, j.cl, h_stats + ((size_t)j.box * max_labels + j.cl - 1) * 7,
+                           h_bounds + ((size_t)j.box * max_labels + j.cl - 1) * 4);
+    }
+  };
+  unsigned hw = std::thread::hardware_concurrency();
+  if (const char* e = getenv("ICSG3D_HOST_THREADS")) hw = (unsigned)std::max(1, atoi(e));
+  const int nthreads = (int)std::min<size_t>({jobs.size() / 8 + 1, (size_t)std::max(1u, hw / 2), (size_t)64});
+  if (nthreads <= 1) { work(); return 0; }
+  std::vector<std::thread> pool;
   for (int t = 1; t < nthreads; ++t) pool.emplace_back(work);
   work();
   for (auto& th : pool) th.join();

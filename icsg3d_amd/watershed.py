@@ -78,9 +78,12 @@ def segment_atoms(mask, species, min_voxels=3, max_atoms=512, num_species=95, wa
 # ----------------------------------------------------------------------------------------------------------------------
 # device primitives on small boxes
 # ----------------------------------------------------------------------------------------------------------------------
-def label_boxes(vols, connectivity=1, max_labels=1024):
+def label_boxes(vols, connectivity=1, max_labels=1024, want_bounds=False, min_voxels=3):
     """skimage.measure.label(vol, connectivity=...) for each int volume in `vols` (extents <= 64): components of equal
-    non-zero value, raster-order numbering.  Returns [(labels int32, n, stats (n,7) = {voxels, z0, y0, x0, z1, y1, x1})]."""
+    non-zero value, raster-order numbering.  Returns [(labels int32, n, stats (n,7) = {voxels, z0, y0, x0, z1, y1, x1})];
+    with want_bounds a fourth entry, int64 (n,4) = {voxels, P, F, flat} per component with more than min_voxels voxels (zeros
+    otherwise): the exact-integer bounds P >= count_nonzero(convex_hull_image(component)) >= F and the flatness flag the
+    convexity test is decided from (ics_op_component_bounds, host threads)."""
     vols = [np.ascontiguousarray(v, dtype=np.int32) for v in vols]
     if not vols:
         return []
@@ -95,9 +98,15 @@ def label_boxes(vols, connectivity=1, max_labels=1024):
         if int(n.max()) <= max_labels:
             break
         max_labels = int(n.max())
+    bounds = None
+    if want_bounds:
+        bounds = np.zeros((len(vols), max_labels, 4), np.int64)
+        L.check(L.load().ics_op_component_bounds(L.i32ptr(lab), L.i32ptr(dims), len(vols), L.i32ptr(n), L.i32ptr(stats),
+                                                 int(max_labels), int(min_voxels), L.i64ptr(bounds)))
     out, off = [], 0
     for b, v in enumerate(vols):
-        out.append((lab[off:off + v.size].reshape(v.shape), int(n[b]), stats[b, :n[b]].copy()))
+        row = (lab[off:off + v.size].reshape(v.shape), int(n[b]), stats[b, :n[b]].copy())
+        out.append(row + (bounds[b, :n[b]].copy(),) if want_bounds else row)
         off += v.size
     return out
 
@@ -145,31 +154,48 @@ class DegenerateComponent(ValueError):
     generate.py:246-248 prints "Failed" and skips the whole sample.  Parity means the same here: the sample fails."""
 
 
-def convex_hull_volume(img, tolerance=1e-10, degenerate="raise"):
+def convex_hull_volume(img, tolerance=1e-10, degenerate="raise", inside=None, within=None):
     """np.count_nonzero(skimage.morphology.convex_hull_image(img)) for a 3-D box: Qhull over the voxel coordinates
     offset by +-0.5 along each axis, grid points counted when every hull inequality is < tolerance (watershed.py:80-81).
     degenerate: "raise" (default, the reference stack's behaviour: DegenerateComponent for coplanar / collinear sets) or
     "solid" (lenient, NOT the reference: the +-0.5 offsets alone make the set full-dimensional, as later scikit-image
     releases effectively do)."""
     from scipy.spatial import ConvexHull, QhullError
-    pts = np.argwhere(np.asarray(img) != 0).astype(np.float64)
-    if len(pts) == 0:
+    a = np.asarray(img) != 0
+    if not a.any():
         return 0
-    try:                                               # skimage first reduces the set to its hull vertices
-        h0 = ConvexHull(pts)
-        pts = h0.points[h0.vertices]
-    except (QhullError, ValueError) as e:              # flat / collinear sets
-        if degenerate != "solid":
-            raise DegenerateComponent("component of %d voxels is flat: convex_hull_image fails in the reference stack "
-                                      "(%s)" % (len(pts), type(e).__name__)) from e
+    if degenerate == "solid" or not is_flat(np.argwhere(a)):
+        # skimage first reduces the set to its hull vertices with one Qhull call.  Any SUPERSET of the vertices gives the same
+        # second hull, and a vertex is an end point of all three axis-parallel grid lines through it (a point strictly
+        # between two points of the set is not a vertex): that subset costs three shifted compares instead of ~0.7 ms of
+        # Qhull set-up (round 6).
+        end = np.ones_like(a)
+        for ax in range(3):
+            prev = np.roll(a, 1, axis=ax); nxt = np.roll(a, -1, axis=ax)
+            idx = [slice(None)] * 3
+            idx[ax] = 0; prev[tuple(idx)] = False
+            idx[ax] = -1; nxt[tuple(idx)] = False
+            before = np.maximum.accumulate(prev, axis=ax)                     # a voxel of the set earlier on this line
+            after = np.flip(np.maximum.accumulate(np.flip(nxt, ax), axis=ax), ax)
+            end &= ~(before & after)
+        pts = np.argwhere(a & end).astype(np.float64)
+    else:
+        raise DegenerateComponent("component of %d voxels is flat: convex_hull_image fails in the reference stack "
+                                  "(QhullError)" % int(a.sum()))
     off = np.zeros((6, 3))
     off[[0, 1], 0] = (-0.5, 0.5); off[[2, 3], 1] = (-0.5, 0.5); off[[4, 5], 2] = (-0.5, 0.5)
     hull = ConvexHull(np.unique((pts[:, None, :] + off[None]).reshape(-1, 3), axis=0))
-    grid = np.indices(img.shape).reshape(3, -1).astype(np.float64)
-    inside = np.ones(grid.shape[1], bool)
-    for eq in hull.equations:
-        inside &= (eq[:3] @ grid + eq[3]) < tolerance
-    return int(np.count_nonzero(inside))
+    # grid points with every hull inequality < tolerance.  Only the points between the two integer bounds need the test
+    # (round 6): inside the axis-line fill a point is inside the hull, outside the 26-direction polytope it is outside -- both
+    # by at least 0.29 voxels, so the tolerance plays no part there.  All facets of a chunk of points in one matrix product.
+    inner = _fill_mask(img) if inside is None else inside
+    outer = _dop_mask(img) if within is None else within
+    cand = np.argwhere(outer & ~inner).astype(np.float64)
+    count = int(np.count_nonzero(inner))
+    A, b0 = hull.equations[:, :3], hull.equations[:, 3:4]
+    for i in range(0, len(cand), 8192):
+        count += int(np.count_nonzero(np.all(A @ cand[i:i + 8192].T + b0 < tolerance, axis=0)))
+    return count
 
 
 # 13 of the 26 directions with components in {-1, 0, 1} (the other 13 are their negatives: taken care of by min / max)
@@ -207,11 +233,16 @@ def dop_count(img):
     this is an UPPER bound of np.count_nonzero(convex_hull_image(img)) -- exact integer arithmetic on doubled coordinates:
     a grid point g is inside iff  2 min_p(d.p) - pad(d) <= 2 d.g <= 2 max_p(d.p) + pad(d)  for the 13 directions d.
     (A grid point outside one of these planes is at least 0.29 voxels outside the hull: no tolerance question arises.)"""
+    return int(np.count_nonzero(_dop_mask(img)))
+
+
+def _dop_mask(img):
+    """boolean volume: the grid points of the box inside the 26-direction polytope (see dop_count)."""
     pts = np.argwhere(np.asarray(img) != 0).astype(np.int64)
     proj = pts @ _DOP_DIRS.T
     hi, lo = 2 * proj.max(0) + _DOP_PAD, 2 * proj.min(0) - _DOP_PAD
     g = 2 * (np.indices(np.shape(img)).reshape(3, -1).T.astype(np.int64) @ _DOP_DIRS.T)
-    return int(np.count_nonzero(np.all((g <= hi) & (g >= lo), axis=1)))
+    return np.all((g <= hi) & (g >= lo), axis=1).reshape(np.shape(img))
 
 
 def fill_count(img, max_iters=4):
@@ -221,6 +252,10 @@ def fill_count(img, max_iters=4):
     convex_hull_image builds: no tolerance question); repeated until nothing changes, the filled set is still inside the
     hull.  voxels / fill_count is therefore an UPPER bound of the convexity watershed.py:80-83 tests: where it stays below
     min_convexity the component is non-convex and Qhull is not needed (about half of the ragged components)."""
+    return int(np.count_nonzero(_fill_mask(img, max_iters)))
+
+
+def _fill_mask(img, max_iters=4):
     a = np.asarray(img) != 0
     n = int(a.sum())
     for _ in range(max_iters):
@@ -232,7 +267,7 @@ def fill_count(img, max_iters=4):
         if m == n:
             break
         n = m
-    return n
+    return a
 
 
 def convexity_bounds(img, degenerate="raise"):
@@ -247,13 +282,41 @@ def convexity_bounds(img, degenerate="raise"):
     return n, n / dop_count(img), n / fill_count(img)
 
 
-def convexity_many(boxes, threshold, degenerate="raise", pool=None):
-    """[(is_convex, value) | DegenerateComponent] for a list of component boxes -- `convexity_at_least` for each, with the
-    hulls that the integer bounds leave undecided computed on a thread pool (Qhull runs without the GIL)."""
+def _bounds_with_masks(img, degenerate):
+    img = np.asarray(img)
+    n = int(np.count_nonzero(img))
+    if degenerate != "solid" and n > 0 and is_flat(np.argwhere(img != 0)):
+        raise DegenerateComponent("component of %d voxels is flat: convex_hull_image fails in the reference stack" % n)
+    if n == 0:
+        return 0, 0.0, 0.0, None, None
+    outer, inner = _dop_mask(img), _fill_mask(img)
+    return n, n / int(outer.sum()), n / int(inner.sum()), outer, inner
+
+
+def convexity_many(boxes, threshold, degenerate="raise", pool=False, bounds=None):
+    """[(is_convex, value) | DegenerateComponent] for a list of component boxes -- `convexity_at_least` for each.
+    bounds: optional per-box rows {voxels, P, F, flat} from ics_op_component_bounds (label_boxes(want_bounds=True)): the
+    integer bounds then cost nothing here, and only the boxes they leave undecided are looked at (their hulls).
+    pool: a concurrent.futures executor (or None for the module's own) to compute those hulls on -- measured no faster
+    than the plain loop (the GIL is released inside Qhull only), so the default is the loop."""
     out, undecided = [None] * len(boxes), []
     for i, box in enumerate(boxes):
+        if bounds is not None:
+            n, P_, F_, flat = (int(v) for v in bounds[i])
+            if flat and degenerate != "solid":
+                out[i] = DegenerateComponent("component of %d voxels is flat: convex_hull_image fails in the reference stack" % n)
+                continue
+            if n == 0:
+                out[i] = (False, 0.0)
+            elif n / P_ >= threshold:
+                out[i] = (True, n / P_)
+            elif n / F_ < threshold:
+                out[i] = (False, n / F_)
+            else:
+                undecided.append((i, n, None, None))
+            continue
         try:
-            n, lo, hi = convexity_bounds(box, degenerate)
+            n, lo, hi, outer, inner = _bounds_with_masks(box, degenerate)
         except DegenerateComponent as e:
             out[i] = e
             continue
@@ -262,12 +325,12 @@ def convexity_many(boxes, threshold, degenerate="raise", pool=None):
         elif hi < threshold:
             out[i] = (False, hi)
         else:
-            undecided.append((i, n))
+            undecided.append((i, n, outer, inner))
 
     def exact(job):
-        i, n = job
+        i, n, outer, inner = job
         try:
-            c = n / convex_hull_volume(boxes[i], degenerate=degenerate)
+            c = n / convex_hull_volume(boxes[i], degenerate=degenerate, inside=inner, within=outer)
             return i, (c >= threshold, c)
         except DegenerateComponent as e:     # (unreachable after the flat test; kept for safety)
             return i, e
@@ -301,12 +364,12 @@ def convexity_at_least(img, threshold, degenerate="raise"):
     of 1.3 ms per component on the host); and through an upper bound (fill_count) that settles about half of the non-convex
     ones.  `value` is then that bound, otherwise the exact convexity.  Flat components raise DegenerateComponent first,
     exactly where the reference stack's Qhull call fails (degenerate="raise")."""
-    n, lower, upper = convexity_bounds(img, degenerate)
+    n, lower, upper, outer, inner = _bounds_with_masks(img, degenerate)
     if lower >= threshold:
         return True, lower
     if n == 0 or upper < threshold:          # (round 6) the inner bound of the hull already says non-convex
         return False, upper
-    c = n / convex_hull_volume(img, degenerate=degenerate)
+    c = n / convex_hull_volume(img, degenerate=degenerate, inside=inner, within=outer)
     return c >= threshold, c
 
 
@@ -379,12 +442,12 @@ def segment_nuclei_batch(binaries, wmin=8, max_iters=5, min_convexity=0.8, tie="
     errors = [None] * len(roots)
     level = list(roots)
     while level:
-        labelled = label_boxes([n.vol for n in level], connectivity=1)
+        labelled = label_boxes([n.vol for n in level], connectivity=1, want_bounds=True)
         todo = []
         # every kept component of the level: crop, then ONE batch of convexity decisions (integer bounds first, the hulls
         # they leave undecided on a thread pool); the reference's order is restored when the results are consumed
-        cand = []
-        for node, (labels, nlab, stats) in zip(level, labelled):
+        cand, cand_bounds = [], []
+        for node, (labels, nlab, stats, bnds) in zip(level, labelled):
             if errors[node.root] is not None:
                 continue
             for cl in range(1, nlab + 1):
@@ -394,7 +457,8 @@ def segment_nuclei_batch(binaries, wmin=8, max_iters=5, min_convexity=0.8, tie="
                 sl = (slice(z0, z1), slice(y0, y1), slice(x0, x1))
                 box = np.where(labels[sl] == cl, cl, 0).astype(np.int32)       # binary_bbox: values {0, cl}
                 cand.append((node, cl, sl, box, int(stats[cl - 1, 0])))
-        decisions = convexity_many([c[3] for c in cand], min_convexity, degenerate)
+                cand_bounds.append(bnds[cl - 1])
+        decisions = convexity_many([c[3] for c in cand], min_convexity, degenerate, bounds=cand_bounds)
         for (node, cl, sl, box, count), dec in zip(cand, decisions):
             if errors[node.root] is not None:                        # an earlier component of this sample was flat:
                 continue                                             # the reference never reaches this one

@@ -178,6 +178,17 @@ int ics_op_segment_atoms(const uint8_t* mask, const uint8_t* species, int batch,
 int ics_op_label_boxes(const int32_t* vols, const int32_t* dims, int nbox, int connectivity, int max_labels,
                        int32_t* labels, int32_t* nlabels, int32_t* stats);
 int ics_op_watershed_split(const int32_t* boxes, const int32_t* dims, const int32_t* cls, int nbox, int tie, int32_t* wss);
+/* Round 6: ics_op_watershed_split runs on HOST threads by default (one box per thread: the flood is a chain of dependent heap
+ * operations, which one CPU core walks ~30x faster than one GPU lane and which cannot be spread over lanes without changing the
+ * pop order the result depends on); ICSG3D_WS_DEVICE=1 selects the kernel.  Both are held to oracle/watershed_ref.py.
+ * ics_op_component_bounds: the exact-integer bounds the convexity test of watershed.py:80-83 is decided from wherever they
+ * are conclusive, for every component (labels 1..nlabels[b], more than min_voxels voxels) of the label volumes ics_op_label_boxes
+ * returned (same dims / stats layout): bounds [nbox][max_labels][4] = {voxels, P, F, flat} with P >= count_nonzero(
+ * convex_hull_image(component)) >= F -- P = bounding-box grid points inside the component's 26-direction polytope, F = the
+ * component closed under axis-parallel line fills -- and flat = 1 for coplanar / collinear components (the reference stack's
+ * Qhull call fails there).  Host threads; no device work. */
+int ics_op_component_bounds(const int32_t* labels, const int32_t* dims, int nbox, const int32_t* nlabels, const int32_t* stats,
+                            int max_labels, int min_voxels, int64_t* bounds);
 /* The three box-level entry points below keep one stream and one grow-only device scratch buffer per host thread (they are
  * called tens of times per sample from the host recursion of segment_nuclei); this releases the calling thread's. */
 int ics_release_caches(void);

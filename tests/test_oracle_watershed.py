@@ -244,15 +244,18 @@ def test_breadth_first_host_logic_against_the_oracle_without_a_gpu(monkeypatch):
     from scipy.spatial import QhullError
     import icsg3d_amd.watershed as P
 
-    def label_boxes(vols, connectivity=1, max_labels=1024):
+    def label_boxes(vols, connectivity=1, max_labels=1024, want_bounds=False, min_voxels=3):
         out = []
         for v in vols:
             lab, n = W.label_equal(v, connectivity=connectivity)
             stats = np.zeros((n, 7), np.int32)
+            bounds = np.zeros((n, 4), np.int64)
             for cl in range(1, n + 1):
                 m = lab == cl
                 stats[cl - 1] = (int(m.sum()),) + W.bbox_of(m)
-            out.append((lab, n, stats))
+                if stats[cl - 1, 0] > min_voxels:      # the bounds the C++ op returns, from the numpy definitions
+                    bounds[cl - 1] = (int(m.sum()), P.dop_count(m), P.fill_count(m), int(P.is_flat(np.argwhere(m))))
+            out.append((lab, n, stats, bounds) if want_bounds else (lab, n, stats))
         return out
 
     monkeypatch.setattr(P, "label_boxes", label_boxes)
@@ -277,3 +280,46 @@ def test_breadth_first_host_logic_against_the_oracle_without_a_gpu(monkeypatch):
     assert any(t[4] in ("recurse", "split") for t in traces[0])
     # the single-volume wrapper and the depth-first form give the same thing
     assert np.array_equal(P.segment_nuclei(vols[0]), P._segment_nuclei_recursive(vols[0]))
+
+
+def test_component_bounds_op_equals_the_numpy_definitions():
+    """ics_op_component_bounds (host threads inside the library, no device work): {voxels, P, F, flat} of every component of
+    labelled boxes equal icsg3d_amd.watershed's numpy definitions dop_count / fill_count / is_flat -- which the test above
+    holds to Qhull's hull (P >= hull >= F, flat <=> Qhull refuses) -- on ragged random volumes, plates and lines."""
+    import icsg3d_amd.watershed as P
+    rng = np.random.default_rng(8)
+    vols = [(rng.uniform(size=(16, 12, 9)) < 0.3).astype(np.int32), (rng.uniform(size=(20, 20, 20)) < 0.5).astype(np.int32),
+            _balls(24, [((7, 7, 5), 4), ((7, 7, 11), 4), ((17, 17, 17), 5)]), np.zeros((4, 4, 4), np.int32)]
+    plate = np.zeros((8, 8, 8), np.int32); plate[3, 1:6, 1:7] = 1; plate[6, 2, 1:7] = 1
+    vols.append(plate)
+    labs, ns, stats = [], [], []
+    for v in vols:
+        lab, n = W.label_equal(v, connectivity=1)
+        st = np.zeros((max(n, 1), 7), np.int32)
+        for cl in range(1, n + 1):
+            m = lab == cl
+            st[cl - 1] = (int(m.sum()),) + W.bbox_of(m)
+        labs.append(lab.astype(np.int32)); ns.append(n); stats.append(st)
+    max_labels = max(max(ns), 1)
+    S = np.zeros((len(vols), max_labels, 7), np.int32)
+    for b, st in enumerate(stats):
+        S[b, :ns[b]] = st[:ns[b]]
+    from icsg3d_amd import _lib as L
+    dims = np.ascontiguousarray([v.shape for v in vols], dtype=np.int32)
+    flat = np.concatenate([l.ravel() for l in labs]).astype(np.int32)
+    n_arr = np.ascontiguousarray(ns, dtype=np.int32)
+    B = np.full((len(vols), max_labels, 4), -1, np.int64)
+    L.check(L.load().ics_op_component_bounds(L.i32ptr(flat), L.i32ptr(dims), len(vols), L.i32ptr(n_arr), L.i32ptr(S), max_labels, 3,
+                                             L.i64ptr(B)))
+    checked = flats = 0
+    for b, lab in enumerate(labs):
+        for cl in range(1, ns[b] + 1):
+            m = lab == cl
+            if m.sum() <= 3:
+                assert list(B[b, cl - 1]) == [0, 0, 0, 0]
+                continue
+            exp = [int(m.sum()), P.dop_count(m), P.fill_count(m), int(P.is_flat(np.argwhere(m)))]
+            assert list(B[b, cl - 1]) == exp, (b, cl, list(B[b, cl - 1]), exp)
+            checked += 1
+            flats += exp[3]
+    assert checked > 30 and flats >= 2
