@@ -127,8 +127,8 @@ enum ConvFlags : int {
   CF_NO_POOL_PRESUM = 1 << 23,   // ICSG3D_NO_POOL_PRESUM: pool-only layers (perceptual taps) keep the BatchNorm-backward reduce pass
   CF_NO_HEAD_LABELS = 1 << 24,   // ICSG3D_NO_HEAD_LABELS: inference labels from the stored probabilities (labels_kernel), not from the fused head's registers
   CF_ZBATCH = 1 << 20,         // internal: conv_fwd_kernel runs gridDim.z independent GEMMs (launch_gemm_zbatch)
-  CF_NO_TICKET = 131072,       // ICSG3D_NO_TICKET: one bias-gradient finalize launch per layer instead of one batched launch per
-                               // step / gradient bucket (round 4)
+  // (131072 was CF_NO_TICKET, the per-layer bias-gradient finalize of round 3: removed in round 6 with the other switches
+  // DESIGN.md records as rejected -- ICSG3D_SIDE_STREAM, ICSG3D_NO_ARENA)
 };
 int conv_flags_from_env();
 

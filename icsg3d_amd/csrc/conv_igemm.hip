@@ -69,7 +69,6 @@ int conv_flags_from_env() {
   if (getenv("ICSG3D_NO_FAST_BNBWD")) f |= CF_NO_FAST_BNBWD;
   if (getenv("ICSG3D_NO_FUSED_HEAD")) f |= CF_NO_FUSED_HEAD;
   if (getenv("ICSG3D_NO_BWD_FOLD")) f |= CF_NO_BWD_FOLD;
-  if (getenv("ICSG3D_NO_TICKET")) f |= CF_NO_TICKET;
   if (getenv("ICSG3D_NO_WINOG")) f |= CF_NO_WINOG;
   if (getenv("ICSG3D_NO_HEAD_BNFUSE")) f |= CF_NO_HEAD_BNFUSE;
   if (getenv("ICSG3D_NO_UP3N")) f |= CF_NO_UP3N;

@@ -118,7 +118,6 @@ size_t pool_bnfuse_partial_doubles(size_t pooled_rows, int C);
 int launch_pool_bnfuse(hipStream_t st, const float* g, int ldg, const unsigned char* mask, const float* ssum, size_t pooled_rows,
                        int C, double cnt, const double* sums_conv, const float* mean, const float* rstd, const float* scale,
                        float* abc, float* c1c2, float* dgamma, float* dbeta, double* ws_partial, size_t ws_partial_doubles);
-int launch_colsum_finalize(hipStream_t st, const float* partial, int nblk, int C, float* out);
 int launch_head_fused(hipStream_t st, const float* x, int ldx, const float* scale, const float* shift, const float* wsoft_k,
                       const float* wsig_k, const float* bsoft, const float* bsig, float* z, const unsigned char* labels,
                       size_t M, int mode, int want_grad, float wsoft, double* partial, int partial_blocks, float* metrics,

@@ -1784,11 +1784,6 @@ int launch_pool_bnfuse(hipStream_t st, const float* g, int ldg, const unsigned c
   ICS_HIP(hipGetLastError());
   return 0;
 }
-int launch_colsum_finalize(hipStream_t st, const float* partial, int nblk, int C, float* out) {
-  ICS_LAUNCH(colsum_finalize_kernel, dim3(C), dim3(256), 0, st, partial, nblk, C, out);
-  ICS_HIP(hipGetLastError());
-  return 0;
-}
 
 bool head_dgrad_ok(int ncls, int cin, size_t M, const BwdStat* bs, int flags) {
   return ncls == 95 && cin == 128 && M % 16 == 0 && (bs == nullptr || bs->partial == nullptr || bs->post_act == ACT_NONE) &&
@@ -2089,32 +2084,34 @@ int launch_sampling(hipStream_t st, const float* mulv, int ld, int latent, const
 // dmulv[b][latent:] = dz*eps*0.5*exp(0.5 lv) + beta*(-0.5)*(1-exp(lv))/B
 // phase 0: everything; phase 1: raw sums only -> sums[5] = {kl, squared error, weighted pm, B, n_elems};
 // phase 2: metrics from the (all-reduced) sums  (data parallel: numerators / denominators)
-__global__ __launch_bounds__(256) void vae_loss_kernel(const float* __restrict__ mulv, int ld, int latent,
+__global__ __launch_bounds__(1024) void vae_loss_kernel(const float* __restrict__ mulv, int ld, int latent,
                                                        int B, const double* __restrict__ mse_partial,
                                                        int n_mse, double n_elems,
                                                        const double* __restrict__ pm_partial,
                                                        PmSums pmc, float alpha,
                                                        float beta, float* __restrict__ metrics,
                                                        double* __restrict__ sums, int phase) {
-  __shared__ double sh[4];
+  // 1024 threads (round 6: with 256 the 8192 fp64 exp() of the KL term alone took 31 us on the step's critical chain)
+  __shared__ double sh[16];
+  const int nt = (int)blockDim.x;
   double kl = 0.0, mse = 0.0, pm = 0.0, nb_tot = (double)B;
   if (phase == 2) {
     kl = sums[0]; mse = sums[1]; pm = sums[2]; nb_tot = sums[3]; n_elems = sums[4];
   } else {
-    for (int i = threadIdx.x; i < B * latent; i += 256) {
+    for (int i = threadIdx.x; i < B * latent; i += nt) {
       const int b = i / latent, j = i % latent;
       const double mu = mulv[b * ld + j], lv = mulv[b * ld + latent + j];
       kl += -0.5 * (1.0 + lv - mu * mu - exp(lv));
     }
-    kl = block_sum_d(kl, sh);
-    for (int i = threadIdx.x; i < n_mse; i += 256) mse += mse_partial[i];
-    mse = block_sum_d(mse, sh);
+    kl = block_sum_dn(kl, sh);
+    for (int i = threadIdx.x; i < n_mse; i += nt) mse += mse_partial[i];
+    mse = block_sum_dn(mse, sh);
     size_t off = 0;
     for (int l = 0; l < 4; ++l) {
       const int nb = pmc.n[l];
       double s = 0.0;
-      for (int i = threadIdx.x; i < nb; i += 256) s += pm_partial[off + i];
-      s = block_sum_d(s, sh);
+      for (int i = threadIdx.x; i < nb; i += nt) s += pm_partial[off + i];
+      s = block_sum_dn(s, sh);
       pm += (double)pmc.w[l] * s / pmc.per[l];
       off += nb;
     }
@@ -2145,7 +2142,7 @@ __global__ void vae_dz_kernel(const float* __restrict__ mulv, int ld, int latent
 int launch_vae_loss(hipStream_t st, const float* mulv, int ld, int latent, int B, const double* mse_partial,
                     int n_mse, double n_elems, const double* pm_partial, const PmSums& pmc, float alpha, float beta,
                     float* metrics, double* sums, int phase) {
-  ICS_LAUNCH(vae_loss_kernel, dim3(1), dim3(256), 0, st, mulv, ld, latent, B, mse_partial, n_mse,
+  ICS_LAUNCH(vae_loss_kernel, dim3(1), dim3(1024), 0, st, mulv, ld, latent, B, mse_partial, n_mse,
                      n_elems, pm_partial, pmc, alpha, beta, metrics, sums, phase);
   ICS_HIP(hipGetLastError());
   return 0;

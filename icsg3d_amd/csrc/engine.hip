@@ -196,12 +196,11 @@ struct Net {
   int device = 0;
   int flags = 0;  // ConvFlags, read from the environment when the handle is created
   hipStream_t st = nullptr;
-  // OPT-IN (ICSG3D_SIDE_STREAM=1, U-Net engine only) second stream for the weight-gradient GEMMs: they need only a
-  // layer's dy, and the chain bn_bwd -> backward-data -> next layer never waits for them until the gradients are
-  // consumed, so the two kernel sequences can fill each other's tail rounds.  Measured: U-Net step 66.50 -> 66.15 ms
-  // (-0.5 %); DFC-VAE 12.59 -> 12.71 ms (its small kernels only slow each other down).  Off by default: concurrent
-  // kernels make every per-kernel duration (HIP events, rocprofv3) -- and with it the roofline accounting --
-  // meaningless, for half a percent.
+  // Second stream for the weight-gradient GEMMs (they need only a layer's dy, and the chain bn_bwd -> backward-data -> next
+  // layer never waits for them until the gradients are consumed).  The DFC-VAE engine uses it (round 5: 5.71 -> 5.44 ms);
+  // for the U-Net engine it measured -0.5 % in rounds 1 and 3 at the price of meaningless per-kernel durations and of the
+  // BatchNorm-backward fusions (which need the weight-gradient GEMM's result in stream order): rejected, and the opt-in
+  // switch (ICSG3D_SIDE_STREAM) was removed in round 6.
   hipStream_t st2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool side_on = true, side_dirty = false;
@@ -306,15 +305,14 @@ struct Net {
     if (st_own) (void)hipStreamDestroy(st_own);
     else if (st) (void)hipStreamDestroy(st);
   }
-  // Device memory comes out of a few large slabs per handle (ICSG3D_NO_ARENA=1: one hipMalloc per buffer, as before round
-  // 5): buffers below kArenaBig are carved out of chunks (128 MB, doubling to 1 GB) at 2 MB alignment (256 B for small ones), larger ones get their
+  // Device memory comes out of a few large slabs per handle: buffers below kArenaBig are carved out of chunks (128 MB, doubling to 1 GB) at 2 MB alignment (256 B for small ones), larger ones get their
   // own allocation.  A handle's few hundred buffers then sit in a handful of contiguous, large-page-backed ranges whatever
   // the process allocated or freed before -- see DESIGN.md section 10 (the DFC-VAE's two-stream schedule ran 10 % slower when
   // its buffers had been allocated one by one after a U-Net training step).
   static constexpr size_t kArenaChunk = (size_t)1 << 30, kArenaBig = (size_t)1 << 28;
   char* arena_cur = nullptr;
   size_t arena_left = 0, arena_next = (size_t)1 << 27;
-  bool arena_on = getenv("ICSG3D_NO_ARENA") == nullptr;
+  bool arena_on = true;
   template <typename T>
   int alloc(T** out, size_t n) {
     const size_t bytes = n * sizeof(T) + 256;
@@ -1079,8 +1077,8 @@ static int conv_grads_from_dy(Net& n, ConvLayer& L, int B, bool need_dA, bool pa
       ICS_CHECK(blocks > 0, "fused BatchNorm-backward apply: the backward-data launch did not take it");
       next->dy_ready = true;
       next->db_blocks = 0;
-      if (n.flags & CF_NO_TICKET) ICS_TRY(launch_colsum_finalize(n.st, next->db_partial, blocks, next->Cout, n.tg(next->t_b)));
-      else { ICS_TRY(colsum_push(n, next->db_partial, blocks, next->Cout, n.tg(next->t_b))); next->db_blocks = blocks; }
+      ICS_TRY(colsum_push(n, next->db_partial, blocks, next->Cout, n.tg(next->t_b)));
+      next->db_blocks = blocks;
       return 0;
     }
     const BwdStat bs = bwd_stat_for(n, next, B);
@@ -1157,8 +1155,8 @@ static int conv_backward(Net& n, ConvLayer& L, int B, GradSrc g0, GradSrc g1, co
     n.prof.end(n.st);
     ICS_CHECK(blocks > 0, "deferred skip backward-data: the launch did not take the fused apply");
     L.db_blocks = 0;
-    if (n.flags & CF_NO_TICKET) ICS_TRY(launch_colsum_finalize(n.st, L.db_partial, blocks, L.Cout, n.tg(L.t_b)));
-    else { ICS_TRY(colsum_push(n, L.db_partial, blocks, L.Cout, n.tg(L.t_b))); L.db_blocks = blocks; }
+    ICS_TRY(colsum_push(n, L.db_partial, blocks, L.Cout, n.tg(L.t_b)));
+    L.db_blocks = blocks;
     return conv_grads_from_dy(n, L, B, need_dA, param_grads, next);
   }
   BwdPre pre{n.ws_bwd2, L.bwd_pre_nblk, L.bwd_pre_ld};
@@ -1176,7 +1174,7 @@ static int conv_backward(Net& n, ConvLayer& L, int B, GradSrc g0, GradSrc g1, co
     pre.nblk = pb; pre.ld = L.Cout;
   }
   n.prof.begin(n.st, "bn_act_bwd:" + L.name, 0, 4.0 * M * L.Cout * (L.has_bn ? (pre.nblk ? 3.0 : 5.0) : 3.0));
-  const bool defer = param_grads && L.db_partial != nullptr && !(n.flags & CF_NO_TICKET);
+  const bool defer = param_grads && L.db_partial != nullptr;
   int db_blocks = 0;
   ICS_TRY(launch_layer_bwd(n.st, lb, L.dy, n.ws_bwd, L.c1c2,
                            (param_grads && L.has_bn) ? n.tg(L.t_gamma) : nullptr,
@@ -1268,7 +1266,7 @@ static UnetRefs unet_refs(Net& n) {
 }
 
 static int unet_build(Net& n, const ics_unet_config& cfg) {
-  n.side_on = getenv("ICSG3D_SIDE_STREAM") != nullptr;
+  n.side_on = false;     // the U-Net's weight gradients stay on the engine's stream (see Net::st2)
   n.kind = 0; n.maxB = cfg.max_batch; n.d = cfg.d; n.C = cfg.in_channels; n.ncls = cfg.num_classes;
   n.lr = cfg.lr; n.loss_weight = cfg.loss_weight > 0 ? cfg.loss_weight : (float)cfg.num_classes;
   n.pool_ties_all = cfg.pool_ties_all; n.bn_unbias = cfg.bn_unbias; n.bce_from_logits = cfg.bce_from_logits ? 1 : 0;
@@ -1888,7 +1886,10 @@ static int vae_step(Net& n, int B, bool training, float* metrics) {
       if ((rc = unet_pm_backward(u, B))) break;
     }
     if (!n.comm) {
-      if ((rc = launch_vae_loss(n.st, r.zml->s, 2 * n.latent, n.latent, B, mse_part, B * mse_bps, (double)M * n.C,
+      // the loss VALUE is not an input of the backward pass: on the second stream (when the step uses one) it leaves the
+      // critical chain; adam_step joins the streams before the metrics can be read (round 6)
+      hipStream_t ls = training ? side_begin(n) : n.st;
+      if ((rc = launch_vae_loss(ls, r.zml->s, 2 * n.latent, n.latent, B, mse_part, B * mse_bps, (double)M * n.C,
                                 pm_part, pmc, n.alpha, n.beta, n.d_metrics))) break;
     } else if (metrics) {
       // data parallel: all-reduce the sums (numerators / denominators), then form the means

@@ -16,6 +16,11 @@ def main():
     _lib.check(_lib.load().ics_set_device(int(os.environ.get("LOCAL_RANK", "0"))))
     import torch.distributed as dist
     dist.init_process_group("gloo")
+    # hang protection for the first run on real multi-GPU hardware: a collective that never completes ends this rank (exit 3)
+    # after ICSG3D_WATCHDOG_S seconds without a beat instead of holding the lease (icsg3d_amd/watchdog.py)
+    from icsg3d_amd.watchdog import StepWatchdog
+    wd = StepWatchdog(rank=rank)
+    wd.beat("start")
     from icsg3d_amd.dataparallel import init_engine_comm
     from icsg3d_amd.engine import UnetEngine
     from icsg3d_amd.synthetic import glorot_params, synthetic_batch, unet_param_shapes
@@ -28,8 +33,13 @@ def main():
         eng = UnetEngine(in_channels=1, d=d, max_batch=B, lr=1e-3)
         # replicas start DIFFERENT on purpose: broadcast_state must make them rank 0's
         eng.set_weights(P if rank == 0 else glorot_params(unet_param_shapes(1, 95), 77))
+        wd.beat("U-Net comm init (sync_bn=%s)" % sync_bn)
         init_engine_comm(eng, dist, rank, world, sync_bn=sync_bn)
-        m = [eng.train_step(X[lo:lo + B], lab[lo:lo + B]) for _ in range(2)]
+        m = []
+        for i in range(2):
+            wd.beat("U-Net train step %d (sync_bn=%s: %s)" % (i, sync_bn, "two communicators in flight" if sync_bn else "buckets only"))
+            m.append(eng.train_step(X[lo:lo + B], lab[lo:lo + B]))
+        wd.beat("U-Net replica comparison (sync_bn=%s)" % sync_bn)
         w = eng.get_weights()
         g = {n: eng.get_grad(n, s) for n, s, tr in eng.tensor_infos() if tr}
         # every rank must hold the same averaged gradients, the same weights and the same BN moving statistics
@@ -48,7 +58,9 @@ def main():
                 # steps and the gradients of the second step agree to fp32 rounding
                 err_m = max(float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-12)) for a, b in zip(m, mr))
                 err_g = max(float(np.abs(g[k] - gr[k]).max() / max(np.abs(gr[k]).max(), 1e-12)) for k in g)
-                out["sync_bn"] = {"metrics_err": err_m, "grad_err": err_g}
+                # SyncBN + overlapped buckets = the two-communicator path (statistics on the split communicator while a
+                # gradient bucket is in flight on the first): the buckets must really have been issued
+                out["sync_bn"] = {"metrics_err": err_m, "grad_err": err_g, "buckets": eng.comm_info()["buckets_last_step"]}
             else:
                 # local BN: each replica = the reference at its own batch; only the loss numerators are comparable
                 out["local_bn"] = {"loss": float(m[0][0]), "loss_full_batch": float(mr[0][0]),
@@ -68,8 +80,13 @@ def main():
         pm.set_weights(P)
         ve = VaeEngine(pm, in_channels=1, d=d, max_batch=B, lr=5e-4)
         ve.set_weights(PV if rank == 0 else glorot_params(vae_param_shapes(1, d=d), 78))
+        wd.beat("DFC-VAE comm init (sync_bn=%s)" % sync_bn)
         init_engine_comm(ve, dist, rank, world, sync_bn=sync_bn)
-        m = [ve.train_step(Xv[lo:lo + B], cond[lo:lo + B], eps[lo:lo + B]) for _ in range(2)]
+        m = []
+        for i in range(2):
+            wd.beat("DFC-VAE train step %d (sync_bn=%s)" % (i, sync_bn))
+            m.append(ve.train_step(Xv[lo:lo + B], cond[lo:lo + B], eps[lo:lo + B]))
+        wd.beat("DFC-VAE replica comparison (sync_bn=%s)" % sync_bn)
         w = ve.get_weights()
         g = {n: ve.get_grad(n, s) for n, s, tr in ve.tensor_infos() if tr}
         for k in sorted(w):
@@ -93,7 +110,9 @@ def main():
         dist.barrier()
     if rank == 0:
         print("DP2_RESULT " + json.dumps(out))
+    wd.beat("teardown")
     dist.destroy_process_group()
+    wd.stop()
 
 
 if __name__ == "__main__":

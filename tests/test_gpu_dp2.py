@@ -28,4 +28,5 @@ def test_two_ranks_match_one_process_at_twice_the_batch():
     r = json.loads(line[len("DP2_RESULT "):])
     assert r["sync_bn"]["metrics_err"] <= 2e-5 and r["sync_bn"]["grad_err"] <= 1e-4, r
     assert r["local_bn"]["buckets"] >= 3, r
+    assert r["sync_bn"]["buckets"] >= 3, r        # SyncBN collectives ran next to overlapped gradient buckets (two communicators)
     assert r["vae_sync_bn"]["metrics_err"] <= 5e-5 and r["vae_sync_bn"]["grad_err"] <= 2e-4, r
