@@ -287,7 +287,7 @@ def main():
         """the timed region is 20 steps = 0.56 s -- too short for the driver's GPU sampler to see and too
         short to say what the chip does after ten seconds at 100 TFLOP/s.  The same step, events off, for >= --soak-seconds,
         between the same barriers, on the host clock and on the GPU's own; reported as `sustained`, never as `value`."""
-        n = max(args.steps, int(args.soak_seconds / max(ms_per_step * 1e-3, 1e-6)) + 1)
+        n = max(args.steps, int(1.03 * args.soak_seconds / max(ms_per_step * 1e-3, 1e-6)) + 2)   # 3 % margin: at least soak_seconds
         wd.beat("sustained soak: %d steps" % n)
         for e in engines:
             e.sync()

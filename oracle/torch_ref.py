@@ -359,6 +359,11 @@ def unet_metrics(soft, labels, num_classes=95):
     wr = yp[:, 1:].sum() / (y[:, 1:].sum() + K_EPS)
     unet_metrics.counts = {"tp": float(tp), "predicted": float(predicted), "wr_tp": float(yp[:, 1:].sum()),
                            "wr_possible": float(y[:, 1:].sum()), "voxels": float(possible)}
+    # K.round at one half is a discontinuity: probabilities within 2e-5 of 0.5 (the fp32 forward tolerance on a probability)
+    # may round either way in an fp32 implementation -- how many such entries each count holds
+    near = (p - 0.5).abs() <= 2e-5
+    unet_metrics.borderline = {"predicted": float(near.sum()), "tp": float((near & (y > 0)).sum()),
+                               "wr_tp": float((near[:, 1:] & (y[:, 1:] > 0)).sum()), "wr_possible": 0.0}
     return float(f1), float(wr)
 
 
