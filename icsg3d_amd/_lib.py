@@ -75,7 +75,7 @@ SIGNATURES = {
     "ics_release_caches": (C.c_int, []),
     "ics_op_label_boxes": (C.c_int, [_I32, _I32, C.c_int, C.c_int, C.c_int, _I32, _I32, _I32]),
     "ics_op_watershed_split": (C.c_int, [_I32, _I32, _I32, C.c_int, C.c_int, _I32]),
-    "ics_op_component_bounds": (C.c_int, [_I32, _I32, C.c_int, _I32, _I32, C.c_int, C.c_int, _I64]),
+    "ics_op_component_bounds": (C.c_int, [_I32, _I32, C.c_int, _I32, _I32, C.c_int, C.c_int, C.c_double, _I64]),
     "ics_op_region_stats": (C.c_int, [_I32, _U8, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _I32]),
     "ics_net_destroy": (C.c_int, [_H]),
     "ics_net_sync": (C.c_int, [_H]),

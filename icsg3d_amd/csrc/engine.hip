@@ -2692,9 +2692,10 @@ int ics_op_region_stats(const int32_t* R, const uint8_t* species, int D, int H, 
   return segment_region_stats(st, R, species, D, H, W, num_labels, num_species, stats);
 }
 int ics_op_component_bounds(const int32_t* labels, const int32_t* dims, int nbox, const int32_t* nlabels, const int32_t* stats,
-                            int max_labels, int min_voxels, int64_t* bounds) {
+                            int max_labels, int min_voxels, double hull_threshold, int64_t* bounds) {
   static_assert(sizeof(long long) == sizeof(int64_t), "int64 layout");
-  return segment_component_bounds(labels, dims, nbox, nlabels, stats, max_labels, min_voxels, reinterpret_cast<long long*>(bounds));
+  return segment_component_bounds(labels, dims, nbox, nlabels, stats, max_labels, min_voxels, hull_threshold,
+                                  reinterpret_cast<long long*>(bounds));
 }
 int ics_op_watershed_split(const int32_t* boxes, const int32_t* dims, const int32_t* cls, int nbox, int tie, int32_t* wss) {
   // Round 6: the boxes of a level go to host threads (segment_watershed_split_host: the flood is sequential per box and a

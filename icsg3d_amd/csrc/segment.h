@@ -40,9 +40,10 @@ int segment_watershed_split(hipStream_t st, const int* h_boxes, const int* h_dim
 int segment_watershed_split_host(const int* h_boxes, const int* h_dims, const int* h_cls, int nbox, int tie, int* h_wss);
 
 // Exact-integer convexity bounds per component of labelled boxes (what ics_op_label_boxes returned), host threads:
-// h_bounds [nbox][max_labels][4] = {voxels, polytope count P >= hull count, axis-line fill count F <= hull count, flat}.
+// h_bounds [nbox][max_labels][5] = {voxels, polytope count P >= hull count, axis-line fill count F <= hull count, flat,
+// H = the exact hull count where hull_threshold > 0 and the two bounds leave voxels / hull >= hull_threshold open, else 0}.
 int segment_component_bounds(const int* h_labels, const int* h_dims, int nbox, const int* h_nlabels, const int* h_stats,
-                             int max_labels, int min_voxels, long long* h_bounds);
+                             int max_labels, int min_voxels, double hull_threshold, long long* h_bounds);
 
 // frees the calling thread's grow-only scratch of the three box-level entry points above
 void segment_release_scratch();

@@ -21,7 +21,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <set>
 #include <thread>
+#include <tuple>
+#include <utility>
 #include <vector>
 
 namespace ics {
@@ -832,12 +835,161 @@ int segment_watershed_split_host(const int* h_boxes, const int* h_dims, const in
 // closed under "every grid point between two voxels of an axis-parallel line".  Also the flatness test (coplanar /
 // collinear sets make the reference stack's Qhull call fail).  In numpy these cost 0.17 ms per component -- more than
 // everything else of a recursion level once the flood left the GPU; here ~10 us, all components of a level in parallel.
-// bounds [nbox][max_labels][4] = {voxels, P, F, flat}; rows of labels with <= min_voxels voxels stay zero.
+// bounds [nbox][max_labels][5] = {voxels, P, F, flat, H}; rows of labels with <= min_voxels voxels stay zero; H = the exact
+// hull count, computed only where hull_threshold > 0 and voxels / P < hull_threshold <= voxels / F (else 0).
 namespace {
-void component_bounds_one(const int* lab, int H, int W, int cl, const int* st, long long* out) {
+// ---- exact grid-point count of convex_hull_image(component) (round 6).  skimage offsets every voxel centre by +-0.5 along one
+// axis at a time and counts the grid points inside the hull of those points; on doubled coordinates everything is an integer:
+// S' = {2p +- e_k}.  The facet planes of conv(S') are found by gift wrapping with exact predicates (coordinates < 2^8, triple
+// products < 2^27) and -- lattice sets being as degenerate as point sets get -- with whole coplanar groups per facet: a
+// supporting plane's points are hulled in 2-D, its polygon's edges are pivoted across to the neighbouring planes.  A grid point
+// is inside iff no plane excludes it; a point ON a plane is inside (Qhull evaluates those to ~1e-16 < the reference's 1e-10
+// tolerance, watershed.py:80-81 / convex_hull_image).  Only the points between the two integer bounds need the test.
+struct HP { int x, y, z; };
+inline long long h_triple(const HP& a, const HP& b, const HP& c, const HP& d) {
+  const long long ux = b.x - a.x, uy = b.y - a.y, uz = b.z - a.z, vx = c.x - a.x, vy = c.y - a.y, vz = c.z - a.z,
+                  wx = d.x - a.x, wy = d.y - a.y, wz = d.z - a.z;
+  return ux * (vy * wz - vz * wy) - uy * (vx * wz - vz * wx) + uz * (vx * wy - vy * wx);
+}
+inline bool h_collinear(const HP& a, const HP& b, const HP& p) {
+  const long long ux = b.x - a.x, uy = b.y - a.y, uz = b.z - a.z, vx = p.x - a.x, vy = p.y - a.y, vz = p.z - a.z;
+  return uy * vz - uz * vy == 0 && uz * vx - ux * vz == 0 && ux * vy - uy * vx == 0;
+}
+struct HPlane {
+  long long nx, ny, nz, d;      // n . p <= d for every point of the set; (n, d) reduced by their gcd
+  bool operator<(const HPlane& o) const { return std::tie(nx, ny, nz, d) < std::tie(o.nx, o.ny, o.nz, o.d); }
+};
+long long h_gcd(long long a, long long b) { a = a < 0 ? -a : a; b = b < 0 ? -b : b; while (b) { const long long t = a % b; a = b; b = t; } return a; }
+// the supporting plane through a, b, c (not collinear), oriented away from the set; false if points lie on both sides
+bool h_plane(const std::vector<HP>& pts, const HP& a, const HP& b, const HP& c, HPlane* out) {
+  long long nx = (long long)(b.y - a.y) * (c.z - a.z) - (long long)(b.z - a.z) * (c.y - a.y);
+  long long ny = (long long)(b.z - a.z) * (c.x - a.x) - (long long)(b.x - a.x) * (c.z - a.z);
+  long long nz = (long long)(b.x - a.x) * (c.y - a.y) - (long long)(b.y - a.y) * (c.x - a.x);
+  const long long g = h_gcd(h_gcd(nx, ny), nz);
+  if (g == 0) return false;
+  nx /= g; ny /= g; nz /= g;
+  const long long d = nx * a.x + ny * a.y + nz * a.z;
+  int side = 0;
+  for (const HP& p : pts) {
+    const long long v = nx * p.x + ny * p.y + nz * p.z - d;
+    if (v == 0) continue;
+    const int s = v > 0 ? 1 : -1;
+    if (side == 0) side = s;
+    else if (side != s) return false;
+  }
+  if (side > 0) { nx = -nx; ny = -ny; nz = -nz; *out = HPlane{nx, ny, nz, -d}; }
+  else *out = HPlane{nx, ny, nz, d};
+  return true;
+}
+// boundary edges (index pairs into pts) of the convex polygon formed by the points on `pl`
+void h_face_edges(const std::vector<HP>& pts, const HPlane& pl, std::vector<std::pair<int, int>>* edges) {
+  std::vector<int> on;
+  for (int i = 0; i < (int)pts.size(); ++i)
+    if (pl.nx * pts[i].x + pl.ny * pts[i].y + pl.nz * pts[i].z == pl.d) on.push_back(i);
+  const long long ax = pl.nx < 0 ? -pl.nx : pl.nx, ay = pl.ny < 0 ? -pl.ny : pl.ny, az = pl.nz < 0 ? -pl.nz : pl.nz;
+  const int drop = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
+  auto U = [&](int i) { return drop == 0 ? pts[i].y : pts[i].x; };
+  auto V = [&](int i) { return drop == 2 ? pts[i].y : pts[i].z; };
+  std::sort(on.begin(), on.end(), [&](int i, int j) { return U(i) != U(j) ? U(i) < U(j) : V(i) < V(j); });
+  auto cross = [&](int o, int a, int b) {
+    return (long long)(U(a) - U(o)) * (V(b) - V(o)) - (long long)(V(a) - V(o)) * (U(b) - U(o));
+  };
+  std::vector<int> h(2 * on.size());
+  int k = 0;
+  for (int i = 0; i < (int)on.size(); ++i) {                      // monotone chain, collinear points dropped
+    while (k >= 2 && cross(h[k - 2], h[k - 1], on[i]) <= 0) --k;
+    h[k++] = on[i];
+  }
+  for (int i = (int)on.size() - 2, t = k + 1; i >= 0; --i) {
+    while (k >= t && cross(h[k - 2], h[k - 1], on[i]) <= 0) --k;
+    h[k++] = on[i];
+  }
+  --k;
+  for (int i = 0; i < k; ++i) edges->push_back({h[i], h[(i + 1) % k]});
+}
+// both supporting planes through the hull edge (a, b): the extreme directions of the set seen along the edge
+void h_pivot(const std::vector<HP>& pts, int ia, int ib, std::vector<HPlane>* out) {
+  const HP &a = pts[ia], &b = pts[ib];
+  int c1 = -1, c2 = -1;
+  for (int i = 0; i < (int)pts.size(); ++i) {
+    if (i == ia || i == ib || h_collinear(a, b, pts[i])) continue;
+    if (c1 < 0) { c1 = c2 = i; continue; }
+    if (h_triple(a, b, pts[c1], pts[i]) < 0) c1 = i;
+    if (h_triple(a, b, pts[c2], pts[i]) > 0) c2 = i;
+  }
+  HPlane pl;
+  if (c1 >= 0 && h_plane(pts, a, b, pts[c1], &pl)) out->push_back(pl);
+  if (c2 >= 0 && h_plane(pts, a, b, pts[c2], &pl)) out->push_back(pl);
+}
+// all facet planes of conv(pts); false if the search did not close (never observed; the caller then falls back to "undecided")
+bool h_planes(const std::vector<HP>& pts, std::set<HPlane>* planes) {
+  if (pts.size() < 4) return false;
+  // a first supporting plane: the points of minimal x lie on x = xmin; tilt it around its extreme points until it is a facet
+  int v0 = 0;
+  for (int i = 1; i < (int)pts.size(); ++i)
+    if (std::tie(pts[i].x, pts[i].y, pts[i].z) < std::tie(pts[v0].x, pts[v0].y, pts[v0].z)) v0 = i;
+  // an edge from the vertex v0: gift wrapping in the projection along z gives a vertical supporting plane through v0; the
+  // points on it are hulled in that plane; any boundary edge of that (possibly degenerate) polygon is a hull edge
+  int v1 = -1;
+  for (int i = 0; i < (int)pts.size(); ++i) {
+    if (pts[i].x == pts[v0].x && pts[i].y == pts[v0].y) continue;            // same projection
+    if (v1 < 0) { v1 = i; continue; }
+    const long long cr = (long long)(pts[v1].x - pts[v0].x) * (pts[i].y - pts[v0].y) -
+                         (long long)(pts[v1].y - pts[v0].y) * (pts[i].x - pts[v0].x);
+    if (cr < 0) v1 = i;
+  }
+  std::vector<std::pair<int, int>> todo;
+  if (v1 < 0) return false;                                                   // every point projects onto v0: a z line
+  {
+    // vertical plane through v0, v1: normal (dy, -dx, 0)
+    long long nx = pts[v1].y - pts[v0].y, ny = -(long long)(pts[v1].x - pts[v0].x);
+    const long long g = h_gcd(nx, ny);
+    nx /= g; ny /= g;
+    long long d = nx * pts[v0].x + ny * pts[v0].y;
+    int side = 0;
+    for (const HP& p : pts) { const long long v = nx * p.x + ny * p.y - d; if (v != 0) { side = v > 0 ? 1 : -1; break; } }
+    if (side > 0) { nx = -nx; ny = -ny; d = -d; }
+    const HPlane vp{nx, ny, 0, d};
+    // is it a facet (three non-collinear points on it)?  then start from its polygon; else from the edge it holds
+    std::vector<int> on;
+    for (int i = 0; i < (int)pts.size(); ++i)
+      if (nx * pts[i].x + ny * pts[i].y == d) on.push_back(i);
+    bool facet = false;
+    for (size_t i = 2; i < on.size() && !facet; ++i) facet = !h_collinear(pts[on[0]], pts[on[1]], pts[on[i]]);
+    if (facet) {
+      planes->insert(vp);
+      h_face_edges(pts, vp, &todo);
+    } else {
+      int lo = on[0], hi = on[0];                                              // the segment's end points
+      for (int i : on) {
+        if (std::tie(pts[i].x, pts[i].y, pts[i].z) < std::tie(pts[lo].x, pts[lo].y, pts[lo].z)) lo = i;
+        if (std::tie(pts[hi].x, pts[hi].y, pts[hi].z) < std::tie(pts[i].x, pts[i].y, pts[i].z)) hi = i;
+      }
+      if (lo == hi) return false;
+      todo.push_back({lo, hi});
+    }
+  }
+  std::set<std::pair<int, int>> seen;
+  size_t guard = 0;
+  while (!todo.empty()) {
+    const std::pair<int, int> e = todo.back();
+    todo.pop_back();
+    const std::pair<int, int> key = e.first < e.second ? e : std::make_pair(e.second, e.first);
+    if (!seen.insert(key).second) continue;
+    if (++guard > 200000) return false;
+    std::vector<HPlane> two;
+    h_pivot(pts, e.first, e.second, &two);
+    for (const HPlane& pl : two)
+      if (planes->insert(pl).second) h_face_edges(pts, pl, &todo);
+  }
+  return planes->size() >= 4;
+}
+
+// bounds of one component; hull_thr > 0: where voxels / P < hull_thr <= voxels / F the exact hull count goes to out[4]
+void component_bounds_one(const int* lab, int H, int W, int cl, const int* st, double hull_thr, long long* out) {
   const int z0 = st[1], y0 = st[2], x0 = st[3], bd = st[4] - st[1], bh = st[5] - st[2], bw = st[6] - st[3];
   const int V = bd * bh * bw;
-  std::vector<unsigned char> a(V), f;
+  std::vector<unsigned char> a(V), f, inP(V);
   std::vector<int> px, py, pz;
   for (int z = 0; z < bd; ++z)
     for (int y = 0; y < bh; ++y)
@@ -848,6 +1000,7 @@ void component_bounds_one(const int* lab, int H, int W, int cl, const int* st, l
       }
   const int n = (int)px.size();
   out[0] = n;
+  out[4] = 0;
   if (n == 0) { out[1] = out[2] = 0; out[3] = 1; return; }
   // flat: all points collinear or coplanar (icsg3d_amd/watershed.py::is_flat, exact integers)
   bool flat = true;
@@ -893,6 +1046,7 @@ void component_bounds_one(const int* lab, int H, int W, int cl, const int* st, l
           const int g = 2 * (dirs[k][0] * z + dirs[k][1] * y + dirs[k][2] * x);
           in = g <= 2 * hi[k] + 1 && g >= 2 * lo[k] - 1;
         }
+        inP[(z * bh + y) * bw + x] = in;
         P += in;
       }
   out[1] = P;
@@ -918,16 +1072,56 @@ void component_bounds_one(const int* lab, int H, int W, int cl, const int* st, l
     cnt = m;
   }
   out[2] = cnt;
+  if (!(hull_thr > 0) || (double)n / (double)P >= hull_thr || (double)n / (double)cnt < hull_thr) return;
+  // undecided by the bounds: the exact count.  Vertex candidates: voxels that end all three of their axis lines.
+  std::vector<HP> pts;
+  for (int i = 0; i < n; ++i) {
+    const int z = pz[i], y = py[i], x = px[i];
+    auto inner = [&](int dz, int dy, int dx) {      // a voxel of the set on BOTH sides along this axis line
+      bool before = false, after = false;
+      for (int t = 1; !before; ++t) {
+        const int zz = z - t * dz, yy = y - t * dy, xx = x - t * dx;
+        if (zz < 0 || yy < 0 || xx < 0) break;
+        before = a[(zz * bh + yy) * bw + xx] != 0;
+      }
+      for (int t = 1; !after; ++t) {
+        const int zz = z + t * dz, yy = y + t * dy, xx = x + t * dx;
+        if (zz >= bd || yy >= bh || xx >= bw) break;
+        after = a[(zz * bh + yy) * bw + xx] != 0;
+      }
+      return before && after;
+    };
+    if (inner(1, 0, 0) || inner(0, 1, 0) || inner(0, 0, 1)) continue;
+    const int X = 2 * x, Y = 2 * y, Z = 2 * z;
+    pts.push_back({X - 1, Y, Z}); pts.push_back({X + 1, Y, Z}); pts.push_back({X, Y - 1, Z});
+    pts.push_back({X, Y + 1, Z}); pts.push_back({X, Y, Z - 1}); pts.push_back({X, Y, Z + 1});
+  }
+  std::sort(pts.begin(), pts.end(), [](const HP& p, const HP& q) { return std::tie(p.x, p.y, p.z) < std::tie(q.x, q.y, q.z); });
+  pts.erase(std::unique(pts.begin(), pts.end(), [](const HP& p, const HP& q) { return p.x == q.x && p.y == q.y && p.z == q.z; }), pts.end());
+  std::set<HPlane> planes;
+  if (!h_planes(pts, &planes)) return;             // out[4] stays 0: the caller decides this one with Qhull
+  long long Hc = cnt;
+  for (int z = 0; z < bd; ++z)
+    for (int y = 0; y < bh; ++y)
+      for (int x = 0; x < bw; ++x) {
+        const int i = (z * bh + y) * bw + x;
+        if (!inP[i] || f[i]) continue;
+        bool in = true;
+        for (const HPlane& pl : planes)
+          if (pl.nx * (2 * x) + pl.ny * (2 * y) + pl.nz * (2 * z) > pl.d) { in = false; break; }
+        Hc += in;
+      }
+  out[4] = Hc;
 }
 }  // namespace
 
 int segment_component_bounds(const int* h_labels, const int* h_dims, int nbox, const int* h_nlabels, const int* h_stats,
-                             int max_labels, int min_voxels, long long* h_bounds) {
+                             int max_labels, int min_voxels, double hull_threshold, long long* h_bounds) {
   ICS_CHECK(h_labels && h_dims && h_nlabels && h_stats && h_bounds && nbox >= 1 && max_labels >= 1, "bad component_bounds arguments");
   std::vector<BoxDesc> desc;
   size_t total = 0;
   ICS_TRY(box_descs(h_dims, nullptr, nbox, &desc, &total));
-  std::memset(h_bounds, 0, (size_t)nbox * max_labels * 4 * sizeof(long long));
+  std::memset(h_bounds, 0, (size_t)nbox * max_labels * 5 * sizeof(long long));
   struct Job { int box, cl; };
   std::vector<Job> jobs;
   for (int b = 0; b < nbox; ++b) {
@@ -941,7 +1135,7 @@ int segment_component_bounds(const int* h_labels, const int* h_dims, int nbox, c
       const Job j = jobs[k];
       const BoxDesc& d = desc[j.box];
       component_bounds_one(h_labels + d.off, d.H, d.W, j.cl, h_stats + ((size_t)j.box * max_labels + j.cl - 1) * 7,
-                           h_bounds + ((size_t)j.box * max_labels + j.cl - 1) * 4);
+                           hull_threshold, h_bounds + ((size_t)j.box * max_labels + j.cl - 1) * 5);
     }
   };
   unsigned hw = std::thread::hardware_concurrency();

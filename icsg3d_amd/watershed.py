@@ -78,12 +78,33 @@ def segment_atoms(mask, species, min_voxels=3, max_atoms=512, num_species=95, wa
 # ----------------------------------------------------------------------------------------------------------------------
 # device primitives on small boxes
 # ----------------------------------------------------------------------------------------------------------------------
-def label_boxes(vols, connectivity=1, max_labels=1024, want_bounds=False, min_voxels=3):
+def component_bounds(labels, stats_rows, min_voxels=3, hull_threshold=0.0):
+    """ics_op_component_bounds for a list of label volumes (int32, labels 1..n_b) with their stats rows (n_b, 7) = {voxels,
+    z0, y0, x0, z1, y1, x1}: [int64 (n_b, 5) = {voxels, P, F, flat, H}] -- the exact-integer bounds P >= hull count >= F, the
+    flatness flag and, where hull_threshold > 0 and the bounds leave `voxels / hull >= hull_threshold` open, the exact hull
+    count H (else 0).  Host threads inside the library; no device work."""
+    if not labels:
+        return []
+    labs = [np.ascontiguousarray(v, dtype=np.int32) for v in labels]
+    n = np.ascontiguousarray([len(st) for st in stats_rows], dtype=np.int32)
+    max_labels = max(int(n.max()), 1)
+    stats = np.zeros((len(labs), max_labels, 7), np.int32)
+    for b, st in enumerate(stats_rows):
+        stats[b, :len(st)] = st
+    dims = np.ascontiguousarray([v.shape for v in labs], dtype=np.int32)
+    flat = np.concatenate([v.ravel() for v in labs])
+    bounds = np.zeros((len(labs), max_labels, 5), np.int64)
+    L.check(L.load().ics_op_component_bounds(L.i32ptr(flat), L.i32ptr(dims), len(labs), L.i32ptr(n), L.i32ptr(stats),
+                                             int(max_labels), int(min_voxels), float(hull_threshold), L.i64ptr(bounds)))
+    return [bounds[b, :n[b]].copy() for b in range(len(labs))]
+
+
+def label_boxes(vols, connectivity=1, max_labels=1024, want_bounds=False, min_voxels=3, hull_threshold=0.0):
     """skimage.measure.label(vol, connectivity=...) for each int volume in `vols` (extents <= 64): components of equal
     non-zero value, raster-order numbering.  Returns [(labels int32, n, stats (n,7) = {voxels, z0, y0, x0, z1, y1, x1})];
-    with want_bounds a fourth entry, int64 (n,4) = {voxels, P, F, flat} per component with more than min_voxels voxels (zeros
-    otherwise): the exact-integer bounds P >= count_nonzero(convex_hull_image(component)) >= F and the flatness flag the
-    convexity test is decided from (ics_op_component_bounds, host threads)."""
+    with want_bounds a fourth entry, int64 (n,5) = {voxels, P, F, flat, H} per component with more than min_voxels voxels
+    (zeros otherwise): the exact-integer bounds P >= count_nonzero(convex_hull_image(component)) >= F, the flatness flag, and
+    the exact count H where hull_threshold > 0 and the bounds leave the decision open (ics_op_component_bounds, host threads)."""
     vols = [np.ascontiguousarray(v, dtype=np.int32) for v in vols]
     if not vols:
         return []
@@ -100,9 +121,9 @@ def label_boxes(vols, connectivity=1, max_labels=1024, want_bounds=False, min_vo
         max_labels = int(n.max())
     bounds = None
     if want_bounds:
-        bounds = np.zeros((len(vols), max_labels, 4), np.int64)
+        bounds = np.zeros((len(vols), max_labels, 5), np.int64)
         L.check(L.load().ics_op_component_bounds(L.i32ptr(lab), L.i32ptr(dims), len(vols), L.i32ptr(n), L.i32ptr(stats),
-                                                 int(max_labels), int(min_voxels), L.i64ptr(bounds)))
+                                                 int(max_labels), int(min_voxels), float(hull_threshold), L.i64ptr(bounds)))
     out, off = [], 0
     for b, v in enumerate(vols):
         row = (lab[off:off + v.size].reshape(v.shape), int(n[b]), stats[b, :n[b]].copy())
@@ -302,7 +323,8 @@ def convexity_many(boxes, threshold, degenerate="raise", pool=False, bounds=None
     out, undecided = [None] * len(boxes), []
     for i, box in enumerate(boxes):
         if bounds is not None:
-            n, P_, F_, flat = (int(v) for v in bounds[i])
+            n, P_, F_, flat = (int(v) for v in bounds[i][:4])
+            H_ = int(bounds[i][4]) if len(bounds[i]) > 4 else 0
             if flat and degenerate != "solid":
                 out[i] = DegenerateComponent("component of %d voxels is flat: convex_hull_image fails in the reference stack" % n)
                 continue
@@ -312,6 +334,8 @@ def convexity_many(boxes, threshold, degenerate="raise", pool=False, bounds=None
                 out[i] = (True, n / P_)
             elif n / F_ < threshold:
                 out[i] = (False, n / F_)
+            elif H_ > 0:                         # the library's exact hull count (integer gift wrapping)
+                out[i] = (n / H_ >= threshold, n / H_)
             else:
                 undecided.append((i, n, None, None))
             continue
@@ -442,7 +466,7 @@ def segment_nuclei_batch(binaries, wmin=8, max_iters=5, min_convexity=0.8, tie="
     errors = [None] * len(roots)
     level = list(roots)
     while level:
-        labelled = label_boxes([n.vol for n in level], connectivity=1, want_bounds=True)
+        labelled = label_boxes([n.vol for n in level], connectivity=1, want_bounds=True, hull_threshold=min_convexity)
         todo = []
         # every kept component of the level: crop, then ONE batch of convexity decisions (integer bounds first, the hulls
         # they leave undecided on a thread pool); the reference's order is restored when the results are consumed
@@ -566,13 +590,12 @@ def refine_atoms(out, max_iters=5, num_species=95, tie="heap", min_convexity=0.8
     # pass 1: what the device's integers decide (flat / convex), and the boxes they leave for the host -- gathered over the
     # whole batch so that their bounds and hulls are computed together (convexity_many: thread pool)
     verdict = [[] for _ in range(B)]          # per sample, per component: True (convex) / "flat" / index into `jobs`
-    jobs = []
+    jobs, job_at = [], []
     for b in range(B):
         if out["failed"][b]:
             continue
         n = int(out["n_atoms"][b])
         st = out["stats"][b, :n]
-        lab0 = out["regions"][b]
         bnd = out["bounds"][b, :n] if out.get("bounds") is not None else None
         for a in range(n):
             if bnd is not None:
@@ -585,10 +608,29 @@ def refine_atoms(out, max_iters=5, num_species=95, tie="heap", min_convexity=0.8
                 if int(st[a, 1]) / int(bnd[a, 0]) >= min_convexity:
                     verdict[b].append(True)
                     continue
-            z0, y0, x0, z1, y1, x1 = (int(v) for v in st[a, 5:11])
             verdict[b].append(len(jobs))
-            jobs.append(lab0[z0:z1, y0:y1, x0:x1] == a + 1)
-    decisions = convexity_many(jobs, min_convexity, degenerate)
+            jobs.append(None)
+            job_at.append((b, a))
+    decisions = [None] * len(jobs)
+    if jobs:
+        # what the device's integers leave open: the library's host pass over the region volumes -- axis-line fill bound and,
+        # where still open, the exact hull count (ics_op_component_bounds); Qhull only if that pass declines a component
+        bs = sorted({b for b, _ in job_at})
+        rows = {}
+        for b in bs:
+            n = int(out["n_atoms"][b])
+            st = out["stats"][b, :n]
+            r7 = np.zeros((n, 7), np.int32)
+            r7[:, 0] = st[:, 1]; r7[:, 1:4] = st[:, 5:8]; r7[:, 4:7] = st[:, 8:11]
+            rows[b] = r7
+        cb = dict(zip(bs, component_bounds([np.asarray(out["regions"][b], np.int32) for b in bs], [rows[b] for b in bs],
+                                           min_voxels=0, hull_threshold=min_convexity)))
+        boxes, brow = [], []
+        for (b, a) in job_at:
+            z0, y0, x0, z1, y1, x1 = (int(v) for v in out["stats"][b, a, 5:11])
+            boxes.append(out["regions"][b][z0:z1, y0:y1, x0:x1] == a + 1)
+            brow.append(cb[b][a])
+        decisions = convexity_many(boxes, min_convexity, degenerate, bounds=brow)
     # pass 2: the reference's order per sample -- every component is tested, the first flat one fails the sample
     for b in range(B):
         if out["failed"][b]:

@@ -183,12 +183,14 @@ int ics_op_watershed_split(const int32_t* boxes, const int32_t* dims, const int3
  * pop order the result depends on); ICSG3D_WS_DEVICE=1 selects the kernel.  Both are held to oracle/watershed_ref.py.
  * ics_op_component_bounds: the exact-integer bounds the convexity test of watershed.py:80-83 is decided from wherever they
  * are conclusive, for every component (labels 1..nlabels[b], more than min_voxels voxels) of the label volumes ics_op_label_boxes
- * returned (same dims / stats layout): bounds [nbox][max_labels][4] = {voxels, P, F, flat} with P >= count_nonzero(
+ * returned (same dims / stats layout): bounds [nbox][max_labels][5] = {voxels, P, F, flat, H} with P >= count_nonzero(
  * convex_hull_image(component)) >= F -- P = bounding-box grid points inside the component's 26-direction polytope, F = the
- * component closed under axis-parallel line fills -- and flat = 1 for coplanar / collinear components (the reference stack's
- * Qhull call fails there).  Host threads; no device work. */
+ * component closed under axis-parallel line fills -- flat = 1 for coplanar / collinear components (the reference stack's
+ * Qhull call fails there), and H = that count itself, computed exactly (integer gift wrapping over the +-0.5 offset voxel
+ * set on doubled coordinates; a grid point on a facet counts as inside, as under the reference's 1e-10 tolerance) only where
+ * hull_threshold > 0 and voxels / P < hull_threshold <= voxels / F, else 0.  Host threads; no device work. */
 int ics_op_component_bounds(const int32_t* labels, const int32_t* dims, int nbox, const int32_t* nlabels, const int32_t* stats,
-                            int max_labels, int min_voxels, int64_t* bounds);
+                            int max_labels, int min_voxels, double hull_threshold, int64_t* bounds);
 /* The three box-level entry points below keep one stream and one grow-only device scratch buffer per host thread (they are
  * called tens of times per sample from the host recursion of segment_nuclei); this releases the calling thread's. */
 int ics_release_caches(void);

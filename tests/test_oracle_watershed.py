@@ -244,17 +244,17 @@ def test_breadth_first_host_logic_against_the_oracle_without_a_gpu(monkeypatch):
     from scipy.spatial import QhullError
     import icsg3d_amd.watershed as P
 
-    def label_boxes(vols, connectivity=1, max_labels=1024, want_bounds=False, min_voxels=3):
+    def label_boxes(vols, connectivity=1, max_labels=1024, want_bounds=False, min_voxels=3, hull_threshold=0.0):
         out = []
         for v in vols:
             lab, n = W.label_equal(v, connectivity=connectivity)
             stats = np.zeros((n, 7), np.int32)
-            bounds = np.zeros((n, 4), np.int64)
+            bounds = np.zeros((n, 5), np.int64)           # H (exact hull count) left 0: the hulls go through Qhull here
             for cl in range(1, n + 1):
                 m = lab == cl
                 stats[cl - 1] = (int(m.sum()),) + W.bbox_of(m)
                 if stats[cl - 1, 0] > min_voxels:      # the bounds the C++ op returns, from the numpy definitions
-                    bounds[cl - 1] = (int(m.sum()), P.dop_count(m), P.fill_count(m), int(P.is_flat(np.argwhere(m))))
+                    bounds[cl - 1, :4] = (int(m.sum()), P.dop_count(m), P.fill_count(m), int(P.is_flat(np.argwhere(m))))
             out.append((lab, n, stats, bounds) if want_bounds else (lab, n, stats))
         return out
 
@@ -285,41 +285,59 @@ def test_breadth_first_host_logic_against_the_oracle_without_a_gpu(monkeypatch):
 def test_component_bounds_op_equals_the_numpy_definitions():
     """ics_op_component_bounds (host threads inside the library, no device work): {voxels, P, F, flat} of every component of
     labelled boxes equal icsg3d_amd.watershed's numpy definitions dop_count / fill_count / is_flat -- which the test above
-    holds to Qhull's hull (P >= hull >= F, flat <=> Qhull refuses) -- on ragged random volumes, plates and lines."""
+    holds to Qhull's hull (P >= hull >= F, flat <=> Qhull refuses) -- and H, the EXACT hull count (integer gift wrapping on
+    doubled coordinates), equals np.count_nonzero(convex_hull_image(component)) as Qhull + the reference's 1e-10 tolerance
+    give it, on every component the bounds leave undecided: ragged random volumes, smooth blobs, unions of balls with holes,
+    plates and lines."""
     import icsg3d_amd.watershed as P
+    from scipy import ndimage
     rng = np.random.default_rng(8)
     vols = [(rng.uniform(size=(16, 12, 9)) < 0.3).astype(np.int32), (rng.uniform(size=(20, 20, 20)) < 0.5).astype(np.int32),
             _balls(24, [((7, 7, 5), 4), ((7, 7, 11), 4), ((17, 17, 17), 5)]), np.zeros((4, 4, 4), np.int32)]
     plate = np.zeros((8, 8, 8), np.int32); plate[3, 1:6, 1:7] = 1; plate[6, 2, 1:7] = 1
     vols.append(plate)
-    labs, ns, stats = [], [], []
+    for _ in range(3):                                    # thresholded smooth noise: what a random-weight U-Net's mask looks like
+        f = ndimage.gaussian_filter(rng.standard_normal((32, 32, 32)), 1.2)
+        vols.append((f >= np.quantile(f, 0.9)).astype(np.int32))
+    holes = _balls(24, [((8, 8, 8), 5), ((8, 8, 15), 5), ((15, 12, 11), 4)]) * (rng.uniform(size=(24, 24, 24)) > 0.06)
+    vols.append(holes.astype(np.int32))
+    labs, stats = [], []
     for v in vols:
         lab, n = W.label_equal(v, connectivity=1)
-        st = np.zeros((max(n, 1), 7), np.int32)
+        st = np.zeros((n, 7), np.int32)
         for cl in range(1, n + 1):
             m = lab == cl
             st[cl - 1] = (int(m.sum()),) + W.bbox_of(m)
-        labs.append(lab.astype(np.int32)); ns.append(n); stats.append(st)
-    max_labels = max(max(ns), 1)
-    S = np.zeros((len(vols), max_labels, 7), np.int32)
-    for b, st in enumerate(stats):
-        S[b, :ns[b]] = st[:ns[b]]
-    from icsg3d_amd import _lib as L
-    dims = np.ascontiguousarray([v.shape for v in vols], dtype=np.int32)
-    flat = np.concatenate([l.ravel() for l in labs]).astype(np.int32)
-    n_arr = np.ascontiguousarray(ns, dtype=np.int32)
-    B = np.full((len(vols), max_labels, 4), -1, np.int64)
-    L.check(L.load().ics_op_component_bounds(L.i32ptr(flat), L.i32ptr(dims), len(vols), L.i32ptr(n_arr), L.i32ptr(S), max_labels, 3,
-                                             L.i64ptr(B)))
-    checked = flats = 0
-    for b, lab in enumerate(labs):
-        for cl in range(1, ns[b] + 1):
-            m = lab == cl
-            if m.sum() <= 3:
-                assert list(B[b, cl - 1]) == [0, 0, 0, 0]
-                continue
-            exp = [int(m.sum()), P.dop_count(m), P.fill_count(m), int(P.is_flat(np.argwhere(m)))]
-            assert list(B[b, cl - 1]) == exp, (b, cl, list(B[b, cl - 1]), exp)
-            checked += 1
-            flats += exp[3]
-    assert checked > 30 and flats >= 2
+        labs.append(lab.astype(np.int32)); stats.append(st)
+    for thr in (0.0, 0.8, 0.5):
+        bounds = P.component_bounds(labs, stats, min_voxels=3, hull_threshold=thr)
+        checked = flats = exact = 0
+        for lab, st, B in zip(labs, stats, bounds):
+            for cl in range(1, len(st) + 1):
+                m = lab == cl
+                if m.sum() <= 3:
+                    assert list(B[cl - 1]) == [0, 0, 0, 0, 0]
+                    continue
+                n_, P_, F_ = int(m.sum()), P.dop_count(m), P.fill_count(m)
+                assert list(B[cl - 1][:4]) == [n_, P_, F_, int(P.is_flat(np.argwhere(m)))], (cl, list(B[cl - 1]))
+                checked += 1
+                flats += int(B[cl - 1][3])
+                undecided = thr > 0 and n_ / P_ < thr <= n_ / F_
+                if undecided:                              # the exact count is there, and it is Qhull's
+                    z0, y0, x0, z1, y1, x1 = st[cl - 1, 1:7]
+                    assert B[cl - 1][4] == P.convex_hull_volume(m[z0:z1, y0:y1, x0:x1], degenerate="solid"), (cl, list(B[cl - 1]))
+                    exact += 1
+                else:
+                    assert B[cl - 1][4] == 0
+        assert checked > 100 and flats >= 2
+        assert exact == 0 if thr == 0.0 else exact > 20, (thr, exact)
+    # the decisions taken from these rows are convexity_at_least's
+    B08 = P.component_bounds(labs, stats, min_voxels=3, hull_threshold=0.8)
+    for lab, st, B in zip(labs[5:7], stats[5:7], B08[5:7]):
+        boxes, rows = [], []
+        for cl in range(1, len(st) + 1):
+            if st[cl - 1, 0] > 3:
+                z0, y0, x0, z1, y1, x1 = st[cl - 1, 1:7]
+                boxes.append(lab[z0:z1, y0:y1, x0:x1] == cl); rows.append(B[cl - 1])
+        got = P.convexity_many(boxes, 0.8, degenerate="solid", bounds=rows)
+        assert [g[0] for g in got] == [P.convexity_at_least(b, 0.8, degenerate="solid")[0] for b in boxes]
