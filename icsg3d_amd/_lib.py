@@ -87,6 +87,7 @@ SIGNATURES = {
     "ics_net_get_grad": (C.c_int, [_H, C.c_char_p, _F, C.c_size_t]),
     "ics_net_get_activation": (C.c_int, [_H, C.c_char_p, _F, C.c_size_t]),
     "ics_net_get_bn_affine": (C.c_int, [_H, C.c_char_p, _F, _F, C.c_size_t]),
+    "ics_net_check_canaries": (C.c_int, [_H, C.POINTER(C.c_int)]),
     "ics_net_set_lr": (C.c_int, [_H, C.c_float]),
     "ics_net_reset_optimizer": (C.c_int, [_H]),
     "ics_net_num_params": (C.c_int, [_H, C.POINTER(C.c_size_t)]),

@@ -313,9 +313,15 @@ struct Net {
   char* arena_cur = nullptr;
   size_t arena_left = 0, arena_next = (size_t)1 << 27;
   bool arena_on = true;
+  // ICSG3D_DEBUG_CANARY=1 (diagnosis aid, round 6): every buffer is followed by 8 KB of 0x5A that nothing may touch;
+  // ics_net_check_canaries reports the buffers whose guard was written to (a kernel running past the end of its output)
+  struct Canary { char* p; size_t len, payload; int index; };
+  std::vector<Canary> canaries;
+  bool canary_on = getenv("ICSG3D_DEBUG_CANARY") != nullptr;
   template <typename T>
   int alloc(T** out, size_t n) {
-    const size_t bytes = n * sizeof(T) + 256;
+    const size_t guard = canary_on ? 8192 : 0;
+    const size_t bytes = n * sizeof(T) + 256 + guard;
     void* p = nullptr;
     if (!arena_on || bytes >= kArenaBig) {
       ICS_HIP(hipMalloc(&p, bytes));
@@ -338,6 +344,11 @@ struct Net {
       arena_left -= pad + bytes;
     }
     ICS_HIP(hipMemsetAsync(p, 0, bytes, st));
+    if (guard) {
+      char* g = static_cast<char*>(p) + n * sizeof(T);
+      ICS_HIP(hipMemsetAsync(g, 0x5A, guard + 256, st));
+      canaries.push_back(Canary{g, guard + 256, n * sizeof(T), (int)canaries.size()});
+    }
     *out = reinterpret_cast<T*>(p);
     return 0;
   }
@@ -2148,17 +2159,53 @@ int ics_net_get_grad(ics_net* net, const char* name, float* host, size_t count) 
 int ics_net_get_activation(ics_net* net, const char* layer, float* host, size_t count) {
   ICS_CHECK(net && layer && host, "null argument");
   Net& n = net->n;
+  // "name" = the stored pre-BatchNorm activation s; parity / diagnosis aids: "name:dy" (gradient w.r.t. s of the last backward
+  // pass), "name:dA" (gradient w.r.t. the layer's input, [rows][padded Cin]), "name:pooled" (the max-pooled BatchNorm output)
+  std::string lname = layer, what;
+  const size_t colon = lname.find(':');
+  if (colon != std::string::npos) { what = lname.substr(colon + 1); lname = lname.substr(0, colon); }
   for (auto& Lp : n.layers) {
-    if (Lp->name != layer) continue;
-    const size_t cnt = n.rows(*Lp, n.last_batch) * Lp->Cout;
+    if (Lp->name != lname) continue;
+    const float* src = Lp->s;
+    size_t cnt = n.rows(*Lp, n.last_batch) * Lp->Cout;
+    if (what == "dy") src = Lp->dy;
+    else if (what == "dA") { src = Lp->dA; cnt = n.rows(*Lp, n.last_batch) * Lp->CinG; }
+    else if (what == "pooled") { src = Lp->pooled; cnt = n.rows(*Lp, n.last_batch) / 8 * Lp->Cout; }
+    else ICS_CHECK(what.empty(), std::string("unknown activation kind: ") + what);
+    ICS_CHECK(src != nullptr, std::string("layer keeps no such buffer: ") + layer);
     ICS_CHECK(cnt == count, std::string("size mismatch for activation ") + layer);
-    ICS_HIP(hipMemcpyAsync(host, Lp->s, cnt * sizeof(float), hipMemcpyDeviceToHost, n.st));
+    ICS_HIP(hipMemcpyAsync(host, src, cnt * sizeof(float), hipMemcpyDeviceToHost, n.st));
     ICS_HIP(hipStreamSynchronize(n.st));
     return 0;
   }
   set_error(std::string("unknown layer: ") + layer);
   return -1;
 }
+// diagnosis aid: with ICSG3D_DEBUG_CANARY=1 at creation, the number of buffers whose guard bytes were overwritten; the first
+// few are described in ics_last_error() (allocation index, payload bytes, first dirty offset)
+int ics_net_check_canaries(ics_net* net, int* dirty) {
+  ICS_CHECK(net && dirty, "null argument");
+  Net& n = net->n;
+  ICS_HIP(hipStreamSynchronize(n.st));
+  std::vector<unsigned char> host;
+  std::string msg;
+  int bad = 0;
+  for (const auto& c : n.canaries) {
+    host.resize(c.len);
+    ICS_HIP(hipMemcpy(host.data(), c.p, c.len, hipMemcpyDeviceToHost));
+    size_t first = c.len;
+    for (size_t i = 0; i < c.len; ++i)
+      if (host[i] != 0x5A) { first = i; break; }
+    if (first < c.len) {
+      ++bad;
+      if (bad <= 8) msg += "alloc #" + std::to_string(c.index) + " payload " + std::to_string(c.payload) + " B: guard dirty from +" + std::to_string(first) + "; ";
+    }
+  }
+  *dirty = bad;
+  if (bad) set_error(msg);
+  return 0;
+}
+
 int ics_net_get_bn_affine(ics_net* net, const char* layer, float* scale, float* shift, size_t count) {
   ICS_CHECK(net && layer && scale && shift, "null argument");
   Net& n = net->n;

@@ -115,6 +115,7 @@ static int run(int d, int C, int B, int with_comm) {
   OK(ics_net_get_optimizer_state(unet, m1, v1, np, &step));
   OK(ics_net_set_optimizer_state(unet, m1, v1, np, step));
   OK(ics_net_reset_optimizer(unet));
+  { int dirty = -1; OK(ics_net_check_canaries(unet, &dirty)); OK(ics_net_check_canaries(vae, &dirty)); }
   {   /* the graph probe needs the profiler off and a resident batch */
     double em, gm; int nodes, rk, nr, nb;
     OK(ics_net_profile_enable(unet, 0)); OK(ics_net_profile_enable(vae, 0));

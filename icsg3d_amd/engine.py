@@ -87,6 +87,12 @@ class _Net:
                 raise ValueError("shape mismatch for %s: %s vs %s" % (k, np.shape(v), known[k]))
             self.set_tensor(k, v)
 
+    def check_canaries(self):
+        """(dirty count, description): diagnosis aid, needs ICSG3D_DEBUG_CANARY=1 when the engine was created."""
+        n = C.c_int(0)
+        L.check(self._lib.ics_net_check_canaries(self._h, C.byref(n)))
+        return n.value, (self._lib.ics_last_error().decode() if n.value else "")
+
     def set_lr(self, lr):
         L.check(self._lib.ics_net_set_lr(self._h, float(lr)))
 

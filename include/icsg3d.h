@@ -227,6 +227,10 @@ int ics_net_get_activation(ics_net* net, const char* layer, float* host, size_t 
 /* the fp32 BatchNorm affine (scale = gamma*rstd, shift = beta - mean*scale) the most recent forward
  * applied to that layer's output; lets a test reproduce the engine's max-pool routing bit-exactly. */
 int ics_net_get_bn_affine(ics_net* net, const char* layer, float* scale, float* shift, size_t count);
+/* Diagnosis aid (round 6): with ICSG3D_DEBUG_CANARY=1 in the environment when the handle is created, every device buffer of
+ * the handle is followed by 8 KB of guard bytes; this reports how many guards were written to (kernels running past the end of
+ * their buffer) and describes the first few in ics_last_error(). */
+int ics_net_check_canaries(ics_net* net, int* dirty);
 int ics_net_set_lr(ics_net* net, float lr);
 /* optimizer step counter (Adam t) and reset of its moments */
 int ics_net_reset_optimizer(ics_net* net);

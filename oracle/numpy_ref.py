@@ -486,18 +486,23 @@ def apply_kink(blocks, cache, P, kink, tol=1e-4, affine=None):
         if blk.pre_act is not None:
             pairs.append((s_ref, s_impl))
             c["kink_s"] = s_impl
-        if blk.has_bn and blk.post_act is not None:
-            if c["training"]:
-                inv = P[n + "/gamma"] / np.sqrt(c["var"] + BN_EPS)
-                bn_impl = s_impl * inv + (P[n + "/beta"] - c["mean"] * inv)
-            else:
-                raise ValueError("kink pinning is for training-mode steps")
-            pairs.append((c["bn"], bn_impl))
-            c["kink_bn"] = bn_impl
+        o32 = None
         if affine is not None and n in affine:
             sc, sh = affine[n]
             o32 = (s_impl.astype(np.float64) * sc.astype(np.float64) + sh.astype(np.float64)).astype(np.float32)
             c["impl_o"] = act_fwd(o32, blk.post_act).astype(s_ref.dtype)
+        if blk.has_bn and blk.post_act is not None:
+            if not c["training"]:
+                raise ValueError("kink pinning is for training-mode steps")
+            if o32 is not None:
+                # the implementation's own fp32 BatchNorm output decides (a value rebuilt with the oracle's statistics can
+                # land on the other side of zero when it is within ~1e-7 of it)
+                bn_impl = o32.astype(s_ref.dtype)
+            else:
+                inv = P[n + "/gamma"] / np.sqrt(c["var"] + BN_EPS)
+                bn_impl = s_impl * inv + (P[n + "/beta"] - c["mean"] * inv)
+            pairs.append((c["bn"], bn_impl))
+            c["kink_bn"] = bn_impl
         cnt = 0
         for ref, impl in pairs:
             diff = (impl > 0) != (ref > 0)

@@ -189,7 +189,10 @@ def test_vae_step_at_stated_batch_matches_pinned_fp64_oracle(d, B):
     ps = {n: _ushape(n, B, d) for n in UNET_LAYERS[:8]}
     kink = {n: ve.get_activation(n, s) for n, s in vs.items()}
     kink_pm = {n: ue.get_activation(n, s) for n, s in ps.items()}
-    aff = {n: ve.get_bn_affine(n, vs[n][-1]) for n in ("e0", "e1", "e2", "e3")}
+    # the engine's fp32 BatchNorm affine of EVERY Conv -> BN -> activation block: the oracle rebuilds the engine's own BN output
+    # from it, bit for bit, for the LeakyReLU / ReLU side (and the encoder's max-pool routing); with 2e7 activations per
+    # layer a value within 1e-7 of zero exists, and its sign under the oracle's own statistics can differ (round 6)
+    aff = {n: ve.get_bn_affine(n, vs[n][-1]) for n in ("e0", "e1", "e2", "e3", "d0", "d1", "d2", "d3", "dout")}
     aff_pm = {n: ue.get_bn_affine(n, ps[n][-1]) for n in ("c2", "c4", "c6")}
     bn_layers = [n for n in vs if n not in ("e4", "enc_dense")]
     stats_eng = {n: _batch_stats_from_moving(ve, n, vs[n][-1], int(np.prod(vs[n][:-1]))) for n in bn_layers}

@@ -65,7 +65,7 @@ def test_vae_step_full_width_four_channels():
     vs["dout"] = (B, d, d, d, C)
     kink = {n: ve.get_activation(n, s) for n, s in vs.items()}
     kink_pm = {n: ue.get_activation(n, s) for n, s in ps.items()}
-    aff = {n: ve.get_bn_affine(n, vs[n][-1]) for n in ("e0", "e1", "e2", "e3")}
+    aff = {n: ve.get_bn_affine(n, vs[n][-1]) for n in ("e0", "e1", "e2", "e3", "d0", "d1", "d2", "d3", "dout")}
     aff_pm = {n: ue.get_bn_affine(n, ps[n][-1]) for n in ("c2", "c4", "c6")}
     m_ref = vo.train_on_batch(X, cond, eps, kink=kink, kink_pm=kink_pm, affine=aff, affine_pm=aff_pm)
     np.testing.assert_allclose(m, m_ref, rtol=3e-5)

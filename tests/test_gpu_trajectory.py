@@ -172,7 +172,7 @@ def test_vae_five_step_trajectory(relerr):
         m = ve.train_step(X, cond, eps)
         kink = {n: ve.get_activation(n, s) for n, s in sh.items()}
         kink_pm = {n: ue.get_activation(n, s) for n, s in shp.items()}
-        aff = {n: ve.get_bn_affine(n, sh[n][-1]) for n in ("e0", "e1", "e2", "e3")}
+        aff = {n: ve.get_bn_affine(n, sh[n][-1]) for n in ("e0", "e1", "e2", "e3", "d0", "d1", "d2", "d3", "dout")}
         aff_pm = {n: ue.get_bn_affine(n, shp[n][-1]) for n in ("c2", "c4", "c6")}
         m_fol = fol.train_on_batch(X, cond, eps, kink=kink, kink_pm=kink_pm, affine=aff, affine_pm=aff_pm)
         np.testing.assert_allclose(m, m_fol, rtol=2e-5, err_msg="following oracle, step %d" % step)

@@ -73,7 +73,7 @@ def test_vae_train_step_matches_oracle(B, C, relerr):
     m = ve.train_step(X, cond, eps)
     kink = {n: ve.get_activation(n, s) for n, s in _vae_layer_shapes(B, d, C).items()}
     kink_pm = {n: ue.get_activation(n, s) for n, s in _pm_layer_shapes(B, d).items()}
-    aff = {n: ve.get_bn_affine(n, _vae_layer_shapes(B, d, C)[n][-1]) for n in ("e0", "e1", "e2", "e3")}
+    aff = {n: ve.get_bn_affine(n, _vae_layer_shapes(B, d, C)[n][-1]) for n in ("e0", "e1", "e2", "e3", "d0", "d1", "d2", "d3", "dout")}
     aff_pm = {n: ue.get_bn_affine(n, _pm_layer_shapes(B, d)[n][-1]) for n in ("c2", "c4", "c6")}
     m_r = vo.train_on_batch(X, cond, eps, kink=kink, kink_pm=kink_pm, affine=aff, affine_pm=aff_pm)
     print("kink flips:", {k: v for k, v in vo.kink_flips.items() if v})
