@@ -51,11 +51,14 @@ def kernel_grad_n(g):        # (Cout,Cin,kd,kh,kw) -> (kd,kh,kw,Cin,Cout)
 GEMM_CONV_MIN_WORK = 2e9      # multiply-adds from which conv3d() takes the GEMM form (fp64 only); 0 forces it, inf disables
 
 
-def _tap_cols(xp, dz, dy, B, D, H, W, C):
-    """(B*D*H*W, 3C): for every output voxel the three x-neighbours of tap row (dz, dy) of the padded NDHWC tensor."""
+def _tap_cols(xp, dz, dy, B, D, H, W, C, buf):
+    """(B*D*H*W, 3C): for every output voxel the three x-neighbours of tap row (dz, dy) of the padded NDHWC tensor, gathered
+    into `buf` (one buffer per convolution call: nine fresh 100 MB - 5 GB temporaries per layer were a quarter of the oracle's
+    time on the GPU box -- page faults and unmaps, not arithmetic)."""
     v = xp[:, dz:dz + D, dy:dy + H]                       # (B, D, H, W + 2, C), C contiguous
     st = v.stride()
-    return v.as_strided((B, D, H, W, 3 * C), (st[0], st[1], st[2], st[3], 1)).reshape(B * D * H * W, 3 * C)
+    buf.view(B, D, H, W, 3 * C).copy_(v.as_strided((B, D, H, W, 3 * C), (st[0], st[1], st[2], st[3], 1)))
+    return buf
 
 
 def _conv_gemm_fwd(x, w):
@@ -65,9 +68,10 @@ def _conv_gemm_fwd(x, w):
     xp = F.pad(x.permute(0, 2, 3, 4, 1), (0, 0, 1, 1, 1, 1, 1, 1)).contiguous()
     wk = w.permute(2, 3, 4, 1, 0).contiguous()            # (3, 3, 3, Cin, Cout)
     y = x.new_zeros(B * D * H * W, Co)
+    buf = x.new_empty(B * D * H * W, 3 * C)
     for dz in range(3):
         for dy in range(3):
-            y.addmm_(_tap_cols(xp, dz, dy, B, D, H, W, C), wk[dz, dy].reshape(3 * C, Co))
+            y.addmm_(_tap_cols(xp, dz, dy, B, D, H, W, C, buf), wk[dz, dy].reshape(3 * C, Co))
     return y.view(B, D, H, W, Co).permute(0, 4, 1, 2, 3)
 
 
@@ -77,9 +81,10 @@ def _conv_gemm_wgrad(x, dy):
     xp = F.pad(x.permute(0, 2, 3, 4, 1), (0, 0, 1, 1, 1, 1, 1, 1)).contiguous()
     dyf = dy.permute(0, 2, 3, 4, 1).reshape(B * D * H * W, Co)
     dw = x.new_empty(3, 3, 3 * C, Co)
+    buf = x.new_empty(B * D * H * W, 3 * C)
     for dz in range(3):
         for dy_ in range(3):
-            torch.mm(_tap_cols(xp, dz, dy_, B, D, H, W, C).t(), dyf, out=dw[dz, dy_])
+            torch.mm(_tap_cols(xp, dz, dy_, B, D, H, W, C, buf).t(), dyf, out=dw[dz, dy_])
     return dw.view(3, 3, 3, C, Co).permute(4, 3, 0, 1, 2).contiguous()
 
 
