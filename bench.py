@@ -43,7 +43,7 @@ UNET_FLOP_PER_GRID = 377.66e9          # fwd 125.886 GFLOP x 3
 UNET_BYTES_PER_GRID = 499.6e6          # fused-minimum activation traffic
 UNET_PARAM_BYTES_PER_STEP = 1.25e9     # 124.6 MB x (1 fwd + 2 bwd + 7 Adam)
 VAE_FLOP_PER_GRID = 33.73e9            # VAE 3 x 2.126 + perceptual 3 x 9.116 GFLOP
-PMC_TRAFFIC_FILES = ("r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json")
+PMC_TRAFFIC_FILES = ("r6_pmc_traffic.json", "r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json")
 
 
 def cpu_baseline(batch=32, d=32):
