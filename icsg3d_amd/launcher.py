@@ -157,6 +157,10 @@ def ensure_ranks(n: int, script: str, argv, count_gpus=visible_gpus, run=subproc
     if under_launcher(n):
         return
     have = count_gpus()
+    if have < n and count_gpus is visible_gpus:
+        # the sysfs count is the cheap, HIP-free answer; before REFUSING a run on its word, ask the runtime itself -- in a
+        # short-lived child process, so that this parent still never initialises HIP
+        have = max(have, _count_in_child())
     if have < n:
         raise SystemExit("--gpus %d requested but %d GPU(s) visible: refusing to run a smaller job under that name"
                          % (n, have))

@@ -125,3 +125,10 @@ def test_batches_below_max_batch_match_a_right_sized_engine():
         np.testing.assert_array_equal(big_v.train_step(X, cond, eps), v.train_step(X, cond, eps))
         wa, wb = big_v.get_weights(), v.get_weights()
         assert all(np.array_equal(wa[k], wb[k]) for k in wa)
+
+
+def test_launcher_counts_this_box_like_the_runtime():
+    """icsg3d_amd.launcher.visible_gpus (KFD topology + render nodes + *_VISIBLE_DEVICES, no HIP in the caller) agrees with
+    hipGetDeviceCount on the box the suite runs on."""
+    from icsg3d_amd import _lib, launcher
+    assert launcher.visible_gpus() == _lib.device_count() >= 1
