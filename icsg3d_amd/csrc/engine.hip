@@ -2035,7 +2035,7 @@ struct ics_net {
 extern "C" {
 
 const char* ics_last_error(void) { return g_err.c_str(); }
-const char* ics_version(void) { return "icsg3d_amd 0.4 (gfx950, fp32 MFMA implicit-GEMM + Winograd)"; }
+const char* ics_version(void) { return "icsg3d_amd 0.6 (gfx950, fp32 MFMA implicit-GEMM + Winograd)"; }
 long long ics_kernel_launches(void) { return g_kernel_launches.load(std::memory_order_relaxed); }
 
 int ics_device_count(int* count) {
