@@ -201,6 +201,68 @@ int main(void) {
     if (ics_op_label_boxes(vols, dims + 3, 1, 2, 8, labels, nlab, bstats) == 0) { fprintf(stderr, "connectivity check missing\n"); return 1; }
     OK(ics_release_caches());     /* the per-thread stream and scratch of the box-level entry points (LeakSanitizer sees the rest) */
   }
+  {  /* round 6: the HOST forms of the box operations are real code under this build (threads, heap flood, integer gift
+        wrapping): a ragged pseudo-random volume, labelled here by a plain flood fill, through ics_op_component_bounds (with
+        and without the exact hull count) and ics_op_watershed_split (many boxes: the thread pool; both tie rules) */
+    enum { D = 20, H = 18, W = 16, V = D * H * W, ML = 512 };
+    int32_t* vol = (int32_t*)calloc(V, 4);
+    int32_t* lab = (int32_t*)calloc(V, 4);
+    int32_t* stack = (int32_t*)malloc(V * 4);
+    int32_t* st7 = (int32_t*)calloc(ML * 7, 4);
+    unsigned lcg = 12345u;
+    for (int i = 0; i < V; ++i) { lcg = lcg * 1664525u + 1013904223u; vol[i] = ((lcg >> 16) % 100) < 38; }
+    for (int z = 6; z < 14; ++z) for (int y = 5; y < 13; ++y) for (int x = 4; x < 12; ++x) vol[(z * H + y) * W + x] = 1;   /* a solid core */
+    int n = 0;
+    for (int s0 = 0; s0 < V && n < ML; ++s0) {
+      if (!vol[s0] || lab[s0]) continue;
+      ++n;
+      int top = 0; stack[top++] = s0; lab[s0] = n;
+      int32_t* r = st7 + (n - 1) * 7;
+      r[0] = 0; r[1] = D; r[2] = H; r[3] = W; r[4] = r[5] = r[6] = 0;
+      while (top) {
+        const int i = stack[--top], x = i % W, y = (i / W) % H, z = i / (W * H);
+        r[0] += 1;
+        if (z < r[1]) r[1] = z; if (y < r[2]) r[2] = y; if (x < r[3]) r[3] = x;
+        if (z + 1 > r[4]) r[4] = z + 1; if (y + 1 > r[5]) r[5] = y + 1; if (x + 1 > r[6]) r[6] = x + 1;
+        const int nb[6] = {z > 0 ? i - H * W : -1, z < D - 1 ? i + H * W : -1, y > 0 ? i - W : -1, y < H - 1 ? i + W : -1,
+                           x > 0 ? i - 1 : -1, x < W - 1 ? i + 1 : -1};
+        for (int k = 0; k < 6; ++k)
+          if (nb[k] >= 0 && vol[nb[k]] && !lab[nb[k]]) { lab[nb[k]] = n; stack[top++] = nb[k]; }
+      }
+    }
+    int32_t dims3[3] = {D, H, W}, nl[1] = {n};
+    int64_t* bnd = (int64_t*)calloc((size_t)ML * 5, 8);
+    OK(ics_op_component_bounds(lab, dims3, 1, nl, st7, ML, 3, 0.0, bnd));
+    OK(ics_op_component_bounds(lab, dims3, 1, nl, st7, ML, 0, 0.3, bnd));
+    OK(ics_op_component_bounds(lab, dims3, 1, nl, st7, ML, 3, 0.8, bnd));
+    int exact = 0;
+    for (int c = 0; c < n; ++c) {
+      if (st7[c * 7] > 3 && !(bnd[c * 5 + 1] >= bnd[c * 5 + 2] && bnd[c * 5 + 2] >= bnd[c * 5])) { fprintf(stderr, "bounds out of order\n"); return 1; }
+      if (bnd[c * 5 + 4]) { ++exact; if (bnd[c * 5 + 4] > bnd[c * 5 + 1] || bnd[c * 5 + 4] < bnd[c * 5 + 2]) { fprintf(stderr, "hull count outside its bounds\n"); return 1; } }
+    }
+    if (exact == 0) { fprintf(stderr, "the exact hull path was not exercised\n"); return 1; }
+    /* every component as its own box {0, 1}, plus the whole volume: dozens of boxes through the thread pool */
+    size_t tot = V; int nb = 1;
+    for (int c = 0; c < n; ++c) tot += (size_t)(st7[c * 7 + 4] - st7[c * 7 + 1]) * (st7[c * 7 + 5] - st7[c * 7 + 2]) * (st7[c * 7 + 6] - st7[c * 7 + 3]);
+    int32_t* boxes = (int32_t*)malloc(tot * 4);
+    int32_t* out = (int32_t*)malloc(tot * 4);
+    int32_t* bd = (int32_t*)malloc((size_t)(n + 1) * 3 * 4);
+    int32_t* bc = (int32_t*)malloc((size_t)(n + 1) * 4);
+    memcpy(boxes, vol, V * 4); bd[0] = D; bd[1] = H; bd[2] = W; bc[0] = 1;
+    size_t off = V;
+    for (int c = 0; c < n; ++c) {
+      const int32_t* r = st7 + c * 7;
+      const int bz = r[4] - r[1], by = r[5] - r[2], bx = r[6] - r[3];
+      for (int z = 0; z < bz; ++z) for (int y = 0; y < by; ++y) for (int x = 0; x < bx; ++x)
+        boxes[off + (z * by + y) * bx + x] = lab[((r[1] + z) * H + r[2] + y) * W + r[3] + x] == c + 1;
+      bd[nb * 3] = bz; bd[nb * 3 + 1] = by; bd[nb * 3 + 2] = bx; bc[nb] = 1; ++nb;
+      off += (size_t)bz * by * bx;
+    }
+    OK(ics_op_watershed_split(boxes, bd, bc, nb, 0, out));
+    OK(ics_op_watershed_split(boxes, bd, bc, nb, 1, out));
+    printf("asan driver: %d components, %d exact hull counts, %d boxes split on host threads\n", n, exact, nb);
+    free(vol); free(lab); free(stack); free(st7); free(bnd); free(boxes); free(out); free(bd); free(bc);
+  }
   printf("asan driver: all entry points walked, no sanitizer report\n");
   return 0;
 }
