@@ -18,6 +18,8 @@
 #include <algorithm>
 #include <atomic>
 #include <climits>
+#include <condition_variable>
+#include <functional>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -25,6 +27,7 @@
 #include <thread>
 #include <tuple>
 #include <utility>
+#include <unistd.h>
 #include <vector>
 
 namespace ics {
@@ -686,6 +689,68 @@ int segment_region_stats(hipStream_t st, const int* h_R, const unsigned char* h_
   return 0;
 }
 
+// ---- a persistent pool of host threads for the box-level host operations below (round 6).  They are called several times per
+// recursion level with a few milliseconds of work each; spawning up to 64 std::threads per call cost 1 - 2 ms of that.  The
+// pool is created on first use, never destroyed (its threads are detached and die with the process: no static-destruction
+// order to get wrong), re-created after a fork (the child has none of the parent's threads), and used by one call at a time.
+namespace {
+class HostPool {
+ public:
+  static HostPool& get() {
+    static std::mutex mu;
+    static HostPool* pool = nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (pool == nullptr || pool->pid_ != getpid()) pool = new HostPool();     // (a forked child leaks the parent's object)
+    return *pool;
+  }
+  int max_threads() const { return nmax_; }
+  // fn() on `n` threads (the caller is one of them); returns when all have finished.  fn pulls its work from an atomic counter.
+  void run(int n, const std::function<void()>& fn) {
+    n = std::max(1, std::min(n, nmax_));
+    if (n == 1) { fn(); return; }
+    std::lock_guard<std::mutex> one_call(run_mu_);
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      job_ = &fn; want_ = n - 1; started_ = 0; finished_ = 0; ++gen_;
+    }
+    cv_work_.notify_all();
+    fn();
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_done_.wait(lk, [&] { return finished_ == want_; });
+    job_ = nullptr;
+  }
+
+ private:
+  HostPool() : pid_(getpid()) {
+    unsigned hw = std::thread::hardware_concurrency();
+    if (const char* e = getenv("ICSG3D_HOST_THREADS")) hw = 2u * (unsigned)std::max(1, atoi(e));
+    nmax_ = (int)std::min<unsigned>(std::max(1u, hw / 2), 64u);
+    for (int t = 1; t < nmax_; ++t) std::thread([this] { worker(); }).detach();
+  }
+  void worker() {
+    unsigned long long seen = 0;
+    std::unique_lock<std::mutex> lk(mu_);
+    for (;;) {
+      cv_work_.wait(lk, [&] { return gen_ != seen && job_ != nullptr && started_ < want_; });
+      seen = gen_;
+      ++started_;
+      const std::function<void()>* job = job_;
+      lk.unlock();
+      (*job)();
+      lk.lock();
+      if (++finished_ == want_) cv_done_.notify_all();
+    }
+  }
+  const pid_t pid_;
+  int nmax_ = 1;
+  std::mutex mu_, run_mu_;
+  std::condition_variable cv_work_, cv_done_;
+  const std::function<void()>* job_ = nullptr;
+  int want_ = 0, started_ = 0, finished_ = 0;
+  unsigned long long gen_ = 0;
+};
+}  // namespace
+
 // ---- the same split on the HOST (round 6).  The priority flood is a chain of dependent heap operations: one GPU lane walks
 // it at ~3 us per voxel (dependent LDS / L2 round trips at 2 GHz), a CPU core at ~0.1 us, and the pop order of equal keys is
 // part of the result, so the flood cannot be spread over lanes without changing it (phases A / B of the
@@ -815,15 +880,9 @@ int segment_watershed_split_host(const int* h_boxes, const int* h_dims, const in
       host_split_box(h_boxes + d.off, d.D, d.H, d.W, tie, h_wss + d.off);
     }
   };
-  unsigned hw = std::thread::hardware_concurrency();
-  if (const char* e = getenv("ICSG3D_HOST_THREADS")) hw = (unsigned)std::max(1, atoi(e));
-  const int nthreads = (int)std::min<size_t>({(size_t)nbox, (size_t)std::max(1u, hw / 2), (size_t)64});
-  if (nthreads <= 1 || total < 4096) { work(); return 0; }
-  std::vector<std::thread> pool;
-  pool.reserve(nthreads - 1);
-  for (int t = 1; t < nthreads; ++t) pool.emplace_back(work);
-  work();
-  for (auto& th : pool) th.join();
+  // threads by the work at hand: one per ~16 k voxels of boxes, at most one per box
+  const int nthreads = (int)std::min<size_t>((size_t)nbox, total / 16384 + 1);
+  HostPool::get().run(nthreads, work);
   return 0;
 }
 
@@ -1138,14 +1197,7 @@ int segment_component_bounds(const int* h_labels, const int* h_dims, int nbox, c
                            hull_threshold, h_bounds + ((size_t)j.box * max_labels + j.cl - 1) * 5);
     }
   };
-  unsigned hw = std::thread::hardware_concurrency();
-  if (const char* e = getenv("ICSG3D_HOST_THREADS")) hw = (unsigned)std::max(1, atoi(e));
-  const int nthreads = (int)std::min<size_t>({jobs.size() / 8 + 1, (size_t)std::max(1u, hw / 2), (size_t)64});
-  if (nthreads <= 1) { work(); return 0; }
-  std::vector<std::thread> pool;
-  for (int t = 1; t < nthreads; ++t) pool.emplace_back(work);
-  work();
-  for (auto& th : pool) th.join();
+  HostPool::get().run((int)(jobs.size() / 8 + 1), work);
   return 0;
 }
 

@@ -132,3 +132,44 @@ def test_launcher_counts_this_box_like_the_runtime():
     hipGetDeviceCount on the box the suite runs on."""
     from icsg3d_amd import _lib, launcher
     assert launcher.visible_gpus() == _lib.device_count() >= 1
+
+
+@pytest.mark.parametrize("B,d", [(3, 16), (2, 32)])
+def test_no_kernel_writes_past_its_buffers(B, d, monkeypatch):
+    """ICSG3D_DEBUG_CANARY=1: 8 KB of guard bytes behind every device buffer of a handle; after train / test / predict steps
+    of both engines and the fused inference tail (odd batch at d = 16: every tile remainder path) none of them was touched.
+    (Round 4 found such a write by accident; this looks for them.)"""
+    from icsg3d_amd.engine import UnetEngine, VaeEngine
+    from icsg3d_amd.synthetic import glorot_params, synthetic_batch, unet_param_shapes, vae_param_shapes
+    monkeypatch.setenv("ICSG3D_DEBUG_CANARY", "1")
+    X, lab, cond = synthetic_batch(B, d, 1, seed=0, noise=1e-3)
+    eps = np.random.default_rng(2).standard_normal((B, 256)).astype(np.float32)
+    ue = UnetEngine(in_channels=1, d=d, max_batch=B, lr=1e-3); ue.set_weights(glorot_params(unet_param_shapes(1, 95), 1))
+    ve = VaeEngine(ue, in_channels=1, d=d, max_batch=B, lr=5e-4); ve.set_weights(glorot_params(vae_param_shapes(1, d=d), 3))
+    assert ue.check_canaries()[0] == 0 and ve.check_canaries()[0] == 0
+    for b in (B, max(B - 1, 1)):
+        ue.train_step(X[:b], lab[:b]); ue.test_step(X[:b], lab[:b]); ue.predict(X[:b])
+        ve.train_step(X[:b], cond[:b], eps[:b]); ve.test_step(X[:b], cond[:b], eps[:b])
+        z = ve.encode(X[:b], cond[:b], eps[:b])[2]
+        ve.decode_to_atoms(ue, z, cond[:b], thresh=0.5, max_atoms=64)
+    for eng in (ue, ve):
+        dirty, what = eng.check_canaries()
+        assert dirty == 0, what
+    ve.close(); ue.close()
+
+
+def test_graph_probe_times_both_forms_and_leaves_the_engine_training():
+    """ics_net_graph_probe (measurement aid): the resident train step eagerly and as a replayed hipGraph."""
+    from icsg3d_amd.engine import UnetEngine, VaeEngine
+    from icsg3d_amd.synthetic import glorot_params, synthetic_batch, unet_param_shapes, vae_param_shapes
+    B, d = 2, 16
+    X, lab, cond = synthetic_batch(B, d, 1, seed=0, noise=1e-3)
+    ue = UnetEngine(in_channels=1, d=d, max_batch=B, lr=1e-3); ue.set_weights(glorot_params(unet_param_shapes(1, 95), 1))
+    ve = VaeEngine(ue, in_channels=1, d=d, max_batch=B, lr=5e-4); ve.set_weights(glorot_params(vae_param_shapes(1, d=d), 3))
+    ue.upload_batch(X, lab)
+    ve.upload_batch(X, cond, np.random.default_rng(2).standard_normal((B, 256)).astype(np.float32))
+    for eng in (ve, ue):
+        eager, graph, nodes = eng.graph_probe(3)
+        assert eager > 0 and graph > 0 and nodes > 50
+    assert np.all(np.isfinite(ve.train_step_resident(True))) and np.all(np.isfinite(ue.train_step_resident(True)))
+    ve.close(); ue.close()

@@ -39,3 +39,37 @@ def test_host_split_equals_the_oracle(tie, monkeypatch):
     monkeypatch.setenv("ICSG3D_HOST_THREADS", "1")                                   # one thread: same bits
     for a, b in zip(got, watershed_split(boxes, cls, tie=tie)):
         assert np.array_equal(a, b)
+
+
+def test_host_pool_survives_concurrent_callers_and_a_fork(monkeypatch):
+    """The library's host thread pool (segment.hip HostPool): created on first use, one call at a time (callers from several
+    Python threads queue), re-created in a forked child (which has none of the parent's threads)."""
+    import os
+    import threading
+    from icsg3d_amd.watershed import watershed_split
+    monkeypatch.setenv("ICSG3D_WS_DEVICE", "0")
+    rng = np.random.default_rng(9)
+    boxes = [np.where(_blob(rng, 12, 28), 1, 0).astype(np.int32) for _ in range(24)]
+    cls = [1] * len(boxes)
+    ref = watershed_split(boxes, cls)                       # (creates the pool)
+    out = [None] * 4
+
+    def call(i):
+        out[i] = watershed_split(boxes, cls)
+    ts = [threading.Thread(target=call, args=(i,)) for i in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for o in out:
+        assert all(np.array_equal(a, b) for a, b in zip(o, ref))
+    pid = os.fork()
+    if pid == 0:                                            # child: the pool's threads do not exist here
+        try:
+            got = watershed_split(boxes, cls)
+            ok = all(np.array_equal(a, b) for a, b in zip(got, ref))
+            os._exit(0 if ok else 1)
+        except BaseException:
+            os._exit(2)
+    _, status = os.waitpid(pid, 0)
+    assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0, status
