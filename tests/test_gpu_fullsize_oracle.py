@@ -23,7 +23,8 @@ pytestmark = [pytest.mark.gpu, pytest.mark.slow]
 FWD_TOL = 1e-5
 VAE_FWD_TOL = 3e-5
 STAT_TOL = 2e-5
-GRAD_TOL = 6e-5               # tests/test_gpu_fullwidth.py's bound at B = 2 / 1
+GRAD_TOL = {32: 6e-5, 64: 1e-4}   # tests/test_gpu_fullwidth.py's bound at B = 2 / 1 is 6e-5; measured here 2.2e-5 (d = 32, B = 32) and
+                                  # 5.1e-5 (d = 64, B = 8: 2 M rows per channel in the top layers)
 VAE_GRAD_TOL = {32: 6e-5, 64: 1.5e-4}
 HEAD_SUM_TOL = 5e-4           # head weight gradients: fp32 operand error of dz at saturated voxels; measured
                               # 3.06e-4 on sig/kernel at d = 64, B = 8 (49 loss-clip decisions pinned), 2.6e-4 at d = 64, B = 1
@@ -168,7 +169,7 @@ def test_unet_step_at_stated_batch_matches_pinned_fp64_oracle(d, B):
             assert e <= HEAD_SUM_TOL, (name, e)
             continue
         worst = max(worst, e)
-        assert e <= GRAD_TOL, (name, e)
+        assert e <= GRAD_TOL[d], (name, e)
     print("d=%d B=%d: metrics %s (oracle %s); worst BN statistic error %.2e; worst pinned gradient error %.2e (head tensors %.2e)"
           % (d, B, m, m_ref, worst_stat, worst, worst_head))
 
