@@ -292,6 +292,12 @@ struct Net {
   ConvLayer *enc_dense = nullptr, *zmulv = nullptr, *dec_dense = nullptr;
 
   ~Net() {
+    if (canary_on && !canaries.empty()) {      // ICSG3D_DEBUG_CANARY=1: every handle -- the temporary ones of the single-op entry
+      if (st) (void)hipStreamSynchronize(st);  // points too -- reports overwritten guard bytes when it goes away
+      std::string msg;
+      const int bad = canaries_dirty(&msg);
+      if (bad) fprintf(stderr, "[icsg3d] CANARY DIRTY (engine kind %d, d %d, max batch %d, %d buffers): %s\n", kind, d, maxB, bad, msg.c_str());
+    }
     if (comm_bn) ncclCommDestroy(comm_bn);
     if (comm) ncclCommDestroy(comm);
     for (void* p : allocs) (void)hipFree(p);
@@ -318,6 +324,24 @@ struct Net {
   struct Canary { char* p; size_t len, payload; int index; };
   std::vector<Canary> canaries;
   bool canary_on = getenv("ICSG3D_DEBUG_CANARY") != nullptr;
+  // number of guards that were written to; *msg describes the first few
+  int canaries_dirty(std::string* msg) const {
+    std::vector<unsigned char> host;
+    int bad = 0;
+    for (const auto& c : canaries) {
+      host.resize(c.len);
+      if (hipMemcpy(host.data(), c.p, c.len, hipMemcpyDeviceToHost) != hipSuccess) continue;
+      size_t first = c.len;
+      for (size_t i = 0; i < c.len; ++i)
+        if (host[i] != 0x5A) { first = i; break; }
+      if (first < c.len) {
+        ++bad;
+        if (bad <= 8 && msg)
+          *msg += "alloc #" + std::to_string(c.index) + " payload " + std::to_string(c.payload) + " B: guard dirty from +" + std::to_string(first) + "; ";
+      }
+    }
+    return bad;
+  }
   template <typename T>
   int alloc(T** out, size_t n) {
     const size_t guard = canary_on ? 8192 : 0;
@@ -2099,7 +2123,7 @@ int ics_vae_create(const ics_vae_config* cfg, ics_net* pm, ics_net** out) {
 int ics_net_destroy(ics_net* net) {
   if (!net) return 0;
   (void)hipStreamSynchronize(net->n.st);
-  delete net;
+  delete net;            // (with ICSG3D_DEBUG_CANARY=1 the destructor reports overwritten guard bytes on stderr)
   return 0;
 }
 int ics_net_sync(ics_net* net) {
@@ -2187,22 +2211,9 @@ int ics_net_check_canaries(ics_net* net, int* dirty) {
   ICS_CHECK(net && dirty, "null argument");
   Net& n = net->n;
   ICS_HIP(hipStreamSynchronize(n.st));
-  std::vector<unsigned char> host;
   std::string msg;
-  int bad = 0;
-  for (const auto& c : n.canaries) {
-    host.resize(c.len);
-    ICS_HIP(hipMemcpy(host.data(), c.p, c.len, hipMemcpyDeviceToHost));
-    size_t first = c.len;
-    for (size_t i = 0; i < c.len; ++i)
-      if (host[i] != 0x5A) { first = i; break; }
-    if (first < c.len) {
-      ++bad;
-      if (bad <= 8) msg += "alloc #" + std::to_string(c.index) + " payload " + std::to_string(c.payload) + " B: guard dirty from +" + std::to_string(first) + "; ";
-    }
-  }
-  *dirty = bad;
-  if (bad) set_error(msg);
+  *dirty = n.canaries_dirty(&msg);
+  if (*dirty) set_error(msg);
   return 0;
 }
 
