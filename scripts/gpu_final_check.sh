@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6, last GPU call: smoke, the whole GPU suite, the contract bench line -- on the final tree
+# the last GPU call of a round: smoke, the whole GPU suite, the contract bench line -- on the final tree
 mkdir -p gpurun_out
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r6_final_smoke.log 2>&1; echo "smoke rc=$?"; tail -4 gpurun_out/r6_final_smoke.log | cut -c1-300
 python -m pytest tests/ -q -m gpu --durations=8 > gpurun_out/r6_final_suite.log 2>&1; echo "suite rc=$?"
