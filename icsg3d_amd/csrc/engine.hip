@@ -160,6 +160,7 @@ struct ConvLayer {
   float* db_partial = nullptr;          // [blocks][Cout] bias-gradient partials of the BatchNorm-backward apply pass (own buffer:
                                         // finalized with every other layer's in one launch, Net::colsum)
   int db_blocks = 0;                    // rows of db_partial the last backward pass wrote
+  size_t db_rows = 0;                   // rows db_partial holds
   // round 4 (conv_bnfuse_kernel): this layer's BatchNorm-backward apply inside its CONSUMER's backward-data launch
   float* xs = nullptr;                  // [2][Cout] xhat as an affine of the stored activation
   float* abc = nullptr;                 // [3][Cout] the apply's per-channel constants
@@ -432,11 +433,20 @@ static int alloc_layer(Net& n, ConvLayer& L, bool need_bwd, bool pooled) {
     ICS_TRY(n.alloc(&L.dA, M * L.CinG));
     ICS_TRY(n.alloc(&L.c1c2, (size_t)2 * L.Cout));
     if ((L.Cout & (L.Cout - 1)) == 0 || L.Cout % 4 == 0) {
-      LayerBwd lb{};
-      lb.B = n.maxB; lb.S = L.S; lb.lgS = ilog2(L.S); lb.C = L.Cout;
-      int rpb;
-      // 512: the head's backward-data launch; M / 128: a Winograd backward-data launch (one row per tile block)
-      ICS_TRY(n.alloc(&L.db_partial, std::max((size_t)std::max(bn_bwd_num_blocks(lb, &rpb), 512), M / 128 + 1) * L.Cout));
+      // 512: the head's backward-data launch; M / 128: a Winograd backward-data launch (one row per tile block); the
+      // BatchNorm-backward pass: its block count is NOT monotone in the batch (rows per block are rounded up to what one
+      // block covers: 16 channels at 32^3 take 1280 blocks for 5 grids and 1536 for 3), so every batch size the handle
+      // accepts is asked -- sizing by max_batch alone let a 3-grid step on a 5-grid handle write 16 KB past the end
+      // (found by scripts/fuzz_steps.py, round 6)
+      size_t rows = std::max((size_t)512, M / 128 + 1);
+      for (int b = 1; b <= n.maxB; ++b) {
+        LayerBwd lb{};
+        lb.B = b; lb.S = L.S; lb.lgS = ilog2(L.S); lb.C = L.Cout;
+        int rpb;
+        rows = std::max(rows, (size_t)bn_bwd_num_blocks(lb, &rpb));
+      }
+      L.db_rows = rows;
+      ICS_TRY(n.alloc(&L.db_partial, rows * L.Cout));
     }
     if (L.has_bn) { ICS_TRY(n.alloc(&L.xs, (size_t)2 * L.Cout)); ICS_TRY(n.alloc(&L.abc, (size_t)3 * L.Cout)); }
   }
@@ -594,10 +604,14 @@ static int enable_winog(Net& n, ConvLayer& L, bool need_bwd) {
 // workspace sizing over all layers (max batch)
 static int alloc_workspaces(Net& n, bool need_bwd) {
   size_t stat = 0, bwd = 0, wg = 0, fw = 0;
+  // Every plan below (tiles, split counts, blocks per pass) is a function of the batch and not necessarily a monotone
+  // one, and a handle runs any batch up to max_batch (the last batch of an epoch): each workspace is sized for the
+  // largest demand over ALL of them, not for max_batch alone.
+  for (int b = 1; b <= n.maxB; ++b)
   for (auto& Lp : n.layers) {
     ConvLayer& L = *Lp;
-    const size_t M = n.rows(L, n.maxB);
-    const ConvGeom g = geom_fwd(L, n.maxB);
+    const size_t M = n.rows(L, b);
+    const ConvGeom g = geom_fwd(L, b);
     // per-block BatchNorm partials [3][Npad][blocks]: the split-K finish pass (and conv_winog.hip) write 64-row blocks
     // whatever the tile of the GEMM launch -- a narrow 128 x 32 tile that splits K (the VAE decoder's thin layers when
     // ICSG3D_NO_UPSPLIT routes them through the direct kernels) needs M / 64 columns, not M / 128: sizing by the tile
@@ -608,25 +622,25 @@ static int alloc_workspaces(Net& n, bool need_bwd) {
     fw = std::max(fw, conv_fwd_workspace_floats(g, L.src, L.nsrc));
     if (need_bwd) {
       const ConvSrc sdy = src_plain(L.dy, L.Cout);
-      fw = std::max(fw, conv_fwd_workspace_floats(geom_bwd(L, n.maxB), &sdy, 1));
+      fw = std::max(fw, conv_fwd_workspace_floats(geom_bwd(L, b), &sdy, 1));
       if (L.split_up) {
         const ConvSrc sd = src_plain(L.dyS, L.ldS);
-        fw = std::max(fw, conv_fwd_workspace_floats(geom_up_dgrad(L, n.maxB), &sd, 1));
-        if (L.Cs) fw = std::max(fw, conv_fwd_workspace_floats(geom_skip_dgrad(L, n.maxB), &sdy, 1));
+        fw = std::max(fw, conv_fwd_workspace_floats(geom_up_dgrad(L, b), &sd, 1));
+        if (L.Cs) fw = std::max(fw, conv_fwd_workspace_floats(geom_skip_dgrad(L, b), &sdy, 1));
       }
       LayerBwd lb{};
-      lb.B = n.maxB; lb.S = L.S; lb.lgS = ilog2(L.S); lb.C = L.Cout;
+      lb.B = b; lb.S = L.S; lb.lgS = ilog2(L.S); lb.C = L.Cout;
       // Cout may be a non power of two only for the head, which never goes through layer_bwd
       if ((L.Cout & (L.Cout - 1)) == 0) bwd = std::max(bwd, layer_bwd_workspace_floats(lb));
       wg = std::max(wg, conv_wgrad_workspace_floats(g, L.src, L.nsrc));
       if (L.wino_w)
-        wg = std::max(wg, conv_wino_wgrad_workspace_floats(L.split_up ? geom_skip_wgrad(L, n.maxB) : g));
+        wg = std::max(wg, conv_wino_wgrad_workspace_floats(L.split_up ? geom_skip_wgrad(L, b) : g));
       if ((L.Cin == 1 || L.cond_fold) && (L.Cout == 16 || L.Cout == 32))
         wg = std::max(wg, conv_thin_c_wgrad_workspace_floats(g));
       if (L.split_up) {
         const ConvSrc lo = src_lowres(L);
-        wg = std::max(wg, conv_wgrad_workspace_floats(geom_up_wgrad(L, n.maxB), &lo, 1));
-        if (L.Cs) wg = std::max(wg, conv_wgrad_workspace_floats(geom_skip_wgrad(L, n.maxB), L.src, 1));
+        wg = std::max(wg, conv_wgrad_workspace_floats(geom_up_wgrad(L, b), &lo, 1));
+        if (L.Cs) wg = std::max(wg, conv_wgrad_workspace_floats(geom_skip_wgrad(L, b), L.src, 1));
       }
     }
   }
@@ -647,7 +661,7 @@ static int alloc_workspaces(Net& n, bool need_bwd) {
     size_t cls = 0; int cmax = 0;
     for (auto& Lp : n.layers)
       if (Lp->taps == 27 && Lp->S >= 3 && Lp->Cout % 4 == 0) {
-        cls = std::max(cls, conv_bnfuse_partial_floats(n.maxB, Lp->S, Lp->Cout));
+        for (int b = 1; b <= n.maxB; ++b) cls = std::max(cls, conv_bnfuse_partial_floats(b, Lp->S, Lp->Cout));
         cmax = std::max(cmax, Lp->Cout);
       }
     n.ws_cls_n = cls;
@@ -1110,6 +1124,7 @@ static int conv_grads_from_dy(Net& n, ConvLayer& L, int B, bool need_dA, bool pa
                                    L.wwb_layout, &ba, &blocks));
       n.prof.end(n.st);
       ICS_CHECK(blocks > 0, "fused BatchNorm-backward apply: the backward-data launch did not take it");
+      ICS_CHECK((size_t)blocks <= next->db_rows, "bias-gradient partial buffer too small for this batch");
       next->dy_ready = true;
       next->db_blocks = 0;
       ICS_TRY(colsum_push(n, next->db_partial, blocks, next->Cout, n.tg(next->t_b)));
@@ -1189,6 +1204,7 @@ static int conv_backward(Net& n, ConvLayer& L, int B, GradSrc g0, GradSrc g1, co
                                  &blocks));
     n.prof.end(n.st);
     ICS_CHECK(blocks > 0, "deferred skip backward-data: the launch did not take the fused apply");
+    ICS_CHECK((size_t)blocks <= L.db_rows, "bias-gradient partial buffer too small for this batch");
     L.db_blocks = 0;
     ICS_TRY(colsum_push(n, L.db_partial, blocks, L.Cout, n.tg(L.t_b)));
     L.db_blocks = blocks;
@@ -1211,6 +1227,11 @@ static int conv_backward(Net& n, ConvLayer& L, int B, GradSrc g0, GradSrc g1, co
   n.prof.begin(n.st, "bn_act_bwd:" + L.name, 0, 4.0 * M * L.Cout * (L.has_bn ? (pre.nblk ? 3.0 : 5.0) : 3.0));
   const bool defer = param_grads && L.db_partial != nullptr;
   int db_blocks = 0;
+  {
+    int rpb;
+    ICS_CHECK(!defer || (size_t)bn_bwd_num_blocks(lb, &rpb) <= L.db_rows, "bias-gradient partial buffer too small for this batch");
+    ICS_CHECK(!L.has_bn || layer_bwd_workspace_floats(lb) <= n.ws_bwd_n, "BatchNorm-backward workspace too small for this batch");
+  }
   ICS_TRY(launch_layer_bwd(n.st, lb, L.dy, n.ws_bwd, L.c1c2,
                            (param_grads && L.has_bn) ? n.tg(L.t_gamma) : nullptr,
                            (param_grads && L.has_bn) ? n.tg(L.t_beta) : nullptr,
@@ -1578,6 +1599,7 @@ static int unet_backward(Net& n, int B) {
       ICS_TRY(launch_head_dgrad(n.st, H.s, n.tp(H.t_w), n.tp(H.t_gamma), r.c18->dy, 128, M, &bs, gb.Npad, &blocks,
                                 r.c18->c1c2, r.c18->db_partial));
       n.prof.end(n.st);
+      ICS_CHECK((size_t)blocks <= r.c18->db_rows, "bias-gradient partial buffer too small for this batch");
       ICS_TRY(colsum_push(n, r.c18->db_partial, blocks, 128, n.tg(r.c18->t_b)));
       r.c18->db_blocks = blocks;
     } else {

@@ -154,6 +154,9 @@ int main(void) {
   if (run(16, 1, 3, 0)) return 1;
   if (run(16, 4, 2, 1)) return 1;      /* 4 channels (Cin 44 -> padded loaders), single-rank communicator */
   if (run(32, 1, 2, 2)) return 1;      /* d = 32 plans, SyncBN */
+  if (run(32, 1, 5, 0)) return 1;      /* plans that are not monotone in the batch: 3 grids on a 5-grid handle need more
+                                          BatchNorm-backward blocks than 5 do (the engine's capacity checks fire if a
+                                          workspace was sized for max_batch alone, round 6) */
   {   /* single-op entry points */
     const int B = 1, S = 8, Cin = 32, Cout = 64;
     size_t nx = (size_t)B * S * S * S * Cin, ny = (size_t)B * S * S * S * Cout, nw = (size_t)27 * Cin * Cout;

@@ -134,11 +134,14 @@ def test_launcher_counts_this_box_like_the_runtime():
     assert launcher.visible_gpus() == _lib.device_count() >= 1
 
 
-@pytest.mark.parametrize("B,d", [(3, 16), (2, 32)])
+@pytest.mark.parametrize("B,d", [(3, 16), (2, 32), (5, 32)])
 def test_no_kernel_writes_past_its_buffers(B, d, monkeypatch):
     """ICSG3D_DEBUG_CANARY=1: 8 KB of guard bytes behind every device buffer of a handle; after train / test / predict steps
-    of both engines and the fused inference tail (odd batch at d = 16: every tile remainder path) none of them was touched.
-    (Round 4 found such a write by accident; this looks for them.)"""
+    of both engines and the fused inference tail at EVERY batch size the handle accepts (odd batches at d = 16: every tile
+    remainder path) none of them was touched.  (Round 4 found such a write by accident; this looks for them.  Round 6's
+    scripts/fuzz_steps.py found the next one: a DFC-VAE train step on 3 grids with a 5-grid handle at d = 32 wrote 16 KB past the
+    bias-gradient partials of e0 and d3 -- the BatchNorm-backward pass takes 1536 blocks for 3 grids and 1280 for 5, and the
+    buffer was sized for max_batch alone.  The (5, 32) case is that handle.)"""
     from icsg3d_amd.engine import UnetEngine, VaeEngine
     from icsg3d_amd.synthetic import glorot_params, synthetic_batch, unet_param_shapes, vae_param_shapes
     monkeypatch.setenv("ICSG3D_DEBUG_CANARY", "1")
@@ -147,7 +150,7 @@ def test_no_kernel_writes_past_its_buffers(B, d, monkeypatch):
     ue = UnetEngine(in_channels=1, d=d, max_batch=B, lr=1e-3); ue.set_weights(glorot_params(unet_param_shapes(1, 95), 1))
     ve = VaeEngine(ue, in_channels=1, d=d, max_batch=B, lr=5e-4); ve.set_weights(glorot_params(vae_param_shapes(1, d=d), 3))
     assert ue.check_canaries()[0] == 0 and ve.check_canaries()[0] == 0
-    for b in (B, max(B - 1, 1)):
+    for b in range(B, 0, -1):
         ue.train_step(X[:b], lab[:b]); ue.test_step(X[:b], lab[:b]); ue.predict(X[:b])
         ve.train_step(X[:b], cond[:b], eps[:b]); ve.test_step(X[:b], cond[:b], eps[:b])
         z = ve.encode(X[:b], cond[:b], eps[:b])[2]
