@@ -87,8 +87,23 @@ def unet_step(eng, B, d, C, seed):
     flips = sum(T.unet_step_grads.flips["kink"].values())
     bad = fwd > FWD_TOL or body > GRAD_TOL or head > HEAD_TOL
     worst = max(errs, key=errs.get)
-    return bad, "unet d=%d C=%d B=%d: loss err %.1e, grads %.1e (head %.1e; worst %s), %d decisions pinned" % (
+    line = "unet d=%d C=%d B=%d: loss err %.1e, grads %.1e (head %.1e; worst %s), %d decisions pinned" % (
         d, C, B, fwd, body, head, worst, flips)
+    if bad and fwd <= FWD_TOL:
+        # Is it the engine or fp32?  The same oracle in fp32 (same pins, torch's own kernels) against itself in fp64: a
+        # gradient the engine misses by no more than a few times what plain fp32 arithmetic misses it by is conditioning
+        # (a head that has become confident: every dz is a difference of nearly equal numbers), not a defect.
+        import torch
+        _, g32, _, _, _ = T.unet_step_grads(P, S, X, lab, kink=kink, affine=affine, clip_pin=clip_pin, want_outputs=False,
+                                            kink_tol=1.0, dtype=torch.float32)
+        e32 = {n: grad_err(g32[n], g_ref[n], g_ref, n) for n in grads}
+        over = {n: (errs[n], e32[n]) for n in errs
+                if errs[n] > (HEAD_TOL if n.split("/")[0] in ("soft", "sig") else GRAD_TOL)}
+        cond = all(e <= 4 * f for e, f in over.values())
+        line += "; over the bound (engine, fp32 torch): %s -> %s" % (
+            {n: "%.1e / %.1e" % v for n, v in over.items()}, "fp32 conditioning" if cond else "ENGINE")
+        bad = not cond
+    return bad, line
 
 
 def vae_step(ve, ue, B, d, C, seed):
@@ -110,8 +125,79 @@ def vae_step(ve, ue, B, d, C, seed):
     errs = {n: grad_err(g, g_ref[n], g_ref, n, floor=1e-6 * gscale) for n, g in grads.items()}
     worst = max(errs, key=errs.get)
     bad = fwd > VAE_FWD_TOL or errs[worst] > VAE_GRAD_TOL
-    return bad, "vae  d=%d C=%d B=%d: metric err %.1e, grads %.1e (worst %s), %d decisions pinned" % (
+    line = "vae  d=%d C=%d B=%d: metric err %.1e, grads %.1e (worst %s), %d decisions pinned" % (
         d, C, B, fwd, errs[worst], worst, sum(T.vae_step_grads.flips.values()))
+    if bad and fwd <= VAE_FWD_TOL:
+        import torch
+        _, g32, _, _, _, _ = T.vae_step_grads(Pv, Sv, Pu, Su, X, cond, eps, in_ch=C, d=d, kink=kink, kink_pm=kink_pm,
+                                              affine=aff, affine_pm=aff_pm, kink_tol=1.0, dtype=torch.float32)
+        over = {n: (errs[n], grad_err(g32[n], g_ref[n], g_ref, n, floor=1e-6 * gscale)) for n in errs if errs[n] > VAE_GRAD_TOL}
+        cond_ = all(e <= 4 * f for e, f in over.values())
+        line += "; over the bound (engine, fp32 torch): %s -> %s" % (
+            {n: "%.1e / %.1e" % v for n, v in over.items()}, "fp32 conditioning" if cond_ else "ENGINE")
+        bad = not cond_
+    return bad, line
+
+
+def infer_checks(ue, ve, Bi, d, C, seed):
+    """Inference-mode entry points with the moving statistics the train steps left, on Bi grids (Bi may exceed max_batch:
+    the host classes stream chunks): model.predict / test_on_batch of the U-Net; encoder / decoder / test_on_batch of the VAE."""
+    import torch
+    X, lab, cond, eps = inputs(Bi, d, C, seed)
+    Pu, Su = engine_state(ue)
+    pu = T.Params(Pu, Su, torch.float64, requires_grad=False)
+    with torch.no_grad():
+        soft_t, sig_t = T.unet_forward(T.to_t(X, torch.float64), pu, False, "tf_cpu")
+    soft, sig = ue.predict(X)
+    e_soft = float(np.abs(soft - T.to_n(soft_t)).max())
+    e_sig = float(np.abs(sig - T.to_n(sig_t)).max())
+    out = ["predict B=%d: soft %.1e sig %.1e" % (Bi, e_soft, e_sig)]
+    bad = e_soft > 1e-5 or e_sig > 1e-5
+    b = min(Bi, ue.max_batch)
+    with torch.no_grad():
+        loss, lsoft, lsig = T.unet_loss(soft_t[:b], sig_t[:b], lab[:b])
+    m = ue.test_step(X[:b], lab[:b])
+    ref = np.array([loss.item(), lsoft.item(), lsig.item()])
+    e_m = float((np.abs(m[:3] - ref) / np.abs(ref)).max())
+    out.append("test_step B=%d: %.1e" % (b, e_m))
+    bad = bad or e_m > 2e-5
+    sp, mk = ue.predict_labels(X, thresh=0.8)
+    pr, sg = T.to_n(soft_t), T.to_n(sig_t)[..., 0]
+    top2 = np.partition(pr, -2, axis=-1)[..., -2:]
+    sure = (top2[..., 1] - top2[..., 0]) > 1e-4
+    n_sp = int((sp[sure] != pr.argmax(-1)[sure]).sum())
+    sure_m = np.abs(sg - 0.8) > 1e-4
+    n_mk = int(((mk != 0)[sure_m] != (sg >= 0.8)[sure_m]).sum())
+    out.append("labels: %d / %d differ outside the margins" % (n_sp, n_mk))
+    if bad:
+        # engine or fp32?  the same forward and loss by torch in fp32 against fp64 (moving statistics a few steps old do not
+        # normalise: activations grow through 14 layers, the heads saturate, and K.clip's upper bound 1 - 1e-7 is 1 - 1.19e-7 in fp32)
+        p32 = T.Params(Pu, Su, torch.float32, requires_grad=False)
+        with torch.no_grad():
+            s32, g32 = T.unet_forward(T.to_t(X, torch.float32), p32, False, "tf_cpu")
+            l32 = [v.item() for v in T.unet_loss(s32[:b], g32[:b], lab[:b])]
+        f_soft = float(np.abs(T.to_n(s32) - T.to_n(soft_t)).max())
+        f_sig = float(np.abs(T.to_n(g32) - T.to_n(sig_t)).max())
+        f_m = float((np.abs(np.array(l32) - ref) / np.abs(ref)).max())
+        e_m32 = float((np.abs(m[:3] - np.array(l32)) / np.abs(l32)).max())
+        cond = (e_soft <= max(1e-5, 4 * f_soft) and e_sig <= max(1e-5, 4 * f_sig) and (e_m <= 2e-5 or e_m32 <= 2e-5 or e_m <= 4 * f_m))
+        out.append("fp32 torch vs fp64: soft %.1e sig %.1e loss %.1e; engine vs fp32 torch loss %.1e -> %s"
+                   % (f_soft, f_sig, f_m, e_m32, "fp32 conditioning" if cond else "ENGINE"))
+        bad = not cond
+    bad = bad or n_sp or n_mk
+    if ve is not None:
+        Pv, Sv = engine_state(ve)
+        b = min(Bi, ve.max_batch)
+        m_ref, _, _, recon, zm, zlv = T.vae_step_grads(Pv, Sv, Pu, Su, X[:b], cond[:b], eps[:b], in_ch=C, d=d, training=False)
+        zm_e, zlv_e, z_e = ve.encode(X[:b], cond[:b], eps[:b])
+        rec_e = ve.decode(z_e, cond[:b])
+        m = ve.test_step(X[:b], cond[:b], eps[:b])
+        e = [float(np.abs(zm_e - zm).max() / max(np.abs(zm).max(), 1e-30)), float(np.abs(zlv_e - zlv).max() / max(np.abs(zlv).max(), 1e-30)),
+             float(np.abs(rec_e - recon).max() / max(np.abs(recon).max(), 1e-30)),
+             float((np.abs(np.asarray(m, np.float64) - m_ref) / np.maximum(np.abs(m_ref), 1e-300)).max())]
+        out.append("vae B=%d: z_mean %.1e z_log_var %.1e recon %.1e test_step %.1e" % (b, *e))
+        bad = bad or max(e[:3]) > 1e-5 or e[3] > 3e-5
+    return bool(bad), "infer d=%d C=%d: " % (d, C) + "; ".join(out)
 
 
 def main():
@@ -148,16 +234,20 @@ def main():
         maxB = int(rng.integers(2, 41 if d == 16 else 10))
         seed = int(rng.integers(1, 1 << 20))
         ush = R.unet_param_shapes(C, 95)
-        ue = UnetEngine(in_channels=C, d=d, max_batch=maxB, lr=float(rng.choice([1e-3, 1e-4])))
+        lr = float(rng.choice([1e-3, 1e-4]))
+        batches = [maxB] + [int(b) for b in rng.integers(1, maxB + 1, size=3)]
+        rng.shuffle(batches)
+        Bi = min(int(rng.integers(1, 2 * maxB + 2)), 24 if d == 16 else 6)    # grids of the inference checks
+        if os.environ.get("FUZZ_ONLY") and str(t) not in os.environ["FUZZ_ONLY"].split(","):
+            continue
+        ue = UnetEngine(in_channels=C, d=d, max_batch=maxB, lr=lr)
         ue.set_weights(R.init_params(ush, seed))
         with_vae = t % 2 == 1
         if with_vae:
             ve = VaeEngine(ue, in_channels=C, d=d, max_batch=maxB, lr=5e-4)
             ve.set_weights(R.init_params(R.vae_param_shapes(C, d=d), seed + 1))
-        batches = [maxB] + [int(b) for b in rng.integers(1, maxB + 1, size=3)]
-        rng.shuffle(batches)
-        print("trial %d: d=%d C=%d max_batch=%d batches %s%s" % (t, d, C, maxB, batches, " + DFC-VAE" if with_vae else ""),
-              flush=True)
+        print("trial %d: d=%d C=%d max_batch=%d lr=%g batches %s%s" % (t, d, C, maxB, lr, batches,
+                                                                       " + DFC-VAE" if with_vae else ""), flush=True)
         for i, B in enumerate(batches):
             try:
                 if with_vae and i % 2 == 0:
@@ -169,6 +259,13 @@ def main():
             nbad += bad
             nstep += 1
             print(("  FAIL " if bad else "  ok   ") + line, flush=True)
+        try:
+            bad, line = infer_checks(ue, ve if with_vae else None, Bi, d, C, seed + 77)
+        except AssertionError as e:
+            bad, line = True, "infer d=%d C=%d B=%d: %s" % (d, C, Bi, str(e)[:200])
+        nbad += bad
+        nstep += 1
+        print(("  FAIL " if bad else "  ok   ") + line, flush=True)
         if with_vae:
             ve.close()
         ue.close()
