@@ -5,7 +5,10 @@ BatchNorm partials of a previous batch size would show -- and checks each step a
 engine's own weights before the step (metrics, every gradient tensor; the engine's ReLU / pool / clip decisions pinned as in
 tests/test_gpu_fullsize_oracle.py).  Prints one line per step and a summary; exit code 1 if any bound is exceeded.
 
-    python scripts/fuzz_steps.py [trials=12] [seed=0]
+Every trial runs with guard bytes behind the device buffers (ICSG3D_DEBUG_CANARY=1) and a third of them with one or two of
+the ICSG3D_NO_* A/B switches.
+
+    python scripts/fuzz_steps.py [trials=12] [seed=0]        (FUZZ_ONLY=3,7: only those trials of the same sequence)
 Reference: /root/reference/unet/unet.py:272-355,370, vae/lattice_vae.py:160-270,296."""
 import os
 import sys
@@ -22,6 +25,14 @@ from oracle import torch_ref as T          # noqa: E402
 
 GRAD_TOL, HEAD_TOL, VAE_GRAD_TOL, FWD_TOL, VAE_FWD_TOL, KINK_TOL = 6e-5, 5e-4, 1e-4, 1e-5, 3e-5, 1e-4
 UNET_LAYERS = [n for n, _, _ in R.UNET_CONVS]
+# the A/B switches of tests/test_gpu_switches.py: a third of the trials run with one or two of them (the general kernels
+# behind a fast path have their own split plans and workspaces)
+SWITCHES = ["ICSG3D_NO_REUSE", "ICSG3D_NO_WGRAD3", "ICSG3D_NO_FWD_SPLITK", "ICSG3D_NO_THIN_N", "ICSG3D_NO_UPSPLIT",
+            "ICSG3D_NO_THIN_C", "ICSG3D_NO_BWD_FOLD", "ICSG3D_NO_WGRAD3S", "ICSG3D_NO_COND_FOLD", "ICSG3D_NO_WINO",
+            "ICSG3D_NO_WINO64", "ICSG3D_NO_UP3", "ICSG3D_NO_WINO_WGRAD", "ICSG3D_NO_FUSED_HEAD", "ICSG3D_NO_FAST_BNBWD",
+            "ICSG3D_NO_THIN1_2STAGE", "ICSG3D_NO_WINOG", "ICSG3D_NO_HEAD_BNFUSE", "ICSG3D_NO_UP3N", "ICSG3D_NO_POOL_PRESUM",
+            "ICSG3D_DGRAD_BNFUSE_MIN=0", "ICSG3D_NO_DGRAD_BNFUSE", "ICSG3D_NO_PM_SIDE", "ICSG3D_NO_VAE_SIDE_WGRAD",
+            "ICSG3D_NO_HEAD_LABELS"]
 RES = {"c1": 1, "c2": 1, "c3": 2, "c4": 2, "c5": 4, "c6": 4, "c9": 8, "c10": 8, "c13": 4, "c14": 4,
        "c15": 2, "c16": 2, "c17": 1, "c18": 1}
 COUT = dict((n, c) for n, _, c in R.UNET_CONVS)
@@ -228,26 +239,34 @@ def main():
             nbad += bad
             print(("  FAIL " if bad else "  ok   ") + line + "  [max_batch %d]" % maxB, flush=True)
         sys.exit(1 if nbad else 0)
+    os.environ["ICSG3D_DEBUG_CANARY"] = "1"      # guard bytes behind every device buffer, checked at the end of each trial
     for t in range(trials):
-        d = int(rng.choice([16, 16, 32]))
+        d = int(rng.choice([16, 16, 16, 32, 32, 64]))
         C = int(rng.choice([1, 4]))
-        maxB = int(rng.integers(2, 41 if d == 16 else 10))
+        maxB = int(rng.integers(2, {16: 41, 32: 10, 64: 4}[d]))
+        sw = [str(v) for v in rng.choice(SWITCHES, size=int(rng.integers(1, 3)), replace=False)] if rng.random() < 0.34 else []
         seed = int(rng.integers(1, 1 << 20))
         ush = R.unet_param_shapes(C, 95)
         lr = float(rng.choice([1e-3, 1e-4]))
         batches = [maxB] + [int(b) for b in rng.integers(1, maxB + 1, size=3)]
         rng.shuffle(batches)
-        Bi = min(int(rng.integers(1, 2 * maxB + 2)), 24 if d == 16 else 6)    # grids of the inference checks
+        Bi = min(int(rng.integers(1, 2 * maxB + 2)), {16: 24, 32: 6, 64: 2}[d])    # grids of the inference checks
         if os.environ.get("FUZZ_ONLY") and str(t) not in os.environ["FUZZ_ONLY"].split(","):
             continue
+        if "FUZZ_SW" in os.environ:                     # override the drawn switches: "none" or a comma list
+            sw = [v for v in os.environ["FUZZ_SW"].split(",") if v and v != "none"]
+        for k in SWITCHES:
+            os.environ.pop(k.split("=")[0], None)
+        for k in sw:                                  # read per handle at creation
+            os.environ[k.split("=")[0]] = k.split("=")[1] if "=" in k else "1"
         ue = UnetEngine(in_channels=C, d=d, max_batch=maxB, lr=lr)
         ue.set_weights(R.init_params(ush, seed))
         with_vae = t % 2 == 1
         if with_vae:
             ve = VaeEngine(ue, in_channels=C, d=d, max_batch=maxB, lr=5e-4)
             ve.set_weights(R.init_params(R.vae_param_shapes(C, d=d), seed + 1))
-        print("trial %d: d=%d C=%d max_batch=%d lr=%g batches %s%s" % (t, d, C, maxB, lr, batches,
-                                                                       " + DFC-VAE" if with_vae else ""), flush=True)
+        print("trial %d: d=%d C=%d max_batch=%d lr=%g batches %s%s %s" % (t, d, C, maxB, lr, batches,
+                                                                          " + DFC-VAE" if with_vae else "", " ".join(sw)), flush=True)
         for i, B in enumerate(batches):
             try:
                 if with_vae and i % 2 == 0:
@@ -266,6 +285,12 @@ def main():
         nbad += bad
         nstep += 1
         print(("  FAIL " if bad else "  ok   ") + line, flush=True)
+        for nm, e in (("vae", ve if with_vae else None), ("unet", ue)):
+            if e is not None:
+                dirty, what = e.check_canaries()
+                if dirty:
+                    nbad += 1
+                    print("  FAIL %s handle: %d guards written: %s" % (nm, dirty, what[:300]), flush=True)
         if with_vae:
             ve.close()
         ue.close()
