@@ -80,10 +80,14 @@ def inputs(B, d, C, seed):
     return X, lab, cond.astype(np.float64), eps
 
 
-def unet_step(eng, B, d, C, seed):
+def unet_step(eng, B, d, C, seed, resident=False):
     X, lab, _, _ = inputs(B, d, C, seed)
     P, S = engine_state(eng)
-    m = eng.train_step(X, lab)
+    if resident:                      # the benchmark's form: upload, then a step on the resident batch
+        eng.upload_batch(X, lab)
+        m = eng.train_step_resident(True)
+    else:
+        m = eng.train_step(X, lab)
     grads = {name: eng.get_grad(name, shape) for name, shape, tr in eng.tensor_infos() if tr}
     kink = {n: eng.get_activation(n, ushape(n, B, d)) for n in UNET_LAYERS}
     affine = {n: eng.get_bn_affine(n, COUT[n]) for n in ("c2", "c4", "c6")}
@@ -117,11 +121,15 @@ def unet_step(eng, B, d, C, seed):
     return bad, line
 
 
-def vae_step(ve, ue, B, d, C, seed):
+def vae_step(ve, ue, B, d, C, seed, resident=False):
     X, _, cond, eps = inputs(B, d, C, seed)
     Pv, Sv = engine_state(ve)
     Pu, Su = engine_state(ue)
-    m = ve.train_step(X, cond, eps)
+    if resident:
+        ve.upload_batch(X, cond, eps)
+        m = ve.train_step_resident(True)
+    else:
+        m = ve.train_step(X, cond, eps)
     grads = {name: ve.get_grad(name, shape) for name, shape, tr in ve.tensor_infos() if tr}
     vs = vae_shapes(B, d, C)
     ps = {n: ushape(n, B, d) for n in UNET_LAYERS[:8]}
@@ -251,6 +259,8 @@ def main():
         batches = [maxB] + [int(b) for b in rng.integers(1, maxB + 1, size=3)]
         rng.shuffle(batches)
         Bi = min(int(rng.integers(1, 2 * maxB + 2)), {16: 24, 32: 6, 64: 2}[d])    # grids of the inference checks
+        comm = int(rng.integers(0, 4))            # 1: a single-rank RCCL communicator (bucketed all-reduce path); 2: + SyncBN
+        res = [bool(v) for v in rng.integers(0, 2, size=4)]      # which steps take the resident form
         if os.environ.get("FUZZ_ONLY") and str(t) not in os.environ["FUZZ_ONLY"].split(","):
             continue
         if "FUZZ_SW" in os.environ:                     # override the drawn switches: "none" or a comma list
@@ -265,14 +275,19 @@ def main():
         if with_vae:
             ve = VaeEngine(ue, in_channels=C, d=d, max_batch=maxB, lr=5e-4)
             ve.set_weights(R.init_params(R.vae_param_shapes(C, d=d), seed + 1))
-        print("trial %d: d=%d C=%d max_batch=%d lr=%g batches %s%s %s" % (t, d, C, maxB, lr, batches,
-                                                                          " + DFC-VAE" if with_vae else "", " ".join(sw)), flush=True)
+        if comm in (1, 2):
+            from icsg3d_amd.engine import comm_unique_id
+            for e in ([ue, ve] if with_vae else [ue]):
+                e.comm_init(0, 1, comm_unique_id()); e.broadcast_state(0); e.set_sync_bn(comm == 2)
+        print("trial %d: d=%d C=%d max_batch=%d lr=%g batches %s%s %s%s resident %s" % (
+            t, d, C, maxB, lr, batches, " + DFC-VAE" if with_vae else "", " ".join(sw),
+            {1: " comm", 2: " comm+syncbn"}.get(comm, ""), [int(v) for v in res]), flush=True)
         for i, B in enumerate(batches):
             try:
                 if with_vae and i % 2 == 0:
-                    bad, line = vae_step(ve, ue, B, d, C, seed + 10 * i)
+                    bad, line = vae_step(ve, ue, B, d, C, seed + 10 * i, res[i])
                 else:
-                    bad, line = unet_step(ue, B, d, C, seed + 10 * i)
+                    bad, line = unet_step(ue, B, d, C, seed + 10 * i, res[i])
             except AssertionError as e:      # the oracle refuses a decision far from its kink: the forward pass differs
                 bad, line = True, "d=%d C=%d B=%d: %s" % (d, C, B, str(e)[:200])
             nbad += bad
