@@ -258,6 +258,10 @@ def bn(x, p, name, training, stats_out=None):
 _SLOPE = {"relu": 0.0, "lrelu": LEAKY}
 
 
+GRAD_CAPTURE = None      # diagnosis aid: a dict here receives {layer: dLoss/ds (NCDHW tensor)} for every block whose stored
+                         # activation s carries a gradient (scripts/fuzz_steps.py FUZZ_DY=1 compares them with the engine's "layer:dy")
+
+
 def block(x, p, name, pre, has_bn, post, training, taps=None, stats=None, pins=None):
     y = conv3d(x, p.t[name + "/kernel"], p.t[name + "/bias"])
     si = pins.impl(name, y) if pins is not None else None
@@ -270,6 +274,8 @@ def block(x, p, name, pre, has_bn, post, training, taps=None, stats=None, pins=N
             pins.count(name, y.detach(), si)
     if taps is not None:
         taps[name] = s
+    if GRAD_CAPTURE is not None and s.requires_grad:
+        s.register_hook(lambda g, n=name: GRAD_CAPTURE.__setitem__(n, g.detach()))
     if not has_bn:
         return s
     o = bn(s, p, name, training, stats)

@@ -137,12 +137,26 @@ def vae_step(ve, ue, B, d, C, seed, resident=False):
     kink_pm = {n: ue.get_activation(n, s) for n, s in ps.items()}
     aff = {n: ve.get_bn_affine(n, vs[n][-1]) for n in ("e0", "e1", "e2", "e3", "d0", "d1", "d2", "d3", "dout")}
     aff_pm = {n: ue.get_bn_affine(n, ps[n][-1]) for n in ("c2", "c4", "c6")}
+    cap = {} if os.environ.get("FUZZ_DY") else None
+    T.GRAD_CAPTURE = cap
     m_ref, g_ref, _, _, _, _ = T.vae_step_grads(Pv, Sv, Pu, Su, X, cond, eps, in_ch=C, d=d, kink=kink, kink_pm=kink_pm,
                                                 affine=aff, affine_pm=aff_pm, kink_tol=KINK_TOL)
+    T.GRAD_CAPTURE = None
+    if cap is not None:      # where along the backward chain does the engine leave the oracle?  dLoss/ds per layer, in backward order
+        order = ["c10", "c9", "c6", "c5", "c4", "c3", "c2", "c1", "dout", "d3", "d2", "d1", "d0", "e4", "e3", "e2", "e1", "e0"]
+        for n in order:
+            if n not in cap:
+                continue
+            ref = T.to_n(cap[n])
+            got = (ue if n.startswith("c") else ve).get_activation(n + ":dy", ref.shape)
+            print("    dy %-5s engine vs fp64: %.1e  (max|dy| %.2e)" % (n, np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-300),
+                                                                    np.abs(ref).max()), flush=True)
     fwd = float((np.abs(np.asarray(m, np.float64) - m_ref) / np.maximum(np.abs(m_ref), 1e-300)).max())
     gscale = max(np.abs(g).max() for g in g_ref.values())
     errs = {n: grad_err(g, g_ref[n], g_ref, n, floor=1e-6 * gscale) for n, g in grads.items()}
     worst = max(errs, key=errs.get)
+    if cap is not None:
+        print("    per-tensor: %s" % {k: "%.1e" % v for k, v in errs.items()}, flush=True)
     bad = fwd > VAE_FWD_TOL or errs[worst] > VAE_GRAD_TOL
     line = "vae  d=%d C=%d B=%d: metric err %.1e, grads %.1e (worst %s), %d decisions pinned" % (
         d, C, B, fwd, errs[worst], worst, sum(T.vae_step_grads.flips.values()))
@@ -259,8 +273,10 @@ def main():
         batches = [maxB] + [int(b) for b in rng.integers(1, maxB + 1, size=3)]
         rng.shuffle(batches)
         Bi = min(int(rng.integers(1, 2 * maxB + 2)), {16: 24, 32: 6, 64: 2}[d])    # grids of the inference checks
-        comm = int(rng.integers(0, 4))            # 1: a single-rank RCCL communicator (bucketed all-reduce path); 2: + SyncBN
-        res = [bool(v) for v in rng.integers(0, 2, size=4)]      # which steps take the resident form
+        comm, res = 0, [False] * 4
+        if not os.environ.get("FUZZ_PLAIN"):      # (FUZZ_PLAIN=1: the draw sequence of the runs in profiles/r6_fuzz.txt before these two existed)
+            comm = int(rng.integers(0, 4))        # 1: a single-rank RCCL communicator (bucketed all-reduce path); 2: + SyncBN
+            res = [bool(v) for v in rng.integers(0, 2, size=4)]      # which steps take the resident form
         if os.environ.get("FUZZ_ONLY") and str(t) not in os.environ["FUZZ_ONLY"].split(","):
             continue
         if "FUZZ_SW" in os.environ:                     # override the drawn switches: "none" or a comma list
