@@ -997,6 +997,9 @@ int conv_fwd_rows_per_block(const ConvGeom& g) {
 // CIN = channels read per voxel; wstride = channels per tap in the packed weights (>= CIN: c1 at C = 1 reads the
 // un-padded input but the weights are packed for the 4-channel padded problem the backward-weight kernel uses).
 // =====================================================================================
+#ifndef ICS_THINC_UNROLL
+#define ICS_THINC_UNROLL 3   // (dz, dy) rows whose loads are in flight together
+#endif
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void conv_thin_c_fwd_kernel(ConvGeom g, const float* __restrict__ x, int wstride,
                                                                const float* __restrict__ wp,
@@ -1013,9 +1016,14 @@ __global__ __launch_bounds__(256) void conv_thin_c_fwd_kernel(ConvGeom g, const 
   const int t = threadIdx.x;
   const int S = g.S, lg = g.lgS;
   const int M = g.B << (3 * lg);
-  const int K = 27 * wstride;
+  // CIN < 4 reads only channel 0 of each tap's wstride packed rows: stage those 27 rows (a block's staging is a chain of
+  // dependent L2 round trips in front of its barrier: 14 per thread for all 27 x wstride rows, 4 for these)
+  constexpr bool WCH = CIN < 4;
+  const int wrow = WCH ? 1 : wstride;
+  const int K = 27 * wrow;
   for (int i = t; i < K * COUT; i += 256) {
-    const int k = i / COUT, n = i - k * COUT;
+    const int kk = i / COUT, n = i - kk * COUT;
+    const int k = WCH ? kk * wstride : kk;
     w[i] = wp[((size_t)(k >> 2) * g.Npad + n) * 4 + (k & 3)];
   }
   __syncthreads();
@@ -1029,7 +1037,7 @@ __global__ __launch_bounds__(256) void conv_thin_c_fwd_kernel(ConvGeom g, const 
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[v][j] = 0.f;
   const float* wq = w + 4 * q;
-#pragma unroll 1
+#pragma unroll ICS_THINC_UNROLL
   for (int gzy = 0; gzy < 9; ++gzy) {
     const int dz = gzy / 3 - 1, dy = gzy % 3 - 1;
     const bool rowok = gvalid && (unsigned)(z + dz) < (unsigned)S && (unsigned)(y + dy) < (unsigned)S;
@@ -1051,7 +1059,7 @@ __global__ __launch_bounds__(256) void conv_thin_c_fwd_kernel(ConvGeom g, const 
       }
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
-        const float* wk = wq + (size_t)((gzy * 3 + dx) * wstride + c4 * 4) * COUT;
+        const float* wk = wq + (size_t)((gzy * 3 + dx) * wrow + c4 * 4) * COUT;
 #pragma unroll
         for (int j = 0; j < (CIN >= 4 ? 4 : 1); ++j) {
           const v4f wv = *reinterpret_cast<const v4f*>(wk + j * COUT);
