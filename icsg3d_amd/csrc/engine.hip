@@ -437,7 +437,7 @@ static int alloc_layer(Net& n, ConvLayer& L, bool need_bwd, bool pooled) {
       // BatchNorm-backward pass: its block count is NOT monotone in the batch (rows per block are rounded up to what one
       // block covers: 16 channels at 32^3 take 1280 blocks for 5 grids and 1536 for 3), so every batch size the handle
       // accepts is asked -- sizing by max_batch alone let a 3-grid step on a 5-grid handle write 16 KB past the end
-      // (found by scripts/fuzz_steps.py, round 6)
+      // (found by tests/tools/fuzz_steps.py, round 6)
       size_t rows = std::max((size_t)512, M / 128 + 1);
       for (int b = 1; b <= n.maxB; ++b) {
         LayerBwd lb{};

@@ -259,7 +259,7 @@ _SLOPE = {"relu": 0.0, "lrelu": LEAKY}
 
 
 GRAD_CAPTURE = None      # diagnosis aid: a dict here receives {layer: dLoss/ds (NCDHW tensor)} for every block whose stored
-                         # activation s carries a gradient (scripts/fuzz_steps.py FUZZ_DY=1 compares them with the engine's "layer:dy")
+                         # activation s carries a gradient (tests/tools/fuzz_steps.py FUZZ_DY=1 compares them with the engine's "layer:dy")
 
 
 def block(x, p, name, pre, has_bn, post, training, taps=None, stats=None, pins=None):

@@ -2,16 +2,15 @@
 import sys, time
 import numpy as np
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
-from oracle import numpy_ref as R
 from icsg3d_amd.engine import UnetEngine
+from icsg3d_amd.synthetic import glorot_params, synthetic_batch, unet_param_shapes
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 d = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 eng = UnetEngine(in_channels=1, d=d, max_batch=B, lr=3e-6)
-P = R.init_params(R.unet_param_shapes(1, 95), 1, np.float32)
-eng.set_weights(P)
-X, lab, _ = R.synthetic_batch(B, d, 1, seed=0)
+eng.set_weights(glorot_params(unet_param_shapes(1, 95), 1))
+X, lab, _ = synthetic_batch(B, d, 1, seed=0)
 eng.upload_batch(X, lab)
 print("metrics", eng.train_step_resident(True))
 eng.sync()

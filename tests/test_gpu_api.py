@@ -139,7 +139,7 @@ def test_no_kernel_writes_past_its_buffers(B, d, monkeypatch):
     """ICSG3D_DEBUG_CANARY=1: 8 KB of guard bytes behind every device buffer of a handle; after train / test / predict steps
     of both engines and the fused inference tail at EVERY batch size the handle accepts (odd batches at d = 16: every tile
     remainder path) none of them was touched.  (Round 4 found such a write by accident; this looks for them.  Round 6's
-    scripts/fuzz_steps.py found the next one: a DFC-VAE train step on 3 grids with a 5-grid handle at d = 32 wrote 16 KB past the
+    tests/tools/fuzz_steps.py found the next one: a DFC-VAE train step on 3 grids with a 5-grid handle at d = 32 wrote 16 KB past the
     bias-gradient partials of e0 and d3 -- the BatchNorm-backward pass takes 1536 blocks for 3 grids and 1280 for 5, and the
     buffer was sized for max_batch alone.  The (5, 32) case is that handle.)"""
     from icsg3d_amd.engine import UnetEngine, VaeEngine

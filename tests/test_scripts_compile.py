@@ -1,4 +1,4 @@
-"""Every helper under scripts/ at least parses (they run on the GPU box, where a syntax error costs a GPU call), and the
+"""Every helper under scripts/ and tests/tools/ at least parses (they run on the GPU box, where a syntax error costs a GPU call), and the
 segmentation sweep's volume generator produces what it says: touching / bridged blobs the oracle splits."""
 import glob
 import os
@@ -11,14 +11,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_scripts_parse(tmp_path):
-    files = sorted(glob.glob(os.path.join(ROOT, "scripts", "*.py")) + glob.glob(os.path.join(ROOT, "scripts", "probes", "*.py")))
+    files = sorted(glob.glob(os.path.join(ROOT, "scripts", "*.py")) + glob.glob(os.path.join(ROOT, "scripts", "probes", "*.py"))
+                   + glob.glob(os.path.join(ROOT, "tests", "tools", "*.py")))
     assert len(files) > 10
     for f in files:
         py_compile.compile(f, cfile=str(tmp_path / (os.path.basename(f) + "c")), doraise=True)
 
 
 def test_fuzz_segment_volumes_exercise_the_non_convex_path():
-    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
     try:
         import fuzz_segment as F
     finally:

@@ -1,17 +1,17 @@
 """Every batch size 1..max_batch on ONE handle (guard bytes on) against a handle created for exactly that batch: the same
 metrics and the same gradients bit for bit -- the plans are functions of the batch, not of max_batch, so nothing may depend on
 what the handle was sized for -- and no guard byte written.  No oracle: engine against engine, which makes the sweep cheap
-enough to cover max_batch = 32 at 32^3, 8 at 64^3 and 64 at 16^3 (scripts/fuzz_steps.py checks values against the oracle at
+enough to cover max_batch = 32 at 32^3, 8 at 64^3 and 64 at 16^3 (tests/tools/fuzz_steps.py checks values against the oracle at
 smaller max_batch).  Found by this class of check in round 6: DESIGN 11.10.
 
-    python scripts/fuzz_batches.py [d=32] [max_batch=32] [C=1]"""
+    python tests/tools/fuzz_batches.py [d=32] [max_batch=32] [C=1]"""
 import os
 import sys
 import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 os.environ["ICSG3D_DEBUG_CANARY"] = "1"
 

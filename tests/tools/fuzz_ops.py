@@ -4,7 +4,7 @@ tests/test_gpu_conv.py does not hold: any batch 1..9, S in {1, 2, 4, 8, 16, 32},
 (oracle/torch_ref.py's layouts).  Tensor-relative tolerance 1e-5 forward / backward-data, 2e-5 backward-weight at
 >= 100 k rows (fp32 accumulation over M rows).  Exit code 1 on any miss.
 
-    python scripts/fuzz_ops.py [cases=60] [seed=0]
+    python tests/tools/fuzz_ops.py [cases=60] [seed=0]
 Reference: Keras Conv3D "same", /root/reference/unet/unet.py:272-336, vae/lattice_vae.py:160-230."""
 import os
 import sys
@@ -12,7 +12,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 from oracle import torch_ref as T          # noqa: E402

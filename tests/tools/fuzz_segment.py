@@ -4,14 +4,14 @@ restatement of watershed_clustering (/root/reference/watershed.py:40-203; skimag
 of random balls / ellipsoids that touch and overlap (non-convex components, splits, recursion levels), thin bridges, salt
 noise; batches of 1..8 grids at 16^3 / 32^3 / 64^3.  Integer work: region volumes, species votes and centroids must be EQUAL.
 
-    python scripts/fuzz_segment.py [trials=40] [seed=0]"""
+    python tests/tools/fuzz_segment.py [trials=40] [seed=0]"""
 import os
 import sys
 import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 from oracle import watershed_ref as W          # noqa: E402

@@ -8,7 +8,7 @@ tests/test_gpu_fullsize_oracle.py).  Prints one line per step and a summary; exi
 Every trial runs with guard bytes behind the device buffers (ICSG3D_DEBUG_CANARY=1) and a third of them with one or two of
 the ICSG3D_NO_* A/B switches.
 
-    python scripts/fuzz_steps.py [trials=12] [seed=0]        (FUZZ_ONLY=3,7: only those trials of the same sequence)
+    python tests/tools/fuzz_steps.py [trials=12] [seed=0]        (FUZZ_ONLY=3,7: only those trials of the same sequence)
 Reference: /root/reference/unet/unet.py:272-355,370, vae/lattice_vae.py:160-270,296."""
 import os
 import sys
@@ -16,7 +16,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 

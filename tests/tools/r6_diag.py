@@ -2,7 +2,7 @@
 threads, (b) the DFC-VAE e0/kernel gradient at B = 32 by row group, default vs ICSG3D_NO_COND_FOLD / _NO_THIN_C."""
 import os, subprocess, sys, time, json
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 what = sys.argv[1]
 

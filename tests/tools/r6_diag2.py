@@ -2,7 +2,7 @@
 process), to localise the e0 / e1 gradient error the pinned oracle test shows only with the fold on."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from icsg3d_amd.engine import UnetEngine, VaeEngine
 from oracle import numpy_ref as R

@@ -2,7 +2,7 @@
 import os, sys
 import numpy as np
 os.environ["ICSG3D_DEBUG_CANARY"] = "1"
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from icsg3d_amd.engine import UnetEngine, VaeEngine
 from oracle import numpy_ref as R

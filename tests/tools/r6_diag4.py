@@ -1,7 +1,7 @@
 """pinned oracle vs engine for e0 / e1 / e2 gradients at B = 32 (TAG = default | nofold via env), saved as npz"""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 torch.set_num_threads(32)

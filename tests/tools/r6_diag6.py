@@ -1,11 +1,11 @@
 """which buffers of a DFC-VAE step at B = 3 depend on the handle's max_batch (3 vs 5)?  They must not."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import numpy_ref as R
 from icsg3d_amd.engine import UnetEngine, VaeEngine
-sys.path.insert(0, os.path.join(ROOT, "scripts"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
 from fuzz_steps import vae_shapes, ushape, UNET_LAYERS, inputs
 
 d, C, B = int(os.environ.get("D", 32)), int(os.environ.get("C", 1)), int(os.environ.get("B", 3))
